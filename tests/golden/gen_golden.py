@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures in this directory from oracle/pyref.py (first-principles big ints).
+
+    python tests/golden/gen_golden.py
+
+The reference has no vectors for this path (parity unpinned), so these are
+mathematically determined values (canonical integers), plus two externally known anchors:
+the EIP-196 value of 2*G1 and the survey's verified roots of unity.
+All field values are canonical (non-Montgomery) hex strings.
+"""
+import hashlib
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", "..", "oracle"))
+import pyref as P  # noqa: E402
+
+hx = lambda x: format(x, "x")
+
+
+def dump(name, obj):
+    with open(os.path.join(HERE, name), "w") as f:
+        json.dump(obj, f, indent=0, separators=(",", ":"))
+    print(name, os.path.getsize(os.path.join(HERE, name)), "bytes")
+
+
+def field_vectors():
+    out = {}
+    for name, m, seed in (("fr", P.R, 11), ("fq", P.P, 12)):
+        xs = [0, 1, 2, m - 1, m - 2, (1 << 253) - 1, (1 << 128) + 5] + [P.synth_raw253(seed, i) for i in range(9)]
+        cases = []
+        for i in range(len(xs)):
+            a, b = xs[i], xs[(i * 7 + 3) % len(xs)]
+            cases.append(dict(a=hx(a), b=hx(b), mul=hx(a * b % m), add=hx((a + b) % m), sub=hx((a - b) % m),
+                              inv=hx(pow(a, -1, m) if a else 0), mont=hx(P.to_mont(a, m))))
+        out[name] = cases
+    out["constants"] = dict(
+        root_of_unity=hx(P.ROOT_OF_UNITY), delta=hx(P.DELTA), zeta=hx(P.ZETA),
+        omega={str(k): hx(P.omega_for(k)) for k in (1, 2, 4, 10, 15, 17, 19, 22, 24, 28)},
+        # SURVEY.md §8 'Verified constants' — computed there with sympy, repeated as an external anchor
+        survey_omega_17="304cd1e79cfa5b0f054e981a27ed7706e7ea6b06a7f266ef8db819c179c2c3ea",
+        survey_omega_19="cf1526aaafac6bacbb67d11a4077806b123f767e4b0883d14cc0193568fc082")
+    return out
+
+
+def g1_vectors():
+    ks = [1, 2, 3, 5, 7, 255, 256, (1 << 64) + 1, (1 << 128) - 1, P.R - 1, P.R - 2] + [P.synth_raw253(21, i) for i in range(5)]
+    muls = []
+    for k in ks:
+        a = P.to_affine(P.scalar_mul(k, P.G1_GEN))
+        assert P.on_curve(a)
+        muls.append(dict(k=hx(k), x=hx(a[0]), y=hx(a[1]), compressed=P.compress(a).hex()))
+    adds = []
+    pts = [P.scalar_mul(k, P.G1_GEN) for k in (3, 5, 5, P.R - 5, 0, 9)]
+    for i in range(len(pts)):
+        for j in range(len(pts)):
+            s = P.to_affine(P.jac_add(pts[i], pts[j]))
+            adds.append(dict(i=i, j=j, x=hx(s[0]), y=hx(s[1])))
+    return dict(
+        mul_gen=muls,
+        add_operands=[dict(zip("xy", map(hx, P.to_affine(p)))) for p in pts],
+        adds=adds,
+        # EIP-196 / alt_bn128 published value of 2*(1,2)
+        eip196_2g=dict(x="30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd3",
+                       y="15ed738c0e0a7c92e7845f96b2ae9c0a68a6a449e3538fc7ff3ebf7a5a18a2c4"),
+        identity_compressed=P.compress((0, 0)).hex())
+
+
+def msm_vectors():
+    cases = []
+
+    def case(name, scalars, points):
+        res = P.msm_naive(scalars, points)
+        cases.append(dict(name=name, scalars=[hx(s) for s in scalars], points=[[hx(x), hx(y)] for x, y in points],
+                          result=[hx(res[0]), hx(res[1])]))
+
+    def pt(i, seed=31):
+        return P.to_affine(P.scalar_mul(P.synth_raw253(seed, i), P.G1_GEN))
+
+    g = (1, 2)
+    case("n1_one", [1], [g])
+    case("n1_zero", [0], [g])
+    case("n1_rminus1", [P.R - 1], [g])
+    case("n2_cancel", [5, 5], [pt(0), (pt(0)[0], (-pt(0)[1]) % P.P)])
+    case("n3_dup_points", [7, 7, 9], [pt(1), pt(1), pt(2)])            # P + P inside one bucket
+    case("n3_identity_base", [3, 4, 5], [pt(3), (0, 0), pt(4)])
+    edge = [0, 1, 2, P.R - 1, P.R - 2, (1 << 13) - 1, 1 << 13, (1 << 16) - 1, 1 << 16, (1 << 15), (1 << 253) - 1,
+            (1 << 128), (1 << 64) - 1, 0xFFFF0000FFFF0000FFFF, 3, 1, 1]
+    case("n17_edge_scalars", edge, [pt(10 + i) for i in range(17)])
+    n = 256
+    sc = [P.from_mont(P.synth_raw253(32, i), P.R) for i in range(n)]
+    for i in range(0, n, 16):
+        sc[i] = i % 3          # small / zero scalars as in real witnesses
+    case("n256_mixed", sc, [pt(100 + i) for i in range(n)])
+    # seed-defined case: scalars[i] = from_mont(raw253(seed_s, i)); points[i] = [raw253(seed_p, i)] G
+    n = 1024
+    sc = [P.from_mont(P.synth_raw253(41, i), P.R) for i in range(n)]
+    pts = [P.to_affine(P.scalar_mul(P.synth_raw253(42, i), P.G1_GEN)) for i in range(n)]
+    res = P.msm_naive(sc, pts)
+    seeded = dict(n=n, seed_scalars=41, seed_points=42, result=[hx(res[0]), hx(res[1])],
+                  point0=[hx(pts[0][0]), hx(pts[0][1])], point_last=[hx(pts[-1][0]), hx(pts[-1][1])])
+    return dict(cases=cases, seeded=seeded)
+
+
+def digest(vals):
+    h = hashlib.sha256()
+    for v in vals:
+        h.update(v.to_bytes(32, "little"))
+    return h.hexdigest()
+
+
+def ntt_vectors():
+    out = []
+    for k in (1, 2, 3, 6):
+        n = 1 << k
+        a = [P.from_mont(P.synth_raw253(50 + k, i), P.R) for i in range(n)]
+        w = P.omega_for(k)
+        f = P.dft_naive(a, w)
+        assert P.fft(a, w) == f
+        out.append(dict(k=k, input=[hx(x) for x in a], output=[hx(x) for x in f]))
+    big = []
+    for k in (10, 11, 13):
+        n = 1 << k
+        a = [P.from_mont(P.synth_raw253(50 + k, i), P.R) for i in range(n)]
+        w = P.omega_for(k)
+        f = P.fft(a, w)
+        inv = P.ifft(a, w)
+        big.append(dict(k=k, seed=50 + k, fft_sha256=digest(f), ifft_sha256=digest(inv),
+                        fft_first=[hx(x) for x in f[:4]], ifft_first=[hx(x) for x in inv[:4]]))
+    return dict(small=out, seeded=big)
+
+
+def domain_vectors():
+    out = []
+    for (j, k) in ((4, 4), (3, 3), (6, 3), (9, 2)):
+        d = P.Domain(j, k)
+        coeffs = [P.from_mont(P.synth_raw253(60 + k + j, i), P.R) for i in range(d.n)]
+        ext = d.coeff_to_extended(coeffs)
+        for i in (0, 1, d.extended_n - 1):
+            assert ext[i] == P.poly_eval(coeffs, d.coset_point(i))
+        extin = [P.from_mont(P.synth_raw253(70 + k + j, i), P.R) for i in range(d.extended_n)]
+        l0, ll, la = P.l_cosets(d, 3 if k > 2 else 1)
+        out.append(dict(j=j, k=k, extended_k=d.extended_k, blinding_factors=3 if k > 2 else 1,
+                        coeffs=[hx(x) for x in coeffs],
+                        lagrange_to_coeff=[hx(x) for x in d.lagrange_to_coeff(coeffs)],
+                        coeff_to_extended=[hx(x) for x in ext],
+                        extended_in=[hx(x) for x in extin],
+                        extended_to_coeff=[hx(x) for x in d.extended_to_coeff(extin)],
+                        divide_by_vanishing=[hx(x) for x in d.divide_by_vanishing_poly(extin)],
+                        t_evaluations=[hx(x) for x in d.t_evaluations],
+                        l0=[hx(x) for x in l0], l_last=[hx(x) for x in ll], l_active=[hx(x) for x in la]))
+    return out
+
+
+def evalh_vectors():
+    """A small non-satisfying circuit exercising every term kind of evaluate_h."""
+    k, degree, bf = 4, 4, 5
+    d = P.Domain(degree, k)
+    n = d.n
+    A0 = lambda r: ["advice", 0, r]
+    A1 = lambda r: ["advice", 1, r]
+    F0 = lambda r: ["fixed", 0, r]
+    F1 = lambda r: ["fixed", 1, r]
+    I0 = lambda r: ["instance", 0, r]
+    gates = [
+        # halo2-lib vertical gate: q * (a + b*c - d)
+        ["prod", F0(0), ["sum", ["sum", A0(0), ["prod", A0(1), A0(2)]], ["neg", A0(3)]]],
+        # constants, scaling, challenge, negative rotation, instance, x*x and 2*x special cases
+        ["sum", ["scaled", ["prod", A1(0), A1(0)], 7], ["neg", ["prod", ["const", 2], A1(-1)]]],
+        ["prod", ["sum", I0(0), ["challenge", 0]], ["sum", F1(1), ["const", P.R - 3]]],
+        ["sum", ["prod", ["const", 1], A0(0)], ["prod", ["const", 0], A1(2)]],
+        ["neg", ["const", 5]],
+    ]
+    lookups = [([["prod", F0(0), A1(0)], A0(1)], [F1(0), ["sum", F1(0), ["const", 1]]])]
+    perm_columns = [["advice", 0], ["fixed", 1], ["instance", 0]]
+    seed = [80]
+
+    def rnd_poly(m=n):
+        seed[0] += 1
+        return [P.from_mont(P.synth_raw253(seed[0], i), P.R) for i in range(m)]
+
+    polys = dict(fixed=[rnd_poly(), rnd_poly()], advice=[rnd_poly(), rnd_poly()], instance=[rnd_poly()],
+                 sigma=[rnd_poly() for _ in perm_columns], perm_z=[rnd_poly(), rnd_poly()],
+                 lookup_z=[rnd_poly()], lookup_a=[rnd_poly()], lookup_s=[rnd_poly()])
+    cosets = {kk: [d.coeff_to_extended(p) for p in v] for kk, v in polys.items()}
+    cosets["l0"], cosets["l_last"], cosets["l_active"] = P.l_cosets(d, bf)
+    ch = dict(beta=P.synth_raw253(90, 0) % P.R, gamma=P.synth_raw253(90, 1) % P.R, theta=P.synth_raw253(90, 2) % P.R,
+              y=P.synth_raw253(90, 3) % P.R, challenges=[P.synth_raw253(90, 4) % P.R])
+
+    def tup(e):
+        return tuple(tup(x) if isinstance(x, list) else x for x in e)
+
+    cs = dict(gates=[tup(g) for g in gates], lookups=[([tup(e) for e in i], [tup(e) for e in t]) for i, t in lookups],
+              perm_columns=[tuple(c) for c in perm_columns], degree=degree, blinding_factors=bf)
+    h = P.evaluate_h_direct(d, cs, cosets, ch)
+    return dict(k=k, degree=degree, blinding_factors=bf, gates=gates, lookups=[list(l) for l in lookups],
+                perm_columns=perm_columns, polys={kk: [[hx(x) for x in p] for p in v] for kk, v in polys.items()},
+                challenges={kk: ([hx(x) for x in v] if isinstance(v, list) else hx(v)) for kk, v in ch.items()},
+                h=[hx(x) for x in h])
+
+
+if __name__ == "__main__":
+    dump("field.json", field_vectors())
+    dump("g1.json", g1_vectors())
+    dump("msm.json", msm_vectors())
+    dump("ntt.json", ntt_vectors())
+    dump("domain.json", domain_vectors())
+    dump("evalh.json", evalh_vectors())
