@@ -231,6 +231,28 @@ ZK_HD inline fe fe_inv(const fe& a) {
 using Fq = FqP;
 using Fr = FrP;
 
+// Fr constants (canonical limbs; halo2curves src/bn256/fr.rs): 2^28-th root of unity, ZETA, DELTA.
+constexpr uint32_t FR_S = 28;
+constexpr uint32_t FR_ROOT_OF_UNITY[8] = {0x60c37c9cu, 0xd34f1ed9u, 0xd39329c8u, 0x3215cf6du,
+                                          0x3dd31f74u, 0x98865ea9u, 0x166d18b7u, 0x03ddb9f5u};
+constexpr uint32_t FR_ZETA[8] = {0xb99c90ddu, 0x8b17ea66u, 0x8d8daaa7u, 0x5bfc4108u, 0x41a91758u, 0xb3c4d79du, 0u, 0u};
+constexpr uint32_t FR_DELTA[8] = {0xe533e9a2u, 0x870e56bbu, 0x5e963f25u, 0x5b5f898eu,
+                                  0xd4c86e71u, 0x64ec26aau, 0x22c6f0cau, 0x09226b6eu};
+template <class P>
+ZK_HD __forceinline__ fe fe_from_canonical(const uint32_t v[8]) {
+    fe t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t.l[i] = v[i];
+    return fe_to_mont<P>(t);
+}
+template <class P>
+ZK_HD __forceinline__ fe fe_from_u64(uint64_t v) {
+    fe t = fe_zero();
+    t.l[0] = (uint32_t)v;
+    t.l[1] = (uint32_t)(v >> 32);
+    return fe_to_mont<P>(t);
+}
+
 // ------------------------------------------------------------------------------------ G1
 // y^2 = x^3 + 3.  Affine identity = (0,0) (halo2curves G1Affine); Jacobian identity z = 0.
 struct g1a { fe x, y; };

@@ -1,0 +1,155 @@
+// ctx.hip — context lifetime, memory helpers, timers, host-side point helpers, synthetic fill.
+#include <stdarg.h>
+
+#include "common.hpp"
+
+namespace zk {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+}  // namespace zk
+using namespace zk;
+
+int zkhip_ctx::get_scratch(const char* name, size_t bytes, void** out) {
+    Scratch& s = scratch[name];
+    if (s.bytes < bytes) {
+        if (s.ptr) {
+            ZK_HIP(hipStreamSynchronize(stream));
+            ZK_HIP(hipFree(s.ptr));
+            s.ptr = nullptr;
+            s.bytes = 0;
+        }
+        size_t want = bytes + bytes / 8;
+        hipError_t e = hipMalloc(&s.ptr, want);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            s.ptr = nullptr;
+            set_error("hipMalloc(%zu) for scratch '%s' failed: %s", want, name, hipGetErrorString(e));
+            return ZKHIP_ENOMEM;
+        }
+        s.bytes = want;
+    }
+    *out = s.ptr;
+    return ZKHIP_OK;
+}
+
+extern "C" {
+
+const char* zkhip_last_error(void) { return g_err; }
+
+int zkhip_init(zkhip_ctx** out, int device_id) {
+    if (!out) { set_error("zkhip_init: out is NULL"); return ZKHIP_EINVAL; }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) {
+        (void)hipGetLastError();
+        set_error("zkhip_init: no HIP device visible (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+        return ZKHIP_ENODEVICE;
+    }
+    if (device_id < 0 || device_id >= ndev) { set_error("zkhip_init: device %d out of range [0,%d)", device_id, ndev); return ZKHIP_EINVAL; }
+    ZK_HIP(hipSetDevice(device_id));
+    zkhip_ctx* c = new zkhip_ctx();
+    c->device = device_id;
+    ZK_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    ZK_HIP(hipEventCreate(&c->ev0));
+    ZK_HIP(hipEventCreate(&c->ev1));
+    *out = c;
+    return ZKHIP_OK;
+}
+
+void zkhip_destroy(zkhip_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& kv : c->scratch)
+        if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+    for (auto& t : c->twiddles)
+        if (t.d_table) (void)hipFree(t.d_table);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int zkhip_set_stream(zkhip_ctx* c, void* s) {
+    if (!c) { set_error("null ctx"); return ZKHIP_EINVAL; }
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return ZKHIP_OK;
+}
+int zkhip_synchronize(zkhip_ctx* c) {
+    if (!c) { set_error("null ctx"); return ZKHIP_EINVAL; }
+    ZK_HIP(hipStreamSynchronize(c->stream));
+    return ZKHIP_OK;
+}
+int zkhip_malloc(zkhip_ctx* c, size_t bytes, void** dptr) {
+    if (!c || !dptr) { set_error("zkhip_malloc: bad argument"); return ZKHIP_EINVAL; }
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 16);
+    if (e != hipSuccess) { (void)hipGetLastError(); set_error("hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); return ZKHIP_ENOMEM; }
+    return ZKHIP_OK;
+}
+int zkhip_free(zkhip_ctx* c, void* dptr) {
+    if (!c) { set_error("null ctx"); return ZKHIP_EINVAL; }
+    if (dptr) { ZK_HIP(hipStreamSynchronize(c->stream)); ZK_HIP(hipFree(dptr)); }
+    return ZKHIP_OK;
+}
+int zkhip_memcpy_h2d(zkhip_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!c) { set_error("null ctx"); return ZKHIP_EINVAL; }
+    ZK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    ZK_HIP(hipStreamSynchronize(c->stream));
+    return ZKHIP_OK;
+}
+int zkhip_memcpy_d2h(zkhip_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!c) { set_error("null ctx"); return ZKHIP_EINVAL; }
+    ZK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(hipStreamSynchronize(c->stream));
+    return ZKHIP_OK;
+}
+int zkhip_timer_start(zkhip_ctx* c) {
+    if (!c) { set_error("null ctx"); return ZKHIP_EINVAL; }
+    ZK_HIP(hipEventRecord(c->ev0, c->stream));
+    return ZKHIP_OK;
+}
+int zkhip_timer_stop_ms(zkhip_ctx* c, float* ms) {
+    if (!c || !ms) { set_error("bad argument"); return ZKHIP_EINVAL; }
+    ZK_HIP(hipEventRecord(c->ev1, c->stream));
+    ZK_HIP(hipEventSynchronize(c->ev1));
+    ZK_HIP(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return ZKHIP_OK;
+}
+
+void zkhip_g1_to_affine(const uint64_t xyz[12], uint64_t out_xy[8]) {
+    g1j p;
+    memcpy(&p, xyz, 96);
+    g1a a = g1j_to_affine(p);
+    memcpy(out_xy, &a, 64);
+}
+void zkhip_g1_to_bytes(const uint64_t xy[8], uint8_t out[32]) {
+    g1a a;
+    memcpy(&a, xy, 64);
+    memset(out, 0, 32);
+    if (g1a_is_id(a)) { out[31] |= 0x80; return; }
+    fe x = fe_from_mont<Fq>(a.x), y = fe_from_mont<Fq>(a.y);
+    memcpy(out, x.l, 32);
+    out[31] |= (uint8_t)((y.l[0] & 1) << 6);
+}
+
+}  // extern "C"
+
+__global__ void k_synth_fill(uint32_t* out, size_t n, uint64_t seed, uint64_t first) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe_store(out + i * 8, synth_raw253(seed, first + i));
+}
+
+extern "C" int zkhip_synth_fill_device(zkhip_ctx* c, void* d_out, size_t n, uint64_t seed, uint64_t first) {
+    if (!c || !d_out) { set_error("zkhip_synth_fill_device: bad argument"); return ZKHIP_EINVAL; }
+    if (n == 0) return ZKHIP_OK;
+    hipLaunchKernelGGL(k_synth_fill, dim3(div_up(n, 256)), dim3(256), 0, c->stream, (uint32_t*)d_out, n, seed, first);
+    ZK_LAUNCH_CHECK();
+    return ZKHIP_OK;
+}

@@ -1,0 +1,470 @@
+// msm.hip — BN254 G1 multi-scalar multiplication for gfx950.
+//
+// Drop-in for halo2curves 0.4.0 msm::best_multiexp as called by ParamsKZG::commit /
+// commit_lagrange [UPSTREAM-RECALL; halo2curves pinned at /root/reference/Cargo.lock:1359-1361,
+// reached from gen_snark_shplonk at /root/reference/src/helpers.rs:233,299].  The sum is unique,
+// so the algorithm is free: this is NOT the reference's per-thread-chunk Pippenger.
+//
+// MI355X design:
+//  * The SRS is fixed for the life of the process, so zkhip_srs_load stores, for every base P_i,
+//    its W window multiples 2^(c*w) P_i in affine form (W*n*64 B; 288 GB HBM makes this cheap).
+//    An MSM is then ONE bucket pass over n*W (digit, point) pairs: no per-window doublings and
+//    one 2^(c-1)-bucket reduction instead of W of them.
+//  * Signed c-bit digits; pairs are counting-sorted by |digit| (global histogram + scan +
+//    scatter), so work is proportional to non-zero digits — zero / small witness values cost
+//    nothing in the upper windows.
+//  * Bucket sums are segmented: every thread adds at most SEG pairs (mixed Jacobian+affine adds),
+//    partial sums are folded in further rounds.  Skewed buckets (boolean columns) therefore cost
+//    depth O(log), not O(count).
+//  * Integer-multiply bound: ~11 field products per pair, 136 v_mad_u64_u32 each.
+#include <algorithm>
+
+#include "common.hpp"
+using namespace zk;
+
+struct zkhip_srs {
+    size_t n = 0;
+    uint32_t c = 0, W = 0, B = 0;
+    void* d_table = nullptr;  // [W][n] affine, Montgomery
+};
+
+static uint32_t pick_window(size_t n) {
+    if (const char* e = getenv("ZKHIP_MSM_C")) {
+        int v = atoi(e);
+        if (v >= 2 && v <= 22) return (uint32_t)v;
+    }
+    uint32_t lg = 0;
+    while (((size_t)1 << lg) < n) ++lg;
+    int c = (int)lg - 1;
+    if (c < 3) c = 3;
+    if (c > 18) c = 18;
+    return (uint32_t)c;
+}
+
+// ------------------------------------------------------------------ SRS precomputation
+__global__ void k_affine_to_jac(const uint32_t* in_xy, uint32_t* out_xyz, size_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    g1j_store(out_xyz + i * 24, g1j_from_affine(g1a_load(in_xy + i * 16)));
+}
+__global__ void k_pow2c(const uint32_t* in_xyz, uint32_t* out_xyz, size_t n, uint32_t c) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    g1j p = g1j_load(in_xyz + i * 24);
+    for (uint32_t j = 0; j < c; ++j) p = g1j_double(p);
+    g1j_store(out_xyz + i * 24, p);
+}
+// Jacobian -> affine with Montgomery's trick over G points per thread (strided for coalescing).
+template <int G>
+__global__ void k_batch_to_affine(const uint32_t* in_xyz, uint32_t* out_xy, size_t n) {
+    size_t T = (size_t)gridDim.x * blockDim.x;
+    size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    fe prefix[G];
+    fe acc = fe_one<Fq>();
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+        size_t i = t + (size_t)j * T;
+        fe z = fe_one<Fq>();
+        if (i < n) {
+            z = fe_load(in_xyz + i * 24 + 16);
+            if (fe_is_zero(z)) z = fe_one<Fq>();
+        }
+        prefix[j] = acc;
+        acc = fe_mul<Fq>(acc, z);
+    }
+    fe inv = fe_inv<Fq>(acc);
+#pragma unroll
+    for (int j = G - 1; j >= 0; --j) {
+        size_t i = t + (size_t)j * T;
+        if (i < n) {
+            g1j p = g1j_load(in_xyz + i * 24);
+            g1a a;
+            if (g1j_is_id(p)) {
+                a.x = fe_zero(); a.y = fe_zero();
+            } else {
+                fe zi = fe_mul<Fq>(inv, prefix[j]);
+                inv = fe_mul<Fq>(inv, p.z);
+                fe zi2 = fe_sqr<Fq>(zi);
+                a.x = fe_mul<Fq>(p.x, zi2);
+                a.y = fe_mul<Fq>(p.y, fe_mul<Fq>(zi2, zi));
+            }
+            g1a_store(out_xy + i * 16, a);
+        }
+    }
+}
+
+namespace zk {
+int launch_batch_to_affine(zkhip_ctx* ctx, const void* d_in_xyz, void* d_out_xy, size_t n) {
+    if (n == 0) return ZKHIP_OK;
+    hipLaunchKernelGGL(k_batch_to_affine<8>, dim3(div_up(div_up(n, 8), 256)), dim3(256), 0, ctx->stream, (const uint32_t*)d_in_xyz,
+                       (uint32_t*)d_out_xy, n);
+    ZK_LAUNCH_CHECK();
+    return ZKHIP_OK;
+}
+}  // namespace zk
+
+static int srs_build(zkhip_ctx* ctx, const void* d_bases, size_t n, zkhip_srs** out) {
+    if (n == 0 || n > ((size_t)1 << 26)) { set_error("zkhip_srs_load: n = %zu out of range (1..2^26)", n); return ZKHIP_EINVAL; }
+    zkhip_srs* s = new zkhip_srs();
+    s->n = n;
+    s->c = pick_window(n);
+    s->W = (255 + s->c - 1) / s->c;
+    s->B = 1u << (s->c - 1);
+    if ((size_t)s->W * n >= ((size_t)1 << 31)) { delete s; set_error("zkhip_srs_load: W*n overflows the 31-bit pair index"); return ZKHIP_EINVAL; }
+    hipError_t e = hipMalloc(&s->d_table, (size_t)s->W * n * 64);
+    if (e != hipSuccess) { (void)hipGetLastError(); delete s; set_error("hipMalloc SRS table (%zu B): %s", (size_t)s->W * n * 64, hipGetErrorString(e)); return ZKHIP_ENOMEM; }
+    void *ja, *jb;
+    int rc = ctx->get_scratch("srs_jac_a", n * 96, &ja);
+    if (rc == ZKHIP_OK) rc = ctx->get_scratch("srs_jac_b", n * 96, &jb);
+    if (rc != ZKHIP_OK) { (void)hipFree(s->d_table); delete s; return rc; }
+    hipStream_t st = ctx->stream;
+    unsigned g = div_up(n, 256);
+    ZK_HIP(hipMemcpyAsync(s->d_table, d_bases, n * 64, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_affine_to_jac, dim3(g), dim3(256), 0, st, (const uint32_t*)d_bases, (uint32_t*)ja, n);
+    constexpr int G = 8;
+    unsigned gt = div_up(div_up(n, G), 256);
+    for (uint32_t w = 1; w < s->W; ++w) {
+        hipLaunchKernelGGL(k_pow2c, dim3(g), dim3(256), 0, st, (const uint32_t*)ja, (uint32_t*)jb, n, s->c);
+        hipLaunchKernelGGL(k_batch_to_affine<G>, dim3(gt), dim3(256), 0, st, (const uint32_t*)jb,
+                           (uint32_t*)((char*)s->d_table + (size_t)w * n * 64), n);
+        std::swap(ja, jb);
+    }
+    ZK_LAUNCH_CHECK();
+    ZK_HIP(hipStreamSynchronize(st));
+    *out = s;
+    return ZKHIP_OK;
+}
+
+// ------------------------------------------------------------------ digit recoding + counting sort
+// Signed digits d_w in [-(2^(c-1)-1), 2^(c-1)], sum d_w 2^(c w) = scalar.  W*c >= 255 so the last
+// carry is zero for every canonical scalar < r < 2^254.
+template <bool SCATTER>
+__global__ void k_digits(const uint32_t* const* scalar_cols, size_t n, uint32_t c, uint32_t W, uint32_t B,
+                         uint32_t* cnt_all, const uint32_t* off_all, uint32_t* cursor_all, uint32_t* entries_all,
+                         size_t items) {
+    __shared__ uint32_t sl[256][9];
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    uint32_t col = blockIdx.y;
+    if (i >= n) return;
+    fe s = fe_from_mont<Fr>(fe_load(scalar_cols[col] + i * 8));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sl[threadIdx.x][j] = s.l[j];
+    sl[threadIdx.x][8] = 0;
+    uint32_t* cnt = cnt_all + (size_t)col * B;
+    const uint32_t* off = off_all + (size_t)col * (B + 1);
+    uint32_t* cursor = cursor_all + (size_t)col * B;
+    uint32_t* entries = entries_all + (size_t)col * items;
+    uint32_t carry = 0, half = 1u << (c - 1), mask = (c == 32) ? 0xffffffffu : ((1u << c) - 1);
+    for (uint32_t w = 0; w < W; ++w) {
+        uint32_t bit = w * c, limb = bit >> 5, sh = bit & 31;
+        uint64_t v = 0;
+        if (limb < 8) v = sl[threadIdx.x][limb] | ((uint64_t)sl[threadIdx.x][limb + 1] << 32);
+        uint32_t raw = ((uint32_t)(v >> sh) & mask) + carry;
+        uint32_t mag, neg;
+        if (raw > half) { mag = (1u << c) - raw; neg = 1; carry = 1; } else { mag = raw; neg = 0; carry = 0; }
+        if (mag != 0) {
+            if (!SCATTER) {
+                atomicAdd(&cnt[mag - 1], 1u);
+            } else {
+                uint32_t pos = off[mag - 1] + atomicAdd(&cursor[mag - 1], 1u);
+                entries[pos] = (uint32_t)(w * n + i) | (neg << 31);
+            }
+        }
+    }
+}
+
+// One block per column.  off_in (if non-null) = exclusive scan of cnt_in; cnt_out = ceil(cnt_in / seg);
+// off_out = exclusive scan of cnt_out (B+1 entries); max_out[col] = max cnt_in.
+__global__ void __launch_bounds__(1024) k_plan(const uint32_t* cnt_in_all, uint32_t B, uint32_t seg, uint32_t* off_in_all,
+                                               uint32_t* cnt_out_all, uint32_t* off_out_all, uint32_t* max_out) {
+    __shared__ uint32_t s_a[1024], s_b[1024], s_m[1024];
+    uint32_t col = blockIdx.x, t = threadIdx.x;
+    const uint32_t* cnt_in = cnt_in_all + (size_t)col * B;
+    uint32_t* off_in = off_in_all ? off_in_all + (size_t)col * (B + 1) : nullptr;
+    uint32_t* cnt_out = cnt_out_all ? cnt_out_all + (size_t)col * B : nullptr;
+    uint32_t* off_out = off_out_all ? off_out_all + (size_t)col * (B + 1) : nullptr;
+    uint32_t per = (B + 1023) / 1024, lo = t * per, hi = min(lo + per, B);
+    uint32_t sa = 0, sb = 0, m = 0;
+    for (uint32_t b = lo; b < hi; ++b) {
+        uint32_t v = cnt_in[b];
+        sa += v;
+        sb += (v + seg - 1) / seg;
+        m = max(m, v);
+    }
+    s_a[t] = sa; s_b[t] = sb; s_m[t] = m;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        uint32_t va = 0, vb = 0, vm = 0;
+        if (t >= d) { va = s_a[t - d]; vb = s_b[t - d]; vm = s_m[t - d]; }
+        __syncthreads();
+        s_a[t] += va; s_b[t] += vb; s_m[t] = max(s_m[t], vm);
+        __syncthreads();
+    }
+    uint32_t ra = s_a[t] - sa, rb = s_b[t] - sb;  // exclusive prefix of this thread's chunk
+    for (uint32_t b = lo; b < hi; ++b) {
+        uint32_t v = cnt_in[b], sv = (v + seg - 1) / seg;
+        if (off_in) off_in[b] = ra;
+        if (off_out) off_out[b] = rb;
+        if (cnt_out) cnt_out[b] = sv;
+        ra += v; rb += sv;
+    }
+    if (t == 1023) {
+        if (off_in) off_in[B] = s_a[1023];
+        if (off_out) off_out[B] = s_b[1023];
+        if (max_out) max_out[col] = s_m[1023];
+    }
+}
+
+__device__ __forceinline__ uint32_t find_bucket(const uint32_t* off, uint32_t B, uint32_t t) {
+    // largest b in [0, B) with off[b] <= t, given off[B] > t
+    uint32_t lo = 0, hi = B;
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (off[mid] <= t) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// Round 0: segment sums of (sign, precomputed affine point) pairs.
+__global__ void __launch_bounds__(256) k_accum_affine(const uint32_t* table, const uint32_t* entries_all, size_t items,
+                                                      const uint32_t* cnt_all, const uint32_t* off_all,
+                                                      const uint32_t* segoff_all, uint32_t B, uint32_t seg,
+                                                      uint32_t* partial_all, size_t partial_stride) {
+    uint32_t col = blockIdx.y;
+    const uint32_t* segoff = segoff_all + (size_t)col * (B + 1);
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= segoff[B]) return;
+    const uint32_t* cnt = cnt_all + (size_t)col * B;
+    const uint32_t* off = off_all + (size_t)col * (B + 1);
+    const uint32_t* entries = entries_all + (size_t)col * items;
+    uint32_t b = find_bucket(segoff, B, t);
+    uint32_t s = t - segoff[b];
+    uint32_t lo = off[b] + s * seg, hi = min(lo + seg, off[b] + cnt[b]);
+    g1j acc = g1j_identity();
+    for (uint32_t j = lo; j < hi; ++j) {
+        uint32_t e = entries[j];
+        g1a p = g1a_load(table + (size_t)(e & 0x7fffffffu) * 16);
+        acc = g1j_add_mixed(acc, g1a_cneg(p, (e >> 31) != 0));
+    }
+    g1j_store(partial_all + ((size_t)col * partial_stride + t) * 24, acc);
+}
+// Rounds >= 1: segment sums of Jacobian partials.
+__global__ void __launch_bounds__(256) k_accum_jac(const uint32_t* in_all, size_t in_stride, const uint32_t* cnt_all,
+                                                   const uint32_t* off_all, const uint32_t* segoff_all, uint32_t B,
+                                                   uint32_t seg, uint32_t* out_all, size_t out_stride) {
+    uint32_t col = blockIdx.y;
+    const uint32_t* segoff = segoff_all + (size_t)col * (B + 1);
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= segoff[B]) return;
+    const uint32_t* cnt = cnt_all + (size_t)col * B;
+    const uint32_t* off = off_all + (size_t)col * (B + 1);
+    const uint32_t* in = in_all + (size_t)col * in_stride * 24;
+    uint32_t b = find_bucket(segoff, B, t);
+    uint32_t s = t - segoff[b];
+    uint32_t lo = off[b] + s * seg, hi = min(lo + seg, off[b] + cnt[b]);
+    g1j acc = g1j_load(in + (size_t)lo * 24);
+    for (uint32_t j = lo + 1; j < hi; ++j) acc = g1j_add(acc, g1j_load(in + (size_t)j * 24));
+    g1j_store(out_all + ((size_t)col * out_stride + t) * 24, acc);
+}
+
+// sum_{b} (b+1) * S_b over CH consecutive buckets per thread (running-sum trick + base * run).
+__global__ void __launch_bounds__(256) k_bucket_chunks(const uint32_t* part_all, size_t part_stride, const uint32_t* cnt_all,
+                                                       const uint32_t* off_all, uint32_t B, uint32_t CH, uint32_t* out_all,
+                                                       uint32_t nchunks) {
+    uint32_t col = blockIdx.y;
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nchunks) return;
+    const uint32_t* cnt = cnt_all + (size_t)col * B;
+    const uint32_t* off = off_all + (size_t)col * (B + 1);
+    const uint32_t* part = part_all + (size_t)col * part_stride * 24;
+    uint32_t base = t * CH;
+    g1j run = g1j_identity(), acc = g1j_identity();
+    for (int j = (int)CH - 1; j >= 0; --j) {
+        uint32_t b = base + (uint32_t)j;
+        if (b < B && cnt[b]) run = g1j_add(run, g1j_load(part + (size_t)off[b] * 24));
+        acc = g1j_add(acc, run);
+    }
+    // + base * run
+    g1j d = run;
+    uint32_t m = base;
+    while (m) {
+        if (m & 1) acc = g1j_add(acc, d);
+        m >>= 1;
+        if (m) d = g1j_double(d);
+    }
+    g1j_store(out_all + ((size_t)col * nchunks + t) * 24, acc);
+}
+
+__global__ void __launch_bounds__(512) k_final_sum(const uint32_t* in_all, uint32_t count, uint32_t* out_all) {
+    __shared__ g1j sh[512];
+    uint32_t col = blockIdx.x, t = threadIdx.x;
+    const uint32_t* in = in_all + (size_t)col * count * 24;
+    g1j acc = g1j_identity();
+    for (uint32_t i = t; i < count; i += 512) acc = g1j_add(acc, g1j_load(in + (size_t)i * 24));
+    sh[t] = acc;
+    __syncthreads();
+    for (uint32_t d = 256; d >= 1; d >>= 1) {
+        if (t < d) sh[t] = g1j_add(sh[t], sh[t + d]);
+        __syncthreads();
+    }
+    if (t == 0) g1j_store(out_all + (size_t)col * 24, sh[0]);
+}
+__global__ void k_set_identity(uint32_t* out_all, uint32_t ncols) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < ncols) g1j_store(out_all + (size_t)t * 24, g1j_identity());
+}
+
+// ------------------------------------------------------------------ host driver
+static int msm_run(zkhip_ctx* ctx, const zkhip_srs* srs, const void* const* d_cols_host, size_t ncols, size_t n, void* d_out) {
+    if (!ctx || !srs || !d_cols_host || !d_out) { set_error("zkhip_msm: null argument"); return ZKHIP_EINVAL; }
+    if (n > srs->n) { set_error("zkhip_msm: n = %zu exceeds the %zu bases loaded", n, srs->n); return ZKHIP_EINVAL; }
+    if (ncols == 0) return ZKHIP_OK;
+    hipStream_t st = ctx->stream;
+    if (n == 0) {
+        hipLaunchKernelGGL(k_set_identity, dim3(div_up(ncols, 64)), dim3(64), 0, st, (uint32_t*)d_out, (uint32_t)ncols);
+        ZK_LAUNCH_CHECK();
+        return ZKHIP_OK;
+    }
+    const uint32_t c = srs->c, W = srs->W, B = srs->B;
+    const size_t items = n * W;
+    const uint32_t seg0_min = 8;
+    // scratch
+    void *d_colptrs, *d_cnt, *d_off, *d_cursor, *d_entries, *d_max, *d_cntA, *d_cntB, *d_offA, *d_offB, *d_pA, *d_pB, *d_chunks;
+    const size_t pstride0 = items / seg0_min + B + 1;
+    ZK_TRY(ctx->get_scratch("msm_colptrs", ncols * sizeof(void*), &d_colptrs));
+    ZK_TRY(ctx->get_scratch("msm_cnt", ncols * B * 4 * 2, &d_cnt));  // cnt + cursor, zeroed together
+    d_cursor = (char*)d_cnt + ncols * B * 4;
+    ZK_TRY(ctx->get_scratch("msm_off", ncols * (B + 1) * 4, &d_off));
+    ZK_TRY(ctx->get_scratch("msm_entries", ncols * items * 4, &d_entries));
+    ZK_TRY(ctx->get_scratch("msm_max", ncols * 4, &d_max));
+    ZK_TRY(ctx->get_scratch("msm_cntA", ncols * B * 4, &d_cntA));
+    ZK_TRY(ctx->get_scratch("msm_cntB", ncols * B * 4, &d_cntB));
+    ZK_TRY(ctx->get_scratch("msm_offA", ncols * (B + 1) * 4, &d_offA));
+    ZK_TRY(ctx->get_scratch("msm_offB", ncols * (B + 1) * 4, &d_offB));
+    ZK_TRY(ctx->get_scratch("msm_pA", ncols * pstride0 * 96, &d_pA));
+    ZK_TRY(ctx->get_scratch("msm_pB", ncols * pstride0 * 96, &d_pB));
+    uint32_t CH = B > 8192 ? B / 8192 : 1;
+    uint32_t nchunks = (B + CH - 1) / CH;
+    ZK_TRY(ctx->get_scratch("msm_chunks", ncols * (size_t)nchunks * 96, &d_chunks));
+
+    ZK_HIP(hipMemcpyAsync(d_colptrs, d_cols_host, ncols * sizeof(void*), hipMemcpyHostToDevice, st));
+    ZK_HIP(hipMemsetAsync(d_cnt, 0, ncols * B * 4 * 2, st));
+    dim3 gn(div_up(n, 256), (unsigned)ncols);
+    hipLaunchKernelGGL(k_digits<false>, gn, dim3(256), 0, st, (const uint32_t* const*)d_colptrs, n, c, W, B, (uint32_t*)d_cnt,
+                       (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, items);
+    hipLaunchKernelGGL(k_plan, dim3((unsigned)ncols), dim3(1024), 0, st, (const uint32_t*)d_cnt, B, 1u, (uint32_t*)d_off,
+                       (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)d_max);
+    std::vector<uint32_t> h_max(ncols);
+    ZK_HIP(hipMemcpyAsync(h_max.data(), d_max, ncols * 4, hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(k_digits<true>, gn, dim3(256), 0, st, (const uint32_t* const*)d_colptrs, n, c, W, B, (uint32_t*)d_cnt,
+                       (const uint32_t*)d_off, (uint32_t*)d_cursor, (uint32_t*)d_entries, items);
+    ZK_LAUNCH_CHECK();
+    ZK_HIP(hipStreamSynchronize(st));
+    uint32_t maxcnt = 0;
+    for (uint32_t v : h_max) maxcnt = std::max(maxcnt, v);
+    if (maxcnt == 0) {
+        hipLaunchKernelGGL(k_set_identity, dim3(div_up(ncols, 64)), dim3(64), 0, st, (uint32_t*)d_out, (uint32_t)ncols);
+        ZK_LAUNCH_CHECK();
+        return ZKHIP_OK;
+    }
+    // Round 0 segment length: aim for ~2 waves per SIMD over the whole chip, never below seg0_min.
+    uint32_t seg = seg0_min;
+    {
+        size_t target_threads = (size_t)256 * 4 * 64 * 4;
+        size_t s = (ncols * items) / target_threads;
+        if (s > seg) seg = (uint32_t)std::min<size_t>(s, 64);
+    }
+    // round 0
+    const uint32_t* cur_cnt = (const uint32_t*)d_cnt;
+    const uint32_t* cur_off = (const uint32_t*)d_off;
+    uint32_t* nxt_cnt = (uint32_t*)d_cntA;
+    uint32_t* nxt_off = (uint32_t*)d_offA;
+    hipLaunchKernelGGL(k_plan, dim3((unsigned)ncols), dim3(1024), 0, st, cur_cnt, B, seg, (uint32_t*)nullptr, nxt_cnt, nxt_off,
+                       (uint32_t*)nullptr);
+    size_t bound = items / seg + B + 1;
+    if (bound > pstride0) bound = pstride0;
+    hipLaunchKernelGGL(k_accum_affine, dim3(div_up(bound, 256), (unsigned)ncols), dim3(256), 0, st, (const uint32_t*)srs->d_table,
+                       (const uint32_t*)d_entries, items, cur_cnt, cur_off, (const uint32_t*)nxt_off, B, seg, (uint32_t*)d_pA,
+                       pstride0);
+    uint32_t* cur_p = (uint32_t*)d_pA;
+    uint32_t* nxt_p = (uint32_t*)d_pB;
+    cur_cnt = nxt_cnt; cur_off = nxt_off;
+    nxt_cnt = (uint32_t*)d_cntB; nxt_off = (uint32_t*)d_offB;
+    maxcnt = (maxcnt + seg - 1) / seg;
+    while (maxcnt > 1) {
+        seg = maxcnt <= 16 ? maxcnt : 8;
+        hipLaunchKernelGGL(k_plan, dim3((unsigned)ncols), dim3(1024), 0, st, cur_cnt, B, seg, (uint32_t*)nullptr, nxt_cnt, nxt_off,
+                           (uint32_t*)nullptr);
+        size_t nb = bound / seg + B + 1;
+        if (nb > pstride0) nb = pstride0;
+        hipLaunchKernelGGL(k_accum_jac, dim3(div_up(nb, 256), (unsigned)ncols), dim3(256), 0, st, (const uint32_t*)cur_p, pstride0,
+                           cur_cnt, cur_off, (const uint32_t*)nxt_off, B, seg, nxt_p, pstride0);
+        bound = nb;
+        std::swap(cur_p, nxt_p);
+        const uint32_t* tc = cur_cnt; const uint32_t* to = cur_off;
+        cur_cnt = nxt_cnt; cur_off = nxt_off;
+        nxt_cnt = (uint32_t*)tc; nxt_off = (uint32_t*)to;
+        if (nxt_cnt == (uint32_t*)d_cnt) { nxt_cnt = (uint32_t*)d_cntB; nxt_off = (uint32_t*)d_offB; }
+        maxcnt = (maxcnt + seg - 1) / seg;
+    }
+    hipLaunchKernelGGL(k_bucket_chunks, dim3(div_up(nchunks, 256), (unsigned)ncols), dim3(256), 0, st, (const uint32_t*)cur_p, pstride0,
+                       cur_cnt, cur_off, B, CH, (uint32_t*)d_chunks, nchunks);
+    hipLaunchKernelGGL(k_final_sum, dim3((unsigned)ncols), dim3(512), 0, st, (const uint32_t*)d_chunks, nchunks, (uint32_t*)d_out);
+    ZK_LAUNCH_CHECK();
+    return ZKHIP_OK;
+}
+
+extern "C" {
+
+int zkhip_srs_load_device(zkhip_ctx* ctx, const void* d_bases, size_t n, zkhip_srs** out) {
+    if (!ctx || !d_bases || !out) { set_error("zkhip_srs_load_device: null argument"); return ZKHIP_EINVAL; }
+    return srs_build(ctx, d_bases, n, out);
+}
+int zkhip_srs_load(zkhip_ctx* ctx, const uint64_t* bases_xy, size_t n, zkhip_srs** out) {
+    if (!ctx || !bases_xy || !out) { set_error("zkhip_srs_load: null argument"); return ZKHIP_EINVAL; }
+    if (n == 0) { set_error("zkhip_srs_load: n = 0"); return ZKHIP_EINVAL; }
+    void* d;
+    ZK_TRY(ctx->get_scratch("srs_upload", n * 64, &d));
+    ZK_HIP(hipMemcpyAsync(d, bases_xy, n * 64, hipMemcpyHostToDevice, ctx->stream));
+    return srs_build(ctx, d, n, out);
+}
+void zkhip_srs_free(zkhip_ctx* ctx, zkhip_srs* s) {
+    if (!s) return;
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    if (s->d_table) (void)hipFree(s->d_table);
+    delete s;
+}
+size_t zkhip_srs_len(const zkhip_srs* s) { return s ? s->n : 0; }
+int zkhip_srs_read(zkhip_ctx* ctx, const zkhip_srs* s, size_t first, size_t count, uint64_t* out_xy) {
+    if (!ctx || !s || !out_xy || first + count > s->n) { set_error("zkhip_srs_read: bad range"); return ZKHIP_EINVAL; }
+    ZK_HIP(hipMemcpyAsync(out_xy, (const char*)s->d_table + first * 64, count * 64, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    return ZKHIP_OK;
+}
+
+int zkhip_msm_g1_batch_device(zkhip_ctx* ctx, const zkhip_srs* srs, const void* const* d_scalar_cols, size_t ncols, size_t n,
+                              void* d_out_xyz) {
+    return msm_run(ctx, srs, d_scalar_cols, ncols, n, d_out_xyz);
+}
+
+int zkhip_msm_g1(zkhip_ctx* ctx, const zkhip_srs* srs, const uint64_t* scalars, size_t n, uint64_t out_xyz[12]) {
+    if (!ctx || !srs || !out_xyz || (!scalars && n)) { set_error("zkhip_msm_g1: null argument"); return ZKHIP_EINVAL; }
+    void *d_s, *d_o;
+    ZK_TRY(ctx->get_scratch("msm_host_scalars", (n ? n : 1) * 32, &d_s));
+    ZK_TRY(ctx->get_scratch("msm_host_out", 96, &d_o));
+    if (n) ZK_HIP(hipMemcpyAsync(d_s, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    const void* cols[1] = {d_s};
+    ZK_TRY(msm_run(ctx, srs, cols, 1, n, d_o));
+    uint64_t jac[12];
+    ZK_HIP(hipMemcpyAsync(jac, d_o, 96, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    // normalise: (x, y, 1) or the identity (0, 1, 0), like G1::from(G1Affine)
+    g1j p;
+    memcpy(&p, jac, 96);
+    g1a a = g1j_to_affine(p);
+    g1j r = g1j_from_affine(a);
+    memcpy(out_xyz, &r, 96);
+    return ZKHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,423 @@
+// ntt.hip — radix-2 NTT / iNTT over BN254 Fr and the EvaluationDomain basis changes, for gfx950.
+//
+// Drop-in for halo2curves 0.4.0 fft::best_fft (natural order in, natural order out) and for
+// halo2_proofs poly::EvaluationDomain::{lagrange_to_coeff, coeff_to_extended, extended_to_coeff,
+// divide_by_vanishing_poly} [UPSTREAM-RECALL; crates pinned at /root/reference/Cargo.lock:1359-1361
+// and :1320-1322].  Results are the unique DFT values, so the decomposition is free:
+//
+//   n = n_1 * n_2 * ... * n_p  (p <= 4 passes, each n_q = 2^s_q <= 2^11)
+//   pass q < p : for fixed outer digits, a size-n_q DFT over digit q held in LDS, then the
+//                Cooley-Tukey twiddle w_n^(prefix * lo * k_q); tiles of T adjacent `lo` values so
+//                every global access is a T*32-byte contiguous run (in place).
+//   pass p     : contiguous rows of n_p, T rows adjacent in k_1 so the digit-reversed scatter of
+//                the outputs is also T*32-byte contiguous (out of place).
+//   The zeta coset scaling / zero padding of coeff_to_extended is fused into the first load, the
+//   1/n and inverse coset scaling of ifft / extended_to_coeff into the last store.
+//
+// Bound: integer multiply (one Fr product per butterfly + one per element per non-final pass);
+// HBM traffic is 64 B per element per pass.
+#include <algorithm>
+
+#include "common.hpp"
+using namespace zk;
+
+#define NTT_TILE 2048  // elements per workgroup tile (64 KB LDS), 256 threads
+
+// ------------------------------------------------------------------ twiddle tables
+__global__ void k_twiddles(uint32_t* table, size_t half_n, fe omega) {
+    const size_t CHK = 64;
+    size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    size_t lo = t * CHK;
+    if (lo >= half_n) return;
+    fe w = fe_pow_u64<Fr>(omega, (uint64_t)lo);
+    size_t hi = lo + CHK < half_n ? lo + CHK : half_n;
+    for (size_t i = lo; i < hi; ++i) {
+        fe_store(table + i * 8, w);
+        w = fe_mul<Fr>(w, omega);
+    }
+}
+
+int zkhip_ctx::get_twiddles(const uint64_t omega[4], uint32_t log_n, const void** d_table) {
+    for (auto& t : twiddles)
+        if (t.log_n == log_n && memcmp(t.omega, omega, 32) == 0) { *d_table = t.d_table; return ZKHIP_OK; }
+    Twiddle t;
+    t.log_n = log_n;
+    memcpy(t.omega, omega, 32);
+    size_t half_n = log_n ? ((size_t)1 << (log_n - 1)) : 1;
+    hipError_t e = hipMalloc(&t.d_table, half_n * 32);
+    if (e != hipSuccess) { (void)hipGetLastError(); set_error("hipMalloc twiddles (%zu B): %s", half_n * 32, hipGetErrorString(e)); return ZKHIP_ENOMEM; }
+    fe w;
+    memcpy(&w, omega, 32);
+    hipLaunchKernelGGL(k_twiddles, dim3(div_up(div_up(half_n, 64), 64)), dim3(64), 0, stream, (uint32_t*)t.d_table, half_n, w);
+    ZK_LAUNCH_CHECK();
+    twiddles.push_back(t);
+    *d_table = t.d_table;
+    return ZKHIP_OK;
+}
+
+// ------------------------------------------------------------------ kernels
+struct NttScale {
+    fe pre[3];   // element i is multiplied by pre[i % 3] on the first load (if use_pre)
+    fe post[3];  // output k is multiplied by post[k % 3] on the last store (if use_post)
+    int use_pre, use_post;
+};
+
+__device__ __forceinline__ uint32_t bitrev(uint32_t v, uint32_t bits) { return bits ? (__brev(v) >> (32 - bits)) : 0; }
+
+__device__ __forceinline__ fe twiddle_at(const uint32_t* table, uint32_t e, uint32_t half_n) {
+    // w^e for e < n from the half table: w^(n/2) = -1
+    if (e < half_n) return fe_load(table + (size_t)e * 8);
+    fe t = fe_load(table + (size_t)(e - half_n) * 8);
+    return fe_neg<Fr>(t);
+}
+
+// s radix-2 DIT stages on a tile laid out tile[row * T + tl], rows = 2^s (rows were loaded bit-reversed).
+__device__ __forceinline__ void tile_ntt(fe* tile, uint32_t s, uint32_t logT, uint32_t m, const uint32_t* table) {
+    uint32_t T = 1u << logT;
+    uint32_t nbf = (1u << s) * T / 2;
+    for (uint32_t st = 0; st < s; ++st) {
+        __syncthreads();
+        uint32_t half = 1u << st;
+        for (uint32_t bf = threadIdx.x; bf < nbf; bf += blockDim.x) {
+            uint32_t tl = bf & (T - 1), pr = bf >> logT;
+            uint32_t j = pr & (half - 1);
+            uint32_t r0 = ((pr >> st) << (st + 1)) | j;
+            uint32_t i0 = r0 * T + tl, i1 = (r0 + half) * T + tl;
+            fe a = tile[i0], b = tile[i1];
+            if (j != 0) b = fe_mul<Fr>(b, fe_load(table + ((size_t)j << (m - 1 - st)) * 8));
+            tile[i0] = fe_add<Fr>(a, b);
+            tile[i1] = fe_sub<Fr>(a, b);
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ fe load_in(const uint32_t* src, uint32_t i, uint32_t n_in, const NttScale& sc) {
+    if (i >= n_in) return fe_zero();
+    fe v = fe_load(src + (size_t)i * 8);
+    if (sc.use_pre) {
+        uint32_t r = i % 3;
+        if (r == 1) v = fe_mul<Fr>(v, sc.pre[1]);
+        else if (r == 2) v = fe_mul<Fr>(v, sc.pre[2]);
+        else if (sc.use_pre > 1) v = fe_mul<Fr>(v, sc.pre[0]);
+    }
+    return v;
+}
+
+// Non-final pass: position = (hi << (s + lo_bits)) | (digit << lo_bits) | lo.
+__global__ void __launch_bounds__(256) k_ntt_strided(const uint32_t* const* srcs, uint32_t* const* dsts, uint32_t m, uint32_t s,
+                                                      uint32_t lo_bits, uint32_t logT, uint32_t n_in, const uint32_t* table,
+                                                      NttScale sc) {
+    __shared__ fe tile[NTT_TILE];
+    const uint32_t* src = srcs[blockIdx.y];
+    uint32_t* dst = dsts[blockIdx.y];
+    uint32_t T = 1u << logT, rows = 1u << s;
+    uint32_t hi_bits = m - s - lo_bits;
+    uint32_t tiles_lo = 1u << (lo_bits - logT);
+    uint32_t lo_tile = blockIdx.x & (tiles_lo - 1), hi = blockIdx.x >> (lo_bits - logT);
+    uint32_t lo0 = lo_tile << logT;
+    uint32_t base = (hi << (s + lo_bits)) | lo0;
+    uint32_t cnt = rows * T;
+    for (uint32_t e = threadIdx.x; e < cnt; e += blockDim.x) {
+        uint32_t tl = e & (T - 1), j = e >> logT;
+        uint32_t pos = base | (j << lo_bits) | tl;
+        tile[bitrev(j, s) * T + tl] = load_in(src, pos, n_in, sc);
+    }
+    tile_ntt(tile, s, logT, m, table);
+    uint32_t half_n = 1u << (m - 1);
+    for (uint32_t e = threadIdx.x; e < cnt; e += blockDim.x) {
+        uint32_t tl = e & (T - 1), r = e >> logT;
+        uint32_t lo = lo0 | tl;
+        fe v = tile[r * T + tl];
+        uint32_t ex = (lo * r) << hi_bits;  // < n
+        if (ex != 0) v = fe_mul<Fr>(v, twiddle_at(table, ex, half_n));
+        fe_store(dst + (size_t)(base | (r << lo_bits) | tl) * 8, v);
+    }
+}
+
+// Final pass: rows of 2^s contiguous elements; T rows adjacent in the first digit k_1.
+// digit widths of the earlier passes are in sw[0..np-2] (sw[0] = s_1 is the most significant slot).
+struct NttDigits { uint32_t np; uint32_t sw[4]; };
+
+__global__ void __launch_bounds__(256) k_ntt_final(const uint32_t* const* srcs, uint32_t* const* dsts, uint32_t m, uint32_t s,
+                                                    uint32_t logT, uint32_t n_in, const uint32_t* table, NttScale sc, NttDigits dg) {
+    __shared__ fe tile[NTT_TILE];
+    const uint32_t* src = srcs[blockIdx.y];
+    uint32_t* dst = dsts[blockIdx.y];
+    uint32_t T = 1u << logT, rows = 1u << s;
+    uint32_t hi_bits = m - s;                 // bits of the row index
+    uint32_t s1 = dg.np > 1 ? dg.sw[0] : 0;   // k_1 is the top s1 bits of the row index
+    uint32_t rest_bits = hi_bits - s1;
+    // blockIdx.x -> (k1 tile, rest)
+    uint32_t rest = blockIdx.x & ((1u << rest_bits) - 1);
+    uint32_t k1_0 = (blockIdx.x >> rest_bits) << logT;
+    uint32_t cnt = rows * T;
+    for (uint32_t e = threadIdx.x; e < cnt; e += blockDim.x) {
+        uint32_t j = e & (rows - 1), tl = e >> s;
+        uint32_t row = ((k1_0 + tl) << rest_bits) | rest;
+        tile[bitrev(j, s) * T + tl] = load_in(src, (row << s) | j, n_in, sc);
+    }
+    tile_ntt(tile, s, logT, m, table);
+    // output index: k = k_1 + k_2 2^{s_1} + ... ; digits k_2..k_{p-1} come out of `rest` (slot order, msb first)
+    uint32_t kbase = 0, shift_out = s1, rem = rest, rb = rest_bits;
+    for (uint32_t q = 1; q + 1 < dg.np; ++q) {
+        uint32_t w = dg.sw[q];
+        rb -= w;
+        uint32_t d = (rem >> rb) & ((1u << w) - 1);
+        kbase |= d << shift_out;
+        shift_out += w;
+    }
+    for (uint32_t e = threadIdx.x; e < cnt; e += blockDim.x) {
+        uint32_t tl = e & (T - 1), r = e >> logT;
+        uint32_t k = (r << hi_bits) | kbase | (k1_0 + tl);
+        fe v = tile[r * T + tl];
+        if (sc.use_post) v = fe_mul<Fr>(v, sc.post[k % 3]);
+        fe_store(dst + (size_t)k * 8, v);
+    }
+}
+
+__global__ void k_mul_periodic(uint32_t* a, size_t n, const uint32_t* tev, uint32_t period_mask) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe v = fe_load(a + i * 8);
+    fe t = fe_load(tev + (size_t)(i & period_mask) * 8);
+    fe_store(a + i * 8, fe_mul<Fr>(v, t));
+}
+
+// ------------------------------------------------------------------ host driver
+static uint32_t ilog2(uint32_t v) { uint32_t l = 0; while ((1u << (l + 1)) <= v) ++l; return l; }
+
+// srcs/dsts: host arrays of device pointers (src[i] may equal dst[i]); src has n_in valid elements.
+static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, size_t npolys, const uint64_t omega[4],
+                   uint32_t m, uint32_t n_in, const NttScale& sc_in) {
+    if (npolys == 0) return ZKHIP_OK;
+    if (m > 26) { set_error("ntt: log_n = %u unsupported (max 26)", m); return ZKHIP_EINVAL; }
+    hipStream_t st = ctx->stream;
+    size_t n = (size_t)1 << m;
+    void* d_ptrs;
+    ZK_TRY(ctx->get_scratch("ntt_ptrs", npolys * sizeof(void*) * 3, &d_ptrs));
+    const uint32_t** d_src = (const uint32_t**)d_ptrs;
+    uint32_t** d_dst = (uint32_t**)d_ptrs + npolys;
+    uint32_t** d_tmp = (uint32_t**)d_ptrs + 2 * npolys;
+    if (m == 0) {  // size-1 transform: copy / scale only
+        for (size_t i = 0; i < npolys; ++i)
+            if (srcs[i] != dsts[i]) ZK_HIP(hipMemcpyAsync(dsts[i], srcs[i], 32, hipMemcpyDeviceToDevice, st));
+        return ZKHIP_OK;
+    }
+    const void* table;
+    ZK_TRY(ctx->get_twiddles(omega, m, &table));
+    // pass plan
+    uint32_t smax = 9;
+    if (const char* e = getenv("ZKHIP_NTT_SMAX")) { int v = atoi(e); if (v >= 4 && v <= 11) smax = (uint32_t)v; }
+    uint32_t np = m <= 11 ? 1 : (m + smax - 1) / smax;
+    if (np > 4) { set_error("ntt: too many passes"); return ZKHIP_EINVAL; }
+    uint32_t sw[4] = {0, 0, 0, 0};
+    for (uint32_t q = 0; q < np; ++q) sw[q] = m / np + (q < m % np ? 1 : 0);
+    std::vector<void*> tmp_host(npolys);
+    if (np > 1) {
+        void* d_tmpbuf;
+        ZK_TRY(ctx->get_scratch("ntt_tmp", npolys * n * 32, &d_tmpbuf));
+        for (size_t i = 0; i < npolys; ++i) tmp_host[i] = (char*)d_tmpbuf + i * n * 32;
+    }
+    std::vector<const void*> all(3 * npolys);
+    for (size_t i = 0; i < npolys; ++i) { all[i] = srcs[i]; all[npolys + i] = dsts[i]; all[2 * npolys + i] = np > 1 ? tmp_host[i] : dsts[i]; }
+    ZK_HIP(hipMemcpyAsync(d_ptrs, all.data(), 3 * npolys * sizeof(void*), hipMemcpyHostToDevice, st));
+    NttScale sc = sc_in;
+    uint32_t lo_bits = m;
+    // passes 1..np-1: in place on dst, except that the first reads src and the last non-final writes tmp
+    const uint32_t** cur_src = d_src;
+    for (uint32_t q = 0; q + 1 < np; ++q) {
+        uint32_t s = sw[q];
+        lo_bits -= s;
+        uint32_t logT = std::min<uint32_t>(ilog2(NTT_TILE) - s, lo_bits);
+        NttScale scq = sc;
+        if (q != 0) scq.use_pre = 0;
+        scq.use_post = 0;
+        uint32_t** out = (q + 2 == np) ? d_tmp : d_dst;
+        unsigned blocks = (unsigned)(n >> (s + logT));
+        hipLaunchKernelGGL(k_ntt_strided, dim3(blocks, (unsigned)npolys), dim3(256), 0, st, (const uint32_t* const*)cur_src,
+                           (uint32_t* const*)out, m, s, lo_bits, logT, q == 0 ? n_in : (uint32_t)n, (const uint32_t*)table, scq);
+        cur_src = (const uint32_t**)out;
+    }
+    {
+        uint32_t s = sw[np - 1];
+        uint32_t s1 = np > 1 ? sw[0] : 0;
+        uint32_t logT = np > 1 ? std::min<uint32_t>(ilog2(NTT_TILE) - s, s1) : 0;
+        NttScale scq = sc;
+        if (np > 1) scq.use_pre = 0;
+        NttDigits dg;
+        dg.np = np;
+        for (int i = 0; i < 4; ++i) dg.sw[i] = sw[i];
+        unsigned blocks = (unsigned)(n >> (s + logT));
+        hipLaunchKernelGGL(k_ntt_final, dim3(blocks, (unsigned)npolys), dim3(256), 0, st, (const uint32_t* const*)cur_src,
+                           (uint32_t* const*)d_dst, m, s, logT, np == 1 ? n_in : (uint32_t)n, (const uint32_t*)table, scq, dg);
+    }
+    ZK_LAUNCH_CHECK();
+    return ZKHIP_OK;
+}
+
+struct zkhip_domain {
+    uint32_t k, extended_k, quotient_poly_degree;
+    fe omega, omega_inv, extended_omega, extended_omega_inv, g_coset, g_coset_inv, ifft_divisor, extended_ifft_divisor;
+    void* d_t_evaluations = nullptr;
+    uint32_t n_t = 0;
+};
+
+static NttScale no_scale() {
+    NttScale s;
+    memset(&s, 0, sizeof s);
+    return s;
+}
+
+extern "C" {
+
+int zkhip_fft_batch_device(zkhip_ctx* ctx, void* const* d_polys, size_t npolys, const uint64_t omega[4], uint32_t log_n) {
+    if (!ctx || !d_polys || !omega) { set_error("zkhip_fft_batch_device: null argument"); return ZKHIP_EINVAL; }
+    return ntt_run(ctx, (const void* const*)d_polys, d_polys, npolys, omega, log_n, 1u << log_n, no_scale());
+}
+
+int zkhip_fft(zkhip_ctx* ctx, uint64_t* a, const uint64_t omega[4], uint32_t log_n) {
+    if (!ctx || !a || !omega) { set_error("zkhip_fft: null argument"); return ZKHIP_EINVAL; }
+    if (log_n > 26) { set_error("zkhip_fft: log_n = %u unsupported (max 26)", log_n); return ZKHIP_EINVAL; }
+    size_t bytes = ((size_t)1 << log_n) * 32;
+    void* d;
+    ZK_TRY(ctx->get_scratch("fft_host", bytes, &d));
+    ZK_HIP(hipMemcpyAsync(d, a, bytes, hipMemcpyHostToDevice, ctx->stream));
+    void* polys[1] = {d};
+    ZK_TRY(zkhip_fft_batch_device(ctx, polys, 1, omega, log_n));
+    ZK_HIP(hipMemcpyAsync(a, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    return ZKHIP_OK;
+}
+
+int zkhip_domain_new(zkhip_ctx* ctx, uint32_t j, uint32_t k, const uint64_t g_coset[4], zkhip_domain** out) {
+    if (!ctx || !out) { set_error("zkhip_domain_new: null argument"); return ZKHIP_EINVAL; }
+    if (j < 2 || k == 0 || k > 26) { set_error("zkhip_domain_new: j = %u, k = %u out of range", j, k); return ZKHIP_EINVAL; }
+    zkhip_domain* d = new zkhip_domain();
+    d->k = k;
+    d->quotient_poly_degree = j - 1;
+    uint32_t ek = k;
+    while (((uint64_t)1 << ek) < ((uint64_t)1 << k) * d->quotient_poly_degree) ++ek;
+    if (ek > 26) { delete d; set_error("zkhip_domain_new: extended_k = %u unsupported (max 26)", ek); return ZKHIP_EINVAL; }
+    d->extended_k = ek;
+    fe w = fe_from_canonical<Fr>(FR_ROOT_OF_UNITY);
+    for (uint32_t i = ek; i < FR_S; ++i) w = fe_sqr<Fr>(w);
+    d->extended_omega = w;
+    for (uint32_t i = k; i < ek; ++i) w = fe_sqr<Fr>(w);
+    d->omega = w;
+    d->omega_inv = fe_inv<Fr>(d->omega);
+    d->extended_omega_inv = fe_inv<Fr>(d->extended_omega);
+    if (g_coset) memcpy(&d->g_coset, g_coset, 32); else d->g_coset = fe_from_canonical<Fr>(FR_ZETA);
+    d->g_coset_inv = fe_sqr<Fr>(d->g_coset);
+    d->ifft_divisor = fe_inv<Fr>(fe_from_u64<Fr>((uint64_t)1 << k));
+    d->extended_ifft_divisor = fe_inv<Fr>(fe_from_u64<Fr>((uint64_t)1 << ek));
+    d->n_t = 1u << (ek - k);
+    std::vector<fe> tev(d->n_t);
+    fe cur = fe_pow_u64<Fr>(d->g_coset, (uint64_t)1 << k), step = fe_pow_u64<Fr>(d->extended_omega, (uint64_t)1 << k);
+    for (uint32_t i = 0; i < d->n_t; ++i) {
+        tev[i] = fe_inv<Fr>(fe_sub<Fr>(cur, fe_one<Fr>()));
+        cur = fe_mul<Fr>(cur, step);
+    }
+    hipError_t e = hipMalloc(&d->d_t_evaluations, d->n_t * 32);
+    if (e != hipSuccess) { (void)hipGetLastError(); delete d; set_error("hipMalloc t_evaluations: %s", hipGetErrorString(e)); return ZKHIP_ENOMEM; }
+    ZK_HIP(hipMemcpyAsync(d->d_t_evaluations, tev.data(), d->n_t * 32, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    *out = d;
+    return ZKHIP_OK;
+}
+void zkhip_domain_free(zkhip_ctx* ctx, zkhip_domain* d) {
+    if (!d) return;
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    if (d->d_t_evaluations) (void)hipFree(d->d_t_evaluations);
+    delete d;
+}
+uint32_t zkhip_domain_k(const zkhip_domain* d) { return d->k; }
+uint32_t zkhip_domain_extended_k(const zkhip_domain* d) { return d->extended_k; }
+uint32_t zkhip_domain_quotient_poly_degree(const zkhip_domain* d) { return d->quotient_poly_degree; }
+void zkhip_domain_constants(const zkhip_domain* d, uint64_t omega[4], uint64_t extended_omega[4], uint64_t g_coset[4]) {
+    if (omega) memcpy(omega, &d->omega, 32);
+    if (extended_omega) memcpy(extended_omega, &d->extended_omega, 32);
+    if (g_coset) memcpy(g_coset, &d->g_coset, 32);
+}
+
+int zkhip_coeff_to_lagrange_device(zkhip_ctx* ctx, const zkhip_domain* d, void* const* polys, size_t npolys) {
+    if (!ctx || !d || !polys) { set_error("zkhip_coeff_to_lagrange_device: null argument"); return ZKHIP_EINVAL; }
+    return ntt_run(ctx, (const void* const*)polys, polys, npolys, (const uint64_t*)&d->omega, d->k, 1u << d->k, no_scale());
+}
+int zkhip_lagrange_to_coeff_device(zkhip_ctx* ctx, const zkhip_domain* d, void* const* polys, size_t npolys) {
+    if (!ctx || !d || !polys) { set_error("zkhip_lagrange_to_coeff_device: null argument"); return ZKHIP_EINVAL; }
+    NttScale sc = no_scale();
+    sc.use_post = 1;
+    sc.post[0] = sc.post[1] = sc.post[2] = d->ifft_divisor;
+    return ntt_run(ctx, (const void* const*)polys, polys, npolys, (const uint64_t*)&d->omega_inv, d->k, 1u << d->k, sc);
+}
+int zkhip_coeff_to_extended_device(zkhip_ctx* ctx, const zkhip_domain* d, const void* const* in, size_t n_in, void* const* out,
+                                   size_t npolys) {
+    if (!ctx || !d || !in || !out) { set_error("zkhip_coeff_to_extended_device: null argument"); return ZKHIP_EINVAL; }
+    if (n_in > ((size_t)1 << d->extended_k)) { set_error("zkhip_coeff_to_extended_device: n_in too large"); return ZKHIP_EINVAL; }
+    NttScale sc = no_scale();
+    sc.use_pre = 1;  // distribute_powers_zeta(into_coset = true): [1, g, g^2] by i mod 3
+    sc.pre[0] = fe_one<Fr>(); sc.pre[1] = d->g_coset; sc.pre[2] = d->g_coset_inv;
+    return ntt_run(ctx, in, out, npolys, (const uint64_t*)&d->extended_omega, d->extended_k, (uint32_t)n_in, sc);
+}
+int zkhip_extended_to_coeff_device(zkhip_ctx* ctx, const zkhip_domain* d, void* const* polys, size_t npolys) {
+    if (!ctx || !d || !polys) { set_error("zkhip_extended_to_coeff_device: null argument"); return ZKHIP_EINVAL; }
+    NttScale sc = no_scale();
+    sc.use_post = 1;  // ifft divisor, then distribute_powers_zeta(into_coset = false): [1, g^-1, g^-2]
+    sc.post[0] = d->extended_ifft_divisor;
+    sc.post[1] = fe_mul<Fr>(d->extended_ifft_divisor, d->g_coset_inv);
+    sc.post[2] = fe_mul<Fr>(d->extended_ifft_divisor, d->g_coset);
+    return ntt_run(ctx, (const void* const*)polys, polys, npolys, (const uint64_t*)&d->extended_omega_inv, d->extended_k,
+                   1u << d->extended_k, sc);
+}
+int zkhip_divide_by_vanishing_device(zkhip_ctx* ctx, const zkhip_domain* d, void* d_a) {
+    if (!ctx || !d || !d_a) { set_error("zkhip_divide_by_vanishing_device: null argument"); return ZKHIP_EINVAL; }
+    size_t n = (size_t)1 << d->extended_k;
+    hipLaunchKernelGGL(k_mul_periodic, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, (uint32_t*)d_a, n,
+                       (const uint32_t*)d->d_t_evaluations, d->n_t - 1);
+    ZK_LAUNCH_CHECK();
+    return ZKHIP_OK;
+}
+
+// host-pointer conveniences
+int zkhip_lagrange_to_coeff(zkhip_ctx* ctx, const zkhip_domain* d, uint64_t* a) {
+    if (!ctx || !d || !a) { set_error("zkhip_lagrange_to_coeff: null argument"); return ZKHIP_EINVAL; }
+    size_t bytes = ((size_t)1 << d->k) * 32;
+    void* dev;
+    ZK_TRY(ctx->get_scratch("fft_host", bytes, &dev));
+    ZK_HIP(hipMemcpyAsync(dev, a, bytes, hipMemcpyHostToDevice, ctx->stream));
+    void* polys[1] = {dev};
+    ZK_TRY(zkhip_lagrange_to_coeff_device(ctx, d, polys, 1));
+    ZK_HIP(hipMemcpyAsync(a, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    return ZKHIP_OK;
+}
+int zkhip_coeff_to_extended(zkhip_ctx* ctx, const zkhip_domain* d, const uint64_t* coeffs, size_t n_in, uint64_t* out) {
+    if (!ctx || !d || !coeffs || !out) { set_error("zkhip_coeff_to_extended: null argument"); return ZKHIP_EINVAL; }
+    size_t en = (size_t)1 << d->extended_k;
+    if (n_in > en) { set_error("zkhip_coeff_to_extended: n_in too large"); return ZKHIP_EINVAL; }
+    void *din, *dout;
+    ZK_TRY(ctx->get_scratch("fft_host_in", (n_in ? n_in : 1) * 32, &din));
+    ZK_TRY(ctx->get_scratch("fft_host", en * 32, &dout));
+    if (n_in) ZK_HIP(hipMemcpyAsync(din, coeffs, n_in * 32, hipMemcpyHostToDevice, ctx->stream));
+    const void* ins[1] = {din};
+    void* outs[1] = {dout};
+    ZK_TRY(zkhip_coeff_to_extended_device(ctx, d, ins, n_in, outs, 1));
+    ZK_HIP(hipMemcpyAsync(out, dout, en * 32, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    return ZKHIP_OK;
+}
+int zkhip_extended_to_coeff(zkhip_ctx* ctx, const zkhip_domain* d, uint64_t* a) {
+    if (!ctx || !d || !a) { set_error("zkhip_extended_to_coeff: null argument"); return ZKHIP_EINVAL; }
+    size_t bytes = ((size_t)1 << d->extended_k) * 32;
+    void* dev;
+    ZK_TRY(ctx->get_scratch("fft_host", bytes, &dev));
+    ZK_HIP(hipMemcpyAsync(dev, a, bytes, hipMemcpyHostToDevice, ctx->stream));
+    void* polys[1] = {dev};
+    ZK_TRY(zkhip_extended_to_coeff_device(ctx, d, polys, 1));
+    ZK_HIP(hipMemcpyAsync(a, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    return ZKHIP_OK;
+}
+
+}  // extern "C"

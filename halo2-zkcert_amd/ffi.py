@@ -1,0 +1,364 @@
+"""ctypes binding of libzkhip.so (include/zkhip.h) plus the host-side mirror of the reference-facing
+names for this path: best_multiexp, best_fft, EvaluationDomain, ParamsKZG.commit / commit_lagrange,
+evaluate_h  [UPSTREAM-RECALL names from halo2curves 0.4.0 / halo2_proofs, the crates the reference
+calls through gen_snark_shplonk at /root/reference/src/helpers.rs:233,299].
+
+There is no CPU fallback: importing works anywhere, but every compute call needs the HIP library and
+a GPU and raises ZkhipError otherwise.  PyTorch is used only for device memory and the stream.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_DIR, "libzkhip.so")
+_LIB = None
+
+
+class ZkhipError(RuntimeError):
+    pass
+
+
+class ZkGraph(C.Structure):
+    _fields_ = [("constants", C.c_void_p), ("rotations", C.c_void_p), ("code", C.c_void_p),
+                ("n_constants", C.c_uint32), ("n_rotations", C.c_uint32), ("n_code_words", C.c_uint32),
+                ("n_calculations", C.c_uint32), ("n_intermediates", C.c_uint32)]
+
+
+class ZkEvalhArgs(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("extended_k", C.c_uint32), ("cs_degree", C.c_uint32), ("blinding_factors", C.c_uint32),
+                ("extended_omega", C.c_uint64 * 4), ("g_coset", C.c_uint64 * 4), ("delta", C.c_uint64 * 4),
+                ("beta", C.c_uint64 * 4), ("gamma", C.c_uint64 * 4), ("theta", C.c_uint64 * 4), ("y", C.c_uint64 * 4),
+                ("n_fixed", C.c_uint32), ("n_advice", C.c_uint32), ("n_instance", C.c_uint32), ("n_challenges", C.c_uint32),
+                ("fixed_cosets", C.c_void_p), ("advice_cosets", C.c_void_p), ("instance_cosets", C.c_void_p),
+                ("challenges", C.c_void_p),
+                ("l0", C.c_void_p), ("l_last", C.c_void_p), ("l_active_row", C.c_void_p),
+                ("custom_gates", ZkGraph),
+                ("n_perm_columns", C.c_uint32), ("n_perm_sets", C.c_uint32),
+                ("perm_column_type", C.c_void_p), ("perm_column_index", C.c_void_p),
+                ("perm_sigma_cosets", C.c_void_p), ("perm_product_cosets", C.c_void_p),
+                ("n_lookups", C.c_uint32), ("_pad", C.c_uint32),
+                ("lookup_graphs", C.c_void_p),
+                ("lookup_product_cosets", C.c_void_p), ("lookup_input_cosets", C.c_void_p),
+                ("lookup_table_cosets", C.c_void_p)]
+
+
+# every symbol include/zkhip.h declares (checked by tests/test_abi.py without a GPU)
+SYMBOLS = [
+    "zkhip_init", "zkhip_destroy", "zkhip_last_error", "zkhip_set_stream", "zkhip_synchronize", "zkhip_malloc", "zkhip_free",
+    "zkhip_memcpy_h2d", "zkhip_memcpy_d2h", "zkhip_timer_start", "zkhip_timer_stop_ms",
+    "zkhip_srs_load", "zkhip_srs_load_device", "zkhip_srs_free", "zkhip_srs_len", "zkhip_kzg_setup", "zkhip_srs_read",
+    "zkhip_msm_g1", "zkhip_msm_g1_batch_device", "zkhip_g1_to_affine", "zkhip_g1_to_bytes",
+    "zkhip_fft", "zkhip_fft_batch_device",
+    "zkhip_domain_new", "zkhip_domain_free", "zkhip_domain_k", "zkhip_domain_extended_k", "zkhip_domain_quotient_poly_degree",
+    "zkhip_domain_constants", "zkhip_lagrange_to_coeff_device", "zkhip_coeff_to_lagrange_device",
+    "zkhip_coeff_to_extended_device", "zkhip_extended_to_coeff_device", "zkhip_divide_by_vanishing_device",
+    "zkhip_lagrange_to_coeff", "zkhip_coeff_to_extended", "zkhip_extended_to_coeff",
+    "zkhip_evaluate_h_device", "zkhip_synth_fill_device",
+]
+
+
+def lib():
+    """Loads libzkhip.so.  Fails loudly: there is no other implementation of the path."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ZkhipError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(make -C halo2-zkcert_amd/csrc); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.zkhip_last_error.restype = C.c_char_p
+        L.zkhip_srs_len.restype = C.c_size_t
+        for f in ("zkhip_domain_k", "zkhip_domain_extended_k", "zkhip_domain_quotient_poly_degree"):
+            getattr(L, f).restype = C.c_uint32
+        _LIB = L
+    return _LIB
+
+
+def _check(rc):
+    if rc != 0:
+        raise ZkhipError(f"zkhip error {rc}: {lib().zkhip_last_error().decode()}")
+
+
+def _p(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+def _u64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+class Context:
+    """One per process and GPU.  Kernels run on torch's current stream."""
+
+    def __init__(self, device=0):
+        import torch
+
+        self.torch = torch
+        if not torch.cuda.is_available():
+            raise ZkhipError("no GPU visible: the zkhip path has no CPU fallback")
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self.h = C.c_void_p()
+        _check(lib().zkhip_init(C.byref(self.h), C.c_int(device)))
+        self.use_torch_stream()
+
+    def use_torch_stream(self):
+        s = self.torch.cuda.current_stream(self.device).cuda_stream
+        _check(lib().zkhip_set_stream(self.h, C.c_void_p(s)))
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            lib().zkhip_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- device memory through torch ----
+    def empty(self, n_elems, width=4):
+        return self.torch.empty((n_elems, width), dtype=self.torch.int64, device=self.device)
+
+    def to_device(self, arr):
+        arr = _u64(arr)
+        return self.torch.from_numpy(arr.view(np.int64)).to(self.device)
+
+    def to_host(self, t):
+        return t.cpu().numpy().view(np.uint64)
+
+    def synchronize(self):
+        _check(lib().zkhip_synchronize(self.h))
+
+    def timer_start(self):
+        _check(lib().zkhip_timer_start(self.h))
+
+    def timer_stop_ms(self):
+        ms = C.c_float()
+        _check(lib().zkhip_timer_stop_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    def synth_fill(self, n, seed, first=0):
+        t = self.empty(n)
+        _check(lib().zkhip_synth_fill_device(self.h, C.c_void_p(t.data_ptr()), C.c_size_t(n), C.c_uint64(seed), C.c_uint64(first)))
+        return t
+
+    # ---- best_fft ----
+    def best_fft(self, a, omega, log_n):
+        """halo2curves fft::best_fft(a, omega, log_n) on a host array (returns the transformed copy)."""
+        a = _u64(a).copy().reshape(1 << log_n, 4)
+        _check(lib().zkhip_fft(self.h, _p(a), _p(_u64(omega)), C.c_uint32(log_n)))
+        return a
+
+    def fft_batch_device(self, polys, omega, log_n):
+        ptrs = (C.c_void_p * len(polys))(*[p.data_ptr() for p in polys])
+        _check(lib().zkhip_fft_batch_device(self.h, ptrs, C.c_size_t(len(polys)), _p(_u64(omega)), C.c_uint32(log_n)))
+
+
+def _ptr_array(tensors):
+    return (C.c_void_p * max(1, len(tensors)))(*[t.data_ptr() for t in tensors])
+
+
+class ParamsKZG:
+    """ParamsKZG<Bn256> restricted to what the prover's commitments use: g and g_lagrange."""
+
+    def __init__(self, ctx, k, g=None, g_lagrange=None):
+        self.ctx, self.k, self.n = ctx, k, 1 << k
+        self.g, self.g_lagrange = g, g_lagrange
+
+    @classmethod
+    def setup(cls, ctx, k, s):
+        """ParamsKZG::setup(k, rng) with the trapdoor given (Montgomery Fr limbs)."""
+        g, gl = C.c_void_p(), C.c_void_p()
+        _check(lib().zkhip_kzg_setup(ctx.h, C.c_uint32(k), _p(_u64(s)), C.byref(g), C.byref(gl)))
+        return cls(ctx, k, g, gl)
+
+    @classmethod
+    def from_bases(cls, ctx, k, g_xy=None, g_lagrange_xy=None):
+        out = []
+        for b in (g_xy, g_lagrange_xy):
+            if b is None:
+                out.append(None)
+                continue
+            b = _u64(b).reshape(-1, 8)
+            h = C.c_void_p()
+            _check(lib().zkhip_srs_load(ctx.h, _p(b), C.c_size_t(b.shape[0]), C.byref(h)))
+            out.append(h)
+        return cls(ctx, k, out[0], out[1])
+
+    def read_bases(self, which, first, count):
+        out = np.zeros((count, 8), dtype=np.uint64)
+        _check(lib().zkhip_srs_read(self.ctx.h, which, C.c_size_t(first), C.c_size_t(count), _p(out)))
+        return out
+
+    def _msm_host(self, srs, scalars):
+        scalars = _u64(scalars).reshape(-1, 4)
+        out = np.zeros(12, dtype=np.uint64)
+        _check(lib().zkhip_msm_g1(self.ctx.h, srs, _p(scalars), C.c_size_t(scalars.shape[0]), _p(out)))
+        return out
+
+    def commit(self, poly):
+        """ParamsKZG::commit(poly): MSM over g[..len] -> G1 (Jacobian, 12 u64)."""
+        return self._msm_host(self.g, poly)
+
+    def commit_lagrange(self, poly):
+        return self._msm_host(self.g_lagrange, poly)
+
+    def commit_batch_device(self, cols, lagrange=False, n=None):
+        """ncols device columns -> (ncols, 12) device tensor of Jacobian sums (asynchronous)."""
+        srs = self.g_lagrange if lagrange else self.g
+        n = n if n is not None else cols[0].shape[0]
+        out = self.ctx.empty(len(cols), 12)
+        _check(lib().zkhip_msm_g1_batch_device(self.ctx.h, srs, _ptr_array(cols), C.c_size_t(len(cols)), C.c_size_t(n),
+                                               C.c_void_p(out.data_ptr())))
+        return out
+
+    def free(self):
+        for h in (self.g, self.g_lagrange):
+            if h is not None:
+                lib().zkhip_srs_free(self.ctx.h, h)
+        self.g = self.g_lagrange = None
+
+
+def best_multiexp(ctx, coeffs, bases_xy):
+    """halo2curves msm::best_multiexp(coeffs, bases) for ad-hoc bases (loads them, then one MSM)."""
+    p = ParamsKZG.from_bases(ctx, 0, g_xy=bases_xy)
+    try:
+        return p.commit(coeffs)
+    finally:
+        p.free()
+
+
+def g1_to_affine(xyz):
+    out = np.zeros(8, dtype=np.uint64)
+    lib().zkhip_g1_to_affine(_p(_u64(xyz)), _p(out))
+    return out
+
+
+def g1_to_bytes(xy):
+    out = (C.c_uint8 * 32)()
+    lib().zkhip_g1_to_bytes(_p(_u64(xy)), out)
+    return bytes(out)
+
+
+class EvaluationDomain:
+    """halo2_proofs::poly::EvaluationDomain::new(j, k)."""
+
+    def __init__(self, ctx, j, k, g_coset=None):
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        _check(lib().zkhip_domain_new(ctx.h, C.c_uint32(j), C.c_uint32(k), _p(_u64(g_coset)) if g_coset is not None else None,
+                                      C.byref(self.h)))
+        self.k = k
+        self.n = 1 << k
+        self.extended_k = lib().zkhip_domain_extended_k(self.h)
+        self.extended_n = 1 << self.extended_k
+        self.quotient_poly_degree = lib().zkhip_domain_quotient_poly_degree(self.h)
+        self.omega, self.extended_omega, self.g_coset = (np.zeros(4, dtype=np.uint64) for _ in range(3))
+        lib().zkhip_domain_constants(self.h, _p(self.omega), _p(self.extended_omega), _p(self.g_coset))
+
+    def free(self):
+        if self.h is not None and self.h.value:
+            lib().zkhip_domain_free(self.ctx.h, self.h)
+            self.h = C.c_void_p()
+
+    # host-array forms (as the reference's Vec<F> callers see them)
+    def lagrange_to_coeff(self, a):
+        a = _u64(a).copy().reshape(self.n, 4)
+        _check(lib().zkhip_lagrange_to_coeff(self.ctx.h, self.h, _p(a)))
+        return a
+
+    def coeff_to_extended(self, coeffs):
+        coeffs = _u64(coeffs).reshape(-1, 4)
+        out = np.zeros((self.extended_n, 4), dtype=np.uint64)
+        _check(lib().zkhip_coeff_to_extended(self.ctx.h, self.h, _p(coeffs), C.c_size_t(coeffs.shape[0]), _p(out)))
+        return out
+
+    def extended_to_coeff(self, a, full=False):
+        a = _u64(a).copy().reshape(self.extended_n, 4)
+        _check(lib().zkhip_extended_to_coeff(self.ctx.h, self.h, _p(a)))
+        return a if full else a[: self.n * self.quotient_poly_degree]
+
+    # device forms (asynchronous)
+    def lagrange_to_coeff_device(self, polys):
+        _check(lib().zkhip_lagrange_to_coeff_device(self.ctx.h, self.h, _ptr_array(polys), C.c_size_t(len(polys))))
+
+    def coeff_to_lagrange_device(self, polys):
+        _check(lib().zkhip_coeff_to_lagrange_device(self.ctx.h, self.h, _ptr_array(polys), C.c_size_t(len(polys))))
+
+    def coeff_to_extended_device(self, polys, n_in=None):
+        outs = [self.ctx.empty(self.extended_n) for _ in polys]
+        n_in = n_in if n_in is not None else polys[0].shape[0]
+        _check(lib().zkhip_coeff_to_extended_device(self.ctx.h, self.h, _ptr_array(polys), C.c_size_t(n_in), _ptr_array(outs),
+                                                    C.c_size_t(len(polys))))
+        return outs
+
+    def extended_to_coeff_device(self, polys):
+        _check(lib().zkhip_extended_to_coeff_device(self.ctx.h, self.h, _ptr_array(polys), C.c_size_t(len(polys))))
+
+    def divide_by_vanishing_poly_device(self, a):
+        _check(lib().zkhip_divide_by_vanishing_device(self.ctx.h, self.h, C.c_void_p(a.data_ptr())))
+
+
+class EvalhPack:
+    """Marshals evaluate_h inputs (device column tensors + host graphs) into zk_evalh_args."""
+
+    def __init__(self):
+        self.keep = []
+
+    def _ptrs(self, tensors):
+        arr = _ptr_array(tensors)
+        self.keep += [arr, tensors]
+        return C.cast(arr, C.c_void_p)
+
+    def graph(self, g, to_mont):
+        consts = _u64(to_mont(g.constants)).reshape(-1, 4)
+        rots = np.array(g.rotations if g.rotations else [0], dtype=np.int32)
+        code = np.array(g.code_words(), dtype=np.int32)
+        self.keep += [consts, rots, code]
+        return ZkGraph(consts.ctypes.data, rots.ctypes.data, code.ctypes.data, len(g.constants), len(g.rotations), len(code),
+                       len(g.calculations), g.num_intermediates)
+
+    def build(self, *, k, extended_k, cs_degree, blinding_factors, extended_omega, g_coset, delta, beta, gamma, theta, y,
+              fixed, advice, instance, challenges, l0, l_last, l_active, gates_graph, perm_columns, sigma, perm_z,
+              lookup_graphs, lookup_z, lookup_a, lookup_s, to_mont):
+        a = ZkEvalhArgs()
+        a.k, a.extended_k, a.cs_degree, a.blinding_factors = k, extended_k, cs_degree, blinding_factors
+        for name, v in (("extended_omega", extended_omega), ("g_coset", g_coset), ("delta", delta), ("beta", beta),
+                        ("gamma", gamma), ("theta", theta), ("y", y)):
+            setattr(a, name, (C.c_uint64 * 4)(*[int(t) for t in v]))
+        a.n_fixed, a.n_advice, a.n_instance = len(fixed), len(advice), len(instance)
+        ch = _u64(challenges).reshape(-1, 4) if len(challenges) else np.zeros((1, 4), dtype=np.uint64)
+        self.keep.append(ch)
+        a.n_challenges = len(challenges)
+        a.challenges = ch.ctypes.data
+        a.fixed_cosets, a.advice_cosets, a.instance_cosets = self._ptrs(fixed), self._ptrs(advice), self._ptrs(instance)
+        a.l0 = l0.data_ptr() if l0 is not None else None
+        a.l_last = l_last.data_ptr() if l_last is not None else None
+        a.l_active_row = l_active.data_ptr() if l_active is not None else None
+        self.keep += [l0, l_last, l_active]
+        a.custom_gates = self.graph(gates_graph, to_mont)
+        tmap = {"advice": 0, "fixed": 1, "instance": 2}
+        ptype = np.array([tmap[t] for t, _ in perm_columns] or [0], dtype=np.uint32)
+        pidx = np.array([i for _, i in perm_columns] or [0], dtype=np.uint32)
+        self.keep += [ptype, pidx]
+        a.n_perm_columns, a.n_perm_sets = len(perm_columns), len(perm_z)
+        a.perm_column_type, a.perm_column_index = ptype.ctypes.data, pidx.ctypes.data
+        a.perm_sigma_cosets, a.perm_product_cosets = self._ptrs(sigma), self._ptrs(perm_z)
+        a.n_lookups = len(lookup_graphs)
+        garr = (ZkGraph * max(1, len(lookup_graphs)))(*[self.graph(g, to_mont) for g in lookup_graphs])
+        self.keep.append(garr)
+        a.lookup_graphs = C.cast(garr, C.c_void_p)
+        a.lookup_product_cosets, a.lookup_input_cosets, a.lookup_table_cosets = (self._ptrs(lookup_z), self._ptrs(lookup_a),
+                                                                                   self._ptrs(lookup_s))
+        self.args = a
+        return a
+
+
+def evaluate_h(ctx, pack, extended_n):
+    """Evaluator::evaluate_h on cosets already on the device -> (extended_n, 4) device tensor."""
+    out = ctx.empty(extended_n)
+    _check(lib().zkhip_evaluate_h_device(ctx.h, C.byref(pack.args), C.c_void_p(out.data_ptr())))
+    return out

@@ -1,0 +1,165 @@
+/* zkhip.h — C ABI of libzkhip.so: the MI355X (gfx950) backend for the arithmetic underneath
+ * halo2_proofs::plonk::create_proof (BN254 G1 MSM, Fr NTT, quotient sweep).
+ *
+ * The reference reaches this arithmetic through generic Rust calls with no FFI seam of its own:
+ *   gen_snark_shplonk      /root/reference/src/helpers.rs:233,299; src/bin/cli.rs:320,343,369,462
+ *   gen_evm_proof_shplonk  /root/reference/src/bin/cli.rs:519
+ * -> halo2_proofs::plonk::create_proof (crate pinned at Cargo.lock:1320-1322)
+ * -> halo2curves msm::best_multiexp / fft::best_fft (crate pinned at Cargo.lock:1359-1361).
+ * Each entry point below names the upstream function whose body a [patch]ed crate would replace
+ * with a call to it ([UPSTREAM-RECALL]: upstream sources are not on this machine); the Rust-side
+ * bindings are in INTEGRATION.md.
+ *
+ * Conventions
+ *  - Field elements: 4 little-endian u64 limbs, Montgomery form (R = 2^256) = the in-memory layout
+ *    of halo2curves bn256::{Fr, Fq}.  G1Affine = {x, y} (8 u64, identity all-zero).  G1 = Jacobian
+ *    {x, y, z} (12 u64, identity z = 0).
+ *  - Every function returns 0 on success or a negative ZKHIP_E* code; zkhip_last_error() gives the
+ *    message for the calling thread.  Nothing throws across the boundary.
+ *  - Buffers are caller-owned.  "_device" entry points take device addresses (hipMalloc or
+ *    torch.Tensor.data_ptr()) and are asynchronous on the context's stream; the others take host
+ *    pointers and return when the result is in host memory.
+ *  - One context per process and GPU; calls on one context must not race.
+ */
+#ifndef ZKHIP_H
+#define ZKHIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZKHIP_OK 0
+#define ZKHIP_EINVAL (-1)   /* bad argument */
+#define ZKHIP_EHIP (-2)     /* HIP runtime / launch failure */
+#define ZKHIP_ENOMEM (-3)
+#define ZKHIP_EPROGRAM (-4) /* malformed evaluation graph */
+#define ZKHIP_ENODEVICE (-5)
+
+typedef struct zkhip_ctx zkhip_ctx;
+typedef struct zkhip_srs zkhip_srs;
+typedef struct zkhip_domain zkhip_domain;
+
+/* ---- context ---- */
+int  zkhip_init(zkhip_ctx** out, int device_id);
+void zkhip_destroy(zkhip_ctx* ctx);
+const char* zkhip_last_error(void);
+/* Launch on an existing HIP stream (e.g. torch.cuda.current_stream().cuda_stream); NULL = the
+ * context's own stream. */
+int  zkhip_set_stream(zkhip_ctx* ctx, void* hip_stream);
+int  zkhip_synchronize(zkhip_ctx* ctx);
+int  zkhip_malloc(zkhip_ctx* ctx, size_t bytes, void** dptr);
+int  zkhip_free(zkhip_ctx* ctx, void* dptr);
+int  zkhip_memcpy_h2d(zkhip_ctx* ctx, void* dst, const void* src, size_t bytes);
+int  zkhip_memcpy_d2h(zkhip_ctx* ctx, void* dst, const void* src, size_t bytes);
+/* HIP-event pair on the context's stream, for timing the kernels where they actually run. */
+int  zkhip_timer_start(zkhip_ctx* ctx);
+int  zkhip_timer_stop_ms(zkhip_ctx* ctx, float* ms);   /* synchronises */
+
+/* ---- SRS: ParamsKZG::{g, g_lagrange} (halo2_proofs src/poly/kzg/commitment.rs) ----
+ * Uploaded once; the device keeps, per base, its W window multiples 2^(c*w) * P_i in affine form
+ * so that an MSM is a single bucket pass with no doublings (sized for 288 GB of HBM). */
+int  zkhip_srs_load(zkhip_ctx* ctx, const uint64_t* bases_xy, size_t n, zkhip_srs** out);
+int  zkhip_srs_load_device(zkhip_ctx* ctx, const void* d_bases_xy, size_t n, zkhip_srs** out);
+void zkhip_srs_free(zkhip_ctx* ctx, zkhip_srs* srs);
+size_t zkhip_srs_len(const zkhip_srs* srs);
+/* ParamsKZG::setup(k, rng) restricted to G1: bases[i] = [s^i] G (monomial) and [l_i(s)] G
+ * (Lagrange), generated on the device.  s is a Montgomery Fr.  Either output may be NULL. */
+int  zkhip_kzg_setup(zkhip_ctx* ctx, uint32_t k, const uint64_t s[4], zkhip_srs** g, zkhip_srs** g_lagrange);
+/* Copies base points [first, first+count) back (affine, Montgomery) — for tests. */
+int  zkhip_srs_read(zkhip_ctx* ctx, const zkhip_srs* srs, size_t first, size_t count, uint64_t* out_xy);
+
+/* ---- MSM: halo2curves msm::best_multiexp(coeffs, bases) -> G1, as called by
+ * ParamsKZG::commit / commit_lagrange with bases = srs[..n] ----
+ * out_xyz is the sum in Jacobian form with z = 1 (or the identity (0,1,0)). */
+int  zkhip_msm_g1(zkhip_ctx* ctx, const zkhip_srs* srs, const uint64_t* scalars, size_t n, uint64_t out_xyz[12]);
+/* ncols independent columns in one pass; d_scalar_cols is a HOST array of device pointers,
+ * d_out_xyz receives ncols x 12 u64 (device).  Asynchronous. */
+int  zkhip_msm_g1_batch_device(zkhip_ctx* ctx, const zkhip_srs* srs, const void* const* d_scalar_cols,
+                               size_t ncols, size_t n, void* d_out_xyz);
+/* G1::to_affine on the host for results fetched from the device (12 u64 -> 8 u64). */
+void zkhip_g1_to_affine(const uint64_t xyz[12], uint64_t out_xy[8]);
+/* G1Affine::to_bytes (32-byte compressed) */
+void zkhip_g1_to_bytes(const uint64_t xy[8], uint8_t out[32]);
+
+/* ---- NTT: halo2curves fft::best_fft(a, omega, log_n): in place, natural order in and out ---- */
+int  zkhip_fft(zkhip_ctx* ctx, uint64_t* a, const uint64_t omega[4], uint32_t log_n);
+/* batch of npolys arrays; d_polys is a HOST array of device pointers.  Asynchronous. */
+int  zkhip_fft_batch_device(zkhip_ctx* ctx, void* const* d_polys, size_t npolys, const uint64_t omega[4], uint32_t log_n);
+
+/* ---- EvaluationDomain (halo2_proofs src/poly/domain.rs) ----
+ * zkhip_domain_new(j, k) = EvaluationDomain::new(j, k); g_coset NULL = Fr::ZETA. */
+int  zkhip_domain_new(zkhip_ctx* ctx, uint32_t j, uint32_t k, const uint64_t g_coset[4], zkhip_domain** out);
+void zkhip_domain_free(zkhip_ctx* ctx, zkhip_domain* dom);
+uint32_t zkhip_domain_k(const zkhip_domain* dom);
+uint32_t zkhip_domain_extended_k(const zkhip_domain* dom);
+uint32_t zkhip_domain_quotient_poly_degree(const zkhip_domain* dom);
+void zkhip_domain_constants(const zkhip_domain* dom, uint64_t omega[4], uint64_t extended_omega[4], uint64_t g_coset[4]);
+/* lagrange_to_coeff / coeff_to_lagrange: npolys arrays of n, in place. */
+int  zkhip_lagrange_to_coeff_device(zkhip_ctx* ctx, const zkhip_domain* dom, void* const* d_polys, size_t npolys);
+int  zkhip_coeff_to_lagrange_device(zkhip_ctx* ctx, const zkhip_domain* dom, void* const* d_polys, size_t npolys);
+/* coeff_to_extended: in[i] has n_in coefficients (zero-extended), out[i] has extended_n values. */
+int  zkhip_coeff_to_extended_device(zkhip_ctx* ctx, const zkhip_domain* dom, const void* const* d_in, size_t n_in,
+                                    void* const* d_out, size_t npolys);
+/* extended_to_coeff: extended_n values in place; the first n*quotient_poly_degree are the result. */
+int  zkhip_extended_to_coeff_device(zkhip_ctx* ctx, const zkhip_domain* dom, void* const* d_polys, size_t npolys);
+/* divide_by_vanishing_poly: a[i] *= t_evaluations[i mod 2^(extended_k-k)], in place. */
+int  zkhip_divide_by_vanishing_device(zkhip_ctx* ctx, const zkhip_domain* dom, void* d_a);
+/* Host-pointer forms (upload, transform, download). */
+int  zkhip_lagrange_to_coeff(zkhip_ctx* ctx, const zkhip_domain* dom, uint64_t* a);
+int  zkhip_coeff_to_extended(zkhip_ctx* ctx, const zkhip_domain* dom, const uint64_t* coeffs, size_t n_in, uint64_t* out);
+int  zkhip_extended_to_coeff(zkhip_ctx* ctx, const zkhip_domain* dom, uint64_t* a);
+
+/* ---- quotient sweep: halo2_proofs plonk::evaluation::Evaluator::evaluate_h ----
+ * Same flattened form the reference's Evaluator holds after keygen.
+ * ValueSource = 3 x int32 {kind, a, b}: */
+enum { ZK_VS_CONSTANT = 0, ZK_VS_INTERMEDIATE = 1, ZK_VS_FIXED = 2, ZK_VS_ADVICE = 3, ZK_VS_INSTANCE = 4,
+       ZK_VS_CHALLENGE = 5, ZK_VS_BETA = 6, ZK_VS_GAMMA = 7, ZK_VS_THETA = 8, ZK_VS_Y = 9,
+       ZK_VS_PREVIOUS = 10 };
+/* Calculation record in the int32 code stream: {op, target, nsrc, nsrc x ValueSource}.
+ * ADD/SUB/MUL: (a, b); SQUARE/DOUBLE/NEGATE/STORE: (a); HORNER: (start, factor, parts...). */
+enum { ZK_OP_ADD = 0, ZK_OP_SUB = 1, ZK_OP_MUL = 2, ZK_OP_SQUARE = 3, ZK_OP_DOUBLE = 4, ZK_OP_NEGATE = 5,
+       ZK_OP_HORNER = 6, ZK_OP_STORE = 7 };
+
+typedef struct {
+    const uint64_t* constants;   /* HOST: n_constants x 4, Montgomery */
+    const int32_t*  rotations;   /* HOST: n_rotations */
+    const int32_t*  code;        /* HOST: n_code_words int32 */
+    uint32_t n_constants, n_rotations, n_code_words, n_calculations, n_intermediates;
+} zk_graph;
+
+typedef struct {
+    uint32_t k, extended_k, cs_degree, blinding_factors;
+    uint64_t extended_omega[4], g_coset[4], delta[4];
+    uint64_t beta[4], gamma[4], theta[4], y[4];
+    uint32_t n_fixed, n_advice, n_instance, n_challenges;
+    const uint64_t* const* fixed_cosets;     /* HOST arrays of DEVICE pointers, each extended_n x 4 */
+    const uint64_t* const* advice_cosets;
+    const uint64_t* const* instance_cosets;
+    const uint64_t* challenges;              /* HOST: n_challenges x 4 */
+    const uint64_t* l0; const uint64_t* l_last; const uint64_t* l_active_row;   /* DEVICE */
+    zk_graph custom_gates;
+    uint32_t n_perm_columns, n_perm_sets;
+    const uint32_t* perm_column_type;        /* HOST: 0 advice, 1 fixed, 2 instance */
+    const uint32_t* perm_column_index;       /* HOST */
+    const uint64_t* const* perm_sigma_cosets;    /* HOST array of DEVICE pointers, n_perm_columns */
+    const uint64_t* const* perm_product_cosets;  /* n_perm_sets */
+    uint32_t n_lookups, _pad;
+    const zk_graph* lookup_graphs;                   /* HOST, n_lookups */
+    const uint64_t* const* lookup_product_cosets;    /* HOST arrays of DEVICE pointers */
+    const uint64_t* const* lookup_input_cosets;      /* permuted input A' */
+    const uint64_t* const* lookup_table_cosets;      /* permuted table S' */
+} zk_evalh_args;
+
+/* d_out: extended_n x 4 u64 (device).  Asynchronous. */
+int  zkhip_evaluate_h_device(zkhip_ctx* ctx, const zk_evalh_args* args, void* d_out);
+
+/* ---- synthetic tables (bench / tests): element i of a column = raw253(seed, i) taken as the
+ * Montgomery limbs (oracle/pyref.py synth_raw253) ---- */
+int  zkhip_synth_fill_device(zkhip_ctx* ctx, void* d_out, size_t n, uint64_t seed, uint64_t first_index);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

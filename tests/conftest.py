@@ -20,3 +20,14 @@ def oracle():
     zo.build()
     zo.lib()
     return zo
+
+
+@pytest.fixture(scope="session")
+def zk():
+    """The product binding + one GPU context (GPU tests only; fails loudly without the HIP library)."""
+    import halo2_zkcert_amd.ffi as ffi
+
+    ffi.lib()
+    ctx = ffi.Context(0)
+    yield ffi, ctx
+    ctx.close()

@@ -1,0 +1,152 @@
+"""GPU parity: MSM / KZG commitments through the C ABI vs the golden vectors and the CPU oracle."""
+import numpy as np
+import pytest
+
+from util import H, load
+
+pytestmark = pytest.mark.gpu
+
+
+def aff(zk, jac):
+    ffi, _ = zk
+    return ffi.g1_to_affine(jac)
+
+
+def test_golden_cases(zk, oracle):
+    ffi, ctx = zk
+    zo = oracle
+    for c in load("msm.json")["cases"]:
+        sc = zo.fr_arr_from_ints([H(s) for s in c["scalars"]])
+        pts = zo.affine_from_ints([(H(x), H(y)) for x, y in c["points"]])
+        res = aff(zk, ffi.best_multiexp(ctx, sc, pts))
+        assert zo.affine_to_ints(res)[0] == (H(c["result"][0]), H(c["result"][1])), c["name"]
+
+
+def test_golden_seeded_1024(zk, oracle):
+    ffi, ctx = zk
+    zo = oracle
+    s = load("msm.json")["seeded"]
+    sc = zo.synth_raw253(s["seed_scalars"], s["n"])
+    pts = zo.fixed_base_mul(zo.fr_arr_from_ints(zo.arr_to_ints(zo.synth_raw253(s["seed_points"], s["n"]))), threads=8)
+    res = aff(zk, ffi.best_multiexp(ctx, sc, pts))
+    assert zo.affine_to_ints(res)[0] == (H(s["result"][0]), H(s["result"][1]))
+    # the device generator agrees with the spec'd PRNG
+    t = ctx.synth_fill(s["n"], s["seed_scalars"])
+    assert (ctx.to_host(t) == sc).all()
+
+
+@pytest.fixture(scope="module")
+def params12(zk, oracle):
+    ffi, ctx = zk
+    s = oracle.fr_from_int(0xC0FFEE1234567)
+    p = ffi.ParamsKZG.setup(ctx, 12, s)
+    yield p, s
+    p.free()
+
+
+def test_setup_matches_oracle(zk, oracle, params12):
+    ffi, ctx = zk
+    zo = oracle
+    p, s = params12
+    mono, lag = zo.kzg_setup_scalars(12, s)
+    idx = [0, 1, 2, 77, 4095]
+    g = p.read_bases(p.g, 0, 4096)
+    gl = p.read_bases(p.g_lagrange, 0, 4096)
+    exp_g = zo.fixed_base_mul(mono[idx], 2)
+    exp_gl = zo.fixed_base_mul(lag[idx], 2)
+    assert (g[idx] == exp_g).all() and (gl[idx] == exp_gl).all()
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 1000, 4096])
+def test_commit_vs_oracle_ragged(zk, oracle, params12, n):
+    ffi, ctx = zk
+    zo = oracle
+    p, _ = params12
+    bases = p.read_bases(p.g, 0, n)
+    sc = zo.synth_raw253(1000 + n, n)
+    exp = zo.g1_to_affine(zo.best_multiexp(sc, bases, 8))
+    got = aff(zk, p.commit(sc))
+    assert (got == exp).all()
+
+
+def test_commit_empty_and_zero(zk, params12):
+    ffi, ctx = zk
+    p, _ = params12
+    assert (aff(zk, p.commit(np.zeros((0, 4), dtype=np.uint64))) == 0).all()
+    assert (aff(zk, p.commit(np.zeros((300, 4), dtype=np.uint64))) == 0).all()
+    with pytest.raises(ffi.ZkhipError):
+        p.commit(np.zeros((4097, 4), dtype=np.uint64))     # more scalars than bases
+
+
+@pytest.mark.parametrize("kind", ["bool", "bytes", "same", "sparse", "rminus1"])
+def test_commit_skewed_scalars(zk, oracle, params12, kind):
+    """Witness-like distributions: every scalar in one bucket, tiny values, mostly zero."""
+    ffi, ctx = zk
+    zo = oracle
+    p, _ = params12
+    n = 4096
+    rng = np.random.default_rng(7)
+    if kind == "bool":
+        vals = [int(v) for v in rng.integers(0, 2, n)]
+    elif kind == "bytes":
+        vals = [int(v) for v in rng.integers(0, 256, n)]
+    elif kind == "same":
+        vals = [0x1234567] * n
+    elif kind == "sparse":
+        vals = [0] * n
+        for i in range(0, n, 97):
+            vals[i] = int(rng.integers(1, 1 << 62))
+    else:
+        R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+        vals = [R - 1 - (i % 3) for i in range(n)]
+    sc = zo.fr_arr_from_ints(vals)
+    bases = p.read_bases(p.g, 0, n)
+    exp = zo.g1_to_affine(zo.best_multiexp(sc, bases, 8))
+    assert (aff(zk, p.commit(sc)) == exp).all()
+
+
+def test_commit_batch_device(zk, oracle, params12):
+    ffi, ctx = zk
+    zo = oracle
+    p, _ = params12
+    n = 4096
+    cols_h = [zo.synth_raw253(500 + j, n) for j in range(3)]
+    cols_h.append(np.zeros((n, 4), dtype=np.uint64))
+    cols = [ctx.to_device(c) for c in cols_h]
+    out = ctx.to_host(p.commit_batch_device(cols, lagrange=True))
+    bases = p.read_bases(p.g_lagrange, 0, n)
+    for j, c in enumerate(cols_h):
+        exp = zo.g1_to_affine(zo.best_multiexp(c, bases, 8))
+        assert (ffi.g1_to_affine(out[j]) == exp).all()
+
+
+def test_commit_lagrange_equals_commit_coeff_equals_trapdoor(zk, oracle, params12):
+    """commit_lagrange(evals) == commit(iNTT(evals)) == [p(s)] G — ties MSM, NTT and the SRS together."""
+    ffi, ctx = zk
+    zo = oracle
+    p, s = params12
+    dom = ffi.EvaluationDomain(ctx, 3, 12)
+    evals = zo.synth_raw253(77, 4096)
+    coeffs = dom.lagrange_to_coeff(evals)
+    c1 = aff(zk, p.commit(coeffs))
+    c2 = aff(zk, p.commit_lagrange(evals))
+    c3 = zo.g1_mul_gen(zo.eval_polynomial(coeffs, s))
+    assert (c1 == c2).all() and (c1 == c3).all()
+    assert ffi.g1_to_bytes(c1) == zo.g1_to_bytes(c3)
+    dom.free()
+
+
+@pytest.mark.parametrize("k", [17])
+def test_full_size_trapdoor_property(zk, oracle, k):
+    """BASELINE config size (2^17 points): MSM(coeffs, SRS) == [p(s)] G with p(s) by Horner on the host."""
+    ffi, ctx = zk
+    zo = oracle
+    s = zo.fr_from_int(0xDEADBEEF12345)
+    p = ffi.ParamsKZG.setup(ctx, k, s)
+    n = 1 << k
+    col = ctx.synth_fill(n, 0xC0FFEE17)
+    out = ctx.to_host(p.commit_batch_device([col]))
+    coeffs = ctx.to_host(col)
+    exp = zo.g1_mul_gen(zo.eval_polynomial(coeffs, s))
+    assert (ffi.g1_to_affine(out[0]) == exp).all()
+    p.free()
