@@ -78,7 +78,7 @@ void zkhip_destroy(zkhip_ctx* c) {
 
 int zkhip_set_stream(zkhip_ctx* c, void* s) {
     if (!c) { set_error("null ctx"); return ZKHIP_EINVAL; }
-    c->stream = s ? (hipStream_t)s : c->own_stream;
+    c->stream = (s == ZKHIP_OWN_STREAM) ? c->own_stream : (hipStream_t)s;
     return ZKHIP_OK;
 }
 int zkhip_synchronize(zkhip_ctx* c) {

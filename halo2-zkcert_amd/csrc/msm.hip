@@ -139,7 +139,7 @@ static int srs_build(zkhip_ctx* ctx, const void* d_bases, size_t n, zkhip_srs** 
 // Signed digits d_w in [-(2^(c-1)-1), 2^(c-1)], sum d_w 2^(c w) = scalar.  W*c >= 255 so the last
 // carry is zero for every canonical scalar < r < 2^254.
 template <bool SCATTER>
-__global__ void k_digits(const uint32_t* const* scalar_cols, size_t n, uint32_t c, uint32_t W, uint32_t B,
+__global__ void k_digits(const uint32_t* const* scalar_cols, size_t n, size_t srs_n, uint32_t c, uint32_t W, uint32_t B,
                          uint32_t* cnt_all, const uint32_t* off_all, uint32_t* cursor_all, uint32_t* entries_all,
                          size_t items) {
     __shared__ uint32_t sl[256][9];
@@ -167,7 +167,7 @@ __global__ void k_digits(const uint32_t* const* scalar_cols, size_t n, uint32_t 
                 atomicAdd(&cnt[mag - 1], 1u);
             } else {
                 uint32_t pos = off[mag - 1] + atomicAdd(&cursor[mag - 1], 1u);
-                entries[pos] = (uint32_t)(w * n + i) | (neg << 31);
+                entries[pos] = (uint32_t)(w * srs_n + i) | (neg << 31);
             }
         }
     }
@@ -350,13 +350,13 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* srs, const void* const* d_co
     ZK_HIP(hipMemcpyAsync(d_colptrs, d_cols_host, ncols * sizeof(void*), hipMemcpyHostToDevice, st));
     ZK_HIP(hipMemsetAsync(d_cnt, 0, ncols * B * 4 * 2, st));
     dim3 gn(div_up(n, 256), (unsigned)ncols);
-    hipLaunchKernelGGL(k_digits<false>, gn, dim3(256), 0, st, (const uint32_t* const*)d_colptrs, n, c, W, B, (uint32_t*)d_cnt,
+    hipLaunchKernelGGL(k_digits<false>, gn, dim3(256), 0, st, (const uint32_t* const*)d_colptrs, n, srs->n, c, W, B, (uint32_t*)d_cnt,
                        (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, items);
     hipLaunchKernelGGL(k_plan, dim3((unsigned)ncols), dim3(1024), 0, st, (const uint32_t*)d_cnt, B, 1u, (uint32_t*)d_off,
                        (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)d_max);
     std::vector<uint32_t> h_max(ncols);
     ZK_HIP(hipMemcpyAsync(h_max.data(), d_max, ncols * 4, hipMemcpyDeviceToHost, st));
-    hipLaunchKernelGGL(k_digits<true>, gn, dim3(256), 0, st, (const uint32_t* const*)d_colptrs, n, c, W, B, (uint32_t*)d_cnt,
+    hipLaunchKernelGGL(k_digits<true>, gn, dim3(256), 0, st, (const uint32_t* const*)d_colptrs, n, srs->n, c, W, B, (uint32_t*)d_cnt,
                        (const uint32_t*)d_off, (uint32_t*)d_cursor, (uint32_t*)d_entries, items);
     ZK_LAUNCH_CHECK();
     ZK_HIP(hipStreamSynchronize(st));

@@ -66,6 +66,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ZkhipError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                              "(make -C halo2-zkcert_amd/csrc); there is no CPU fallback")
+        # torch bundles its own libamdhip64 (same SONAME).  Load torch first so that libzkhip.so binds
+        # to that copy: two HIP runtimes in one process do not share devices or streams.
+        import torch  # noqa: F401
+
         L = C.CDLL(LIB_PATH)
         L.zkhip_last_error.restype = C.c_char_p
         L.zkhip_srs_len.restype = C.c_size_t

@@ -45,8 +45,10 @@ typedef struct zkhip_domain zkhip_domain;
 int  zkhip_init(zkhip_ctx** out, int device_id);
 void zkhip_destroy(zkhip_ctx* ctx);
 const char* zkhip_last_error(void);
-/* Launch on an existing HIP stream (e.g. torch.cuda.current_stream().cuda_stream); NULL = the
- * context's own stream. */
+/* Launch on an existing HIP stream (e.g. torch.cuda.current_stream().cuda_stream; NULL is HIP's
+ * default stream, which is also torch's default).  ZKHIP_OWN_STREAM selects the context's own
+ * non-blocking stream, the initial setting. */
+#define ZKHIP_OWN_STREAM ((void*)(intptr_t)-1)
 int  zkhip_set_stream(zkhip_ctx* ctx, void* hip_stream);
 int  zkhip_synchronize(zkhip_ctx* ctx);
 int  zkhip_malloc(zkhip_ctx* ctx, size_t bytes, void** dptr);
@@ -72,10 +74,11 @@ int  zkhip_srs_read(zkhip_ctx* ctx, const zkhip_srs* srs, size_t first, size_t c
 
 /* ---- MSM: halo2curves msm::best_multiexp(coeffs, bases) -> G1, as called by
  * ParamsKZG::commit / commit_lagrange with bases = srs[..n] ----
- * out_xyz is the sum in Jacobian form with z = 1 (or the identity (0,1,0)). */
+ * zkhip_msm_g1: out_xyz is the sum in Jacobian form with z = 1 (or the identity (0,1,0)). */
 int  zkhip_msm_g1(zkhip_ctx* ctx, const zkhip_srs* srs, const uint64_t* scalars, size_t n, uint64_t out_xyz[12]);
 /* ncols independent columns in one pass; d_scalar_cols is a HOST array of device pointers,
- * d_out_xyz receives ncols x 12 u64 (device).  Asynchronous. */
+ * d_out_xyz receives ncols x 12 u64 (device): Jacobian sums, any representative (normalise with
+ * zkhip_g1_to_affine after fetching).  Asynchronous apart from one 4-byte-per-column read-back. */
 int  zkhip_msm_g1_batch_device(zkhip_ctx* ctx, const zkhip_srs* srs, const void* const* d_scalar_cols,
                                size_t ncols, size_t n, void* d_out_xyz);
 /* G1::to_affine on the host for results fetched from the device (12 u64 -> 8 u64). */
