@@ -56,8 +56,24 @@ struct zkhip_ctx {
     };
     std::vector<Twiddle> twiddles;
 
+    // optional per-kernel HIP-event timing on the launch stream (zkhip_profile_*)
+    bool prof_on = false;
+    struct ProfSpan { const char* name; hipEvent_t e0, e1; };
+    std::vector<ProfSpan> prof_spans;
+    std::vector<hipEvent_t> prof_pool;
+    hipEvent_t prof_event();
+    void prof_begin(const char* name);
+    void prof_end();
+
     int get_scratch(const char* name, size_t bytes, void** out);
     int get_twiddles(const uint64_t omega[4], uint32_t log_n, const void** d_table);
+};
+
+// RAII span around one kernel launch (no-op unless profiling is enabled)
+struct ProfScope {
+    zkhip_ctx* c;
+    ProfScope(zkhip_ctx* ctx, const char* name) : c(ctx) { if (c->prof_on) c->prof_begin(name); }
+    ~ProfScope() { if (c->prof_on) c->prof_end(); }
 };
 
 static inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }

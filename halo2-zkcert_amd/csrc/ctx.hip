@@ -37,9 +37,47 @@ int zkhip_ctx::get_scratch(const char* name, size_t bytes, void** out) {
     return ZKHIP_OK;
 }
 
+hipEvent_t zkhip_ctx::prof_event() {
+    if (!prof_pool.empty()) { hipEvent_t e = prof_pool.back(); prof_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+void zkhip_ctx::prof_begin(const char* name) {
+    ProfSpan sp{name, prof_event(), prof_event()};
+    (void)hipEventRecord(sp.e0, stream);
+    prof_spans.push_back(sp);
+}
+void zkhip_ctx::prof_end() { (void)hipEventRecord(prof_spans.back().e1, stream); }
+
 extern "C" {
 
 const char* zkhip_last_error(void) { return g_err; }
+
+int zkhip_profile_enable(zkhip_ctx* c, int on) {
+    if (!c) { set_error("null ctx"); return ZKHIP_EINVAL; }
+    ZK_HIP(hipStreamSynchronize(c->stream));
+    for (auto& sp : c->prof_spans) { c->prof_pool.push_back(sp.e0); c->prof_pool.push_back(sp.e1); }
+    c->prof_spans.clear();
+    c->prof_on = on != 0;
+    return ZKHIP_OK;
+}
+int zkhip_profile_read(zkhip_ctx* c, const char* kernel, double* total_ms, uint64_t* launches) {
+    if (!c || !kernel || !total_ms || !launches) { set_error("zkhip_profile_read: null argument"); return ZKHIP_EINVAL; }
+    ZK_HIP(hipStreamSynchronize(c->stream));
+    double t = 0;
+    uint64_t n = 0;
+    for (auto& sp : c->prof_spans) {
+        if (strcmp(sp.name, kernel) != 0) continue;
+        float ms = 0;
+        ZK_HIP(hipEventElapsedTime(&ms, sp.e0, sp.e1));
+        t += ms;
+        ++n;
+    }
+    *total_ms = t;
+    *launches = n;
+    return ZKHIP_OK;
+}
 
 int zkhip_init(zkhip_ctx** out, int device_id) {
     if (!out) { set_error("zkhip_init: out is NULL"); return ZKHIP_EINVAL; }
@@ -70,6 +108,8 @@ void zkhip_destroy(zkhip_ctx* c) {
         if (kv.second.ptr) (void)hipFree(kv.second.ptr);
     for (auto& t : c->twiddles)
         if (t.d_table) (void)hipFree(t.d_table);
+    for (auto& sp : c->prof_spans) { (void)hipEventDestroy(sp.e0); (void)hipEventDestroy(sp.e1); }
+    for (auto e : c->prof_pool) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -127,6 +167,13 @@ void zkhip_g1_to_affine(const uint64_t xyz[12], uint64_t out_xy[8]) {
     memcpy(&p, xyz, 96);
     g1a a = g1j_to_affine(p);
     memcpy(out_xy, &a, 64);
+}
+void zkhip_g1_add(const uint64_t a[12], const uint64_t b[12], uint64_t out[12]) {
+    g1j p, q;
+    memcpy(&p, a, 96);
+    memcpy(&q, b, 96);
+    g1j r = g1j_add(p, q);
+    memcpy(out, &r, 96);
 }
 void zkhip_g1_to_bytes(const uint64_t xy[8], uint8_t out[32]) {
     g1a a;

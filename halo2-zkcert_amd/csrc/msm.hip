@@ -139,14 +139,14 @@ static int srs_build(zkhip_ctx* ctx, const void* d_bases, size_t n, zkhip_srs** 
 // Signed digits d_w in [-(2^(c-1)-1), 2^(c-1)], sum d_w 2^(c w) = scalar.  W*c >= 255 so the last
 // carry is zero for every canonical scalar < r < 2^254.
 template <bool SCATTER>
-__global__ void k_digits(const uint32_t* const* scalar_cols, size_t n, size_t srs_n, uint32_t c, uint32_t W, uint32_t B,
+__global__ void k_digits(const uint32_t* const* scalar_cols, size_t n, size_t first, size_t srs_n, uint32_t c, uint32_t W, uint32_t B,
                          uint32_t* cnt_all, const uint32_t* off_all, uint32_t* cursor_all, uint32_t* entries_all,
                          size_t items) {
     __shared__ uint32_t sl[256][9];
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     uint32_t col = blockIdx.y;
     if (i >= n) return;
-    fe s = fe_from_mont<Fr>(fe_load(scalar_cols[col] + i * 8));
+    fe s = fe_from_mont<Fr>(fe_load(scalar_cols[col] + (first + i) * 8));
 #pragma unroll
     for (int j = 0; j < 8; ++j) sl[threadIdx.x][j] = s.l[j];
     sl[threadIdx.x][8] = 0;
@@ -167,7 +167,7 @@ __global__ void k_digits(const uint32_t* const* scalar_cols, size_t n, size_t sr
                 atomicAdd(&cnt[mag - 1], 1u);
             } else {
                 uint32_t pos = off[mag - 1] + atomicAdd(&cursor[mag - 1], 1u);
-                entries[pos] = (uint32_t)(w * srs_n + i) | (neg << 31);
+                entries[pos] = (uint32_t)(w * srs_n + first + i) | (neg << 31);
             }
         }
     }
@@ -315,9 +315,10 @@ __global__ void k_set_identity(uint32_t* out_all, uint32_t ncols) {
 }
 
 // ------------------------------------------------------------------ host driver
-static int msm_run(zkhip_ctx* ctx, const zkhip_srs* srs, const void* const* d_cols_host, size_t ncols, size_t n, void* d_out) {
+// columns hold at least first + n scalars; scalar first + i pairs with base first + i.
+static int msm_run(zkhip_ctx* ctx, const zkhip_srs* srs, const void* const* d_cols_host, size_t ncols, size_t first, size_t n, void* d_out) {
     if (!ctx || !srs || !d_cols_host || !d_out) { set_error("zkhip_msm: null argument"); return ZKHIP_EINVAL; }
-    if (n > srs->n) { set_error("zkhip_msm: n = %zu exceeds the %zu bases loaded", n, srs->n); return ZKHIP_EINVAL; }
+    if (first + n > srs->n) { set_error("zkhip_msm: range [%zu, %zu) exceeds the %zu bases loaded", first, first + n, srs->n); return ZKHIP_EINVAL; }
     if (ncols == 0) return ZKHIP_OK;
     hipStream_t st = ctx->stream;
     if (n == 0) {
@@ -350,14 +351,16 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* srs, const void* const* d_co
     ZK_HIP(hipMemcpyAsync(d_colptrs, d_cols_host, ncols * sizeof(void*), hipMemcpyHostToDevice, st));
     ZK_HIP(hipMemsetAsync(d_cnt, 0, ncols * B * 4 * 2, st));
     dim3 gn(div_up(n, 256), (unsigned)ncols);
-    hipLaunchKernelGGL(k_digits<false>, gn, dim3(256), 0, st, (const uint32_t* const*)d_colptrs, n, srs->n, c, W, B, (uint32_t*)d_cnt,
-                       (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, items);
+    { ProfScope ps(ctx, "msm_digits");
+    hipLaunchKernelGGL(k_digits<false>, gn, dim3(256), 0, st, (const uint32_t* const*)d_colptrs, n, first, srs->n, c, W, B, (uint32_t*)d_cnt,
+                       (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, items); }
     hipLaunchKernelGGL(k_plan, dim3((unsigned)ncols), dim3(1024), 0, st, (const uint32_t*)d_cnt, B, 1u, (uint32_t*)d_off,
                        (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)d_max);
     std::vector<uint32_t> h_max(ncols);
     ZK_HIP(hipMemcpyAsync(h_max.data(), d_max, ncols * 4, hipMemcpyDeviceToHost, st));
-    hipLaunchKernelGGL(k_digits<true>, gn, dim3(256), 0, st, (const uint32_t* const*)d_colptrs, n, srs->n, c, W, B, (uint32_t*)d_cnt,
-                       (const uint32_t*)d_off, (uint32_t*)d_cursor, (uint32_t*)d_entries, items);
+    { ProfScope ps(ctx, "msm_digits");
+    hipLaunchKernelGGL(k_digits<true>, gn, dim3(256), 0, st, (const uint32_t* const*)d_colptrs, n, first, srs->n, c, W, B, (uint32_t*)d_cnt,
+                       (const uint32_t*)d_off, (uint32_t*)d_cursor, (uint32_t*)d_entries, items); }
     ZK_LAUNCH_CHECK();
     ZK_HIP(hipStreamSynchronize(st));
     uint32_t maxcnt = 0;
@@ -383,9 +386,10 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* srs, const void* const* d_co
                        (uint32_t*)nullptr);
     size_t bound = items / seg + B + 1;
     if (bound > pstride0) bound = pstride0;
+    { ProfScope ps(ctx, "msm_accum_affine");
     hipLaunchKernelGGL(k_accum_affine, dim3(div_up(bound, 256), (unsigned)ncols), dim3(256), 0, st, (const uint32_t*)srs->d_table,
                        (const uint32_t*)d_entries, items, cur_cnt, cur_off, (const uint32_t*)nxt_off, B, seg, (uint32_t*)d_pA,
-                       pstride0);
+                       pstride0); }
     uint32_t* cur_p = (uint32_t*)d_pA;
     uint32_t* nxt_p = (uint32_t*)d_pB;
     cur_cnt = nxt_cnt; cur_off = nxt_off;
@@ -397,8 +401,9 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* srs, const void* const* d_co
                            (uint32_t*)nullptr);
         size_t nb = bound / seg + B + 1;
         if (nb > pstride0) nb = pstride0;
+        { ProfScope ps(ctx, "msm_accum_jac");
         hipLaunchKernelGGL(k_accum_jac, dim3(div_up(nb, 256), (unsigned)ncols), dim3(256), 0, st, (const uint32_t*)cur_p, pstride0,
-                           cur_cnt, cur_off, (const uint32_t*)nxt_off, B, seg, nxt_p, pstride0);
+                           cur_cnt, cur_off, (const uint32_t*)nxt_off, B, seg, nxt_p, pstride0); }
         bound = nb;
         std::swap(cur_p, nxt_p);
         const uint32_t* tc = cur_cnt; const uint32_t* to = cur_off;
@@ -407,9 +412,10 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* srs, const void* const* d_co
         if (nxt_cnt == (uint32_t*)d_cnt) { nxt_cnt = (uint32_t*)d_cntB; nxt_off = (uint32_t*)d_offB; }
         maxcnt = (maxcnt + seg - 1) / seg;
     }
+    { ProfScope ps(ctx, "msm_tail");
     hipLaunchKernelGGL(k_bucket_chunks, dim3(div_up(nchunks, 256), (unsigned)ncols), dim3(256), 0, st, (const uint32_t*)cur_p, pstride0,
                        cur_cnt, cur_off, B, CH, (uint32_t*)d_chunks, nchunks);
-    hipLaunchKernelGGL(k_final_sum, dim3((unsigned)ncols), dim3(512), 0, st, (const uint32_t*)d_chunks, nchunks, (uint32_t*)d_out);
+    hipLaunchKernelGGL(k_final_sum, dim3((unsigned)ncols), dim3(512), 0, st, (const uint32_t*)d_chunks, nchunks, (uint32_t*)d_out); }
     ZK_LAUNCH_CHECK();
     return ZKHIP_OK;
 }
@@ -444,7 +450,11 @@ int zkhip_srs_read(zkhip_ctx* ctx, const zkhip_srs* s, size_t first, size_t coun
 
 int zkhip_msm_g1_batch_device(zkhip_ctx* ctx, const zkhip_srs* srs, const void* const* d_scalar_cols, size_t ncols, size_t n,
                               void* d_out_xyz) {
-    return msm_run(ctx, srs, d_scalar_cols, ncols, n, d_out_xyz);
+    return msm_run(ctx, srs, d_scalar_cols, ncols, 0, n, d_out_xyz);
+}
+int zkhip_msm_g1_batch_range_device(zkhip_ctx* ctx, const zkhip_srs* srs, const void* const* d_scalar_cols, size_t ncols, size_t first,
+                                    size_t count, void* d_out_xyz) {
+    return msm_run(ctx, srs, d_scalar_cols, ncols, first, count, d_out_xyz);
 }
 
 int zkhip_msm_g1(zkhip_ctx* ctx, const zkhip_srs* srs, const uint64_t* scalars, size_t n, uint64_t out_xyz[12]) {
@@ -454,7 +464,7 @@ int zkhip_msm_g1(zkhip_ctx* ctx, const zkhip_srs* srs, const uint64_t* scalars, 
     ZK_TRY(ctx->get_scratch("msm_host_out", 96, &d_o));
     if (n) ZK_HIP(hipMemcpyAsync(d_s, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
     const void* cols[1] = {d_s};
-    ZK_TRY(msm_run(ctx, srs, cols, 1, n, d_o));
+    ZK_TRY(msm_run(ctx, srs, cols, 1, 0, n, d_o));
     uint64_t jac[12];
     ZK_HIP(hipMemcpyAsync(jac, d_o, 96, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(hipStreamSynchronize(ctx->stream));

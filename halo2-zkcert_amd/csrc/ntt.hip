@@ -235,6 +235,7 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
         scq.use_post = 0;
         uint32_t** out = (q + 2 == np) ? d_tmp : d_dst;
         unsigned blocks = (unsigned)(n >> (s + logT));
+        ProfScope ps(ctx, "ntt_strided");
         hipLaunchKernelGGL(k_ntt_strided, dim3(blocks, (unsigned)npolys), dim3(256), 0, st, (const uint32_t* const*)cur_src,
                            (uint32_t* const*)out, m, s, lo_bits, logT, q == 0 ? n_in : (uint32_t)n, (const uint32_t*)table, scq);
         cur_src = (const uint32_t**)out;
@@ -249,6 +250,7 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
         dg.np = np;
         for (int i = 0; i < 4; ++i) dg.sw[i] = sw[i];
         unsigned blocks = (unsigned)(n >> (s + logT));
+        ProfScope ps(ctx, "ntt_final");
         hipLaunchKernelGGL(k_ntt_final, dim3(blocks, (unsigned)npolys), dim3(256), 0, st, (const uint32_t* const*)cur_src,
                            (uint32_t* const*)d_dst, m, s, logT, np == 1 ? n_in : (uint32_t)n, (const uint32_t*)table, scq, dg);
     }

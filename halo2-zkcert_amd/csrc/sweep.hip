@@ -426,6 +426,7 @@ extern "C" int zkhip_evaluate_h_device(zkhip_ctx* ctx, const zk_evalh_args* A, v
     size_t lds = (size_t)std::max<uint32_t>(L.max_slots, 1) * 8 * 4 * block;
     if (lds > 160 * 1024) { set_error("zkhip_evaluate_h_device: %u live intermediates exceed the LDS budget", L.max_slots); return ZKHIP_EPROGRAM; }
     if (lds > 64 * 1024) ZK_HIP(hipFuncSetAttribute((const void*)k_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ProfScope ps(ctx, "sweep");
     hipLaunchKernelGGL(k_sweep, dim3((unsigned)(isize / block)), dim3(block), lds, st, P);
     ZK_LAUNCH_CHECK();
     return ZKHIP_OK;

@@ -48,8 +48,10 @@ class ZkEvalhArgs(C.Structure):
 SYMBOLS = [
     "zkhip_init", "zkhip_destroy", "zkhip_last_error", "zkhip_set_stream", "zkhip_synchronize", "zkhip_malloc", "zkhip_free",
     "zkhip_memcpy_h2d", "zkhip_memcpy_d2h", "zkhip_timer_start", "zkhip_timer_stop_ms",
+    "zkhip_profile_enable", "zkhip_profile_read",
     "zkhip_srs_load", "zkhip_srs_load_device", "zkhip_srs_free", "zkhip_srs_len", "zkhip_kzg_setup", "zkhip_srs_read",
-    "zkhip_msm_g1", "zkhip_msm_g1_batch_device", "zkhip_g1_to_affine", "zkhip_g1_to_bytes",
+    "zkhip_msm_g1", "zkhip_msm_g1_batch_device", "zkhip_msm_g1_batch_range_device", "zkhip_g1_add", "zkhip_g1_to_affine",
+    "zkhip_g1_to_bytes",
     "zkhip_fft", "zkhip_fft_batch_device",
     "zkhip_domain_new", "zkhip_domain_free", "zkhip_domain_k", "zkhip_domain_extended_k", "zkhip_domain_quotient_poly_degree",
     "zkhip_domain_constants", "zkhip_lagrange_to_coeff_device", "zkhip_coeff_to_lagrange_device",
@@ -144,6 +146,15 @@ class Context:
         _check(lib().zkhip_timer_stop_ms(self.h, C.byref(ms)))
         return ms.value
 
+    def profile_enable(self, on=True):
+        _check(lib().zkhip_profile_enable(self.h, C.c_int(1 if on else 0)))
+
+    def profile_read(self, kernel):
+        """(total_ms, launches) of the named kernel since profile_enable, from HIP events on its stream."""
+        ms, n = C.c_double(), C.c_uint64()
+        _check(lib().zkhip_profile_read(self.h, kernel.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def synth_fill(self, n, seed, first=0):
         t = self.empty(n)
         _check(lib().zkhip_synth_fill_device(self.h, C.c_void_p(t.data_ptr()), C.c_size_t(n), C.c_uint64(seed), C.c_uint64(first)))
@@ -210,13 +221,13 @@ class ParamsKZG:
     def commit_lagrange(self, poly):
         return self._msm_host(self.g_lagrange, poly)
 
-    def commit_batch_device(self, cols, lagrange=False, n=None):
-        """ncols device columns -> (ncols, 12) device tensor of Jacobian sums (asynchronous)."""
+    def commit_batch_device(self, cols, lagrange=False, n=None, first=0):
+        """ncols device columns -> (ncols, 12) device tensor of Jacobian sums over points [first, first+n)."""
         srs = self.g_lagrange if lagrange else self.g
-        n = n if n is not None else cols[0].shape[0]
+        n = n if n is not None else cols[0].shape[0] - first
         out = self.ctx.empty(len(cols), 12)
-        _check(lib().zkhip_msm_g1_batch_device(self.ctx.h, srs, _ptr_array(cols), C.c_size_t(len(cols)), C.c_size_t(n),
-                                               C.c_void_p(out.data_ptr())))
+        _check(lib().zkhip_msm_g1_batch_range_device(self.ctx.h, srs, _ptr_array(cols), C.c_size_t(len(cols)), C.c_size_t(first),
+                                                     C.c_size_t(n), C.c_void_p(out.data_ptr())))
         return out
 
     def free(self):
@@ -238,6 +249,12 @@ def best_multiexp(ctx, coeffs, bases_xy):
 def g1_to_affine(xyz):
     out = np.zeros(8, dtype=np.uint64)
     lib().zkhip_g1_to_affine(_p(_u64(xyz)), _p(out))
+    return out
+
+
+def g1_add(a, b):
+    out = np.zeros(12, dtype=np.uint64)
+    lib().zkhip_g1_add(_p(_u64(a)), _p(_u64(b)), _p(out))
     return out
 
 

@@ -1,0 +1,309 @@
+"""The create_proof-shaped schedule over the hot-path kernels, on synthetic 2^k-row tables.
+
+Mirrors the order of operations of halo2_proofs::plonk::create_proof
+[UPSTREAM-RECALL src/plonk/prover.rs; crate pinned at /root/reference/Cargo.lock:1320-1322; reached
+from gen_snark_shplonk at /root/reference/src/helpers.rs:233,299 and src/bin/cli.rs:320,343,369,462]:
+
+  1 commit advice (A MSMs over g_lagrange)                          -> transcript -> theta
+  2 lookup permuted columns: 2L iNTT_n + 2L MSM_n                   -> transcript -> beta, gamma
+  3 permutation / lookup grand products: (Zp + L) iNTT_n + MSM_n    -> transcript
+  4 vanishing random poly: 1 MSM_n                                  -> transcript -> y
+  5 advice/instance iNTT_n; (A+I+3L+Zp) coset NTT_{e n}; quotient sweep; / (X^n-1); iNTT_{e n};
+    q MSM_n over g                                                  -> transcript -> x
+  6 SHPLONK: 2 MSM_n
+
+What is NOT here ("next" rows): witness synthesis, the lookup permute (sort), the
+grand-product scans, the evaluations at x, SHPLONK's polynomial construction and the real
+Poseidon/Keccak transcript.  Their outputs are replaced by synthetic columns of the right shape and
+the transcript by BLAKE2b over the same commitment bytes, so every Fiat-Shamir host round trip of the
+real prover is still on the critical path.
+
+The schedule is written against a small backend interface so the same code drives the HIP library
+(GpuBackend, here) and, in tests/ and bench.py's cpu_baseline leg only, the CPU oracle.
+"""
+import hashlib
+
+import numpy as np
+
+from . import evaluator as ev
+
+R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+
+
+class CircuitShape:
+    """Column / gate shape of one of the reference's circuits."""
+
+    def __init__(self, name, k, n_basic_advice, n_lookup_advice, n_instance, degree, blinding_factors, seed):
+        self.name, self.k, self.seed = name, k, seed
+        self.n_basic, self.n_lookup = n_basic_advice, n_lookup_advice
+        self.n_advice = n_basic_advice + n_lookup_advice
+        self.n_instance = n_instance
+        # fixed: one selector per basic advice column, one constants column, one lookup table column
+        self.n_fixed = n_basic_advice + 1 + (1 if n_lookup_advice else 0)
+        self.degree, self.blinding_factors = degree, blinding_factors
+        A = lambda c, r: ("advice", c, r)
+        # halo2-lib FlexGateConfig vertical gate on every basic advice column: q * (a + b*c - d)
+        self.gates = [("prod", ("fixed", c, 0), ("sum", ("sum", A(c, 0), ("prod", A(c, 1), A(c, 2))), ("neg", A(c, 3))))
+                      for c in range(n_basic_advice)]
+        # halo2-lib RangeConfig: lookup_advice in the [0, 2^lookup_bits) table column
+        self.lookups = [([A(n_basic_advice + i, 0)], [("fixed", self.n_fixed - 1, 0)]) for i in range(n_lookup_advice)]
+        self.perm_columns = ([("advice", c) for c in range(self.n_advice)] + [("fixed", n_basic_advice)]
+                             + [("instance", i) for i in range(n_instance)])
+        chunk = degree - 2
+        self.n_perm_sets = -(-len(self.perm_columns) // chunk)
+
+    @classmethod
+    def rsa(cls, k=17):
+        """RSA circuit, README row k=17: 3 advice + 1 lookup-advice + 1 fixed(constants) (+ selectors, table)."""
+        basic = {15: 12, 16: 6, 17: 3}.get(k, 3)
+        return cls(f"rsa_k{k}", k, basic, 1, 1, 4, 6, 0xC0FFEE00 + k)
+
+    @classmethod
+    def small(cls, k=8):
+        return cls(f"small_k{k}", k, 2, 1, 1, 4, 6, 0x5EED00 + k)
+
+    def counts(self, dom_extended_k):
+        L, Zp, A, I = len(self.lookups), self.n_perm_sets, self.n_advice, self.n_instance
+        q = self.degree - 1
+        return dict(msm=A + 3 * L + Zp + 1 + q + 2, intt_n=A + I + 3 * L + Zp, ntt_ext=A + I + 3 * L + Zp, intt_ext=1,
+                    sweep_rows=1 << dom_extended_k)
+
+
+def challenge(tag, commitment_bytes):
+    """Stand-in Fiat-Shamir squeeze: BLAKE2b(tag || commitments) reduced into Fr (canonical int)."""
+    h = hashlib.blake2b(tag.encode() + b"".join(commitment_bytes), digest_size=64).digest()
+    return int.from_bytes(h, "little") % R
+
+
+class GpuBackend:
+    """Drives libzkhip.so; columns are (n, 4) int64 torch tensors resident in HBM."""
+
+    def __init__(self, ctx, ffi):
+        self.ctx, self.ffi = ctx, ffi
+
+    def setup(self, k, degree, s_int):
+        self.params = self.ffi.ParamsKZG.setup(self.ctx, k, self.fr(s_int))
+        self.domain = self.ffi.EvaluationDomain(self.ctx, degree, k)
+        return self.domain
+
+    def fr(self, x):
+        """canonical int -> Montgomery limbs (host; uses the library's own host-side arithmetic)"""
+        return fr_from_int_host(x)
+
+    def fr_many(self, xs):
+        return np.stack([fr_from_int_host(x) for x in xs]) if len(xs) else np.zeros((0, 4), dtype=np.uint64)
+
+    def synth(self, n, seed):
+        return self.ctx.synth_fill(n, seed)
+
+    def clone(self, cols):
+        return [c.clone() for c in cols]
+
+    def partial_commit(self, cols, lagrange, first, count):
+        """Jacobian sums over the point range [first, first+count): (ncols, 12) int64 device tensor."""
+        return self.params.commit_batch_device(cols, lagrange=lagrange, n=count, first=first)
+
+    def g1_add(self, a, b):
+        return self.ffi.g1_add(a, b)
+
+    def finish(self, jac_rows):
+        """host (ncols, 12) uint64 -> list of (affine (8,), 32 compressed bytes)"""
+        res = []
+        for j in range(jac_rows.shape[0]):
+            a = self.ffi.g1_to_affine(jac_rows[j])
+            res.append((a, self.ffi.g1_to_bytes(a)))
+        return res
+
+    def commit(self, cols, lagrange):
+        """one host round trip per batch (the Fiat-Shamir sync point)"""
+        if not cols:
+            return []
+        return self.finish(self.ctx.to_host(self.partial_commit(cols, lagrange, 0, cols[0].shape[0])))
+
+    def lagrange_to_coeff(self, cols):
+        self.domain.lagrange_to_coeff_device(cols)
+
+    def coeff_to_extended(self, cols):
+        return self.domain.coeff_to_extended_device(cols)
+
+    def evaluate_h(self, kw):
+        pack = self.ffi.EvalhPack()
+        pack.build(**kw)
+        return self.ffi.evaluate_h(self.ctx, pack, self.domain.extended_n)
+
+    def divide_and_to_coeff(self, h):
+        self.domain.divide_by_vanishing_poly_device(h)
+        self.domain.extended_to_coeff_device([h])
+        return h
+
+    def split(self, h, n, pieces):
+        return [h[i * n:(i + 1) * n] for i in range(pieces)]
+
+    def to_host(self, col):
+        return self.ctx.to_host(col)
+
+    def l_cosets(self, blinding_factors):
+        """l_0, l_last, l_active_row cosets (keygen-time, plonk/keygen.rs) computed with the library's own NTTs."""
+        n, dom = self.domain.n, self.domain
+        one = fr_from_int_host(1)
+
+        def unit(rows):
+            a = np.zeros((n, 4), dtype=np.uint64)
+            for r in rows:
+                a[r] = one
+            t = self.ctx.to_device(a)
+            dom.lagrange_to_coeff_device([t])
+            return dom.coeff_to_extended_device([t])[0]
+
+        l0 = unit([0])
+        l_blind = unit([n - 1 - i for i in range(blinding_factors)])
+        l_last = unit([n - blinding_factors - 1])
+        # l_active = 1 - (l_last + l_blind): evaluate with a one-op sweep so no extra kernel is needed
+        g = ev.GraphEvaluator()
+        s = g.add_calculation(ev.OP_ADD, [(ev.VS_FIXED, 0, g.add_rotation(0)), (ev.VS_FIXED, 1, 0)])
+        g.add_calculation(ev.OP_SUB, [(ev.VS_CONSTANT, 1, 0), s])
+        zero = np.zeros(4, dtype=np.uint64)
+        kw = dict(k=dom.k, extended_k=dom.extended_k, cs_degree=3, blinding_factors=blinding_factors,
+                  extended_omega=dom.extended_omega, g_coset=dom.g_coset, delta=zero, beta=zero, gamma=zero, theta=zero, y=zero,
+                  fixed=[l_last, l_blind], advice=[], instance=[], challenges=[], l0=None, l_last=None, l_active=None,
+                  gates_graph=g, perm_columns=[], sigma=[], perm_z=[], lookup_graphs=[], lookup_z=[], lookup_a=[], lookup_s=[],
+                  to_mont=self.fr_many)
+        l_active = self.evaluate_h(kw)
+        return l0, l_last, l_active
+
+
+class ShardedCommit:
+    """Point-range sharding of every MSM over the ranks of a torch.distributed group:
+    rank r sums points [r n/N, (r+1) n/N) of every column, the N x ncols partial sums (96 B each) are
+    all-gathered as raw bytes and folded locally — RCCL has no curve-point reduction, and the payload is
+    latency-sized.  Everything else is delegated to the wrapped backend unchanged (replicated)."""
+
+    def __init__(self, inner, rank, world, dist):
+        self.inner, self.rank, self.world, self.dist = inner, rank, world, dist
+
+    def __getattr__(self, name):
+        return getattr(self.inner, name)
+
+    def commit(self, cols, lagrange):
+        if not cols:
+            return []
+        import torch
+
+        n = cols[0].shape[0]
+        lo, hi = self.rank * n // self.world, (self.rank + 1) * n // self.world
+        part = self.inner.partial_commit(cols, lagrange, lo, hi - lo)
+        if not torch.is_tensor(part):
+            part = torch.from_numpy(np.ascontiguousarray(part).view(np.int64))
+        outs = [torch.empty_like(part) for _ in range(self.world)]
+        self.dist.all_gather(outs, part)
+        parts = [o.cpu().numpy().view(np.uint64).reshape(len(cols), 12) for o in outs]
+        total = parts[0].copy()
+        for p in parts[1:]:
+            for j in range(len(cols)):
+                total[j] = self.inner.g1_add(total[j], p[j])
+        return self.inner.finish(total)
+
+
+_P_FR = None
+
+
+def fr_from_int_host(x):
+    """canonical int -> Montgomery (x * 2^256 mod r) limbs; plain Python big-int arithmetic."""
+    v = (x % R) * (1 << 256) % R
+    return np.array([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+
+
+ZETA = 0xB3C4D79D41A917585BFC41088D8DAAA78B17EA66B99C90DD
+DELTA = 0x09226B6E22C6F0CA64EC26AAD4C86E715B5F898E5E963F25870E56BBE533E9A2
+
+
+class Prover:
+    """Keygen-shaped setup once, then prove() = one create_proof-shaped pass (the benchmark step)."""
+
+    def __init__(self, backend, shape, srs_trapdoor=0x1D5C0FFEE):
+        self.b, self.shape = backend, shape
+        self.dom = backend.setup(shape.k, shape.degree, srs_trapdoor)
+        self.n = 1 << shape.k
+        sh, b, n = shape, backend, self.n
+        seed = sh.seed * 1000
+        # pk: fixed columns (Lagrange -> coeff -> extended cosets), sigma polys, l cosets
+        fixed = [b.synth(n, seed + 100 + i) for i in range(sh.n_fixed)]
+        b.lagrange_to_coeff(fixed)
+        self.fixed_cosets = b.coeff_to_extended(fixed)
+        sigma = [b.synth(n, seed + 200 + i) for i in range(len(sh.perm_columns))]
+        self.sigma_cosets = b.coeff_to_extended(sigma)
+        self.l0, self.l_last, self.l_active = b.l_cosets(sh.blinding_factors)
+        self.gates_graph = ev.build_custom_gates(sh.gates)
+        self.lookup_graphs = [ev.build_lookup(i, t) for i, t in sh.lookups]
+
+    def witness(self, proof_seed):
+        """Synthetic advice / instance tables in Lagrange form, resident on the device (untimed)."""
+        sh, n = self.shape, self.n
+        base = sh.seed * 1000 + proof_seed * 100000
+        return dict(advice=[self.b.synth(n, base + 1 + i) for i in range(sh.n_advice)],
+                    instance=[self.b.synth(n, base + 50 + i) for i in range(sh.n_instance)],
+                    base=base)
+
+    def prove(self, wit):
+        """One pass.  Returns the transcript trace: every commitment's bytes and the challenges."""
+        sh, b, n, dom = self.shape, self.b, self.n, self.dom
+        base = wit["base"]
+        L, Zp = len(sh.lookups), sh.n_perm_sets
+        trace = {"commitments": [], "challenges": {}}
+
+        def absorb(tag, pts):
+            byts = [p[1] for p in pts]
+            trace["commitments"] += [(tag, x.hex()) for x in byts]
+            return byts
+
+        # 1. advice commitments (Lagrange basis)
+        advice = b.clone(wit["advice"])
+        instance = b.clone(wit["instance"])
+        t1 = absorb("advice", b.commit(advice, lagrange=True))
+        theta = challenge("theta", t1)
+        # 2. lookup permuted input / table (synthetic stand-ins for the sorted columns), coefficient form
+        perm_in = [b.synth(n, base + 300 + i) for i in range(L)]
+        perm_tab = [b.synth(n, base + 320 + i) for i in range(L)]
+        b.lagrange_to_coeff(perm_in + perm_tab)
+        t2 = absorb("lookup_permuted", b.commit(perm_in + perm_tab, lagrange=False)) if L else []
+        beta, gamma = challenge("beta", t1 + t2), challenge("gamma", t1 + t2)
+        # 3. grand products (synthetic stand-ins), coefficient form
+        perm_z = [b.synth(n, base + 340 + i) for i in range(Zp)]
+        look_z = [b.synth(n, base + 360 + i) for i in range(L)]
+        b.lagrange_to_coeff(perm_z + look_z)
+        t3 = absorb("products", b.commit(perm_z + look_z, lagrange=False))
+        # 4. vanishing argument's random polynomial
+        rand_poly = [b.synth(n, base + 380)]
+        t4 = absorb("random_poly", b.commit(rand_poly, lagrange=False))
+        y = challenge("y", t1 + t2 + t3 + t4)
+        # 5. quotient: advice/instance to coefficients, everything to the extended coset, sweep, divide, back
+        b.lagrange_to_coeff(advice + instance)
+        ext = b.coeff_to_extended(advice + instance + perm_in + perm_tab + look_z + perm_z)
+        o = 0
+        adv_c, o = ext[o:o + sh.n_advice], o + sh.n_advice
+        ins_c, o = ext[o:o + sh.n_instance], o + sh.n_instance
+        pin_c, o = ext[o:o + L], o + L
+        ptab_c, o = ext[o:o + L], o + L
+        lz_c, o = ext[o:o + L], o + L
+        pz_c = ext[o:o + Zp]
+        kw = dict(k=sh.k, extended_k=dom.extended_k, cs_degree=sh.degree, blinding_factors=sh.blinding_factors,
+                  extended_omega=dom.extended_omega, g_coset=dom.g_coset, delta=b.fr(DELTA), beta=b.fr(beta), gamma=b.fr(gamma),
+                  theta=b.fr(theta), y=b.fr(y), fixed=self.fixed_cosets, advice=adv_c, instance=ins_c, challenges=[],
+                  l0=self.l0, l_last=self.l_last, l_active=self.l_active, gates_graph=self.gates_graph,
+                  perm_columns=sh.perm_columns, sigma=self.sigma_cosets, perm_z=pz_c, lookup_graphs=self.lookup_graphs,
+                  lookup_z=lz_c, lookup_a=pin_c, lookup_s=ptab_c, to_mont=b.fr_many)
+        h = b.evaluate_h(kw)
+        h = b.divide_and_to_coeff(h)
+        pieces = b.split(h, n, dom.quotient_poly_degree)
+        t5 = absorb("quotient", b.commit(pieces, lagrange=False))
+        x = challenge("x", t1 + t2 + t3 + t4 + t5)
+        # 6. SHPLONK: two commitments to n-size polynomials (synthetic stand-ins for the quotient polys)
+        w1 = [b.synth(n, base + 400)]
+        t6 = absorb("shplonk_h1", b.commit(w1, lagrange=False))
+        w2 = [b.synth(n, base + 401)]
+        t7 = absorb("shplonk_h2", b.commit(w2, lagrange=False))
+        trace["challenges"] = dict(theta=theta, beta=beta, gamma=gamma, y=y, x=x)
+        trace["h_pieces"] = pieces
+        trace["n_commitments"] = len(trace["commitments"])
+        assert len(t6 + t7) == 2
+        return trace

@@ -59,6 +59,12 @@ int  zkhip_memcpy_d2h(zkhip_ctx* ctx, void* dst, const void* src, size_t bytes);
 int  zkhip_timer_start(zkhip_ctx* ctx);
 int  zkhip_timer_stop_ms(zkhip_ctx* ctx, float* ms);   /* synchronises */
 
+/* Per-kernel timing: while enabled, every launch of the named kernels is bracketed by HIP events on
+ * the launch stream.  Names: "msm_digits", "msm_accum_affine", "msm_accum_jac", "msm_tail",
+ * "ntt_strided", "ntt_final", "sweep".  zkhip_profile_enable also clears the record. */
+int  zkhip_profile_enable(zkhip_ctx* ctx, int on);
+int  zkhip_profile_read(zkhip_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches);
+
 /* ---- SRS: ParamsKZG::{g, g_lagrange} (halo2_proofs src/poly/kzg/commitment.rs) ----
  * Uploaded once; the device keeps, per base, its W window multiples 2^(c*w) * P_i in affine form
  * so that an MSM is a single bucket pass with no doublings (sized for 288 GB of HBM). */
@@ -81,6 +87,13 @@ int  zkhip_msm_g1(zkhip_ctx* ctx, const zkhip_srs* srs, const uint64_t* scalars,
  * zkhip_g1_to_affine after fetching).  Asynchronous apart from one 4-byte-per-column read-back. */
 int  zkhip_msm_g1_batch_device(zkhip_ctx* ctx, const zkhip_srs* srs, const void* const* d_scalar_cols,
                                size_t ncols, size_t n, void* d_out_xyz);
+/* The same over the point range [first, first+count): scalar first+i of every column pairs with base
+ * first+i.  One rank's share of a point-range-sharded MSM; the partial sums are
+ * exchanged as raw bytes and folded with zkhip_g1_add. */
+int  zkhip_msm_g1_batch_range_device(zkhip_ctx* ctx, const zkhip_srs* srs, const void* const* d_scalar_cols,
+                                     size_t ncols, size_t first, size_t count, void* d_out_xyz);
+/* G1 + G1 on the host (Jacobian, 12 u64 each). */
+void zkhip_g1_add(const uint64_t a[12], const uint64_t b[12], uint64_t out[12]);
 /* G1::to_affine on the host for results fetched from the device (12 u64 -> 8 u64). */
 void zkhip_g1_to_affine(const uint64_t xyz[12], uint64_t out_xy[8]);
 /* G1Affine::to_bytes (32-byte compressed) */

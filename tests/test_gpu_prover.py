@@ -1,0 +1,52 @@
+"""GPU parity: the whole create_proof-shaped pass (16 commitments + quotient pieces) vs the oracle backend."""
+import numpy as np
+import pytest
+
+import halo2_zkcert_amd.prover as pv
+from oracle_backend import OracleBackend
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("k", [7, 10])
+def test_pass_matches_oracle(zk, oracle, k):
+    ffi, ctx = zk
+    sh = pv.CircuitShape.small(k)
+    gp = pv.Prover(pv.GpuBackend(ctx, ffi), sh)
+    cp = pv.Prover(OracleBackend(8), sh)
+    # keygen-side artefacts first
+    for a, b in zip(gp.fixed_cosets + gp.sigma_cosets + [gp.l0, gp.l_last, gp.l_active],
+                    cp.fixed_cosets + cp.sigma_cosets + [cp.l0, cp.l_last, cp.l_active]):
+        assert (ctx.to_host(a) == b).all()
+    tg = gp.prove(gp.witness(3))
+    tc = cp.prove(cp.witness(3))
+    assert tg["commitments"] == tc["commitments"]          # every commitment, byte for byte
+    assert tg["challenges"] == tc["challenges"]
+    for a, b in zip(tg["h_pieces"], tc["h_pieces"]):
+        assert (ctx.to_host(a) == b).all()
+
+
+def test_rsa_k17_pass_properties(zk, oracle):
+    """BASELINE size (configs[1], RSA k=17): size-independent checks on the full pass.
+    Determinism, and the quotient pieces commit to the same points the oracle derives from the
+    pieces' own coefficients via the SRS trapdoor: commit(piece) == [piece(s)] G."""
+    ffi, ctx = zk
+    zo = oracle
+    sh = pv.CircuitShape.rsa(17)
+    s = 0x1D5C0FFEE
+    gp = pv.Prover(pv.GpuBackend(ctx, ffi), sh, srs_trapdoor=s)
+    w = gp.witness(0)
+    t1 = gp.prove(w)
+    t2 = gp.prove(w)
+    assert t1["commitments"] == t2["commitments"] and t1["n_commitments"] == 16
+    qc = [c for tag, c in t1["commitments"] if tag == "quotient"]
+    sm = zo.fr_from_int(s)
+    for piece, c in zip(t1["h_pieces"], qc):
+        exp = zo.g1_mul_gen(zo.eval_polynomial(ctx.to_host(piece), sm))
+        assert zo.g1_to_bytes(exp).hex() == c
+    # advice commitments (Lagrange basis) against the trapdoor too: commit_lagrange(v) == [iNTT(v)(s)] G
+    dom = gp.dom
+    col = w["advice"][0].clone()
+    dom.lagrange_to_coeff_device([col])
+    exp = zo.g1_mul_gen(zo.eval_polynomial(ctx.to_host(col), sm))
+    assert zo.g1_to_bytes(exp).hex() == t1["commitments"][0][1]

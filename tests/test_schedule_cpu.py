@@ -1,0 +1,32 @@
+"""CPU: the create_proof-shaped schedule (host logic in halo2_zkcert_amd/prover.py) run on the oracle backend."""
+import numpy as np
+
+import halo2_zkcert_amd.prover as pv
+from oracle_backend import OracleBackend
+
+
+def test_schedule_shape_and_determinism(oracle):
+    sh = pv.CircuitShape.small(5)
+    p = pv.Prover(OracleBackend(2), sh)
+    t1 = p.prove(p.witness(0))
+    t2 = p.prove(p.witness(0))
+    t3 = p.prove(p.witness(1))
+    counts = sh.counts(p.dom.extended_k)
+    assert t1["n_commitments"] == counts["msm"] == 3 + 3 * 1 + sh.n_perm_sets + 1 + 3 + 2
+    assert t1["commitments"] == t2["commitments"] and t1["challenges"] == t2["challenges"]
+    assert t1["commitments"] != t3["commitments"]
+    assert all((a == b).all() for a, b in zip(t1["h_pieces"], t2["h_pieces"]))
+
+
+def test_rsa_shape_matches_survey():
+    sh = pv.CircuitShape.rsa(17)
+    c = sh.counts(19)
+    # A=4, I=1, L=1, P=6, d=4 => 16 MSMs, 11 iNTT_n, 11 NTT_4n + 1 iNTT_4n
+    assert (sh.n_advice, sh.n_instance, len(sh.lookups), len(sh.perm_columns), sh.n_perm_sets) == (4, 1, 1, 6, 3)
+    assert c["msm"] == 16 and c["intt_n"] == 11 and c["ntt_ext"] == 11 and c["intt_ext"] == 1
+
+
+def test_challenge_is_canonical():
+    x = pv.challenge("t", [b"\x01" * 32])
+    assert 0 <= x < pv.R and x == pv.challenge("t", [b"\x01" * 32]) and x != pv.challenge("u", [b"\x01" * 32])
+    assert (pv.fr_from_int_host(5) == __import__("zkoracle_py").fr_from_int(5)).all()
