@@ -780,6 +780,10 @@ void zko_synth_raw253(uint64_t seed, uint64_t idx, uint64_t out[4]) {
     out[3] &= 0x1FFFFFFFFFFFFFFFULL;
 }
 
+void zko_synth_fill(uint64_t seed, uint64_t first, size_t n, uint64_t* out) {
+    for (size_t i = 0; i < n; ++i) zko_synth_raw253(seed, first + i, out + 4 * i);
+}
+
 /* [k]G by an 8-bit windowed fixed-base table (32 windows x 255 entries), batch-normalised. */
 void zko_fixed_base_mul(const uint64_t* scalars, size_t n, uint64_t* out_xy, int threads) {
     if (threads < 1) threads = 1;

@@ -125,6 +125,7 @@ int zko_evaluate_h(const zk_evalh_args* args, uint64_t* out, int threads);
 /* ---- synthetic data (repo-wide spec; also csrc/synth.hip) ---- */
 uint64_t zko_splitmix64(uint64_t x);
 void zko_synth_raw253(uint64_t seed, uint64_t idx, uint64_t out[4]);
+void zko_synth_fill(uint64_t seed, uint64_t first, size_t n, uint64_t* out);   /* n x 4 */
 /* fixed-base scalar multiples of the generator: out_xy[i] = [scalars[i]] G (scalars Montgomery Fr) */
 void zko_fixed_base_mul(const uint64_t* scalars, size_t n, uint64_t* out_xy, int threads);
 /* ParamsKZG::setup scalars (halo2_proofs poly/kzg/commitment.rs): monomial[i] = s^i,

@@ -170,9 +170,7 @@ def fr_constants():
 
 def synth_raw253(seed, n, start=0):
     out = new(n, 4)
-    L = lib()
-    for i in range(n):
-        L.zko_synth_raw253(C.c_uint64(seed), C.c_uint64(start + i), C.c_void_p(out.ctypes.data + 32 * i))
+    lib().zko_synth_fill(C.c_uint64(seed), C.c_uint64(start), C.c_size_t(n), p(out))
     return out
 
 
