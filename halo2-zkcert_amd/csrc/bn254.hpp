@@ -1,12 +1,26 @@
-// bn254.hpp — device-side BN254 Fq / Fr Montgomery arithmetic and G1 group law for gfx950.
+// bn254.hpp — BN254 Fq / Fr arithmetic and the G1 group law for gfx950 (host + device).
 //
-// Replaces (on the device) halo2curves 0.4.0 src/bn256/{fq,fr,curve}.rs + src/derive/{field,curve}.rs
-// [UPSTREAM-RECALL; crate pinned at /root/reference/Cargo.lock:1359-1361].  Same memory layout as
-// the Rust types: 4 little-endian u64 limbs in Montgomery form (R = 2^256), here viewed as 8 u32
-// limbs because the CDNA4 integer multiplier is 32x32 (v_mad_u64_u32).
+// Replaces halo2curves 0.4.0 src/bn256/{fq,fr,curve}.rs + src/derive/{field,curve}.rs on the device
+// [UPSTREAM-RECALL; crate pinned at /root/reference/Cargo.lock:1359-1361].
 //
-// No MFMA: none of this is a dense contraction.  The cost model is the 32-bit multiply pipe:
-// one Montgomery product = 8*8 + 8*8 + 8 = 136 v_mad_u64_u32 per lane.
+// Representation (chosen for the CDNA4 integer pipe, measured in profiles/r01_microbench_gfx950.txt:
+// v_mad_u64_u32 is the only wide multiplier, ~5 cycles per wave-instruction, and has no carry-in):
+//   * in registers a field element is 9 limbs of 29 bits ("fe"), value possibly unreduced
+//     (< B*p for a compile-time bound B <= 120, 128 p < 2^261).  29-bit limbs leave 6 spare bits in
+//     a 64-bit column accumulator, so a Montgomery product is 171 chained v_mad_u64_u32 with NO
+//     carry handling until one final pass, against ~600 instructions for the 8x32-bit CIOS form.
+//   * Montgomery radix is R' = 2^261 (nine 29-bit reduction steps).  mul(a, b) = a*b/R' mod p.
+//   * in memory (and across the C ABI) an element is 8 x u32 = halo2curves' 4 x u64 Montgomery form
+//     with R = 2^256, canonical (< p).  Conversions:
+//       load_raw   : v            (B = 1)   — for linear pipelines (NTT: scale-preserving) and for
+//                                              tables this library stores itself in R' form
+//       load_x32   : 32 * v       (B = 32)  — exactly the R' form of the same field element, unreduced
+//       store_raw  : canonical(a)
+//       store_div32: canonical(a / 32)      — back from the R' form to the ABI form
+//   * bounds are carried in the type (el<P, B>) and checked by static_assert: a subtraction adds
+//     (B_b + 1) p so it never goes negative; a product contracts to (A*B/128 + 1) p.
+//
+// No MFMA: nothing here is a dense contraction.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -15,379 +29,570 @@
 
 namespace zk {
 
-struct alignas(16) fe {
-    uint32_t l[8];
+constexpr uint32_t LB = 29;
+constexpr uint32_t LMASK = (1u << LB) - 1;
+
+struct fe {
+    uint32_t l[9];
+};
+struct alignas(16) fe32 {  // memory / ABI form
+    uint32_t w[8];
 };
 
 struct FqP {
-    static constexpr uint32_t M[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u,
-                                      0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
-    static constexpr uint32_t INV = 0xe4866389u;  // -M^-1 mod 2^32
-    static constexpr uint32_t ONE[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u,
-                                        0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
-    static constexpr uint32_t R2[8] = {0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u,
-                                       0x0a417ff6u, 0x47ab1effu, 0xcab8351fu, 0x06d89f71u};
+    static constexpr uint32_t M[9] = {0x187cfd47u, 0x010460b6u, 0x1c72a34fu, 0x02d522d0u, 0x1585d978u,
+                                      0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
+    static constexpr uint32_t INV = 0x04866389u;  // -p^-1 mod 2^29
+    static constexpr uint32_t ONE[9] = {0x157ccc21u, 0x141c2758u, 0x185230d3u, 0x014c0419u, 0x0aa36fb9u,
+                                        0x1d4240ceu, 0x11d54c07u, 0x052ac7a8u, 0x000dc836u};  // 2^261 mod p
+    static constexpr uint32_t R2[9] = {0x059bac10u, 0x0d1503a3u, 0x018016b8u, 0x10ab0ca8u, 0x02632639u,
+                                       0x02c0169fu, 0x169bfd53u, 0x11869d4cu, 0x002a11a6u};   // 2^522 mod p
+    static constexpr uint32_t NEGINV32 = 9;       // -p^-1 mod 32
 };
 struct FrP {
-    static constexpr uint32_t M[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u,
-                                      0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
-    static constexpr uint32_t INV = 0xefffffffu;
-    static constexpr uint32_t ONE[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u,
-                                        0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
-    static constexpr uint32_t R2[8] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u,
-                                       0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};
+    static constexpr uint32_t M[9] = {0x10000001u, 0x1f0fac9fu, 0x0e5c2450u, 0x07d090f3u, 0x1585d283u,
+                                      0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
+    static constexpr uint32_t INV = 0x0fffffffu;
+    static constexpr uint32_t ONE[9] = {0x0fffff57u, 0x1ea70ab4u, 0x052c068bu, 0x17504f49u, 0x0aa8075bu,
+                                        0x1d4240ceu, 0x11d54c07u, 0x052ac7a8u, 0x000dc836u};
+    static constexpr uint32_t R2[9] = {0x05b69bd4u, 0x06170a5au, 0x020cddceu, 0x1db6310bu, 0x0e54d0ffu,
+                                       0x1cf855e3u, 0x1c15e103u, 0x07d09161u, 0x000a054au};
+    static constexpr uint32_t NEGINV32 = 31;
 };
+using Fq = FqP;
+using Fr = FrP;
+constexpr uint64_t P8_MAGIC34 = 5417ull;  // floor(2^34 / ((p >> 232) + 1)), same for both moduli
 
+// limb i of k*p, normalised (compile-time for constant k); the top limb keeps everything above bit 232.
+template <class P>
+ZK_HD constexpr uint32_t kp_limb(uint32_t k, int i) {
+    uint64_t c = 0;
+    uint32_t r = 0;
+    for (int j = 0; j <= i; ++j) {
+        c += (uint64_t)k * P::M[j];
+        r = (j < 8) ? (uint32_t)(c & LMASK) : (uint32_t)c;
+        c >>= LB;
+    }
+    return r;
+}
+// limb i of k*p in "borrow-spread" form: every limb below the top is >= 2^29 - 1, so that
+// spread(k p) - b is limb-wise non-negative for any normalised b with top limb <= top(k p) - 1.
+template <class P>
+ZK_HD constexpr uint32_t kp_spread(uint32_t k, int i) {
+    return i == 0 ? kp_limb<P>(k, 0) + (1u << LB) : i < 8 ? kp_limb<P>(k, i) + LMASK : kp_limb<P>(k, 8) - 1;
+}
+
+// ---------------------------------------------------------------------------------- raw limb ops
+ZK_HD __forceinline__ void fe_normalize(fe& a) {  // limbs < 2^32 in, limbs < 2^29 (top: whatever is left) out
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        a.l[i + 1] += a.l[i] >> LB;
+        a.l[i] &= LMASK;
+    }
+}
 ZK_HD __forceinline__ fe fe_zero() {
     fe r;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) r.l[i] = 0;
+    for (int i = 0; i < 9; ++i) r.l[i] = 0;
     return r;
 }
-template <class P>
-ZK_HD __forceinline__ fe fe_one() {
-    fe r;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) r.l[i] = P::ONE[i];
-    return r;
-}
-ZK_HD __forceinline__ bool fe_is_zero(const fe& a) {
+ZK_HD __forceinline__ bool fe_is_zero_exact(const fe& a) {
     uint32_t o = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o |= a.l[i];
-    return o == 0;
-}
-ZK_HD __forceinline__ bool fe_eq(const fe& a, const fe& b) {
-    uint32_t o = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) o |= a.l[i] ^ b.l[i];
+    for (int i = 0; i < 9; ++i) o |= a.l[i];
     return o == 0;
 }
 
-// 16-byte vector loads/stores (coalesced: lane i touches element i).
-ZK_HD __forceinline__ fe fe_load(const void* p) {
+// a * b / 2^261 mod p; normalised inputs of any bounds A, B; output < (A*B/128 + 1) p, normalised.
+template <class P>
+ZK_HD __forceinline__ fe fe_mul_raw(const fe& a, const fe& b) {
+    uint64_t acc[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) acc[j] = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) acc[j] += (uint64_t)a.l[j] * b.l[i];
+        uint32_t q = ((uint32_t)acc[0] * P::INV) & LMASK;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) acc[j] += (uint64_t)q * P::M[j];
+        uint64_t carry = acc[0] >> LB;  // low 29 bits are zero by construction
+        acc[0] = acc[1] + carry;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) acc[j] = acc[j + 1];
+        acc[8] = 0;
+    }
+    fe r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        r.l[j] = (uint32_t)acc[j] & LMASK;
+        acc[j + 1] += acc[j] >> LB;
+    }
+    r.l[8] = (uint32_t)acc[8];
+    return r;
+}
+
+// returns a - k p if that is >= 0, else a  (runtime k <= 127)
+template <class P>
+ZK_HD __forceinline__ fe fe_cond_sub_kp(const fe& a, uint32_t k) {
+    fe d;
+    int64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        c += (int64_t)a.l[i] - (int64_t)((uint64_t)k * P::M[i]);
+        d.l[i] = i < 8 ? (uint32_t)c & LMASK : (uint32_t)c;
+        c >>= LB;  // arithmetic shift
+    }
+    bool neg = c < 0;
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = neg ? a.l[i] : d.l[i];
+    return r;
+}
+// canonical representative (< p) of any normalised a < 126 p.  Used at stores and zero tests only.
+template <class P>
+ZK_HD __forceinline__ fe fe_canonical(const fe& a_in) {
+    fe a = a_in;
+    uint32_t k = (uint32_t)(((uint64_t)a.l[8] * P8_MAGIC34) >> 34);  // underestimates floor(a / p) by at most 3
+    a = fe_cond_sub_kp<P>(a, k);
+    a = fe_cond_sub_kp<P>(a, 2);
+    a = fe_cond_sub_kp<P>(a, 1);
+    return a;
+}
+template <class P>
+ZK_HD __forceinline__ bool fe_is_zero_modp(const fe& a) {
+    return fe_is_zero_exact(fe_canonical<P>(a));
+}
+
+// 8 x u32 <-> 9 x 29-bit.  SHIFT = 0: value v;  SHIFT = 5: value 32 v.
+template <int SHIFT>
+ZK_HD __forceinline__ fe fe_split(const fe32& m) {
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        int bit = 29 * i - SHIFT;  // first source bit of limb i
+        uint32_t v;
+        if (bit < 0) {
+            v = m.w[0] << (-bit);
+        } else {
+            int wi = bit >> 5, sh = bit & 31;
+            uint32_t lo = wi < 8 ? m.w[wi] : 0u, hi = wi + 1 < 8 ? m.w[wi + 1] : 0u;
+            v = sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
+        }
+        r.l[i] = i < 8 ? (v & LMASK) : v;
+    }
+    return r;
+}
+ZK_HD __forceinline__ fe32 fe_pack(const fe& a) {  // canonical limbs (value < 2^256)
+    fe32 m;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        int bit = 32 * j, li = bit / 29, sh = bit % 29;
+        uint64_t v = (uint64_t)a.l[li] >> sh;
+        int have = 29 - sh;
+        if (li + 1 < 9) v |= (uint64_t)a.l[li + 1] << have;
+        if (have + 29 < 32 && li + 2 < 9) v |= (uint64_t)a.l[li + 2] << (have + 29);
+        m.w[j] = (uint32_t)v;
+    }
+    return m;
+}
+ZK_HD __forceinline__ fe32 mem_load(const void* p) {
     const uint4* q = reinterpret_cast<const uint4*>(p);
     uint4 a = q[0], b = q[1];
-    fe r;
-    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
-    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
-    return r;
+    fe32 m;
+    m.w[0] = a.x; m.w[1] = a.y; m.w[2] = a.z; m.w[3] = a.w;
+    m.w[4] = b.x; m.w[5] = b.y; m.w[6] = b.z; m.w[7] = b.w;
+    return m;
 }
-ZK_HD __forceinline__ void fe_store(void* p, const fe& v) {
+ZK_HD __forceinline__ void mem_store(void* p, const fe32& m) {
     uint4* q = reinterpret_cast<uint4*>(p);
-    q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
-    q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+    q[0] = make_uint4(m.w[0], m.w[1], m.w[2], m.w[3]);
+    q[1] = make_uint4(m.w[4], m.w[5], m.w[6], m.w[7]);
 }
-
-// r = (t >= M) ? t - M : t, branch-free.
+// exact division by 32 mod p: add k p with k = -a p^-1 mod 32, then shift.  a < 88 p.
 template <class P>
-ZK_HD __forceinline__ void fe_cond_sub(fe& t) {
-    uint32_t d[8];
-    uint64_t br = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        uint64_t x = (uint64_t)t.l[i] - P::M[i] - br;
-        d[i] = (uint32_t)x;
-        br = (x >> 32) & 1;
-    }
-    bool keep = br != 0;  // t < M
-#pragma unroll
-    for (int i = 0; i < 8; ++i) t.l[i] = keep ? t.l[i] : d[i];
-}
-
-template <class P>
-ZK_HD __forceinline__ fe fe_add(const fe& a, const fe& b) {
-    fe t;
+ZK_HD __forceinline__ fe fe_div32(const fe& a) {
+    uint32_t k = (a.l[0] * P::NEGINV32) & 31u;
     uint64_t c = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        c += (uint64_t)a.l[i] + b.l[i];
-        t.l[i] = (uint32_t)c;
-        c >>= 32;
-    }
-    fe_cond_sub<P>(t);  // both moduli < 2^254: a + b < 2^255, no carry out
-    return t;
-}
-template <class P>
-ZK_HD __forceinline__ fe fe_sub(const fe& a, const fe& b) {
-    fe t;
-    uint64_t br = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        uint64_t x = (uint64_t)a.l[i] - b.l[i] - br;
-        t.l[i] = (uint32_t)x;
-        br = (x >> 32) & 1;
-    }
-    uint32_t mask = br ? 0xffffffffu : 0u;
-    uint64_t c = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        c += (uint64_t)t.l[i] + (P::M[i] & mask);
-        t.l[i] = (uint32_t)c;
-        c >>= 32;
-    }
-    return t;
-}
-template <class P>
-ZK_HD __forceinline__ fe fe_neg(const fe& a) {
-    return fe_sub<P>(fe_zero(), a);
-}
-template <class P>
-ZK_HD __forceinline__ fe fe_dbl(const fe& a) {
-    return fe_add<P>(a, a);
-}
-
-// CIOS Montgomery product, 8 x 32-bit limbs.  M < 2^254 so the running value stays below
-// 2^33 * M < 2^288: nine limbs suffice.
-template <class P>
-ZK_HD __forceinline__ fe fe_mul(const fe& a, const fe& b) {
     uint32_t t[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) t[i] = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        uint64_t c = 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            c = (uint64_t)a.l[j] * b.l[i] + t[j] + c;
-            t[j] = (uint32_t)c;
-            c >>= 32;
-        }
-        t[8] += (uint32_t)c;
-        uint32_t q = t[0] * P::INV;
-        c = (uint64_t)q * P::M[0] + t[0];
-        c >>= 32;
-#pragma unroll
-        for (int j = 1; j < 8; ++j) {
-            c = (uint64_t)q * P::M[j] + t[j] + c;
-            t[j - 1] = (uint32_t)c;
-            c >>= 32;
-        }
-        c += t[8];
-        t[7] = (uint32_t)c;
-        t[8] = (uint32_t)(c >> 32);
+    for (int i = 0; i < 9; ++i) {
+        c += (uint64_t)a.l[i] + (uint64_t)k * P::M[i];
+        t[i] = i < 8 ? (uint32_t)c & LMASK : (uint32_t)c;
+        c >>= LB;
     }
     fe r;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) r.l[i] = t[i];
-    fe_cond_sub<P>(r);
+    for (int i = 0; i < 9; ++i) {
+        uint32_t lo = t[i] >> 5, hi = i + 1 < 9 ? (t[i + 1] & 31u) << (LB - 5) : 0u;
+        r.l[i] = i < 8 ? (lo | hi) & LMASK : lo;
+    }
     return r;
 }
+
+// ---------------------------------------------------------------------------------- typed elements
+// el<P, B>: value < (B / 16) p, limbs normalised.  Bounds are in sixteenths of p so that the +1 p of
+// every Montgomery contraction does not compound into uselessly loose integer bounds.
+constexpr int U = 16;                 // one p
+constexpr int BMAX = 120 * U;         // 120 p < 2^261 with room for fe_canonical's estimate
+constexpr int mul_bound(int a, int b) { return (a * b + 128 * U - 1) / (128 * U) + U; }
+constexpr int ceil_p(int b) { return (b + U - 1) / U; }
+
+template <class P, int B>
+struct el {
+    static_assert(B >= 1 && B <= BMAX, "lazy bound out of range (value must stay below 2^261 and canonicalise)");
+    fe v;
+    ZK_HD el() {}
+    ZK_HD explicit el(const fe& f) : v(f) {}
+    template <int A>
+    ZK_HD el(const el<P, A>& o) : v(o.v) { static_assert(A <= B, "narrowing a lazy bound"); }
+};
+
+template <class P, int A, int B>
+ZK_HD __forceinline__ el<P, mul_bound(A, B)> operator*(const el<P, A>& a, const el<P, B>& b) {
+    return el<P, mul_bound(A, B)>(fe_mul_raw<P>(a.v, b.v));
+}
+template <class P, int A>
+ZK_HD __forceinline__ el<P, mul_bound(A, A)> sqr(const el<P, A>& a) {
+    return el<P, mul_bound(A, A)>(fe_mul_raw<P>(a.v, a.v));
+}
+template <class P, int A, int B>
+ZK_HD __forceinline__ el<P, A + B> operator+(const el<P, A>& a, const el<P, B>& b) {
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = a.v.l[i] + b.v.l[i];
+    fe_normalize(r);
+    return el<P, A + B>(r);
+}
+// a - b + (ceil(B) + 1) p
+template <class P, int A, int B>
+ZK_HD __forceinline__ el<P, A + (ceil_p(B) + 1) * U> operator-(const el<P, A>& a, const el<P, B>& b) {
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = a.v.l[i] + kp_spread<P>(ceil_p(B) + 1, i) - b.v.l[i];
+    fe_normalize(r);
+    return el<P, A + (ceil_p(B) + 1) * U>(r);
+}
+template <class P, int B>
+ZK_HD __forceinline__ el<P, (ceil_p(B) + 1) * U> neg(const el<P, B>& b) {
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = kp_spread<P>(ceil_p(B) + 1, i) - b.v.l[i];
+    fe_normalize(r);
+    return el<P, (ceil_p(B) + 1) * U>(r);
+}
+// a * K for a small constant K (K * 2^29 must fit 32 bits: K <= 8)
+template <int K, class P, int A>
+ZK_HD __forceinline__ el<P, K * A> mul_small(const el<P, A>& a) {
+    static_assert(K >= 1 && K <= 8, "small multiple");
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = a.v.l[i] * (uint32_t)K;
+    fe_normalize(r);
+    return el<P, K * A>(r);
+}
+template <class P, int A>
+ZK_HD __forceinline__ bool is_zero(const el<P, A>& a) { return fe_is_zero_modp<P>(a.v); }
+template <class P, int A, int B>
+ZK_HD __forceinline__ bool equal(const el<P, A>& a, const el<P, B>& b) { return is_zero(a - b); }
+template <class P, int A>
+ZK_HD __forceinline__ el<P, U> canonical(const el<P, A>& a) { return el<P, U>(fe_canonical<P>(a.v)); }
+// re-contract a grown value: a * 1 (in R' form) < (A/128 + 1) p
+template <class P, int A>
+ZK_HD __forceinline__ el<P, mul_bound(A, U)> reduce(const el<P, A>& a) {
+    fe o;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) o.l[i] = P::ONE[i];
+    return el<P, mul_bound(A, U)>(fe_mul_raw<P>(a.v, o));
+}
+template <class P, int A>
+ZK_HD __forceinline__ el<P, A> select(bool c, const el<P, A>& a, const el<P, A>& b) {  // c ? a : b
+    el<P, A> r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.v.l[i] = c ? a.v.l[i] : b.v.l[i];
+    return r;
+}
+
 template <class P>
-ZK_HD __forceinline__ fe fe_sqr(const fe& a) {
-    return fe_mul<P>(a, a);
+ZK_HD __forceinline__ el<P, U> one() {
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = P::ONE[i];
+    return el<P, U>(r);
 }
 template <class P>
-ZK_HD __forceinline__ fe fe_from_mont(const fe& a) {
-    fe one = fe_zero();
-    one.l[0] = 1;
-    return fe_mul<P>(a, one);
-}
+ZK_HD __forceinline__ el<P, U> zero() { return el<P, U>(fe_zero()); }
 template <class P>
-ZK_HD __forceinline__ fe fe_to_mont(const fe& a) {
+using el1 = el<P, U>;        // canonical-sized (< p)
+template <class P>
+using el2 = el<P, 2 * U>;    // product-sized (< 2p)
+
+// memory <-> registers (see the header comment for which one to use where)
+template <class P>
+ZK_HD __forceinline__ el<P, U> load_raw(const void* p) { return el<P, U>(fe_split<0>(mem_load(p))); }
+template <class P>
+ZK_HD __forceinline__ el<P, 32 * U> load_x32(const void* p) { return el<P, 32 * U>(fe_split<5>(mem_load(p))); }
+template <class P, int A>
+ZK_HD __forceinline__ void store_raw(void* p, const el<P, A>& a) { mem_store(p, fe_pack(fe_canonical<P>(a.v))); }
+template <class P, int A>
+ZK_HD __forceinline__ fe32 to_abi(const el<P, A>& a) {
+    static_assert(A <= 88 * U, "to_abi input bound");
+    return fe_pack(fe_canonical<P>(fe_div32<P>(a.v)));
+}
+template <class P, int A>
+ZK_HD __forceinline__ void store_div32(void* p, const el<P, A>& a) { mem_store(p, to_abi(a)); }
+// ABI value (x 2^256, canonical) -> exact R' form (x 2^261), reduced (< 2p): 32 v, then one product by "one"
+template <class P>
+ZK_HD __forceinline__ el2<P> from_abi(const fe32& m) { return reduce(el<P, 32 * U>(fe_split<5>(m))); }
+// plain integer x < 2^64 -> R' form
+template <class P>
+ZK_HD __forceinline__ el2<P> from_u64(uint64_t x) {
+    fe t = fe_zero(), r2;
+    t.l[0] = (uint32_t)(x & LMASK);
+    t.l[1] = (uint32_t)((x >> 29) & LMASK);
+    t.l[2] = (uint32_t)(x >> 58);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r2.l[i] = P::R2[i];
+    return el2<P>(fe_mul_raw<P>(t, r2));
+}
+// canonical 8 x u32 integer (not Montgomery) -> R' form
+template <class P>
+ZK_HD __forceinline__ el2<P> from_canonical_words(const uint32_t w[8]) {
+    fe32 m;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m.w[i] = w[i];
     fe r2;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) r2.l[i] = P::R2[i];
-    return fe_mul<P>(a, r2);
+    for (int i = 0; i < 9; ++i) r2.l[i] = P::R2[i];
+    return el2<P>(fe_mul_raw<P>(fe_split<0>(m), r2));
 }
-// a^e, e given as 8 u32 limbs (runtime), left-to-right.
-template <class P>
-ZK_HD inline fe fe_pow(const fe& a, const uint32_t e[8]) {
-    fe acc = fe_one<P>();
-    bool started = false;
-    for (int i = 255; i >= 0; --i) {
-        if (started) acc = fe_sqr<P>(acc);
-        if ((e[i >> 5] >> (i & 31)) & 1) {
-            acc = started ? fe_mul<P>(acc, a) : a;
-            started = true;
-        }
-    }
-    return acc;
+// R' form -> canonical integer words (the field element itself)
+template <class P, int A>
+ZK_HD __forceinline__ fe32 to_canonical_words(const el<P, A>& a) {
+    fe o = fe_zero();
+    o.l[0] = 1;
+    return fe_pack(fe_canonical<P>(fe_mul_raw<P>(a.v, o)));
 }
+// ABI words (x 2^256 canonical) -> canonical integer words of x: (v * 32) / 2^261
 template <class P>
-ZK_HD inline fe fe_pow_u64(const fe& a, uint64_t e) {
-    fe acc = fe_one<P>();
+ZK_HD __forceinline__ fe32 abi_to_canonical_words(const fe32& m) {
+    fe o = fe_zero();
+    o.l[0] = 32;
+    return fe_pack(fe_canonical<P>(fe_mul_raw<P>(fe_split<0>(m), o)));
+}
+
+// a^e; results < 2 p
+template <class P>
+ZK_HD inline el2<P> pow_u64(const el2<P>& a, uint64_t e) {
+    el2<P> acc = one<P>();
     bool started = false;
     for (int i = 63; i >= 0; --i) {
-        if (started) acc = fe_sqr<P>(acc);
+        if (started) acc = sqr(acc);
         if ((e >> i) & 1) {
-            acc = started ? fe_mul<P>(acc, a) : a;
+            if (started) acc = acc * a; else acc = a;
             started = true;
         }
     }
     return acc;
 }
-// Fermat inverse (0 -> 0).
 template <class P>
-ZK_HD inline fe fe_inv(const fe& a) {
+ZK_HD inline el2<P> pow_words(const el2<P>& a, const uint32_t e[8]) {
+    el2<P> acc = one<P>();
+    bool started = false;
+    for (int i = 255; i >= 0; --i) {
+        if (started) acc = sqr(acc);
+        if ((e[i >> 5] >> (i & 31)) & 1) {
+            if (started) acc = acc * a; else acc = a;
+            started = true;
+        }
+    }
+    return acc;
+}
+// Fermat inverse (0 -> 0)
+template <class P>
+ZK_HD inline el2<P> inv(const el2<P>& a) {
+    fe t;
+    for (int i = 0; i < 9; ++i) t.l[i] = P::M[i];
+    fe32 pm = fe_pack(t);
     uint32_t e[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) e[i] = P::M[i];
+    for (int i = 0; i < 8; ++i) e[i] = pm.w[i];
     e[0] -= 2;
-    if (fe_is_zero(a)) return a;
-    return fe_pow<P>(a, e);
+    return pow_words<P>(a, e);
 }
 
-using Fq = FqP;
-using Fr = FrP;
-
-// Fr constants (canonical limbs; halo2curves src/bn256/fr.rs): 2^28-th root of unity, ZETA, DELTA.
+// Fr constants as canonical integer words (halo2curves src/bn256/fr.rs): 2^28-th root of unity, ZETA, DELTA.
 constexpr uint32_t FR_S = 28;
 constexpr uint32_t FR_ROOT_OF_UNITY[8] = {0x60c37c9cu, 0xd34f1ed9u, 0xd39329c8u, 0x3215cf6du,
                                           0x3dd31f74u, 0x98865ea9u, 0x166d18b7u, 0x03ddb9f5u};
 constexpr uint32_t FR_ZETA[8] = {0xb99c90ddu, 0x8b17ea66u, 0x8d8daaa7u, 0x5bfc4108u, 0x41a91758u, 0xb3c4d79du, 0u, 0u};
 constexpr uint32_t FR_DELTA[8] = {0xe533e9a2u, 0x870e56bbu, 0x5e963f25u, 0x5b5f898eu,
                                   0xd4c86e71u, 0x64ec26aau, 0x22c6f0cau, 0x09226b6eu};
-template <class P>
-ZK_HD __forceinline__ fe fe_from_canonical(const uint32_t v[8]) {
-    fe t;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) t.l[i] = v[i];
-    return fe_to_mont<P>(t);
-}
-template <class P>
-ZK_HD __forceinline__ fe fe_from_u64(uint64_t v) {
-    fe t = fe_zero();
-    t.l[0] = (uint32_t)v;
-    t.l[1] = (uint32_t)(v >> 32);
-    return fe_to_mont<P>(t);
-}
 
 // ------------------------------------------------------------------------------------ G1
-// y^2 = x^3 + 3.  Affine identity = (0,0) (halo2curves G1Affine); Jacobian identity z = 0.
-struct g1a { fe x, y; };
-struct g1j { fe x, y, z; };
+// y^2 = x^3 + 3.  Register forms (coordinates in R' form):
+//   g1a: affine, both coordinates < 2p; identity = exact (0, 0)
+//   g1j: Jacobian with the loop invariant X < BX p, Y < BY p, Z < BZ p; identity = exact Z = 0
+constexpr int BX = 16 * U, BY = 8 * U, BZ = 4 * U;
+struct g1a { el2<Fq> x, y; };
+struct g1j { el<Fq, BX> x; el<Fq, BY> y; el<Fq, BZ> z; };
 
-ZK_HD __forceinline__ bool g1a_is_id(const g1a& p) { return fe_is_zero(p.x) && fe_is_zero(p.y); }
-ZK_HD __forceinline__ bool g1j_is_id(const g1j& p) { return fe_is_zero(p.z); }
+ZK_HD __forceinline__ bool g1a_is_id(const g1a& p) { return fe_is_zero_exact(p.x.v) && fe_is_zero_exact(p.y.v); }
+ZK_HD __forceinline__ bool g1j_is_id(const g1j& p) { return fe_is_zero_exact(p.z.v); }
 ZK_HD __forceinline__ g1j g1j_identity() {
     g1j r;
-    r.x = fe_zero(); r.y = fe_one<Fq>(); r.z = fe_zero();
+    r.x = zero<Fq>(); r.y = one<Fq>(); r.z = zero<Fq>();
+    return r;
+}
+ZK_HD __forceinline__ g1a g1a_identity() {
+    g1a r;
+    r.x = zero<Fq>(); r.y = zero<Fq>();
     return r;
 }
 ZK_HD __forceinline__ g1j g1j_from_affine(const g1a& a) {
     if (g1a_is_id(a)) return g1j_identity();
     g1j r;
-    r.x = a.x; r.y = a.y; r.z = fe_one<Fq>();
+    r.x = a.x; r.y = a.y; r.z = one<Fq>();
     return r;
 }
-ZK_HD __forceinline__ g1a g1a_load(const void* p) {
+// table / scratch format: R' form, canonical, 32 B per coordinate
+ZK_HD __forceinline__ g1a g1a_load_raw(const void* p) {
     g1a r;
-    r.x = fe_load(p);
-    r.y = fe_load(reinterpret_cast<const char*>(p) + 32);
+    r.x = load_raw<Fq>(p);
+    r.y = load_raw<Fq>(reinterpret_cast<const char*>(p) + 32);
     return r;
 }
-ZK_HD __forceinline__ void g1a_store(void* p, const g1a& v) {
-    fe_store(p, v.x);
-    fe_store(reinterpret_cast<char*>(p) + 32, v.y);
+ZK_HD __forceinline__ void g1a_store_raw(void* p, const g1a& v) {
+    store_raw<Fq>(p, v.x);
+    store_raw<Fq>(reinterpret_cast<char*>(p) + 32, v.y);
 }
-ZK_HD __forceinline__ g1j g1j_load(const void* p) {
+ZK_HD __forceinline__ g1j g1j_load_raw(const void* p) {
     g1j r;
-    r.x = fe_load(p);
-    r.y = fe_load(reinterpret_cast<const char*>(p) + 32);
-    r.z = fe_load(reinterpret_cast<const char*>(p) + 64);
+    r.x = load_raw<Fq>(p);
+    r.y = load_raw<Fq>(reinterpret_cast<const char*>(p) + 32);
+    r.z = load_raw<Fq>(reinterpret_cast<const char*>(p) + 64);
     return r;
 }
-ZK_HD __forceinline__ void g1j_store(void* p, const g1j& v) {
-    fe_store(p, v.x);
-    fe_store(reinterpret_cast<char*>(p) + 32, v.y);
-    fe_store(reinterpret_cast<char*>(p) + 64, v.z);
+ZK_HD __forceinline__ void g1j_store_raw(void* p, const g1j& v) {
+    store_raw<Fq>(p, v.x);
+    store_raw<Fq>(reinterpret_cast<char*>(p) + 32, v.y);
+    store_raw<Fq>(reinterpret_cast<char*>(p) + 64, v.z);
+}
+// ABI format (halo2curves G1Affine / G1, R = 2^256)
+ZK_HD __forceinline__ g1a g1a_load_abi(const void* p) {
+    g1a r;
+    r.x = from_abi<Fq>(mem_load(p));
+    r.y = from_abi<Fq>(mem_load(reinterpret_cast<const char*>(p) + 32));
+    if (fe_is_zero_modp<Fq>(r.x.v) && fe_is_zero_modp<Fq>(r.y.v)) return g1a_identity();
+    return r;
+}
+ZK_HD __forceinline__ void g1a_store_abi(void* p, const g1a& v) {
+    mem_store(p, to_abi(v.x));
+    mem_store(reinterpret_cast<char*>(p) + 32, to_abi(v.y));
+}
+ZK_HD __forceinline__ g1j g1j_load_abi(const void* p) {
+    g1j r;
+    r.x = from_abi<Fq>(mem_load(p));
+    r.y = from_abi<Fq>(mem_load(reinterpret_cast<const char*>(p) + 32));
+    auto z = from_abi<Fq>(mem_load(reinterpret_cast<const char*>(p) + 64));
+    if (fe_is_zero_modp<Fq>(z.v)) return g1j_identity();
+    r.z = z;
+    return r;
+}
+ZK_HD __forceinline__ void g1j_store_abi(void* p, const g1j& v) {
+    mem_store(p, to_abi(v.x));
+    mem_store(reinterpret_cast<char*>(p) + 32, to_abi(v.y));
+    mem_store(reinterpret_cast<char*>(p) + 64, to_abi(v.z));
 }
 
-// dbl-2009-l (a = 0): 2M + 5S
+// dbl-2009-l (a = 0): 2M + 5S (+2 contractions)
 ZK_HD inline g1j g1j_double(const g1j& p) {
     if (g1j_is_id(p)) return p;
-    fe a = fe_sqr<Fq>(p.x);
-    fe b = fe_sqr<Fq>(p.y);
-    fe c = fe_sqr<Fq>(b);
-    fe d = fe_add<Fq>(p.x, b);
-    d = fe_sqr<Fq>(d);
-    d = fe_sub<Fq>(fe_sub<Fq>(d, a), c);
-    d = fe_dbl<Fq>(d);
-    fe e = fe_add<Fq>(fe_dbl<Fq>(a), a);
-    fe f = fe_sqr<Fq>(e);
+    auto a = sqr(p.x);
+    auto b = sqr(p.y);
+    auto c = sqr(b);
+    auto xb = sqr(p.x + b);
+    auto d = mul_small<2>(xb - (a + c));
+    auto e = mul_small<3>(a);
+    auto f = sqr(e);
     g1j r;
-    r.z = fe_dbl<Fq>(fe_mul<Fq>(p.y, p.z));
-    r.x = fe_sub<Fq>(f, fe_dbl<Fq>(d));
-    fe c8 = fe_dbl<Fq>(fe_dbl<Fq>(fe_dbl<Fq>(c)));
-    r.y = fe_sub<Fq>(fe_mul<Fq>(e, fe_sub<Fq>(d, r.x)), c8);
+    r.z = mul_small<2>(p.y * p.z);
+    auto x3 = reduce(f - mul_small<2>(d));
+    r.y = reduce(e * (d - x3) - mul_small<8>(c));
+    r.x = x3;
     return r;
 }
 
-// madd-2007-bl with exceptional cases: 7M + 4S
+// madd-2007-bl with the exceptional cases (Z3 = 2 Z1 H); q affine with coordinates < 2p: 8M + 3S
 ZK_HD inline g1j g1j_add_mixed(const g1j& p, const g1a& q) {
     if (g1a_is_id(q)) return p;
     if (g1j_is_id(p)) return g1j_from_affine(q);
-    fe z1z1 = fe_sqr<Fq>(p.z);
-    fe u2 = fe_mul<Fq>(q.x, z1z1);
-    fe s2 = fe_mul<Fq>(fe_mul<Fq>(q.y, z1z1), p.z);
-    if (fe_eq(p.x, u2)) {
-        if (fe_eq(p.y, s2)) return g1j_double(p);
+    auto z1z1 = sqr(p.z);
+    auto u2 = q.x * z1z1;
+    auto s2 = q.y * z1z1 * p.z;
+    auto h = u2 - p.x;
+    auto rr = s2 - p.y;
+    if (is_zero(h)) {
+        if (is_zero(rr)) return g1j_double(p);
         return g1j_identity();
     }
-    fe h = fe_sub<Fq>(u2, p.x);
-    fe hh = fe_sqr<Fq>(h);
-    fe i = fe_dbl<Fq>(fe_dbl<Fq>(hh));
-    fe j = fe_mul<Fq>(h, i);
-    fe r = fe_dbl<Fq>(fe_sub<Fq>(s2, p.y));
-    fe v = fe_mul<Fq>(p.x, i);
+    auto hh = sqr(h);
+    auto i = mul_small<4>(hh);
+    auto j = h * i;
+    auto r = mul_small<2>(rr);
+    auto v = p.x * i;
     g1j o;
-    o.x = fe_sub<Fq>(fe_sub<Fq>(fe_sub<Fq>(fe_sqr<Fq>(r), j), v), v);
-    fe yj = fe_dbl<Fq>(fe_mul<Fq>(p.y, j));
-    o.y = fe_sub<Fq>(fe_mul<Fq>(r, fe_sub<Fq>(v, o.x)), yj);
-    fe zh = fe_add<Fq>(p.z, h);
-    o.z = fe_sub<Fq>(fe_sub<Fq>(fe_sqr<Fq>(zh), z1z1), hh);
+    auto x3 = sqr(r) - (j + mul_small<2>(v));
+    o.y = r * (v - x3) - mul_small<2>(p.y * j);
+    o.z = mul_small<2>(p.z * h);
+    o.x = x3;
     return o;
 }
 
-// add-2007-bl with exceptional cases: 11M + 5S
+// add-2007-bl with the exceptional cases: 11M + 5S
 ZK_HD inline g1j g1j_add(const g1j& p, const g1j& q) {
     if (g1j_is_id(p)) return q;
     if (g1j_is_id(q)) return p;
-    fe z1z1 = fe_sqr<Fq>(p.z);
-    fe z2z2 = fe_sqr<Fq>(q.z);
-    fe u1 = fe_mul<Fq>(p.x, z2z2);
-    fe u2 = fe_mul<Fq>(q.x, z1z1);
-    fe s1 = fe_mul<Fq>(fe_mul<Fq>(p.y, q.z), z2z2);
-    fe s2 = fe_mul<Fq>(fe_mul<Fq>(q.y, p.z), z1z1);
-    if (fe_eq(u1, u2)) {
-        if (fe_eq(s1, s2)) return g1j_double(p);
+    auto z1z1 = sqr(p.z);
+    auto z2z2 = sqr(q.z);
+    auto u1 = p.x * z2z2;
+    auto u2 = q.x * z1z1;
+    auto s1 = p.y * q.z * z2z2;
+    auto s2 = q.y * p.z * z1z1;
+    auto h = u2 - u1;
+    auto rr = s2 - s1;
+    if (is_zero(h)) {
+        if (is_zero(rr)) return g1j_double(p);
         return g1j_identity();
     }
-    fe h = fe_sub<Fq>(u2, u1);
-    fe i = fe_sqr<Fq>(fe_dbl<Fq>(h));
-    fe j = fe_mul<Fq>(h, i);
-    fe r = fe_dbl<Fq>(fe_sub<Fq>(s2, s1));
-    fe v = fe_mul<Fq>(u1, i);
+    auto i = sqr(mul_small<2>(h));
+    auto j = h * i;
+    auto r = mul_small<2>(rr);
+    auto v = u1 * i;
     g1j o;
-    o.x = fe_sub<Fq>(fe_sub<Fq>(fe_sub<Fq>(fe_sqr<Fq>(r), j), v), v);
-    fe sj = fe_dbl<Fq>(fe_mul<Fq>(s1, j));
-    o.y = fe_sub<Fq>(fe_mul<Fq>(r, fe_sub<Fq>(v, o.x)), sj);
-    fe zz = fe_add<Fq>(p.z, q.z);
-    o.z = fe_mul<Fq>(fe_sub<Fq>(fe_sub<Fq>(fe_sqr<Fq>(zz), z1z1), z2z2), h);
+    auto x3 = sqr(r) - (j + mul_small<2>(v));
+    o.y = r * (v - x3) - mul_small<2>(s1 * j);
+    auto zz = sqr(p.z + q.z);
+    o.z = (zz - (z1z1 + z2z2)) * h;
+    o.x = x3;
     return o;
 }
 
-ZK_HD __forceinline__ g1a g1a_neg(const g1a& p) {
+// (x, +-y); the identity stays the exact (0, 0)
+ZK_HD __forceinline__ g1a g1a_cneg(const g1a& p, bool do_neg) {
     g1a r;
     r.x = p.x;
-    r.y = fe_is_zero(p.y) ? p.y : fe_sub<Fq>(fe_zero(), p.y);
-    return r;
-}
-ZK_HD __forceinline__ g1a g1a_cneg(const g1a& p, bool neg) {
-    g1a n = g1a_neg(p);
-    g1a r;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { r.x.l[i] = p.x.l[i]; r.y.l[i] = neg ? n.y.l[i] : p.y.l[i]; }
+    el<Fq, 3 * U> y3 = p.y;
+    el<Fq, 3 * U> s = select(do_neg && !g1a_is_id(p), neg(p.y), y3);
+    r.y = el2<Fq>(fe_cond_sub_kp<Fq>(s.v, 1));  // < 3p -> < 2p
     return r;
 }
 ZK_HD inline g1a g1j_to_affine(const g1j& p) {
     g1a r;
-    if (g1j_is_id(p)) { r.x = fe_zero(); r.y = fe_zero(); return r; }
-    fe zi = fe_inv<Fq>(p.z);
-    fe zi2 = fe_sqr<Fq>(zi);
-    r.x = fe_mul<Fq>(p.x, zi2);
-    r.y = fe_mul<Fq>(p.y, fe_mul<Fq>(zi2, zi));
+    if (g1j_is_id(p)) return g1a_identity();
+    el2<Fq> zi = inv<Fq>(reduce(p.z));
+    auto zi2 = sqr(zi);
+    r.x = p.x * zi2;
+    r.y = p.y * (zi2 * zi);
     return r;
 }
 
@@ -399,14 +604,14 @@ ZK_HD __forceinline__ uint64_t splitmix64(uint64_t x) {
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
 }
-ZK_HD __forceinline__ fe synth_raw253(uint64_t seed, uint64_t idx) {
-    fe r;
+ZK_HD __forceinline__ fe32 synth_raw253(uint64_t seed, uint64_t idx) {
+    fe32 r;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         uint64_t w = splitmix64(seed + (idx * 4 + (uint64_t)j) * 0x2545F4914F6CDD1Dull);
         if (j == 3) w &= 0x1FFFFFFFFFFFFFFFull;
-        r.l[2 * j] = (uint32_t)w;
-        r.l[2 * j + 1] = (uint32_t)(w >> 32);
+        r.w[2 * j] = (uint32_t)w;
+        r.w[2 * j + 1] = (uint32_t)(w >> 32);
     }
     return r;
 }

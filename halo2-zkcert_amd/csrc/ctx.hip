@@ -163,26 +163,19 @@ int zkhip_timer_stop_ms(zkhip_ctx* c, float* ms) {
 }
 
 void zkhip_g1_to_affine(const uint64_t xyz[12], uint64_t out_xy[8]) {
-    g1j p;
-    memcpy(&p, xyz, 96);
-    g1a a = g1j_to_affine(p);
-    memcpy(out_xy, &a, 64);
+    g1a_store_abi(out_xy, g1j_to_affine(g1j_load_abi(xyz)));
 }
 void zkhip_g1_add(const uint64_t a[12], const uint64_t b[12], uint64_t out[12]) {
-    g1j p, q;
-    memcpy(&p, a, 96);
-    memcpy(&q, b, 96);
-    g1j r = g1j_add(p, q);
-    memcpy(out, &r, 96);
+    g1j_store_abi(out, g1j_add(g1j_load_abi(a), g1j_load_abi(b)));
 }
 void zkhip_g1_to_bytes(const uint64_t xy[8], uint8_t out[32]) {
-    g1a a;
-    memcpy(&a, xy, 64);
+    fe32 x = abi_to_canonical_words<Fq>(mem_load(xy)), y = abi_to_canonical_words<Fq>(mem_load(xy + 4));
+    uint32_t any = 0;
+    for (int i = 0; i < 8; ++i) any |= x.w[i] | y.w[i];
     memset(out, 0, 32);
-    if (g1a_is_id(a)) { out[31] |= 0x80; return; }
-    fe x = fe_from_mont<Fq>(a.x), y = fe_from_mont<Fq>(a.y);
-    memcpy(out, x.l, 32);
-    out[31] |= (uint8_t)((y.l[0] & 1) << 6);
+    if (!any) { out[31] |= 0x80; return; }
+    memcpy(out, x.w, 32);
+    out[31] |= (uint8_t)((y.w[0] & 1) << 6);
 }
 
 }  // extern "C"
@@ -190,7 +183,7 @@ void zkhip_g1_to_bytes(const uint64_t xy[8], uint8_t out[32]) {
 __global__ void k_synth_fill(uint32_t* out, size_t n, uint64_t seed, uint64_t first) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    fe_store(out + i * 8, synth_raw253(seed, first + i));
+    mem_store(out + i * 8, synth_raw253(seed, first + i));
 }
 
 extern "C" int zkhip_synth_fill_device(zkhip_ctx* c, void* d_out, size_t n, uint64_t seed, uint64_t first) {

@@ -42,53 +42,57 @@ static uint32_t pick_window(size_t n) {
 }
 
 // ------------------------------------------------------------------ SRS precomputation
-__global__ void k_affine_to_jac(const uint32_t* in_xy, uint32_t* out_xyz, size_t n) {
+// Tables and scratch hold coordinates in the library's own R' = 2^261 Montgomery form, canonical,
+// 32 B each ("raw"): loading one is a limb split, no multiplication.
+__global__ void k_import_bases(const uint32_t* in_xy_abi, uint32_t* out_xy_raw, uint32_t* out_xyz_raw, size_t n, int in_is_raw) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    g1j_store(out_xyz + i * 24, g1j_from_affine(g1a_load(in_xy + i * 16)));
+    g1a a = in_is_raw ? g1a_load_raw(in_xy_abi + i * 16) : g1a_load_abi(in_xy_abi + i * 16);
+    g1a_store_raw(out_xy_raw + i * 16, a);
+    g1j_store_raw(out_xyz_raw + i * 24, g1j_from_affine(a));
 }
 __global__ void k_pow2c(const uint32_t* in_xyz, uint32_t* out_xyz, size_t n, uint32_t c) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    g1j p = g1j_load(in_xyz + i * 24);
+    g1j p = g1j_load_raw(in_xyz + i * 24);
     for (uint32_t j = 0; j < c; ++j) p = g1j_double(p);
-    g1j_store(out_xyz + i * 24, p);
+    g1j_store_raw(out_xyz + i * 24, p);
 }
-// Jacobian -> affine with Montgomery's trick over G points per thread (strided for coalescing).
+// Jacobian -> affine with Montgomery's trick over G points per thread (strided for coalescing); raw in, raw out.
 template <int G>
 __global__ void k_batch_to_affine(const uint32_t* in_xyz, uint32_t* out_xy, size_t n) {
     size_t T = (size_t)gridDim.x * blockDim.x;
     size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    fe prefix[G];
-    fe acc = fe_one<Fq>();
+    el2<Fq> prefix[G];
+    el2<Fq> acc = one<Fq>();
 #pragma unroll
     for (int j = 0; j < G; ++j) {
         size_t i = t + (size_t)j * T;
-        fe z = fe_one<Fq>();
+        el1<Fq> z = one<Fq>();
         if (i < n) {
-            z = fe_load(in_xyz + i * 24 + 16);
-            if (fe_is_zero(z)) z = fe_one<Fq>();
+            z = load_raw<Fq>(in_xyz + i * 24 + 16);
+            if (fe_is_zero_exact(z.v)) z = one<Fq>();
         }
         prefix[j] = acc;
-        acc = fe_mul<Fq>(acc, z);
+        acc = acc * z;
     }
-    fe inv = fe_inv<Fq>(acc);
+    el2<Fq> inv_acc = inv<Fq>(acc);
 #pragma unroll
     for (int j = G - 1; j >= 0; --j) {
         size_t i = t + (size_t)j * T;
         if (i < n) {
-            g1j p = g1j_load(in_xyz + i * 24);
+            g1j p = g1j_load_raw(in_xyz + i * 24);
             g1a a;
             if (g1j_is_id(p)) {
-                a.x = fe_zero(); a.y = fe_zero();
+                a = g1a_identity();
             } else {
-                fe zi = fe_mul<Fq>(inv, prefix[j]);
-                inv = fe_mul<Fq>(inv, p.z);
-                fe zi2 = fe_sqr<Fq>(zi);
-                a.x = fe_mul<Fq>(p.x, zi2);
-                a.y = fe_mul<Fq>(p.y, fe_mul<Fq>(zi2, zi));
+                el2<Fq> zi = inv_acc * prefix[j];
+                inv_acc = inv_acc * p.z;
+                auto zi2 = sqr(zi);
+                a.x = p.x * zi2;
+                a.y = p.y * (zi2 * zi);
             }
-            g1a_store(out_xy + i * 16, a);
+            g1a_store_raw(out_xy + i * 16, a);
         }
     }
 }
@@ -103,7 +107,8 @@ int launch_batch_to_affine(zkhip_ctx* ctx, const void* d_in_xyz, void* d_out_xy,
 }
 }  // namespace zk
 
-static int srs_build(zkhip_ctx* ctx, const void* d_bases, size_t n, zkhip_srs** out) {
+namespace zk { int srs_build_raw(zkhip_ctx* ctx, const void* d_bases_raw, size_t n, zkhip_srs** out); }
+static int srs_build(zkhip_ctx* ctx, const void* d_bases, size_t n, zkhip_srs** out, int bases_are_raw) {
     if (n == 0 || n > ((size_t)1 << 26)) { set_error("zkhip_srs_load: n = %zu out of range (1..2^26)", n); return ZKHIP_EINVAL; }
     zkhip_srs* s = new zkhip_srs();
     s->n = n;
@@ -119,8 +124,8 @@ static int srs_build(zkhip_ctx* ctx, const void* d_bases, size_t n, zkhip_srs** 
     if (rc != ZKHIP_OK) { (void)hipFree(s->d_table); delete s; return rc; }
     hipStream_t st = ctx->stream;
     unsigned g = div_up(n, 256);
-    ZK_HIP(hipMemcpyAsync(s->d_table, d_bases, n * 64, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(k_affine_to_jac, dim3(g), dim3(256), 0, st, (const uint32_t*)d_bases, (uint32_t*)ja, n);
+    hipLaunchKernelGGL(k_import_bases, dim3(g), dim3(256), 0, st, (const uint32_t*)d_bases, (uint32_t*)s->d_table, (uint32_t*)ja, n,
+                       bases_are_raw);
     constexpr int G = 8;
     unsigned gt = div_up(div_up(n, G), 256);
     for (uint32_t w = 1; w < s->W; ++w) {
@@ -135,6 +140,10 @@ static int srs_build(zkhip_ctx* ctx, const void* d_bases, size_t n, zkhip_srs** 
     return ZKHIP_OK;
 }
 
+namespace zk {
+int srs_build_raw(zkhip_ctx* ctx, const void* d_bases_raw, size_t n, zkhip_srs** out) { return srs_build(ctx, d_bases_raw, n, out, 1); }
+}  // namespace zk
+
 // ------------------------------------------------------------------ digit recoding + counting sort
 // Signed digits d_w in [-(2^(c-1)-1), 2^(c-1)], sum d_w 2^(c w) = scalar.  W*c >= 255 so the last
 // carry is zero for every canonical scalar < r < 2^254.
@@ -146,9 +155,9 @@ __global__ void k_digits(const uint32_t* const* scalar_cols, size_t n, size_t fi
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     uint32_t col = blockIdx.y;
     if (i >= n) return;
-    fe s = fe_from_mont<Fr>(fe_load(scalar_cols[col] + (first + i) * 8));
+    fe32 s = abi_to_canonical_words<Fr>(mem_load(scalar_cols[col] + (first + i) * 8));
 #pragma unroll
-    for (int j = 0; j < 8; ++j) sl[threadIdx.x][j] = s.l[j];
+    for (int j = 0; j < 8; ++j) sl[threadIdx.x][j] = s.w[j];
     sl[threadIdx.x][8] = 0;
     uint32_t* cnt = cnt_all + (size_t)col * B;
     const uint32_t* off = off_all + (size_t)col * (B + 1);
@@ -243,10 +252,10 @@ __global__ void __launch_bounds__(256) k_accum_affine(const uint32_t* table, con
     g1j acc = g1j_identity();
     for (uint32_t j = lo; j < hi; ++j) {
         uint32_t e = entries[j];
-        g1a p = g1a_load(table + (size_t)(e & 0x7fffffffu) * 16);
+        g1a p = g1a_load_raw(table + (size_t)(e & 0x7fffffffu) * 16);
         acc = g1j_add_mixed(acc, g1a_cneg(p, (e >> 31) != 0));
     }
-    g1j_store(partial_all + ((size_t)col * partial_stride + t) * 24, acc);
+    g1j_store_raw(partial_all + ((size_t)col * partial_stride + t) * 24, acc);
 }
 // Rounds >= 1: segment sums of Jacobian partials.
 __global__ void __launch_bounds__(256) k_accum_jac(const uint32_t* in_all, size_t in_stride, const uint32_t* cnt_all,
@@ -262,9 +271,9 @@ __global__ void __launch_bounds__(256) k_accum_jac(const uint32_t* in_all, size_
     uint32_t b = find_bucket(segoff, B, t);
     uint32_t s = t - segoff[b];
     uint32_t lo = off[b] + s * seg, hi = min(lo + seg, off[b] + cnt[b]);
-    g1j acc = g1j_load(in + (size_t)lo * 24);
-    for (uint32_t j = lo + 1; j < hi; ++j) acc = g1j_add(acc, g1j_load(in + (size_t)j * 24));
-    g1j_store(out_all + ((size_t)col * out_stride + t) * 24, acc);
+    g1j acc = g1j_load_raw(in + (size_t)lo * 24);
+    for (uint32_t j = lo + 1; j < hi; ++j) acc = g1j_add(acc, g1j_load_raw(in + (size_t)j * 24));
+    g1j_store_raw(out_all + ((size_t)col * out_stride + t) * 24, acc);
 }
 
 // sum_{b} (b+1) * S_b over CH consecutive buckets per thread (running-sum trick + base * run).
@@ -281,7 +290,7 @@ __global__ void __launch_bounds__(256) k_bucket_chunks(const uint32_t* part_all,
     g1j run = g1j_identity(), acc = g1j_identity();
     for (int j = (int)CH - 1; j >= 0; --j) {
         uint32_t b = base + (uint32_t)j;
-        if (b < B && cnt[b]) run = g1j_add(run, g1j_load(part + (size_t)off[b] * 24));
+        if (b < B && cnt[b]) run = g1j_add(run, g1j_load_raw(part + (size_t)off[b] * 24));
         acc = g1j_add(acc, run);
     }
     // + base * run
@@ -292,7 +301,7 @@ __global__ void __launch_bounds__(256) k_bucket_chunks(const uint32_t* part_all,
         m >>= 1;
         if (m) d = g1j_double(d);
     }
-    g1j_store(out_all + ((size_t)col * nchunks + t) * 24, acc);
+    g1j_store_raw(out_all + ((size_t)col * nchunks + t) * 24, acc);
 }
 
 __global__ void __launch_bounds__(512) k_final_sum(const uint32_t* in_all, uint32_t count, uint32_t* out_all) {
@@ -300,18 +309,18 @@ __global__ void __launch_bounds__(512) k_final_sum(const uint32_t* in_all, uint3
     uint32_t col = blockIdx.x, t = threadIdx.x;
     const uint32_t* in = in_all + (size_t)col * count * 24;
     g1j acc = g1j_identity();
-    for (uint32_t i = t; i < count; i += 512) acc = g1j_add(acc, g1j_load(in + (size_t)i * 24));
+    for (uint32_t i = t; i < count; i += 512) acc = g1j_add(acc, g1j_load_raw(in + (size_t)i * 24));
     sh[t] = acc;
     __syncthreads();
     for (uint32_t d = 256; d >= 1; d >>= 1) {
         if (t < d) sh[t] = g1j_add(sh[t], sh[t + d]);
         __syncthreads();
     }
-    if (t == 0) g1j_store(out_all + (size_t)col * 24, sh[0]);
+    if (t == 0) g1j_store_abi(out_all + (size_t)col * 24, sh[0]);   // the ABI result: halo2curves G1 (R = 2^256)
 }
 __global__ void k_set_identity(uint32_t* out_all, uint32_t ncols) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < ncols) g1j_store(out_all + (size_t)t * 24, g1j_identity());
+    if (t < ncols) g1j_store_abi(out_all + (size_t)t * 24, g1j_identity());
 }
 
 // ------------------------------------------------------------------ host driver
@@ -424,7 +433,7 @@ extern "C" {
 
 int zkhip_srs_load_device(zkhip_ctx* ctx, const void* d_bases, size_t n, zkhip_srs** out) {
     if (!ctx || !d_bases || !out) { set_error("zkhip_srs_load_device: null argument"); return ZKHIP_EINVAL; }
-    return srs_build(ctx, d_bases, n, out);
+    return srs_build(ctx, d_bases, n, out, 0);
 }
 int zkhip_srs_load(zkhip_ctx* ctx, const uint64_t* bases_xy, size_t n, zkhip_srs** out) {
     if (!ctx || !bases_xy || !out) { set_error("zkhip_srs_load: null argument"); return ZKHIP_EINVAL; }
@@ -432,7 +441,7 @@ int zkhip_srs_load(zkhip_ctx* ctx, const uint64_t* bases_xy, size_t n, zkhip_srs
     void* d;
     ZK_TRY(ctx->get_scratch("srs_upload", n * 64, &d));
     ZK_HIP(hipMemcpyAsync(d, bases_xy, n * 64, hipMemcpyHostToDevice, ctx->stream));
-    return srs_build(ctx, d, n, out);
+    return srs_build(ctx, d, n, out, 0);
 }
 void zkhip_srs_free(zkhip_ctx* ctx, zkhip_srs* s) {
     if (!s) return;
@@ -445,6 +454,7 @@ int zkhip_srs_read(zkhip_ctx* ctx, const zkhip_srs* s, size_t first, size_t coun
     if (!ctx || !s || !out_xy || first + count > s->n) { set_error("zkhip_srs_read: bad range"); return ZKHIP_EINVAL; }
     ZK_HIP(hipMemcpyAsync(out_xy, (const char*)s->d_table + first * 64, count * 64, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < count; ++i) g1a_store_abi(out_xy + 8 * i, g1a_load_raw(out_xy + 8 * i));  // table form -> ABI form
     return ZKHIP_OK;
 }
 
@@ -469,11 +479,7 @@ int zkhip_msm_g1(zkhip_ctx* ctx, const zkhip_srs* srs, const uint64_t* scalars, 
     ZK_HIP(hipMemcpyAsync(jac, d_o, 96, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(hipStreamSynchronize(ctx->stream));
     // normalise: (x, y, 1) or the identity (0, 1, 0), like G1::from(G1Affine)
-    g1j p;
-    memcpy(&p, jac, 96);
-    g1a a = g1j_to_affine(p);
-    g1j r = g1j_from_affine(a);
-    memcpy(out_xyz, &r, 96);
+    g1j_store_abi(out_xyz, g1j_from_affine(g1j_to_affine(g1j_load_abi(jac))));
     return ZKHIP_OK;
 }
 

@@ -21,19 +21,27 @@
 #include "common.hpp"
 using namespace zk;
 
-#define NTT_TILE 2048  // elements per workgroup tile (64 KB LDS), 256 threads
+#define NTT_TILE 2048  // elements per workgroup tile, 256 threads; 9 x u32 per element = 72 KiB of LDS
+
+// Twiddle / scale constants live in the library's R' = 2^261 form so that mul(v, w) = v * w for data in
+// ANY fixed Montgomery scaling: the NTT is linear, so ABI data (x 2^256) is transformed as it is —
+// no domain conversion on load or store, only the limb split / canonical pack.
+//
+// Lazy bounds inside a tile: a butterfly maps (a, b) -> (a + b w, a - b w + 3p) with b w < 2p, so a
+// value grows by at most 3p per stage: <= (2 + 3*11) p = 35 p after an 11-stage tile (limit 120 p).
 
 // ------------------------------------------------------------------ twiddle tables
-__global__ void k_twiddles(uint32_t* table, size_t half_n, fe omega) {
+__global__ void k_twiddles(uint32_t* table, size_t half_n, fe omega_v) {
     const size_t CHK = 64;
     size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     size_t lo = t * CHK;
     if (lo >= half_n) return;
-    fe w = fe_pow_u64<Fr>(omega, (uint64_t)lo);
+    el2<Fr> omega(omega_v);
+    el2<Fr> w = pow_u64<Fr>(omega, (uint64_t)lo);
     size_t hi = lo + CHK < half_n ? lo + CHK : half_n;
     for (size_t i = lo; i < hi; ++i) {
-        fe_store(table + i * 8, w);
-        w = fe_mul<Fr>(w, omega);
+        store_raw<Fr>(table + i * 8, w);
+        w = w * omega;
     }
 }
 
@@ -46,9 +54,8 @@ int zkhip_ctx::get_twiddles(const uint64_t omega[4], uint32_t log_n, const void*
     size_t half_n = log_n ? ((size_t)1 << (log_n - 1)) : 1;
     hipError_t e = hipMalloc(&t.d_table, half_n * 32);
     if (e != hipSuccess) { (void)hipGetLastError(); set_error("hipMalloc twiddles (%zu B): %s", half_n * 32, hipGetErrorString(e)); return ZKHIP_ENOMEM; }
-    fe w;
-    memcpy(&w, omega, 32);
-    hipLaunchKernelGGL(k_twiddles, dim3(div_up(div_up(half_n, 64), 64)), dim3(64), 0, stream, (uint32_t*)t.d_table, half_n, w);
+    el2<Fr> w = from_abi<Fr>(mem_load(omega));
+    hipLaunchKernelGGL(k_twiddles, dim3(div_up(div_up(half_n, 64), 64)), dim3(64), 0, stream, (uint32_t*)t.d_table, half_n, w.v);
     ZK_LAUNCH_CHECK();
     twiddles.push_back(t);
     *d_table = t.d_table;
@@ -57,18 +64,20 @@ int zkhip_ctx::get_twiddles(const uint64_t omega[4], uint32_t log_n, const void*
 
 // ------------------------------------------------------------------ kernels
 struct NttScale {
-    fe pre[3];   // element i is multiplied by pre[i % 3] on the first load (if use_pre)
+    fe pre[3];   // element i is multiplied by pre[i % 3] on the first load (if use_pre); R' form, < 2p
     fe post[3];  // output k is multiplied by post[k % 3] on the last store (if use_post)
     int use_pre, use_post;
 };
+using tile_el = el<Fr, 40 * U>;   // anything held in a tile
+
+extern __shared__ uint32_t ntt_lds[];   // fe tile[NTT_TILE]
 
 __device__ __forceinline__ uint32_t bitrev(uint32_t v, uint32_t bits) { return bits ? (__brev(v) >> (32 - bits)) : 0; }
 
-__device__ __forceinline__ fe twiddle_at(const uint32_t* table, uint32_t e, uint32_t half_n) {
+__device__ __forceinline__ el2<Fr> twiddle_at(const uint32_t* table, uint32_t e, uint32_t half_n) {
     // w^e for e < n from the half table: w^(n/2) = -1
-    if (e < half_n) return fe_load(table + (size_t)e * 8);
-    fe t = fe_load(table + (size_t)(e - half_n) * 8);
-    return fe_neg<Fr>(t);
+    if (e < half_n) return load_raw<Fr>(table + (size_t)e * 8);
+    return neg(load_raw<Fr>(table + (size_t)(e - half_n) * 8));
 }
 
 // s radix-2 DIT stages on a tile laid out tile[row * T + tl], rows = 2^s (rows were loaded bit-reversed).
@@ -83,10 +92,21 @@ __device__ __forceinline__ void tile_ntt(fe* tile, uint32_t s, uint32_t logT, ui
             uint32_t j = pr & (half - 1);
             uint32_t r0 = ((pr >> st) << (st + 1)) | j;
             uint32_t i0 = r0 * T + tl, i1 = (r0 + half) * T + tl;
-            fe a = tile[i0], b = tile[i1];
-            if (j != 0) b = fe_mul<Fr>(b, fe_load(table + ((size_t)j << (m - 1 - st)) * 8));
-            tile[i0] = fe_add<Fr>(a, b);
-            tile[i1] = fe_sub<Fr>(a, b);
+            fe a = tile[i0];
+            el2<Fr> bw;
+            if (j != 0) bw = tile_el(tile[i1]) * load_raw<Fr>(table + ((size_t)j << (m - 1 - st)) * 8);
+            else if (st == 0) bw = el2<Fr>(tile[i1]);   // fresh loads are < 2p: twiddle 1 needs no product
+            else bw = reduce(tile_el(tile[i1]));         // twiddle 1 later on: contract so the +3p/stage bound holds
+            fe sum, dif;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                sum.l[q] = a.l[q] + bw.v.l[q];
+                dif.l[q] = a.l[q] + kp_spread<Fr>(3, q) - bw.v.l[q];
+            }
+            fe_normalize(sum);
+            fe_normalize(dif);
+            tile[i0] = sum;
+            tile[i1] = dif;
         }
     }
     __syncthreads();
@@ -94,21 +114,20 @@ __device__ __forceinline__ void tile_ntt(fe* tile, uint32_t s, uint32_t logT, ui
 
 __device__ __forceinline__ fe load_in(const uint32_t* src, uint32_t i, uint32_t n_in, const NttScale& sc) {
     if (i >= n_in) return fe_zero();
-    fe v = fe_load(src + (size_t)i * 8);
+    el1<Fr> v = load_raw<Fr>(src + (size_t)i * 8);
     if (sc.use_pre) {
         uint32_t r = i % 3;
-        if (r == 1) v = fe_mul<Fr>(v, sc.pre[1]);
-        else if (r == 2) v = fe_mul<Fr>(v, sc.pre[2]);
-        else if (sc.use_pre > 1) v = fe_mul<Fr>(v, sc.pre[0]);
+        if (r == 1) return (v * el2<Fr>(sc.pre[1])).v;
+        if (r == 2) return (v * el2<Fr>(sc.pre[2])).v;
     }
-    return v;
+    return v.v;
 }
 
 // Non-final pass: position = (hi << (s + lo_bits)) | (digit << lo_bits) | lo.
 __global__ void __launch_bounds__(256) k_ntt_strided(const uint32_t* const* srcs, uint32_t* const* dsts, uint32_t m, uint32_t s,
                                                       uint32_t lo_bits, uint32_t logT, uint32_t n_in, const uint32_t* table,
                                                       NttScale sc) {
-    __shared__ fe tile[NTT_TILE];
+    fe* tile = reinterpret_cast<fe*>(ntt_lds);
     const uint32_t* src = srcs[blockIdx.y];
     uint32_t* dst = dsts[blockIdx.y];
     uint32_t T = 1u << logT, rows = 1u << s;
@@ -128,10 +147,11 @@ __global__ void __launch_bounds__(256) k_ntt_strided(const uint32_t* const* srcs
     for (uint32_t e = threadIdx.x; e < cnt; e += blockDim.x) {
         uint32_t tl = e & (T - 1), r = e >> logT;
         uint32_t lo = lo0 | tl;
-        fe v = tile[r * T + tl];
+        tile_el v(tile[r * T + tl]);
         uint32_t ex = (lo * r) << hi_bits;  // < n
-        if (ex != 0) v = fe_mul<Fr>(v, twiddle_at(table, ex, half_n));
-        fe_store(dst + (size_t)(base | (r << lo_bits) | tl) * 8, v);
+        void* out = dst + (size_t)(base | (r << lo_bits) | tl) * 8;
+        if (ex != 0) store_raw<Fr>(out, v * twiddle_at(table, ex, half_n));
+        else store_raw<Fr>(out, v);
     }
 }
 
@@ -141,7 +161,7 @@ struct NttDigits { uint32_t np; uint32_t sw[4]; };
 
 __global__ void __launch_bounds__(256) k_ntt_final(const uint32_t* const* srcs, uint32_t* const* dsts, uint32_t m, uint32_t s,
                                                     uint32_t logT, uint32_t n_in, const uint32_t* table, NttScale sc, NttDigits dg) {
-    __shared__ fe tile[NTT_TILE];
+    fe* tile = reinterpret_cast<fe*>(ntt_lds);
     const uint32_t* src = srcs[blockIdx.y];
     uint32_t* dst = dsts[blockIdx.y];
     uint32_t T = 1u << logT, rows = 1u << s;
@@ -170,18 +190,17 @@ __global__ void __launch_bounds__(256) k_ntt_final(const uint32_t* const* srcs, 
     for (uint32_t e = threadIdx.x; e < cnt; e += blockDim.x) {
         uint32_t tl = e & (T - 1), r = e >> logT;
         uint32_t k = (r << hi_bits) | kbase | (k1_0 + tl);
-        fe v = tile[r * T + tl];
-        if (sc.use_post) v = fe_mul<Fr>(v, sc.post[k % 3]);
-        fe_store(dst + (size_t)k * 8, v);
+        tile_el v(tile[r * T + tl]);
+        void* out = dst + (size_t)k * 8;
+        if (sc.use_post) store_raw<Fr>(out, v * el2<Fr>(sc.post[k % 3]));
+        else store_raw<Fr>(out, v);
     }
 }
 
 __global__ void k_mul_periodic(uint32_t* a, size_t n, const uint32_t* tev, uint32_t period_mask) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    fe v = fe_load(a + i * 8);
-    fe t = fe_load(tev + (size_t)(i & period_mask) * 8);
-    fe_store(a + i * 8, fe_mul<Fr>(v, t));
+    store_raw<Fr>(a + i * 8, load_raw<Fr>(a + i * 8) * load_raw<Fr>(tev + (size_t)(i & period_mask) * 8));
 }
 
 // ------------------------------------------------------------------ host driver
@@ -206,6 +225,12 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
     }
     const void* table;
     ZK_TRY(ctx->get_twiddles(omega, m, &table));
+    static bool lds_attr_set = false;
+    if (!lds_attr_set) {
+        ZK_HIP(hipFuncSetAttribute((const void*)k_ntt_strided, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NTT_TILE * sizeof(fe))));
+        ZK_HIP(hipFuncSetAttribute((const void*)k_ntt_final, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NTT_TILE * sizeof(fe))));
+        lds_attr_set = true;
+    }
     // pass plan
     uint32_t smax = 9;
     if (const char* e = getenv("ZKHIP_NTT_SMAX")) { int v = atoi(e); if (v >= 4 && v <= 11) smax = (uint32_t)v; }
@@ -236,7 +261,7 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
         uint32_t** out = (q + 2 == np) ? d_tmp : d_dst;
         unsigned blocks = (unsigned)(n >> (s + logT));
         ProfScope ps(ctx, "ntt_strided");
-        hipLaunchKernelGGL(k_ntt_strided, dim3(blocks, (unsigned)npolys), dim3(256), 0, st, (const uint32_t* const*)cur_src,
+        hipLaunchKernelGGL(k_ntt_strided, dim3(blocks, (unsigned)npolys), dim3(256), NTT_TILE * sizeof(fe), st, (const uint32_t* const*)cur_src,
                            (uint32_t* const*)out, m, s, lo_bits, logT, q == 0 ? n_in : (uint32_t)n, (const uint32_t*)table, scq);
         cur_src = (const uint32_t**)out;
     }
@@ -251,7 +276,7 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
         for (int i = 0; i < 4; ++i) dg.sw[i] = sw[i];
         unsigned blocks = (unsigned)(n >> (s + logT));
         ProfScope ps(ctx, "ntt_final");
-        hipLaunchKernelGGL(k_ntt_final, dim3(blocks, (unsigned)npolys), dim3(256), 0, st, (const uint32_t* const*)cur_src,
+        hipLaunchKernelGGL(k_ntt_final, dim3(blocks, (unsigned)npolys), dim3(256), NTT_TILE * sizeof(fe), st, (const uint32_t* const*)cur_src,
                            (uint32_t* const*)d_dst, m, s, logT, np == 1 ? n_in : (uint32_t)n, (const uint32_t*)table, scq, dg);
     }
     ZK_LAUNCH_CHECK();
@@ -260,8 +285,11 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
 
 struct zkhip_domain {
     uint32_t k, extended_k, quotient_poly_degree;
-    fe omega, omega_inv, extended_omega, extended_omega_inv, g_coset, g_coset_inv, ifft_divisor, extended_ifft_divisor;
-    void* d_t_evaluations = nullptr;
+    // R' form, < 2p
+    el2<Fr> omega, omega_inv, extended_omega, extended_omega_inv, g_coset, g_coset_inv, ifft_divisor, extended_ifft_divisor;
+    // the same four roots in ABI form (keys of the twiddle cache, and what the caller sees)
+    uint64_t omega_abi[4], omega_inv_abi[4], extended_omega_abi[4], extended_omega_inv_abi[4], g_coset_abi[4];
+    void* d_t_evaluations = nullptr;   // raw R' form
     uint32_t n_t = 0;
 };
 
@@ -302,23 +330,28 @@ int zkhip_domain_new(zkhip_ctx* ctx, uint32_t j, uint32_t k, const uint64_t g_co
     while (((uint64_t)1 << ek) < ((uint64_t)1 << k) * d->quotient_poly_degree) ++ek;
     if (ek > 26) { delete d; set_error("zkhip_domain_new: extended_k = %u unsupported (max 26)", ek); return ZKHIP_EINVAL; }
     d->extended_k = ek;
-    fe w = fe_from_canonical<Fr>(FR_ROOT_OF_UNITY);
-    for (uint32_t i = ek; i < FR_S; ++i) w = fe_sqr<Fr>(w);
+    el2<Fr> w = from_canonical_words<Fr>(FR_ROOT_OF_UNITY);
+    for (uint32_t i = ek; i < FR_S; ++i) w = sqr(w);
     d->extended_omega = w;
-    for (uint32_t i = k; i < ek; ++i) w = fe_sqr<Fr>(w);
+    for (uint32_t i = k; i < ek; ++i) w = sqr(w);
     d->omega = w;
-    d->omega_inv = fe_inv<Fr>(d->omega);
-    d->extended_omega_inv = fe_inv<Fr>(d->extended_omega);
-    if (g_coset) memcpy(&d->g_coset, g_coset, 32); else d->g_coset = fe_from_canonical<Fr>(FR_ZETA);
-    d->g_coset_inv = fe_sqr<Fr>(d->g_coset);
-    d->ifft_divisor = fe_inv<Fr>(fe_from_u64<Fr>((uint64_t)1 << k));
-    d->extended_ifft_divisor = fe_inv<Fr>(fe_from_u64<Fr>((uint64_t)1 << ek));
+    d->omega_inv = inv<Fr>(d->omega);
+    d->extended_omega_inv = inv<Fr>(d->extended_omega);
+    if (g_coset) d->g_coset = from_abi<Fr>(mem_load(g_coset)); else d->g_coset = from_canonical_words<Fr>(FR_ZETA);
+    d->g_coset_inv = sqr(d->g_coset);
+    d->ifft_divisor = inv<Fr>(from_u64<Fr>((uint64_t)1 << k));
+    d->extended_ifft_divisor = inv<Fr>(from_u64<Fr>((uint64_t)1 << ek));
+    mem_store(d->omega_abi, to_abi(d->omega));
+    mem_store(d->omega_inv_abi, to_abi(d->omega_inv));
+    mem_store(d->extended_omega_abi, to_abi(d->extended_omega));
+    mem_store(d->extended_omega_inv_abi, to_abi(d->extended_omega_inv));
+    mem_store(d->g_coset_abi, to_abi(d->g_coset));
     d->n_t = 1u << (ek - k);
-    std::vector<fe> tev(d->n_t);
-    fe cur = fe_pow_u64<Fr>(d->g_coset, (uint64_t)1 << k), step = fe_pow_u64<Fr>(d->extended_omega, (uint64_t)1 << k);
+    std::vector<fe32> tev(d->n_t);
+    el2<Fr> cur = pow_u64<Fr>(d->g_coset, (uint64_t)1 << k), step = pow_u64<Fr>(d->extended_omega, (uint64_t)1 << k);
     for (uint32_t i = 0; i < d->n_t; ++i) {
-        tev[i] = fe_inv<Fr>(fe_sub<Fr>(cur, fe_one<Fr>()));
-        cur = fe_mul<Fr>(cur, step);
+        tev[i] = fe_pack(fe_canonical<Fr>(inv<Fr>(reduce(cur - one<Fr>())).v));
+        cur = cur * step;
     }
     hipError_t e = hipMalloc(&d->d_t_evaluations, d->n_t * 32);
     if (e != hipSuccess) { (void)hipGetLastError(); delete d; set_error("hipMalloc t_evaluations: %s", hipGetErrorString(e)); return ZKHIP_ENOMEM; }
@@ -337,21 +370,21 @@ uint32_t zkhip_domain_k(const zkhip_domain* d) { return d->k; }
 uint32_t zkhip_domain_extended_k(const zkhip_domain* d) { return d->extended_k; }
 uint32_t zkhip_domain_quotient_poly_degree(const zkhip_domain* d) { return d->quotient_poly_degree; }
 void zkhip_domain_constants(const zkhip_domain* d, uint64_t omega[4], uint64_t extended_omega[4], uint64_t g_coset[4]) {
-    if (omega) memcpy(omega, &d->omega, 32);
-    if (extended_omega) memcpy(extended_omega, &d->extended_omega, 32);
-    if (g_coset) memcpy(g_coset, &d->g_coset, 32);
+    if (omega) memcpy(omega, d->omega_abi, 32);
+    if (extended_omega) memcpy(extended_omega, d->extended_omega_abi, 32);
+    if (g_coset) memcpy(g_coset, d->g_coset_abi, 32);
 }
 
 int zkhip_coeff_to_lagrange_device(zkhip_ctx* ctx, const zkhip_domain* d, void* const* polys, size_t npolys) {
     if (!ctx || !d || !polys) { set_error("zkhip_coeff_to_lagrange_device: null argument"); return ZKHIP_EINVAL; }
-    return ntt_run(ctx, (const void* const*)polys, polys, npolys, (const uint64_t*)&d->omega, d->k, 1u << d->k, no_scale());
+    return ntt_run(ctx, (const void* const*)polys, polys, npolys, d->omega_abi, d->k, 1u << d->k, no_scale());
 }
 int zkhip_lagrange_to_coeff_device(zkhip_ctx* ctx, const zkhip_domain* d, void* const* polys, size_t npolys) {
     if (!ctx || !d || !polys) { set_error("zkhip_lagrange_to_coeff_device: null argument"); return ZKHIP_EINVAL; }
     NttScale sc = no_scale();
     sc.use_post = 1;
-    sc.post[0] = sc.post[1] = sc.post[2] = d->ifft_divisor;
-    return ntt_run(ctx, (const void* const*)polys, polys, npolys, (const uint64_t*)&d->omega_inv, d->k, 1u << d->k, sc);
+    sc.post[0] = sc.post[1] = sc.post[2] = d->ifft_divisor.v;
+    return ntt_run(ctx, (const void* const*)polys, polys, npolys, d->omega_inv_abi, d->k, 1u << d->k, sc);
 }
 int zkhip_coeff_to_extended_device(zkhip_ctx* ctx, const zkhip_domain* d, const void* const* in, size_t n_in, void* const* out,
                                    size_t npolys) {
@@ -359,18 +392,17 @@ int zkhip_coeff_to_extended_device(zkhip_ctx* ctx, const zkhip_domain* d, const 
     if (n_in > ((size_t)1 << d->extended_k)) { set_error("zkhip_coeff_to_extended_device: n_in too large"); return ZKHIP_EINVAL; }
     NttScale sc = no_scale();
     sc.use_pre = 1;  // distribute_powers_zeta(into_coset = true): [1, g, g^2] by i mod 3
-    sc.pre[0] = fe_one<Fr>(); sc.pre[1] = d->g_coset; sc.pre[2] = d->g_coset_inv;
-    return ntt_run(ctx, in, out, npolys, (const uint64_t*)&d->extended_omega, d->extended_k, (uint32_t)n_in, sc);
+    sc.pre[0] = one<Fr>().v; sc.pre[1] = d->g_coset.v; sc.pre[2] = d->g_coset_inv.v;
+    return ntt_run(ctx, in, out, npolys, d->extended_omega_abi, d->extended_k, (uint32_t)n_in, sc);
 }
 int zkhip_extended_to_coeff_device(zkhip_ctx* ctx, const zkhip_domain* d, void* const* polys, size_t npolys) {
     if (!ctx || !d || !polys) { set_error("zkhip_extended_to_coeff_device: null argument"); return ZKHIP_EINVAL; }
     NttScale sc = no_scale();
     sc.use_post = 1;  // ifft divisor, then distribute_powers_zeta(into_coset = false): [1, g^-1, g^-2]
-    sc.post[0] = d->extended_ifft_divisor;
-    sc.post[1] = fe_mul<Fr>(d->extended_ifft_divisor, d->g_coset_inv);
-    sc.post[2] = fe_mul<Fr>(d->extended_ifft_divisor, d->g_coset);
-    return ntt_run(ctx, (const void* const*)polys, polys, npolys, (const uint64_t*)&d->extended_omega_inv, d->extended_k,
-                   1u << d->extended_k, sc);
+    sc.post[0] = d->extended_ifft_divisor.v;
+    sc.post[1] = (d->extended_ifft_divisor * d->g_coset_inv).v;
+    sc.post[2] = (d->extended_ifft_divisor * d->g_coset).v;
+    return ntt_run(ctx, (const void* const*)polys, polys, npolys, d->extended_omega_inv_abi, d->extended_k, 1u << d->extended_k, sc);
 }
 int zkhip_divide_by_vanishing_device(zkhip_ctx* ctx, const zkhip_domain* d, void* d_a) {
     if (!ctx || !d || !d_a) { set_error("zkhip_divide_by_vanishing_device: null argument"); return ZKHIP_EINVAL; }

@@ -16,8 +16,8 @@ __global__ void k_fixed_base_table(uint32_t* table_xy) {
     if (t >= 32 * 256) return;
     uint32_t w = t >> 8, d = t & 255;
     g1a gen;
-    gen.x = fe_from_u64<Fq>(1);
-    gen.y = fe_from_u64<Fq>(2);
+    gen.x = from_u64<Fq>(1);
+    gen.y = from_u64<Fq>(2);
     g1j base = g1j_from_affine(gen);
     for (uint32_t i = 0; i < 8 * w; ++i) base = g1j_double(base);
     g1j acc = g1j_identity();
@@ -25,28 +25,31 @@ __global__ void k_fixed_base_table(uint32_t* table_xy) {
         acc = g1j_double(acc);
         if ((d >> b) & 1) acc = g1j_add(acc, base);
     }
-    g1a_store(table_xy + (size_t)t * 16, g1j_to_affine(acc));
+    g1a_store_raw(table_xy + (size_t)t * 16, g1j_to_affine(acc));
 }
 __global__ void __launch_bounds__(256) k_fixed_base_mul(const uint32_t* scalars, size_t n, const uint32_t* table_xy, uint32_t* out_xyz) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    fe k = fe_from_mont<Fr>(fe_load(scalars + i * 8));
+    fe32 k = abi_to_canonical_words<Fr>(mem_load(scalars + i * 8));
     g1j acc = g1j_identity();
 #pragma unroll 1
     for (uint32_t w = 0; w < 32; ++w) {
         uint32_t limb = 0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) limb = (w >> 2) == (uint32_t)j ? k.l[j] : limb;
+        for (int j = 0; j < 8; ++j) limb = (w >> 2) == (uint32_t)j ? k.w[j] : limb;
         uint32_t d = (limb >> ((w & 3) * 8)) & 255;
-        if (d) acc = g1j_add_mixed(acc, g1a_load(table_xy + ((size_t)w * 256 + d) * 16));
+        if (d) acc = g1j_add_mixed(acc, g1a_load_raw(table_xy + ((size_t)w * 256 + d) * 16));
     }
-    g1j_store(out_xyz + i * 24, acc);
+    g1j_store_raw(out_xyz + i * 24, acc);
 }
-namespace zk { int launch_batch_to_affine(zkhip_ctx* ctx, const void* d_in_xyz, void* d_out_xy, size_t n); }  // msm.hip
+namespace zk {  // msm.hip
+int launch_batch_to_affine(zkhip_ctx* ctx, const void* d_in_xyz, void* d_out_xy, size_t n);
+int srs_build_raw(zkhip_ctx* ctx, const void* d_bases_raw, size_t n, zkhip_srs** out);
+}
 
 extern "C" int zkhip_fixed_base_mul_device(zkhip_ctx* ctx, const void* d_scalars, size_t n, void* d_out_xy);
 
-// device scalars (Montgomery Fr) -> affine bases
+// device scalars (ABI Montgomery Fr) -> affine bases in the library's table form (R' = 2^261, canonical)
 extern "C" int zkhip_fixed_base_mul_device(zkhip_ctx* ctx, const void* d_scalars, size_t n, void* d_out_xy) {
     if (!ctx || !d_scalars || !d_out_xy) { set_error("zkhip_fixed_base_mul_device: null argument"); return ZKHIP_EINVAL; }
     if (n == 0) return ZKHIP_OK;
@@ -67,49 +70,48 @@ extern "C" int zkhip_kzg_setup(zkhip_ctx* ctx, uint32_t k, const uint64_t s_u[4]
     if (!ctx || !s_u || (!g && !g_lagrange)) { set_error("zkhip_kzg_setup: null argument"); return ZKHIP_EINVAL; }
     if (k > 24) { set_error("zkhip_kzg_setup: k = %u unsupported (max 24)", k); return ZKHIP_EINVAL; }
     size_t n = (size_t)1 << k;
-    fe s;
-    memcpy(&s, s_u, 32);
-    std::vector<fe> sc(n);
+    el2<Fr> s = from_abi<Fr>(mem_load(s_u));
+    std::vector<fe32> sc(n);
     void *d_sc, *d_pts;
     ZK_TRY(ctx->get_scratch("kzg_scalars", n * 32, &d_sc));
     ZK_TRY(ctx->get_scratch("kzg_points", n * 64, &d_pts));
-    fe sn;
+    el2<Fr> sn;
     {
-        fe cur = fe_one<Fr>();
-        for (size_t i = 0; i < n; ++i) { sc[i] = cur; cur = fe_mul<Fr>(cur, s); }
+        el2<Fr> cur = one<Fr>();
+        for (size_t i = 0; i < n; ++i) { sc[i] = to_abi(cur); cur = cur * s; }
         sn = cur;
     }
     if (g) {
         ZK_HIP(hipMemcpyAsync(d_sc, sc.data(), n * 32, hipMemcpyHostToDevice, ctx->stream));
         ZK_HIP(hipStreamSynchronize(ctx->stream));
         ZK_TRY(zkhip_fixed_base_mul_device(ctx, d_sc, n, d_pts));
-        ZK_TRY(zkhip_srs_load_device(ctx, d_pts, n, g));
+        ZK_TRY(srs_build_raw(ctx, d_pts, n, g));
     }
     if (g_lagrange) {
         // l_i(s) = (s^n - 1)/n * w^i / (s - w^i), batch-inverted
-        fe omega = fe_from_canonical<Fr>(FR_ROOT_OF_UNITY);
-        for (uint32_t i = k; i < FR_S; ++i) omega = fe_sqr<Fr>(omega);
-        fe num = fe_mul<Fr>(fe_sub<Fr>(sn, fe_one<Fr>()), fe_inv<Fr>(fe_from_u64<Fr>((uint64_t)n)));
-        std::vector<fe> den(n), pre(n);
-        fe w = fe_one<Fr>(), acc = fe_one<Fr>();
+        el2<Fr> omega = from_canonical_words<Fr>(FR_ROOT_OF_UNITY);
+        for (uint32_t i = k; i < FR_S; ++i) omega = sqr(omega);
+        el2<Fr> num = reduce(sn - one<Fr>()) * inv<Fr>(from_u64<Fr>((uint64_t)n));
+        std::vector<el2<Fr>> den(n), pre(n), val(n);
+        el2<Fr> w = one<Fr>(), acc = one<Fr>();
         for (size_t i = 0; i < n; ++i) {
-            den[i] = fe_sub<Fr>(s, w);
-            if (fe_is_zero(den[i])) { set_error("zkhip_kzg_setup: s is an n-th root of unity"); return ZKHIP_EINVAL; }
+            den[i] = reduce(s - w);
+            if (is_zero(den[i])) { set_error("zkhip_kzg_setup: s is an n-th root of unity"); return ZKHIP_EINVAL; }
             pre[i] = acc;
-            acc = fe_mul<Fr>(acc, den[i]);
-            sc[i] = fe_mul<Fr>(num, w);
-            w = fe_mul<Fr>(w, omega);
+            acc = acc * den[i];
+            val[i] = num * w;
+            w = w * omega;
         }
-        fe inv = fe_inv<Fr>(acc);
+        el2<Fr> iv = inv<Fr>(acc);
         for (size_t i = n; i-- > 0;) {
-            fe di = fe_mul<Fr>(inv, pre[i]);
-            inv = fe_mul<Fr>(inv, den[i]);
-            sc[i] = fe_mul<Fr>(sc[i], di);
+            el2<Fr> di = iv * pre[i];
+            iv = iv * den[i];
+            sc[i] = to_abi(val[i] * di);
         }
         ZK_HIP(hipMemcpyAsync(d_sc, sc.data(), n * 32, hipMemcpyHostToDevice, ctx->stream));
         ZK_HIP(hipStreamSynchronize(ctx->stream));
         ZK_TRY(zkhip_fixed_base_mul_device(ctx, d_sc, n, d_pts));
-        ZK_TRY(zkhip_srs_load_device(ctx, d_pts, n, g_lagrange));
+        ZK_TRY(srs_build_raw(ctx, d_pts, n, g_lagrange));
     }
     return ZKHIP_OK;
 }

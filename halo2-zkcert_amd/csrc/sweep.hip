@@ -20,25 +20,34 @@
 using namespace zk;
 
 enum : uint32_t { K_SLOT = 0, K_CONST = 1, K_COL = 2 };
-enum : uint32_t { I_ADD = 0, I_SUB, I_MUL, I_SQR, I_DBL, I_NEG, I_MOV, I_MULADD, I_ACC };
+enum : uint32_t { I_ADD = 0, I_SUB, I_MUL, I_SQR, I_DBL, I_NEG, I_MOV, I_MULADD, I_ACC, I_RED };
+// Lazy bounds (bn254.hpp) are static per instruction — the same for every row — so the host lowering tracks
+// them in sixteenths of p exactly like the el<P, B> types do, picks the k p constant of every SUB / NEG
+// (field c of the instruction) and inserts a contraction (I_RED = product by one) where a sum would
+// leave the representable range.  Column loads enter as 32 v (B = 32 p): the R' form of an ABI value.
+static const int SW_U = 16, SW_BMAX = 120 * 16, SW_COL = 32 * 16, SW_CONST = 16;
+static inline int sw_mul_bound(int a, int b) { return (a * b + 128 * SW_U - 1) / (128 * SW_U) + SW_U; }
+static inline int sw_ceil_p(int b) { return (b + SW_U - 1) / SW_U; }
 
 static inline uint32_t mk_operand(uint32_t kind, uint32_t a, uint32_t b = 0) { return (kind << 28) | ((a & 0x3fff) << 14) | (b & 0x3fff); }
 
 struct DevIns { uint32_t op_dst, a, b, c; };
 
-struct Section { uint32_t begin, end, result; };  // instruction range and result operand
+struct Section { uint32_t begin, end, result, bound; };  // instruction range, result operand and its lazy bound
 
 // ------------------------------------------------------------------ host lowering
 struct Lowering {
     std::vector<DevIns> code;
-    std::vector<fe> consts;
+    std::vector<fe32> consts;   // R' form, canonical (raw)
     std::vector<int32_t> rots;
     std::vector<const void*> cols;  // fixed ++ advice ++ instance device pointers
     uint32_t n_fixed = 0, n_advice = 0, n_instance = 0;
     uint32_t c_zero = 0, c_one = 0, c_beta = 0, c_gamma = 0, c_theta = 0, c_y = 0, c_chal0 = 0;
     uint32_t max_slots = 0;
 
-    uint32_t add_const(const fe& v) { consts.push_back(v); return (uint32_t)consts.size() - 1; }
+    uint32_t add_const(const fe32& v) { consts.push_back(v); return (uint32_t)consts.size() - 1; }
+    // ABI Montgomery limbs (what the caller holds) -> table entry
+    uint32_t add_const_abi(const uint64_t* p) { return add_const(fe_pack(fe_canonical<Fr>(from_abi<Fr>(mem_load(p)).v))); }
     uint32_t add_rot(int32_t r) {
         for (size_t i = 0; i < rots.size(); ++i) if (rots[i] == r) return (uint32_t)i;
         rots.push_back(r);
@@ -65,7 +74,7 @@ static int lower_graph(Lowering& L, const zk_graph& g, const zk_evalh_args& A, b
         pc += 3 + 3 * nsrc;
     }
     const uint32_t base_const = (uint32_t)L.consts.size();
-    for (uint32_t i = 0; i < g.n_constants; ++i) { fe v; memcpy(&v, g.constants + 4 * i, 32); L.consts.push_back(v); }
+    for (uint32_t i = 0; i < g.n_constants; ++i) L.add_const_abi(g.constants + 4 * i);
     std::vector<uint32_t> rotmap(g.n_rotations);
     for (uint32_t i = 0; i < g.n_rotations; ++i) rotmap[i] = L.add_rot(g.rotations[i]);
 
@@ -93,13 +102,38 @@ static int lower_graph(Lowering& L, const zk_graph& g, const zk_evalh_args& A, b
         return ZKHIP_EPROGRAM;
     };
 
-    // Virtual instruction list with virtual registers = intermediate ids (or temporaries >= n_intermediates).
+    // Virtual instruction list; virtual registers = intermediate ids, temporaries >= n_intermediates.
     struct VIns { uint32_t op; int32_t dst; uint32_t a, b, c; int32_t ra, rb, rc; };  // r* = virtual reg read or -1
     std::vector<VIns> v;
+    std::vector<int> rbound(g.n_intermediates, 0);   // lazy bound of every virtual register (sixteenths of p)
+    int vbound = SW_CONST;                           // bound of the running `value` (acc mode): starts at 0
     auto opnd = [&](const int32_t* vs, uint32_t* o, int32_t* r) -> int {
         ZK_TRY(resolve(vs, o));
         *r = (*o == NEEDS_SLOT) ? vs[1] : -1;  // a real register (slot assigned below) or an alias operand
         return 0;
+    };
+    auto bound_of = [&](uint32_t o, int32_t r) -> int { return r >= 0 ? rbound[r] : ((o >> 28) == K_COL ? SW_COL : SW_CONST); };
+    // contract operand (o, r) into a fresh temporary register; returns the new (o, r)
+    auto contract = [&](uint32_t& o, int32_t& r) {
+        int32_t t = (int32_t)rbound.size();
+        rbound.push_back(sw_mul_bound(bound_of(o, r), SW_CONST));
+        v.push_back({I_RED, t, o, 0, 0, r, -1, -1});
+        o = NEEDS_SLOT; r = t;
+    };
+    auto emit_add = [&](int32_t dst, uint32_t oa, int32_t ra, uint32_t ob, int32_t rb) {
+        while (bound_of(oa, ra) + bound_of(ob, rb) > SW_BMAX) {
+            if (bound_of(oa, ra) >= bound_of(ob, rb)) contract(oa, ra); else contract(ob, rb);
+        }
+        v.push_back({I_ADD, dst, oa, ob, 0, ra, rb, -1});
+        rbound[dst] = bound_of(oa, ra) + bound_of(ob, rb);
+    };
+    auto emit_sub = [&](int32_t dst, uint32_t oa, int32_t ra, uint32_t ob, int32_t rb) {
+        while (bound_of(oa, ra) + (sw_ceil_p(bound_of(ob, rb)) + 1) * SW_U > SW_BMAX) {
+            if (bound_of(ob, rb) > 2 * SW_U) contract(ob, rb); else contract(oa, ra);
+        }
+        uint32_t k = (uint32_t)sw_ceil_p(bound_of(ob, rb)) + 1;
+        v.push_back({I_SUB, dst, oa, ob, k, ra, rb, -1});
+        rbound[dst] = bound_of(oa, ra) + (int)k * SW_U;
     };
     // which intermediate ids are real registers
     std::vector<char> is_reg(g.n_intermediates, 0);
@@ -114,7 +148,9 @@ static int lower_graph(Lowering& L, const zk_graph& g, const zk_evalh_args& A, b
             if (vs[0] == ZK_VS_INTERMEDIATE && (vs[1] < 0 || (uint32_t)vs[1] >= g.n_intermediates || val[vs[1]] == UNDEF)) break;
             uint32_t o; int32_t r;
             ZK_TRY(opnd(vs, &o, &r));
+            while (sw_mul_bound(vbound, SW_CONST) + bound_of(o, r) > SW_BMAX) contract(o, r);
             v.push_back({I_ACC, -1, o, 0, 0, r, -1, -1});
+            vbound = sw_mul_bound(vbound, SW_CONST) + bound_of(o, r);
             ++next_part;
         }
         return 0;
@@ -129,30 +165,51 @@ static int lower_graph(Lowering& L, const zk_graph& g, const zk_evalh_args& A, b
                 ZK_TRY(opnd(c.src[0], &o[0], &r[0]));
                 if (r[0] >= 0) {  // copy of a register: keep liveness simple, emit a move
                     v.push_back({I_MOV, c.target, o[0], 0, 0, r[0], -1, -1});
+                    rbound[c.target] = rbound[r[0]];
                     val[c.target] = NEEDS_SLOT; is_reg[c.target] = 1;
                 } else {
                     val[c.target] = o[0];  // alias: no instruction
                 }
                 break; }
-            case ZK_OP_ADD: case ZK_OP_SUB: case ZK_OP_MUL: {
+            case ZK_OP_ADD: case ZK_OP_SUB: {
                 ZK_TRY(opnd(c.src[0], &o[0], &r[0])); ZK_TRY(opnd(c.src[1], &o[1], &r[1]));
-                uint32_t op = c.op == ZK_OP_ADD ? I_ADD : c.op == ZK_OP_SUB ? I_SUB : I_MUL;
-                v.push_back({op, c.target, o[0], o[1], 0, r[0], r[1], -1}); val[c.target] = NEEDS_SLOT; is_reg[c.target] = 1;
+                if (c.op == ZK_OP_ADD) emit_add(c.target, o[0], r[0], o[1], r[1]); else emit_sub(c.target, o[0], r[0], o[1], r[1]);
+                val[c.target] = NEEDS_SLOT; is_reg[c.target] = 1;
                 break; }
-            case ZK_OP_SQUARE: case ZK_OP_DOUBLE: case ZK_OP_NEGATE: {
+            case ZK_OP_MUL: {
+                ZK_TRY(opnd(c.src[0], &o[0], &r[0])); ZK_TRY(opnd(c.src[1], &o[1], &r[1]));
+                v.push_back({I_MUL, c.target, o[0], o[1], 0, r[0], r[1], -1});
+                rbound[c.target] = sw_mul_bound(bound_of(o[0], r[0]), bound_of(o[1], r[1]));
+                val[c.target] = NEEDS_SLOT; is_reg[c.target] = 1;
+                break; }
+            case ZK_OP_SQUARE: {
                 ZK_TRY(opnd(c.src[0], &o[0], &r[0]));
-                uint32_t op = c.op == ZK_OP_SQUARE ? I_SQR : c.op == ZK_OP_DOUBLE ? I_DBL : I_NEG;
-                v.push_back({op, c.target, o[0], 0, 0, r[0], -1, -1}); val[c.target] = NEEDS_SLOT; is_reg[c.target] = 1;
+                v.push_back({I_SQR, c.target, o[0], 0, 0, r[0], -1, -1});
+                rbound[c.target] = sw_mul_bound(bound_of(o[0], r[0]), bound_of(o[0], r[0]));
+                val[c.target] = NEEDS_SLOT; is_reg[c.target] = 1;
+                break; }
+            case ZK_OP_DOUBLE: {
+                ZK_TRY(opnd(c.src[0], &o[0], &r[0]));
+                emit_add(c.target, o[0], r[0], o[0], r[0]);
+                val[c.target] = NEEDS_SLOT; is_reg[c.target] = 1;
+                break; }
+            case ZK_OP_NEGATE: {
+                ZK_TRY(opnd(c.src[0], &o[0], &r[0]));
+                emit_sub(c.target, mk_operand(K_CONST, L.c_zero), -1, o[0], r[0]);
+                val[c.target] = NEEDS_SLOT; is_reg[c.target] = 1;
                 break; }
             case ZK_OP_HORNER: {
                 uint32_t os, of; int32_t rs, rf;
                 ZK_TRY(opnd(c.src[0], &os, &rs)); ZK_TRY(opnd(c.src[1], &of, &rf));
                 v.push_back({I_MOV, c.target, os, 0, 0, rs, -1, -1});
+                rbound[c.target] = bound_of(os, rs);
                 for (size_t p = 2; p < c.src.size(); ++p) {
                     uint32_t op_; int32_t rp;
                     ZK_TRY(opnd(c.src[p], &op_, &rp));
+                    while (sw_mul_bound(rbound[c.target], bound_of(of, rf)) + bound_of(op_, rp) > SW_BMAX) contract(op_, rp);
                     // dst = dst * factor + part   (a = dst register itself)
                     v.push_back({I_MULADD, c.target, 0xf0000000u, of, op_, c.target, rf, rp});
+                    rbound[c.target] = sw_mul_bound(rbound[c.target], bound_of(of, rf)) + bound_of(op_, rp);
                 }
                 val[c.target] = NEEDS_SLOT; is_reg[c.target] = 1;
                 break; }
@@ -168,13 +225,14 @@ static int lower_graph(Lowering& L, const zk_graph& g, const zk_evalh_args& A, b
         if (val[t] == NEEDS_SLOT) result_reg = t; else result_op = val[t];
     }
     // liveness -> slots
-    std::vector<int32_t> last_use(g.n_intermediates, -1);
+    const size_t nreg = rbound.size();
+    std::vector<int32_t> last_use(nreg, -1);
     for (size_t i = 0; i < v.size(); ++i) {
         for (int32_t r : {v[i].ra, v[i].rb, v[i].rc}) if (r >= 0) last_use[r] = (int32_t)i;
         if (v[i].dst >= 0 && last_use[v[i].dst] < (int32_t)i) last_use[v[i].dst] = (int32_t)i;
     }
     if (result_reg >= 0) last_use[result_reg] = (int32_t)v.size();
-    std::vector<int32_t> slot_of(g.n_intermediates, -1);
+    std::vector<int32_t> slot_of(nreg, -1);
     std::vector<uint32_t> free_slots;
     uint32_t nslots = 0;
     sec->begin = (uint32_t)L.code.size();
@@ -195,10 +253,12 @@ static int lower_graph(Lowering& L, const zk_graph& g, const zk_evalh_args& A, b
             if (last_use[x.dst] == (int32_t)i) { free_slots.push_back(dst); slot_of[x.dst] = -2; }  // dead store
         }
         if (x.op == I_MULADD) a = mk_operand(K_SLOT, dst);
+        if (x.op == I_SUB) c = x.c;   // the k of the (k p) constant
         L.code.push_back({x.op | (dst << 8), a, b, c});
     }
     sec->end = (uint32_t)L.code.size();
     sec->result = acc_mode ? 0xffffffffu : result_reg >= 0 ? mk_operand(K_SLOT, (uint32_t)slot_of[result_reg]) : result_op;
+    sec->bound = acc_mode ? (uint32_t)vbound : result_reg >= 0 ? (uint32_t)rbound[result_reg] : (uint32_t)bound_of(result_op, -1);
     L.max_slots = std::max(L.max_slots, nslots);
     if (nslots > 0x3fff) { set_error("evaluate_h: too many live intermediates"); return ZKHIP_EPROGRAM; }
     return ZKHIP_OK;
@@ -207,11 +267,12 @@ static int lower_graph(Lowering& L, const zk_graph& g, const zk_evalh_args& A, b
 // ------------------------------------------------------------------ device
 struct SweepParams {
     const DevIns* code;
-    const uint32_t* consts;        // fe table
+    const uint32_t* consts;        // raw R'-form table
+    const uint32_t* kp;            // kp[k][9]: borrow-spread limbs of k p, k <= 120
     const int32_t* rots;
-    const uint32_t* const* cols;   // fixed ++ advice ++ instance
+    const uint32_t* const* cols;   // fixed ++ advice ++ instance (ABI form)
     uint32_t* out;
-    uint32_t isize_mask, rot_scale, nslots;
+    uint32_t isize_mask, rot_scale, nslots, final_reduce;
     Section gates;
     // permutation
     uint32_t n_perm_sets, n_perm_cols, chunk_len; int32_t last_rot;
@@ -219,7 +280,7 @@ struct SweepParams {
     const uint32_t* const* sigma;         // n_perm_cols
     const uint32_t* const* perm_z;        // n_perm_sets
     const uint32_t* l0; const uint32_t* l_last; const uint32_t* l_active;
-    const uint32_t* xtable; uint32_t half_n;  // extended_omega^i, i < isize/2
+    const uint32_t* xtable; uint32_t half_n;  // extended_omega^i, i < isize/2 (raw R' form)
     uint32_t c_beta, c_gamma, c_y, c_one, c_delta, c_delta_start;
     // lookups
     uint32_t n_lookups;
@@ -227,26 +288,48 @@ struct SweepParams {
     const uint32_t* const* lookup_z; const uint32_t* const* lookup_a; const uint32_t* const* lookup_s;
 };
 
-extern __shared__ uint32_t sweep_lds[];
+extern __shared__ uint32_t sweep_lds[];   // [slot][9][lane]
 
 __device__ __forceinline__ fe slot_read(uint32_t slot) {
     fe r;
-    const uint32_t* p = sweep_lds + (size_t)slot * 8 * blockDim.x + threadIdx.x;
+    const uint32_t* p = sweep_lds + (size_t)slot * 9 * blockDim.x + threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) r.l[i] = p[i * blockDim.x];
+    for (int i = 0; i < 9; ++i) r.l[i] = p[i * blockDim.x];
     return r;
 }
 __device__ __forceinline__ void slot_write(uint32_t slot, const fe& v) {
-    uint32_t* p = sweep_lds + (size_t)slot * 8 * blockDim.x + threadIdx.x;
+    uint32_t* p = sweep_lds + (size_t)slot * 9 * blockDim.x + threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) p[i * blockDim.x] = v.l[i];
+    for (int i = 0; i < 9; ++i) p[i * blockDim.x] = v.l[i];
 }
+// operand -> limbs.  Bounds are the host's business (see the lowering); columns enter as 32 v.
 __device__ __forceinline__ fe fetch(const SweepParams& P, uint32_t o, uint32_t row) {
     uint32_t kind = o >> 28, a = (o >> 14) & 0x3fff, b = o & 0x3fff;
     if (kind == K_SLOT) return slot_read(a);
-    if (kind == K_CONST) return fe_load(P.consts + (size_t)a * 8);
+    if (kind == K_CONST) return fe_split<0>(mem_load(P.consts + (size_t)a * 8));
     uint32_t r = (uint32_t)((int32_t)row + P.rots[b] * (int32_t)P.rot_scale) & P.isize_mask;
-    return fe_load(P.cols[a] + (size_t)r * 8);
+    return fe_split<5>(mem_load(P.cols[a] + (size_t)r * 8));
+}
+__device__ __forceinline__ fe raw_add(const fe& a, const fe& b) {
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] + b.l[i];
+    fe_normalize(r);
+    return r;
+}
+__device__ __forceinline__ fe raw_sub(const SweepParams& P, const fe& a, const fe& b, uint32_t k) {
+    fe r;
+    const uint32_t* kp = P.kp + (size_t)k * 9;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] + kp[i] - b.l[i];
+    fe_normalize(r);
+    return r;
+}
+__device__ __forceinline__ fe raw_one() {
+    fe o;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) o.l[i] = Fr::ONE[i];
+    return o;
 }
 __device__ __forceinline__ void run_section(const SweepParams& P, const Section& s, uint32_t row, fe& value, const fe& y) {
     for (uint32_t pc = s.begin; pc < s.end; ++pc) {
@@ -255,83 +338,91 @@ __device__ __forceinline__ void run_section(const SweepParams& P, const Section&
         fe a = fetch(P, in.a, row);
         fe r;
         switch (op) {
-            case I_ADD: r = fe_add<Fr>(a, fetch(P, in.b, row)); break;
-            case I_SUB: r = fe_sub<Fr>(a, fetch(P, in.b, row)); break;
-            case I_MUL: r = fe_mul<Fr>(a, fetch(P, in.b, row)); break;
-            case I_SQR: r = fe_sqr<Fr>(a); break;
-            case I_DBL: r = fe_dbl<Fr>(a); break;
-            case I_NEG: r = fe_neg<Fr>(a); break;
+            case I_ADD: r = raw_add(a, fetch(P, in.b, row)); break;
+            case I_SUB: r = raw_sub(P, a, fetch(P, in.b, row), in.c); break;
+            case I_MUL: r = fe_mul_raw<Fr>(a, fetch(P, in.b, row)); break;
+            case I_SQR: r = fe_mul_raw<Fr>(a, a); break;
             case I_MOV: r = a; break;
-            case I_MULADD: r = fe_add<Fr>(fe_mul<Fr>(a, fetch(P, in.b, row)), fetch(P, in.c, row)); break;
-            default: /* I_ACC */ value = fe_add<Fr>(fe_mul<Fr>(value, y), a); continue;
+            case I_RED: r = fe_mul_raw<Fr>(a, raw_one()); break;
+            case I_MULADD: r = raw_add(fe_mul_raw<Fr>(a, fetch(P, in.b, row)), fetch(P, in.c, row)); break;
+            default: /* I_ACC */ value = raw_add(fe_mul_raw<Fr>(value, y), a); continue;
         }
         slot_write(dst, r);
     }
 }
 
+// The fixed permutation / lookup terms are written with the typed elements, so their bounds are checked
+// at compile time; `value` and a lookup's table_value arrive from the interpreter with host-checked
+// bounds <= 120 p, which is what their types say.
+using elv = el<Fr, BMAX>;
+using elc = el<Fr, 32 * U>;   // a column value as loaded
+__device__ __forceinline__ elc ldc(const uint32_t* col, uint32_t row) { return load_x32<Fr>(col + (size_t)row * 8); }
+__device__ __forceinline__ el1<Fr> ldk(const SweepParams& P, uint32_t idx) { return load_raw<Fr>(P.consts + (size_t)idx * 8); }
+
 __global__ void __launch_bounds__(128) k_sweep(SweepParams P) {
     uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;  // isize is a multiple of the block size
-    const fe y = fe_load(P.consts + (size_t)P.c_y * 8);
-    fe value = fe_zero();
-    run_section(P, P.gates, row, value, y);
-    if (P.gates.result != 0xffffffffu) value = fetch(P, P.gates.result, row);  // 0xffffffff: `value` already holds it
+    const el1<Fr> y = ldk(P, P.c_y);
+    elv value(fe_zero());
+    run_section(P, P.gates, row, value.v, y.v);
+    if (P.gates.result != 0xffffffffu) value = elv(fetch(P, P.gates.result, row));  // 0xffffffff: `value` already holds it
 
     const uint32_t mask = P.isize_mask;
     if (P.n_perm_sets) {
-        const fe beta = fe_load(P.consts + (size_t)P.c_beta * 8), gamma = fe_load(P.consts + (size_t)P.c_gamma * 8);
-        const fe one = fe_load(P.consts + (size_t)P.c_one * 8);
+        const el1<Fr> beta = ldk(P, P.c_beta), gamma = ldk(P, P.c_gamma), k_one = ldk(P, P.c_one);
         uint32_t r_next = (row + P.rot_scale) & mask;
         uint32_t r_last = (uint32_t)((int32_t)row + P.last_rot * (int32_t)P.rot_scale) & mask;
-        fe l0 = fe_load(P.l0 + (size_t)row * 8), ll = fe_load(P.l_last + (size_t)row * 8), la = fe_load(P.l_active + (size_t)row * 8);
-        fe zf = fe_load(P.perm_z[0] + (size_t)row * 8);
-        value = fe_add<Fr>(fe_mul<Fr>(value, y), fe_mul<Fr>(fe_sub<Fr>(one, zf), l0));
-        fe zl = fe_load(P.perm_z[P.n_perm_sets - 1] + (size_t)row * 8);
-        value = fe_add<Fr>(fe_mul<Fr>(value, y), fe_mul<Fr>(fe_sub<Fr>(fe_sqr<Fr>(zl), zl), ll));
+        elc l0 = ldc(P.l0, row), ll = ldc(P.l_last, row), la = ldc(P.l_active, row);
+        elc zf = ldc(P.perm_z[0], row);
+        value = value * y + (k_one - zf) * l0;
+        elc zl = ldc(P.perm_z[P.n_perm_sets - 1], row);
+        value = value * y + (sqr(zl) - zl) * ll;
         for (uint32_t s = 1; s < P.n_perm_sets; ++s) {
-            fe zi = fe_load(P.perm_z[s] + (size_t)row * 8), zp = fe_load(P.perm_z[s - 1] + (size_t)r_last * 8);
-            value = fe_add<Fr>(fe_mul<Fr>(value, y), fe_mul<Fr>(fe_sub<Fr>(zi, zp), l0));
+            elc zi = ldc(P.perm_z[s], row), zp = ldc(P.perm_z[s - 1], r_last);
+            value = value * y + (zi - zp) * l0;
         }
         // current_delta = beta * g_coset * extended_omega^row
-        fe xw = row < P.half_n ? fe_load(P.xtable + (size_t)row * 8) : fe_neg<Fr>(fe_load(P.xtable + (size_t)(row - P.half_n) * 8));
-        fe cur = fe_mul<Fr>(fe_load(P.consts + (size_t)P.c_delta_start * 8), xw);
-        const fe delta = fe_load(P.consts + (size_t)P.c_delta * 8);
+        el2<Fr> xw;
+        if (row < P.half_n) xw = load_raw<Fr>(P.xtable + (size_t)row * 8);
+        else xw = neg(load_raw<Fr>(P.xtable + (size_t)(row - P.half_n) * 8));
+        el2<Fr> cur = ldk(P, P.c_delta_start) * xw;
+        const el1<Fr> delta = ldk(P, P.c_delta);
         for (uint32_t s = 0; s < P.n_perm_sets; ++s) {
             uint32_t c0 = s * P.chunk_len, c1 = min(c0 + P.chunk_len, P.n_perm_cols);
-            fe left = fe_load(P.perm_z[s] + (size_t)r_next * 8), right = fe_load(P.perm_z[s] + (size_t)row * 8);
+            elc left = ldc(P.perm_z[s], r_next), right = ldc(P.perm_z[s], row);
             for (uint32_t c = c0; c < c1; ++c) {
-                fe v = fe_load(P.cols[P.perm_col_slot[c]] + (size_t)row * 8);
-                fe sg = fe_load(P.sigma[c] + (size_t)row * 8);
-                left = fe_mul<Fr>(left, fe_add<Fr>(fe_add<Fr>(v, fe_mul<Fr>(beta, sg)), gamma));
-                right = fe_mul<Fr>(right, fe_add<Fr>(fe_add<Fr>(v, cur), gamma));
-                cur = fe_mul<Fr>(cur, delta);
+                elc v = ldc(P.cols[P.perm_col_slot[c]], row);
+                elc sg = ldc(P.sigma[c], row);
+                left = left * (v + beta * sg + gamma);
+                right = right * (v + cur + gamma);
+                cur = cur * delta;
             }
-            value = fe_add<Fr>(fe_mul<Fr>(value, y), fe_mul<Fr>(fe_sub<Fr>(left, right), la));
+            value = value * y + (left - right) * la;
         }
     }
     if (P.n_lookups) {
-        const fe beta = fe_load(P.consts + (size_t)P.c_beta * 8), gamma = fe_load(P.consts + (size_t)P.c_gamma * 8);
-        const fe one = fe_load(P.consts + (size_t)P.c_one * 8);
-        fe l0 = fe_load(P.l0 + (size_t)row * 8), ll = fe_load(P.l_last + (size_t)row * 8), la = fe_load(P.l_active + (size_t)row * 8);
+        const el1<Fr> beta = ldk(P, P.c_beta), gamma = ldk(P, P.c_gamma), k_one = ldk(P, P.c_one);
+        elc l0 = ldc(P.l0, row), ll = ldc(P.l_last, row), la = ldc(P.l_active, row);
         uint32_t r_next = (row + P.rot_scale) & mask, r_prev = (row - P.rot_scale) & mask;
         for (uint32_t n = 0; n < P.n_lookups; ++n) {
             Section sec = P.lookup_secs[n];
             fe dummy = fe_zero();
-            run_section(P, sec, row, dummy, y);
-            fe table_value = fetch(P, sec.result, row);
-            fe z = fe_load(P.lookup_z[n] + (size_t)row * 8), zn = fe_load(P.lookup_z[n] + (size_t)r_next * 8);
-            fe a = fe_load(P.lookup_a[n] + (size_t)row * 8), ap = fe_load(P.lookup_a[n] + (size_t)r_prev * 8);
-            fe sv = fe_load(P.lookup_s[n] + (size_t)row * 8);
-            fe a_minus_s = fe_sub<Fr>(a, sv);
-            value = fe_add<Fr>(fe_mul<Fr>(value, y), fe_mul<Fr>(fe_sub<Fr>(one, z), l0));
-            value = fe_add<Fr>(fe_mul<Fr>(value, y), fe_mul<Fr>(fe_sub<Fr>(fe_sqr<Fr>(z), z), ll));
-            fe t = fe_mul<Fr>(fe_mul<Fr>(fe_add<Fr>(a, beta), fe_add<Fr>(sv, gamma)), zn);
-            t = fe_sub<Fr>(t, fe_mul<Fr>(z, table_value));
-            value = fe_add<Fr>(fe_mul<Fr>(value, y), fe_mul<Fr>(t, la));
-            value = fe_add<Fr>(fe_mul<Fr>(value, y), fe_mul<Fr>(a_minus_s, l0));
-            value = fe_add<Fr>(fe_mul<Fr>(value, y), fe_mul<Fr>(fe_mul<Fr>(a_minus_s, fe_sub<Fr>(a, ap)), la));
+            run_section(P, sec, row, dummy, y.v);
+            elv table_value(fetch(P, sec.result, row));
+            elc z = ldc(P.lookup_z[n], row), zn = ldc(P.lookup_z[n], r_next);
+            elc a = ldc(P.lookup_a[n], row), ap = ldc(P.lookup_a[n], r_prev);
+            elc sv = ldc(P.lookup_s[n], row);
+            auto a_minus_s = a - sv;
+            value = value * y + (k_one - z) * l0;
+            value = value * y + (sqr(z) - z) * ll;
+            auto t = (a + beta) * (sv + gamma) * zn - z * table_value;
+            value = value * y + t * la;
+            value = value * y + a_minus_s * l0;
+            value = value * y + a_minus_s * (a - ap) * la;
         }
     }
-    fe_store(P.out + (size_t)row * 8, value);
+    // back to the ABI form; the host sets final_reduce when the gate program alone could leave > 88 p
+    if (P.final_reduce) value = reduce(value);
+    store_div32<Fr>(P.out + (size_t)row * 8, el<Fr, 88 * U>(value.v));
 }
 
 // ------------------------------------------------------------------ entry point
@@ -345,13 +436,12 @@ extern "C" int zkhip_evaluate_h_device(zkhip_ctx* ctx, const zk_evalh_args* A, v
     for (uint32_t i = 0; i < A->n_fixed; ++i) L.cols.push_back(A->fixed_cosets[i]);
     for (uint32_t i = 0; i < A->n_advice; ++i) L.cols.push_back(A->advice_cosets[i]);
     for (uint32_t i = 0; i < A->n_instance; ++i) L.cols.push_back(A->instance_cosets[i]);
-    auto cst = [&](const uint64_t* p) { fe v; memcpy(&v, p, 32); return L.add_const(v); };
-    L.c_zero = L.add_const(fe_zero());
-    L.c_one = L.add_const(fe_one<Fr>());
+    auto cst = [&](const uint64_t* p) { return L.add_const_abi(p); };
+    L.c_zero = L.add_const(fe_pack(fe_zero()));
+    L.c_one = L.add_const(fe_pack(fe_canonical<Fr>(one<Fr>().v)));
     L.c_beta = cst(A->beta); L.c_gamma = cst(A->gamma); L.c_theta = cst(A->theta); L.c_y = cst(A->y);
     uint32_t c_delta = cst(A->delta);
-    fe beta, gc; memcpy(&beta, A->beta, 32); memcpy(&gc, A->g_coset, 32);
-    uint32_t c_delta_start = L.add_const(fe_mul<Fr>(beta, gc));
+    uint32_t c_delta_start = L.add_const(fe_pack(fe_canonical<Fr>((from_abi<Fr>(mem_load(A->beta)) * from_abi<Fr>(mem_load(A->g_coset))).v)));
     L.c_chal0 = (uint32_t)L.consts.size();
     for (uint32_t i = 0; i < A->n_challenges; ++i) cst(A->challenges + 4 * i);
 
@@ -375,6 +465,10 @@ extern "C" int zkhip_evaluate_h_device(zkhip_ctx* ctx, const zk_evalh_args* A, v
     auto put = [&](const void* p, size_t bytes) { size_t off = (blob.size() + 31) & ~(size_t)31; blob.resize(off + bytes); if (bytes) memcpy(blob.data() + off, p, bytes); return off; };
     size_t o_code = put(L.code.data(), L.code.size() * sizeof(DevIns));
     size_t o_consts = put(L.consts.data(), L.consts.size() * 32);
+    std::vector<uint32_t> kp(121 * 9, 0);
+    for (uint32_t k = 1; k <= 120; ++k)
+        for (int i = 0; i < 9; ++i) kp[k * 9 + i] = kp_spread<Fr>(k, i);
+    size_t o_kp = put(kp.data(), kp.size() * 4);
     size_t o_rots = put(L.rots.data(), L.rots.size() * 4);
     size_t o_cols = put(L.cols.data(), L.cols.size() * sizeof(void*));
     size_t o_pslot = put(perm_slot.data(), perm_slot.size() * 4);
@@ -395,6 +489,8 @@ extern "C" int zkhip_evaluate_h_device(zkhip_ctx* ctx, const zk_evalh_args* A, v
     char* b = (char*)d_blob;
     P.code = (const DevIns*)(b + o_code);
     P.consts = (const uint32_t*)(b + o_consts);
+    P.kp = (const uint32_t*)(b + o_kp);
+    P.final_reduce = (A->n_perm_sets == 0 && A->n_lookups == 0 && gates.bound > 88 * 16) ? 1u : 0u;
     P.rots = (const int32_t*)(b + o_rots);
     P.cols = (const uint32_t* const*)(b + o_cols);
     P.out = (uint32_t*)d_out;
@@ -423,7 +519,7 @@ extern "C" int zkhip_evaluate_h_device(zkhip_ctx* ctx, const zk_evalh_args* A, v
         P.half_n = (uint32_t)(isize >> 1);
     }
     const unsigned block = isize >= 128 ? 128 : 64;
-    size_t lds = (size_t)std::max<uint32_t>(L.max_slots, 1) * 8 * 4 * block;
+    size_t lds = (size_t)std::max<uint32_t>(L.max_slots, 1) * 9 * 4 * block;
     if (lds > 160 * 1024) { set_error("zkhip_evaluate_h_device: %u live intermediates exceed the LDS budget", L.max_slots); return ZKHIP_EPROGRAM; }
     if (lds > 64 * 1024) ZK_HIP(hipFuncSetAttribute((const void*)k_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ProfScope ps(ctx, "sweep");
