@@ -96,7 +96,7 @@ def main():
     ms_per_step = dt * 1000.0 / args.steps
 
     kernels = {}
-    for name in ("msm_digits", "msm_accum_affine", "msm_accum_jac", "msm_tail", "ntt_strided", "ntt_final", "sweep"):
+    for name in ("msm_digits", "msm_plan", "msm_accum_affine", "msm_accum_jac", "msm_tail", "ntt_strided", "ntt_final", "sweep"):
         ms, launches = ctx.profile_read(name)
         kernels[name] = dict(ms_per_step=round(ms / args.steps, 4), launches_per_step=launches / args.steps)
     ctx.profile_enable(False)
@@ -109,6 +109,12 @@ def main():
         alg_bytes_per_launch = 96.0 * pairs_per_step / max(acc["launches_per_step"], 1)
         avg_launch_s = acc["ms_per_step"] / max(acc["launches_per_step"], 1) / 1000.0
         achieved = alg_bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        # the roofline that actually binds the kernel: the 32-bit integer multiplier (v_mad_u64_u32), measured at
+        # 29.8 T lane-ops/s chip-wide (profiles/r01_microbench_gfx950.txt).  One pair costs W windows x 11 field
+        # products x 171 mads.
+        c_bits, windows = backend.params.window()
+        mads_per_step = pairs_per_step * windows * 11 * 171
+        int_achieved = mads_per_step / (acc["ms_per_step"] / 1000.0) / 1e12 if acc["ms_per_step"] > 0 else 0.0
         out = {
             "metric": "create_proof wall-time (s): RSA k=17 / SHA256 k=19 / agg k=22 at 1/2/4/8 GPU",
             "value": round(ms_per_step / 1000.0, 6), "unit": "s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -125,7 +131,9 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": None,
                          "algorithmic_bytes_per_launch": round(alg_bytes_per_launch),
                          "avg_launch_ms": round(avg_launch_s * 1000.0, 4),
-                         "note": "MSM is integer-multiply bound, not HBM bound: see DESIGN.md for the mad-pipe roofline"},
+                         "note": "MSM is integer-multiply bound, not HBM bound: see int_roofline and DESIGN.md"},
+            "int_roofline": {"kernel": "msm_accum_affine", "bound": "v_mad_u64_u32 issue", "achieved": round(int_achieved, 2), "peak": 29.8,
+                             "unit": "Tmad/s", "frac": round(int_achieved / 29.8, 4), "window_bits": c_bits, "windows": windows},
             "kernels_ms_per_step": kernels,
         }
         if not args.no_cpu_baseline and world == 1:

@@ -291,8 +291,15 @@ ZK_HD __forceinline__ el<P, K * A> mul_small(const el<P, A>& a) {
     fe_normalize(r);
     return el<P, K * A>(r);
 }
+// a == 0 mod p?  If a = k p with k < A/16 then k = a_0 * p_0^-1 mod 2^29: three instructions reject every
+// other value; the exact test runs only when the filter fires (probability ~ k_max / 2^29 per lane).
 template <class P, int A>
-ZK_HD __forceinline__ bool is_zero(const el<P, A>& a) { return fe_is_zero_modp<P>(a.v); }
+ZK_HD __forceinline__ bool is_zero(const el<P, A>& a) {
+    constexpr uint32_t PINV = ((1u << LB) - P::INV) & LMASK;   // p^-1 mod 2^29
+    uint32_t k = (a.v.l[0] * PINV) & LMASK;
+    if (k >= (uint32_t)ceil_p(A)) return false;
+    return fe_is_zero_modp<P>(a.v);
+}
 template <class P, int A, int B>
 ZK_HD __forceinline__ bool equal(const el<P, A>& a, const el<P, B>& b) { return is_zero(a - b); }
 template <class P, int A>
@@ -577,13 +584,13 @@ ZK_HD inline g1j g1j_add(const g1j& p, const g1j& q) {
     return o;
 }
 
-// (x, +-y); the identity stays the exact (0, 0)
-ZK_HD __forceinline__ g1a g1a_cneg(const g1a& p, bool do_neg) {
+// table entry (canonical coordinates) -> (x, +-y) as a madd operand; the identity stays the exact (0, 0)
+ZK_HD __forceinline__ g1a g1a_load_raw_cneg(const void* p, bool do_neg) {
+    el1<Fq> x = load_raw<Fq>(p), y = load_raw<Fq>(reinterpret_cast<const char*>(p) + 32);
+    bool id = fe_is_zero_exact(x.v) && fe_is_zero_exact(y.v);
     g1a r;
-    r.x = p.x;
-    el<Fq, 3 * U> y3 = p.y;
-    el<Fq, 3 * U> s = select(do_neg && !g1a_is_id(p), neg(p.y), y3);
-    r.y = el2<Fq>(fe_cond_sub_kp<Fq>(s.v, 1));  // < 3p -> < 2p
+    r.x = x;
+    r.y = select(do_neg && !id, neg(y), el2<Fq>(y));   // 2p - y < 2p
     return r;
 }
 ZK_HD inline g1a g1j_to_affine(const g1j& p) {

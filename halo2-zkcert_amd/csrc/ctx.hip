@@ -15,7 +15,10 @@ void set_error(const char* fmt, ...) {
 using namespace zk;
 
 int zkhip_ctx::get_scratch(const char* name, size_t bytes, void** out) {
-    Scratch& s = scratch[name];
+    // scratch is private to the stream it is used on: two streams may run the same kind of call concurrently
+    char key[96];
+    snprintf(key, sizeof key, "%s@%p", name, (void*)stream);
+    Scratch& s = scratch[key];
     if (s.bytes < bytes) {
         if (s.ptr) {
             ZK_HIP(hipStreamSynchronize(stream));

@@ -149,8 +149,9 @@ int srs_build_raw(zkhip_ctx* ctx, const void* d_bases_raw, size_t n, zkhip_srs**
 // carry is zero for every canonical scalar < r < 2^254.
 template <bool SCATTER>
 __global__ void k_digits(const uint32_t* const* scalar_cols, size_t n, size_t first, size_t srs_n, uint32_t c, uint32_t W, uint32_t B,
-                         uint32_t* cnt_all, const uint32_t* off_all, uint32_t* cursor_all, uint32_t* entries_all,
-                         size_t items) {
+                         uint32_t* cnt_all, const uint32_t* off_all, uint32_t* rank_all, uint32_t* entries_all, size_t items) {
+    // pass 1 (SCATTER = false): rank[w][i] = position of pair (i, w) inside its bucket (one returning atomic);
+    // pass 2 (SCATTER = true):  entries[off[bucket] + rank] = pair — no atomics.
     __shared__ uint32_t sl[256][9];
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     uint32_t col = blockIdx.y;
@@ -160,8 +161,8 @@ __global__ void k_digits(const uint32_t* const* scalar_cols, size_t n, size_t fi
     for (int j = 0; j < 8; ++j) sl[threadIdx.x][j] = s.w[j];
     sl[threadIdx.x][8] = 0;
     uint32_t* cnt = cnt_all + (size_t)col * B;
-    const uint32_t* off = off_all + (size_t)col * (B + 1);
-    uint32_t* cursor = cursor_all + (size_t)col * B;
+    const uint32_t* off = off_all + (size_t)col * (B + 4);
+    uint32_t* rank = rank_all + (size_t)col * items;
     uint32_t* entries = entries_all + (size_t)col * items;
     uint32_t carry = 0, half = 1u << (c - 1), mask = (c == 32) ? 0xffffffffu : ((1u << c) - 1);
     for (uint32_t w = 0; w < W; ++w) {
@@ -173,55 +174,116 @@ __global__ void k_digits(const uint32_t* const* scalar_cols, size_t n, size_t fi
         if (raw > half) { mag = (1u << c) - raw; neg = 1; carry = 1; } else { mag = raw; neg = 0; carry = 0; }
         if (mag != 0) {
             if (!SCATTER) {
-                atomicAdd(&cnt[mag - 1], 1u);
+                rank[(size_t)w * n + i] = atomicAdd(&cnt[mag - 1], 1u);
             } else {
-                uint32_t pos = off[mag - 1] + atomicAdd(&cursor[mag - 1], 1u);
+                uint32_t pos = off[mag - 1] + rank[(size_t)w * n + i];
                 entries[pos] = (uint32_t)(w * srs_n + first + i) | (neg << 31);
             }
         }
     }
 }
 
-// One block per column.  off_in (if non-null) = exclusive scan of cnt_in; cnt_out = ceil(cnt_in / seg);
-// off_out = exclusive scan of cnt_out (B+1 entries); max_out[col] = max cnt_in.
-__global__ void __launch_bounds__(1024) k_plan(const uint32_t* cnt_in_all, uint32_t B, uint32_t seg, uint32_t* off_in_all,
+// One block (1024 threads) per column: off_in (if non-null) = exclusive scan of cnt_in; cnt_out = ceil(cnt_in / seg);
+// off_out = exclusive scan of cnt_out (B + 1 entries each); max_out[col] = max cnt_in.
+// Tiles of 1024 x PER counters; every thread keeps its PER consecutive counters in registers (16-byte loads,
+// all in flight at once), wave-level shuffles do the scan, a running carry links the tiles.
+// ceil(v / seg) without a hardware divide: seg_magic = ceil(2^32 / seg); exact for v * seg < 2^32 (v < 2^26, seg <= 64).
+__device__ __forceinline__ uint32_t ceil_div_magic(uint32_t v, uint32_t seg, uint32_t seg_magic) {
+    return seg == 1 ? v : __umulhi(v + seg - 1, seg_magic);
+}
+template <int PER>
+__global__ void __launch_bounds__(1024) k_plan(const uint32_t* cnt_in_all, uint32_t B, uint32_t seg, uint32_t seg_magic, uint32_t* off_in_all,
                                                uint32_t* cnt_out_all, uint32_t* off_out_all, uint32_t* max_out) {
-    __shared__ uint32_t s_a[1024], s_b[1024], s_m[1024];
-    uint32_t col = blockIdx.x, t = threadIdx.x;
+    __shared__ uint32_t w_a[16], w_b[16], w_m[16];
+    uint32_t col = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t* cnt_in = cnt_in_all + (size_t)col * B;
-    uint32_t* off_in = off_in_all ? off_in_all + (size_t)col * (B + 1) : nullptr;
+    uint32_t* off_in = off_in_all ? off_in_all + (size_t)col * (B + 4) : nullptr;
     uint32_t* cnt_out = cnt_out_all ? cnt_out_all + (size_t)col * B : nullptr;
-    uint32_t* off_out = off_out_all ? off_out_all + (size_t)col * (B + 1) : nullptr;
-    uint32_t per = (B + 1023) / 1024, lo = t * per, hi = min(lo + per, B);
-    uint32_t sa = 0, sb = 0, m = 0;
-    for (uint32_t b = lo; b < hi; ++b) {
-        uint32_t v = cnt_in[b];
-        sa += v;
-        sb += (v + seg - 1) / seg;
-        m = max(m, v);
-    }
-    s_a[t] = sa; s_b[t] = sb; s_m[t] = m;
-    __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
-        uint32_t va = 0, vb = 0, vm = 0;
-        if (t >= d) { va = s_a[t - d]; vb = s_b[t - d]; vm = s_m[t - d]; }
+    uint32_t* off_out = off_out_all ? off_out_all + (size_t)col * (B + 4) : nullptr;
+    uint32_t carry_a = 0, carry_b = 0, gmax = 0;
+    for (uint32_t tile0 = 0; tile0 < B; tile0 += 1024 * PER) {
+        uint32_t lo = tile0 + t * PER;
+        uint32_t v[PER];
+        if (PER >= 4 && lo + PER <= B) {
+#pragma unroll
+            for (int q = 0; q < PER / 4; ++q) {
+                uint4 x = reinterpret_cast<const uint4*>(cnt_in + lo)[q];
+                v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < PER; ++q) v[q] = lo + q < B ? cnt_in[lo + q] : 0u;
+        }
+        uint32_t sa = 0, sb = 0, m = 0;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) { sa += v[q]; sb += ceil_div_magic(v[q], seg, seg_magic); m = max(m, v[q]); }
+        uint32_t ia = sa, ib = sb, im = m;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t ua = __shfl_up(ia, d), ub = __shfl_up(ib, d);
+            if ((int)lane >= d) { ia += ua; ib += ub; }
+            im = max(im, __shfl_xor(im, d));
+        }
+        __syncthreads();   // previous tile's totals have been consumed
+        if (lane == 63) { w_a[wave] = ia; w_b[wave] = ib; }
+        if (lane == 0) w_m[wave] = im;
         __syncthreads();
-        s_a[t] += va; s_b[t] += vb; s_m[t] = max(s_m[t], vm);
-        __syncthreads();
+        uint32_t base_a = carry_a, base_b = carry_b, tot_a = 0, tot_b = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            if (w < (int)wave) { base_a += w_a[w]; base_b += w_b[w]; }
+            tot_a += w_a[w]; tot_b += w_b[w]; gmax = max(gmax, w_m[w]);
+        }
+        uint32_t ra = base_a + ia - sa, rb = base_b + ib - sb;  // exclusive prefix of this thread's counters
+        if (PER >= 4 && lo + PER <= B) {
+            // 16-byte stores; the per-column stride of the offset arrays is B + 4 entries to keep them aligned
+            uint32_t oa[PER], ob[PER], oc[PER];
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                uint32_t sv = ceil_div_magic(v[q], seg, seg_magic);
+                oa[q] = ra; ob[q] = rb; oc[q] = sv;
+                ra += v[q]; rb += sv;
+            }
+            const bool al_in = off_in && ((reinterpret_cast<uintptr_t>(off_in + lo) & 15) == 0);
+            const bool al_out = off_out && ((reinterpret_cast<uintptr_t>(off_out + lo) & 15) == 0);
+#pragma unroll
+            for (int q = 0; q < PER / 4; ++q) {
+                if (off_in) {
+                    if (al_in) reinterpret_cast<uint4*>(off_in + lo)[q] = make_uint4(oa[4 * q], oa[4 * q + 1], oa[4 * q + 2], oa[4 * q + 3]);
+                    else { off_in[lo + 4 * q] = oa[4 * q]; off_in[lo + 4 * q + 1] = oa[4 * q + 1]; off_in[lo + 4 * q + 2] = oa[4 * q + 2]; off_in[lo + 4 * q + 3] = oa[4 * q + 3]; }
+                }
+                if (off_out) {
+                    if (al_out) reinterpret_cast<uint4*>(off_out + lo)[q] = make_uint4(ob[4 * q], ob[4 * q + 1], ob[4 * q + 2], ob[4 * q + 3]);
+                    else { off_out[lo + 4 * q] = ob[4 * q]; off_out[lo + 4 * q + 1] = ob[4 * q + 1]; off_out[lo + 4 * q + 2] = ob[4 * q + 2]; off_out[lo + 4 * q + 3] = ob[4 * q + 3]; }
+                }
+                if (cnt_out) reinterpret_cast<uint4*>(cnt_out + lo)[q] = make_uint4(oc[4 * q], oc[4 * q + 1], oc[4 * q + 2], oc[4 * q + 3]);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                if (lo + q < B) {
+                    uint32_t sv = ceil_div_magic(v[q], seg, seg_magic);
+                    if (off_in) off_in[lo + q] = ra;
+                    if (off_out) off_out[lo + q] = rb;
+                    if (cnt_out) cnt_out[lo + q] = sv;
+                    ra += v[q]; rb += sv;
+                }
+            }
+        }
+        carry_a += tot_a; carry_b += tot_b;
     }
-    uint32_t ra = s_a[t] - sa, rb = s_b[t] - sb;  // exclusive prefix of this thread's chunk
-    for (uint32_t b = lo; b < hi; ++b) {
-        uint32_t v = cnt_in[b], sv = (v + seg - 1) / seg;
-        if (off_in) off_in[b] = ra;
-        if (off_out) off_out[b] = rb;
-        if (cnt_out) cnt_out[b] = sv;
-        ra += v; rb += sv;
+    if (t == 0) {
+        if (off_in) off_in[B] = carry_a;
+        if (off_out) off_out[B] = carry_b;
+        if (max_out) max_out[col] = gmax;
     }
-    if (t == 1023) {
-        if (off_in) off_in[B] = s_a[1023];
-        if (off_out) off_out[B] = s_b[1023];
-        if (max_out) max_out[col] = s_m[1023];
-    }
+}
+static void launch_plan(hipStream_t st, unsigned ncols, const uint32_t* cnt_in, uint32_t B, uint32_t seg, uint32_t* off_in,
+                        uint32_t* cnt_out, uint32_t* off_out, uint32_t* max_out) {
+    uint32_t magic = seg > 1 ? (uint32_t)((((uint64_t)1 << 32) + seg - 1) / seg) : 0;
+    if (B >= 32768) hipLaunchKernelGGL(k_plan<32>, dim3(ncols), dim3(1024), 0, st, cnt_in, B, seg, magic, off_in, cnt_out, off_out, max_out);
+    else if (B >= 4096) hipLaunchKernelGGL(k_plan<4>, dim3(ncols), dim3(1024), 0, st, cnt_in, B, seg, magic, off_in, cnt_out, off_out, max_out);
+    else hipLaunchKernelGGL(k_plan<1>, dim3(ncols), dim3(1024), 0, st, cnt_in, B, seg, magic, off_in, cnt_out, off_out, max_out);
 }
 
 __device__ __forceinline__ uint32_t find_bucket(const uint32_t* off, uint32_t B, uint32_t t) {
@@ -235,25 +297,25 @@ __device__ __forceinline__ uint32_t find_bucket(const uint32_t* off, uint32_t B,
 }
 
 // Round 0: segment sums of (sign, precomputed affine point) pairs.
-__global__ void __launch_bounds__(256) k_accum_affine(const uint32_t* table, const uint32_t* entries_all, size_t items,
+__global__ void __launch_bounds__(256) k_accum_affine(const uint32_t* const* tables, const uint32_t* entries_all, size_t items,
                                                       const uint32_t* cnt_all, const uint32_t* off_all,
                                                       const uint32_t* segoff_all, uint32_t B, uint32_t seg,
                                                       uint32_t* partial_all, size_t partial_stride) {
     uint32_t col = blockIdx.y;
-    const uint32_t* segoff = segoff_all + (size_t)col * (B + 1);
+    const uint32_t* segoff = segoff_all + (size_t)col * (B + 4);
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= segoff[B]) return;
     const uint32_t* cnt = cnt_all + (size_t)col * B;
-    const uint32_t* off = off_all + (size_t)col * (B + 1);
+    const uint32_t* off = off_all + (size_t)col * (B + 4);
     const uint32_t* entries = entries_all + (size_t)col * items;
+    const uint32_t* table = tables[col];
     uint32_t b = find_bucket(segoff, B, t);
     uint32_t s = t - segoff[b];
     uint32_t lo = off[b] + s * seg, hi = min(lo + seg, off[b] + cnt[b]);
     g1j acc = g1j_identity();
     for (uint32_t j = lo; j < hi; ++j) {
         uint32_t e = entries[j];
-        g1a p = g1a_load_raw(table + (size_t)(e & 0x7fffffffu) * 16);
-        acc = g1j_add_mixed(acc, g1a_cneg(p, (e >> 31) != 0));
+        acc = g1j_add_mixed(acc, g1a_load_raw_cneg(table + (size_t)(e & 0x7fffffffu) * 16, (e >> 31) != 0));
     }
     g1j_store_raw(partial_all + ((size_t)col * partial_stride + t) * 24, acc);
 }
@@ -262,11 +324,11 @@ __global__ void __launch_bounds__(256) k_accum_jac(const uint32_t* in_all, size_
                                                    const uint32_t* off_all, const uint32_t* segoff_all, uint32_t B,
                                                    uint32_t seg, uint32_t* out_all, size_t out_stride) {
     uint32_t col = blockIdx.y;
-    const uint32_t* segoff = segoff_all + (size_t)col * (B + 1);
+    const uint32_t* segoff = segoff_all + (size_t)col * (B + 4);
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= segoff[B]) return;
     const uint32_t* cnt = cnt_all + (size_t)col * B;
-    const uint32_t* off = off_all + (size_t)col * (B + 1);
+    const uint32_t* off = off_all + (size_t)col * (B + 4);
     const uint32_t* in = in_all + (size_t)col * in_stride * 24;
     uint32_t b = find_bucket(segoff, B, t);
     uint32_t s = t - segoff[b];
@@ -276,46 +338,54 @@ __global__ void __launch_bounds__(256) k_accum_jac(const uint32_t* in_all, size_
     g1j_store_raw(out_all + ((size_t)col * out_stride + t) * 24, acc);
 }
 
-// sum_{b} (b+1) * S_b over CH consecutive buckets per thread (running-sum trick + base * run).
-__global__ void __launch_bounds__(256) k_bucket_chunks(const uint32_t* part_all, size_t part_stride, const uint32_t* cnt_all,
-                                                       const uint32_t* off_all, uint32_t B, uint32_t CH, uint32_t* out_all,
-                                                       uint32_t nchunks) {
-    uint32_t col = blockIdx.y;
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nchunks) return;
-    const uint32_t* cnt = cnt_all + (size_t)col * B;
-    const uint32_t* off = off_all + (size_t)col * (B + 1);
-    const uint32_t* part = part_all + (size_t)col * part_stride * 24;
-    uint32_t base = t * CH;
-    g1j run = g1j_identity(), acc = g1j_identity();
-    for (int j = (int)CH - 1; j >= 0; --j) {
-        uint32_t b = base + (uint32_t)j;
-        if (b < B && cnt[b]) run = g1j_add(run, g1j_load_raw(part + (size_t)off[b] * 24));
-        acc = g1j_add(acc, run);
-    }
-    // + base * run
-    g1j d = run;
-    uint32_t m = base;
-    while (m) {
-        if (m & 1) acc = g1j_add(acc, d);
-        m >>= 1;
-        if (m) d = g1j_double(d);
-    }
-    g1j_store_raw(out_all + ((size_t)col * nchunks + t) * 24, acc);
-}
-
-__global__ void __launch_bounds__(512) k_final_sum(const uint32_t* in_all, uint32_t count, uint32_t* out_all) {
-    __shared__ g1j sh[512];
-    uint32_t col = blockIdx.x, t = threadIdx.x;
-    const uint32_t* in = in_all + (size_t)col * count * 24;
-    g1j acc = g1j_identity();
-    for (uint32_t i = t; i < count; i += 512) acc = g1j_add(acc, g1j_load_raw(in + (size_t)i * 24));
-    sh[t] = acc;
+__device__ __forceinline__ void block_tree_sum(g1j* sh, uint32_t t, uint32_t nthreads, const g1j& mine) {
+    sh[t] = mine;
     __syncthreads();
-    for (uint32_t d = 256; d >= 1; d >>= 1) {
+    for (uint32_t d = nthreads >> 1; d >= 1; d >>= 1) {
         if (t < d) sh[t] = g1j_add(sh[t], sh[t + d]);
         __syncthreads();
     }
+}
+// sum_{b} (b+1) * S_b over CH consecutive buckets per thread (running-sum trick + base * run), then a
+// tree over the block's 256 threads: one partial sum per block.
+__global__ void __launch_bounds__(256) k_bucket_chunks(const uint32_t* part_all, size_t part_stride, const uint32_t* cnt_all,
+                                                       const uint32_t* off_all, uint32_t B, uint32_t CH, uint32_t* out_all,
+                                                       uint32_t nchunks) {
+    __shared__ g1j sh[256];
+    uint32_t col = blockIdx.y;
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    g1j acc = g1j_identity();
+    if (t < nchunks) {
+        const uint32_t* cnt = cnt_all + (size_t)col * B;
+        const uint32_t* off = off_all + (size_t)col * (B + 4);
+        const uint32_t* part = part_all + (size_t)col * part_stride * 24;
+        uint32_t base = t * CH;
+        g1j run = g1j_identity();
+        for (int j = (int)CH - 1; j >= 0; --j) {
+            uint32_t b = base + (uint32_t)j;
+            if (b < B && cnt[b]) run = g1j_add(run, g1j_load_raw(part + (size_t)off[b] * 24));
+            acc = g1j_add(acc, run);
+        }
+        // + base * run
+        g1j d = run;
+        uint32_t m = base;
+        while (m) {
+            if (m & 1) acc = g1j_add(acc, d);
+            m >>= 1;
+            if (m) d = g1j_double(d);
+        }
+    }
+    block_tree_sum(sh, threadIdx.x, 256, acc);
+    if (threadIdx.x == 0) g1j_store_raw(out_all + ((size_t)col * gridDim.x + blockIdx.x) * 24, sh[0]);
+}
+
+__global__ void __launch_bounds__(64) k_final_sum(const uint32_t* in_all, uint32_t count, uint32_t* out_all) {
+    __shared__ g1j sh[64];
+    uint32_t col = blockIdx.x, t = threadIdx.x;
+    const uint32_t* in = in_all + (size_t)col * count * 24;
+    g1j acc = g1j_identity();
+    for (uint32_t i = t; i < count; i += 64) acc = g1j_add(acc, g1j_load_raw(in + (size_t)i * 24));
+    block_tree_sum(sh, t, 64, acc);
     if (t == 0) g1j_store_abi(out_all + (size_t)col * 24, sh[0]);   // the ABI result: halo2curves G1 (R = 2^256)
 }
 __global__ void k_set_identity(uint32_t* out_all, uint32_t ncols) {
@@ -325,8 +395,16 @@ __global__ void k_set_identity(uint32_t* out_all, uint32_t ncols) {
 
 // ------------------------------------------------------------------ host driver
 // columns hold at least first + n scalars; scalar first + i pairs with base first + i.
-static int msm_run(zkhip_ctx* ctx, const zkhip_srs* srs, const void* const* d_cols_host, size_t ncols, size_t first, size_t n, void* d_out) {
-    if (!ctx || !srs || !d_cols_host || !d_out) { set_error("zkhip_msm: null argument"); return ZKHIP_EINVAL; }
+static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const void* const* d_cols_host, size_t ncols, size_t first, size_t n,
+                   void* d_out) {
+    if (!ctx || !srs_per_col || !d_cols_host || !d_out) { set_error("zkhip_msm: null argument"); return ZKHIP_EINVAL; }
+    if (ncols == 0) return ZKHIP_OK;
+    const zkhip_srs* srs = srs_per_col[0];
+    for (size_t j = 0; j < ncols; ++j) {
+        const zkhip_srs* q = srs_per_col[j];
+        if (!q) { set_error("zkhip_msm: null SRS for column %zu", j); return ZKHIP_EINVAL; }
+        if (q->n != srs->n || q->c != srs->c) { set_error("zkhip_msm: the SRS of column %zu has a different size", j); return ZKHIP_EINVAL; }
+    }
     if (first + n > srs->n) { set_error("zkhip_msm: range [%zu, %zu) exceeds the %zu bases loaded", first, first + n, srs->n); return ZKHIP_EINVAL; }
     if (ncols == 0) return ZKHIP_OK;
     hipStream_t st = ctx->stream;
@@ -339,37 +417,47 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* srs, const void* const* d_co
     const size_t items = n * W;
     const uint32_t seg0_min = 8;
     // scratch
-    void *d_colptrs, *d_cnt, *d_off, *d_cursor, *d_entries, *d_max, *d_cntA, *d_cntB, *d_offA, *d_offB, *d_pA, *d_pB, *d_chunks;
+    void *d_colptrs, *d_cnt, *d_off, *d_rank, *d_entries, *d_max, *d_cntA, *d_cntB, *d_offA, *d_offB, *d_pA, *d_pB, *d_chunks;
     const size_t pstride0 = items / seg0_min + B + 1;
-    ZK_TRY(ctx->get_scratch("msm_colptrs", ncols * sizeof(void*), &d_colptrs));
-    ZK_TRY(ctx->get_scratch("msm_cnt", ncols * B * 4 * 2, &d_cnt));  // cnt + cursor, zeroed together
-    d_cursor = (char*)d_cnt + ncols * B * 4;
-    ZK_TRY(ctx->get_scratch("msm_off", ncols * (B + 1) * 4, &d_off));
+    ZK_TRY(ctx->get_scratch("msm_colptrs", 2 * ncols * sizeof(void*), &d_colptrs));
+    ZK_TRY(ctx->get_scratch("msm_cnt", ncols * B * 4, &d_cnt));
+    ZK_TRY(ctx->get_scratch("msm_rank", ncols * items * 4, &d_rank));
+    ZK_TRY(ctx->get_scratch("msm_off", ncols * (B + 4) * 4, &d_off));
     ZK_TRY(ctx->get_scratch("msm_entries", ncols * items * 4, &d_entries));
     ZK_TRY(ctx->get_scratch("msm_max", ncols * 4, &d_max));
     ZK_TRY(ctx->get_scratch("msm_cntA", ncols * B * 4, &d_cntA));
     ZK_TRY(ctx->get_scratch("msm_cntB", ncols * B * 4, &d_cntB));
-    ZK_TRY(ctx->get_scratch("msm_offA", ncols * (B + 1) * 4, &d_offA));
-    ZK_TRY(ctx->get_scratch("msm_offB", ncols * (B + 1) * 4, &d_offB));
+    ZK_TRY(ctx->get_scratch("msm_offA", ncols * (B + 4) * 4, &d_offA));
+    ZK_TRY(ctx->get_scratch("msm_offB", ncols * (B + 4) * 4, &d_offB));
     ZK_TRY(ctx->get_scratch("msm_pA", ncols * pstride0 * 96, &d_pA));
     ZK_TRY(ctx->get_scratch("msm_pB", ncols * pstride0 * 96, &d_pB));
     uint32_t CH = B > 8192 ? B / 8192 : 1;
     uint32_t nchunks = (B + CH - 1) / CH;
-    ZK_TRY(ctx->get_scratch("msm_chunks", ncols * (size_t)nchunks * 96, &d_chunks));
+    uint32_t nchunk_blocks = div_up(nchunks, 256);
+    ZK_TRY(ctx->get_scratch("msm_chunks", ncols * (size_t)nchunk_blocks * 96, &d_chunks));
 
-    ZK_HIP(hipMemcpyAsync(d_colptrs, d_cols_host, ncols * sizeof(void*), hipMemcpyHostToDevice, st));
-    ZK_HIP(hipMemsetAsync(d_cnt, 0, ncols * B * 4 * 2, st));
+    std::vector<const void*> h_ptrs(2 * ncols);
+    for (size_t j = 0; j < ncols; ++j) { h_ptrs[j] = d_cols_host[j]; h_ptrs[ncols + j] = srs_per_col[j]->d_table; }
+    ZK_HIP(hipMemcpyAsync(d_colptrs, h_ptrs.data(), 2 * ncols * sizeof(void*), hipMemcpyHostToDevice, st));
+    ZK_HIP(hipMemsetAsync(d_cnt, 0, ncols * B * 4, st));
     dim3 gn(div_up(n, 256), (unsigned)ncols);
+    // Round-0 segment length depends on the problem size only: aim for ~2 waves per SIMD over the chip.
+    uint32_t seg = seg0_min;
+    {
+        size_t target_threads = (size_t)256 * 4 * 64 * 4;
+        size_t sgl = (ncols * items) / target_threads;
+        if (sgl > seg) seg = (uint32_t)std::min<size_t>(sgl, 64);
+    }
     { ProfScope ps(ctx, "msm_digits");
     hipLaunchKernelGGL(k_digits<false>, gn, dim3(256), 0, st, (const uint32_t* const*)d_colptrs, n, first, srs->n, c, W, B, (uint32_t*)d_cnt,
-                       (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, items); }
-    hipLaunchKernelGGL(k_plan, dim3((unsigned)ncols), dim3(1024), 0, st, (const uint32_t*)d_cnt, B, 1u, (uint32_t*)d_off,
-                       (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)d_max);
+                       (const uint32_t*)nullptr, (uint32_t*)d_rank, (uint32_t*)nullptr, items); }
+    { ProfScope ps(ctx, "msm_plan");
+    launch_plan(st, (unsigned)ncols, (const uint32_t*)d_cnt, B, seg, (uint32_t*)d_off, (uint32_t*)d_cntA, (uint32_t*)d_offA, (uint32_t*)d_max); }
     std::vector<uint32_t> h_max(ncols);
     ZK_HIP(hipMemcpyAsync(h_max.data(), d_max, ncols * 4, hipMemcpyDeviceToHost, st));
     { ProfScope ps(ctx, "msm_digits");
     hipLaunchKernelGGL(k_digits<true>, gn, dim3(256), 0, st, (const uint32_t* const*)d_colptrs, n, first, srs->n, c, W, B, (uint32_t*)d_cnt,
-                       (const uint32_t*)d_off, (uint32_t*)d_cursor, (uint32_t*)d_entries, items); }
+                       (const uint32_t*)d_off, (uint32_t*)d_rank, (uint32_t*)d_entries, items); }
     ZK_LAUNCH_CHECK();
     ZK_HIP(hipStreamSynchronize(st));
     uint32_t maxcnt = 0;
@@ -379,24 +467,16 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* srs, const void* const* d_co
         ZK_LAUNCH_CHECK();
         return ZKHIP_OK;
     }
-    // Round 0 segment length: aim for ~2 waves per SIMD over the whole chip, never below seg0_min.
-    uint32_t seg = seg0_min;
-    {
-        size_t target_threads = (size_t)256 * 4 * 64 * 4;
-        size_t s = (ncols * items) / target_threads;
-        if (s > seg) seg = (uint32_t)std::min<size_t>(s, 64);
-    }
-    // round 0
+    // round 0 (its plan was computed together with the bucket offsets)
     const uint32_t* cur_cnt = (const uint32_t*)d_cnt;
     const uint32_t* cur_off = (const uint32_t*)d_off;
     uint32_t* nxt_cnt = (uint32_t*)d_cntA;
     uint32_t* nxt_off = (uint32_t*)d_offA;
-    hipLaunchKernelGGL(k_plan, dim3((unsigned)ncols), dim3(1024), 0, st, cur_cnt, B, seg, (uint32_t*)nullptr, nxt_cnt, nxt_off,
-                       (uint32_t*)nullptr);
     size_t bound = items / seg + B + 1;
     if (bound > pstride0) bound = pstride0;
     { ProfScope ps(ctx, "msm_accum_affine");
-    hipLaunchKernelGGL(k_accum_affine, dim3(div_up(bound, 256), (unsigned)ncols), dim3(256), 0, st, (const uint32_t*)srs->d_table,
+    hipLaunchKernelGGL(k_accum_affine, dim3(div_up(bound, 256), (unsigned)ncols), dim3(256), 0, st,
+                       (const uint32_t* const*)((const void**)d_colptrs + ncols),
                        (const uint32_t*)d_entries, items, cur_cnt, cur_off, (const uint32_t*)nxt_off, B, seg, (uint32_t*)d_pA,
                        pstride0); }
     uint32_t* cur_p = (uint32_t*)d_pA;
@@ -406,8 +486,8 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* srs, const void* const* d_co
     maxcnt = (maxcnt + seg - 1) / seg;
     while (maxcnt > 1) {
         seg = maxcnt <= 16 ? maxcnt : 8;
-        hipLaunchKernelGGL(k_plan, dim3((unsigned)ncols), dim3(1024), 0, st, cur_cnt, B, seg, (uint32_t*)nullptr, nxt_cnt, nxt_off,
-                           (uint32_t*)nullptr);
+        { ProfScope ps(ctx, "msm_plan");
+        launch_plan(st, (unsigned)ncols, cur_cnt, B, seg, (uint32_t*)nullptr, nxt_cnt, nxt_off, (uint32_t*)nullptr); }
         size_t nb = bound / seg + B + 1;
         if (nb > pstride0) nb = pstride0;
         { ProfScope ps(ctx, "msm_accum_jac");
@@ -422,9 +502,9 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* srs, const void* const* d_co
         maxcnt = (maxcnt + seg - 1) / seg;
     }
     { ProfScope ps(ctx, "msm_tail");
-    hipLaunchKernelGGL(k_bucket_chunks, dim3(div_up(nchunks, 256), (unsigned)ncols), dim3(256), 0, st, (const uint32_t*)cur_p, pstride0,
+    hipLaunchKernelGGL(k_bucket_chunks, dim3(nchunk_blocks, (unsigned)ncols), dim3(256), 0, st, (const uint32_t*)cur_p, pstride0,
                        cur_cnt, cur_off, B, CH, (uint32_t*)d_chunks, nchunks);
-    hipLaunchKernelGGL(k_final_sum, dim3((unsigned)ncols), dim3(512), 0, st, (const uint32_t*)d_chunks, nchunks, (uint32_t*)d_out); }
+    hipLaunchKernelGGL(k_final_sum, dim3((unsigned)ncols), dim3(64), 0, st, (const uint32_t*)d_chunks, nchunk_blocks, (uint32_t*)d_out); }
     ZK_LAUNCH_CHECK();
     return ZKHIP_OK;
 }
@@ -450,6 +530,10 @@ void zkhip_srs_free(zkhip_ctx* ctx, zkhip_srs* s) {
     delete s;
 }
 size_t zkhip_srs_len(const zkhip_srs* s) { return s ? s->n : 0; }
+void zkhip_srs_window(const zkhip_srs* s, uint32_t* c, uint32_t* windows) {
+    if (c) *c = s ? s->c : 0;
+    if (windows) *windows = s ? s->W : 0;
+}
 int zkhip_srs_read(zkhip_ctx* ctx, const zkhip_srs* s, size_t first, size_t count, uint64_t* out_xy) {
     if (!ctx || !s || !out_xy || first + count > s->n) { set_error("zkhip_srs_read: bad range"); return ZKHIP_EINVAL; }
     ZK_HIP(hipMemcpyAsync(out_xy, (const char*)s->d_table + first * 64, count * 64, hipMemcpyDeviceToHost, ctx->stream));
@@ -460,11 +544,17 @@ int zkhip_srs_read(zkhip_ctx* ctx, const zkhip_srs* s, size_t first, size_t coun
 
 int zkhip_msm_g1_batch_device(zkhip_ctx* ctx, const zkhip_srs* srs, const void* const* d_scalar_cols, size_t ncols, size_t n,
                               void* d_out_xyz) {
-    return msm_run(ctx, srs, d_scalar_cols, ncols, 0, n, d_out_xyz);
+    std::vector<const zkhip_srs*> v(ncols, srs);
+    return msm_run(ctx, v.data(), d_scalar_cols, ncols, 0, n, d_out_xyz);
+}
+int zkhip_msm_g1_multi_device(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const void* const* d_scalar_cols, size_t ncols,
+                              size_t first, size_t count, void* d_out_xyz) {
+    return msm_run(ctx, srs_per_col, d_scalar_cols, ncols, first, count, d_out_xyz);
 }
 int zkhip_msm_g1_batch_range_device(zkhip_ctx* ctx, const zkhip_srs* srs, const void* const* d_scalar_cols, size_t ncols, size_t first,
                                     size_t count, void* d_out_xyz) {
-    return msm_run(ctx, srs, d_scalar_cols, ncols, first, count, d_out_xyz);
+    std::vector<const zkhip_srs*> v(ncols, srs);
+    return msm_run(ctx, v.data(), d_scalar_cols, ncols, first, count, d_out_xyz);
 }
 
 int zkhip_msm_g1(zkhip_ctx* ctx, const zkhip_srs* srs, const uint64_t* scalars, size_t n, uint64_t out_xyz[12]) {
@@ -474,7 +564,8 @@ int zkhip_msm_g1(zkhip_ctx* ctx, const zkhip_srs* srs, const uint64_t* scalars, 
     ZK_TRY(ctx->get_scratch("msm_host_out", 96, &d_o));
     if (n) ZK_HIP(hipMemcpyAsync(d_s, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
     const void* cols[1] = {d_s};
-    ZK_TRY(msm_run(ctx, srs, cols, 1, 0, n, d_o));
+    const zkhip_srs* one_srs[1] = {srs};
+    ZK_TRY(msm_run(ctx, one_srs, cols, 1, 0, n, d_o));
     uint64_t jac[12];
     ZK_HIP(hipMemcpyAsync(jac, d_o, 96, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(hipStreamSynchronize(ctx->stream));

@@ -57,6 +57,7 @@ int zkhip_ctx::get_twiddles(const uint64_t omega[4], uint32_t log_n, const void*
     el2<Fr> w = from_abi<Fr>(mem_load(omega));
     hipLaunchKernelGGL(k_twiddles, dim3(div_up(div_up(half_n, 64), 64)), dim3(64), 0, stream, (uint32_t*)t.d_table, half_n, w.v);
     ZK_LAUNCH_CHECK();
+    ZK_HIP(hipStreamSynchronize(stream));   // one-time: the table is shared by every stream of the context
     twiddles.push_back(t);
     *d_table = t.d_table;
     return ZKHIP_OK;

@@ -56,7 +56,7 @@ void zkt_g1_sum_mixed(const uint64_t* pts_abi, const uint8_t* negs, size_t n, ui
     for (size_t i = 0; i < n; ++i) {
         uint64_t raw[8];
         g1a_store_raw(raw, g1a_load_abi(pts_abi + 8 * i));
-        acc = g1j_add_mixed(acc, g1a_cneg(g1a_load_raw(raw), negs[i] != 0));
+        acc = g1j_add_mixed(acc, g1a_load_raw_cneg(raw, negs[i] != 0));
         if (i % 7 == 3) {  // round-trip the accumulator through the scratch format too
             uint64_t j[12];
             g1j_store_raw(j, acc);

@@ -54,7 +54,9 @@ extern "C" int zkhip_fixed_base_mul_device(zkhip_ctx* ctx, const void* d_scalars
     if (!ctx || !d_scalars || !d_out_xy) { set_error("zkhip_fixed_base_mul_device: null argument"); return ZKHIP_EINVAL; }
     if (n == 0) return ZKHIP_OK;
     void *d_table, *d_jac;
-    auto it = ctx->scratch.find("fixed_base_table");
+    char key[96];
+    snprintf(key, sizeof key, "fixed_base_table@%p", (void*)ctx->stream);
+    auto it = ctx->scratch.find(key);
     bool have = it != ctx->scratch.end() && it->second.ptr;
     ZK_TRY(ctx->get_scratch("fixed_base_table", 32 * 256 * 64, &d_table));
     ZK_TRY(ctx->get_scratch("fixed_base_jac", n * 96, &d_jac));

@@ -49,8 +49,8 @@ SYMBOLS = [
     "zkhip_init", "zkhip_destroy", "zkhip_last_error", "zkhip_set_stream", "zkhip_synchronize", "zkhip_malloc", "zkhip_free",
     "zkhip_memcpy_h2d", "zkhip_memcpy_d2h", "zkhip_timer_start", "zkhip_timer_stop_ms",
     "zkhip_profile_enable", "zkhip_profile_read",
-    "zkhip_srs_load", "zkhip_srs_load_device", "zkhip_srs_free", "zkhip_srs_len", "zkhip_kzg_setup", "zkhip_srs_read",
-    "zkhip_msm_g1", "zkhip_msm_g1_batch_device", "zkhip_msm_g1_batch_range_device", "zkhip_g1_add", "zkhip_g1_to_affine",
+    "zkhip_srs_load", "zkhip_srs_load_device", "zkhip_srs_free", "zkhip_srs_len", "zkhip_srs_window", "zkhip_kzg_setup", "zkhip_srs_read",
+    "zkhip_msm_g1", "zkhip_msm_g1_batch_device", "zkhip_msm_g1_batch_range_device", "zkhip_msm_g1_multi_device", "zkhip_g1_add", "zkhip_g1_to_affine",
     "zkhip_g1_to_bytes",
     "zkhip_fft", "zkhip_fft_batch_device",
     "zkhip_domain_new", "zkhip_domain_free", "zkhip_domain_k", "zkhip_domain_extended_k", "zkhip_domain_quotient_poly_degree",
@@ -203,6 +203,11 @@ class ParamsKZG:
             out.append(h)
         return cls(ctx, k, out[0], out[1])
 
+    def window(self):
+        c, w = C.c_uint32(), C.c_uint32()
+        lib().zkhip_srs_window(self.g if self.g is not None else self.g_lagrange, C.byref(c), C.byref(w))
+        return c.value, w.value
+
     def read_bases(self, which, first, count):
         out = np.zeros((count, 8), dtype=np.uint64)
         _check(lib().zkhip_srs_read(self.ctx.h, which, C.c_size_t(first), C.c_size_t(count), _p(out)))
@@ -222,12 +227,14 @@ class ParamsKZG:
         return self._msm_host(self.g_lagrange, poly)
 
     def commit_batch_device(self, cols, lagrange=False, n=None, first=0):
-        """ncols device columns -> (ncols, 12) device tensor of Jacobian sums over points [first, first+n)."""
-        srs = self.g_lagrange if lagrange else self.g
+        """ncols device columns -> (ncols, 12) device tensor of Jacobian sums over points [first, first+n).
+        `lagrange` is one bool for the batch or one per column (ParamsKZG::commit_lagrange vs commit)."""
+        flags = list(lagrange) if isinstance(lagrange, (list, tuple)) else [bool(lagrange)] * len(cols)
+        srs = (C.c_void_p * len(cols))(*[(self.g_lagrange if f else self.g).value for f in flags])
         n = n if n is not None else cols[0].shape[0] - first
         out = self.ctx.empty(len(cols), 12)
-        _check(lib().zkhip_msm_g1_batch_range_device(self.ctx.h, srs, _ptr_array(cols), C.c_size_t(len(cols)), C.c_size_t(first),
-                                                     C.c_size_t(n), C.c_void_p(out.data_ptr())))
+        _check(lib().zkhip_msm_g1_multi_device(self.ctx.h, srs, _ptr_array(cols), C.c_size_t(len(cols)), C.c_size_t(first),
+                                               C.c_size_t(n), C.c_void_p(out.data_ptr())))
         return out
 
     def free(self):

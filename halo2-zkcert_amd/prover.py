@@ -21,6 +21,7 @@ real prover is still on the critical path.
 The schedule is written against a small backend interface so the same code drives the HIP library
 (GpuBackend, here) and, in tests/ and bench.py's cpu_baseline leg only, the CPU oracle.
 """
+import contextlib
 import hashlib
 
 import numpy as np
@@ -80,6 +81,30 @@ class GpuBackend:
 
     def __init__(self, ctx, ffi):
         self.ctx, self.ffi = ctx, ffi
+        self.torch = ctx.torch
+        self.main = self.torch.cuda.current_stream(ctx.device)
+        self.side = self.torch.cuda.Stream(device=ctx.device)
+
+    @contextlib.contextmanager
+    def overlap(self):
+        """Work issued inside runs on a second HIP stream, ordered after everything already issued on the main
+        stream.  Used for the coset NTTs, which only depend on finished columns and would otherwise wait behind
+        an MSM whose tail occupies a few CUs.  join() makes the main stream wait for it."""
+        ev = self.torch.cuda.Event()
+        ev.record(self.main)
+        self.side.wait_event(ev)
+        with self.torch.cuda.stream(self.side):
+            self.ctx.use_torch_stream()
+            try:
+                yield
+            finally:
+                pass
+        self.ctx.use_torch_stream()
+
+    def join(self):
+        ev = self.torch.cuda.Event()
+        ev.record(self.side)
+        self.main.wait_event(ev)
 
     def setup(self, k, degree, s_int):
         self.params = self.ffi.ParamsKZG.setup(self.ctx, k, self.fr(s_int))
@@ -256,36 +281,43 @@ class Prover:
             trace["commitments"] += [(tag, x.hex()) for x in byts]
             return byts
 
-        # 1. advice commitments (Lagrange basis)
+        # 1. advice commitments (Lagrange basis).  The vanishing argument's random polynomial does not depend on
+        #    any challenge, so its commitment (step 4, monomial basis) rides in the same MSM pass; it enters the
+        #    transcript at its usual place.  The coset NTTs of finished columns (step 5) are issued on a second
+        #    stream as soon as their inputs exist, so they run beside the latency-bound MSM tails.
         advice = b.clone(wit["advice"])
         instance = b.clone(wit["instance"])
-        t1 = absorb("advice", b.commit(advice, lagrange=True))
+        rand_poly = [b.synth(n, base + 380)]
+        with b.overlap():
+            adv_coeff = b.clone(wit["advice"] + wit["instance"])
+            b.lagrange_to_coeff(adv_coeff)
+            ext_adv = b.coeff_to_extended(adv_coeff)
+        c1 = b.commit(advice + rand_poly, lagrange=[True] * len(advice) + [False])
+        t1 = absorb("advice", c1[:len(advice)])
         theta = challenge("theta", t1)
         # 2. lookup permuted input / table (synthetic stand-ins for the sorted columns), coefficient form
         perm_in = [b.synth(n, base + 300 + i) for i in range(L)]
         perm_tab = [b.synth(n, base + 320 + i) for i in range(L)]
         b.lagrange_to_coeff(perm_in + perm_tab)
+        with b.overlap():
+            ext_perm = b.coeff_to_extended(perm_in + perm_tab)
         t2 = absorb("lookup_permuted", b.commit(perm_in + perm_tab, lagrange=False)) if L else []
         beta, gamma = challenge("beta", t1 + t2), challenge("gamma", t1 + t2)
         # 3. grand products (synthetic stand-ins), coefficient form
         perm_z = [b.synth(n, base + 340 + i) for i in range(Zp)]
         look_z = [b.synth(n, base + 360 + i) for i in range(L)]
         b.lagrange_to_coeff(perm_z + look_z)
+        with b.overlap():
+            ext_prod = b.coeff_to_extended(look_z + perm_z)
         t3 = absorb("products", b.commit(perm_z + look_z, lagrange=False))
-        # 4. vanishing argument's random polynomial
-        rand_poly = [b.synth(n, base + 380)]
-        t4 = absorb("random_poly", b.commit(rand_poly, lagrange=False))
+        # 4. vanishing argument's random polynomial (committed in pass 1)
+        t4 = absorb("random_poly", c1[len(advice):])
         y = challenge("y", t1 + t2 + t3 + t4)
-        # 5. quotient: advice/instance to coefficients, everything to the extended coset, sweep, divide, back
-        b.lagrange_to_coeff(advice + instance)
-        ext = b.coeff_to_extended(advice + instance + perm_in + perm_tab + look_z + perm_z)
-        o = 0
-        adv_c, o = ext[o:o + sh.n_advice], o + sh.n_advice
-        ins_c, o = ext[o:o + sh.n_instance], o + sh.n_instance
-        pin_c, o = ext[o:o + L], o + L
-        ptab_c, o = ext[o:o + L], o + L
-        lz_c, o = ext[o:o + L], o + L
-        pz_c = ext[o:o + Zp]
+        # 5. quotient: everything is on the extended coset by now; sweep, divide, back to coefficients
+        b.join()
+        adv_c, ins_c = ext_adv[:sh.n_advice], ext_adv[sh.n_advice:]
+        pin_c, ptab_c = ext_perm[:L], ext_perm[L:]
+        lz_c, pz_c = ext_prod[:L], ext_prod[L:]
         kw = dict(k=sh.k, extended_k=dom.extended_k, cs_degree=sh.degree, blinding_factors=sh.blinding_factors,
                   extended_omega=dom.extended_omega, g_coset=dom.g_coset, delta=b.fr(DELTA), beta=b.fr(beta), gamma=b.fr(gamma),
                   theta=b.fr(theta), y=b.fr(y), fixed=self.fixed_cosets, advice=adv_c, instance=ins_c, challenges=[],

@@ -60,7 +60,7 @@ int  zkhip_timer_start(zkhip_ctx* ctx);
 int  zkhip_timer_stop_ms(zkhip_ctx* ctx, float* ms);   /* synchronises */
 
 /* Per-kernel timing: while enabled, every launch of the named kernels is bracketed by HIP events on
- * the launch stream.  Names: "msm_digits", "msm_accum_affine", "msm_accum_jac", "msm_tail",
+ * the launch stream.  Names: "msm_digits", "msm_plan", "msm_accum_affine", "msm_accum_jac", "msm_tail",
  * "ntt_strided", "ntt_final", "sweep".  zkhip_profile_enable also clears the record. */
 int  zkhip_profile_enable(zkhip_ctx* ctx, int on);
 int  zkhip_profile_read(zkhip_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches);
@@ -72,6 +72,9 @@ int  zkhip_srs_load(zkhip_ctx* ctx, const uint64_t* bases_xy, size_t n, zkhip_sr
 int  zkhip_srs_load_device(zkhip_ctx* ctx, const void* d_bases_xy, size_t n, zkhip_srs** out);
 void zkhip_srs_free(zkhip_ctx* ctx, zkhip_srs* srs);
 size_t zkhip_srs_len(const zkhip_srs* srs);
+/* window width c (bits) and number of windows W = ceil(255 / c) chosen for this SRS: one MSM over n scalars
+ * is n * W (digit, point) pairs. */
+void zkhip_srs_window(const zkhip_srs* srs, uint32_t* c, uint32_t* windows);
 /* ParamsKZG::setup(k, rng) restricted to G1: bases[i] = [s^i] G (monomial) and [l_i(s)] G
  * (Lagrange), generated on the device.  s is a Montgomery Fr.  Either output may be NULL. */
 int  zkhip_kzg_setup(zkhip_ctx* ctx, uint32_t k, const uint64_t s[4], zkhip_srs** g, zkhip_srs** g_lagrange);
@@ -92,6 +95,10 @@ int  zkhip_msm_g1_batch_device(zkhip_ctx* ctx, const zkhip_srs* srs, const void*
  * exchanged as raw bytes and folded with zkhip_g1_add. */
 int  zkhip_msm_g1_batch_range_device(zkhip_ctx* ctx, const zkhip_srs* srs, const void* const* d_scalar_cols,
                                      size_t ncols, size_t first, size_t count, void* d_out_xyz);
+/* The same with one SRS per column (all of the same length): lets commitments over g and g_lagrange that
+ * do not depend on each other (advice columns + the vanishing argument's random polynomial) share one pass. */
+int  zkhip_msm_g1_multi_device(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const void* const* d_scalar_cols,
+                               size_t ncols, size_t first, size_t count, void* d_out_xyz);
 /* G1 + G1 on the host (Jacobian, 12 u64 each). */
 void zkhip_g1_add(const uint64_t a[12], const uint64_t b[12], uint64_t out[12]);
 /* G1::to_affine on the host for results fetched from the device (12 u64 -> 8 u64). */

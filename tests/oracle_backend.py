@@ -1,5 +1,7 @@
 """Backend for halo2_zkcert_amd.prover.Prover that computes with the CPU oracle (TEST INFRASTRUCTURE:
 the checker for the GPU schedule and bench.py's cpu_baseline leg — never the product path)."""
+import contextlib
+
 import numpy as np
 
 import zkoracle_py as zo
@@ -17,6 +19,13 @@ class OracleBackend:
         self.domain = zo.Domain(degree, k)
         return self.domain
 
+    @contextlib.contextmanager
+    def overlap(self):
+        yield
+
+    def join(self):
+        pass
+
     def fr(self, x):
         return zo.fr_from_int(x)
 
@@ -30,8 +39,9 @@ class OracleBackend:
         return [c.copy() for c in cols]
 
     def partial_commit(self, cols, lagrange, first, count):
-        bases = self.g_lagrange if lagrange else self.g
-        return np.stack([zo.best_multiexp(c[first:first + count], bases[first:first + count], self.threads) for c in cols])
+        flags = list(lagrange) if isinstance(lagrange, (list, tuple)) else [bool(lagrange)] * len(cols)
+        return np.stack([zo.best_multiexp(c[first:first + count], (self.g_lagrange if f else self.g)[first:first + count], self.threads)
+                         for c, f in zip(cols, flags)])
 
     def g1_add(self, a, b):
         o = zo.new(12)

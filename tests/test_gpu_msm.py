@@ -150,3 +150,26 @@ def test_full_size_trapdoor_property(zk, oracle, k):
     exp = zo.g1_mul_gen(zo.eval_polynomial(coeffs, s))
     assert (ffi.g1_to_affine(out[0]) == exp).all()
     p.free()
+
+
+@pytest.mark.parametrize("k", [20, 22])
+def test_large_msm_trapdoor_property(zk, oracle, k):
+    """BASELINE configs[2..3] sizes (2^20, 2^22 points; window c = 18): commit(coeffs) == [p(s)] G,
+    commit_lagrange(evals) == commit(iNTT(evals)).  Size-independent, O(n) host work."""
+    ffi, ctx = zk
+    zo = oracle
+    s = zo.fr_from_int(0xFEEDFACE0000 + k)
+    p = ffi.ParamsKZG.setup(ctx, k, s)
+    n = 1 << k
+    col = ctx.synth_fill(n, 0xC0FFEE00 + k)
+    coeffs = ctx.to_host(col)
+    out = ctx.to_host(p.commit_batch_device([col]))
+    exp = zo.g1_mul_gen(zo.eval_polynomial(coeffs, s))
+    assert (ffi.g1_to_affine(out[0]) == exp).all()
+    dom = ffi.EvaluationDomain(ctx, 3, k)
+    ev = col.clone()
+    dom.coeff_to_lagrange_device([ev])
+    out2 = ctx.to_host(p.commit_batch_device([ev], lagrange=True))
+    assert (ffi.g1_to_affine(out2[0]) == exp).all()
+    dom.free()
+    p.free()
