@@ -48,11 +48,17 @@ struct zkhip_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::map<std::string, zk::Scratch> scratch;
-    // twiddle tables keyed by (log_n, omega limbs)
+    // Twiddle tables keyed by (log_n, omega).  w^e for any e < 2^log_n is lo[e & (2^h - 1)] * hi[e >> h]
+    // (two tables of ~sqrt(n) entries: L2-resident, against a 16 * n-byte table that every strided NTT pass
+    // would gather from at random); bf[j] = w^(j * n / 2048) are the butterfly twiddles of one tile.
     struct Twiddle {
         uint32_t log_n;
         uint64_t omega[4];
-        void* d_table;  // n/2 Fr
+        uint32_t h;          // bits of the low table
+        void* d_lo;          // 2^h entries: w^j
+        void* d_hi;          // 2^(log_n - h) entries: w^(j 2^h)
+        void* d_bf;          // min(1024, n/2) entries: w^(j * n / 2^bf_bits'), see ntt.hip
+        uint32_t bf_bits;    // bf has 2^bf_bits entries, bf[j] = w^(j << (log_n - 1 - bf_bits))
     };
     std::vector<Twiddle> twiddles;
 
@@ -66,7 +72,7 @@ struct zkhip_ctx {
     void prof_end();
 
     int get_scratch(const char* name, size_t bytes, void** out);
-    int get_twiddles(const uint64_t omega[4], uint32_t log_n, const void** d_table);
+    int get_twiddles(const uint64_t omega[4], uint32_t log_n, const Twiddle** out);
 };
 
 // RAII span around one kernel launch (no-op unless profiling is enabled)

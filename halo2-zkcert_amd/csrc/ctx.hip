@@ -110,7 +110,7 @@ void zkhip_destroy(zkhip_ctx* c) {
     for (auto& kv : c->scratch)
         if (kv.second.ptr) (void)hipFree(kv.second.ptr);
     for (auto& t : c->twiddles)
-        if (t.d_table) (void)hipFree(t.d_table);
+        if (t.d_lo) (void)hipFree(t.d_lo);   // lo, hi and bf share one allocation
     for (auto& sp : c->prof_spans) { (void)hipEventDestroy(sp.e0); (void)hipEventDestroy(sp.e1); }
     for (auto e : c->prof_pool) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);

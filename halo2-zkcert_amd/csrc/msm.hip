@@ -31,7 +31,7 @@ struct zkhip_srs {
 static uint32_t pick_window(size_t n) {
     if (const char* e = getenv("ZKHIP_MSM_C")) {
         int v = atoi(e);
-        if (v >= 2 && v <= 22) return (uint32_t)v;
+        if (v >= 2 && v <= 19) return (uint32_t)v;
     }
     uint32_t lg = 0;
     while (((size_t)1 << lg) < n) ++lg;
@@ -144,49 +144,148 @@ namespace zk {
 int srs_build_raw(zkhip_ctx* ctx, const void* d_bases_raw, size_t n, zkhip_srs** out) { return srs_build(ctx, d_bases_raw, n, out, 1); }
 }  // namespace zk
 
-// ------------------------------------------------------------------ digit recoding + counting sort
-// Signed digits d_w in [-(2^(c-1)-1), 2^(c-1)], sum d_w 2^(c w) = scalar.  W*c >= 255 so the last
-// carry is zero for every canonical scalar < r < 2^254.
+// ------------------------------------------------------------------ digit recoding + sort by bucket
+// Signed digits d_w in [-(2^(c-1)-1), 2^(c-1)], sum d_w 2^(c w) = scalar.  W*c >= 255 so the last carry is
+// zero for every canonical scalar < r < 2^254.  The n*W (digit, point) pairs are grouped by bucket |d| - 1
+// with a two-level most-significant-digit radix partition whose histograms live in LDS:
+//   hi pass: 256 scalars (256 W pairs) per block, P = 2^HB partitions by the top bits of the bucket;
+//   lo pass: 4096-pair tiles inside one partition, 2^LB bins by the low bits.
+// Each pass counts, reserves contiguous space with ONE returning global atomic per (tile, bin) — a wave
+// touches consecutive counters — and scatters with ranks from LDS atomics.  Per-pair global atomics and the
+// 4-byte scatter over the whole n*W range, which made the first version memory-bound at 2^22, are gone.
+struct SortGeom { uint32_t c, W, B, HB, LB, P; };
+#define SORT_TILE 4096u
+
+__device__ __forceinline__ void digit_at(const uint32_t* sl, uint32_t w, uint32_t c, uint32_t half, uint32_t mask, uint32_t& carry,
+                                         uint32_t& mag, uint32_t& neg) {
+    uint32_t bit = w * c, limb = bit >> 5, sh = bit & 31;
+    uint64_t v = 0;
+    if (limb < 8) v = sl[limb] | ((uint64_t)sl[limb + 1] << 32);
+    uint32_t raw = ((uint32_t)(v >> sh) & mask) + carry;
+    if (raw > half) { mag = (1u << c) - raw; neg = 1; carry = 1; } else { mag = raw; neg = 0; carry = 0; }
+}
+
+// SCATTER = false: part_cnt[p] += pairs of this block in partition p.
+// SCATTER = true : tmp_entry / tmp_key get the pairs grouped by partition (part_off from k_part_scan).
 template <bool SCATTER>
-__global__ void k_digits(const uint32_t* const* scalar_cols, size_t n, size_t first, size_t srs_n, uint32_t c, uint32_t W, uint32_t B,
-                         uint32_t* cnt_all, const uint32_t* off_all, uint32_t* rank_all, uint32_t* entries_all, size_t items) {
-    // pass 1 (SCATTER = false): rank[w][i] = position of pair (i, w) inside its bucket (one returning atomic);
-    // pass 2 (SCATTER = true):  entries[off[bucket] + rank] = pair — no atomics.
+__global__ void __launch_bounds__(256) k_sort_hi(const uint32_t* const* scalar_cols, size_t n, size_t first, size_t srs_n, SortGeom g,
+                                                 uint32_t* part_cnt_all, uint32_t* part_cursor_all, const uint32_t* part_off_all,
+                                                 uint32_t* tmp_entry_all, uint16_t* tmp_key_all, size_t items) {
     __shared__ uint32_t sl[256][9];
-    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    uint32_t col = blockIdx.y;
-    if (i >= n) return;
-    fe32 s = abi_to_canonical_words<Fr>(mem_load(scalar_cols[col] + (first + i) * 8));
+    __shared__ uint32_t hist[128], base[128];
+    const uint32_t tid = threadIdx.x, col = blockIdx.y;
+    size_t i = blockIdx.x * (size_t)256 + tid;
+    const bool live = i < n;
+    if (tid < 128) hist[tid] = 0;
+    if (live) {
+        fe32 sc = abi_to_canonical_words<Fr>(mem_load(scalar_cols[col] + (first + i) * 8));
 #pragma unroll
-    for (int j = 0; j < 8; ++j) sl[threadIdx.x][j] = s.w[j];
-    sl[threadIdx.x][8] = 0;
-    uint32_t* cnt = cnt_all + (size_t)col * B;
-    const uint32_t* off = off_all + (size_t)col * (B + 4);
-    uint32_t* rank = rank_all + (size_t)col * items;
-    uint32_t* entries = entries_all + (size_t)col * items;
-    uint32_t carry = 0, half = 1u << (c - 1), mask = (c == 32) ? 0xffffffffu : ((1u << c) - 1);
-    for (uint32_t w = 0; w < W; ++w) {
-        uint32_t bit = w * c, limb = bit >> 5, sh = bit & 31;
-        uint64_t v = 0;
-        if (limb < 8) v = sl[threadIdx.x][limb] | ((uint64_t)sl[threadIdx.x][limb + 1] << 32);
-        uint32_t raw = ((uint32_t)(v >> sh) & mask) + carry;
-        uint32_t mag, neg;
-        if (raw > half) { mag = (1u << c) - raw; neg = 1; carry = 1; } else { mag = raw; neg = 0; carry = 0; }
-        if (mag != 0) {
-            if (!SCATTER) {
-                rank[(size_t)w * n + i] = atomicAdd(&cnt[mag - 1], 1u);
-            } else {
-                uint32_t pos = off[mag - 1] + rank[(size_t)w * n + i];
-                entries[pos] = (uint32_t)(w * srs_n + first + i) | (neg << 31);
+        for (int j = 0; j < 8; ++j) sl[tid][j] = sc.w[j];
+        sl[tid][8] = 0;
+    }
+    __syncthreads();
+    const uint32_t half = 1u << (g.c - 1), mask = (1u << g.c) - 1, lomask = (1u << g.LB) - 1;
+    if (live) {
+        uint32_t carry = 0, mag, neg;
+        for (uint32_t w = 0; w < g.W; ++w) {
+            digit_at(sl[tid], w, g.c, half, mask, carry, mag, neg);
+            if (mag) atomicAdd(&hist[(mag - 1) >> g.LB], 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t* part_cnt = part_cnt_all + (size_t)col * 128;
+    if (!SCATTER) {
+        if (tid < g.P && hist[tid]) atomicAdd(&part_cnt[tid], hist[tid]);
+        return;
+    }
+    if (tid < g.P) {
+        uint32_t h = hist[tid];
+        base[tid] = h ? part_off_all[(size_t)col * 132 + tid] + atomicAdd(&part_cursor_all[(size_t)col * 128 + tid], h) : 0u;
+        hist[tid] = 0;
+    }
+    __syncthreads();
+    if (live) {
+        uint32_t* tmp_entry = tmp_entry_all + (size_t)col * items;
+        uint16_t* tmp_key = tmp_key_all + (size_t)col * items;
+        uint32_t carry = 0, mag, neg;
+        for (uint32_t w = 0; w < g.W; ++w) {
+            digit_at(sl[tid], w, g.c, half, mask, carry, mag, neg);
+            if (mag) {
+                uint32_t b = mag - 1, p = b >> g.LB;
+                uint32_t pos = base[p] + atomicAdd(&hist[p], 1u);
+                tmp_entry[pos] = (uint32_t)(w * srs_n + first + i) | (neg << 31);
+                tmp_key[pos] = (uint16_t)(b & lomask);
             }
         }
     }
 }
 
-// One block (1024 threads) per column: off_in (if non-null) = exclusive scan of cnt_in; cnt_out = ceil(cnt_in / seg);
-// off_out = exclusive scan of cnt_out (B + 1 entries each); max_out[col] = max cnt_in.
-// Tiles of 1024 x PER counters; every thread keeps its PER consecutive counters in registers (16-byte loads,
-// all in flight at once), wave-level shuffles do the scan, a running carry links the tiles.
+// part_off = exclusive scan of part_cnt (P + 1 entries); tile_start = exclusive scan of ceil(part_cnt / SORT_TILE).
+__global__ void __launch_bounds__(128) k_part_scan(const uint32_t* part_cnt_all, uint32_t P, uint32_t* part_off_all, uint32_t* tile_start_all) {
+    __shared__ uint32_t a[128], b[128];
+    uint32_t col = blockIdx.x, t = threadIdx.x;
+    uint32_t v = t < P ? part_cnt_all[(size_t)col * 128 + t] : 0u;
+    uint32_t tl = (v + SORT_TILE - 1) / SORT_TILE;
+    a[t] = v; b[t] = tl;
+    __syncthreads();
+    for (uint32_t d = 1; d < 128; d <<= 1) {
+        uint32_t x = t >= d ? a[t - d] : 0u, y = t >= d ? b[t - d] : 0u;
+        __syncthreads();
+        a[t] += x; b[t] += y;
+        __syncthreads();
+    }
+    uint32_t* po = part_off_all + (size_t)col * 132;
+    uint32_t* ts = tile_start_all + (size_t)col * 132;
+    if (t < P) { po[t] = a[t] - v; ts[t] = b[t] - tl; }
+    if (t == P - 1) { po[P] = a[t]; ts[P] = b[t]; }
+}
+
+// One 4096-pair tile of one partition.  SCATTER = false: cnt[bucket] += ...; SCATTER = true: entries sorted by bucket.
+template <bool SCATTER>
+__global__ void __launch_bounds__(256) k_sort_lo(const uint32_t* part_off_all, const uint32_t* tile_start_all, SortGeom g,
+                                                 const uint32_t* tmp_entry_all, const uint16_t* tmp_key_all, size_t items,
+                                                 uint32_t* cnt_all, const uint32_t* off_all, uint32_t* cursor_all, uint32_t* entries_all) {
+    __shared__ uint32_t hist[2048], base[2048];
+    const uint32_t tid = threadIdx.x, col = blockIdx.y, blk = blockIdx.x;
+    const uint32_t* po = part_off_all + (size_t)col * 132;
+    const uint32_t* ts = tile_start_all + (size_t)col * 132;
+    if (blk >= ts[g.P]) return;
+    uint32_t lo_p = 0, hi_p = g.P;   // largest p with ts[p] <= blk
+    while (hi_p - lo_p > 1) {
+        uint32_t mid = (lo_p + hi_p) >> 1;
+        if (ts[mid] <= blk) lo_p = mid; else hi_p = mid;
+    }
+    const uint32_t p = lo_p;
+    const uint32_t beg = po[p] + (blk - ts[p]) * SORT_TILE, end = min(beg + SORT_TILE, po[p + 1]);
+    const uint32_t nbins = 1u << g.LB;
+    for (uint32_t j = tid; j < nbins; j += 256) hist[j] = 0;
+    __syncthreads();
+    const uint16_t* tmp_key = tmp_key_all + (size_t)col * items;
+    for (uint32_t j = beg + tid; j < end; j += 256) atomicAdd(&hist[tmp_key[j]], 1u);
+    __syncthreads();
+    const uint32_t bucket0 = p << g.LB;
+    if (!SCATTER) {
+        uint32_t* cnt = cnt_all + (size_t)col * g.B;
+        for (uint32_t j = tid; j < nbins; j += 256)
+            if (hist[j]) atomicAdd(&cnt[bucket0 + j], hist[j]);
+        return;
+    }
+    const uint32_t* off = off_all + (size_t)col * (g.B + 4);
+    uint32_t* cursor = cursor_all + (size_t)col * g.B;
+    for (uint32_t j = tid; j < nbins; j += 256) {
+        uint32_t h = hist[j];
+        base[j] = h ? off[bucket0 + j] + atomicAdd(&cursor[bucket0 + j], h) : 0u;
+        hist[j] = 0;
+    }
+    __syncthreads();
+    const uint32_t* tmp_entry = tmp_entry_all + (size_t)col * items;
+    uint32_t* entries = entries_all + (size_t)col * items;
+    for (uint32_t j = beg + tid; j < end; j += 256) {
+        uint32_t key = tmp_key[j];
+        entries[base[key] + atomicAdd(&hist[key], 1u)] = tmp_entry[j];
+    }
+}
+
 // ceil(v / seg) without a hardware divide: seg_magic = ceil(2^32 / seg); exact for v * seg < 2^32 (v < 2^26, seg <= 64).
 __device__ __forceinline__ uint32_t ceil_div_magic(uint32_t v, uint32_t seg, uint32_t seg_magic) {
     return seg == 1 ? v : __umulhi(v + seg - 1, seg_magic);
@@ -417,12 +516,30 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
     const size_t items = n * W;
     const uint32_t seg0_min = 8;
     // scratch
-    void *d_colptrs, *d_cnt, *d_off, *d_rank, *d_entries, *d_max, *d_cntA, *d_cntB, *d_offA, *d_offB, *d_pA, *d_pB, *d_chunks;
+    void *d_colptrs, *d_zero, *d_off, *d_tmp_entry, *d_tmp_key, *d_entries, *d_max, *d_cntA, *d_cntB, *d_offA, *d_offB, *d_pA, *d_pB, *d_chunks;
     const size_t pstride0 = items / seg0_min + B + 1;
+    SortGeom g;
+    g.c = c; g.W = W; g.B = B;
+    const uint32_t KB = c - 1;
+    g.HB = KB > 8 ? 7 : KB / 2;
+    g.LB = KB - g.HB;
+    g.P = 1u << g.HB;
+    if (g.LB > 11) { set_error("zkhip_msm: window c = %u unsupported by the sort (max 19)", c); return ZKHIP_EINVAL; }
     ZK_TRY(ctx->get_scratch("msm_colptrs", 2 * ncols * sizeof(void*), &d_colptrs));
-    ZK_TRY(ctx->get_scratch("msm_cnt", ncols * B * 4, &d_cnt));
-    ZK_TRY(ctx->get_scratch("msm_rank", ncols * items * 4, &d_rank));
+    // zeroed every call: part_cnt[128] + part_cursor[128] + cnt[B] + cursor[B] per column
+    const size_t zero_words = ncols * (256 + 2 * (size_t)B);
+    ZK_TRY(ctx->get_scratch("msm_zero", zero_words * 4, &d_zero));
+    uint32_t* d_part_cnt = (uint32_t*)d_zero;
+    uint32_t* d_part_cursor = d_part_cnt + ncols * 128;
+    uint32_t* d_cnt = d_part_cursor + ncols * 128;
+    uint32_t* d_cursor = d_cnt + ncols * (size_t)B;
+    void* d_part;
+    ZK_TRY(ctx->get_scratch("msm_part", ncols * 264 * 4, &d_part));   // part_off[132] + tile_start[132] per column
+    uint32_t* d_part_off = (uint32_t*)d_part;
+    uint32_t* d_tile_start = d_part_off + ncols * 132;
     ZK_TRY(ctx->get_scratch("msm_off", ncols * (B + 4) * 4, &d_off));
+    ZK_TRY(ctx->get_scratch("msm_tmp_entry", ncols * items * 4, &d_tmp_entry));
+    ZK_TRY(ctx->get_scratch("msm_tmp_key", ncols * items * 2, &d_tmp_key));
     ZK_TRY(ctx->get_scratch("msm_entries", ncols * items * 4, &d_entries));
     ZK_TRY(ctx->get_scratch("msm_max", ncols * 4, &d_max));
     ZK_TRY(ctx->get_scratch("msm_cntA", ncols * B * 4, &d_cntA));
@@ -439,8 +556,7 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
     std::vector<const void*> h_ptrs(2 * ncols);
     for (size_t j = 0; j < ncols; ++j) { h_ptrs[j] = d_cols_host[j]; h_ptrs[ncols + j] = srs_per_col[j]->d_table; }
     ZK_HIP(hipMemcpyAsync(d_colptrs, h_ptrs.data(), 2 * ncols * sizeof(void*), hipMemcpyHostToDevice, st));
-    ZK_HIP(hipMemsetAsync(d_cnt, 0, ncols * B * 4, st));
-    dim3 gn(div_up(n, 256), (unsigned)ncols);
+    ZK_HIP(hipMemsetAsync(d_zero, 0, zero_words * 4, st));
     // Round-0 segment length depends on the problem size only: aim for ~2 waves per SIMD over the chip.
     uint32_t seg = seg0_min;
     {
@@ -448,16 +564,25 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
         size_t sgl = (ncols * items) / target_threads;
         if (sgl > seg) seg = (uint32_t)std::min<size_t>(sgl, 64);
     }
+    dim3 gn(div_up(n, 256), (unsigned)ncols);
+    dim3 gt(div_up(items, SORT_TILE) + g.P, (unsigned)ncols);
+    std::vector<uint32_t> h_max(ncols);
     { ProfScope ps(ctx, "msm_digits");
-    hipLaunchKernelGGL(k_digits<false>, gn, dim3(256), 0, st, (const uint32_t* const*)d_colptrs, n, first, srs->n, c, W, B, (uint32_t*)d_cnt,
-                       (const uint32_t*)nullptr, (uint32_t*)d_rank, (uint32_t*)nullptr, items); }
+    hipLaunchKernelGGL(k_sort_hi<false>, gn, dim3(256), 0, st, (const uint32_t* const*)d_colptrs, n, first, srs->n, g, d_part_cnt, d_part_cursor,
+                       (const uint32_t*)d_part_off, (uint32_t*)d_tmp_entry, (uint16_t*)d_tmp_key, items);
+    hipLaunchKernelGGL(k_part_scan, dim3((unsigned)ncols), dim3(128), 0, st, (const uint32_t*)d_part_cnt, g.P, d_part_off, d_tile_start);
+    hipLaunchKernelGGL(k_sort_hi<true>, gn, dim3(256), 0, st, (const uint32_t* const*)d_colptrs, n, first, srs->n, g, d_part_cnt, d_part_cursor,
+                       (const uint32_t*)d_part_off, (uint32_t*)d_tmp_entry, (uint16_t*)d_tmp_key, items);
+    hipLaunchKernelGGL(k_sort_lo<false>, gt, dim3(256), 0, st, (const uint32_t*)d_part_off, (const uint32_t*)d_tile_start, g,
+                       (const uint32_t*)d_tmp_entry, (const uint16_t*)d_tmp_key, items, d_cnt, (const uint32_t*)d_off, d_cursor,
+                       (uint32_t*)d_entries); }
     { ProfScope ps(ctx, "msm_plan");
     launch_plan(st, (unsigned)ncols, (const uint32_t*)d_cnt, B, seg, (uint32_t*)d_off, (uint32_t*)d_cntA, (uint32_t*)d_offA, (uint32_t*)d_max); }
-    std::vector<uint32_t> h_max(ncols);
     ZK_HIP(hipMemcpyAsync(h_max.data(), d_max, ncols * 4, hipMemcpyDeviceToHost, st));
     { ProfScope ps(ctx, "msm_digits");
-    hipLaunchKernelGGL(k_digits<true>, gn, dim3(256), 0, st, (const uint32_t* const*)d_colptrs, n, first, srs->n, c, W, B, (uint32_t*)d_cnt,
-                       (const uint32_t*)d_off, (uint32_t*)d_rank, (uint32_t*)d_entries, items); }
+    hipLaunchKernelGGL(k_sort_lo<true>, gt, dim3(256), 0, st, (const uint32_t*)d_part_off, (const uint32_t*)d_tile_start, g,
+                       (const uint32_t*)d_tmp_entry, (const uint16_t*)d_tmp_key, items, d_cnt, (const uint32_t*)d_off, d_cursor,
+                       (uint32_t*)d_entries); }
     ZK_LAUNCH_CHECK();
     ZK_HIP(hipStreamSynchronize(st));
     uint32_t maxcnt = 0;

@@ -31,37 +31,57 @@ using namespace zk;
 // value grows by at most 3p per stage: <= (2 + 3*11) p = 35 p after an 11-stage tile (limit 120 p).
 
 // ------------------------------------------------------------------ twiddle tables
-__global__ void k_twiddles(uint32_t* table, size_t half_n, fe omega_v) {
-    const size_t CHK = 64;
+// table[i] = base^i for i < count, CHK consecutive powers per thread
+__global__ void k_powers(uint32_t* table, size_t count, fe base_v) {
+    const size_t CHK = 16;
     size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     size_t lo = t * CHK;
-    if (lo >= half_n) return;
-    el2<Fr> omega(omega_v);
-    el2<Fr> w = pow_u64<Fr>(omega, (uint64_t)lo);
-    size_t hi = lo + CHK < half_n ? lo + CHK : half_n;
+    if (lo >= count) return;
+    el2<Fr> base(base_v);
+    el2<Fr> w = pow_u64<Fr>(base, (uint64_t)lo);
+    size_t hi = lo + CHK < count ? lo + CHK : count;
     for (size_t i = lo; i < hi; ++i) {
         store_raw<Fr>(table + i * 8, w);
-        w = w * omega;
+        w = w * base;
     }
 }
 
-int zkhip_ctx::get_twiddles(const uint64_t omega[4], uint32_t log_n, const void** d_table) {
+int zkhip_ctx::get_twiddles(const uint64_t omega[4], uint32_t log_n, const Twiddle** out) {
     for (auto& t : twiddles)
-        if (t.log_n == log_n && memcmp(t.omega, omega, 32) == 0) { *d_table = t.d_table; return ZKHIP_OK; }
+        if (t.log_n == log_n && memcmp(t.omega, omega, 32) == 0) { *out = &t; return ZKHIP_OK; }
     Twiddle t;
     t.log_n = log_n;
     memcpy(t.omega, omega, 32);
-    size_t half_n = log_n ? ((size_t)1 << (log_n - 1)) : 1;
-    hipError_t e = hipMalloc(&t.d_table, half_n * 32);
-    if (e != hipSuccess) { (void)hipGetLastError(); set_error("hipMalloc twiddles (%zu B): %s", half_n * 32, hipGetErrorString(e)); return ZKHIP_ENOMEM; }
+    t.h = (log_n + 1) / 2;
+    t.bf_bits = log_n >= 1 ? std::min<uint32_t>(10, log_n - 1) : 0;
+    size_t n_lo = (size_t)1 << t.h, n_hi = (size_t)1 << (log_n - t.h), n_bf = (size_t)1 << t.bf_bits;
+    void* base;
+    hipError_t e = hipMalloc(&base, (n_lo + n_hi + n_bf) * 32);
+    if (e != hipSuccess) { (void)hipGetLastError(); set_error("hipMalloc twiddles: %s", hipGetErrorString(e)); return ZKHIP_ENOMEM; }
+    t.d_lo = base;
+    t.d_hi = (char*)base + n_lo * 32;
+    t.d_bf = (char*)base + (n_lo + n_hi) * 32;
     el2<Fr> w = from_abi<Fr>(mem_load(omega));
-    hipLaunchKernelGGL(k_twiddles, dim3(div_up(div_up(half_n, 64), 64)), dim3(64), 0, stream, (uint32_t*)t.d_table, half_n, w.v);
+    el2<Fr> w_hi = pow_u64<Fr>(w, (uint64_t)1 << t.h);
+    el2<Fr> w_bf = log_n >= 1 ? pow_u64<Fr>(w, (uint64_t)1 << (log_n - 1 - t.bf_bits)) : w;
+    auto launch = [&](void* tab, size_t cnt, const el2<Fr>& b) {
+        hipLaunchKernelGGL(k_powers, dim3(div_up(div_up(cnt, 16), 64)), dim3(64), 0, stream, (uint32_t*)tab, cnt, b.v);
+    };
+    launch(t.d_lo, n_lo, w);
+    launch(t.d_hi, n_hi, w_hi);
+    launch(t.d_bf, n_bf, w_bf);
     ZK_LAUNCH_CHECK();
-    ZK_HIP(hipStreamSynchronize(stream));   // one-time: the table is shared by every stream of the context
+    ZK_HIP(hipStreamSynchronize(stream));   // one-time: the tables are shared by every stream of the context
+    twiddles.reserve(64);                   // pointers handed out stay valid
     twiddles.push_back(t);
-    *d_table = t.d_table;
+    *out = &twiddles.back();
     return ZKHIP_OK;
 }
+
+struct TwDev {   // device view
+    const uint32_t* lo; const uint32_t* hi; const uint32_t* bf;
+    uint32_t h, bf_shift;   // bf index of w^(j << (m-1-st)) is j << (bf_bits - st) ... see tile_ntt
+};
 
 // ------------------------------------------------------------------ kernels
 struct NttScale {
@@ -75,14 +95,13 @@ extern __shared__ uint32_t ntt_lds[];   // fe tile[NTT_TILE]
 
 __device__ __forceinline__ uint32_t bitrev(uint32_t v, uint32_t bits) { return bits ? (__brev(v) >> (32 - bits)) : 0; }
 
-__device__ __forceinline__ el2<Fr> twiddle_at(const uint32_t* table, uint32_t e, uint32_t half_n) {
-    // w^e for e < n from the half table: w^(n/2) = -1
-    if (e < half_n) return load_raw<Fr>(table + (size_t)e * 8);
-    return neg(load_raw<Fr>(table + (size_t)(e - half_n) * 8));
+__device__ __forceinline__ el2<Fr> twiddle_at(const TwDev& tw, uint32_t e) {
+    // w^e = lo[e mod 2^h] * hi[e >> h]: two cache-resident loads and one product
+    return load_raw<Fr>(tw.lo + (size_t)(e & ((1u << tw.h) - 1)) * 8) * load_raw<Fr>(tw.hi + (size_t)(e >> tw.h) * 8);
 }
 
 // s radix-2 DIT stages on a tile laid out tile[row * T + tl], rows = 2^s (rows were loaded bit-reversed).
-__device__ __forceinline__ void tile_ntt(fe* tile, uint32_t s, uint32_t logT, uint32_t m, const uint32_t* table) {
+__device__ __forceinline__ void tile_ntt(fe* tile, uint32_t s, uint32_t logT, const TwDev& tw) {
     uint32_t T = 1u << logT;
     uint32_t nbf = (1u << s) * T / 2;
     for (uint32_t st = 0; st < s; ++st) {
@@ -95,7 +114,8 @@ __device__ __forceinline__ void tile_ntt(fe* tile, uint32_t s, uint32_t logT, ui
             uint32_t i0 = r0 * T + tl, i1 = (r0 + half) * T + tl;
             fe a = tile[i0];
             el2<Fr> bw;
-            if (j != 0) bw = tile_el(tile[i1]) * load_raw<Fr>(table + ((size_t)j << (m - 1 - st)) * 8);
+            // w^(j << (m-1-st)) = bf[j << (bf_bits - st)]   (tw.bf_shift = bf_bits; s <= bf_bits + 1)
+            if (j != 0) bw = tile_el(tile[i1]) * load_raw<Fr>(tw.bf + ((size_t)j << (tw.bf_shift - st)) * 8);
             else if (st == 0) bw = el2<Fr>(tile[i1]);   // fresh loads are < 2p: twiddle 1 needs no product
             else bw = reduce(tile_el(tile[i1]));         // twiddle 1 later on: contract so the +3p/stage bound holds
             fe sum, dif;
@@ -126,8 +146,7 @@ __device__ __forceinline__ fe load_in(const uint32_t* src, uint32_t i, uint32_t 
 
 // Non-final pass: position = (hi << (s + lo_bits)) | (digit << lo_bits) | lo.
 __global__ void __launch_bounds__(256) k_ntt_strided(const uint32_t* const* srcs, uint32_t* const* dsts, uint32_t m, uint32_t s,
-                                                      uint32_t lo_bits, uint32_t logT, uint32_t n_in, const uint32_t* table,
-                                                      NttScale sc) {
+                                                      uint32_t lo_bits, uint32_t logT, uint32_t n_in, TwDev tw, NttScale sc) {
     fe* tile = reinterpret_cast<fe*>(ntt_lds);
     const uint32_t* src = srcs[blockIdx.y];
     uint32_t* dst = dsts[blockIdx.y];
@@ -143,25 +162,24 @@ __global__ void __launch_bounds__(256) k_ntt_strided(const uint32_t* const* srcs
         uint32_t pos = base | (j << lo_bits) | tl;
         tile[bitrev(j, s) * T + tl] = load_in(src, pos, n_in, sc);
     }
-    tile_ntt(tile, s, logT, m, table);
-    uint32_t half_n = 1u << (m - 1);
+    tile_ntt(tile, s, logT, tw);
     for (uint32_t e = threadIdx.x; e < cnt; e += blockDim.x) {
         uint32_t tl = e & (T - 1), r = e >> logT;
         uint32_t lo = lo0 | tl;
         tile_el v(tile[r * T + tl]);
         uint32_t ex = (lo * r) << hi_bits;  // < n
         void* out = dst + (size_t)(base | (r << lo_bits) | tl) * 8;
-        if (ex != 0) store_raw<Fr>(out, v * twiddle_at(table, ex, half_n));
+        if (ex != 0) store_raw<Fr>(out, v * twiddle_at(tw, ex));
         else store_raw<Fr>(out, v);
     }
 }
 
 // Final pass: rows of 2^s contiguous elements; T rows adjacent in the first digit k_1.
 // digit widths of the earlier passes are in sw[0..np-2] (sw[0] = s_1 is the most significant slot).
-struct NttDigits { uint32_t np; uint32_t sw[4]; };
+struct NttDigits { uint32_t np; uint32_t sw[6]; };
 
 __global__ void __launch_bounds__(256) k_ntt_final(const uint32_t* const* srcs, uint32_t* const* dsts, uint32_t m, uint32_t s,
-                                                    uint32_t logT, uint32_t n_in, const uint32_t* table, NttScale sc, NttDigits dg) {
+                                                    uint32_t logT, uint32_t n_in, TwDev tw, NttScale sc, NttDigits dg) {
     fe* tile = reinterpret_cast<fe*>(ntt_lds);
     const uint32_t* src = srcs[blockIdx.y];
     uint32_t* dst = dsts[blockIdx.y];
@@ -178,7 +196,7 @@ __global__ void __launch_bounds__(256) k_ntt_final(const uint32_t* const* srcs, 
         uint32_t row = ((k1_0 + tl) << rest_bits) | rest;
         tile[bitrev(j, s) * T + tl] = load_in(src, (row << s) | j, n_in, sc);
     }
-    tile_ntt(tile, s, logT, m, table);
+    tile_ntt(tile, s, logT, tw);
     // output index: k = k_1 + k_2 2^{s_1} + ... ; digits k_2..k_{p-1} come out of `rest` (slot order, msb first)
     uint32_t kbase = 0, shift_out = s1, rem = rest, rb = rest_bits;
     for (uint32_t q = 1; q + 1 < dg.np; ++q) {
@@ -224,8 +242,9 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
             if (srcs[i] != dsts[i]) ZK_HIP(hipMemcpyAsync(dsts[i], srcs[i], 32, hipMemcpyDeviceToDevice, st));
         return ZKHIP_OK;
     }
-    const void* table;
-    ZK_TRY(ctx->get_twiddles(omega, m, &table));
+    const zkhip_ctx::Twiddle* twh;
+    ZK_TRY(ctx->get_twiddles(omega, m, &twh));
+    TwDev tw{(const uint32_t*)twh->d_lo, (const uint32_t*)twh->d_hi, (const uint32_t*)twh->d_bf, twh->h, twh->bf_bits};
     static bool lds_attr_set = false;
     if (!lds_attr_set) {
         ZK_HIP(hipFuncSetAttribute((const void*)k_ntt_strided, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NTT_TILE * sizeof(fe))));
@@ -233,11 +252,15 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
         lds_attr_set = true;
     }
     // pass plan
-    uint32_t smax = 9;
-    if (const char* e = getenv("ZKHIP_NTT_SMAX")) { int v = atoi(e); if (v >= 4 && v <= 11) smax = (uint32_t)v; }
+    // Bits per pass.  Small transforms (whole batch cache-resident) take 9 bits per pass: runs of T = 4..8 elements
+    // are fine out of L2 / Infinity Cache.  Large ones take 6 bits per pass so that every global access is a run
+    // of T = 32 elements (1 KiB): 256-byte runs at multi-megabyte strides measured ~120 GB/s (TLB / DRAM-page
+    // bound), an order of magnitude below what an extra pass over the data costs.
+    uint32_t smax = m >= 20 ? 6 : 9;
+    if (const char* e = getenv(m >= 20 ? "ZKHIP_NTT_SMAX_LARGE" : "ZKHIP_NTT_SMAX")) { int v = atoi(e); if (v >= 4 && v <= 11) smax = (uint32_t)v; }
     uint32_t np = m <= 11 ? 1 : (m + smax - 1) / smax;
-    if (np > 4) { set_error("ntt: too many passes"); return ZKHIP_EINVAL; }
-    uint32_t sw[4] = {0, 0, 0, 0};
+    if (np > 6) { set_error("ntt: too many passes"); return ZKHIP_EINVAL; }
+    uint32_t sw[6] = {0, 0, 0, 0, 0, 0};
     for (uint32_t q = 0; q < np; ++q) sw[q] = m / np + (q < m % np ? 1 : 0);
     std::vector<void*> tmp_host(npolys);
     if (np > 1) {
@@ -263,7 +286,7 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
         unsigned blocks = (unsigned)(n >> (s + logT));
         ProfScope ps(ctx, "ntt_strided");
         hipLaunchKernelGGL(k_ntt_strided, dim3(blocks, (unsigned)npolys), dim3(256), NTT_TILE * sizeof(fe), st, (const uint32_t* const*)cur_src,
-                           (uint32_t* const*)out, m, s, lo_bits, logT, q == 0 ? n_in : (uint32_t)n, (const uint32_t*)table, scq);
+                           (uint32_t* const*)out, m, s, lo_bits, logT, q == 0 ? n_in : (uint32_t)n, tw, scq);
         cur_src = (const uint32_t**)out;
     }
     {
@@ -274,11 +297,11 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
         if (np > 1) scq.use_pre = 0;
         NttDigits dg;
         dg.np = np;
-        for (int i = 0; i < 4; ++i) dg.sw[i] = sw[i];
+        for (int i = 0; i < 6; ++i) dg.sw[i] = sw[i];
         unsigned blocks = (unsigned)(n >> (s + logT));
         ProfScope ps(ctx, "ntt_final");
         hipLaunchKernelGGL(k_ntt_final, dim3(blocks, (unsigned)npolys), dim3(256), NTT_TILE * sizeof(fe), st, (const uint32_t* const*)cur_src,
-                           (uint32_t* const*)d_dst, m, s, logT, np == 1 ? n_in : (uint32_t)n, (const uint32_t*)table, scq, dg);
+                           (uint32_t* const*)d_dst, m, s, logT, np == 1 ? n_in : (uint32_t)n, tw, scq, dg);
     }
     ZK_LAUNCH_CHECK();
     return ZKHIP_OK;

@@ -280,7 +280,7 @@ struct SweepParams {
     const uint32_t* const* sigma;         // n_perm_cols
     const uint32_t* const* perm_z;        // n_perm_sets
     const uint32_t* l0; const uint32_t* l_last; const uint32_t* l_active;
-    const uint32_t* xtable; uint32_t half_n;  // extended_omega^i, i < isize/2 (raw R' form)
+    const uint32_t* xt_lo; const uint32_t* xt_hi; uint32_t xt_h;  // extended_omega^i = lo[i mod 2^h] * hi[i >> h] (raw R' form)
     uint32_t c_beta, c_gamma, c_y, c_one, c_delta, c_delta_start;
     // lookups
     uint32_t n_lookups;
@@ -381,9 +381,7 @@ __global__ void __launch_bounds__(128) k_sweep(SweepParams P) {
             value = value * y + (zi - zp) * l0;
         }
         // current_delta = beta * g_coset * extended_omega^row
-        el2<Fr> xw;
-        if (row < P.half_n) xw = load_raw<Fr>(P.xtable + (size_t)row * 8);
-        else xw = neg(load_raw<Fr>(P.xtable + (size_t)(row - P.half_n) * 8));
+        el2<Fr> xw = load_raw<Fr>(P.xt_lo + (size_t)(row & ((1u << P.xt_h) - 1)) * 8) * load_raw<Fr>(P.xt_hi + (size_t)(row >> P.xt_h) * 8);
         el2<Fr> cur = ldk(P, P.c_delta_start) * xw;
         const el1<Fr> delta = ldk(P, P.c_delta);
         for (uint32_t s = 0; s < P.n_perm_sets; ++s) {
@@ -513,10 +511,11 @@ extern "C" int zkhip_evaluate_h_device(zkhip_ctx* ctx, const zk_evalh_args* A, v
     P.lookup_s = (const uint32_t* const*)(b + o_ls);
     if (A->n_perm_sets) {
         if (!A->l0 || !A->l_last || !A->l_active_row) { set_error("zkhip_evaluate_h_device: l0/l_last/l_active_row missing"); return ZKHIP_EINVAL; }
-        const void* xt;
+        const zkhip_ctx::Twiddle* xt;
         ZK_TRY(ctx->get_twiddles(A->extended_omega, A->extended_k, &xt));
-        P.xtable = (const uint32_t*)xt;
-        P.half_n = (uint32_t)(isize >> 1);
+        P.xt_lo = (const uint32_t*)xt->d_lo;
+        P.xt_hi = (const uint32_t*)xt->d_hi;
+        P.xt_h = xt->h;
     }
     const unsigned block = isize >= 128 ? 128 : 64;
     size_t lds = (size_t)std::max<uint32_t>(L.max_slots, 1) * 9 * 4 * block;
