@@ -9,9 +9,11 @@ A step = one pass of halo2_zkcert_amd.prover.Prover.prove over the RSA k=17 synt
 with a host round trip at every Fiat-Shamir point.  Inputs (witness columns, SRS, pk cosets) are resident
 in HBM before the timed region.  Prints ONE JSON line (rank 0).
 
-N > 1: one process per GPU over RCCL; every MSM is point-range sharded over the ranks (96-byte partial
-sums all-gathered and folded); NTTs and the sweep are replicated this round -> "strong" scaling of the
-MSM share only.
+N > 1: one process per GPU over RCCL.  Default: the path partitions by proof (the reference's leaf proofs are
+independent, SURVEY.md §3.5 / BASELINE config 5) — every rank runs its own pass on its own witness, no
+data-path collective, "scaling": "weak"; `value` is the wall time of the N-proof job (max over ranks).
+--shard-msm instead splits ONE proof: every MSM is point-range sharded over the ranks, the 96-byte partial sums
+are all-gathered and folded, NTTs and the sweep are replicated -> "strong" (DESIGN.md §multi-GPU).
 """
 import argparse
 import json
@@ -36,7 +38,7 @@ def cpu_baseline(shape, threads):
     p.prove(w)
     dt = time.perf_counter() - t0
     return dict(value=round(dt, 4), unit="s", cores=threads, kind="port",
-                sample=f"1 full pass of the same schedule ({shape.name}: 16 MSM, 11+11+1 NTT, 1 sweep), setup excluded")
+                sample=f"1 full pass of the same schedule ({shape.name}), setup excluded")
 
 
 def main():
@@ -45,7 +47,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--k", type=int, default=17)
+    ap.add_argument("--shape", default="rsa", choices=["rsa", "sha256"], help="circuit shape (BASELINE configs[1] / configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shard-msm", action="store_true", help="N > 1: split one proof (strong scaling) instead of one proof per GPU")
     args = ap.parse_args()
 
     import torch
@@ -66,12 +70,13 @@ def main():
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
     ctx = ffi.Context(local_rank)
-    shape = pv.CircuitShape.rsa(args.k)
+    shape = pv.CircuitShape.rsa(args.k) if args.shape == "rsa" else pv.CircuitShape.sha256(args.k)
     backend = pv.GpuBackend(ctx, ffi)
-    if world > 1:
+    shard = world > 1 and args.shard_msm
+    if shard:
         backend = pv.ShardedCommit(backend, rank, world, dist)
     prover = pv.Prover(backend, shape)
-    wit = prover.witness(0)
+    wit = prover.witness(0 if (shard or world == 1) else rank)   # one independent proof per rank unless sharding one
     n = 1 << shape.k
     counts = shape.counts(prover.dom.extended_k)
 
@@ -105,20 +110,21 @@ def main():
         # dominant kernel: MSM bucket accumulation.  Algorithmic bytes = 96 B per (scalar, point) pair
         # (SURVEY.md §8(d)); one step issues `msm` columns of n/world pairs in 7 launches.
         acc = kernels["msm_accum_affine"]
-        pairs_per_step = counts["msm"] * (n // world)
+        pairs_per_step = counts["msm"] * (n // world if shard else n)
         alg_bytes_per_launch = 96.0 * pairs_per_step / max(acc["launches_per_step"], 1)
         avg_launch_s = acc["ms_per_step"] / max(acc["launches_per_step"], 1) / 1000.0
         achieved = alg_bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         # the roofline that actually binds the kernel: the 32-bit integer multiplier (v_mad_u64_u32), measured at
         # 29.8 T lane-ops/s chip-wide (profiles/r01_microbench_gfx950.txt).  One pair costs W windows x 11 field
         # products x 171 mads.
-        c_bits, windows = backend.params.window()
+        c_bits, windows = prover.b.params.window()
         mads_per_step = pairs_per_step * windows * 11 * 171
         int_achieved = mads_per_step / (acc["ms_per_step"] / 1000.0) / 1e12 if acc["ms_per_step"] > 0 else 0.0
         out = {
             "metric": "create_proof wall-time (s): RSA k=17 / SHA256 k=19 / agg k=22 at 1/2/4/8 GPU",
             "value": round(ms_per_step / 1000.0, 6), "unit": "s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": False, "scaling": "strong" if shard else "weak", "vs_baseline": None,
+            "proofs_per_step": 1 if (shard or world == 1) else world,
             "dtype": "u256 (8x u32 Montgomery limbs, BN254 Fr/Fq)", "data": "synthetic",
             "config": {"workload": f"create_proof-shaped hot-path pass, {shape.name}: {counts['msm']} MSM_2^{shape.k} + "
                                    f"{counts['intt_n']} iNTT_2^{shape.k} + {counts['ntt_ext']} NTT_2^{prover.dom.extended_k} + "
@@ -126,7 +132,8 @@ def main():
                                    "uniform synthetic witness; BLAKE2b stand-in transcript",
                        "k": shape.k, "advice": shape.n_advice, "fixed": shape.n_fixed, "lookups": len(shape.lookups),
                        "perm_columns": len(shape.perm_columns), "degree": shape.degree,
-                       "parallelism": "1 GPU" if world == 1 else f"MSM point-range sharded x{world}, NTT/sweep replicated"},
+                       "parallelism": "1 GPU" if world == 1 else (f"one proof, MSM point-range sharded x{world}, NTT/sweep replicated" if shard
+                                                                   else f"{world} independent proofs, one per GPU, no collective")},
             "roofline": {"kernel": "msm_accum_affine (k_accum_affine)", "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0,
                          "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": None,
                          "algorithmic_bytes_per_launch": round(alg_bytes_per_launch),

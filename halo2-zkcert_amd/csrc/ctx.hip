@@ -168,6 +168,29 @@ int zkhip_timer_stop_ms(zkhip_ctx* c, float* ms) {
 void zkhip_g1_to_affine(const uint64_t xyz[12], uint64_t out_xy[8]) {
     g1a_store_abi(out_xy, g1j_to_affine(g1j_load_abi(xyz)));
 }
+// n points with ONE field inversion (Montgomery's trick): the per-batch host step between the MSM and the transcript
+void zkhip_g1_batch_to_affine(const uint64_t* xyz, size_t n, uint64_t* out_xy) {
+    std::vector<g1j> p(n);
+    std::vector<el2<Fq>> pre(n);
+    el2<Fq> acc = one<Fq>();
+    for (size_t i = 0; i < n; ++i) {
+        p[i] = g1j_load_abi(xyz + 12 * i);
+        pre[i] = acc;
+        if (!g1j_is_id(p[i])) acc = acc * p[i].z;
+    }
+    el2<Fq> iv = inv<Fq>(acc);
+    for (size_t i = n; i-- > 0;) {
+        g1a a = g1a_identity();
+        if (!g1j_is_id(p[i])) {
+            el2<Fq> zi = iv * pre[i];
+            iv = iv * p[i].z;
+            auto zi2 = sqr(zi);
+            a.x = p[i].x * zi2;
+            a.y = p[i].y * (zi2 * zi);
+        }
+        g1a_store_abi(out_xy + 8 * i, a);
+    }
+}
 void zkhip_g1_add(const uint64_t a[12], const uint64_t b[12], uint64_t out[12]) {
     g1j_store_abi(out, g1j_add(g1j_load_abi(a), g1j_load_abi(b)));
 }

@@ -290,99 +290,123 @@ __global__ void __launch_bounds__(256) k_sort_lo(const uint32_t* part_off_all, c
 __device__ __forceinline__ uint32_t ceil_div_magic(uint32_t v, uint32_t seg, uint32_t seg_magic) {
     return seg == 1 ? v : __umulhi(v + seg - 1, seg_magic);
 }
-template <int PER>
-__global__ void __launch_bounds__(1024) k_plan(const uint32_t* cnt_in_all, uint32_t B, uint32_t seg, uint32_t seg_magic, uint32_t* off_in_all,
-                                               uint32_t* cnt_out_all, uint32_t* off_out_all, uint32_t* max_out) {
-    __shared__ uint32_t w_a[16], w_b[16], w_m[16];
-    uint32_t col = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const uint32_t* cnt_in = cnt_in_all + (size_t)col * B;
-    uint32_t* off_in = off_in_all ? off_in_all + (size_t)col * (B + 4) : nullptr;
-    uint32_t* cnt_out = cnt_out_all ? cnt_out_all + (size_t)col * B : nullptr;
-    uint32_t* off_out = off_out_all ? off_out_all + (size_t)col * (B + 4) : nullptr;
-    uint32_t carry_a = 0, carry_b = 0, gmax = 0;
-    for (uint32_t tile0 = 0; tile0 < B; tile0 += 1024 * PER) {
-        uint32_t lo = tile0 + t * PER;
-        uint32_t v[PER];
-        if (PER >= 4 && lo + PER <= B) {
+// Scans over the per-bucket counters, spread over B / 2048 blocks per column (one CU moves only ~10 B/clk):
+//   k_plan_sums : per block, sum of cnt_in, sum of ceil(cnt_in / seg), max of cnt_in
+//   k_plan_apply: every block adds up the sums of the blocks before it, then scans its own 2048 counters:
+//                 off_in (if non-null) = exclusive scan of cnt_in; cnt_out = ceil(cnt_in / seg);
+//                 off_out = exclusive scan of cnt_out (B + 1 entries each); max_out[col] = max cnt_in.
+#define PLAN_PER 8
+#define PLAN_BLOCK (256 * PLAN_PER)
+__device__ __forceinline__ void plan_load(const uint32_t* cnt_in, uint32_t B, uint32_t lo, uint32_t v[PLAN_PER]) {
+    if (lo + PLAN_PER <= B) {
 #pragma unroll
-            for (int q = 0; q < PER / 4; ++q) {
-                uint4 x = reinterpret_cast<const uint4*>(cnt_in + lo)[q];
-                v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < PER; ++q) v[q] = lo + q < B ? cnt_in[lo + q] : 0u;
+        for (int q = 0; q < PLAN_PER / 4; ++q) {
+            uint4 x = reinterpret_cast<const uint4*>(cnt_in + lo)[q];
+            v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
         }
-        uint32_t sa = 0, sb = 0, m = 0;
+    } else {
 #pragma unroll
-        for (int q = 0; q < PER; ++q) { sa += v[q]; sb += ceil_div_magic(v[q], seg, seg_magic); m = max(m, v[q]); }
-        uint32_t ia = sa, ib = sb, im = m;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            uint32_t ua = __shfl_up(ia, d), ub = __shfl_up(ib, d);
-            if ((int)lane >= d) { ia += ua; ib += ub; }
-            im = max(im, __shfl_xor(im, d));
-        }
-        __syncthreads();   // previous tile's totals have been consumed
-        if (lane == 63) { w_a[wave] = ia; w_b[wave] = ib; }
-        if (lane == 0) w_m[wave] = im;
-        __syncthreads();
-        uint32_t base_a = carry_a, base_b = carry_b, tot_a = 0, tot_b = 0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            if (w < (int)wave) { base_a += w_a[w]; base_b += w_b[w]; }
-            tot_a += w_a[w]; tot_b += w_b[w]; gmax = max(gmax, w_m[w]);
-        }
-        uint32_t ra = base_a + ia - sa, rb = base_b + ib - sb;  // exclusive prefix of this thread's counters
-        if (PER >= 4 && lo + PER <= B) {
-            // 16-byte stores; the per-column stride of the offset arrays is B + 4 entries to keep them aligned
-            uint32_t oa[PER], ob[PER], oc[PER];
-#pragma unroll
-            for (int q = 0; q < PER; ++q) {
-                uint32_t sv = ceil_div_magic(v[q], seg, seg_magic);
-                oa[q] = ra; ob[q] = rb; oc[q] = sv;
-                ra += v[q]; rb += sv;
-            }
-            const bool al_in = off_in && ((reinterpret_cast<uintptr_t>(off_in + lo) & 15) == 0);
-            const bool al_out = off_out && ((reinterpret_cast<uintptr_t>(off_out + lo) & 15) == 0);
-#pragma unroll
-            for (int q = 0; q < PER / 4; ++q) {
-                if (off_in) {
-                    if (al_in) reinterpret_cast<uint4*>(off_in + lo)[q] = make_uint4(oa[4 * q], oa[4 * q + 1], oa[4 * q + 2], oa[4 * q + 3]);
-                    else { off_in[lo + 4 * q] = oa[4 * q]; off_in[lo + 4 * q + 1] = oa[4 * q + 1]; off_in[lo + 4 * q + 2] = oa[4 * q + 2]; off_in[lo + 4 * q + 3] = oa[4 * q + 3]; }
-                }
-                if (off_out) {
-                    if (al_out) reinterpret_cast<uint4*>(off_out + lo)[q] = make_uint4(ob[4 * q], ob[4 * q + 1], ob[4 * q + 2], ob[4 * q + 3]);
-                    else { off_out[lo + 4 * q] = ob[4 * q]; off_out[lo + 4 * q + 1] = ob[4 * q + 1]; off_out[lo + 4 * q + 2] = ob[4 * q + 2]; off_out[lo + 4 * q + 3] = ob[4 * q + 3]; }
-                }
-                if (cnt_out) reinterpret_cast<uint4*>(cnt_out + lo)[q] = make_uint4(oc[4 * q], oc[4 * q + 1], oc[4 * q + 2], oc[4 * q + 3]);
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < PER; ++q) {
-                if (lo + q < B) {
-                    uint32_t sv = ceil_div_magic(v[q], seg, seg_magic);
-                    if (off_in) off_in[lo + q] = ra;
-                    if (off_out) off_out[lo + q] = rb;
-                    if (cnt_out) cnt_out[lo + q] = sv;
-                    ra += v[q]; rb += sv;
-                }
-            }
-        }
-        carry_a += tot_a; carry_b += tot_b;
-    }
-    if (t == 0) {
-        if (off_in) off_in[B] = carry_a;
-        if (off_out) off_out[B] = carry_b;
-        if (max_out) max_out[col] = gmax;
+        for (int q = 0; q < PLAN_PER; ++q) v[q] = lo + q < B ? cnt_in[lo + q] : 0u;
     }
 }
-static void launch_plan(hipStream_t st, unsigned ncols, const uint32_t* cnt_in, uint32_t B, uint32_t seg, uint32_t* off_in,
-                        uint32_t* cnt_out, uint32_t* off_out, uint32_t* max_out) {
+__global__ void __launch_bounds__(256) k_plan_sums(const uint32_t* cnt_in_all, uint32_t B, uint32_t seg, uint32_t seg_magic,
+                                                   uint32_t* sums_all /* [col][nblk][4] */) {
+    __shared__ uint32_t w_a[4], w_b[4], w_m[4];
+    uint32_t col = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    uint32_t v[PLAN_PER];
+    plan_load(cnt_in_all + (size_t)col * B, B, blockIdx.x * PLAN_BLOCK + t * PLAN_PER, v);
+    uint32_t sa = 0, sb = 0, m = 0;
+#pragma unroll
+    for (int q = 0; q < PLAN_PER; ++q) { sa += v[q]; sb += ceil_div_magic(v[q], seg, seg_magic); m = max(m, v[q]); }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { sa += __shfl_xor(sa, d); sb += __shfl_xor(sb, d); m = max(m, __shfl_xor(m, d)); }
+    if (lane == 0) { w_a[wave] = sa; w_b[wave] = sb; w_m[wave] = m; }
+    __syncthreads();
+    if (t == 0) {
+        uint32_t* o = sums_all + ((size_t)col * gridDim.x + blockIdx.x) * 4;
+        o[0] = w_a[0] + w_a[1] + w_a[2] + w_a[3];
+        o[1] = w_b[0] + w_b[1] + w_b[2] + w_b[3];
+        o[2] = max(max(w_m[0], w_m[1]), max(w_m[2], w_m[3]));
+    }
+}
+__global__ void __launch_bounds__(256) k_plan_apply(const uint32_t* cnt_in_all, uint32_t B, uint32_t seg, uint32_t seg_magic,
+                                                    const uint32_t* sums_all, uint32_t* off_in_all, uint32_t* cnt_out_all,
+                                                    uint32_t* off_out_all, uint32_t* max_out) {
+    __shared__ uint32_t w_a[4], w_b[4], s_base[3];
+    uint32_t col = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6, nblk = gridDim.x;
+    const uint32_t* sums = sums_all + (size_t)col * nblk * 4;
+    // base of this block = sums of the blocks before it; the last block also publishes the totals
+    if (wave == 0) {
+        uint32_t ba = 0, bb = 0, bm = 0, ta = 0, tb = 0;
+        for (uint32_t j = lane; j < nblk; j += 64) {
+            uint32_t a = sums[j * 4], b = sums[j * 4 + 1];
+            if (j < blockIdx.x) { ba += a; bb += b; }
+            ta += a; tb += b; bm = max(bm, sums[j * 4 + 2]);
+        }
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            ba += __shfl_xor(ba, d); bb += __shfl_xor(bb, d); ta += __shfl_xor(ta, d); tb += __shfl_xor(tb, d);
+            bm = max(bm, __shfl_xor(bm, d));
+        }
+        if (lane == 0) {
+            s_base[0] = ba; s_base[1] = bb;
+            if (blockIdx.x == nblk - 1) {
+                if (off_in_all) off_in_all[(size_t)col * (B + 4) + B] = ta;
+                if (off_out_all) off_out_all[(size_t)col * (B + 4) + B] = tb;
+                if (max_out) max_out[col] = bm;
+            }
+        }
+    }
+    uint32_t lo = blockIdx.x * PLAN_BLOCK + t * PLAN_PER;
+    uint32_t v[PLAN_PER], sv[PLAN_PER];
+    plan_load(cnt_in_all + (size_t)col * B, B, lo, v);
+    uint32_t sa = 0, sb = 0;
+#pragma unroll
+    for (int q = 0; q < PLAN_PER; ++q) { sv[q] = ceil_div_magic(v[q], seg, seg_magic); sa += v[q]; sb += sv[q]; }
+    uint32_t ia = sa, ib = sb;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t ua = __shfl_up(ia, d), ub = __shfl_up(ib, d);
+        if ((int)lane >= d) { ia += ua; ib += ub; }
+    }
+    if (lane == 63) { w_a[wave] = ia; w_b[wave] = ib; }
+    __syncthreads();
+    uint32_t ra = s_base[0] + ia - sa, rb = s_base[1] + ib - sb;
+    for (uint32_t w = 0; w < wave; ++w) { ra += w_a[w]; rb += w_b[w]; }
+    uint32_t* off_in = off_in_all ? off_in_all + (size_t)col * (B + 4) : nullptr;
+    uint32_t* off_out = off_out_all ? off_out_all + (size_t)col * (B + 4) : nullptr;
+    uint32_t* cnt_out = cnt_out_all ? cnt_out_all + (size_t)col * B : nullptr;
+    uint32_t oa[PLAN_PER], ob[PLAN_PER];
+#pragma unroll
+    for (int q = 0; q < PLAN_PER; ++q) { oa[q] = ra; ob[q] = rb; ra += v[q]; rb += sv[q]; }
+    if (lo + PLAN_PER <= B) {
+#pragma unroll
+        for (int q = 0; q < PLAN_PER / 4; ++q) {
+            if (off_in) reinterpret_cast<uint4*>(off_in + lo)[q] = make_uint4(oa[4 * q], oa[4 * q + 1], oa[4 * q + 2], oa[4 * q + 3]);
+            if (off_out) reinterpret_cast<uint4*>(off_out + lo)[q] = make_uint4(ob[4 * q], ob[4 * q + 1], ob[4 * q + 2], ob[4 * q + 3]);
+            if (cnt_out) reinterpret_cast<uint4*>(cnt_out + lo)[q] = make_uint4(sv[4 * q], sv[4 * q + 1], sv[4 * q + 2], sv[4 * q + 3]);
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < PLAN_PER; ++q) {
+            if (lo + q < B) {
+                if (off_in) off_in[lo + q] = oa[q];
+                if (off_out) off_out[lo + q] = ob[q];
+                if (cnt_out) cnt_out[lo + q] = sv[q];
+            }
+        }
+    }
+}
+static int launch_plan(zkhip_ctx* ctx, unsigned ncols, const uint32_t* cnt_in, uint32_t B, uint32_t seg, uint32_t* off_in,
+                       uint32_t* cnt_out, uint32_t* off_out, uint32_t* max_out) {
     uint32_t magic = seg > 1 ? (uint32_t)((((uint64_t)1 << 32) + seg - 1) / seg) : 0;
-    if (B >= 32768) hipLaunchKernelGGL(k_plan<32>, dim3(ncols), dim3(1024), 0, st, cnt_in, B, seg, magic, off_in, cnt_out, off_out, max_out);
-    else if (B >= 4096) hipLaunchKernelGGL(k_plan<4>, dim3(ncols), dim3(1024), 0, st, cnt_in, B, seg, magic, off_in, cnt_out, off_out, max_out);
-    else hipLaunchKernelGGL(k_plan<1>, dim3(ncols), dim3(1024), 0, st, cnt_in, B, seg, magic, off_in, cnt_out, off_out, max_out);
+    unsigned nblk = div_up(B, PLAN_BLOCK);
+    void* d_sums;
+    ZK_TRY(ctx->get_scratch("msm_plan_sums", (size_t)ncols * nblk * 16, &d_sums));
+    hipLaunchKernelGGL(k_plan_sums, dim3(nblk, ncols), dim3(256), 0, ctx->stream, cnt_in, B, seg, magic, (uint32_t*)d_sums);
+    hipLaunchKernelGGL(k_plan_apply, dim3(nblk, ncols), dim3(256), 0, ctx->stream, cnt_in, B, seg, magic, (const uint32_t*)d_sums, off_in,
+                       cnt_out, off_out, max_out);
+    return ZKHIP_OK;
 }
 
 __device__ __forceinline__ uint32_t find_bucket(const uint32_t* off, uint32_t B, uint32_t t) {
@@ -577,7 +601,7 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
                        (const uint32_t*)d_tmp_entry, (const uint16_t*)d_tmp_key, items, d_cnt, (const uint32_t*)d_off, d_cursor,
                        (uint32_t*)d_entries); }
     { ProfScope ps(ctx, "msm_plan");
-    launch_plan(st, (unsigned)ncols, (const uint32_t*)d_cnt, B, seg, (uint32_t*)d_off, (uint32_t*)d_cntA, (uint32_t*)d_offA, (uint32_t*)d_max); }
+    ZK_TRY(launch_plan(ctx, (unsigned)ncols, (const uint32_t*)d_cnt, B, seg, (uint32_t*)d_off, (uint32_t*)d_cntA, (uint32_t*)d_offA, (uint32_t*)d_max)); }
     ZK_HIP(hipMemcpyAsync(h_max.data(), d_max, ncols * 4, hipMemcpyDeviceToHost, st));
     { ProfScope ps(ctx, "msm_digits");
     hipLaunchKernelGGL(k_sort_lo<true>, gt, dim3(256), 0, st, (const uint32_t*)d_part_off, (const uint32_t*)d_tile_start, g,
@@ -612,7 +636,7 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
     while (maxcnt > 1) {
         seg = maxcnt <= 16 ? maxcnt : 8;
         { ProfScope ps(ctx, "msm_plan");
-        launch_plan(st, (unsigned)ncols, cur_cnt, B, seg, (uint32_t*)nullptr, nxt_cnt, nxt_off, (uint32_t*)nullptr); }
+        ZK_TRY(launch_plan(ctx, (unsigned)ncols, cur_cnt, B, seg, (uint32_t*)nullptr, nxt_cnt, nxt_off, (uint32_t*)nullptr)); }
         size_t nb = bound / seg + B + 1;
         if (nb > pstride0) nb = pstride0;
         { ProfScope ps(ctx, "msm_accum_jac");

@@ -252,12 +252,11 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
         lds_attr_set = true;
     }
     // pass plan
-    // Bits per pass.  Small transforms (whole batch cache-resident) take 9 bits per pass: runs of T = 4..8 elements
-    // are fine out of L2 / Infinity Cache.  Large ones take 6 bits per pass so that every global access is a run
-    // of T = 32 elements (1 KiB): 256-byte runs at multi-megabyte strides measured ~120 GB/s (TLB / DRAM-page
-    // bound), an order of magnitude below what an extra pass over the data costs.
-    uint32_t smax = m >= 20 ? 6 : 9;
-    if (const char* e = getenv(m >= 20 ? "ZKHIP_NTT_SMAX_LARGE" : "ZKHIP_NTT_SMAX")) { int v = atoi(e); if (v >= 4 && v <= 11) smax = (uint32_t)v; }
+    // Up to 9 bits per pass (T = 4..8 elements per contiguous run).  Measured on MI355X: 6-bit passes with
+    // 1 KiB runs are 7 % SLOWER at 2^24 than 8/9-bit passes — the kernels are bound by per-element work
+    // (butterfly products, the inter-pass twiddle, canonical stores), not by the run length.
+    uint32_t smax = 9;
+    if (const char* e = getenv("ZKHIP_NTT_SMAX")) { int v = atoi(e); if (v >= 4 && v <= 11) smax = (uint32_t)v; }
     uint32_t np = m <= 11 ? 1 : (m + smax - 1) / smax;
     if (np > 6) { set_error("ntt: too many passes"); return ZKHIP_EINVAL; }
     uint32_t sw[6] = {0, 0, 0, 0, 0, 0};

@@ -50,7 +50,7 @@ SYMBOLS = [
     "zkhip_memcpy_h2d", "zkhip_memcpy_d2h", "zkhip_timer_start", "zkhip_timer_stop_ms",
     "zkhip_profile_enable", "zkhip_profile_read",
     "zkhip_srs_load", "zkhip_srs_load_device", "zkhip_srs_free", "zkhip_srs_len", "zkhip_srs_window", "zkhip_kzg_setup", "zkhip_srs_read",
-    "zkhip_msm_g1", "zkhip_msm_g1_batch_device", "zkhip_msm_g1_batch_range_device", "zkhip_msm_g1_multi_device", "zkhip_g1_add", "zkhip_g1_to_affine",
+    "zkhip_msm_g1", "zkhip_msm_g1_batch_device", "zkhip_msm_g1_batch_range_device", "zkhip_msm_g1_multi_device", "zkhip_g1_add", "zkhip_g1_to_affine", "zkhip_g1_batch_to_affine",
     "zkhip_g1_to_bytes",
     "zkhip_fft", "zkhip_fft_batch_device",
     "zkhip_domain_new", "zkhip_domain_free", "zkhip_domain_k", "zkhip_domain_extended_k", "zkhip_domain_quotient_poly_degree",
@@ -259,6 +259,14 @@ def g1_to_affine(xyz):
     return out
 
 
+def g1_batch_to_affine(xyz_rows):
+    """(n, 12) Jacobian rows -> (n, 8) affine rows with one field inversion (Curve::batch_normalize)."""
+    xyz_rows = _u64(xyz_rows).reshape(-1, 12)
+    out = np.zeros((xyz_rows.shape[0], 8), dtype=np.uint64)
+    lib().zkhip_g1_batch_to_affine(_p(xyz_rows), C.c_size_t(xyz_rows.shape[0]), _p(out))
+    return out
+
+
 def g1_add(a, b):
     out = np.zeros(12, dtype=np.uint64)
     lib().zkhip_g1_add(_p(_u64(a)), _p(_u64(b)), _p(out))
@@ -311,12 +319,16 @@ class EvaluationDomain:
 
     # device forms (asynchronous)
     def lagrange_to_coeff_device(self, polys):
+        if not polys:
+            return
         _check(lib().zkhip_lagrange_to_coeff_device(self.ctx.h, self.h, _ptr_array(polys), C.c_size_t(len(polys))))
 
     def coeff_to_lagrange_device(self, polys):
         _check(lib().zkhip_coeff_to_lagrange_device(self.ctx.h, self.h, _ptr_array(polys), C.c_size_t(len(polys))))
 
     def coeff_to_extended_device(self, polys, n_in=None):
+        if not polys:
+            return []
         outs = [self.ctx.empty(self.extended_n) for _ in polys]
         n_in = n_in if n_in is not None else polys[0].shape[0]
         _check(lib().zkhip_coeff_to_extended_device(self.ctx.h, self.h, _ptr_array(polys), C.c_size_t(n_in), _ptr_array(outs),

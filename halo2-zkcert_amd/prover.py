@@ -34,7 +34,8 @@ R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
 class CircuitShape:
     """Column / gate shape of one of the reference's circuits."""
 
-    def __init__(self, name, k, n_basic_advice, n_lookup_advice, n_instance, degree, blinding_factors, seed):
+    def __init__(self, name, k, n_basic_advice, n_lookup_advice, n_instance, degree, blinding_factors, seed, gates=None,
+                 n_fixed=None, perm_columns=None):
         self.name, self.k, self.seed = name, k, seed
         self.n_basic, self.n_lookup = n_basic_advice, n_lookup_advice
         self.n_advice = n_basic_advice + n_lookup_advice
@@ -50,6 +51,12 @@ class CircuitShape:
         self.lookups = [([A(n_basic_advice + i, 0)], [("fixed", self.n_fixed - 1, 0)]) for i in range(n_lookup_advice)]
         self.perm_columns = ([("advice", c) for c in range(self.n_advice)] + [("fixed", n_basic_advice)]
                              + [("instance", i) for i in range(n_instance)])
+        if gates is not None:
+            self.gates = gates
+        if n_fixed is not None:
+            self.n_fixed = n_fixed
+        if perm_columns is not None:
+            self.perm_columns = perm_columns
         chunk = degree - 2
         self.n_perm_sets = -(-len(self.perm_columns) // chunk)
 
@@ -58,6 +65,34 @@ class CircuitShape:
         """RSA circuit, README row k=17: 3 advice + 1 lookup-advice + 1 fixed(constants) (+ selectors, table)."""
         basic = {15: 12, 16: 6, 17: 3}.get(k, 3)
         return cls(f"rsa_k{k}", k, basic, 1, 1, 4, 6, 0xC0FFEE00 + k)
+
+    @classmethod
+    def sha256(cls, k=19, n_advice=32, n_fixed=12):
+        """zkEVM SHA-256 bit circuit shape: many narrow bit/word columns, fixed q_* and
+        round-constant columns, boolean and word-decomposition gates of degree up to 5, no lookup; the two digest words are
+        the only permutation (instance copy) columns.  Column counts are parameters (the real ones are in zkevm-hashes)."""
+        A = lambda c, r: ("advice", c, r)
+        F = lambda c, r=0: ("fixed", c, r)
+        one = ("const", 1)
+        gates = []
+        for c in range(n_advice):
+            q = F(c % n_fixed)
+            if c % 4 == 0:      # q * b * (1 - b): bit columns
+                gates.append(("prod", q, ("prod", A(c, 0), ("sum", one, ("neg", A(c, 0))))))
+            elif c % 4 == 1:    # q * (a ^ b ^ c as a degree-3 polynomial over bits of neighbouring rows)
+                x, y, z = A(c, 0), A(c - 1, 0), A(c - 1, 1)
+                xy = ("prod", x, y)
+                gates.append(("prod", q, ("sum", A(c, 1), ("neg", ("sum", ("sum", x, y), ("scaled", ("prod", xy, z), 4))))))
+            elif c % 4 == 2:    # word recomposition over rotations: q * (w - sum 2^i b_i)
+                acc = A(c - 2, -3)
+                for i, r in enumerate((-2, -1, 0, 1, 2, 3)):
+                    acc = ("sum", ("scaled", acc, 2), A(c - 2, r))
+                gates.append(("prod", q, ("sum", A(c, 0), ("neg", acc))))
+            else:               # round-constant addition with a carry bit, degree 5 with two selectors
+                t = ("sum", ("sum", A(c, 0), A(c - 1, 0)), F((c + 1) % n_fixed))
+                gates.append(("prod", ("prod", q, F((c + 5) % n_fixed)), ("prod", t, ("prod", A(c - 3, 0), ("sum", one, ("neg", A(c - 3, 1)))))))
+        return cls(f"sha256_k{k}", k, n_advice, 0, 1, 5, 6, 0x5A256000 + k, gates=gates, n_fixed=n_fixed,
+                   perm_columns=[("advice", 0), ("advice", 1), ("instance", 0)])
 
     @classmethod
     def small(cls, k=8):
@@ -133,11 +168,8 @@ class GpuBackend:
 
     def finish(self, jac_rows):
         """host (ncols, 12) uint64 -> list of (affine (8,), 32 compressed bytes)"""
-        res = []
-        for j in range(jac_rows.shape[0]):
-            a = self.ffi.g1_to_affine(jac_rows[j])
-            res.append((a, self.ffi.g1_to_bytes(a)))
-        return res
+        aff = self.ffi.g1_batch_to_affine(jac_rows)
+        return [(aff[j], self.ffi.g1_to_bytes(aff[j])) for j in range(aff.shape[0])]
 
     def commit(self, cols, lagrange):
         """one host round trip per batch (the Fiat-Shamir sync point)"""

@@ -103,6 +103,8 @@ int  zkhip_msm_g1_multi_device(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_c
 void zkhip_g1_add(const uint64_t a[12], const uint64_t b[12], uint64_t out[12]);
 /* G1::to_affine on the host for results fetched from the device (12 u64 -> 8 u64). */
 void zkhip_g1_to_affine(const uint64_t xyz[12], uint64_t out_xy[8]);
+/* n points at once with a single field inversion (Curve::batch_normalize). */
+void zkhip_g1_batch_to_affine(const uint64_t* xyz, size_t n, uint64_t* out_xy);
 /* G1Affine::to_bytes (32-byte compressed) */
 void zkhip_g1_to_bytes(const uint64_t xy[8], uint8_t out[32]);
 

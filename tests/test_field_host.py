@@ -128,3 +128,21 @@ def test_long_mixed_sum_keeps_invariants(zt, oracle):
     sc = zo.fr_arr_from_ints([(R - 1) if s else 1 for s in negs])
     exp = zo.g1_to_affine(zo.best_multiexp(sc, pts, 8))
     assert (zo.g1_to_affine(o) == exp).all()
+
+
+def test_batch_to_affine(zt, oracle):
+    zo = oracle
+    import halo2_zkcert_amd.ffi as ffi
+
+    n = 9
+    pts = zo.fixed_base_mul(zo.fr_arr_from_ints(list(range(3, 3 + n))), 2)
+    z = zo.fq_from_int(0x9876543210F)
+    z2 = zo._binary("zko_fq_mul", z, z)
+    z3 = zo._binary("zko_fq_mul", z2, z)
+    jac = np.zeros((n, 12), dtype=np.uint64)
+    for i in range(n):
+        jac[i] = np.concatenate([zo._binary("zko_fq_mul", pts[i, :4], z2), zo._binary("zko_fq_mul", pts[i, 4:], z3), z])
+    jac[4] = 0                      # identity in the middle of the batch
+    exp = pts.copy()
+    exp[4] = 0
+    assert (ffi.g1_batch_to_affine(jac) == exp).all()

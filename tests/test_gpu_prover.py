@@ -26,6 +26,21 @@ def test_pass_matches_oracle(zk, oracle, k):
         assert (ctx.to_host(a) == b).all()
 
 
+def test_sha_shape_pass_matches_oracle(zk, oracle):
+    """BASELINE configs[2] shape (wide boolean-gate circuit, degree 5 -> extension 4, no lookup) at a size the oracle
+    finishes in seconds: whole pass, byte for byte."""
+    ffi, ctx = zk
+    sh = pv.CircuitShape.sha256(9, n_advice=12, n_fixed=5)
+    gp = pv.Prover(pv.GpuBackend(ctx, ffi), sh)
+    cp = pv.Prover(OracleBackend(8), sh)
+    tg = gp.prove(gp.witness(1))
+    tc = cp.prove(cp.witness(1))
+    assert tg["commitments"] == tc["commitments"] and tg["challenges"] == tc["challenges"]
+    for a, b in zip(tg["h_pieces"], tc["h_pieces"]):
+        assert (ctx.to_host(a) == b).all()
+    assert len(tg["h_pieces"]) == 4 and gp.dom.extended_k == 11
+
+
 def test_rsa_k17_pass_properties(zk, oracle):
     """BASELINE size (configs[1], RSA k=17): size-independent checks on the full pass.
     Determinism, and the quotient pieces commit to the same points the oracle derives from the

@@ -30,3 +30,11 @@ def test_challenge_is_canonical():
     x = pv.challenge("t", [b"\x01" * 32])
     assert 0 <= x < pv.R and x == pv.challenge("t", [b"\x01" * 32]) and x != pv.challenge("u", [b"\x01" * 32])
     assert (pv.fr_from_int_host(5) == __import__("zkoracle_py").fr_from_int(5)).all()
+
+
+def test_sha_shape_counts():
+    sh = pv.CircuitShape.sha256(19)
+    # 32 advice + 1 instance, no lookup, 3 permutation columns at degree 5 -> one product polynomial, 4 quotient pieces
+    assert (sh.n_advice, sh.n_instance, len(sh.lookups), sh.n_perm_sets, sh.degree) == (32, 1, 0, 1, 5)
+    c = sh.counts(21)
+    assert c["msm"] == 32 + 0 + 1 + 1 + 4 + 2 and c["ntt_ext"] == 32 + 1 + 0 + 1
