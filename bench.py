@@ -115,10 +115,10 @@ def main():
         avg_launch_s = acc["ms_per_step"] / max(acc["launches_per_step"], 1) / 1000.0
         achieved = alg_bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         # the roofline that actually binds the kernel: the 32-bit integer multiplier (v_mad_u64_u32), measured at
-        # 29.8 T lane-ops/s chip-wide (profiles/r01_microbench_gfx950.txt).  One pair costs W windows x 11 field
-        # products x 171 mads.
+        # 29.8 T lane-ops/s chip-wide (profiles/r01_microbench_gfx950.txt).  One pair costs W windows x one XYZZ mixed
+        # addition = 8 products (171 mads) + 2 squarings (126 mads).
         c_bits, windows = prover.b.params.window()
-        mads_per_step = pairs_per_step * windows * 11 * 171
+        mads_per_step = pairs_per_step * windows * (8 * 171 + 2 * 126)
         int_achieved = mads_per_step / (acc["ms_per_step"] / 1000.0) / 1e12 if acc["ms_per_step"] > 0 else 0.0
         out = {
             "metric": "create_proof wall-time (s): RSA k=17 / SHA256 k=19 / agg k=22 at 1/2/4/8 GPU",

@@ -132,6 +132,38 @@ ZK_HD __forceinline__ fe fe_mul_raw(const fe& a, const fe& b) {
     return r;
 }
 
+// a * a / 2^261 mod p: the 36 cross products once (doubled), 9 squares, then the 81 reduction products:
+// 126 multiplier instructions instead of 171.  Columns stay below 2 * 4 * 2^58 + 2^58 + 9 * 2^58 < 2^63.
+template <class P>
+ZK_HD __forceinline__ fe fe_sqr_raw(const fe& a) {
+    uint64_t col[18];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) col[k] = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int j = i + 1; j < 9; ++j) col[i + j] += (uint64_t)a.l[i] * a.l[j];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) col[k] <<= 1;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) col[2 * i] += (uint64_t)a.l[i] * a.l[i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        uint32_t q = ((uint32_t)col[i] * P::INV) & LMASK;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) col[i + j] += (uint64_t)q * P::M[j];
+        col[i + 1] += col[i] >> LB;   // low 29 bits of col[i] are zero now
+    }
+    fe r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        r.l[j] = (uint32_t)col[9 + j] & LMASK;
+        col[10 + j] += col[9 + j] >> LB;
+    }
+    r.l[8] = (uint32_t)col[17];
+    return r;
+}
+
 // returns a - k p if that is >= 0, else a  (runtime k <= 127)
 template <class P>
 ZK_HD __forceinline__ fe fe_cond_sub_kp(const fe& a, uint32_t k) {
@@ -254,7 +286,7 @@ ZK_HD __forceinline__ el<P, mul_bound(A, B)> operator*(const el<P, A>& a, const 
 }
 template <class P, int A>
 ZK_HD __forceinline__ el<P, mul_bound(A, A)> sqr(const el<P, A>& a) {
-    return el<P, mul_bound(A, A)>(fe_mul_raw<P>(a.v, a.v));
+    return el<P, mul_bound(A, A)>(fe_sqr_raw<P>(a.v));
 }
 template <class P, int A, int B>
 ZK_HD __forceinline__ el<P, A + B> operator+(const el<P, A>& a, const el<P, B>& b) {
@@ -582,6 +614,110 @@ ZK_HD inline g1j g1j_add(const g1j& p, const g1j& q) {
     o.z = (zz - (z1z1 + z2z2)) * h;
     o.x = x3;
     return o;
+}
+
+// ---- XYZZ coordinates (x = X / ZZ, y = Y / ZZZ, ZZ^3 = ZZZ^2) for the MSM accumulators: a mixed addition is
+// 8M + 2S against 8M + 3S in Jacobian form, a full addition 12M + 2S against 11M + 5S.  ZZ and ZZZ are always
+// direct products (< 2p), which also keeps the lazy bounds small.  Identity = exact ZZ = 0.
+constexpr int XBX = 8 * U, XBY = 6 * U;
+struct g1x { el<Fq, XBX> x; el<Fq, XBY> y; el2<Fq> zz, zzz; };
+
+ZK_HD __forceinline__ bool g1x_is_id(const g1x& p) { return fe_is_zero_exact(p.zz.v); }
+ZK_HD __forceinline__ g1x g1x_identity() {
+    g1x r;
+    r.x = zero<Fq>(); r.y = one<Fq>(); r.zz = zero<Fq>(); r.zzz = zero<Fq>();
+    return r;
+}
+ZK_HD __forceinline__ g1x g1x_from_affine(const g1a& a) {
+    if (g1a_is_id(a)) return g1x_identity();
+    g1x r;
+    r.x = a.x; r.y = a.y; r.zz = one<Fq>(); r.zzz = one<Fq>();
+    return r;
+}
+ZK_HD __forceinline__ g1x g1x_load_raw(const void* p) {
+    g1x r;
+    const char* c = reinterpret_cast<const char*>(p);
+    r.x = load_raw<Fq>(c); r.y = load_raw<Fq>(c + 32); r.zz = load_raw<Fq>(c + 64); r.zzz = load_raw<Fq>(c + 96);
+    return r;
+}
+ZK_HD __forceinline__ void g1x_store_raw(void* p, const g1x& v) {
+    char* c = reinterpret_cast<char*>(p);
+    store_raw<Fq>(c, v.x); store_raw<Fq>(c + 32, v.y); store_raw<Fq>(c + 64, v.zz); store_raw<Fq>(c + 96, v.zzz);
+}
+// dbl-2008-s-1 (a = 0): 6M + 3S
+ZK_HD inline g1x g1x_double(const g1x& p) {
+    if (g1x_is_id(p)) return p;
+    auto u = mul_small<2>(p.y);
+    auto v = sqr(u);
+    auto w = u * v;
+    auto s = p.x * v;
+    auto m = mul_small<3>(sqr(p.x));
+    g1x r;
+    auto x3 = sqr(m) - mul_small<2>(s);
+    r.y = m * (s - x3) - w * p.y;
+    r.zz = v * p.zz;
+    r.zzz = w * p.zzz;
+    r.x = x3;
+    return r;
+}
+// madd-2008-s with the exceptional cases: 8M + 2S
+ZK_HD inline g1x g1x_add_mixed(const g1x& p, const g1a& q) {
+    if (g1a_is_id(q)) return p;
+    if (g1x_is_id(p)) return g1x_from_affine(q);
+    auto u2 = q.x * p.zz;
+    auto s2 = q.y * p.zzz;
+    auto pp_ = u2 - p.x;
+    auto r = s2 - p.y;
+    if (is_zero(pp_)) {
+        if (is_zero(r)) return g1x_double(p);
+        return g1x_identity();
+    }
+    auto pp = sqr(pp_);
+    auto ppp = pp_ * pp;
+    auto q_ = p.x * pp;
+    g1x o;
+    auto x3 = sqr(r) - (ppp + mul_small<2>(q_));
+    o.y = r * (q_ - x3) - p.y * ppp;
+    o.zz = p.zz * pp;
+    o.zzz = p.zzz * ppp;
+    o.x = x3;
+    return o;
+}
+// add-2008-s with the exceptional cases: 12M + 2S
+ZK_HD inline g1x g1x_add(const g1x& p, const g1x& q) {
+    if (g1x_is_id(p)) return q;
+    if (g1x_is_id(q)) return p;
+    auto u1 = p.x * q.zz;
+    auto u2 = q.x * p.zz;
+    auto s1 = p.y * q.zzz;
+    auto s2 = q.y * p.zzz;
+    auto pp_ = u2 - u1;
+    auto r = s2 - s1;
+    if (is_zero(pp_)) {
+        if (is_zero(r)) return g1x_double(p);
+        return g1x_identity();
+    }
+    auto pp = sqr(pp_);
+    auto ppp = pp_ * pp;
+    auto q_ = u1 * pp;
+    g1x o;
+    auto x3 = sqr(r) - (ppp + mul_small<2>(q_));
+    o.y = r * (q_ - x3) - s1 * ppp;
+    o.zz = p.zz * q.zz * pp;
+    o.zzz = p.zzz * q.zzz * ppp;
+    o.x = x3;
+    return o;
+}
+// XYZZ -> a Jacobian representative with Z = ZZ * ZZZ (no inversion): X' = X ZZ ZZZ^2, Y' = Y ZZ^3 ZZZ^2
+ZK_HD inline g1j g1x_to_jacobian(const g1x& p) {
+    if (g1x_is_id(p)) return g1j_identity();
+    auto z3sq = sqr(p.zzz);
+    auto t = p.zz * z3sq;            // ZZ ZZZ^2
+    g1j r;
+    r.x = p.x * t;
+    r.y = p.y * (t * sqr(p.zz));     // ZZ^3 ZZZ^2
+    r.z = p.zz * p.zzz;
+    return r;
 }
 
 // table entry (canonical coordinates) -> (x, +-y) as a madd operand; the identity stays the exact (0, 0)

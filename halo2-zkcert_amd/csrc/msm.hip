@@ -435,12 +435,12 @@ __global__ void __launch_bounds__(256) k_accum_affine(const uint32_t* const* tab
     uint32_t b = find_bucket(segoff, B, t);
     uint32_t s = t - segoff[b];
     uint32_t lo = off[b] + s * seg, hi = min(lo + seg, off[b] + cnt[b]);
-    g1j acc = g1j_identity();
+    g1x acc = g1x_identity();
     for (uint32_t j = lo; j < hi; ++j) {
         uint32_t e = entries[j];
-        acc = g1j_add_mixed(acc, g1a_load_raw_cneg(table + (size_t)(e & 0x7fffffffu) * 16, (e >> 31) != 0));
+        acc = g1x_add_mixed(acc, g1a_load_raw_cneg(table + (size_t)(e & 0x7fffffffu) * 16, (e >> 31) != 0));
     }
-    g1j_store_raw(partial_all + ((size_t)col * partial_stride + t) * 24, acc);
+    g1x_store_raw(partial_all + ((size_t)col * partial_stride + t) * 32, acc);
 }
 // Rounds >= 1: segment sums of Jacobian partials.
 __global__ void __launch_bounds__(256) k_accum_jac(const uint32_t* in_all, size_t in_stride, const uint32_t* cnt_all,
@@ -452,20 +452,20 @@ __global__ void __launch_bounds__(256) k_accum_jac(const uint32_t* in_all, size_
     if (t >= segoff[B]) return;
     const uint32_t* cnt = cnt_all + (size_t)col * B;
     const uint32_t* off = off_all + (size_t)col * (B + 4);
-    const uint32_t* in = in_all + (size_t)col * in_stride * 24;
+    const uint32_t* in = in_all + (size_t)col * in_stride * 32;
     uint32_t b = find_bucket(segoff, B, t);
     uint32_t s = t - segoff[b];
     uint32_t lo = off[b] + s * seg, hi = min(lo + seg, off[b] + cnt[b]);
-    g1j acc = g1j_load_raw(in + (size_t)lo * 24);
-    for (uint32_t j = lo + 1; j < hi; ++j) acc = g1j_add(acc, g1j_load_raw(in + (size_t)j * 24));
-    g1j_store_raw(out_all + ((size_t)col * out_stride + t) * 24, acc);
+    g1x acc = g1x_load_raw(in + (size_t)lo * 32);
+    for (uint32_t j = lo + 1; j < hi; ++j) acc = g1x_add(acc, g1x_load_raw(in + (size_t)j * 32));
+    g1x_store_raw(out_all + ((size_t)col * out_stride + t) * 32, acc);
 }
 
-__device__ __forceinline__ void block_tree_sum(g1j* sh, uint32_t t, uint32_t nthreads, const g1j& mine) {
+__device__ __forceinline__ void block_tree_sum(g1x* sh, uint32_t t, uint32_t nthreads, const g1x& mine) {
     sh[t] = mine;
     __syncthreads();
     for (uint32_t d = nthreads >> 1; d >= 1; d >>= 1) {
-        if (t < d) sh[t] = g1j_add(sh[t], sh[t + d]);
+        if (t < d) sh[t] = g1x_add(sh[t], sh[t + d]);
         __syncthreads();
     }
 }
@@ -474,42 +474,42 @@ __device__ __forceinline__ void block_tree_sum(g1j* sh, uint32_t t, uint32_t nth
 __global__ void __launch_bounds__(256) k_bucket_chunks(const uint32_t* part_all, size_t part_stride, const uint32_t* cnt_all,
                                                        const uint32_t* off_all, uint32_t B, uint32_t CH, uint32_t* out_all,
                                                        uint32_t nchunks) {
-    __shared__ g1j sh[256];
+    __shared__ g1x sh[256];
     uint32_t col = blockIdx.y;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    g1j acc = g1j_identity();
+    g1x acc = g1x_identity();
     if (t < nchunks) {
         const uint32_t* cnt = cnt_all + (size_t)col * B;
         const uint32_t* off = off_all + (size_t)col * (B + 4);
-        const uint32_t* part = part_all + (size_t)col * part_stride * 24;
+        const uint32_t* part = part_all + (size_t)col * part_stride * 32;
         uint32_t base = t * CH;
-        g1j run = g1j_identity();
+        g1x run = g1x_identity();
         for (int j = (int)CH - 1; j >= 0; --j) {
             uint32_t b = base + (uint32_t)j;
-            if (b < B && cnt[b]) run = g1j_add(run, g1j_load_raw(part + (size_t)off[b] * 24));
-            acc = g1j_add(acc, run);
+            if (b < B && cnt[b]) run = g1x_add(run, g1x_load_raw(part + (size_t)off[b] * 32));
+            acc = g1x_add(acc, run);
         }
         // + base * run
-        g1j d = run;
+        g1x d = run;
         uint32_t m = base;
         while (m) {
-            if (m & 1) acc = g1j_add(acc, d);
+            if (m & 1) acc = g1x_add(acc, d);
             m >>= 1;
-            if (m) d = g1j_double(d);
+            if (m) d = g1x_double(d);
         }
     }
     block_tree_sum(sh, threadIdx.x, 256, acc);
-    if (threadIdx.x == 0) g1j_store_raw(out_all + ((size_t)col * gridDim.x + blockIdx.x) * 24, sh[0]);
+    if (threadIdx.x == 0) g1x_store_raw(out_all + ((size_t)col * gridDim.x + blockIdx.x) * 32, sh[0]);
 }
 
 __global__ void __launch_bounds__(64) k_final_sum(const uint32_t* in_all, uint32_t count, uint32_t* out_all) {
-    __shared__ g1j sh[64];
+    __shared__ g1x sh[64];
     uint32_t col = blockIdx.x, t = threadIdx.x;
-    const uint32_t* in = in_all + (size_t)col * count * 24;
-    g1j acc = g1j_identity();
-    for (uint32_t i = t; i < count; i += 64) acc = g1j_add(acc, g1j_load_raw(in + (size_t)i * 24));
+    const uint32_t* in = in_all + (size_t)col * count * 32;
+    g1x acc = g1x_identity();
+    for (uint32_t i = t; i < count; i += 64) acc = g1x_add(acc, g1x_load_raw(in + (size_t)i * 32));
     block_tree_sum(sh, t, 64, acc);
-    if (t == 0) g1j_store_abi(out_all + (size_t)col * 24, sh[0]);   // the ABI result: halo2curves G1 (R = 2^256)
+    if (t == 0) g1j_store_abi(out_all + (size_t)col * 24, g1x_to_jacobian(sh[0]));   // the ABI result: halo2curves G1 (R = 2^256)
 }
 __global__ void k_set_identity(uint32_t* out_all, uint32_t ncols) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -570,12 +570,12 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
     ZK_TRY(ctx->get_scratch("msm_cntB", ncols * B * 4, &d_cntB));
     ZK_TRY(ctx->get_scratch("msm_offA", ncols * (B + 4) * 4, &d_offA));
     ZK_TRY(ctx->get_scratch("msm_offB", ncols * (B + 4) * 4, &d_offB));
-    ZK_TRY(ctx->get_scratch("msm_pA", ncols * pstride0 * 96, &d_pA));
-    ZK_TRY(ctx->get_scratch("msm_pB", ncols * pstride0 * 96, &d_pB));
+    ZK_TRY(ctx->get_scratch("msm_pA", ncols * pstride0 * 128, &d_pA));
+    ZK_TRY(ctx->get_scratch("msm_pB", ncols * pstride0 * 128, &d_pB));
     uint32_t CH = B > 8192 ? B / 8192 : 1;
     uint32_t nchunks = (B + CH - 1) / CH;
     uint32_t nchunk_blocks = div_up(nchunks, 256);
-    ZK_TRY(ctx->get_scratch("msm_chunks", ncols * (size_t)nchunk_blocks * 96, &d_chunks));
+    ZK_TRY(ctx->get_scratch("msm_chunks", ncols * (size_t)nchunk_blocks * 128, &d_chunks));
 
     std::vector<const void*> h_ptrs(2 * ncols);
     for (size_t j = 0; j < ncols; ++j) { h_ptrs[j] = d_cols_host[j]; h_ptrs[ncols + j] = srs_per_col[j]->d_table; }

@@ -34,6 +34,25 @@ void zkt_fr_raw_roundtrip(const uint64_t* a, uint64_t* o) { store_raw<Fr>(o, loa
 void zkt_fr_x32_roundtrip(const uint64_t* a, uint64_t* o) { store_div32<Fr>(o, load_x32<Fr>(a)); }
 void zkt_fr_to_canonical(const uint64_t* a, uint64_t* o) { mem_store(o, abi_to_canonical_words<Fr>(mem_load(a))); }
 void zkt_fr_from_canonical(const uint64_t* a, uint64_t* o) { mem_store(o, to_abi(from_canonical_words<Fr>((const uint32_t*)a))); }
+// the same sum through the XYZZ accumulator the MSM kernels use
+void zkt_g1x_sum_mixed(const uint64_t* pts_abi, const uint8_t* negs, size_t n, uint64_t* o) {
+    g1x acc = g1x_identity(), other = g1x_identity();
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t raw[8];
+        g1a_store_raw(raw, g1a_load_abi(pts_abi + 8 * i));
+        g1x& tgt = (i & 1) ? other : acc;          // two partial sums, folded with the full addition below
+        tgt = g1x_add_mixed(tgt, g1a_load_raw_cneg(raw, negs[i] != 0));
+        if (i % 5 == 2) {
+            uint64_t x[16];
+            g1x_store_raw(x, tgt);
+            tgt = g1x_load_raw(x);
+        }
+        if (i % 64 == 63) { acc = g1x_add(acc, other); other = g1x_identity(); }
+    }
+    acc = g1x_add(acc, other);
+    acc = g1x_add(acc, g1x_double(acc));            // 3 * sum
+    g1j_store_abi(o, g1x_to_jacobian(acc));
+}
 // canonical(v + k p) == v for every k the lazy representation allows
 int zkt_canon_kp(const uint64_t* a, uint32_t k, int field) {
     fe v = fe_split<0>(mem_load(a)), s = v;

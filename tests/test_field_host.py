@@ -128,6 +128,11 @@ def test_long_mixed_sum_keeps_invariants(zt, oracle):
     sc = zo.fr_arr_from_ints([(R - 1) if s else 1 for s in negs])
     exp = zo.g1_to_affine(zo.best_multiexp(sc, pts, 8))
     assert (zo.g1_to_affine(o) == exp).all()
+    # XYZZ accumulators (mixed add, full add, double, storage round trip): 3 * the same sum
+    zt.zkt_g1x_sum_mixed(zo.p(pts), negs.ctypes.data_as(C.c_void_p), C.c_size_t(n), zo.p(o))
+    sc3 = zo.fr_arr_from_ints([(R - 3) if s else 3 for s in negs])
+    exp3 = zo.g1_to_affine(zo.best_multiexp(sc3, pts, 8))
+    assert (zo.g1_to_affine(o) == exp3).all()
 
 
 def test_batch_to_affine(zt, oracle):
