@@ -25,6 +25,24 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
+def host_threads():
+    """Cores this process may actually use: scheduler affinity, capped by a cgroup CPU quota if one is set."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = max(1, min(n, q // per))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(shape, threads):
     """The CPU oracle (oracle/zkoracle.c, OpenMP) running the same schedule once on the host cores.
     kind = "port": the reference's rayon prover cannot be built here (no Rust; un-vendored crates)."""
@@ -135,7 +153,11 @@ def main():
                        "parallelism": "1 GPU" if world == 1 else (f"one proof, MSM point-range sharded x{world}, NTT/sweep replicated" if shard
                                                                    else f"{world} independent proofs, one per GPU, no collective")},
             "roofline": {"kernel": "msm_accum_affine (k_accum_affine)", "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0,
-                         "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / 8000.0, 5),
+                         # HBM bytes per launch from the PMC passes committed in profiles/r01_v3_pmc_fetch_write.csv
+                         # (FETCH_SIZE + WRITE_SIZE of k_accum_affine: 144.5 MB + 35.4 MB per 2^17 x 16-window column =
+                         # 85.8 B per (pair, window)), scaled to this launch shape; not re-measured live.
+                         "traffic": round(85.8 * (pairs_per_step / max(acc["launches_per_step"], 1)) * windows),
                          "algorithmic_bytes_per_launch": round(alg_bytes_per_launch),
                          "avg_launch_ms": round(avg_launch_s * 1000.0, 4),
                          "note": "MSM is integer-multiply bound, not HBM bound: see int_roofline and DESIGN.md"},
@@ -144,7 +166,7 @@ def main():
             "kernels_ms_per_step": kernels,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(shape, os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(shape, host_threads())
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
