@@ -5,8 +5,9 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A step = one pass of halo2_zkcert_amd.prover.Prover.prove over the RSA k=17 synthetic table
-(BASELINE.json configs[1]): 16 MSM_2^17, 11 iNTT_2^17, 11 NTT_2^19 + 1 iNTT_2^19, one 2^19-row sweep,
-with a host round trip at every Fiat-Shamir point.  Inputs (witness columns, SRS, pk cosets) are resident
+(BASELINE.json configs[1]): 16 MSM_2^17, 11 iNTT_2^17, 11 NTT_2^19 + 1 iNTT_2^19, one 2^19-row sweep, the lookup
+theta-compression, the permutation / lookup grand products and the evaluations at x, with a host round trip at
+every Fiat-Shamir point.  Inputs (witness columns, SRS, pk cosets) are resident
 in HBM before the timed region.  Prints ONE JSON line (rank 0).
 
 N > 1: one process per GPU over RCCL.  Default: the path partitions by proof (the reference's leaf proofs are
@@ -119,7 +120,8 @@ def main():
     ms_per_step = dt * 1000.0 / args.steps
 
     kernels = {}
-    for name in ("msm_digits", "msm_plan", "msm_accum_affine", "msm_accum_jac", "msm_tail", "ntt_strided", "ntt_final", "sweep"):
+    for name in ("msm_digits", "msm_plan", "msm_accum_affine", "msm_accum_jac", "msm_tail", "ntt_strided", "ntt_final", "sweep",
+                 "grand_product", "eval_polynomial"):
         ms, launches = ctx.profile_read(name)
         kernels[name] = dict(ms_per_step=round(ms / args.steps, 4), launches_per_step=launches / args.steps)
     ctx.profile_enable(False)
@@ -146,8 +148,10 @@ def main():
             "dtype": "u256 (8x u32 Montgomery limbs, BN254 Fr/Fq)", "data": "synthetic",
             "config": {"workload": f"create_proof-shaped hot-path pass, {shape.name}: {counts['msm']} MSM_2^{shape.k} + "
                                    f"{counts['intt_n']} iNTT_2^{shape.k} + {counts['ntt_ext']} NTT_2^{prover.dom.extended_k} + "
-                                   f"1 iNTT_2^{prover.dom.extended_k} + 1 sweep over 2^{prover.dom.extended_k} rows; "
-                                   "uniform synthetic witness; BLAKE2b stand-in transcript",
+                                   f"1 iNTT_2^{prover.dom.extended_k} + 1 sweep over 2^{prover.dom.extended_k} rows + lookup compression, "
+                                   f"{shape.n_perm_sets}+{len(shape.lookups)} grand products, evaluations at x; "
+                                   "uniform synthetic witness; permuted lookup columns and SHPLONK polynomials synthetic; "
+                                   "BLAKE2b stand-in transcript",
                        "k": shape.k, "advice": shape.n_advice, "fixed": shape.n_fixed, "lookups": len(shape.lookups),
                        "perm_columns": len(shape.perm_columns), "degree": shape.degree,
                        "parallelism": "1 GPU" if world == 1 else (f"one proof, MSM point-range sharded x{world}, NTT/sweep replicated" if shard

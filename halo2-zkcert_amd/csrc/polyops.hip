@@ -1,0 +1,482 @@
+// polyops.hip — the O(n) field work of create_proof between the commitments ("next" tier):
+// batch inversion, running products (permutation / lookup grand products), polynomial evaluation at a point.
+//
+// Restates halo2_proofs plonk/permutation/prover.rs (Argument::commit), plonk/lookup/prover.rs (commit_product),
+// arithmetic.rs (eval_polynomial) and ff::BatchInvert [UPSTREAM-RECALL; crate pinned at
+// /root/reference/Cargo.lock:1320-1322].  Values are unique, so the evaluation order is free; the random blinding
+// rows upstream draws from its rng are an input.
+//
+// All three are latency-shaped on a GPU (a Fermat inversion is 380 dependent products; a scan is log-depth), so the
+// kernels keep 8 elements per thread in registers, combine 256 threads through an LDS product tree and use ONE
+// inversion per 2048 elements.
+#include <algorithm>
+
+#include "common.hpp"
+using namespace zk;
+
+#define PO_PER 8
+#define PO_BLOCK 256
+#define PO_TILE (PO_PER * PO_BLOCK)
+
+// ------------------------------------------------------------------ batch inversion
+// FORM 0: raw R'-form scratch (internal);  FORM 1: ABI values (x 2^256) in and out.
+template <int FORM>
+__device__ __forceinline__ el2<Fr> inv_load(const uint32_t* p) {
+    if (FORM == 0) return load_raw<Fr>(p);
+    return reduce(load_x32<Fr>(p));
+}
+template <int FORM>
+__device__ __forceinline__ void inv_store(uint32_t* p, const el2<Fr>& v) {
+    if (FORM == 0) store_raw<Fr>(p, v); else store_div32<Fr>(p, v);
+}
+
+template <int FORM>
+__global__ void __launch_bounds__(PO_BLOCK) k_batch_invert(uint32_t* a, size_t n) {
+    __shared__ fe tree[2 * PO_BLOCK];   // tree[256 + t] = leaf t, tree[i] = tree[2i] * tree[2i+1]
+    const uint32_t t = threadIdx.x;
+    const size_t base = (size_t)blockIdx.x * PO_TILE;
+    // element j of thread t: index base + j * 256 + t (coalesced; the grouping is irrelevant to an inversion)
+    el2<Fr> v[PO_PER], pre[PO_PER];
+    el2<Fr> acc = one<Fr>();
+#pragma unroll
+    for (int j = 0; j < PO_PER; ++j) {
+        size_t i = base + (size_t)j * PO_BLOCK + t;
+        v[j] = one<Fr>();
+        if (i < n) {
+            v[j] = inv_load<FORM>(a + i * 8);
+            if (fe_is_zero_modp<Fr>(v[j].v)) v[j] = el2<Fr>(fe_zero());
+        }
+        pre[j] = acc;
+        if (!fe_is_zero_exact(v[j].v)) acc = acc * v[j];
+    }
+    tree[PO_BLOCK + t] = acc.v;
+    __syncthreads();
+    for (uint32_t w = PO_BLOCK / 2; w >= 1; w >>= 1) {
+        if (t < w) tree[w + t] = (el2<Fr>(tree[2 * (w + t)]) * el2<Fr>(tree[2 * (w + t) + 1])).v;
+        __syncthreads();
+    }
+    // every lane of wave 0 inverts the root (same cost as one lane; avoids a broadcast)
+    __shared__ fe root_inv;
+    if (t < 64) {
+        el2<Fr> r = inv<Fr>(el2<Fr>(tree[1]));
+        if (t == 0) root_inv = r.v;
+    }
+    __syncthreads();
+    // down-sweep: inv(node) known -> inv(left) = inv(node) * right, inv(right) = inv(node) * left
+    if (t == 0) tree[1] = root_inv;
+    __syncthreads();
+    for (uint32_t w = 1; w < PO_BLOCK; w <<= 1) {
+        if (t < w) {
+            uint32_t node = w + t;
+            el2<Fr> in(tree[node]), l(tree[2 * node]), r(tree[2 * node + 1]);
+            tree[2 * node] = (in * r).v;
+            tree[2 * node + 1] = (in * l).v;
+        }
+        __syncthreads();
+    }
+    el2<Fr> iv(tree[PO_BLOCK + t]);   // inverse of this thread's product
+#pragma unroll
+    for (int j = PO_PER - 1; j >= 0; --j) {
+        size_t i = base + (size_t)j * PO_BLOCK + t;
+        if (!fe_is_zero_exact(v[j].v)) {
+            el2<Fr> r = iv * pre[j];
+            iv = iv * v[j];
+            if (i < n) inv_store<FORM>(a + i * 8, r);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ running products
+// Exclusive prefix products over `nseg` independent arrays of n raw R'-form values (in), 8 consecutive per thread:
+//   pass 1: out_local[i] = product of in[tile_start .. i) within the tile, block_tot[seg][blk] = product of the tile
+//   pass 2: block_pre[seg][blk] = product of the tiles before blk (one block per segment)
+//   pass 3: z[i] = first[seg] * block_pre * out_local   (ABI form), rows >= n_keep replaced by the blinding values
+__global__ void __launch_bounds__(PO_BLOCK) k_rp_local(const uint32_t* in_all, size_t n, uint32_t* local_all, uint32_t* block_tot_all,
+                                                       uint32_t nblk) {
+    __shared__ fe sc[PO_BLOCK];
+    const uint32_t t = threadIdx.x, seg = blockIdx.y;
+    const uint32_t* in = in_all + (size_t)seg * n * 8;
+    uint32_t* local = local_all + (size_t)seg * n * 8;
+    const size_t lo = (size_t)blockIdx.x * PO_TILE + (size_t)t * PO_PER;
+    el2<Fr> pre[PO_PER];
+    el2<Fr> acc = one<Fr>();
+#pragma unroll
+    for (int j = 0; j < PO_PER; ++j) {
+        pre[j] = acc;
+        if (lo + j < n) acc = acc * load_raw<Fr>(in + (lo + j) * 8);
+    }
+    // inclusive scan of the per-thread products (Hillis-Steele, 8 steps)
+    sc[t] = acc.v;
+    __syncthreads();
+    for (uint32_t d = 1; d < PO_BLOCK; d <<= 1) {
+        fe other;
+        bool has = t >= d;
+        if (has) other = sc[t - d];
+        __syncthreads();
+        if (has) sc[t] = (el2<Fr>(sc[t]) * el2<Fr>(other)).v;
+        __syncthreads();
+    }
+    el2<Fr> before = t ? el2<Fr>(sc[t - 1]) : el2<Fr>(one<Fr>());
+#pragma unroll
+    for (int j = 0; j < PO_PER; ++j)
+        if (lo + j < n) store_raw<Fr>(local + (lo + j) * 8, before * pre[j]);
+    if (t == PO_BLOCK - 1) store_raw<Fr>(block_tot_all + ((size_t)seg * nblk + blockIdx.x) * 8, el2<Fr>(sc[t]));
+}
+__global__ void __launch_bounds__(1024) k_rp_blocks(const uint32_t* block_tot_all, uint32_t* block_pre_all, uint32_t nblk) {
+    __shared__ fe sc[1024];
+    const uint32_t t = threadIdx.x, seg = blockIdx.x;
+    const uint32_t* tot = block_tot_all + (size_t)seg * nblk * 8;
+    uint32_t* pre = block_pre_all + (size_t)seg * nblk * 8;
+    el2<Fr> carry = one<Fr>();
+    for (uint32_t b0 = 0; b0 < nblk; b0 += 1024) {
+        uint32_t b = b0 + t;
+        sc[t] = b < nblk ? load_raw<Fr>(tot + (size_t)b * 8).v : one<Fr>().v;
+        __syncthreads();
+        for (uint32_t d = 1; d < 1024; d <<= 1) {
+            fe other;
+            bool has = t >= d;
+            if (has) other = sc[t - d];
+            __syncthreads();
+            if (has) sc[t] = (el2<Fr>(sc[t]) * el2<Fr>(other)).v;
+            __syncthreads();
+        }
+        el2<Fr> excl = t ? el2<Fr>(sc[t - 1]) : el2<Fr>(one<Fr>());
+        if (b < nblk) store_raw<Fr>(pre + (size_t)b * 8, carry * excl);
+        carry = carry * el2<Fr>(sc[1023]);
+        __syncthreads();
+    }
+}
+// seg_first[seg]: raw R'-form multiplier of the whole segment (chains the permutation sets); may be null (= 1)
+__global__ void __launch_bounds__(PO_BLOCK) k_rp_apply(const uint32_t* local_all, const uint32_t* block_pre_all, const uint32_t* seg_first,
+                                                       size_t n, uint32_t nblk, uint32_t* const* z_out, size_t n_keep,
+                                                       const uint32_t* blinding_all /* [seg][n - n_keep] ABI */) {
+    const uint32_t seg = blockIdx.y;
+    size_t i = (size_t)blockIdx.x * PO_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    uint32_t* z = z_out[seg];
+    if (i >= n_keep) {
+        mem_store(z + i * 8, mem_load(blinding_all + ((size_t)seg * (n - n_keep) + (i - n_keep)) * 8));
+        return;
+    }
+    el2<Fr> v = load_raw<Fr>(local_all + ((size_t)seg * n + i) * 8) * load_raw<Fr>(block_pre_all + ((size_t)seg * nblk + i / PO_TILE) * 8);
+    if (seg_first) v = v * load_raw<Fr>(seg_first + (size_t)seg * 8);
+    store_div32<Fr>(z + i * 8, v);   // R' form -> ABI form
+}
+// seg_first[0] = 1, seg_first[s] = seg_first[s-1] * (unchained z_{s-1}[last_row])  with unchained z = block_pre * local
+// (segments >= nchain are independent: first = 1)
+__global__ void k_rp_chain(const uint32_t* local_all, const uint32_t* block_pre_all, size_t n, uint32_t nblk, uint32_t nseg, uint32_t nchain,
+                           size_t last_row, uint32_t* seg_first) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    el2<Fr> f = one<Fr>();
+    for (uint32_t s = 0; s < nseg; ++s) {
+        if (s >= nchain) { store_raw<Fr>(seg_first + (size_t)s * 8, one<Fr>()); continue; }
+        store_raw<Fr>(seg_first + (size_t)s * 8, f);
+        el2<Fr> last = load_raw<Fr>(local_all + ((size_t)s * n + last_row) * 8) * load_raw<Fr>(block_pre_all + ((size_t)s * nblk + last_row / PO_TILE) * 8);
+        f = f * last;
+    }
+}
+
+// ------------------------------------------------------------------ permutation / lookup fractions
+struct PermParams {
+    const uint32_t* const* values;   // ncols ABI columns (Lagrange)
+    const uint32_t* const* sigmas;   // ncols ABI columns
+    uint32_t ncols, chunk_len;
+    fe beta, gamma;                  // R' form, canonical
+    const uint32_t* dbeta;           // [ncols] raw R' form: delta^j * beta
+    const uint32_t* w_lo; const uint32_t* w_hi; uint32_t w_h;   // omega^i = lo * hi
+};
+// DEN = 1: out[set][i] = prod_j (beta sigma_j + gamma + v_j);  DEN = 0: out[set][i] *= prod_j (delta^j w^i beta + gamma + v_j)
+template <int DEN>
+__global__ void __launch_bounds__(256) k_perm_terms(PermParams P, size_t n, uint32_t* out_all) {
+    const uint32_t set = blockIdx.y;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const el1<Fr> beta(P.beta), gamma(P.gamma);
+    uint32_t c0 = set * P.chunk_len, c1 = min(c0 + P.chunk_len, P.ncols);
+    uint32_t* out = out_all + ((size_t)set * n + i) * 8;
+    el2<Fr> acc = one<Fr>();
+    if (DEN) {
+        for (uint32_t c = c0; c < c1; ++c)
+            acc = acc * (beta * load_x32<Fr>(P.sigmas[c] + i * 8) + gamma + load_x32<Fr>(P.values[c] + i * 8));
+    } else {
+        acc = load_raw<Fr>(out);
+        el2<Fr> wi = load_raw<Fr>(P.w_lo + (i & (((size_t)1 << P.w_h) - 1)) * 8) * load_raw<Fr>(P.w_hi + (i >> P.w_h) * 8);
+        for (uint32_t c = c0; c < c1; ++c)
+            acc = acc * (wi * load_raw<Fr>(P.dbeta + (size_t)c * 8) + gamma + load_x32<Fr>(P.values[c] + i * 8));
+    }
+    store_raw<Fr>(out, acc);
+}
+// DEN = 1: out[i] = (pin + beta)(ptab + gamma);  DEN = 0: out[i] *= (cin + beta)(ctab + gamma)
+template <int DEN>
+__global__ void __launch_bounds__(256) k_lookup_terms(const uint32_t* a, const uint32_t* b, fe beta_v, fe gamma_v, size_t n, uint32_t* out) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const el1<Fr> beta(beta_v), gamma(gamma_v);
+    auto t = (load_x32<Fr>(a + i * 8) + beta) * (load_x32<Fr>(b + i * 8) + gamma);
+    if (DEN) store_raw<Fr>(out + i * 8, t);
+    else store_raw<Fr>(out + i * 8, load_raw<Fr>(out + i * 8) * t);
+}
+
+// ------------------------------------------------------------------ evaluation at a point
+// partial[poly][blk] = sum_{i in tile} c_i x^(i - tile_start)   (coefficients loaded raw: the sum is linear in them)
+// xs: raw R'-form points, one per polynomial
+__global__ void __launch_bounds__(PO_BLOCK) k_eval_tiles(const uint32_t* const* polys, size_t n, const uint32_t* xs, uint32_t* partial_all, uint32_t nblk) {
+    __shared__ fe sc[PO_BLOCK];
+    const uint32_t t = threadIdx.x, poly = blockIdx.y;
+    const uint32_t* c = polys[poly];
+    const el2<Fr> x = load_raw<Fr>(xs + (size_t)poly * 8);
+    const size_t lo = (size_t)blockIdx.x * PO_TILE + (size_t)t * PO_PER;
+    // Horner over this thread's 8 coefficients
+    el<Fr, 4 * U> acc = zero<Fr>();
+#pragma unroll
+    for (int j = PO_PER - 1; j >= 0; --j) {
+        el1<Fr> cj = zero<Fr>();
+        if (lo + j < n) cj = load_raw<Fr>(c + (lo + j) * 8);
+        acc = acc * x + cj;
+    }
+    sc[t] = acc.v;
+    // x^8, then pairwise: left + right * x^(8 * span)
+    el2<Fr> xp = x;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) xp = sqr(xp);
+    __syncthreads();
+    for (uint32_t span = 1; span < PO_BLOCK; span <<= 1) {
+        if ((t & (2 * span - 1)) == 0) sc[t] = (el<Fr, 4 * U>(sc[t]) + el<Fr, 4 * U>(sc[t + span]) * xp).v;   // < 4p + 2p: contract below
+        __syncthreads();
+        if ((t & (2 * span - 1)) == 0) sc[t] = reduce(el<Fr, 8 * U>(sc[t])).v;
+        xp = sqr(xp);
+        __syncthreads();
+    }
+    if (t == 0) store_raw<Fr>(partial_all + ((size_t)poly * nblk + blockIdx.x) * 8, el2<Fr>(sc[0]));
+}
+// out[poly] = sum_b partial[poly][b] * x^(2048 b), one block per polynomial
+__global__ void __launch_bounds__(PO_BLOCK) k_eval_final(const uint32_t* partial_all, uint32_t nblk, const uint32_t* xs, uint32_t* out) {
+    __shared__ fe sc[PO_BLOCK];
+    const uint32_t t = threadIdx.x, poly = blockIdx.x;
+    const uint32_t* part = partial_all + (size_t)poly * nblk * 8;
+    el2<Fr> xt = pow_u64<Fr>(el2<Fr>(load_raw<Fr>(xs + (size_t)poly * 8)), PO_TILE);   // x^2048
+    el2<Fr> step = pow_u64<Fr>(xt, PO_BLOCK);                        // x^(2048 * 256)
+    el2<Fr> xw = pow_u64<Fr>(xt, t);                                 // x^(2048 t)
+    el<Fr, 4 * U> acc = zero<Fr>();
+    for (uint32_t b = t; b < nblk; b += PO_BLOCK) {
+        acc = reduce(acc + load_raw<Fr>(part + (size_t)b * 8) * xw);
+        xw = xw * step;
+    }
+    sc[t] = acc.v;
+    __syncthreads();
+    for (uint32_t d = PO_BLOCK / 2; d >= 1; d >>= 1) {
+        if (t < d) sc[t] = reduce(el<Fr, 4 * U>(sc[t]) + el<Fr, 4 * U>(sc[t + d])).v;
+        __syncthreads();
+    }
+    if (t == 0) store_raw<Fr>(out + (size_t)poly * 8, el2<Fr>(sc[0]));
+}
+
+// ------------------------------------------------------------------ host drivers
+static fe32 abi_to_raw(const uint64_t* p) { return fe_pack(fe_canonical<Fr>(from_abi<Fr>(mem_load(p)).v)); }
+static fe abi_to_fe(const uint64_t* p) { return fe_canonical<Fr>(from_abi<Fr>(mem_load(p)).v); }
+
+// z_out[seg] (ABI) = running products of nseg raw arrays `d_terms` ([seg][n]); chain: multiply segment s by the last kept row of s-1
+static int running_products(zkhip_ctx* ctx, const void* d_terms, uint32_t nseg, size_t n, size_t n_keep, uint32_t nchain, size_t chain_row,
+                            const void* d_blinding, void* const* z_out_host) {
+    const bool chain = nchain > 1;
+    hipStream_t st = ctx->stream;
+    uint32_t nblk = div_up(n, PO_TILE);
+    void *d_local, *d_tot, *d_pre, *d_first, *d_zptr;
+    ZK_TRY(ctx->get_scratch("po_local", (size_t)nseg * n * 32, &d_local));
+    ZK_TRY(ctx->get_scratch("po_tot", (size_t)nseg * nblk * 32, &d_tot));
+    ZK_TRY(ctx->get_scratch("po_pre", (size_t)nseg * nblk * 32, &d_pre));
+    ZK_TRY(ctx->get_scratch("po_first", (size_t)nseg * 32, &d_first));
+    ZK_TRY(ctx->get_scratch("po_zptr", (size_t)nseg * sizeof(void*), &d_zptr));
+    ZK_HIP(hipMemcpyAsync(d_zptr, z_out_host, nseg * sizeof(void*), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_rp_local, dim3(nblk, nseg), dim3(PO_BLOCK), 0, st, (const uint32_t*)d_terms, n, (uint32_t*)d_local, (uint32_t*)d_tot, nblk);
+    hipLaunchKernelGGL(k_rp_blocks, dim3(nseg), dim3(1024), 0, st, (const uint32_t*)d_tot, (uint32_t*)d_pre, nblk);
+    if (chain) hipLaunchKernelGGL(k_rp_chain, dim3(1), dim3(64), 0, st, (const uint32_t*)d_local, (const uint32_t*)d_pre, n, nblk, nseg, nchain,
+                                  chain_row, (uint32_t*)d_first);
+    hipLaunchKernelGGL(k_rp_apply, dim3(div_up(n, PO_BLOCK), nseg), dim3(PO_BLOCK), 0, st, (const uint32_t*)d_local, (const uint32_t*)d_pre,
+                       chain ? (const uint32_t*)d_first : (const uint32_t*)nullptr, n, nblk, (uint32_t* const*)d_zptr, n_keep,
+                       (const uint32_t*)d_blinding);
+    ZK_LAUNCH_CHECK();
+    return ZKHIP_OK;
+}
+
+extern "C" {
+
+int zkhip_batch_invert_device(zkhip_ctx* ctx, void* d_a, size_t n) {
+    if (!ctx || !d_a) { set_error("zkhip_batch_invert_device: null argument"); return ZKHIP_EINVAL; }
+    if (n == 0) return ZKHIP_OK;
+    ProfScope ps(ctx, "batch_invert");
+    hipLaunchKernelGGL(k_batch_invert<1>, dim3(div_up(n, PO_TILE)), dim3(PO_BLOCK), 0, ctx->stream, (uint32_t*)d_a, n);
+    ZK_LAUNCH_CHECK();
+    return ZKHIP_OK;
+}
+
+// xs_host: npolys ABI points (one per polynomial)
+static int eval_at(zkhip_ctx* ctx, const void* const* d_polys, size_t npolys, size_t n, const uint64_t* xs_host, void* d_out) {
+    if (npolys == 0) return ZKHIP_OK;
+    if (n == 0) { ZK_HIP(hipMemsetAsync(d_out, 0, npolys * 32, ctx->stream)); return ZKHIP_OK; }
+    uint32_t nblk = div_up(n, PO_TILE);
+    void *d_ptrs, *d_part, *d_xs;
+    ZK_TRY(ctx->get_scratch("po_eval_ptrs", npolys * sizeof(void*), &d_ptrs));
+    ZK_TRY(ctx->get_scratch("po_eval_part", npolys * (size_t)nblk * 32, &d_part));
+    ZK_TRY(ctx->get_scratch("po_eval_xs", npolys * 32, &d_xs));
+    std::vector<fe32> xs(npolys);
+    for (size_t j = 0; j < npolys; ++j) xs[j] = abi_to_raw(xs_host + 4 * j);
+    ZK_HIP(hipMemcpyAsync(d_ptrs, d_polys, npolys * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(hipMemcpyAsync(d_xs, xs.data(), npolys * 32, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));   // xs is a host temporary
+    ProfScope ps(ctx, "eval_polynomial");
+    hipLaunchKernelGGL(k_eval_tiles, dim3(nblk, (unsigned)npolys), dim3(PO_BLOCK), 0, ctx->stream, (const uint32_t* const*)d_ptrs, n,
+                       (const uint32_t*)d_xs, (uint32_t*)d_part, nblk);
+    hipLaunchKernelGGL(k_eval_final, dim3((unsigned)npolys), dim3(PO_BLOCK), 0, ctx->stream, (const uint32_t*)d_part, nblk, (const uint32_t*)d_xs,
+                       (uint32_t*)d_out);
+    ZK_LAUNCH_CHECK();
+    return ZKHIP_OK;
+}
+int zkhip_eval_polynomial_device(zkhip_ctx* ctx, const void* const* d_polys, size_t npolys, size_t n, const uint64_t x[4], void* d_out) {
+    if (!ctx || !d_polys || !x || !d_out) { set_error("zkhip_eval_polynomial_device: null argument"); return ZKHIP_EINVAL; }
+    std::vector<uint64_t> xs(4 * (npolys ? npolys : 1));
+    for (size_t j = 0; j < npolys; ++j) memcpy(&xs[4 * j], x, 32);
+    return eval_at(ctx, d_polys, npolys, n, xs.data(), d_out);
+}
+int zkhip_eval_polynomials_at_device(zkhip_ctx* ctx, const void* const* d_polys, size_t npolys, size_t n, const uint64_t* xs, void* d_out) {
+    if (!ctx || !d_polys || !xs || !d_out) { set_error("zkhip_eval_polynomials_at_device: null argument"); return ZKHIP_EINVAL; }
+    return eval_at(ctx, d_polys, npolys, n, xs, d_out);
+}
+
+int zkhip_permutation_products_device(zkhip_ctx* ctx, uint32_t k, const void* const* d_values, const void* const* d_sigmas, size_t ncols,
+                                      uint32_t chunk_len, const uint64_t beta[4], const uint64_t gamma[4], uint32_t blinding_factors,
+                                      const void* d_blinding, void* const* d_z) {
+    if (!ctx || !d_values || !d_sigmas || !beta || !gamma || !d_z || (blinding_factors && !d_blinding)) { set_error("zkhip_permutation_products_device: null argument"); return ZKHIP_EINVAL; }
+    if (ncols == 0) return ZKHIP_OK;
+    if (chunk_len == 0 || k == 0 || k > 26) { set_error("zkhip_permutation_products_device: bad chunk_len / k"); return ZKHIP_EINVAL; }
+    size_t n = (size_t)1 << k;
+    if (blinding_factors + 1 >= n) { set_error("zkhip_permutation_products_device: too many blinding factors"); return ZKHIP_EINVAL; }
+    uint32_t nsets = (uint32_t)((ncols + chunk_len - 1) / chunk_len);
+    hipStream_t st = ctx->stream;
+    // omega_k and its split power tables
+    el2<Fr> w = from_canonical_words<Fr>(FR_ROOT_OF_UNITY);
+    for (uint32_t i = k; i < FR_S; ++i) w = sqr(w);
+    uint64_t w_abi[4];
+    mem_store(w_abi, to_abi(w));
+    const zkhip_ctx::Twiddle* tw;
+    ZK_TRY(ctx->get_twiddles(w_abi, k, &tw));
+    // per-column constants delta^j * beta (raw R' form)
+    el2<Fr> b = from_abi<Fr>(mem_load(beta)), delta = from_canonical_words<Fr>(FR_DELTA), dj = one<Fr>();
+    std::vector<fe32> dbeta(ncols);
+    for (size_t j = 0; j < ncols; ++j) { dbeta[j] = fe_pack(fe_canonical<Fr>((dj * b).v)); dj = dj * delta; }
+    void *d_ptrs, *d_dbeta, *d_terms;
+    ZK_TRY(ctx->get_scratch("po_perm_ptrs", 2 * ncols * sizeof(void*), &d_ptrs));
+    ZK_TRY(ctx->get_scratch("po_perm_dbeta", ncols * 32, &d_dbeta));
+    ZK_TRY(ctx->get_scratch("po_terms", (size_t)nsets * n * 32, &d_terms));
+    std::vector<const void*> ptrs(2 * ncols);
+    for (size_t j = 0; j < ncols; ++j) { ptrs[j] = d_values[j]; ptrs[ncols + j] = d_sigmas[j]; }
+    ZK_HIP(hipMemcpyAsync(d_ptrs, ptrs.data(), 2 * ncols * sizeof(void*), hipMemcpyHostToDevice, st));
+    ZK_HIP(hipMemcpyAsync(d_dbeta, dbeta.data(), ncols * 32, hipMemcpyHostToDevice, st));
+    ZK_HIP(hipStreamSynchronize(st));   // host temporaries
+    PermParams P;
+    P.values = (const uint32_t* const*)d_ptrs;
+    P.sigmas = (const uint32_t* const*)((const void**)d_ptrs + ncols);
+    P.ncols = (uint32_t)ncols; P.chunk_len = chunk_len;
+    P.beta = abi_to_fe(beta); P.gamma = abi_to_fe(gamma);
+    P.dbeta = (const uint32_t*)d_dbeta;
+    P.w_lo = (const uint32_t*)tw->d_lo; P.w_hi = (const uint32_t*)tw->d_hi; P.w_h = tw->h;
+    ProfScope ps(ctx, "grand_product");
+    dim3 grid(div_up(n, 256), nsets);
+    hipLaunchKernelGGL(k_perm_terms<1>, grid, dim3(256), 0, st, P, n, (uint32_t*)d_terms);
+    hipLaunchKernelGGL(k_batch_invert<0>, dim3(div_up((size_t)nsets * n, PO_TILE)), dim3(PO_BLOCK), 0, st, (uint32_t*)d_terms, (size_t)nsets * n);
+    hipLaunchKernelGGL(k_perm_terms<0>, grid, dim3(256), 0, st, P, n, (uint32_t*)d_terms);
+    return running_products(ctx, d_terms, nsets, n, n - blinding_factors, nsets, n - blinding_factors - 1, d_blinding, d_z);
+}
+
+int zkhip_lookup_product_device(zkhip_ctx* ctx, uint32_t k, const void* d_compressed_input, const void* d_compressed_table,
+                                const void* d_permuted_input, const void* d_permuted_table, const uint64_t beta[4], const uint64_t gamma[4],
+                                uint32_t blinding_factors, const void* d_blinding, void* d_z) {
+    if (!ctx || !d_compressed_input || !d_compressed_table || !d_permuted_input || !d_permuted_table || !beta || !gamma || !d_z ||
+        (blinding_factors && !d_blinding)) { set_error("zkhip_lookup_product_device: null argument"); return ZKHIP_EINVAL; }
+    if (k == 0 || k > 26) { set_error("zkhip_lookup_product_device: bad k"); return ZKHIP_EINVAL; }
+    size_t n = (size_t)1 << k;
+    if (blinding_factors + 1 >= n) { set_error("zkhip_lookup_product_device: too many blinding factors"); return ZKHIP_EINVAL; }
+    hipStream_t st = ctx->stream;
+    void* d_terms;
+    ZK_TRY(ctx->get_scratch("po_terms", n * 32, &d_terms));
+    fe bv = abi_to_fe(beta), gv = abi_to_fe(gamma);
+    ProfScope ps(ctx, "grand_product");
+    hipLaunchKernelGGL(k_lookup_terms<1>, dim3(div_up(n, 256)), dim3(256), 0, st, (const uint32_t*)d_permuted_input, (const uint32_t*)d_permuted_table,
+                       bv, gv, n, (uint32_t*)d_terms);
+    hipLaunchKernelGGL(k_batch_invert<0>, dim3(div_up(n, PO_TILE)), dim3(PO_BLOCK), 0, st, (uint32_t*)d_terms, n);
+    hipLaunchKernelGGL(k_lookup_terms<0>, dim3(div_up(n, 256)), dim3(256), 0, st, (const uint32_t*)d_compressed_input,
+                       (const uint32_t*)d_compressed_table, bv, gv, n, (uint32_t*)d_terms);
+    void* zs[1] = {d_z};
+    return running_products(ctx, d_terms, 1, n, n - blinding_factors, 0, 0, d_blinding, zs);
+}
+
+// permutation::commit and every lookup's commit_product behind ONE batch inversion (each inversion pass has a
+// ~0.3 ms latency floor: 380 dependent products on one wave).  Segments: the permutation sets, then the lookups.
+int zkhip_grand_products_device(zkhip_ctx* ctx, uint32_t k, const uint64_t beta[4], const uint64_t gamma[4], uint32_t blinding_factors,
+                                const void* const* d_values, const void* const* d_sigmas, size_t ncols, uint32_t chunk_len,
+                                const void* d_perm_blinding, void* const* d_perm_z,
+                                size_t n_lookups, const void* const* d_compressed_input, const void* const* d_compressed_table,
+                                const void* const* d_permuted_input, const void* const* d_permuted_table, const void* d_lookup_blinding,
+                                void* const* d_lookup_z) {
+    if (!ctx || !beta || !gamma) { set_error("zkhip_grand_products_device: null argument"); return ZKHIP_EINVAL; }
+    if (ncols && (!d_values || !d_sigmas || !d_perm_z || chunk_len == 0)) { set_error("zkhip_grand_products_device: bad permutation arguments"); return ZKHIP_EINVAL; }
+    if (n_lookups && (!d_compressed_input || !d_compressed_table || !d_permuted_input || !d_permuted_table || !d_lookup_z)) { set_error("zkhip_grand_products_device: bad lookup arguments"); return ZKHIP_EINVAL; }
+    if (k == 0 || k > 26) { set_error("zkhip_grand_products_device: bad k"); return ZKHIP_EINVAL; }
+    size_t n = (size_t)1 << k;
+    const uint32_t bf = blinding_factors;
+    if (bf + 1 >= n) { set_error("zkhip_grand_products_device: too many blinding factors"); return ZKHIP_EINVAL; }
+    uint32_t nsets = ncols ? (uint32_t)((ncols + chunk_len - 1) / chunk_len) : 0;
+    uint32_t nseg = nsets + (uint32_t)n_lookups;
+    if (nseg == 0) return ZKHIP_OK;
+    if (bf && ((nsets && !d_perm_blinding) || (n_lookups && !d_lookup_blinding))) { set_error("zkhip_grand_products_device: blinding rows missing"); return ZKHIP_EINVAL; }
+    hipStream_t st = ctx->stream;
+    void *d_terms, *d_blind;
+    ZK_TRY(ctx->get_scratch("po_terms", (size_t)nseg * n * 32, &d_terms));
+    ZK_TRY(ctx->get_scratch("po_blind", (size_t)nseg * (bf ? bf : 1) * 32, &d_blind));
+    if (bf && nsets) ZK_HIP(hipMemcpyAsync(d_blind, d_perm_blinding, (size_t)nsets * bf * 32, hipMemcpyDeviceToDevice, st));
+    if (bf && n_lookups) ZK_HIP(hipMemcpyAsync((char*)d_blind + (size_t)nsets * bf * 32, d_lookup_blinding, n_lookups * bf * 32, hipMemcpyDeviceToDevice, st));
+    fe bv = abi_to_fe(beta), gv = abi_to_fe(gamma);
+    PermParams P;
+    memset(&P, 0, sizeof P);
+    ProfScope ps(ctx, "grand_product");
+    if (nsets) {
+        el2<Fr> w = from_canonical_words<Fr>(FR_ROOT_OF_UNITY);
+        for (uint32_t i = k; i < FR_S; ++i) w = sqr(w);
+        uint64_t w_abi[4];
+        mem_store(w_abi, to_abi(w));
+        const zkhip_ctx::Twiddle* tw;
+        ZK_TRY(ctx->get_twiddles(w_abi, k, &tw));
+        el2<Fr> b = from_abi<Fr>(mem_load(beta)), delta = from_canonical_words<Fr>(FR_DELTA), dj = one<Fr>();
+        std::vector<fe32> dbeta(ncols);
+        for (size_t j = 0; j < ncols; ++j) { dbeta[j] = fe_pack(fe_canonical<Fr>((dj * b).v)); dj = dj * delta; }
+        void *d_ptrs, *d_dbeta;
+        ZK_TRY(ctx->get_scratch("po_perm_ptrs", 2 * ncols * sizeof(void*), &d_ptrs));
+        ZK_TRY(ctx->get_scratch("po_perm_dbeta", ncols * 32, &d_dbeta));
+        std::vector<const void*> ptrs(2 * ncols);
+        for (size_t j = 0; j < ncols; ++j) { ptrs[j] = d_values[j]; ptrs[ncols + j] = d_sigmas[j]; }
+        ZK_HIP(hipMemcpyAsync(d_ptrs, ptrs.data(), 2 * ncols * sizeof(void*), hipMemcpyHostToDevice, st));
+        ZK_HIP(hipMemcpyAsync(d_dbeta, dbeta.data(), ncols * 32, hipMemcpyHostToDevice, st));
+        ZK_HIP(hipStreamSynchronize(st));   // host temporaries
+        P.values = (const uint32_t* const*)d_ptrs;
+        P.sigmas = (const uint32_t* const*)((const void**)d_ptrs + ncols);
+        P.ncols = (uint32_t)ncols; P.chunk_len = chunk_len;
+        P.beta = bv; P.gamma = gv;
+        P.dbeta = (const uint32_t*)d_dbeta;
+        P.w_lo = (const uint32_t*)tw->d_lo; P.w_hi = (const uint32_t*)tw->d_hi; P.w_h = tw->h;
+        hipLaunchKernelGGL(k_perm_terms<1>, dim3(div_up(n, 256), nsets), dim3(256), 0, st, P, n, (uint32_t*)d_terms);
+    }
+    for (size_t l = 0; l < n_lookups; ++l)
+        hipLaunchKernelGGL(k_lookup_terms<1>, dim3(div_up(n, 256)), dim3(256), 0, st, (const uint32_t*)d_permuted_input[l],
+                           (const uint32_t*)d_permuted_table[l], bv, gv, n, (uint32_t*)d_terms + ((size_t)nsets + l) * n * 8);
+    hipLaunchKernelGGL(k_batch_invert<0>, dim3(div_up((size_t)nseg * n, PO_TILE)), dim3(PO_BLOCK), 0, st, (uint32_t*)d_terms, (size_t)nseg * n);
+    if (nsets) hipLaunchKernelGGL(k_perm_terms<0>, dim3(div_up(n, 256), nsets), dim3(256), 0, st, P, n, (uint32_t*)d_terms);
+    for (size_t l = 0; l < n_lookups; ++l)
+        hipLaunchKernelGGL(k_lookup_terms<0>, dim3(div_up(n, 256)), dim3(256), 0, st, (const uint32_t*)d_compressed_input[l],
+                           (const uint32_t*)d_compressed_table[l], bv, gv, n, (uint32_t*)d_terms + ((size_t)nsets + l) * n * 8);
+    std::vector<void*> zs(nseg);
+    for (uint32_t i = 0; i < nsets; ++i) zs[i] = d_perm_z[i];
+    for (size_t l = 0; l < n_lookups; ++l) zs[nsets + l] = d_lookup_z[l];
+    return running_products(ctx, d_terms, nseg, n, n - bf, nsets, n - bf - 1, d_blind, zs.data());
+}
+
+}  // extern "C"

@@ -58,6 +58,8 @@ SYMBOLS = [
     "zkhip_coeff_to_extended_device", "zkhip_extended_to_coeff_device", "zkhip_divide_by_vanishing_device",
     "zkhip_lagrange_to_coeff", "zkhip_coeff_to_extended", "zkhip_extended_to_coeff",
     "zkhip_evaluate_h_device", "zkhip_synth_fill_device",
+    "zkhip_batch_invert_device", "zkhip_eval_polynomial_device", "zkhip_eval_polynomials_at_device", "zkhip_permutation_products_device",
+    "zkhip_lookup_product_device", "zkhip_grand_products_device",
 ]
 
 
@@ -170,6 +172,66 @@ class Context:
     def fft_batch_device(self, polys, omega, log_n):
         ptrs = (C.c_void_p * len(polys))(*[p.data_ptr() for p in polys])
         _check(lib().zkhip_fft_batch_device(self.h, ptrs, C.c_size_t(len(polys)), _p(_u64(omega)), C.c_uint32(log_n)))
+
+
+def batch_invert_device(ctx, col):
+    """ff::BatchInvert on a device column, in place."""
+    _check(lib().zkhip_batch_invert_device(ctx.h, C.c_void_p(col.data_ptr()), C.c_size_t(col.shape[0])))
+
+
+def eval_polynomials_device(ctx, polys, x):
+    """arithmetic::eval_polynomial for a batch of device polynomials of equal length -> (npolys, 4) device tensor."""
+    out = ctx.empty(len(polys))
+    if polys:
+        _check(lib().zkhip_eval_polynomial_device(ctx.h, _ptr_array(polys), C.c_size_t(len(polys)), C.c_size_t(polys[0].shape[0]),
+                                                  _p(_u64(x)), C.c_void_p(out.data_ptr())))
+    return out
+
+
+def eval_polynomials_at_device(ctx, polys, xs):
+    """one point per polynomial: xs is an (npolys, 4) host array"""
+    out = ctx.empty(len(polys))
+    if polys:
+        xs = _u64(xs).reshape(len(polys), 4)
+        _check(lib().zkhip_eval_polynomials_at_device(ctx.h, _ptr_array(polys), C.c_size_t(len(polys)), C.c_size_t(polys[0].shape[0]), _p(xs),
+                                                      C.c_void_p(out.data_ptr())))
+    return out
+
+
+def grand_products_device(ctx, k, beta, gamma, blinding_factors, values, sigmas, chunk_len, perm_blinding, lookups, lookup_blinding):
+    """permutation::commit + every lookup's commit_product behind one batch inversion.
+    lookups: list of (compressed_input, compressed_table, permuted_input, permuted_table).  -> (perm z list, lookup z list)"""
+    nsets = -(-len(values) // chunk_len) if values else 0
+    pz = [ctx.empty(1 << k) for _ in range(nsets)]
+    lz = [ctx.empty(1 << k) for _ in lookups]
+    none = C.c_void_p(0)
+    cols = list(zip(*lookups)) if lookups else [[], [], [], []]
+    _check(lib().zkhip_grand_products_device(
+        ctx.h, C.c_uint32(k), _p(_u64(beta)), _p(_u64(gamma)), C.c_uint32(blinding_factors),
+        _ptr_array(values), _ptr_array(sigmas), C.c_size_t(len(values)), C.c_uint32(max(1, chunk_len)),
+        C.c_void_p(perm_blinding.data_ptr()) if nsets else none, _ptr_array(pz),
+        C.c_size_t(len(lookups)), _ptr_array(list(cols[0])), _ptr_array(list(cols[1])), _ptr_array(list(cols[2])), _ptr_array(list(cols[3])),
+        C.c_void_p(lookup_blinding.data_ptr()) if lookups else none, _ptr_array(lz)))
+    return pz, lz
+
+
+def permutation_products_device(ctx, k, values, sigmas, chunk_len, beta, gamma, blinding_factors, blinding):
+    """permutation::prover::commit: list of z columns (Lagrange form).  blinding: (nsets * bf, 4) device tensor."""
+    nsets = -(-len(values) // chunk_len)
+    zs = [ctx.empty(1 << k) for _ in range(nsets)]
+    if values:
+        _check(lib().zkhip_permutation_products_device(ctx.h, C.c_uint32(k), _ptr_array(values), _ptr_array(sigmas), C.c_size_t(len(values)),
+                                                       C.c_uint32(chunk_len), _p(_u64(beta)), _p(_u64(gamma)), C.c_uint32(blinding_factors),
+                                                       C.c_void_p(blinding.data_ptr()), _ptr_array(zs)))
+    return zs
+
+
+def lookup_product_device(ctx, k, cin, ctab, pin, ptab, beta, gamma, blinding_factors, blinding):
+    z = ctx.empty(1 << k)
+    _check(lib().zkhip_lookup_product_device(ctx.h, C.c_uint32(k), C.c_void_p(cin.data_ptr()), C.c_void_p(ctab.data_ptr()),
+                                             C.c_void_p(pin.data_ptr()), C.c_void_p(ptab.data_ptr()), _p(_u64(beta)), _p(_u64(gamma)),
+                                             C.c_uint32(blinding_factors), C.c_void_p(blinding.data_ptr()), C.c_void_p(z.data_ptr())))
+    return z
 
 
 def _ptr_array(tensors):

@@ -12,11 +12,14 @@ from gen_snark_shplonk at /root/reference/src/helpers.rs:233,299 and src/bin/cli
     q MSM_n over g                                                  -> transcript -> x
   6 SHPLONK: 2 MSM_n
 
-What is NOT here ("next" rows): witness synthesis, the lookup permute (sort), the
-grand-product scans, the evaluations at x, SHPLONK's polynomial construction and the real
-Poseidon/Keccak transcript.  Their outputs are replaced by synthetic columns of the right shape and
-the transcript by BLAKE2b over the same commitment bytes, so every Fiat-Shamir host round trip of the
-real prover is still on the critical path.
+Also computed for real: the theta-compression of the lookup expressions, the permutation and
+lookup grand products (batch inversion + running product; the blinding rows are seeded stand-ins for the rng),
+and the evaluations of every queried polynomial at x * omega^rotation.
+
+What is NOT here ("next" rows): witness synthesis, the lookup permute (sort), SHPLONK's
+polynomial construction and the real Poseidon/Keccak transcript.  Their outputs are replaced by synthetic
+columns of the right shape and the transcript by BLAKE2b over the same commitment / evaluation bytes, so
+every Fiat-Shamir host round trip of the real prover is still on the critical path.
 
 The schedule is written against a small backend interface so the same code drives the HIP library
 (GpuBackend, here) and, in tests/ and bench.py's cpu_baseline leg only, the CPU oracle.
@@ -97,6 +100,29 @@ class CircuitShape:
     @classmethod
     def small(cls, k=8):
         return cls(f"small_k{k}", k, 2, 1, 1, 4, 6, 0x5EED00 + k)
+
+    def queries(self):
+        """Distinct (kind, column, rotation) queries of the gates and lookups (what create_proof evaluates at x)."""
+        seen, out = set(), []
+
+        def walk(e):
+            if e[0] in ("advice", "fixed", "instance"):
+                if e not in seen:
+                    seen.add(e)
+                    out.append(e)
+            else:
+                for c in e[1:]:
+                    if isinstance(c, tuple):
+                        walk(c)
+
+        for g in self.gates:
+            walk(g)
+        for ins, tabs in self.lookups:
+            for e in ins + tabs:
+                walk(e)
+        for t, i in self.perm_columns:
+            walk((t, i, 0))
+        return out
 
     def counts(self, dom_extended_k):
         L, Zp, A, I = len(self.lookups), self.n_perm_sets, self.n_advice, self.n_instance
@@ -199,6 +225,43 @@ class GpuBackend:
     def to_host(self, col):
         return self.ctx.to_host(col)
 
+    def compress(self, graph, fixed_l, advice_l, instance_l, theta, k):
+        """lookup::prover::compress_expressions: the graph (Horner in theta over the expressions) evaluated on the
+        Lagrange domain itself — the sweep interpreter with rotation scale 1 (k = extended_k)."""
+        zero = np.zeros(4, dtype=np.uint64)
+        kw = dict(k=k, extended_k=k, cs_degree=3, blinding_factors=0, extended_omega=zero, g_coset=zero, delta=zero, beta=zero,
+                  gamma=zero, theta=self.fr(theta), y=zero, fixed=fixed_l, advice=advice_l, instance=instance_l, challenges=[],
+                  l0=None, l_last=None, l_active=None, gates_graph=graph, perm_columns=[], sigma=[], perm_z=[], lookup_graphs=[],
+                  lookup_z=[], lookup_a=[], lookup_s=[], to_mont=self.fr_many)
+        pack = self.ffi.EvalhPack()
+        pack.build(**kw)
+        return self.ffi.evaluate_h(self.ctx, pack, 1 << k)
+
+    def permutation_products(self, k, values, sigmas, chunk_len, beta, gamma, bf, blinding):
+        return self.ffi.permutation_products_device(self.ctx, k, values, sigmas, chunk_len, self.fr(beta), self.fr(gamma), bf, blinding)
+
+    def lookup_product(self, k, cin, ctab, pin, ptab, beta, gamma, bf, blinding):
+        return self.ffi.lookup_product_device(self.ctx, k, cin, ctab, pin, ptab, self.fr(beta), self.fr(gamma), bf, blinding)
+
+    def eval_polys_at(self, polys, xs):
+        """-> host (npolys, 4) ABI values polys[j](xs[j]); one launch pair and one transfer for the whole query set"""
+        return self.ctx.to_host(self.ffi.eval_polynomials_at_device(self.ctx, polys, self.fr_many(xs)))
+
+    def grand_products(self, k, beta, gamma, bf, values, sigmas, chunk_len, perm_blinding, lookups, lookup_blinding):
+        return self.ffi.grand_products_device(self.ctx, k, self.fr(beta), self.fr(gamma), bf, values, sigmas, chunk_len, perm_blinding,
+                                              lookups, lookup_blinding)
+
+    def to_host_many(self, tensors):
+        """one device->host transfer for a list of small results"""
+        if not tensors:
+            return []
+        flat = self.ctx.to_host(self.torch.cat(tensors, dim=0))
+        out, o = [], 0
+        for t in tensors:
+            out.append(flat[o:o + t.shape[0]])
+            o += t.shape[0]
+        return out
+
     def l_cosets(self, blinding_factors):
         """l_0, l_last, l_active_row cosets (keygen-time, plonk/keygen.rs) computed with the library's own NTTs."""
         n, dom = self.domain.n, self.domain
@@ -270,6 +333,7 @@ def fr_from_int_host(x):
     return np.array([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
 
 
+ROOT_OF_UNITY = 0x03DDB9F5166D18B798865EA93DD31F743215CF6DD39329C8D34F1ED960C37C9C   # order 2^28 (SURVEY.md §8 constants)
 ZETA = 0xB3C4D79D41A917585BFC41088D8DAAA78B17EA66B99C90DD
 DELTA = 0x09226B6E22C6F0CA64EC26AAD4C86E715B5F898E5E963F25870E56BBE533E9A2
 
@@ -283,15 +347,28 @@ class Prover:
         self.n = 1 << shape.k
         sh, b, n = shape, backend, self.n
         seed = sh.seed * 1000
-        # pk: fixed columns (Lagrange -> coeff -> extended cosets), sigma polys, l cosets
-        fixed = [b.synth(n, seed + 100 + i) for i in range(sh.n_fixed)]
-        b.lagrange_to_coeff(fixed)
-        self.fixed_cosets = b.coeff_to_extended(fixed)
-        sigma = [b.synth(n, seed + 200 + i) for i in range(len(sh.perm_columns))]
-        self.sigma_cosets = b.coeff_to_extended(sigma)
+        # pk: fixed columns and sigma polynomials in Lagrange form, coefficient form and as extended cosets; l cosets
+        self.fixed_lagrange = [b.synth(n, seed + 100 + i) for i in range(sh.n_fixed)]
+        self.fixed_coeff = b.clone(self.fixed_lagrange)
+        b.lagrange_to_coeff(self.fixed_coeff)
+        self.fixed_cosets = b.coeff_to_extended(self.fixed_coeff)
+        self.sigma_lagrange = [b.synth(n, seed + 200 + i) for i in range(len(sh.perm_columns))]
+        self.sigma_coeff = b.clone(self.sigma_lagrange)
+        b.lagrange_to_coeff(self.sigma_coeff)
+        self.sigma_cosets = b.coeff_to_extended(self.sigma_coeff)
         self.l0, self.l_last, self.l_active = b.l_cosets(sh.blinding_factors)
         self.gates_graph = ev.build_custom_gates(sh.gates)
         self.lookup_graphs = [ev.build_lookup(i, t) for i, t in sh.lookups]
+        self.compress_graphs = []
+        for inputs, tables in sh.lookups:
+            pair = []
+            for exprs in (inputs, tables):
+                g = ev.GraphEvaluator()
+                parts = [g.add_expression(x) for x in exprs]
+                g.add_calculation(ev.OP_HORNER, [(ev.VS_CONSTANT, 0, 0), (ev.VS_THETA, 0, 0)] + parts)
+                pair.append(g)
+            self.compress_graphs.append(pair)
+        self.omega = pow(ROOT_OF_UNITY, 1 << (28 - sh.k), R)
 
     def witness(self, proof_seed):
         """Synthetic advice / instance tables in Lagrange form, resident on the device (untimed)."""
@@ -327,17 +404,25 @@ class Prover:
         c1 = b.commit(advice + rand_poly, lagrange=[True] * len(advice) + [False])
         t1 = absorb("advice", c1[:len(advice)])
         theta = challenge("theta", t1)
-        # 2. lookup permuted input / table (synthetic stand-ins for the sorted columns), coefficient form
-        perm_in = [b.synth(n, base + 300 + i) for i in range(L)]
-        perm_tab = [b.synth(n, base + 320 + i) for i in range(L)]
+        # 2. lookups: theta-compress the input / table expressions (real), permuted input / table (synthetic stand-ins
+        #    for the sorted columns); commit the permuted pair in coefficient form
+        compressed = [(b.compress(gi, self.fixed_lagrange, wit["advice"], wit["instance"], theta, sh.k),
+                       b.compress(gt, self.fixed_lagrange, wit["advice"], wit["instance"], theta, sh.k)) for gi, gt in self.compress_graphs]
+        perm_in_l = [b.synth(n, base + 300 + i) for i in range(L)]
+        perm_tab_l = [b.synth(n, base + 320 + i) for i in range(L)]
+        perm_in, perm_tab = b.clone(perm_in_l), b.clone(perm_tab_l)
         b.lagrange_to_coeff(perm_in + perm_tab)
         with b.overlap():
             ext_perm = b.coeff_to_extended(perm_in + perm_tab)
         t2 = absorb("lookup_permuted", b.commit(perm_in + perm_tab, lagrange=False)) if L else []
         beta, gamma = challenge("beta", t1 + t2), challenge("gamma", t1 + t2)
-        # 3. grand products (synthetic stand-ins), coefficient form
-        perm_z = [b.synth(n, base + 340 + i) for i in range(Zp)]
-        look_z = [b.synth(n, base + 360 + i) for i in range(L)]
+        # 3. grand products: permutation (chunks of degree-2 columns) and one per lookup; blinding rows are seeded stand-ins
+        bf = sh.blinding_factors
+        cols = {"advice": wit["advice"], "fixed": self.fixed_lagrange, "instance": wit["instance"]}
+        perm_values = [cols[t][i] for t, i in sh.perm_columns]
+        perm_z, look_z = b.grand_products(sh.k, beta, gamma, bf, perm_values, self.sigma_lagrange, sh.degree - 2, b.synth(Zp * bf, base + 340),
+                                          [(compressed[i][0], compressed[i][1], perm_in_l[i], perm_tab_l[i]) for i in range(L)],
+                                          b.synth(max(1, L) * bf, base + 360))
         b.lagrange_to_coeff(perm_z + look_z)
         with b.overlap():
             ext_prod = b.coeff_to_extended(look_z + perm_z)
@@ -361,12 +446,41 @@ class Prover:
         pieces = b.split(h, n, dom.quotient_poly_degree)
         t5 = absorb("quotient", b.commit(pieces, lagrange=False))
         x = challenge("x", t1 + t2 + t3 + t4 + t5)
+        # 5b. evaluations at x * omega^rot of everything the verifier queries (create_proof's eval_polynomial calls)
+        queries = {}   # rotation -> list of coefficient-form polynomials
+        def q(poly, rot):
+            queries.setdefault(rot, []).append(poly)
+        for kind, col, rot in sh.queries():
+            if kind == "advice":
+                q(adv_coeff[col], rot)
+            elif kind == "fixed":
+                q(self.fixed_coeff[col], rot)
+        for p_ in self.sigma_coeff:
+            q(p_, 0)
+        last_rot = -(bf + 1)
+        for i, z in enumerate(perm_z):
+            q(z, 0); q(z, 1)
+            if i + 1 < len(perm_z):
+                q(z, last_rot)
+        for i in range(L):
+            q(look_z[i], 0); q(look_z[i], 1); q(perm_in[i], 0); q(perm_in[i], -1); q(perm_tab[i], 0)
+        q(rand_poly[0], 0)
+        rots = sorted(queries)
+        flat_polys = [p_ for rot in rots for p_ in queries[rot]]
+        flat_points = [x * pow(self.omega, rot % n, R) % R for rot in rots for _ in queries[rot]]
+        flat = b.eval_polys_at(flat_polys, flat_points)
+        evals, o = [], 0
+        for rot in rots:
+            evals.append((rot, flat[o:o + len(queries[rot])]))
+            o += len(queries[rot])
+        ev_bytes = [e.tobytes() for _, e in evals]
+        trace["evals"] = evals
         # 6. SHPLONK: two commitments to n-size polynomials (synthetic stand-ins for the quotient polys)
         w1 = [b.synth(n, base + 400)]
         t6 = absorb("shplonk_h1", b.commit(w1, lagrange=False))
         w2 = [b.synth(n, base + 401)]
         t7 = absorb("shplonk_h2", b.commit(w2, lagrange=False))
-        trace["challenges"] = dict(theta=theta, beta=beta, gamma=gamma, y=y, x=x)
+        trace["challenges"] = dict(theta=theta, beta=beta, gamma=gamma, y=y, x=x, v=challenge("v", t1 + t2 + t3 + t4 + t5 + ev_bytes))
         trace["h_pieces"] = pieces
         trace["n_commitments"] = len(trace["commitments"])
         assert len(t6 + t7) == 2

@@ -61,7 +61,7 @@ int  zkhip_timer_stop_ms(zkhip_ctx* ctx, float* ms);   /* synchronises */
 
 /* Per-kernel timing: while enabled, every launch of the named kernels is bracketed by HIP events on
  * the launch stream.  Names: "msm_digits", "msm_plan", "msm_accum_affine", "msm_accum_jac", "msm_tail",
- * "ntt_strided", "ntt_final", "sweep".  zkhip_profile_enable also clears the record. */
+ * "ntt_strided", "ntt_final", "sweep", "grand_product", "batch_invert", "eval_polynomial".  zkhip_profile_enable also clears the record. */
 int  zkhip_profile_enable(zkhip_ctx* ctx, int on);
 int  zkhip_profile_read(zkhip_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches);
 
@@ -179,6 +179,38 @@ typedef struct {
 
 /* d_out: extended_n x 4 u64 (device).  Asynchronous. */
 int  zkhip_evaluate_h_device(zkhip_ctx* ctx, const zk_evalh_args* args, void* d_out);
+
+/* ---- grand products and evaluations: the O(n) field work of create_proof between the commitments ----
+ * All columns are DEVICE arrays of n = 2^k ABI field elements; pointer lists are HOST arrays.  Asynchronous.
+ * ff::BatchInvert: a[i] <- 1 / a[i], zeros stay zero, in place. */
+int  zkhip_batch_invert_device(zkhip_ctx* ctx, void* d_a, size_t n);
+/* arithmetic::eval_polynomial for a batch: d_out[j] = polys[j](x), npolys x 4 u64 on the device. */
+int  zkhip_eval_polynomial_device(zkhip_ctx* ctx, const void* const* d_polys, size_t npolys, size_t n, const uint64_t x[4], void* d_out);
+/* The same with one point per polynomial (xs: npolys x 4 u64 on the HOST): every (polynomial, x * omega^rotation) query of
+ * create_proof in one pass. */
+int  zkhip_eval_polynomials_at_device(zkhip_ctx* ctx, const void* const* d_polys, size_t npolys, size_t n, const uint64_t* xs, void* d_out);
+/* plonk::permutation::prover::Argument::commit, up to the commitment: the grand-product polynomials z (Lagrange form), one
+ * per chunk of chunk_len = cs.degree() - 2 columns.  values[j] / sigmas[j]: the j-th permutation column and its sigma
+ * polynomial, both in Lagrange form.  The last blinding_factors rows of every z are copied from d_blinding
+ * ([set][blinding_factors] elements: upstream draws them from its rng). */
+int  zkhip_permutation_products_device(zkhip_ctx* ctx, uint32_t k, const void* const* d_values, const void* const* d_sigmas, size_t ncols,
+                                       uint32_t chunk_len, const uint64_t beta[4], const uint64_t gamma[4], uint32_t blinding_factors,
+                                       const void* d_blinding, void* const* d_z);
+/* plonk::lookup::prover::Permuted::commit_product: z of one lookup from the theta-compressed input / table columns and
+ * their permuted forms. */
+int  zkhip_lookup_product_device(zkhip_ctx* ctx, uint32_t k, const void* d_compressed_input, const void* d_compressed_table,
+                                 const void* d_permuted_input, const void* d_permuted_table, const uint64_t beta[4],
+                                 const uint64_t gamma[4], uint32_t blinding_factors, const void* d_blinding, void* d_z);
+
+/* Both of the above for a whole proof behind a single batch inversion (an inversion pass is latency-bound: 380 dependent
+ * products).  Either part may be empty (ncols = 0 / n_lookups = 0).  Lookup arrays are HOST arrays of device columns;
+ * d_lookup_blinding holds [lookup][blinding_factors] elements. */
+int  zkhip_grand_products_device(zkhip_ctx* ctx, uint32_t k, const uint64_t beta[4], const uint64_t gamma[4], uint32_t blinding_factors,
+                                 const void* const* d_values, const void* const* d_sigmas, size_t ncols, uint32_t chunk_len,
+                                 const void* d_perm_blinding, void* const* d_perm_z,
+                                 size_t n_lookups, const void* const* d_compressed_input, const void* const* d_compressed_table,
+                                 const void* const* d_permuted_input, const void* const* d_permuted_table, const void* d_lookup_blinding,
+                                 void* const* d_lookup_z);
 
 /* ---- synthetic tables (bench / tests): element i of a column = raw253(seed, i) taken as the
  * Montgomery limbs (oracle/pyref.py synth_raw253) ---- */

@@ -375,3 +375,40 @@ def evaluate_h_direct(dom, cs, cosets, ch):
             acc = (acc * y + t) % R
         out.append(acc)
     return out
+
+
+# ----------------------------------------------------------------------------- grand products (a8)
+def permutation_products(k, values, sigmas, chunk_len, beta, gamma, bf, blinding):
+    """z polynomials of the permutation argument, Lagrange form, straight from the definition:
+    z_s[0] = last z of the previous set (1 for the first); z_s[i+1] = z_s[i] * prod_j (v_j + delta^j w^i beta + gamma)
+    / (v_j + beta sigma_j + gamma); the last bf rows are the given blinding values."""
+    n = 1 << k
+    w = omega_for(k)
+    out = []
+    last = 1
+    j_global = 0
+    for s in range(0, len(values), chunk_len):
+        cols = list(range(s, min(s + chunk_len, len(values))))
+        z = [last]
+        for i in range(n - 1):
+            num = den = 1
+            for jj, c in enumerate(cols):
+                num = num * (values[c][i] + pow(DELTA, j_global + jj, R) * pow(w, i, R) * beta + gamma) % R
+                den = den * (values[c][i] + beta * sigmas[c][i] + gamma) % R
+            z.append(z[-1] * num * pow(den, -1, R) % R)
+        j_global += len(cols)
+        for t in range(bf):
+            z[n - bf + t] = blinding[len(out)][t]
+        last = z[n - bf - 1]
+        out.append(z)
+    return out
+
+
+def lookup_product(k, cin, ctab, pin, ptab, beta, gamma, bf, blinding):
+    n = 1 << k
+    z = [1]
+    for i in range(n - bf - 1):
+        num = (cin[i] + beta) * (ctab[i] + gamma) % R
+        den = (pin[i] + beta) * (ptab[i] + gamma) % R
+        z.append(z[-1] * num * pow(den, -1, R) % R)
+    return z + list(blinding)

@@ -767,6 +767,91 @@ int zko_evaluate_h(const zk_evalh_args* A, uint64_t* out_u, int threads) {
     return 0;
 }
 
+void zko_eval_polynomial(const uint64_t* coeffs, size_t n, const uint64_t x[4], uint64_t out[4]);
+/* ------------------------------------------------------------------ a8: grand products
+ * halo2_proofs src/plonk/permutation/prover.rs (Argument::commit), src/plonk/lookup/prover.rs (commit_product),
+ * ff::BatchInvert.  The random blinding rows are an input here (upstream draws them from its rng). */
+void zko_batch_invert(uint64_t* a_u, size_t n) {
+    fe* a = (fe*)a_u;
+    fe* pre = (fe*)malloc((n + 1) * sizeof(fe));
+    fe acc = FR.one;
+    for (size_t i = 0; i < n; ++i) {
+        pre[i] = acc;
+        if (!fe_is_zero(&a[i])) f_mul(&FR, &acc, &a[i], &acc);
+    }
+    fe inv; f_inv(&FR, &acc, &inv);
+    for (size_t i = n; i-- > 0;) {
+        if (fe_is_zero(&a[i])) continue;
+        fe t; f_mul(&FR, &inv, &pre[i], &t);
+        f_mul(&FR, &inv, &a[i], &inv);
+        a[i] = t;
+    }
+    free(pre);
+}
+void zko_permutation_products(uint32_t k, uint32_t n_cols, uint32_t chunk_len, const uint64_t* const* values, const uint64_t* const* sigmas,
+                              const uint64_t beta_u[4], const uint64_t gamma_u[4], uint32_t bf, const uint64_t* blinding_rand,
+                              uint64_t* const* z_out, int threads) {
+    (void)threads;
+    size_t n = (size_t)1 << k;
+    const fe* beta = FE(beta_u); const fe* gamma = FE(gamma_u);
+    fe omega; zko_fr_root_of_unity(k, omega.l);
+    fe delta; f_to_mont(&FR, &FR_DELTA_CANON, &delta);
+    fe deltaomega = FR.one, last_z = FR.one;
+    fe* mv = (fe*)malloc(n * sizeof(fe));
+    uint32_t nsets = (n_cols + chunk_len - 1) / chunk_len;
+    for (uint32_t s = 0; s < nsets; ++s) {
+        uint32_t c0 = s * chunk_len, c1 = c0 + chunk_len > n_cols ? n_cols : c0 + chunk_len;
+        for (size_t i = 0; i < n; ++i) mv[i] = FR.one;
+        for (uint32_t c = c0; c < c1; ++c)
+            for (size_t i = 0; i < n; ++i) {
+                fe t; f_mul(&FR, beta, FE(sigmas[c] + 4 * i), &t); f_add(&FR, &t, gamma, &t); f_add(&FR, &t, FE(values[c] + 4 * i), &t);
+                f_mul(&FR, &mv[i], &t, &mv[i]);
+            }
+        zko_batch_invert((uint64_t*)mv, n);
+        for (uint32_t c = c0; c < c1; ++c) {
+            fe dw = deltaomega;
+            for (size_t i = 0; i < n; ++i) {
+                fe t; f_mul(&FR, &dw, beta, &t); f_add(&FR, &t, gamma, &t); f_add(&FR, &t, FE(values[c] + 4 * i), &t);
+                f_mul(&FR, &mv[i], &t, &mv[i]);
+                f_mul(&FR, &dw, &omega, &dw);
+            }
+            f_mul(&FR, &deltaomega, &delta, &deltaomega);
+        }
+        fe* z = (fe*)z_out[s];
+        z[0] = last_z;
+        for (size_t row = 1; row < n; ++row) f_mul(&FR, &z[row - 1], &mv[row - 1], &z[row]);
+        for (uint32_t j = 0; j < bf; ++j) memcpy(&z[n - bf + j], blinding_rand + 4 * ((size_t)s * bf + j), 32);
+        last_z = z[n - (bf + 1)];
+    }
+    free(mv);
+}
+void zko_lookup_product(uint32_t k, const uint64_t* compressed_input, const uint64_t* compressed_table, const uint64_t* permuted_input,
+                        const uint64_t* permuted_table, const uint64_t beta_u[4], const uint64_t gamma_u[4], uint32_t bf,
+                        const uint64_t* blinding_rand, uint64_t* z_out) {
+    size_t n = (size_t)1 << k;
+    const fe* beta = FE(beta_u); const fe* gamma = FE(gamma_u);
+    fe* lp = (fe*)malloc(n * sizeof(fe));
+    for (size_t i = 0; i < n; ++i) {
+        fe a, b; f_add(&FR, beta, FE(permuted_input + 4 * i), &a); f_add(&FR, gamma, FE(permuted_table + 4 * i), &b);
+        f_mul(&FR, &a, &b, &lp[i]);
+    }
+    zko_batch_invert((uint64_t*)lp, n);
+    for (size_t i = 0; i < n; ++i) {
+        fe a, b; f_add(&FR, FE(compressed_input + 4 * i), beta, &a); f_add(&FR, FE(compressed_table + 4 * i), gamma, &b);
+        f_mul(&FR, &lp[i], &a, &lp[i]); f_mul(&FR, &lp[i], &b, &lp[i]);
+    }
+    fe* z = (fe*)z_out;
+    fe state = FR.one;
+    z[0] = FR.one;   /* once(ONE).chain(lookup_product).scan(ONE, *=): first output is ONE * ONE */
+    for (size_t i = 1; i < n - bf; ++i) { f_mul(&FR, &state, &lp[i - 1], &state); z[i] = state; }
+    for (uint32_t j = 0; j < bf; ++j) memcpy(&z[n - bf + j], blinding_rand + 4 * j, 32);
+    free(lp);
+}
+/* eval_polynomial for a batch (halo2_proofs src/arithmetic.rs) */
+void zko_eval_polynomials(const uint64_t* const* polys, size_t npolys, size_t n, const uint64_t x[4], uint64_t* out) {
+    for (size_t j = 0; j < npolys; ++j) zko_eval_polynomial(polys[j], n, x, out + 4 * j);
+}
+
 /* ------------------------------------------------------------------ synthetic data */
 uint64_t zko_splitmix64(uint64_t x) {
     x += 0x9E3779B97F4A7C15ULL;

@@ -122,6 +122,18 @@ typedef struct {
 /* out: extended_n x 4.  Returns 0, or -1 on a malformed program. */
 int zko_evaluate_h(const zk_evalh_args* args, uint64_t* out, int threads);
 
+/* ---- a8 (next rows): grand products and evaluations ---- */
+void zko_batch_invert(uint64_t* a, size_t n);   /* zeros stay zero (ff::BatchInvert) */
+/* permutation::prover::commit: z polynomials (Lagrange form, blinding rows = blinding_rand[set][bf]) */
+void zko_permutation_products(uint32_t k, uint32_t n_cols, uint32_t chunk_len, const uint64_t* const* values,
+                              const uint64_t* const* sigmas, const uint64_t beta[4], const uint64_t gamma[4], uint32_t blinding_factors,
+                              const uint64_t* blinding_rand, uint64_t* const* z_out, int threads);
+/* lookup::prover::commit_product */
+void zko_lookup_product(uint32_t k, const uint64_t* compressed_input, const uint64_t* compressed_table, const uint64_t* permuted_input,
+                        const uint64_t* permuted_table, const uint64_t beta[4], const uint64_t gamma[4], uint32_t blinding_factors,
+                        const uint64_t* blinding_rand, uint64_t* z_out);
+void zko_eval_polynomials(const uint64_t* const* polys, size_t npolys, size_t n, const uint64_t x[4], uint64_t* out);
+
 /* ---- synthetic data (repo-wide spec; also csrc/synth.hip) ---- */
 uint64_t zko_splitmix64(uint64_t x);
 void zko_synth_raw253(uint64_t seed, uint64_t idx, uint64_t out[4]);

@@ -211,6 +211,45 @@ def g1_to_bytes(aff):
     return bytes(o)
 
 
+def batch_invert(a):
+    a = u64(a).copy().reshape(-1, 4)
+    lib().zko_batch_invert(p(a), C.c_size_t(a.shape[0]))
+    return a
+
+
+def _ptrs(cols):
+    arr = (C.c_void_p * max(1, len(cols)))(*[c.ctypes.data for c in cols])
+    return arr
+
+
+def permutation_products(k, values, sigmas, chunk_len, beta, gamma, bf, blinding):
+    """values/sigmas: lists of (n,4) Lagrange columns; blinding: (nsets, bf, 4).  Returns the list of z columns."""
+    n = 1 << k
+    values = [u64(v).reshape(n, 4) for v in values]
+    sigmas = [u64(v).reshape(n, 4) for v in sigmas]
+    nsets = -(-len(values) // chunk_len)
+    zs = [new(n, 4) for _ in range(nsets)]
+    bl = u64(blinding).reshape(nsets, bf, 4)
+    lib().zko_permutation_products(C.c_uint32(k), C.c_uint32(len(values)), C.c_uint32(chunk_len), _ptrs(values), _ptrs(sigmas),
+                                   p(u64(beta)), p(u64(gamma)), C.c_uint32(bf), p(bl), _ptrs(zs), C.c_int(1))
+    return zs
+
+
+def lookup_product(k, cin, ctab, pin, ptab, beta, gamma, bf, blinding):
+    n = 1 << k
+    z = new(n, 4)
+    lib().zko_lookup_product(C.c_uint32(k), p(u64(cin)), p(u64(ctab)), p(u64(pin)), p(u64(ptab)), p(u64(beta)), p(u64(gamma)),
+                             C.c_uint32(bf), p(u64(blinding).reshape(bf, 4)), p(z))
+    return z
+
+
+def eval_polynomials(polys, x):
+    polys = [u64(q).reshape(-1, 4) for q in polys]
+    out = new(len(polys), 4)
+    lib().zko_eval_polynomials(_ptrs(polys), C.c_size_t(len(polys)), C.c_size_t(polys[0].shape[0]), p(u64(x)), p(out))
+    return out
+
+
 class Domain:
     def __init__(self, j, k, g_coset=None):
         self.h = C.c_void_p(lib().zko_domain_new(j, k, p(u64(g_coset)) if g_coset is not None else None))

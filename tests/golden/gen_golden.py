@@ -201,10 +201,43 @@ def evalh_vectors():
                 h=[hx(x) for x in h])
 
 
+def products_vectors():
+    k, bf, chunk = 4, 3, 2
+    n = 1 << k
+    seed = [700]
+
+    def col():
+        seed[0] += 1
+        return [P.from_mont(P.synth_raw253(seed[0], i), P.R) for i in range(n)]
+
+    values = [col() for _ in range(5)]
+    sigmas = [col() for _ in range(5)]
+    beta, gamma = P.synth_raw253(710, 0) % P.R, P.synth_raw253(710, 1) % P.R
+    nsets = 3
+    blind = [[P.synth_raw253(720 + s, t) % P.R for t in range(bf)] for s in range(nsets)]
+    z = P.permutation_products(k, values, sigmas, chunk, beta, gamma, bf, blind)
+    cin, ctab, pin, ptab = col(), col(), col(), col()
+    lblind = [P.synth_raw253(730, t) % P.R for t in range(bf)]
+    lz = P.lookup_product(k, cin, ctab, pin, ptab, beta, gamma, bf, lblind)
+    inv_in = [0, 1, 2, P.R - 1] + col()[:6]
+    x = P.synth_raw253(740, 0) % P.R
+    return dict(k=k, bf=bf, chunk_len=chunk, beta=hx(beta), gamma=hx(gamma),
+                values=[[hx(v) for v in c] for c in values], sigmas=[[hx(v) for v in c] for c in sigmas],
+                blinding=[[hx(v) for v in b] for b in blind], z=[[hx(v) for v in c] for c in z],
+                lookup=dict(cin=[hx(v) for v in cin], ctab=[hx(v) for v in ctab], pin=[hx(v) for v in pin], ptab=[hx(v) for v in ptab],
+                            blinding=[hx(v) for v in lblind], z=[hx(v) for v in lz]),
+                batch_invert=dict(input=[hx(v) for v in inv_in], output=[hx(pow(v, -1, P.R) if v else 0) for v in inv_in]),
+                evals=dict(x=hx(x), values=[hx(P.poly_eval(c, x)) for c in values]))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "products":
+        dump("products.json", products_vectors())
+        sys.exit(0)
     dump("field.json", field_vectors())
     dump("g1.json", g1_vectors())
     dump("msm.json", msm_vectors())
     dump("ntt.json", ntt_vectors())
     dump("domain.json", domain_vectors())
     dump("evalh.json", evalh_vectors())
+    dump("products.json", products_vectors())

@@ -82,5 +82,34 @@ class OracleBackend:
     def to_host(self, col):
         return col
 
+    def compress(self, graph, fixed_l, advice_l, instance_l, theta, k):
+        zero = np.zeros(4, dtype=np.uint64)
+        kw = dict(k=k, extended_k=k, cs_degree=3, blinding_factors=0, extended_omega=zero, g_coset=zero, delta=zero, beta=zero,
+                  gamma=zero, theta=self.fr(theta), y=zero, fixed=fixed_l, advice=advice_l, instance=instance_l, challenges=[],
+                  l0=zero, l_last=zero, l_active=zero, gates_graph=graph, perm_columns=[], sigma=[], perm_z=[], lookup_graphs=[],
+                  lookup_z=[], lookup_a=[], lookup_s=[], to_mont=self.fr_many)
+        pack = zo.EvalhPack()
+        pack.build(**kw)
+        return zo.evaluate_h(pack, 1 << k, self.threads)
+
+    def permutation_products(self, k, values, sigmas, chunk_len, beta, gamma, bf, blinding):
+        nsets = -(-len(values) // chunk_len)
+        return zo.permutation_products(k, values, sigmas, chunk_len, self.fr(beta), self.fr(gamma), bf, blinding.reshape(nsets, bf, 4))
+
+    def lookup_product(self, k, cin, ctab, pin, ptab, beta, gamma, bf, blinding):
+        return zo.lookup_product(k, cin, ctab, pin, ptab, self.fr(beta), self.fr(gamma), bf, blinding)
+
+    def eval_polys_at(self, polys, xs):
+        return np.stack([zo.eval_polynomial(q, self.fr(x)) for q, x in zip(polys, xs)]) if polys else np.zeros((0, 4), dtype=np.uint64)
+
+    def grand_products(self, k, beta, gamma, bf, values, sigmas, chunk_len, perm_blinding, lookups, lookup_blinding):
+        pz = self.permutation_products(k, values, sigmas, chunk_len, beta, gamma, bf, perm_blinding) if values else []
+        lb = lookup_blinding.reshape(-1, bf, 4) if lookups else None
+        lz = [self.lookup_product(k, *lookups[i], beta, gamma, bf, lb[i]) for i in range(len(lookups))]
+        return pz, lz
+
+    def to_host_many(self, arrays):
+        return list(arrays)
+
     def l_cosets(self, blinding_factors):
         return self.domain.l_cosets(blinding_factors, self.threads)

@@ -22,6 +22,7 @@ def test_pass_matches_oracle(zk, oracle, k):
     tc = cp.prove(cp.witness(3))
     assert tg["commitments"] == tc["commitments"]          # every commitment, byte for byte
     assert tg["challenges"] == tc["challenges"]
+    assert len(tg["evals"]) == len(tc["evals"]) and all(ra == rb and (ea == eb).all() for (ra, ea), (rb, eb) in zip(tg["evals"], tc["evals"]))
     for a, b in zip(tg["h_pieces"], tc["h_pieces"]):
         assert (ctx.to_host(a) == b).all()
 

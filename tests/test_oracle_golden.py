@@ -148,3 +148,24 @@ def test_kzg_setup_consistency(oracle):
     c2 = zo.g1_to_affine(zo.best_multiexp(evals, gl, 2))
     c3 = zo.g1_mul_gen(zo.eval_polynomial(coeffs, s))
     assert (c1 == c2).all() and (c1 == c3).all()
+
+
+def test_grand_products_and_batch_invert(oracle):
+    zo = oracle
+    g = load("products.json")
+    k, bf = g["k"], g["bf"]
+    F = lambda xs: zo.fr_arr_from_ints([H(x) for x in xs])
+    values = [F(c) for c in g["values"]]
+    sigmas = [F(c) for c in g["sigmas"]]
+    beta, gamma = zo.fr_from_int(H(g["beta"])), zo.fr_from_int(H(g["gamma"]))
+    blind = np.stack([F(b) for b in g["blinding"]])
+    zs = zo.permutation_products(k, values, sigmas, g["chunk_len"], beta, gamma, bf, blind)
+    for z, exp in zip(zs, g["z"]):
+        assert zo.fr_arr_to_ints(z) == [H(x) for x in exp]
+    L = g["lookup"]
+    lz = zo.lookup_product(k, F(L["cin"]), F(L["ctab"]), F(L["pin"]), F(L["ptab"]), beta, gamma, bf, F(L["blinding"]))
+    assert zo.fr_arr_to_ints(lz) == [H(x) for x in L["z"]]
+    bi = g["batch_invert"]
+    assert zo.fr_arr_to_ints(zo.batch_invert(F(bi["input"]))) == [H(x) for x in bi["output"]]
+    ev = g["evals"]
+    assert zo.fr_arr_to_ints(zo.eval_polynomials(values, zo.fr_from_int(H(ev["x"])))) == [H(x) for x in ev["values"]]
