@@ -65,3 +65,11 @@ def test_host_point_helpers(built, oracle):
     ident = np.zeros(12, dtype=np.uint64)
     assert (ffi.g1_to_affine(ident) == 0).all()
     assert ffi.g1_to_bytes(np.zeros(8, dtype=np.uint64)).hex() == g["identity_compressed"]
+
+
+def test_missing_library_is_an_error_not_a_fallback(built, monkeypatch, tmp_path):
+    ffi = built
+    monkeypatch.setattr(ffi, "_LIB", None)
+    monkeypatch.setattr(ffi, "LIB_PATH", str(tmp_path / "libzkhip.so"))
+    with pytest.raises(ffi.ZkhipError, match="no CPU fallback"):
+        ffi.lib()
