@@ -145,7 +145,7 @@ def main():
             "value": round(ms_per_step / 1000.0, 6), "unit": "s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": False, "scaling": "strong" if shard else "weak", "vs_baseline": None,
             "proofs_per_step": 1 if (shard or world == 1) else world,
-            "dtype": "u256 (8x u32 Montgomery limbs, BN254 Fr/Fq)", "data": "synthetic",
+            "dtype": "u256 (BN254 Fr/Fq, Montgomery, 9 x 29-bit limbs in registers / 8 x u32 in HBM)", "data": "synthetic",
             "config": {"workload": f"create_proof-shaped hot-path pass, {shape.name}: {counts['msm']} MSM_2^{shape.k} + "
                                    f"{counts['intt_n']} iNTT_2^{shape.k} + {counts['ntt_ext']} NTT_2^{prover.dom.extended_k} + "
                                    f"1 iNTT_2^{prover.dom.extended_k} + 1 sweep over 2^{prover.dom.extended_k} rows + lookup compression, "

@@ -10,13 +10,12 @@
 //    its W window multiples 2^(c*w) P_i in affine form (W*n*64 B; 288 GB HBM makes this cheap).
 //    An MSM is then ONE bucket pass over n*W (digit, point) pairs: no per-window doublings and
 //    one 2^(c-1)-bucket reduction instead of W of them.
-//  * Signed c-bit digits; pairs are counting-sorted by |digit| (global histogram + scan +
-//    scatter), so work is proportional to non-zero digits — zero / small witness values cost
-//    nothing in the upper windows.
-//  * Bucket sums are segmented: every thread adds at most SEG pairs (mixed Jacobian+affine adds),
+//  * Signed c-bit digits; pairs are grouped by |digit| with an LDS-histogram radix partition, so work is
+//    proportional to non-zero digits — zero / small witness values cost nothing in the upper windows.
+//  * Bucket sums are segmented: every thread adds at most SEG pairs (XYZZ + affine mixed additions, 8M + 2S),
 //    partial sums are folded in further rounds.  Skewed buckets (boolean columns) therefore cost
 //    depth O(log), not O(count).
-//  * Integer-multiply bound: ~11 field products per pair, 136 v_mad_u64_u32 each.
+//  * Integer-multiply bound: 8 * 171 + 2 * 126 = 1620 v_mad_u64_u32 per (pair, window).
 #include <algorithm>
 
 #include "common.hpp"

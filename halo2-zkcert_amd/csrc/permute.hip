@@ -1,0 +1,244 @@
+// permute.hip — the lookup argument's permuted input / table columns on the GPU.
+//
+// Restates halo2_proofs plonk/lookup/prover.rs permute_expression_pair [UPSTREAM-RECALL; crate pinned at
+// /root/reference/Cargo.lock:1320-1322]: over the usable rows, A' = the input column sorted by field-element order
+// (canonical integer), S'[i] = A'[i] where A'[i] starts a run, and the table values not consumed that way fill the
+// remaining rows (ascending value into descending row).  The result is unique, so the method is free:
+//   1. both columns -> canonical integers, padded with an all-ones sentinel to n = 2^k, bitonic-sorted
+//      (2048-element tiles in LDS, the large strides in global passes);
+//   2. run starts, one binary search per distinct input value into the sorted table (marks the consumed instance,
+//      raises ConstraintSystemFailure if absent), two exclusive scans, a compaction and a gather.
+#include <algorithm>
+
+#include "common.hpp"
+using namespace zk;
+
+#define BT_TILE 2048u   // elements per LDS tile (64 KiB), 256 threads
+
+struct key256 { uint32_t w[8]; };   // canonical integer, w[7] most significant
+
+__device__ __forceinline__ bool key_less(const key256& a, const key256& b) {
+#pragma unroll
+    for (int i = 7; i >= 0; --i) {
+        if (a.w[i] != b.w[i]) return a.w[i] < b.w[i];
+    }
+    return false;
+}
+__device__ __forceinline__ bool key_eq(const key256& a, const key256& b) {
+    uint32_t d = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d |= a.w[i] ^ b.w[i];
+    return d == 0;
+}
+__device__ __forceinline__ key256 key_load(const uint32_t* p) {
+    fe32 m = mem_load(p);
+    key256 k;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) k.w[i] = m.w[i];
+    return k;
+}
+__device__ __forceinline__ void key_store(uint32_t* p, const key256& k) {
+    fe32 m;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m.w[i] = k.w[i];
+    mem_store(p, m);
+}
+
+// ABI column -> canonical integers; rows >= usable get the sentinel 2^256 - 1 (sorts last)
+__global__ void k_pe_keys(const uint32_t* col, size_t n, size_t usable, uint32_t* keys) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe32 m;
+    if (i < usable) m = abi_to_canonical_words<Fr>(mem_load(col + i * 8));
+    else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m.w[j] = 0xffffffffu;
+    }
+    mem_store(keys + i * 8, m);
+}
+
+// Bitonic network: for (k = 2; k <= n; k <<= 1) for (j = k >> 1; j > 0; j >>= 1) compare-exchange(i, i ^ j), ascending iff (i & k) == 0.
+// k_bitonic_tile runs, inside one 2048-element tile held in LDS, every step (k, j) with k_lo <= k <= k_hi and j < 2048
+// (for k > 2048 only the j < 2048 tail of that k).
+__global__ void __launch_bounds__(256) k_bitonic_tile(uint32_t* keys, uint32_t k_lo, uint32_t k_hi) {
+    __shared__ key256 t[BT_TILE];
+    const uint32_t tid = threadIdx.x;
+    const size_t base = (size_t)blockIdx.x * BT_TILE;
+    for (uint32_t e = tid; e < BT_TILE; e += 256) t[e] = key_load(keys + (base + e) * 8);
+    __syncthreads();
+    for (uint32_t k = k_lo; k <= k_hi; k <<= 1) {
+        for (uint32_t j = min(k >> 1, BT_TILE >> 1); j > 0; j >>= 1) {
+            for (uint32_t p = tid; p < BT_TILE / 2; p += 256) {
+                uint32_t i = ((p & ~(j - 1)) << 1) | (p & (j - 1));   // index with bit j clear
+                uint32_t l = i | j;
+                bool asc = (((base + i) & k) == 0);
+                key256 a = t[i], b = t[l];
+                if (key_less(b, a) == asc) { t[i] = b; t[l] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t e = tid; e < BT_TILE; e += 256) key_store(keys + (base + e) * 8, t[e]);
+}
+// one global step (k, j) with j >= 2048
+__global__ void k_bitonic_global(uint32_t* keys, size_t n, uint32_t k, uint32_t j) {
+    size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (p >= n / 2) return;
+    size_t i = ((p & ~((size_t)j - 1)) << 1) | (p & ((size_t)j - 1));
+    size_t l = i | j;
+    bool asc = ((i & k) == 0);
+    key256 a = key_load(keys + i * 8), b = key_load(keys + l * 8);
+    if (key_less(b, a) == asc) { key_store(keys + i * 8, b); key_store(keys + l * 8, a); }
+}
+
+static int bitonic_sort(zkhip_ctx* ctx, void* d_keys, size_t n) {
+    hipStream_t st = ctx->stream;
+    if (n < BT_TILE || (n & (n - 1))) { set_error("bitonic_sort: n must be a power of two >= %u", BT_TILE); return ZKHIP_EINVAL; }
+    unsigned tiles = (unsigned)(n / BT_TILE);
+    hipLaunchKernelGGL(k_bitonic_tile, dim3(tiles), dim3(256), 0, st, (uint32_t*)d_keys, 2u, BT_TILE);
+    for (size_t k = 2 * BT_TILE; k <= n; k <<= 1) {
+        for (size_t j = k >> 1; j >= BT_TILE; j >>= 1)
+            hipLaunchKernelGGL(k_bitonic_global, dim3(div_up(n / 2, 256)), dim3(256), 0, st, (uint32_t*)d_keys, n, (uint32_t)k, (uint32_t)j);
+        hipLaunchKernelGGL(k_bitonic_tile, dim3(tiles), dim3(256), 0, st, (uint32_t*)d_keys, (uint32_t)k, (uint32_t)k);
+    }
+    ZK_LAUNCH_CHECK();
+    return ZKHIP_OK;
+}
+
+// first[row] (as !first -> rep flag) and the consumed table instances
+__global__ void k_pe_mark(const uint32_t* A, const uint32_t* T, size_t usable, uint32_t* rep_flag, uint32_t* left_flag, uint32_t* err) {
+    size_t row = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (row >= usable) return;
+    key256 a = key_load(A + row * 8);
+    bool first = row == 0 || !key_eq(a, key_load(A + (row - 1) * 8));
+    rep_flag[row] = first ? 0u : 1u;
+    if (!first) return;
+    size_t lo = 0, hi = usable;   // first table entry >= a
+    while (lo < hi) {
+        size_t mid = (lo + hi) >> 1;
+        if (key_less(key_load(T + mid * 8), a)) lo = mid + 1; else hi = mid;
+    }
+    if (lo >= usable || !key_eq(key_load(T + lo * 8), a)) { atomicOr(err, 1u); return; }
+    left_flag[lo] = 0u;   // consumed (left_flag was initialised to 1)
+}
+__global__ void k_fill_u32(uint32_t* p, size_t n, uint32_t v) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+// generic exclusive scan of u32 flags: block sums, then apply (blocks of 2048)
+__global__ void __launch_bounds__(256) k_scan_sums(const uint32_t* in, size_t n, uint32_t* sums) {
+    __shared__ uint32_t w[4];
+    size_t lo = (size_t)blockIdx.x * 2048 + threadIdx.x * 8;
+    uint32_t s = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += lo + q < n ? in[lo + q] : 0u;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) s += __shfl_xor(s, d);
+    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[blockIdx.x] = w[0] + w[1] + w[2] + w[3];
+}
+__global__ void __launch_bounds__(256) k_scan_apply(const uint32_t* in, size_t n, const uint32_t* sums, uint32_t nblk, uint32_t* out, uint32_t* total) {
+    __shared__ uint32_t w[4], s_base;
+    uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (wave == 0) {
+        uint32_t b = 0, tot = 0;
+        for (uint32_t j = lane; j < nblk; j += 64) { uint32_t v = sums[j]; if (j < blockIdx.x) b += v; tot += v; }
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { b += __shfl_xor(b, d); tot += __shfl_xor(tot, d); }
+        if (lane == 0) { s_base = b; if (blockIdx.x == 0 && total) *total = tot; }
+    }
+    size_t lo = (size_t)blockIdx.x * 2048 + t * 8;
+    uint32_t v[8], s = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { v[q] = lo + q < n ? in[lo + q] : 0u; s += v[q]; }
+    uint32_t inc = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { uint32_t u = __shfl_up(inc, d); if ((int)lane >= d) inc += u; }
+    if (lane == 63) w[wave] = inc;
+    __syncthreads();
+    uint32_t r = s_base + inc - s;
+    for (uint32_t q = 0; q < wave; ++q) r += w[q];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { if (lo + q < n) out[lo + q] = r; r += v[q]; }
+}
+static int scan_u32(zkhip_ctx* ctx, const void* d_in, size_t n, void* d_out, void* d_total, const char* tag) {
+    unsigned nblk = div_up(n, 2048);
+    void* d_sums;
+    ZK_TRY(ctx->get_scratch(tag, nblk * 4, &d_sums));
+    hipLaunchKernelGGL(k_scan_sums, dim3(nblk), dim3(256), 0, ctx->stream, (const uint32_t*)d_in, n, (uint32_t*)d_sums);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nblk), dim3(256), 0, ctx->stream, (const uint32_t*)d_in, n, (const uint32_t*)d_sums, nblk,
+                       (uint32_t*)d_out, (uint32_t*)d_total);
+    return ZKHIP_OK;
+}
+__global__ void k_pe_compact(const uint32_t* T, const uint32_t* left_flag, const uint32_t* left_rank, size_t usable, uint32_t* leftover) {
+    size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (t >= usable || !left_flag[t]) return;
+    key_store(leftover + (size_t)left_rank[t] * 8, key_load(T + t * 8));
+}
+// canonical integer words -> ABI form
+__device__ __forceinline__ void store_from_canonical(uint32_t* p, const key256& k) {
+    mem_store(p, to_abi(from_canonical_words<Fr>(k.w)));
+}
+__global__ void k_pe_finish(const uint32_t* A, const uint32_t* leftover, const uint32_t* rep_flag, const uint32_t* rep_rank,
+                            const uint32_t* totals /* [0] = #repeated, [1] = #leftover */, size_t n, size_t usable,
+                            const uint32_t* blind_in, const uint32_t* blind_tab, uint32_t* perm_in, uint32_t* perm_tab, uint32_t* err) {
+    size_t row = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    if (row >= usable) {
+        mem_store(perm_in + row * 8, mem_load(blind_in + (row - usable) * 8));
+        mem_store(perm_tab + row * 8, mem_load(blind_tab + (row - usable) * 8));
+        return;
+    }
+    if (row == 0 && totals[0] != totals[1]) atomicOr(err, 2u);
+    key256 a = key_load(A + row * 8);
+    store_from_canonical(perm_in + row * 8, a);
+    if (!rep_flag[row]) { store_from_canonical(perm_tab + row * 8, a); return; }
+    uint32_t R = totals[0];
+    uint32_t idx = R - 1 - rep_rank[row];   // ascending leftover value -> descending repeated row
+    if (idx >= totals[1]) return;           // inconsistent counts: flagged above
+    store_from_canonical(perm_tab + row * 8, key_load(leftover + (size_t)idx * 8));
+}
+
+extern "C" int zkhip_permute_expression_pair_device(zkhip_ctx* ctx, uint32_t k, uint32_t blinding_factors, const void* d_input,
+                                                    const void* d_table, const void* d_blind_in, const void* d_blind_tab,
+                                                    void* d_perm_in, void* d_perm_tab) {
+    if (!ctx || !d_input || !d_table || !d_blind_in || !d_blind_tab || !d_perm_in || !d_perm_tab) { set_error("zkhip_permute_expression_pair_device: null argument"); return ZKHIP_EINVAL; }
+    if (k < 1 || k > 26) { set_error("zkhip_permute_expression_pair_device: k = %u unsupported (1..26)", k); return ZKHIP_EINVAL; }
+    size_t n = (size_t)1 << k;
+    size_t np = std::max(n, (size_t)BT_TILE);   // sort size: short columns are padded with sentinels to one tile
+    if ((size_t)blinding_factors + 1 >= n) { set_error("zkhip_permute_expression_pair_device: too many blinding factors"); return ZKHIP_EINVAL; }
+    size_t usable = n - (blinding_factors + 1);
+    hipStream_t st = ctx->stream;
+    void *dA, *dT, *d_flags, *d_ranks, *d_left, *d_misc;
+    ZK_TRY(ctx->get_scratch("pe_keys_a", np * 32, &dA));
+    ZK_TRY(ctx->get_scratch("pe_keys_t", np * 32, &dT));
+    ZK_TRY(ctx->get_scratch("pe_flags", 2 * n * 4, &d_flags));
+    ZK_TRY(ctx->get_scratch("pe_ranks", 2 * n * 4, &d_ranks));
+    ZK_TRY(ctx->get_scratch("pe_left", n * 32, &d_left));
+    ZK_TRY(ctx->get_scratch("pe_misc", 16, &d_misc));   // totals[2], err
+    uint32_t* rep_flag = (uint32_t*)d_flags; uint32_t* left_flag = rep_flag + n;
+    uint32_t* rep_rank = (uint32_t*)d_ranks; uint32_t* left_rank = rep_rank + n;
+    uint32_t* totals = (uint32_t*)d_misc; uint32_t* err = totals + 2;
+    ProfScope ps(ctx, "lookup_permute");
+    ZK_HIP(hipMemsetAsync(d_misc, 0, 16, st));
+    unsigned g = div_up(n, 256);
+    hipLaunchKernelGGL(k_pe_keys, dim3(div_up(np, 256)), dim3(256), 0, st, (const uint32_t*)d_input, np, usable, (uint32_t*)dA);
+    hipLaunchKernelGGL(k_pe_keys, dim3(div_up(np, 256)), dim3(256), 0, st, (const uint32_t*)d_table, np, usable, (uint32_t*)dT);
+    ZK_TRY(bitonic_sort(ctx, dA, np));
+    ZK_TRY(bitonic_sort(ctx, dT, np));
+    hipLaunchKernelGGL(k_fill_u32, dim3(g), dim3(256), 0, st, left_flag, n, 1u);
+    ZK_HIP(hipMemsetAsync(rep_flag, 0, n * 4, st));
+    hipLaunchKernelGGL(k_pe_mark, dim3(div_up(usable, 256)), dim3(256), 0, st, (const uint32_t*)dA, (const uint32_t*)dT, usable, rep_flag, left_flag, err);
+    ZK_TRY(scan_u32(ctx, rep_flag, usable, rep_rank, totals, "pe_sums_a"));
+    ZK_TRY(scan_u32(ctx, left_flag, usable, left_rank, totals + 1, "pe_sums_b"));
+    hipLaunchKernelGGL(k_pe_compact, dim3(div_up(usable, 256)), dim3(256), 0, st, (const uint32_t*)dT, left_flag, left_rank, usable, (uint32_t*)d_left);
+    hipLaunchKernelGGL(k_pe_finish, dim3(g), dim3(256), 0, st, (const uint32_t*)dA, (const uint32_t*)d_left, rep_flag, rep_rank, totals, n, usable,
+                       (const uint32_t*)d_blind_in, (const uint32_t*)d_blind_tab, (uint32_t*)d_perm_in, (uint32_t*)d_perm_tab, err);
+    ZK_LAUNCH_CHECK();
+    uint32_t h_err = 0;
+    ZK_HIP(hipMemcpyAsync(&h_err, err, 4, hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipStreamSynchronize(st));
+    if (h_err) { set_error("permute_expression_pair: an input value is not in the table (ConstraintSystemFailure)"); return ZKHIP_ECONSTRAINT; }
+    return ZKHIP_OK;
+}

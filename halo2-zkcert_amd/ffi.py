@@ -20,6 +20,13 @@ class ZkhipError(RuntimeError):
     pass
 
 
+class ConstraintSystemFailure(ZkhipError):
+    """halo2_proofs plonk::Error::ConstraintSystemFailure (ZKHIP_ECONSTRAINT)."""
+
+
+ECONSTRAINT = -6
+
+
 class ZkGraph(C.Structure):
     _fields_ = [("constants", C.c_void_p), ("rotations", C.c_void_p), ("code", C.c_void_p),
                 ("n_constants", C.c_uint32), ("n_rotations", C.c_uint32), ("n_code_words", C.c_uint32),
@@ -59,7 +66,7 @@ SYMBOLS = [
     "zkhip_lagrange_to_coeff", "zkhip_coeff_to_extended", "zkhip_extended_to_coeff",
     "zkhip_evaluate_h_device", "zkhip_synth_fill_device",
     "zkhip_batch_invert_device", "zkhip_eval_polynomial_device", "zkhip_eval_polynomials_at_device", "zkhip_permutation_products_device",
-    "zkhip_lookup_product_device", "zkhip_grand_products_device",
+    "zkhip_permute_expression_pair_device", "zkhip_lookup_product_device", "zkhip_grand_products_device",
 ]
 
 
@@ -224,6 +231,18 @@ def permutation_products_device(ctx, k, values, sigmas, chunk_len, beta, gamma, 
                                                        C.c_uint32(chunk_len), _p(_u64(beta)), _p(_u64(gamma)), C.c_uint32(blinding_factors),
                                                        C.c_void_p(blinding.data_ptr()), _ptr_array(zs)))
     return zs
+
+
+def permute_expression_pair_device(ctx, k, blinding_factors, cin, ctab, blind_in, blind_tab):
+    """lookup::prover::permute_expression_pair on device columns; raises ConstraintSystemFailure like halo2 does."""
+    pin, ptab = ctx.empty(1 << k), ctx.empty(1 << k)
+    rc = lib().zkhip_permute_expression_pair_device(ctx.h, C.c_uint32(k), C.c_uint32(blinding_factors), C.c_void_p(cin.data_ptr()),
+                                                    C.c_void_p(ctab.data_ptr()), C.c_void_p(blind_in.data_ptr()),
+                                                    C.c_void_p(blind_tab.data_ptr()), C.c_void_p(pin.data_ptr()), C.c_void_p(ptab.data_ptr()))
+    if rc == ECONSTRAINT:
+        raise ConstraintSystemFailure(lib().zkhip_last_error().decode())
+    _check(rc)
+    return pin, ptab
 
 
 def lookup_product_device(ctx, k, cin, ctab, pin, ptab, beta, gamma, blinding_factors, blinding):

@@ -36,6 +36,7 @@ extern "C" {
 #define ZKHIP_ENOMEM (-3)
 #define ZKHIP_EPROGRAM (-4) /* malformed evaluation graph */
 #define ZKHIP_ENODEVICE (-5)
+#define ZKHIP_ECONSTRAINT (-6) /* the witness violates the argument (halo2 Error::ConstraintSystemFailure) */
 
 typedef struct zkhip_ctx zkhip_ctx;
 typedef struct zkhip_srs zkhip_srs;
@@ -196,6 +197,13 @@ int  zkhip_eval_polynomials_at_device(zkhip_ctx* ctx, const void* const* d_polys
 int  zkhip_permutation_products_device(zkhip_ctx* ctx, uint32_t k, const void* const* d_values, const void* const* d_sigmas, size_t ncols,
                                        uint32_t chunk_len, const uint64_t beta[4], const uint64_t gamma[4], uint32_t blinding_factors,
                                        const void* d_blinding, void* const* d_z);
+/* plonk::lookup::prover::permute_expression_pair (halo2_proofs plonk/lookup/prover.rs): A' = the theta-compressed input
+ * column sorted over the usable rows n - (blinding_factors + 1); S'[i] = A'[i] where A'[i] != A'[i-1], the unused table
+ * values (ascending) fill the other rows (descending); the last blinding_factors + 1 rows of both take d_blind_in /
+ * d_blind_tab ([blinding_factors + 1] elements each, drawn by the caller).  Synchronises the stream.  Returns
+ * ZKHIP_ECONSTRAINT if an input value does not occur in the table. */
+int  zkhip_permute_expression_pair_device(zkhip_ctx* ctx, uint32_t k, uint32_t blinding_factors, const void* d_input, const void* d_table,
+                                          const void* d_blind_in, const void* d_blind_tab, void* d_perm_in, void* d_perm_tab);
 /* plonk::lookup::prover::Permuted::commit_product: z of one lookup from the theta-compressed input / table columns and
  * their permuted forms. */
 int  zkhip_lookup_product_device(zkhip_ctx* ctx, uint32_t k, const void* d_compressed_input, const void* d_compressed_table,

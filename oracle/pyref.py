@@ -412,3 +412,29 @@ def lookup_product(k, cin, ctab, pin, ptab, beta, gamma, bf, blinding):
         den = (pin[i] + beta) * (ptab[i] + gamma) % R
         z.append(z[-1] * num * pow(den, -1, R) % R)
     return z + list(blinding)
+
+
+def permute_expression_pair(k, bf, inp, tab, blind_in, blind_tab):
+    """lookup permutation from its definition: A' = sorted input over the usable rows; S' = a permutation of the table
+    with S'[i] = A'[i] wherever A'[i] != A'[i-1]; remaining table values ascending into the remaining rows descending."""
+    from collections import Counter
+
+    n = 1 << k
+    u = n - (bf + 1)
+    a = sorted(inp[:u])
+    left = Counter(tab[:u])
+    s = [None] * u
+    rep = []
+    for i, v in enumerate(a):
+        if i == 0 or v != a[i - 1]:
+            s[i] = v
+            if left[v] <= 0:
+                raise ValueError("ConstraintSystemFailure")
+            left[v] -= 1
+        else:
+            rep.append(i)
+    for v in sorted(left):
+        for _ in range(left[v]):
+            s[rep.pop()] = v
+    assert not rep
+    return a + list(blind_in), s + list(blind_tab)

@@ -847,6 +847,56 @@ void zko_lookup_product(uint32_t k, const uint64_t* compressed_input, const uint
     for (uint32_t j = 0; j < bf; ++j) memcpy(&z[n - bf + j], blinding_rand + 4 * j, 32);
     free(lp);
 }
+/* lookup::prover::permute_expression_pair (halo2_proofs src/plonk/lookup/prover.rs): sort the input column over the
+ * usable rows, put each distinct input value in the table column at its first row, fill the repeated rows with the
+ * leftover table values (ascending value -> descending row), append the blinding rows.  -1 = ConstraintSystemFailure. */
+typedef struct { fe canon, mont; } pe_item;
+static int pe_cmp(const void* a, const void* b) {
+    const pe_item* x = (const pe_item*)a; const pe_item* y = (const pe_item*)b;
+    for (int i = 3; i >= 0; --i) {
+        if (x->canon.l[i] < y->canon.l[i]) return -1;
+        if (x->canon.l[i] > y->canon.l[i]) return 1;
+    }
+    return 0;
+}
+int zko_permute_expression_pair(uint32_t k, uint32_t bf, const uint64_t* input, const uint64_t* table, const uint64_t* blind_in,
+                                const uint64_t* blind_tab, uint64_t* perm_in, uint64_t* perm_tab) {
+    size_t n = (size_t)1 << k, u = n - (bf + 1);
+    pe_item* A = (pe_item*)malloc(u * sizeof(pe_item));
+    pe_item* T = (pe_item*)malloc(u * sizeof(pe_item));
+    for (size_t i = 0; i < u; ++i) {
+        A[i].mont = *FE(input + 4 * i); f_from_mont(&FR, &A[i].mont, &A[i].canon);
+        T[i].mont = *FE(table + 4 * i); f_from_mont(&FR, &T[i].mont, &T[i].canon);
+    }
+    qsort(A, u, sizeof(pe_item), pe_cmp);
+    qsort(T, u, sizeof(pe_item), pe_cmp);   /* BTreeMap iteration order, with multiplicity */
+    char* removed = (char*)calloc(u, 1);
+    size_t* repeated = (size_t*)malloc(u * sizeof(size_t));
+    size_t nrep = 0;
+    int rc = 0;
+    fe* pin = (fe*)perm_in; fe* ptab = (fe*)perm_tab;
+    for (size_t row = 0; row < u && rc == 0; ++row) {
+        pin[row] = A[row].mont;
+        if (row == 0 || pe_cmp(&A[row], &A[row - 1]) != 0) {
+            ptab[row] = A[row].mont;
+            size_t lo = 0, hi = u;   /* first table entry >= value */
+            while (lo < hi) { size_t mid = (lo + hi) / 2; if (pe_cmp(&T[mid], &A[row]) < 0) lo = mid + 1; else hi = mid; }
+            if (lo >= u || pe_cmp(&T[lo], &A[row]) != 0) rc = -1; else removed[lo] = 1;
+        } else {
+            repeated[nrep++] = row;
+        }
+    }
+    if (rc == 0) {
+        for (size_t t = 0; t < u; ++t) {
+            if (removed[t]) continue;
+            ptab[repeated[--nrep]] = T[t].mont;
+        }
+        if (nrep != 0) rc = -1;
+        for (uint32_t j = 0; j <= bf; ++j) { memcpy(&pin[u + j], blind_in + 4 * j, 32); memcpy(&ptab[u + j], blind_tab + 4 * j, 32); }
+    }
+    free(A); free(T); free(removed); free(repeated);
+    return rc;
+}
 /* eval_polynomial for a batch (halo2_proofs src/arithmetic.rs) */
 void zko_eval_polynomials(const uint64_t* const* polys, size_t npolys, size_t n, const uint64_t x[4], uint64_t* out) {
     for (size_t j = 0; j < npolys; ++j) zko_eval_polynomial(polys[j], n, x, out + 4 * j);

@@ -132,6 +132,9 @@ void zko_permutation_products(uint32_t k, uint32_t n_cols, uint32_t chunk_len, c
 void zko_lookup_product(uint32_t k, const uint64_t* compressed_input, const uint64_t* compressed_table, const uint64_t* permuted_input,
                         const uint64_t* permuted_table, const uint64_t beta[4], const uint64_t gamma[4], uint32_t blinding_factors,
                         const uint64_t* blinding_rand, uint64_t* z_out);
+/* lookup::prover::permute_expression_pair; blind_* hold blinding_factors + 1 elements each; -1 = ConstraintSystemFailure */
+int zko_permute_expression_pair(uint32_t k, uint32_t blinding_factors, const uint64_t* input, const uint64_t* table,
+                                const uint64_t* blind_in, const uint64_t* blind_tab, uint64_t* perm_in, uint64_t* perm_tab);
 void zko_eval_polynomials(const uint64_t* const* polys, size_t npolys, size_t n, const uint64_t x[4], uint64_t* out);
 
 /* ---- synthetic data (repo-wide spec; also csrc/synth.hip) ---- */

@@ -243,6 +243,16 @@ def lookup_product(k, cin, ctab, pin, ptab, beta, gamma, bf, blinding):
     return z
 
 
+def permute_expression_pair(k, bf, inp, tab, blind_in, blind_tab):
+    n = 1 << k
+    pin, ptab = new(n, 4), new(n, 4)
+    rc = lib().zko_permute_expression_pair(C.c_uint32(k), C.c_uint32(bf), p(u64(inp)), p(u64(tab)), p(u64(blind_in)), p(u64(blind_tab)),
+                                           p(pin), p(ptab))
+    if rc != 0:
+        raise ValueError("ConstraintSystemFailure: an input value is not in the table")
+    return pin, ptab
+
+
 def eval_polynomials(polys, x):
     polys = [u64(q).reshape(-1, 4) for q in polys]
     out = new(len(polys), 4)

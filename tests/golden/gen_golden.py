@@ -219,6 +219,20 @@ def products_vectors():
     cin, ctab, pin, ptab = col(), col(), col(), col()
     lblind = [P.synth_raw253(730, t) % P.R for t in range(bf)]
     lz = P.lookup_product(k, cin, ctab, pin, ptab, beta, gamma, bf, lblind)
+    # lookup permutation: a small table with repeats, inputs drawn from it (plus values > 2^128 to exercise the full compare)
+    import random
+    rnd = random.Random(5)
+    u = n - (bf + 1)
+    base_vals = [0, 1, 2, 3, 5, (1 << 130) + 7, (1 << 130) + 8, P.R - 1]
+    tab = [rnd.choice(base_vals) for _ in range(u)]
+    inp = [rnd.choice(tab) for _ in range(u)]
+    tab_full = tab + [P.synth_raw253(750, i) % P.R for i in range(bf + 1)]
+    inp_full = inp + [P.synth_raw253(751, i) % P.R for i in range(bf + 1)]
+    bi = [P.synth_raw253(752, i) % P.R for i in range(bf + 1)]
+    bt = [P.synth_raw253(753, i) % P.R for i in range(bf + 1)]
+    pa, ps = P.permute_expression_pair(k, bf, inp_full, tab_full, bi, bt)
+    permute = dict(input=[hx(v) for v in inp_full], table=[hx(v) for v in tab_full], blind_in=[hx(v) for v in bi], blind_tab=[hx(v) for v in bt],
+                   permuted_input=[hx(v) for v in pa], permuted_table=[hx(v) for v in ps])
     inv_in = [0, 1, 2, P.R - 1] + col()[:6]
     x = P.synth_raw253(740, 0) % P.R
     return dict(k=k, bf=bf, chunk_len=chunk, beta=hx(beta), gamma=hx(gamma),
@@ -227,7 +241,7 @@ def products_vectors():
                 lookup=dict(cin=[hx(v) for v in cin], ctab=[hx(v) for v in ctab], pin=[hx(v) for v in pin], ptab=[hx(v) for v in ptab],
                             blinding=[hx(v) for v in lblind], z=[hx(v) for v in lz]),
                 batch_invert=dict(input=[hx(v) for v in inv_in], output=[hx(pow(v, -1, P.R) if v else 0) for v in inv_in]),
-                evals=dict(x=hx(x), values=[hx(P.poly_eval(c, x)) for c in values]))
+                evals=dict(x=hx(x), values=[hx(P.poly_eval(c, x)) for c in values]), permute=permute)
 
 
 if __name__ == "__main__":

@@ -128,3 +128,72 @@ def test_full_size_permutation_telescopes(zk, oracle):
     assert (z1[: n - bf] == one).all()          # identity sigmas: constant 1 (chained from z0's last kept row = 1)
     assert (z1[n - bf:] == blind.reshape(nsets, bf, 4)[1]).all()
     dom.free()
+
+
+def _lookup_columns(zo, k, bf, seed, distinct, dup_table=False):
+    """A satisfiable (input, table) pair: the table holds `distinct` different values (the rest repeats of them or of a
+    filler), the input draws from the table with a skewed distribution."""
+    n = 1 << k
+    u = n - (bf + 1)
+    rng = np.random.default_rng(seed)
+    pool = zo.synth_raw253(seed, distinct)
+    for i in range(distinct):
+        pool[i][3] &= (1 << 60) - 1      # canonical (< r)
+    tab = np.empty((n, 4), dtype=np.uint64)
+    tab[:distinct] = pool
+    tab[distinct:] = pool[rng.integers(0, distinct if dup_table else 1, n - distinct)]
+    tab[:u] = tab[:u][rng.permutation(u)] if distinct <= u else tab[:u]
+    present = np.unique(tab[:u], axis=0)
+    idx = np.minimum((rng.random(n) ** 3 * len(present)).astype(np.int64), len(present) - 1)
+    inp = present[idx]
+    return inp, tab
+
+
+@pytest.mark.parametrize("k,bf,distinct,dup", [(4, 5, 3, True), (8, 5, 100, False), (11, 5, 1500, True), (12, 6, 4000, False), (14, 5, 9000, True)])
+def test_permute_expression_pair_vs_oracle(zk, oracle, k, bf, distinct, dup):
+    ffi, ctx = zk
+    zo = oracle
+    inp, tab = _lookup_columns(zo, k, bf, 6100 + k, min(distinct, (1 << k) - bf - 1), dup)
+    bi, bt = zo.synth_raw253(6200 + k, bf + 1), zo.synth_raw253(6300 + k, bf + 1)
+    ea, es = zo.permute_expression_pair(k, bf, inp, tab, bi, bt)
+    ga, gs = ffi.permute_expression_pair_device(ctx, k, bf, ctx.to_device(inp), ctx.to_device(tab), ctx.to_device(bi), ctx.to_device(bt))
+    assert (ctx.to_host(ga) == ea).all()
+    assert (ctx.to_host(gs) == es).all()
+
+
+def test_permute_expression_pair_golden_and_failure(zk, oracle):
+    ffi, ctx = zk
+    zo = oracle
+    g = load("products.json")
+    pm = g["permute"]
+    F = lambda xs: zo.fr_arr_from_ints([H(x) for x in xs])
+    dev = lambda name: ctx.to_device(F(pm[name]))
+    ga, gs = ffi.permute_expression_pair_device(ctx, g["k"], g["bf"], dev("input"), dev("table"), dev("blind_in"), dev("blind_tab"))
+    assert zo.fr_arr_to_ints(ctx.to_host(ga)) == [H(x) for x in pm["permuted_input"]]
+    assert zo.fr_arr_to_ints(ctx.to_host(gs)) == [H(x) for x in pm["permuted_table"]]
+    bad = F(pm["input"])
+    bad[1] = zo.fr_from_int(0x1234567)   # not a table value
+    with pytest.raises(ffi.ConstraintSystemFailure):
+        ffi.permute_expression_pair_device(ctx, g["k"], g["bf"], ctx.to_device(bad), dev("table"), dev("blind_in"), dev("blind_tab"))
+
+
+def test_permute_expression_pair_properties_large(zk, oracle):
+    """k = 17 (the RSA circuit's size): multiset equality with the inputs and the argument's row rule, checked on the host
+    with numpy on the canonical values."""
+    ffi, ctx = zk
+    zo = oracle
+    k, bf = 17, 5
+    n, u = 1 << k, (1 << k) - 6
+    inp, tab = _lookup_columns(zo, k, bf, 6400, 1 << 16, True)
+    bi, bt = zo.synth_raw253(6500, bf + 1), zo.synth_raw253(6600, bf + 1)
+    ga, gs = ffi.permute_expression_pair_device(ctx, k, bf, ctx.to_device(inp), ctx.to_device(tab), ctx.to_device(bi), ctx.to_device(bt))
+    ga, gs = ctx.to_host(ga), ctx.to_host(gs)
+    assert (ga[u:] == bi).all() and (gs[u:] == bt).all()
+    key = lambda a: [tuple(r) for r in a]
+    assert sorted(key(ga[:u])) == sorted(key(inp[:u]))
+    assert sorted(key(gs[:u])) == sorted(key(tab[:u]))
+    same_as_table = (ga[:u] == gs[:u]).all(axis=1)
+    same_as_prev = np.concatenate([[False], (ga[1:u] == ga[:u - 1]).all(axis=1)])
+    assert (same_as_table | same_as_prev).all() and same_as_table[0]
+    ea, es = zo.permute_expression_pair(k, bf, inp, tab, bi, bt)
+    assert (ga == ea).all() and (gs == es).all()

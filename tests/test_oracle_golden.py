@@ -169,3 +169,17 @@ def test_grand_products_and_batch_invert(oracle):
     assert zo.fr_arr_to_ints(zo.batch_invert(F(bi["input"]))) == [H(x) for x in bi["output"]]
     ev = g["evals"]
     assert zo.fr_arr_to_ints(zo.eval_polynomials(values, zo.fr_from_int(H(ev["x"])))) == [H(x) for x in ev["values"]]
+
+
+def test_permute_expression_pair(oracle):
+    zo = oracle
+    g = load("products.json")
+    pm = g["permute"]
+    F = lambda xs: zo.fr_arr_from_ints([H(x) for x in xs])
+    pin, ptab = zo.permute_expression_pair(g["k"], g["bf"], F(pm["input"]), F(pm["table"]), F(pm["blind_in"]), F(pm["blind_tab"]))
+    assert zo.fr_arr_to_ints(pin) == [H(x) for x in pm["permuted_input"]]
+    assert zo.fr_arr_to_ints(ptab) == [H(x) for x in pm["permuted_table"]]
+    bad = F(pm["input"])
+    bad[0] = zo.fr_from_int(12345678901234567890)       # not in the table
+    with pytest.raises(ValueError):
+        zo.permute_expression_pair(g["k"], g["bf"], bad, F(pm["table"]), F(pm["blind_in"]), F(pm["blind_tab"]))
