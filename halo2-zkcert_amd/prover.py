@@ -16,9 +16,11 @@ Also computed for real: the theta-compression of the lookup e
 lookup grand products (batch inversion + running product; the blinding rows are seeded stand-ins for the rng),
 and the evaluations of every queried polynomial at x * omega^rotation.
 
-What is NOT here ("next" rows): witness synthesis, the lookup permute (sort), SHPLONK's
-polynomial construction and the real Poseidon/Keccak transcript.  Their outputs are replaced by synthetic
-columns of the right shape and the transcript by BLAKE2b over the same commitment / evaluation bytes, so
+The lookup argument's permuted columns are computed for real too (permute_expression_pair: a sort), which is why
+the synthetic lookup-advice columns draw their values from the table column: the lookup has to be satisfiable.
+
+What is NOT here ("next" rows): witness synthesis, SHPLONK's polynomial construction and the
+real Poseidon/Keccak transcript.  Their outputs are replaced by synthetic columns of the right shape and the transcript by BLAKE2b over the same commitment / evaluation bytes, so
 every Fiat-Shamir host round trip of the real prover is still on the critical path.
 
 The schedule is written against a small backend interface so the same code drives the HIP library
@@ -182,6 +184,13 @@ class GpuBackend:
     def synth(self, n, seed):
         return self.ctx.synth_fill(n, seed)
 
+    def gather(self, col, idx):
+        """col[idx] (idx: host int64 array) — witness construction only"""
+        return col[self.torch.from_numpy(idx).to(col.device)].contiguous()
+
+    def permute(self, k, bf, cin, ctab, blind_in, blind_tab):
+        return self.ffi.permute_expression_pair_device(self.ctx, k, bf, cin, ctab, blind_in, blind_tab)
+
     def clone(self, cols):
         return [c.clone() for c in cols]
 
@@ -324,7 +333,13 @@ class ShardedCommit:
         return self.inner.finish(total)
 
 
-_P_FR = None
+def splitmix64(x):
+    """numpy uint64 -> uint64 (the finaliser of oracle/pyref.py's PRNG spec; used for the lookup witness' row choice)"""
+    with np.errstate(over="ignore"):
+        z = x + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
 
 
 def fr_from_int_host(x):
@@ -371,10 +386,16 @@ class Prover:
         self.omega = pow(ROOT_OF_UNITY, 1 << (28 - sh.k), R)
 
     def witness(self, proof_seed):
-        """Synthetic advice / instance tables in Lagrange form, resident on the device (untimed)."""
+        """Synthetic advice / instance tables in Lagrange form, resident on the device (untimed).  Lookup-advice columns
+        take their values from the table column (about two occurrences of each of the first n/2 table rows), so the
+        lookup argument is satisfiable like a real range check's."""
         sh, n = self.shape, self.n
         base = sh.seed * 1000 + proof_seed * 100000
-        return dict(advice=[self.b.synth(n, base + 1 + i) for i in range(sh.n_advice)],
+        advice = [self.b.synth(n, base + 1 + i) for i in range(sh.n_basic)]
+        for j in range(sh.n_lookup):
+            idx = (splitmix64(np.arange(n, dtype=np.uint64) + np.uint64(((base + 20 + j) << 32) & 0xFFFFFFFFFFFFFFFF)) % np.uint64(n // 2)).astype(np.int64)
+            advice.append(self.b.gather(self.fixed_lagrange[sh.n_fixed - 1], idx))
+        return dict(advice=advice,
                     instance=[self.b.synth(n, base + 50 + i) for i in range(sh.n_instance)],
                     base=base)
 
@@ -404,12 +425,14 @@ class Prover:
         c1 = b.commit(advice + rand_poly, lagrange=[True] * len(advice) + [False])
         t1 = absorb("advice", c1[:len(advice)])
         theta = challenge("theta", t1)
-        # 2. lookups: theta-compress the input / table expressions (real), permuted input / table (synthetic stand-ins
-        #    for the sorted columns); commit the permuted pair in coefficient form
+        # 2. lookups: theta-compress the input / table expressions, permute_expression_pair (sort; blinding rows are
+        #    seeded stand-ins for the rng); commit the permuted pair in coefficient form
+        bf = sh.blinding_factors
         compressed = [(b.compress(gi, self.fixed_lagrange, wit["advice"], wit["instance"], theta, sh.k),
                        b.compress(gt, self.fixed_lagrange, wit["advice"], wit["instance"], theta, sh.k)) for gi, gt in self.compress_graphs]
-        perm_in_l = [b.synth(n, base + 300 + i) for i in range(L)]
-        perm_tab_l = [b.synth(n, base + 320 + i) for i in range(L)]
+        permuted = [b.permute(sh.k, bf, compressed[i][0], compressed[i][1], b.synth(bf + 1, base + 300 + i), b.synth(bf + 1, base + 320 + i))
+                    for i in range(L)]
+        perm_in_l, perm_tab_l = [p_[0] for p_ in permuted], [p_[1] for p_ in permuted]
         perm_in, perm_tab = b.clone(perm_in_l), b.clone(perm_tab_l)
         b.lagrange_to_coeff(perm_in + perm_tab)
         with b.overlap():
@@ -417,7 +440,6 @@ class Prover:
         t2 = absorb("lookup_permuted", b.commit(perm_in + perm_tab, lagrange=False)) if L else []
         beta, gamma = challenge("beta", t1 + t2), challenge("gamma", t1 + t2)
         # 3. grand products: permutation (chunks of degree-2 columns) and one per lookup; blinding rows are seeded stand-ins
-        bf = sh.blinding_factors
         cols = {"advice": wit["advice"], "fixed": self.fixed_lagrange, "instance": wit["instance"]}
         perm_values = [cols[t][i] for t, i in sh.perm_columns]
         perm_z, look_z = b.grand_products(sh.k, beta, gamma, bf, perm_values, self.sigma_lagrange, sh.degree - 2, b.synth(Zp * bf, base + 340),

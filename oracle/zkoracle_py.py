@@ -272,7 +272,7 @@ class Domain:
         lib().zko_domain_get(self.h, p(self.omega), p(self.extended_omega), p(self.g_coset))
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:   # module globals are gone at interpreter shutdown
             lib().zko_domain_free(self.h)
             self.h = None
 

@@ -35,6 +35,12 @@ class OracleBackend:
     def synth(self, n, seed):
         return zo.synth_raw253(seed, n)
 
+    def gather(self, col, idx):
+        return np.ascontiguousarray(col[idx])
+
+    def permute(self, k, bf, cin, ctab, blind_in, blind_tab):
+        return zo.permute_expression_pair(k, bf, cin, ctab, blind_in, blind_tab)
+
     def clone(self, cols):
         return [c.copy() for c in cols]
 
