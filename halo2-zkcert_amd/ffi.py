@@ -67,6 +67,7 @@ SYMBOLS = [
     "zkhip_evaluate_h_device", "zkhip_synth_fill_device",
     "zkhip_batch_invert_device", "zkhip_eval_polynomial_device", "zkhip_eval_polynomials_at_device", "zkhip_permutation_products_device",
     "zkhip_permute_expression_pair_device", "zkhip_lookup_product_device", "zkhip_grand_products_device",
+    "zkhip_linear_combination_device", "zkhip_kate_division_device",
 ]
 
 
@@ -243,6 +244,28 @@ def permute_expression_pair_device(ctx, k, blinding_factors, cin, ctab, blind_in
         raise ConstraintSystemFailure(lib().zkhip_last_error().decode())
     _check(rc)
     return pin, ptab
+
+
+def linear_combination_device(ctx, polys, coeffs, low=None):
+    """sum_j coeffs[j] * polys[j] - low; coeffs (npolys, 4) and low (nlow, 4) are host ABI arrays."""
+    n = polys[0].shape[0]
+    out = ctx.empty(n)
+    coeffs = _u64(coeffs).reshape(len(polys), 4)
+    nlow = 0 if low is None else len(low)
+    low_a = _u64(low).reshape(nlow, 4) if nlow else None
+    _check(lib().zkhip_linear_combination_device(ctx.h, C.c_size_t(n), _ptr_array(polys), C.c_size_t(len(polys)), _p(coeffs),
+                                                 _p(low_a) if nlow else None, C.c_size_t(nlow), C.c_void_p(out.data_ptr())))
+    return out
+
+
+def kate_division_device(ctx, polys, roots):
+    """In place: polys[j] /= prod (X - r) for r in roots[j] (each a list of host ABI elements)."""
+    if not polys:
+        return
+    n = polys[0].shape[0]
+    counts = np.array([len(r) for r in roots], dtype=np.uint32)
+    flat = _u64(np.concatenate([_u64(r).reshape(-1, 4) for r in roots if len(r)])) if counts.sum() else np.zeros((1, 4), dtype=np.uint64)
+    _check(lib().zkhip_kate_division_device(ctx.h, C.c_size_t(n), _ptr_array(polys), C.c_size_t(len(polys)), _p(counts), _p(flat)))
 
 
 def lookup_product_device(ctx, k, cin, ctab, pin, ptab, beta, gamma, blinding_factors, blinding):

@@ -191,6 +191,14 @@ class GpuBackend:
     def permute(self, k, bf, cin, ctab, blind_in, blind_tab):
         return self.ffi.permute_expression_pair_device(self.ctx, k, bf, cin, ctab, blind_in, blind_tab)
 
+    def lincomb(self, polys, coeffs, low):
+        """sum_j coeffs[j] polys[j] - low (coeffs, low: canonical ints)"""
+        return self.ffi.linear_combination_device(self.ctx, polys, self.fr_many(coeffs), self.fr_many(low) if low else None)
+
+    def kate_division(self, polys, roots):
+        """in place: polys[j] /= prod (X - r), r in roots[j] (canonical ints)"""
+        self.ffi.kate_division_device(self.ctx, polys, [self.fr_many(r) for r in roots])
+
     def clone(self, cols):
         return [c.clone() for c in cols]
 

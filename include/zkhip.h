@@ -220,6 +220,18 @@ int  zkhip_grand_products_device(zkhip_ctx* ctx, uint32_t k, const uint64_t beta
                                  const void* const* d_permuted_input, const void* const* d_permuted_table, const void* d_lookup_blinding,
                                  void* const* d_lookup_z);
 
+/* ---- SHPLONK multi-open prover arithmetic (halo2_proofs poly/kzg/multiopen/shplonk/prover.rs, reached through
+ * gen_snark_shplonk at /root/reference/src/helpers.rs:233,299) ----
+ * d_out[i] = sum_j coeffs[j] * d_polys[j][i] - (i < nlow ? low[i] : 0): the y- / v-power combinations of the rotation sets'
+ * polynomials minus the low-degree interpolant.  d_polys is a HOST array of device polynomials of n coefficients; coeffs
+ * (npolys x 4) and low (nlow x 4) are host arrays; d_out must not alias an input. */
+int  zkhip_linear_combination_device(zkhip_ctx* ctx, size_t n, const void* const* d_polys, size_t npolys, const uint64_t* coeffs,
+                                     const uint64_t* low, size_t nlow, void* d_out);
+/* arithmetic::kate_division, in place and batched: polynomial j (n coefficients) is divided by prod_t (X - roots[j][t]) over
+ * its nroots[j] roots (roots: host, all polynomials' roots concatenated); remainders are dropped and the vacated top
+ * coefficients are zero, i.e. the result is already "resized to n". */
+int  zkhip_kate_division_device(zkhip_ctx* ctx, size_t n, void* const* d_polys, size_t npolys, const uint32_t* nroots, const uint64_t* roots);
+
 /* ---- synthetic tables (bench / tests): element i of a column = raw253(seed, i) taken as the
  * Montgomery limbs (oracle/pyref.py synth_raw253) ---- */
 int  zkhip_synth_fill_device(zkhip_ctx* ctx, void* d_out, size_t n, uint64_t seed, uint64_t first_index);

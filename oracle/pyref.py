@@ -438,3 +438,148 @@ def permute_expression_pair(k, bf, inp, tab, blind_in, blind_tab):
             s[rep.pop()] = v
     assert not rep
     return a + list(blind_in), s + list(blind_tab)
+
+
+# ----------------------------------------------------------------------------- SHPLONK multi-open
+# halo2_proofs src/poly/kzg/multiopen/shplonk.rs (construct_intermediate_sets), shplonk/prover.rs (create_proof),
+# shplonk/verifier.rs (verify_proof) [UPSTREAM-RECALL; crate pinned at /root/reference/Cargo.lock:1320-1322; reached through
+# gen_snark_shplonk, /root/reference/src/helpers.rs:233,299].  Polynomials are coefficient lists of ints mod R.
+def construct_intermediate_sets(queries):
+    """queries: [(commitment_id, point, eval)] in query order.  Commitments are grouped by the SET of points they are opened at;
+    sets appear in the order their first commitment does, points inside a set ascending (BTreeSet over Fr's Ord = canonical
+    integer order).  Returns (rotation_sets, super_point_set): rotation_sets = [dict(points=[..], commitments=[(id, evals)])]."""
+    super_points = sorted({pt for _, pt, _ in queries})
+    per_commitment = []            # [(id, set(points))], first-appearance order
+    for cid, pt, _ in queries:
+        for ent in per_commitment:
+            if ent[0] == cid:
+                ent[1].add(pt)
+                break
+        else:
+            per_commitment.append((cid, {pt}))
+    sets = []                      # [(frozenset(points), [ids])]
+    for cid, pts in per_commitment:
+        for ent in sets:
+            if ent[0] == pts:
+                ent[1].append(cid)
+                break
+        else:
+            sets.append((set(pts), [cid]))
+    ev = {(cid, pt): e for cid, pt, e in queries}
+    rotation_sets = []
+    for pts, ids in sets:
+        points = sorted(pts)
+        rotation_sets.append(dict(points=points, commitments=[(cid, [ev[(cid, pt)] for pt in points]) for cid in ids]))
+    return rotation_sets, super_points
+
+
+def lagrange_interpolate(points, evals):
+    """coefficients (len(points)) of the polynomial through (points[i], evals[i])"""
+    m = len(points)
+    out = [0] * m
+    for i in range(m):
+        num = [1]                  # prod_{j != i} (X - x_j)
+        den = 1
+        for j in range(m):
+            if j == i:
+                continue
+            num = [(a - points[j] * b) % R for a, b in zip([0] + num, num + [0])]
+            den = den * (points[i] - points[j]) % R
+        c = evals[i] * pow(den, R - 2, R) % R
+        for d in range(len(num)):
+            out[d] = (out[d] + c * num[d]) % R
+    return out
+
+
+def eval_vanishing(roots, z):
+    acc = 1
+    for r in roots:
+        acc = acc * (z - r) % R
+    return acc
+
+
+def kate_division(a, root):
+    """a / (X - root), remainder dropped: len(a) - 1 coefficients (arithmetic::kate_division)"""
+    q = [0] * (len(a) - 1)
+    s = 0
+    for j in range(len(a) - 1, 0, -1):
+        s = (a[j] + root * s) % R
+        q[j - 1] = s
+    return q
+
+
+def shplonk_quotient(polys, rotation_sets, y, v, n):
+    """h(X) = sum_i v^i [sum_j y^j (P_ij - R_ij)](X) / Z_i(X), R_ij = the interpolant of P_ij's evals on set i's points"""
+    h = [0] * n
+    vp = 1
+    for rs in rotation_sets:
+        num = [0] * n
+        yp = 1
+        for cid, evals in rs["commitments"]:
+            low = lagrange_interpolate(rs["points"], evals)
+            pj = polys[cid]
+            for d in range(n):
+                num[d] = (num[d] + yp * (pj[d] - (low[d] if d < len(low) else 0))) % R
+            yp = yp * y % R
+        for r in rs["points"]:
+            num = kate_division(num, r)
+        num += [0] * (n - len(num))
+        for d in range(n):
+            h[d] = (h[d] + vp * num[d]) % R
+        vp = vp * v % R
+    return h
+
+
+def shplonk_linearisation(polys, rotation_sets, super_points, y, v, u, h, n):
+    """[sum_i v^i Z_{T\\S_i}(u) sum_j y^j (P_ij(X) - R_ij(u)) - Z_T(u) h(X)] / (X - u), scaled by 1 / Z_{T\\S_0}(u)"""
+    l = [0] * n
+    vp = 1
+    z_diffs = []
+    for rs in rotation_sets:
+        z_i = eval_vanishing([p_ for p_ in super_points if p_ not in rs["points"]], u)
+        z_diffs.append(z_i)
+        yp = 1
+        for cid, evals in rs["commitments"]:
+            r_u = poly_eval(lagrange_interpolate(rs["points"], evals), u)
+            c = vp * z_i % R * yp % R
+            pj = polys[cid]
+            for d in range(n):
+                l[d] = (l[d] + c * pj[d]) % R
+            l[0] = (l[0] - c * r_u) % R
+            yp = yp * y % R
+        vp = vp * v % R
+    zt = eval_vanishing(super_points, u)
+    for d in range(n):
+        l[d] = (l[d] - zt * h[d]) % R
+    assert poly_eval(l, u) == 0, "shplonk: linearisation does not vanish at u"
+    q = kate_division(l, u) + [0]
+    inv0 = pow(z_diffs[0], R - 2, R)
+    return [c * inv0 % R for c in q]
+
+
+def shplonk_verify(commitments, rotation_sets, super_points, y, v, u, h1, h2, s):
+    """The verifier's pairing check e(h2, [s]_2) = e(L, [1]_2) restated with the trapdoor s: s * h2 == L in G1, where
+    L = sum_i v^i z_i (sum_j y^j C_ij) - [sum_i v^i z_i sum_j y^j R_ij(u)] G - z_0 h1 + u h2, z_i = Z_{T\\S_i}(u) / Z_{T\\S_0}(u),
+    z_0 = Z_T(u) / Z_{T\\S_0}(u).  commitments: id -> affine point; h1, h2 affine."""
+    G = (1, 2)
+    inv0 = None
+    acc = INF
+    r_acc = 0
+    vp = 1
+    for i, rs in enumerate(rotation_sets):
+        z_i = eval_vanishing([p_ for p_ in super_points if p_ not in rs["points"]], u)
+        if i == 0:
+            inv0 = pow(z_i, R - 2, R)
+        z_i = z_i * inv0 % R
+        yp = 1
+        for cid, evals in rs["commitments"]:
+            c = vp * z_i % R * yp % R
+            acc = jac_add(acc, scalar_mul(c, from_affine(commitments[cid])))
+            r_acc = (r_acc + c * poly_eval(lagrange_interpolate(rs["points"], evals), u)) % R
+            yp = yp * y % R
+        vp = vp * v % R
+    z_0 = eval_vanishing(super_points, u) * inv0 % R
+    acc = jac_add(acc, scalar_mul((-r_acc) % R, from_affine(G)))
+    acc = jac_add(acc, scalar_mul((-z_0) % R, from_affine(h1)))
+    acc = jac_add(acc, scalar_mul(u, from_affine(h2)))
+    return to_affine(acc) == to_affine(scalar_mul(s % R, from_affine(h2)))

@@ -902,6 +902,34 @@ void zko_eval_polynomials(const uint64_t* const* polys, size_t npolys, size_t n,
     for (size_t j = 0; j < npolys; ++j) zko_eval_polynomial(polys[j], n, x, out + 4 * j);
 }
 
+/* ------------------------------------------------------------------ SHPLONK's polynomial arithmetic
+ * halo2_proofs src/poly/kzg/multiopen/shplonk/prover.rs [UPSTREAM-RECALL]: the prover forms linear combinations of
+ * coefficient-form polynomials (powers of y within a rotation set, of v across sets), subtracts the low-degree
+ * interpolant, and divides by prod (X - r) with arithmetic::kate_division (synthetic division, remainder dropped). */
+void zko_linear_combination(const uint64_t* const* polys, size_t npolys, size_t n, const uint64_t* coeffs, const uint64_t* low, size_t nlow,
+                            uint64_t* out) {
+    for (size_t i = 0; i < n; ++i) {
+        fe acc; memset(&acc, 0, sizeof acc);
+        for (size_t j = 0; j < npolys; ++j) {
+            fe t; f_mul(&FR, FE(polys[j] + 4 * i), FE(coeffs + 4 * j), &t);
+            f_add(&FR, &acc, &t, &acc);
+        }
+        if (i < nlow) f_sub(&FR, &acc, FE(low + 4 * i), &acc);
+        memcpy(out + 4 * i, acc.l, 32);
+    }
+}
+/* a <- a / (X - root), in place: q[j] = s[j+1] with s[j] = a[j] + root * s[j+1]; q[n-1] = 0 (upstream returns n-1 coefficients and the
+ * caller resizes to n) */
+void zko_kate_division(uint64_t* a, size_t n, const uint64_t root[4]) {
+    fe s; memset(&s, 0, sizeof s);
+    for (size_t j = n; j-- > 0;) {
+        fe aj; memcpy(aj.l, a + 4 * j, 32);
+        memcpy(a + 4 * j, s.l, 32);
+        f_mul(&FR, &s, FE(root), &s);
+        f_add(&FR, &s, &aj, &s);
+    }
+}
+
 /* ------------------------------------------------------------------ synthetic data */
 uint64_t zko_splitmix64(uint64_t x) {
     x += 0x9E3779B97F4A7C15ULL;

@@ -135,6 +135,10 @@ void zko_lookup_product(uint32_t k, const uint64_t* compressed_input, const uint
 /* lookup::prover::permute_expression_pair; blind_* hold blinding_factors + 1 elements each; -1 = ConstraintSystemFailure */
 int zko_permute_expression_pair(uint32_t k, uint32_t blinding_factors, const uint64_t* input, const uint64_t* table,
                                 const uint64_t* blind_in, const uint64_t* blind_tab, uint64_t* perm_in, uint64_t* perm_tab);
+/* shplonk prover: out = sum_j coeffs[j] * polys[j] - low (low: nlow leading coefficients); a <- a / (X - root) */
+void zko_linear_combination(const uint64_t* const* polys, size_t npolys, size_t n, const uint64_t* coeffs, const uint64_t* low, size_t nlow,
+                            uint64_t* out);
+void zko_kate_division(uint64_t* a, size_t n, const uint64_t root[4]);
 void zko_eval_polynomials(const uint64_t* const* polys, size_t npolys, size_t n, const uint64_t x[4], uint64_t* out);
 
 /* ---- synthetic data (repo-wide spec; also csrc/synth.hip) ---- */

@@ -260,6 +260,25 @@ def eval_polynomials(polys, x):
     return out
 
 
+def linear_combination(polys, coeffs, low=None):
+    """sum_j coeffs[j] * polys[j] minus the low-degree polynomial `low` (shplonk prover)."""
+    polys = [u64(q).reshape(-1, 4) for q in polys]
+    coeffs = u64(coeffs).reshape(len(polys), 4)
+    low = u64(low).reshape(-1, 4) if low is not None and len(low) else new(0, 4)
+    out = new(polys[0].shape[0], 4)
+    lib().zko_linear_combination(_ptrs(polys), C.c_size_t(len(polys)), C.c_size_t(polys[0].shape[0]), p(coeffs), p(low) if len(low) else None,
+                                 C.c_size_t(len(low)), p(out))
+    return out
+
+
+def kate_division(a, roots):
+    """a / prod (X - r) for r in roots (remainders dropped), same length as a."""
+    a = u64(a).copy().reshape(-1, 4)
+    for r in u64(roots).reshape(-1, 4):
+        lib().zko_kate_division(p(a), C.c_size_t(a.shape[0]), p(r))
+    return a
+
+
 class Domain:
     def __init__(self, j, k, g_coset=None):
         self.h = C.c_void_p(lib().zko_domain_new(j, k, p(u64(g_coset)) if g_coset is not None else None))

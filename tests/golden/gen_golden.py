@@ -244,9 +244,49 @@ def products_vectors():
                 evals=dict(x=hx(x), values=[hx(P.poly_eval(c, x)) for c in values]), permute=permute)
 
 
+def shplonk_vectors():
+    """SHPLONK prover polynomials h(X), h'(X) for six polynomials opened at four different point sets (k = 5), the
+    commitments under the SRS trapdoor, and the verifier's verdict (pyref.shplonk_verify: an independent equation)."""
+    k, s = 5, 0x1D5C0FFEE
+    n = 1 << k
+    polys = {i: [P.synth_raw253(800 + i, j) % P.R for j in range(n)] for i in range(6)}
+    x = P.synth_raw253(810, 0) % P.R
+    w = P.omega_for(k)
+    pts = {0: [x], 1: [x, x * w % P.R], 2: [x * w % P.R, x], 3: [x, x * w % P.R, x * pow(w, n - 3, P.R) % P.R], 4: [x],
+           5: [x, x * pow(w, n - 1, P.R) % P.R]}
+    queries = [(i, pt, P.poly_eval(polys[i], pt)) for i in [0, 1, 3, 2, 5, 4] for pt in pts[i]]
+    y, v, u = (P.synth_raw253(811, j) % P.R for j in range(3))
+    rs, sp = P.construct_intermediate_sets(queries)
+    h = P.shplonk_quotient(polys, rs, y, v, n)
+    f = P.shplonk_linearisation(polys, rs, sp, y, v, u, h, n)
+    G = P.from_affine((1, 2))
+    com = lambda q: P.to_affine(P.scalar_mul(P.poly_eval(q, s), G))
+    C = {i: com(polys[i]) for i in polys}
+    h1, h2 = com(h), com(f)
+    assert P.shplonk_verify(C, rs, sp, y, v, u, h1, h2, s)
+    # primitives: one linear combination with a low-degree correction, one division by three roots
+    cf = [P.synth_raw253(812, j) % P.R for j in range(6)]
+    low = [P.synth_raw253(813, j) % P.R for j in range(3)]
+    lc = [(sum(cf[i] * polys[i][d] for i in range(6)) - (low[d] if d < 3 else 0)) % P.R for d in range(n)]
+    roots = [3, x, P.R - 5]
+    prod = list(polys[0][:n - 3])
+    for r in roots:
+        prod = [(a - r * b_) % P.R for a, b_ in zip([0] + prod, prod + [0])]
+    return dict(k=k, s=hx(s), polys=[[hx(c) for c in polys[i]] for i in range(6)],
+                queries=[[i, hx(pt), hx(e)] for i, pt, e in queries], y=hx(y), v=hx(v), u=hx(u),
+                set_sizes=[len(r["points"]) for r in rs], set_members=[[c[0] for c in r["commitments"]] for r in rs],
+                h=[hx(c) for c in h], h_prime=[hx(c) for c in f],
+                commitments=[[hx(C[i][0]), hx(C[i][1])] for i in range(6)], h1=[hx(h1[0]), hx(h1[1])], h2=[hx(h2[0]), hx(h2[1])],
+                lincomb=dict(coeffs=[hx(c) for c in cf], low=[hx(c) for c in low], out=[hx(c) for c in lc]),
+                division=dict(dividend=[hx(c) for c in prod], roots=[hx(r) for r in roots], quotient=[hx(c) for c in polys[0][:n - 3]] + ["0"] * 3))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "products":
         dump("products.json", products_vectors())
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "shplonk":
+        dump("shplonk.json", shplonk_vectors())
         sys.exit(0)
     dump("field.json", field_vectors())
     dump("g1.json", g1_vectors())
@@ -255,3 +295,4 @@ if __name__ == "__main__":
     dump("domain.json", domain_vectors())
     dump("evalh.json", evalh_vectors())
     dump("products.json", products_vectors())
+    dump("shplonk.json", shplonk_vectors())

@@ -41,6 +41,13 @@ class OracleBackend:
     def permute(self, k, bf, cin, ctab, blind_in, blind_tab):
         return zo.permute_expression_pair(k, bf, cin, ctab, blind_in, blind_tab)
 
+    def lincomb(self, polys, coeffs, low):
+        return zo.linear_combination(polys, self.fr_many(coeffs), self.fr_many(low) if low else None)
+
+    def kate_division(self, polys, roots):
+        for q, rs in zip(polys, roots):
+            q[:] = zo.kate_division(q, self.fr_many(rs))
+
     def clone(self, cols):
         return [c.copy() for c in cols]
 

@@ -1,0 +1,96 @@
+"""GPU parity: SHPLONK prover arithmetic (linear combinations, kate division, the whole multi-open) vs golden vectors and the oracle."""
+import numpy as np
+import pytest
+
+from util import H, load
+
+pytestmark = pytest.mark.gpu
+R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+
+
+def _case(zo):
+    g = load("shplonk.json")
+    F = lambda xs: zo.fr_arr_from_ints([H(x) for x in xs])
+    return g, F
+
+
+def test_primitives_golden(zk, oracle):
+    ffi, ctx = zk
+    zo = oracle
+    g, F = _case(zo)
+    polys = [ctx.to_device(F(c)) for c in g["polys"]]
+    lc = g["lincomb"]
+    out = ffi.linear_combination_device(ctx, polys, F(lc["coeffs"]), F(lc["low"]))
+    assert zo.fr_arr_to_ints(ctx.to_host(out)) == [H(x) for x in lc["out"]]
+    dv = g["division"]
+    a = ctx.to_device(F(dv["dividend"]))
+    ffi.kate_division_device(ctx, [a], [F(dv["roots"])])
+    assert zo.fr_arr_to_ints(ctx.to_host(a)) == [H(x) for x in dv["quotient"]]
+
+
+def test_multiopen_golden(zk, oracle):
+    import halo2_zkcert_amd.prover as pv
+    import halo2_zkcert_amd.shplonk as sp
+
+    ffi, ctx = zk
+    zo = oracle
+    g, F = _case(zo)
+    b = pv.GpuBackend(ffi, ctx)
+    b.setup(g["k"], 3, H(g["s"]))
+    polys = {i: ctx.to_device(F(c)) for i, c in enumerate(g["polys"])}
+    queries = [(i, H(pt), H(e)) for i, pt, e in g["queries"]]
+    ch = {"shplonk_y": H(g["y"]), "shplonk_v": H(g["v"]), "shplonk_u": H(g["u"])}
+    pr = sp.ProverSHPLONK(b).create_proof(polys, queries, lambda t: ch[t], lambda t, c: None)
+    assert zo.fr_arr_to_ints(ctx.to_host(pr["h_x"])) == [H(x) for x in g["h"]]
+    assert zo.fr_arr_to_ints(ctx.to_host(pr["l_x"])) == [H(x) for x in g["h_prime"]]
+    for got, exp in ((pr["h1"], g["h1"]), (pr["h2"], g["h2"])):
+        assert zo.affine_to_ints(np.asarray(got[0]).reshape(1, 8))[0] == (H(exp[0]), H(exp[1]))
+
+
+@pytest.mark.parametrize("n,npolys,nlow", [(1, 1, 1), (100, 3, 4), (2048, 4, 0), (5000, 7, 2), (1 << 15, 70, 3)])
+def test_linear_combination_vs_oracle(zk, oracle, n, npolys, nlow):
+    ffi, ctx = zk
+    zo = oracle
+    polys = [zo.synth_raw253(7000 + j, n) for j in range(npolys)]
+    cf = zo.synth_raw253(7100 + n, npolys)
+    cf[0] = 0
+    low = zo.synth_raw253(7200 + n, nlow) if nlow else None
+    exp = zo.linear_combination(polys, cf, low)
+    got = ffi.linear_combination_device(ctx, [ctx.to_device(q) for q in polys], cf, low)
+    assert (ctx.to_host(got) == exp).all()
+
+
+@pytest.mark.parametrize("n", [1, 2, 9, 2047, 2048, 2049, 1 << 14, (1 << 17) + 13, 1 << 20])
+def test_kate_division_vs_oracle(zk, oracle, n):
+    """several polynomials with different numbers of roots in one call; dividends are arbitrary (remainders dropped)"""
+    ffi, ctx = zk
+    zo = oracle
+    polys = [zo.synth_raw253(7300 + j, n) for j in range(4)]
+    roots = [zo.synth_raw253(7400 + j, c) for j, c in enumerate((1, 3, 0, 4))]
+    roots[1][1] = 0                                  # division by X
+    roots[3][2] = zo.fr_from_int(1)                  # and by X - 1
+    dev = [ctx.to_device(q) for q in polys]
+    ffi.kate_division_device(ctx, dev, roots)
+    for q, r, d in zip(polys, roots, dev):
+        exp = zo.kate_division(q, r) if len(r) else q
+        assert (ctx.to_host(d) == exp).all()
+
+
+def test_division_is_exact_on_multiples(zk, oracle):
+    """k = 17: (X - r1)(X - r2) q(X) divided back gives q(X) — a size-independent property at the benchmark's size"""
+    ffi, ctx = zk
+    zo = oracle
+    n = 1 << 17
+    q = zo.synth_raw253(7500, n)
+    q[n - 2:] = 0
+    r = zo.synth_raw253(7501, 2)
+    # multiply by (X - r): shift minus r * q, twice, with the oracle's field ops on whole columns
+    cur = q.copy()
+    for j in range(2):
+        shifted = np.zeros_like(cur)
+        shifted[1:] = cur[:-1]
+        neg_r = zo.fr_from_int((R - zo.fr_to_int(r[j])) % R)
+        cur = zo.linear_combination([shifted, cur], np.stack([zo.fr_from_int(1), neg_r]))
+    d = ctx.to_device(cur)
+    ffi.kate_division_device(ctx, [d], [r])
+    assert (ctx.to_host(d) == q).all()

@@ -183,3 +183,43 @@ def test_permute_expression_pair(oracle):
     bad[0] = zo.fr_from_int(12345678901234567890)       # not in the table
     with pytest.raises(ValueError):
         zo.permute_expression_pair(g["k"], g["bf"], bad, F(pm["table"]), F(pm["blind_in"]), F(pm["blind_tab"]))
+
+
+def _shplonk_case(zo):
+    g = load("shplonk.json")
+    F = lambda xs: zo.fr_arr_from_ints([H(x) for x in xs])
+    polys = {i: F(c) for i, c in enumerate(g["polys"])}
+    queries = [(i, H(pt), H(e)) for i, pt, e in g["queries"]]
+    ch = {"shplonk_y": H(g["y"]), "shplonk_v": H(g["v"]), "shplonk_u": H(g["u"])}
+    return g, F, polys, queries, ch
+
+
+def test_shplonk_primitives(oracle):
+    zo = oracle
+    g, F, polys, _, _ = _shplonk_case(zo)
+    lc = g["lincomb"]
+    out = zo.linear_combination([polys[i] for i in range(6)], F(lc["coeffs"]), F(lc["low"]))
+    assert zo.fr_arr_to_ints(out) == [H(x) for x in lc["out"]]
+    dv = g["division"]
+    assert zo.fr_arr_to_ints(zo.kate_division(F(dv["dividend"]), F(dv["roots"]))) == [H(x) for x in dv["quotient"]]
+
+
+def test_shplonk_prover_host_logic(oracle):
+    """halo2_zkcert_amd.shplonk (the host side of the product path) driven by the oracle backend: rotation-set grouping,
+    h(X), h'(X) and both commitments against the golden vectors (whose generator also checked the verifier equation)."""
+    import halo2_zkcert_amd.shplonk as sp
+    from oracle_backend import OracleBackend
+
+    zo = oracle
+    g, F, polys, queries, ch = _shplonk_case(zo)
+    b = OracleBackend(2)
+    b.setup(g["k"], 3, H(g["s"]))
+    written = []
+    pr = sp.ProverSHPLONK(b).create_proof(polys, queries, lambda t: ch[t], lambda t, c: written.append(t))
+    assert [len(r.points) for r in pr["rotation_sets"]] == g["set_sizes"]
+    assert [[c[0] for c in r.commitments] for r in pr["rotation_sets"]] == g["set_members"]
+    assert zo.fr_arr_to_ints(pr["h_x"]) == [H(x) for x in g["h"]]
+    assert zo.fr_arr_to_ints(pr["l_x"]) == [H(x) for x in g["h_prime"]]
+    assert written == ["shplonk_h1", "shplonk_h2"]
+    for got, exp in ((pr["h1"], g["h1"]), (pr["h2"], g["h2"])):
+        assert zo.affine_to_ints(got[0].reshape(1, 8))[0] == (H(exp[0]), H(exp[1]))
