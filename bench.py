@@ -121,7 +121,7 @@ def main():
 
     kernels = {}
     for name in ("msm_digits", "msm_plan", "msm_accum_affine", "msm_accum_jac", "msm_tail", "ntt_strided", "ntt_final", "sweep",
-                 "lookup_permute", "grand_product", "eval_polynomial"):
+                 "lookup_permute", "grand_product", "eval_polynomial", "linear_combination", "kate_division"):
         ms, launches = ctx.profile_read(name)
         kernels[name] = dict(ms_per_step=round(ms / args.steps, 4), launches_per_step=launches / args.steps)
     ctx.profile_enable(False)
@@ -150,7 +150,7 @@ def main():
                                    f"{counts['intt_n']} iNTT_2^{shape.k} + {counts['ntt_ext']} NTT_2^{prover.dom.extended_k} + "
                                    f"1 iNTT_2^{prover.dom.extended_k} + 1 sweep over 2^{prover.dom.extended_k} rows + lookup compression, "
                                    f"{shape.n_perm_sets}+{len(shape.lookups)} grand products, evaluations at x; "
-                                   "uniform synthetic witness (lookup inputs drawn from the table), lookup permute (sort) real; SHPLONK polynomials synthetic; "
+                                   "lookup permute (sort) and SHPLONK multi-open computed; uniform synthetic witness (lookup inputs drawn from the table); "
                                    "BLAKE2b stand-in transcript",
                        "k": shape.k, "advice": shape.n_advice, "fixed": shape.n_fixed, "lookups": len(shape.lookups),
                        "perm_columns": len(shape.perm_columns), "degree": shape.degree,

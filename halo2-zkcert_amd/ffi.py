@@ -67,7 +67,7 @@ SYMBOLS = [
     "zkhip_evaluate_h_device", "zkhip_synth_fill_device",
     "zkhip_batch_invert_device", "zkhip_eval_polynomial_device", "zkhip_eval_polynomials_at_device", "zkhip_permutation_products_device",
     "zkhip_permute_expression_pair_device", "zkhip_lookup_product_device", "zkhip_grand_products_device",
-    "zkhip_linear_combination_device", "zkhip_kate_division_device",
+    "zkhip_linear_combination_device", "zkhip_divide_by_linear_device", "zkhip_kate_division_device",
 ]
 
 
@@ -256,6 +256,17 @@ def linear_combination_device(ctx, polys, coeffs, low=None):
     _check(lib().zkhip_linear_combination_device(ctx.h, C.c_size_t(n), _ptr_array(polys), C.c_size_t(len(polys)), _p(coeffs),
                                                  _p(low_a) if nlow else None, C.c_size_t(nlow), C.c_void_p(out.data_ptr())))
     return out
+
+
+def divide_by_linear_device(ctx, srcs, roots):
+    """-> new polynomials srcs[j] / (X - roots[j]); roots: host (len(srcs), 4) ABI array"""
+    if not srcs:
+        return []
+    n = srcs[0].shape[0]
+    outs = [ctx.empty(n) for _ in srcs]
+    _check(lib().zkhip_divide_by_linear_device(ctx.h, C.c_size_t(n), _ptr_array(srcs), _ptr_array(outs), C.c_size_t(len(srcs)),
+                                               _p(_u64(roots).reshape(len(srcs), 4))))
+    return outs
 
 
 def kate_division_device(ctx, polys, roots):

@@ -10,7 +10,7 @@ from gen_snark_shplonk at /root/reference/src/helpers.rs:233,299 and src/bin/cli
   4 vanishing random poly: 1 MSM_n                                  -> transcript -> y
   5 advice/instance iNTT_n; (A+I+3L+Zp) coset NTT_{e n}; quotient sweep; / (X^n-1); iNTT_{e n};
     q MSM_n over g                                                  -> transcript -> x
-  6 SHPLONK: 2 MSM_n
+  6 SHPLONK multi-open of every queried polynomial: linear combinations, kate divisions, 2 MSM_n
 
 Also computed for real: the theta-compression of the lookup expressions, the permutation and
 lookup grand products (batch inversion + running product; the blinding rows are seeded stand-ins for the rng),
@@ -19,8 +19,8 @@ and the evaluations of every queried polynomial at x * omega^rotation.
 The lookup argument's permuted columns are computed for real too (permute_expression_pair: a sort), which is why
 the synthetic lookup-advice columns draw their values from the table column: the lookup has to be satisfiable.
 
-What is NOT here ("next" rows): witness synthesis, SHPLONK's polynomial construction and the
-real Poseidon/Keccak transcript.  Their outputs are replaced by synthetic columns of the right shape and the transcript by BLAKE2b over the same commitment / evaluation bytes, so
+What is NOT here ("next" rows): witness synthesis and the real Poseidon/Keccak transcript.  The witness is
+replaced by synthetic columns of the right shape and the transcript by BLAKE2b over the same commitment / evaluation bytes, so
 every Fiat-Shamir host round trip of the real prover is still on the critical path.
 
 The schedule is written against a small backend interface so the same code drives the HIP library
@@ -32,8 +32,10 @@ import hashlib
 import numpy as np
 
 from . import evaluator as ev
+from .shplonk import ProverSHPLONK as ShplonkProver
 
 R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+R_INV_256 = pow(1 << 256, -1, R)
 
 
 class CircuitShape:
@@ -195,6 +197,10 @@ class GpuBackend:
         """sum_j coeffs[j] polys[j] - low (coeffs, low: canonical ints)"""
         return self.ffi.linear_combination_device(self.ctx, polys, self.fr_many(coeffs), self.fr_many(low) if low else None)
 
+    def divide_by_linear(self, srcs, roots):
+        """-> new polynomials srcs[j] / (X - roots[j])"""
+        return self.ffi.divide_by_linear_device(self.ctx, srcs, self.fr_many(roots))
+
     def kate_division(self, polys, roots):
         """in place: polys[j] /= prod (X - r), r in roots[j] (canonical ints)"""
         self.ffi.kate_division_device(self.ctx, polys, [self.fr_many(r) for r in roots])
@@ -341,6 +347,12 @@ class ShardedCommit:
         return self.inner.finish(total)
 
 
+def from_mont_host(limbs):
+    """Montgomery limbs (4 x u64) -> canonical int"""
+    v = sum(int(limbs[i]) << (64 * i) for i in range(4))
+    return v * R_INV_256 % R
+
+
 def splitmix64(x):
     """numpy uint64 -> uint64 (the finaliser of oracle/pyref.py's PRNG spec; used for the lookup witness' row choice)"""
     with np.errstate(over="ignore"):
@@ -476,42 +488,48 @@ class Prover:
         pieces = b.split(h, n, dom.quotient_poly_degree)
         t5 = absorb("quotient", b.commit(pieces, lagrange=False))
         x = challenge("x", t1 + t2 + t3 + t4 + t5)
-        # 5b. evaluations at x * omega^rot of everything the verifier queries (create_proof's eval_polynomial calls)
-        queries = {}   # rotation -> list of coefficient-form polynomials
-        def q(poly, rot):
-            queries.setdefault(rot, []).append(poly)
-        for kind, col, rot in sh.queries():
-            if kind == "advice":
-                q(adv_coeff[col], rot)
-            elif kind == "fixed":
-                q(self.fixed_coeff[col], rot)
-        for p_ in self.sigma_coeff:
-            q(p_, 0)
+        # 5b. evaluations at x * omega^rot of everything the verifier queries (create_proof's eval_polynomial calls), in
+        #     upstream's query order: advice, permutation products, lookups, fixed, sigma, vanishing (h, random poly)
+        polys = {}
+        for i_, c_ in enumerate(adv_coeff[:sh.n_advice]):
+            polys[("advice", i_)] = c_
+        for i_, c_ in enumerate(self.fixed_coeff):
+            polys[("fixed", i_)] = c_
+        for i_, c_ in enumerate(self.sigma_coeff):
+            polys[("sigma", i_)] = c_
+        for i_, c_ in enumerate(perm_z):
+            polys[("perm_z", i_)] = c_
+        for i_ in range(L):
+            polys[("lookup_z", i_)], polys[("lookup_a", i_)], polys[("lookup_s", i_)] = look_z[i_], perm_in[i_], perm_tab[i_]
+        polys[("random", 0)] = rand_poly[0]
+        xn = pow(x, n, R)
+        polys[("h", 0)] = b.lincomb(pieces, [pow(xn, i_, R) for i_ in range(len(pieces))], None)   # sum_i x^(n i) h_i(X)
         last_rot = -(bf + 1)
-        for i, z in enumerate(perm_z):
-            q(z, 0); q(z, 1)
-            if i + 1 < len(perm_z):
-                q(z, last_rot)
-        for i in range(L):
-            q(look_z[i], 0); q(look_z[i], 1); q(perm_in[i], 0); q(perm_in[i], -1); q(perm_tab[i], 0)
-        q(rand_poly[0], 0)
-        rots = sorted(queries)
-        flat_polys = [p_ for rot in rots for p_ in queries[rot]]
-        flat_points = [x * pow(self.omega, rot % n, R) % R for rot in rots for _ in queries[rot]]
-        flat = b.eval_polys_at(flat_polys, flat_points)
-        evals, o = [], 0
-        for rot in rots:
-            evals.append((rot, flat[o:o + len(queries[rot])]))
-            o += len(queries[rot])
-        ev_bytes = [e.tobytes() for _, e in evals]
-        trace["evals"] = evals
-        # 6. SHPLONK: two commitments to n-size polynomials (synthetic stand-ins for the quotient polys)
-        w1 = [b.synth(n, base + 400)]
-        t6 = absorb("shplonk_h1", b.commit(w1, lagrange=False))
-        w2 = [b.synth(n, base + 401)]
-        t7 = absorb("shplonk_h2", b.commit(w2, lagrange=False))
-        trace["challenges"] = dict(theta=theta, beta=beta, gamma=gamma, y=y, x=x, v=challenge("v", t1 + t2 + t3 + t4 + t5 + ev_bytes))
+        qlist = [(("advice", col), rot) for kind, col, rot in sh.queries() if kind == "advice"]
+        for i_ in range(len(perm_z)):
+            qlist += [(("perm_z", i_), 0), (("perm_z", i_), 1)]
+        for i_ in reversed(range(len(perm_z) - 1)):
+            qlist.append((("perm_z", i_), last_rot))
+        for i_ in range(L):
+            qlist += [(("lookup_z", i_), 0), (("lookup_a", i_), 0), (("lookup_s", i_), 0), (("lookup_a", i_), -1), (("lookup_z", i_), 1)]
+        qlist += [(("fixed", col), rot) for kind, col, rot in sh.queries() if kind == "fixed"]
+        qlist += [(("sigma", i_), 0) for i_ in range(len(self.sigma_coeff))]
+        qlist += [(("h", 0), 0), (("random", 0), 0)]
+        points = [x * pow(self.omega, rot % n, R) % R for _, rot in qlist]
+        flat = b.eval_polys_at([polys[key] for key, _ in qlist], points)
+        evals = {q_: from_mont_host(flat[i_]) for i_, q_ in enumerate(qlist)}
+        trace["evals"] = [(q_, flat[i_]) for i_, q_ in enumerate(qlist)]
+        trace["eval_ints"] = evals
+        # the transcript receives every evaluation except h's (the verifier recomputes it)
+        tx = t1 + t2 + t3 + t4 + t5 + [flat[i_].tobytes() for i_, q_ in enumerate(qlist) if q_[0][0] != "h"]
+        # 6. SHPLONK multi-open of all of them: two more commitments
+        def write_points(tag, pts):
+            tx.extend(absorb(tag, pts))
+        opening = ShplonkProver(b).create_proof(polys, [(key, pt, evals[(key, rot)]) for (key, rot), pt in zip(qlist, points)],
+                                                lambda tag: challenge(tag, tx), write_points)
+        trace["challenges"] = dict(theta=theta, beta=beta, gamma=gamma, y=y, x=x, shplonk_y=opening["y"], shplonk_v=opening["v"],
+                                   shplonk_u=opening["u"])
+        trace["opening"] = opening
         trace["h_pieces"] = pieces
         trace["n_commitments"] = len(trace["commitments"])
-        assert len(t6 + t7) == 2
         return trace

@@ -8,6 +8,8 @@ multi-open scheme behind gen_snark_shplonk, /root/reference/src/helpers.rs:233,2
   per rotation set i (commitments opened at the same set of points S_i):
       N_i(X) = sum_j y^j (P_ij(X) - R_ij(X)),  R_ij = interpolant of P_ij's evaluations on S_i
       Q_i(X) = N_i(X) / prod_{r in S_i} (X - r)
+             = sum_{r in S_i} [N_i(X) / (X - r)] / prod_{s in S_i, s != r} (r - s)      (N_i vanishes on S_i: partial fractions,
+               so all divisions of all sets are independent and go through one device pass)
   h(X) = sum_i v^i Q_i(X);  commit -> transcript;  u <- transcript
   L(X) = sum_i v^i Z_{T \\ S_i}(u) sum_j y^j (P_ij(X) - R_ij(u)) - Z_T(u) h(X),  T = all points
   h'(X) = L(X) / (X - u) / Z_{T \\ S_0}(u);  commit -> transcript
@@ -19,7 +21,7 @@ R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
 
 
 def _inv(x):
-    return pow(x % R, R - 2, R)
+    return pow(x % R, -1, R)
 
 
 class RotationSet:
@@ -81,7 +83,7 @@ def _eval_small(coeffs, x):
 
 
 class ProverSHPLONK:
-    """create_proof(queries, ...) over a backend offering lincomb / kate_division / commit."""
+    """create_proof(queries, ...) over a backend offering lincomb / divide_by_linear / commit."""
 
     def __init__(self, backend):
         self.b = backend
@@ -94,21 +96,30 @@ class ProverSHPLONK:
         y = squeeze("shplonk_y")
         v = squeeze("shplonk_v")
         sets, super_points = construct_intermediate_sets(queries)
-        lows = []
-        numerators = []
+        numerators, interpolants = [], []
         for rs in sets:
             low = [0] * len(rs.points)
-            coeffs, yp = [], 1
+            coeffs, yp, r_set = [], 1, []
             for key, evals in rs.commitments:
                 r_ij = lagrange_interpolate(rs.points, evals)
+                r_set.append(r_ij)
                 low = [(a + yp * c) % R for a, c in zip(low, r_ij)]
                 coeffs.append(yp)
                 yp = yp * y % R
-            lows.append(low)
+            interpolants.append(r_set)
             numerators.append(b.lincomb([polys[key] for key, _ in rs.commitments], coeffs, low))
-        b.kate_division(numerators, [rs.points for rs in sets])
         vs = [pow(v, i, R) for i in range(len(sets))]
-        h_x = b.lincomb(numerators, vs, None)
+        srcs, roots, weights = [], [], []
+        for i, rs in enumerate(sets):
+            for r in rs.points:
+                den = 1
+                for s_ in rs.points:
+                    if s_ != r:
+                        den = den * (r - s_) % R
+                srcs.append(numerators[i])
+                roots.append(r)
+                weights.append(vs[i] * _inv(den) % R)
+        h_x = b.lincomb(b.divide_by_linear(srcs, roots), weights, None)
         h1 = b.commit([h_x], lagrange=False)
         write_points("shplonk_h1", h1)
         u = squeeze("shplonk_u")
@@ -118,16 +129,16 @@ class ProverSHPLONK:
         cols, coeffs, const = [], [], 0
         for i, rs in enumerate(sets):
             yp = 1
-            for key, evals in rs.commitments:
+            for j, (key, evals) in enumerate(rs.commitments):
                 c = vs[i] * z_diffs[i] % R * yp % R * inv0 % R
                 cols.append(polys[key])
                 coeffs.append(c)
-                const = (const + c * _eval_small(lagrange_interpolate(rs.points, evals), u)) % R
+                const = (const + c * _eval_small(interpolants[i][j], u)) % R
                 yp = yp * y % R
         cols.append(h_x)
         coeffs.append((-zt * inv0) % R)
         l_x = b.lincomb(cols, coeffs, [const])
-        b.kate_division([l_x], [[u]])
+        l_x = b.divide_by_linear([l_x], [u])[0]
         h2 = b.commit([l_x], lagrange=False)
         write_points("shplonk_h2", h2)
         return dict(y=y, v=v, u=u, h1=h1[0], h2=h2[0], h_x=h_x, l_x=l_x, rotation_sets=sets, super_point_set=super_points)

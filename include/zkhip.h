@@ -224,9 +224,13 @@ int  zkhip_grand_products_device(zkhip_ctx* ctx, uint32_t k, const uint64_t beta
  * gen_snark_shplonk at /root/reference/src/helpers.rs:233,299) ----
  * d_out[i] = sum_j coeffs[j] * d_polys[j][i] - (i < nlow ? low[i] : 0): the y- / v-power combinations of the rotation sets'
  * polynomials minus the low-degree interpolant.  d_polys is a HOST array of device polynomials of n coefficients; coeffs
- * (npolys x 4) and low (nlow x 4) are host arrays; d_out must not alias an input. */
+ * (npolys x 4) and low (nlow x 4, nlow <= 8) are host arrays; d_out must not alias an input. */
 int  zkhip_linear_combination_device(zkhip_ctx* ctx, size_t n, const void* const* d_polys, size_t npolys, const uint64_t* coeffs,
                                      const uint64_t* low, size_t nlow, void* d_out);
+/* d_dst[j] = d_src[j] / (X - roots[j]) (remainder dropped, top coefficient zero) for npolys polynomials of n coefficients in
+ * one pass; d_dst[j] may equal d_src[j].  The shplonk prover divides an exact multiple N of prod_t (X - r_t) through
+ * partial fractions: N / prod_t (X - r_t) = sum_t N / (X - r_t) / prod_{s != t} (r_t - r_s), i.e. independent divisions. */
+int  zkhip_divide_by_linear_device(zkhip_ctx* ctx, size_t n, const void* const* d_src, void* const* d_dst, size_t npolys, const uint64_t* roots);
 /* arithmetic::kate_division, in place and batched: polynomial j (n coefficients) is divided by prod_t (X - roots[j][t]) over
  * its nroots[j] roots (roots: host, all polynomials' roots concatenated); remainders are dropped and the vacated top
  * coefficients are zero, i.e. the result is already "resized to n". */

@@ -44,6 +44,9 @@ class OracleBackend:
     def lincomb(self, polys, coeffs, low):
         return zo.linear_combination(polys, self.fr_many(coeffs), self.fr_many(low) if low else None)
 
+    def divide_by_linear(self, srcs, roots):
+        return [zo.kate_division(q, self.fr_many([r])) for q, r in zip(srcs, roots)]
+
     def kate_division(self, polys, roots):
         for q, rs in zip(polys, roots):
             q[:] = zo.kate_division(q, self.fr_many(rs))

@@ -35,7 +35,7 @@ def test_multiopen_golden(zk, oracle):
     ffi, ctx = zk
     zo = oracle
     g, F = _case(zo)
-    b = pv.GpuBackend(ffi, ctx)
+    b = pv.GpuBackend(ctx, ffi)
     b.setup(g["k"], 3, H(g["s"]))
     polys = {i: ctx.to_device(F(c)) for i, c in enumerate(g["polys"])}
     queries = [(i, H(pt), H(e)) for i, pt, e in g["queries"]]
@@ -94,3 +94,18 @@ def test_division_is_exact_on_multiples(zk, oracle):
     d = ctx.to_device(cur)
     ffi.kate_division_device(ctx, [d], [r])
     assert (ctx.to_host(d) == q).all()
+
+
+@pytest.mark.parametrize("n,count", [(100, 1), (1 << 13, 5), (1 << 16, 20)])
+def test_divide_by_linear_vs_oracle(zk, oracle, n, count):
+    """independent divisions into fresh outputs (the partial-fraction form the multi-open uses); count > 16 spans two launches"""
+    ffi, ctx = zk
+    zo = oracle
+    srcs = [zo.synth_raw253(7600 + j, n) for j in range(min(count, 3))]
+    roots = zo.synth_raw253(7700 + n, count)
+    dev = [ctx.to_device(q) for q in srcs]
+    outs = ffi.divide_by_linear_device(ctx, [dev[j % len(dev)] for j in range(count)], roots)
+    for j in range(count):
+        assert (ctx.to_host(outs[j]) == zo.kate_division(srcs[j % len(srcs)], roots[j:j + 1])).all()
+    for q, d in zip(srcs, dev):
+        assert (ctx.to_host(d) == q).all()          # sources untouched
