@@ -190,6 +190,15 @@ class GpuBackend:
         """col[idx] (idx: host int64 array) — witness construction only"""
         return col[self.torch.from_numpy(idx).to(col.device)].contiguous()
 
+    def from_host(self, arr):
+        return self.ctx.to_device(arr)
+
+    def concat(self, cols):
+        return self.torch.cat(cols, dim=0)
+
+    def coeff_to_lagrange(self, cols):
+        self.domain.coeff_to_lagrange_device(cols)
+
     def permute(self, k, bf, cin, ctab, blind_in, blind_tab):
         return self.ffi.permute_expression_pair_device(self.ctx, k, bf, cin, ctab, blind_in, blind_tab)
 
@@ -376,18 +385,24 @@ DELTA = 0x09226B6E22C6F0CA64EC26AAD4C86E715B5F898E5E963F25870E56BBE533E9A2
 class Prover:
     """Keygen-shaped setup once, then prove() = one create_proof-shaped pass (the benchmark step)."""
 
-    def __init__(self, backend, shape, srs_trapdoor=0x1D5C0FFEE):
+    def __init__(self, backend, shape, srs_trapdoor=0x1D5C0FFEE, satisfiable=False):
+        """satisfiable=True (halo2-lib shaped circuits only): selectors, copy constraints and witness are built so that every
+        gate, the permutation and the lookup hold, i.e. prove() returns a proof the verifier accepts.  The arithmetic is the
+        same either way; with False the fixed / sigma columns are uniform synthetic values."""
         self.b, self.shape = backend, shape
+        self.satisfiable = satisfiable
         self.dom = backend.setup(shape.k, shape.degree, srs_trapdoor)
         self.n = 1 << shape.k
         sh, b, n = shape, backend, self.n
         seed = sh.seed * 1000
         # pk: fixed columns and sigma polynomials in Lagrange form, coefficient form and as extended cosets; l cosets
         self.fixed_lagrange = [b.synth(n, seed + 100 + i) for i in range(sh.n_fixed)]
+        self.sigma_lagrange = [b.synth(n, seed + 200 + i) for i in range(len(sh.perm_columns))]
+        if satisfiable:
+            self._build_satisfiable(seed)
         self.fixed_coeff = b.clone(self.fixed_lagrange)
         b.lagrange_to_coeff(self.fixed_coeff)
         self.fixed_cosets = b.coeff_to_extended(self.fixed_coeff)
-        self.sigma_lagrange = [b.synth(n, seed + 200 + i) for i in range(len(sh.perm_columns))]
         self.sigma_coeff = b.clone(self.sigma_lagrange)
         b.lagrange_to_coeff(self.sigma_coeff)
         self.sigma_cosets = b.coeff_to_extended(self.sigma_coeff)
@@ -405,6 +420,73 @@ class Prover:
             self.compress_graphs.append(pair)
         self.omega = pow(ROOT_OF_UNITY, 1 << (28 - sh.k), R)
 
+    def _build_satisfiable(self, seed):
+        """Selectors, copy constraints and the witness recipe of a satisfiable instance (witness-synthesis stand-in):
+          * selector of basic column c = 1 on rows 0, 4, 8, ... (the vertical gate a + b c - d over rows i .. i+3);
+          * copy constraints: usable/8 two-cycles, each tying the `b` input of a gate to a cell of the lookup-advice, constants,
+            instance or another basic column (`c` inputs) — sigma is the identity sigma_j(w^i) = delta^j w^i with those swapped;
+          * witness(): free cells random, copies gathered, lookup inputs drawn from the table, gate outputs computed by the
+            sweep interpreter on the Lagrange domain.
+        Only index arithmetic happens on the host; every field value is produced by the backend."""
+        sh, b, n = self.shape, self.b, self.n
+        assert sh.n_basic and sh.gates and len(sh.gates) == sh.n_basic, "satisfiable instances need the halo2-lib gate shape"
+        u = n - (sh.blinding_factors + 1)
+        one = fr_from_int_host(1)
+        gate_rows = np.arange(0, u - 3, 4)
+        sel = np.zeros((n, 4), dtype=np.uint64)
+        sel[gate_rows] = one
+        out_mask = np.zeros((n, 4), dtype=np.uint64)
+        out_mask[gate_rows + 3] = one
+        for c in range(sh.n_basic):
+            self.fixed_lagrange[c] = b.from_host(sel)
+        self._out_mask = b.from_host(out_mask)
+        # copy pairs (global cell id = perm-column index * n + row)
+        P = len(sh.perm_columns)
+        col_of = {pc: j for j, pc in enumerate(sh.perm_columns)}
+        rng = np.random.default_rng(seed)
+        partner_cols = [col_of[("advice", sh.n_basic + l)] for l in range(sh.n_lookup)] + [col_of[("fixed", sh.n_basic)]] \
+            + [col_of[("instance", i)] for i in range(sh.n_instance)] + [col_of[("advice", c)] for c in range(sh.n_basic)]
+        m = max(1, u // 8)
+        src_rows = rng.permutation(gate_rows)[:m] + 1                      # `b` inputs
+        m = len(src_rows)
+        dst_rows = rng.permutation(gate_rows)[:m] + 2                      # `c` inputs when the partner is a basic column
+        other_rows = rng.permutation(u)[:m]
+        pairs = []
+        for t in range(m):
+            pcol = partner_cols[t % len(partner_cols)]
+            kind, idx = sh.perm_columns[pcol]
+            prow = dst_rows[t] if (kind == "advice" and idx < sh.n_basic) else other_rows[t]
+            pairs.append((col_of[("advice", t % sh.n_basic)] * n + int(src_rows[t]), pcol * n + int(prow)))
+        perm = np.arange(P * n, dtype=np.int64)
+        value_src = np.arange(P * n, dtype=np.int64)
+        for p_, q_ in pairs:
+            perm[p_], perm[q_] = q_, p_
+            value_src[p_] = q_
+        self._value_src = value_src
+        self.copy_pairs = pairs
+        # identity permutation values delta^j * w^i, then the swaps
+        xpoly = np.zeros((n, 4), dtype=np.uint64)
+        xpoly[1] = one
+        omega_col = [b.from_host(xpoly)]
+        b.coeff_to_lagrange(omega_col)
+        ident = b.concat([b.lincomb(omega_col, [pow(DELTA, j, R)], None) for j in range(P)])
+        sig = b.gather(ident, perm)
+        self.sigma_lagrange = [sig[j * n:(j + 1) * n] for j in range(P)]
+        if hasattr(self.sigma_lagrange[0], "contiguous"):
+            self.sigma_lagrange = [c.contiguous() for c in self.sigma_lagrange]
+        else:
+            self.sigma_lagrange = [np.ascontiguousarray(c) for c in self.sigma_lagrange]
+        # out = mask * (a(-3) + a(-2) a(-1)) + (1 - mask) * a(0), per basic column; the mask is appended to the fixed columns
+        self._fill_graphs = []
+        A = lambda c, r: ("advice", c, r)
+        for c in range(sh.n_basic):
+            mk = ("fixed", sh.n_fixed, 0)
+            e = ("sum", ("prod", mk, ("sum", A(c, -3), ("prod", A(c, -2), A(c, -1)))), ("prod", ("sum", ("const", 1), ("neg", mk)), A(c, 0)))
+            g = ev.GraphEvaluator()
+            r_ = g.add_expression(e)
+            g.add_calculation(ev.OP_HORNER, [(ev.VS_CONSTANT, 0, 0), (ev.VS_THETA, 0, 0), r_])
+            self._fill_graphs.append(g)
+
     def witness(self, proof_seed):
         """Synthetic advice / instance tables in Lagrange form, resident on the device (untimed).  Lookup-advice columns
         take their values from the table column (about two occurrences of each of the first n/2 table rows), so the
@@ -415,19 +497,29 @@ class Prover:
         for j in range(sh.n_lookup):
             idx = (splitmix64(np.arange(n, dtype=np.uint64) + np.uint64(((base + 20 + j) << 32) & 0xFFFFFFFFFFFFFFFF)) % np.uint64(n // 2)).astype(np.int64)
             advice.append(self.b.gather(self.fixed_lagrange[sh.n_fixed - 1], idx))
-        return dict(advice=advice,
-                    instance=[self.b.synth(n, base + 50 + i) for i in range(sh.n_instance)],
-                    base=base)
+        instance = [self.b.synth(n, base + 50 + i) for i in range(sh.n_instance)]
+        if self.satisfiable:
+            b = self.b
+            cols = {"advice": advice, "fixed": self.fixed_lagrange, "instance": instance}
+            stack = b.concat([cols[t][i] for t, i in sh.perm_columns])
+            for c in range(sh.n_basic):       # copies: only basic-advice cells take their partner's value
+                j = sh.perm_columns.index(("advice", c))
+                advice[c] = b.gather(stack, self._value_src[j * n:(j + 1) * n])
+            for c in range(sh.n_basic):       # gate outputs
+                advice[c] = b.compress(self._fill_graphs[c], self.fixed_lagrange + [self._out_mask], advice, instance, 0, sh.k)
+            return dict(advice=advice, instance=instance, base=base)
+        return dict(advice=advice, instance=instance, base=base)
 
     def prove(self, wit):
         """One pass.  Returns the transcript trace: every commitment's bytes and the challenges."""
         sh, b, n, dom = self.shape, self.b, self.n, self.dom
         base = wit["base"]
         L, Zp = len(sh.lookups), sh.n_perm_sets
-        trace = {"commitments": [], "challenges": {}}
+        trace = {"commitments": [], "challenges": {}, "points": {}}
 
         def absorb(tag, pts):
             byts = [p[1] for p in pts]
+            trace["points"].setdefault(tag, []).extend(p[0] for p in pts)
             trace["commitments"] += [(tag, x.hex()) for x in byts]
             return byts
 
@@ -520,6 +612,7 @@ class Prover:
         evals = {q_: from_mont_host(flat[i_]) for i_, q_ in enumerate(qlist)}
         trace["evals"] = [(q_, flat[i_]) for i_, q_ in enumerate(qlist)]
         trace["eval_ints"] = evals
+        trace["query_list"] = qlist
         # the transcript receives every evaluation except h's (the verifier recomputes it)
         tx = t1 + t2 + t3 + t4 + t5 + [flat[i_].tobytes() for i_, q_ in enumerate(qlist) if q_[0][0] != "h"]
         # 6. SHPLONK multi-open of all of them: two more commitments

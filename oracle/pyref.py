@@ -583,3 +583,120 @@ def shplonk_verify(commitments, rotation_sets, super_points, y, v, u, h1, h2, s)
     acc = jac_add(acc, scalar_mul((-z_0) % R, from_affine(h1)))
     acc = jac_add(acc, scalar_mul(u, from_affine(h2)))
     return to_affine(acc) == to_affine(scalar_mul(s % R, from_affine(h2)))
+
+
+# ----------------------------------------------------------------------------- PLONK verifier (algebraic)
+# halo2_proofs src/plonk/verifier.rs verify_proof, permutation/verifier.rs, lookup/verifier.rs, vanishing/verifier.rs
+# [UPSTREAM-RECALL], restated on integers.  The final pairing is replaced by the same equation under the SRS trapdoor
+# (shplonk_verify).  Fiat-Shamir is NOT re-derived here: the challenges are inputs (the schedule uses a stand-in hash).
+def eval_expr_at(e, get):
+    """expression tree -> value, get(kind, column, rotation) supplying the opened evaluations"""
+    k = e[0]
+    if k == "const":
+        return e[1] % R
+    if k in ("fixed", "advice", "instance"):
+        return get(k, e[1], e[2])
+    if k == "neg":
+        return (-eval_expr_at(e[1], get)) % R
+    if k == "sum":
+        return (eval_expr_at(e[1], get) + eval_expr_at(e[2], get)) % R
+    if k == "prod":
+        return eval_expr_at(e[1], get) * eval_expr_at(e[2], get) % R
+    if k == "scaled":
+        return eval_expr_at(e[1], get) * e[2] % R
+    raise ValueError(k)
+
+
+def lagrange_basis_at(k, rows, x):
+    """l_i(x) for i in rows: (x^n - 1) / n * w^i / (x - w^i)"""
+    n = 1 << k
+    w = omega_for(k)
+    c = (pow(x, n, R) - 1) * pow(n, R - 2, R) % R
+    return [c * pow(w, i % n, R) % R * pow((x - pow(w, i % n, R)) % R, R - 2, R) % R for i in rows]
+
+
+def plonk_expected_h(vk, instance_cols, evals, ch):
+    """The verifier's value of the quotient at x from the opened evaluations.
+    vk: dict(k, degree, blinding_factors, gates, lookups, perm_columns); instance_cols: full Lagrange columns (ints);
+    evals: ((kind, index), rotation) -> int with kinds advice, fixed, sigma, perm_z, lookup_z, lookup_a, lookup_s;
+    ch: theta, beta, gamma, y, x."""
+    k, bf = vk["k"], vk["blinding_factors"]
+    n = 1 << k
+    x, y, beta, gamma, theta = ch["x"], ch["y"], ch["beta"], ch["gamma"], ch["theta"]
+    w = omega_for(k)
+    inst_cache = {}
+
+    def get(kind, col, rot):
+        if kind == "instance":      # QUERY_INSTANCE = false for KZG: the verifier evaluates the instance polynomial itself
+            if (col, rot) not in inst_cache:
+                pt = x * pow(w, rot % n, R) % R
+                ls = lagrange_basis_at(k, range(n), pt)
+                inst_cache[(col, rot)] = sum(a * b for a, b in zip(instance_cols[col], ls)) % R
+            return inst_cache[(col, rot)]
+        return evals[((kind, col), rot)]
+
+    ls = lagrange_basis_at(k, range(-(bf + 1), 1), x)       # rows n-bf-1 .. n-1, 0
+    l_last, l_blind, l_0 = ls[0], sum(ls[1:bf + 1]) % R, ls[bf + 1]
+    l_active = (1 - l_last - l_blind) % R
+    last_rot = -(bf + 1)
+    terms = [eval_expr_at(g, get) for g in vk["gates"]]
+    chunk = vk["degree"] - 2
+    cols = vk["perm_columns"]
+    nsets = -(-len(cols) // chunk) if cols else 0
+    Z = lambda s, rot: evals[(("perm_z", s), rot)]
+    if nsets:
+        terms.append(l_0 * (1 - Z(0, 0)) % R)
+        terms.append(l_last * (Z(nsets - 1, 0) ** 2 - Z(nsets - 1, 0)) % R)
+        for s in range(1, nsets):
+            terms.append(l_0 * (Z(s, 0) - Z(s - 1, last_rot)) % R)
+        cur = beta * x % R
+        for s in range(nsets):
+            left, right = Z(s, 1), Z(s, 0)
+            for j in range(s * chunk, min(len(cols), (s + 1) * chunk)):
+                v = get(cols[j][0], cols[j][1], 0)
+                left = left * (v + beta * evals[(("sigma", j), 0)] + gamma) % R
+                right = right * (v + cur + gamma) % R
+                cur = cur * DELTA % R
+            terms.append(l_active * (left - right) % R)
+    for li, (inputs, tables) in enumerate(vk["lookups"]):
+        z0, z1 = evals[(("lookup_z", li), 0)], evals[(("lookup_z", li), 1)]
+        a0, am1, s0 = evals[(("lookup_a", li), 0)], evals[(("lookup_a", li), -1)], evals[(("lookup_s", li), 0)]
+
+        def compress(exprs):
+            acc = 0
+            for ex in exprs:
+                acc = (acc * theta + eval_expr_at(ex, get)) % R
+            return acc
+
+        terms.append(l_0 * (1 - z0) % R)
+        terms.append(l_last * (z0 * z0 - z0) % R)
+        terms.append(l_active * (z1 * (a0 + beta) % R * (s0 + gamma) - z0 * (compress(inputs) + beta) % R * (compress(tables) + gamma)) % R)
+        terms.append(l_0 * (a0 - s0) % R)
+        terms.append(l_active * (a0 - s0) % R * (a0 - am1) % R)
+    acc = 0
+    for t in terms:
+        acc = (acc * y + t) % R
+    return acc * pow((pow(x, n, R) - 1) % R, R - 2, R) % R
+
+
+def plonk_verify(vk, instance_cols, commitments, h_pieces, evals, query_list, ch, h1, h2, s):
+    """commitments: key -> affine point for every queried polynomial except h; h_pieces: the quotient's piece commitments;
+    query_list: [(key, rotation)] in the prover's query order (h included); True iff the multi-open verifies with h's
+    evaluation REPLACED by the value the constraint system dictates."""
+    k = vk["k"]
+    n = 1 << k
+    x = ch["x"]
+    w = omega_for(k)
+    expected_h = plonk_expected_h(vk, instance_cols, evals, ch)
+    xn = pow(x, n, R)
+    hc = INF
+    for piece in reversed(h_pieces):
+        hc = jac_add(scalar_mul(xn, hc), from_affine(piece))
+    coms = dict(commitments)
+    coms[("h", 0)] = to_affine(hc)
+    queries = []
+    for key, rot in query_list:
+        ev = expected_h if key == ("h", 0) else evals[(key, rot)]
+        queries.append((key, x * pow(w, rot % n, R) % R, ev))
+    rs, sp = construct_intermediate_sets(queries)
+    return shplonk_verify(coms, rs, sp, ch["shplonk_y"], ch["shplonk_v"], ch["shplonk_u"], h1, h2, s)

@@ -41,6 +41,16 @@ class OracleBackend:
     def permute(self, k, bf, cin, ctab, blind_in, blind_tab):
         return zo.permute_expression_pair(k, bf, cin, ctab, blind_in, blind_tab)
 
+    def from_host(self, arr):
+        return np.array(arr, dtype=np.uint64)
+
+    def concat(self, cols):
+        return np.concatenate(cols, axis=0)
+
+    def coeff_to_lagrange(self, cols):
+        for c in cols:
+            c[:] = self.domain.coeff_to_lagrange(c, self.threads)
+
     def lincomb(self, polys, coeffs, low):
         return zo.linear_combination(polys, self.fr_many(coeffs), self.fr_many(low) if low else None)
 

@@ -1,0 +1,42 @@
+"""Runs oracle/pyref.py's algebraic PLONK + SHPLONK verifier over a Prover trace (TEST INFRASTRUCTURE)."""
+import numpy as np
+
+import pyref as P
+import zkoracle_py as zo
+
+
+def _pts(arrs):
+    return [zo.affine_to_ints(np.asarray(a, dtype=np.uint64).reshape(1, 8))[0] for a in arrs]
+
+
+def verify_trace(prover, wit, trace, srs_trapdoor=0x1D5C0FFEE, tamper=None):
+    """True iff the proof in `trace` verifies.  The vk part (fixed / sigma commitments) is committed here with the prover's
+    own backend, as keygen would.  tamper(evals, commitments) may corrupt the proof first."""
+    sh, b = prover.shape, prover.b
+    vk = dict(k=sh.k, degree=sh.degree, blinding_factors=sh.blinding_factors, gates=sh.gates, lookups=sh.lookups,
+              perm_columns=sh.perm_columns)
+    pts = trace["points"]
+    coms = {}
+    for i, p_ in enumerate(_pts(pts["advice"])):
+        coms[("advice", i)] = p_
+    L = len(sh.lookups)
+    lp = _pts(pts.get("lookup_permuted", []))
+    for i in range(L):
+        coms[("lookup_a", i)], coms[("lookup_s", i)] = lp[i], lp[L + i]
+    prods = _pts(pts["products"])
+    for i in range(sh.n_perm_sets):
+        coms[("perm_z", i)] = prods[i]
+    for i in range(L):
+        coms[("lookup_z", i)] = prods[sh.n_perm_sets + i]
+    coms[("random", 0)] = _pts(pts["random_poly"])[0]
+    for i, c in enumerate(b.commit(prover.fixed_coeff, lagrange=False)):
+        coms[("fixed", i)] = _pts([c[0]])[0]
+    for i, c in enumerate(b.commit(prover.sigma_coeff, lagrange=False)):
+        coms[("sigma", i)] = _pts([c[0]])[0]
+    h_pieces = _pts(pts["quotient"])
+    evals = {q: v for q, v in trace["eval_ints"].items() if q[0] != ("h", 0)}
+    instance = [zo.fr_arr_to_ints(b.to_host(c)) for c in wit["instance"]]
+    h1, h2 = _pts(pts["shplonk_h1"])[0], _pts(pts["shplonk_h2"])[0]
+    if tamper:
+        tamper(evals, coms, instance)
+    return P.plonk_verify(vk, instance, coms, h_pieces, evals, trace["query_list"], trace["challenges"], h1, h2, srs_trapdoor)
