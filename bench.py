@@ -51,7 +51,7 @@ def cpu_baseline(shape, threads):
     import halo2_zkcert_amd.prover as pv
     from oracle_backend import OracleBackend
 
-    p = pv.Prover(OracleBackend(threads), shape)
+    p = pv.Prover(OracleBackend(threads), shape, satisfiable=shape.name.startswith("rsa"))
     w = p.witness(0)
     t0 = time.perf_counter()
     p.prove(w)
@@ -94,7 +94,7 @@ def main():
     shard = world > 1 and args.shard_msm
     if shard:
         backend = pv.ShardedCommit(backend, rank, world, dist)
-    prover = pv.Prover(backend, shape)
+    prover = pv.Prover(backend, shape, satisfiable=args.shape == "rsa")   # rsa shape: a satisfiable instance, i.e. a valid proof
     wit = prover.witness(0 if (shard or world == 1) else rank)   # one independent proof per rank unless sharding one
     n = 1 << shape.k
     counts = shape.counts(prover.dom.extended_k)
@@ -150,7 +150,7 @@ def main():
                                    f"{counts['intt_n']} iNTT_2^{shape.k} + {counts['ntt_ext']} NTT_2^{prover.dom.extended_k} + "
                                    f"1 iNTT_2^{prover.dom.extended_k} + 1 sweep over 2^{prover.dom.extended_k} rows + lookup compression, "
                                    f"{shape.n_perm_sets}+{len(shape.lookups)} grand products, evaluations at x; "
-                                   "lookup permute (sort) and SHPLONK multi-open computed; uniform synthetic witness (lookup inputs drawn from the table); "
+                                   "lookup permute (sort) and SHPLONK multi-open computed; " + ("synthetic SATISFIABLE instance (gates, copy constraints, lookup hold: the output is a valid proof, see tests/test_gpu_prover.py::test_rsa_k17_valid_proof); " if args.shape == "rsa" else "uniform synthetic witness; ") +
                                    "BLAKE2b stand-in transcript",
                        "k": shape.k, "advice": shape.n_advice, "fixed": shape.n_fixed, "lookups": len(shape.lookups),
                        "perm_columns": len(shape.perm_columns), "degree": shape.degree,
