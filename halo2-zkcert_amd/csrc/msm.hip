@@ -460,22 +460,117 @@ __global__ void __launch_bounds__(256) k_accum_jac(const uint32_t* in_all, size_
     g1x_store_raw(out_all + ((size_t)col * out_stride + t) * 32, acc);
 }
 
-__device__ __forceinline__ void block_tree_sum(g1x* sh, uint32_t t, uint32_t nthreads, const g1x& mine) {
-    sh[t] = mine;
+// ---- quad-cooperative XYZZ arithmetic for the latency-bound tail -------------------------------------------------
+// The bucket reduction is a chain of ~45 dependent point operations executed by a few thousand threads: the chip idles
+// and the chain's length is what costs.  Here FOUR adjacent lanes hold the same operands and each computes one of the
+// up-to-four independent field products of a dependency level (operands picked by lane & 3, ONE shared instruction
+// stream, results exchanged with DPP quad broadcasts): an addition is 4 product levels instead of 14 products, a doubling
+// 3 instead of 9.  Every lane of the quad returns the full result.
+// The broadcast is written as inline assembly: with the update_dpp builtin the compiler folds the DPP move into the consuming
+// subtraction and (observed on ROCm 7.2, gfx950) produces a wrong doubling.  One s_nop covers the VALU-write -> DPP-read hazard.
+template <int K, int B>
+__device__ __forceinline__ el<Fq, B> quad_bcast(const el<Fq, B>& a) {
+    static_assert(K >= 0 && K < 4, "quad lane");
+    el<Fq, B> r;
+#define ZK_QB(o, i) "v_mov_b32_dpp %" #o ", %" #i " quad_perm:[%18,%18,%18,%18] row_mask:0xf bank_mask:0xf\n"
+    asm volatile("s_nop 1\n" ZK_QB(0, 9) ZK_QB(1, 10) ZK_QB(2, 11) ZK_QB(3, 12) ZK_QB(4, 13) ZK_QB(5, 14) ZK_QB(6, 15) ZK_QB(7, 16) ZK_QB(8, 17)
+                 : "=&v"(r.v.l[0]), "=&v"(r.v.l[1]), "=&v"(r.v.l[2]), "=&v"(r.v.l[3]), "=&v"(r.v.l[4]), "=&v"(r.v.l[5]), "=&v"(r.v.l[6]),
+                   "=&v"(r.v.l[7]), "=&v"(r.v.l[8])
+                 : "v"(a.v.l[0]), "v"(a.v.l[1]), "v"(a.v.l[2]), "v"(a.v.l[3]), "v"(a.v.l[4]), "v"(a.v.l[5]), "v"(a.v.l[6]), "v"(a.v.l[7]),
+                   "v"(a.v.l[8]), "n"(K));
+#undef ZK_QB
+    return r;
+}
+template <int B>
+__device__ __forceinline__ el<Fq, B> quad_pick(uint32_t q, const el<Fq, B>& a0, const el<Fq, B>& a1, const el<Fq, B>& a2, const el<Fq, B>& a3) {
+    el<Fq, B> r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        uint32_t lo = (q & 1) ? a1.v.l[i] : a0.v.l[i];
+        uint32_t hi = (q & 1) ? a3.v.l[i] : a2.v.l[i];
+        r.v.l[i] = (q & 2) ? hi : lo;
+    }
+    return r;
+}
+__device__ inline g1x g1x_double_q4(const g1x& p, uint32_t q) {
+    if (g1x_is_id(p)) return p;
+    using A1 = el<Fq, 12 * U>;
+    auto u = mul_small<2>(p.y);                                   // 12 p
+    // level 1: v = u^2 | xx = x^2
+    A1 a = quad_pick<12 * U>(q, A1(u), A1(p.x), A1(u), A1(p.x));
+    auto r1 = a * a;
+    auto v = quad_bcast<0>(r1), xx = quad_bcast<1>(r1);
+    auto m = mul_small<3>(xx);
+    // level 2: w = u v | s = x v | mm = m^2 | zz3 = v zz
+    using B2 = decltype(m);
+    auto r2 = quad_pick<12 * U>(q, A1(u), A1(p.x), A1(m), A1(v)) * quad_pick(q, B2(v), B2(v), m, B2(p.zz));
+    auto w = quad_bcast<0>(r2), s_ = quad_bcast<1>(r2), mm = quad_bcast<2>(r2), zz3 = quad_bcast<3>(r2);
+    auto x3 = mm - mul_small<2>(s_);
+    // level 3: t = m (s - x3) | wy = w y | zzz3 = w zzz
+    auto d = s_ - x3;
+    using B3 = decltype(d);
+    using A3 = decltype(m);
+    auto r3 = quad_pick(q, m, A3(w), A3(w), A3(w)) * quad_pick(q, d, B3(p.y), B3(p.zzz), B3(p.zzz));
+    g1x o;
+    o.x = x3;
+    o.y = quad_bcast<0>(r3) - quad_bcast<1>(r3);
+    o.zz = zz3;
+    o.zzz = quad_bcast<2>(r3);
+    return o;
+}
+__device__ inline g1x g1x_add_q4(const g1x& p, const g1x& g, uint32_t q) {
+    if (g1x_is_id(p)) return g;
+    if (g1x_is_id(g)) return p;
+    // level 1: u2 = g.x p.zz | s2 = g.y p.zzz | u1 = p.x g.zz | s1 = p.y g.zzz
+    using A1 = el<Fq, XBX>;
+    auto r1 = quad_pick<XBX>(q, g.x, A1(g.y), p.x, A1(p.y)) * quad_pick(q, p.zz, p.zzz, g.zz, g.zzz);
+    auto u2 = quad_bcast<0>(r1), s2 = quad_bcast<1>(r1), u1 = quad_bcast<2>(r1), s1 = quad_bcast<3>(r1);
+    auto pp_ = u2 - u1;
+    auto r = s2 - s1;
+    if (is_zero(pp_)) {
+        if (is_zero(r)) return g1x_double_q4(p, q);
+        return g1x_identity();
+    }
+    // level 2: pp = pp_^2 | rr = r^2 | zz12 = p.zz g.zz | zzz12 = p.zzz g.zzz
+    using A2 = decltype(pp_);
+    auto r2 = quad_pick(q, pp_, r, A2(p.zz), A2(p.zzz)) * quad_pick(q, pp_, r, A2(g.zz), A2(g.zzz));
+    auto pp = quad_bcast<0>(r2), rr = quad_bcast<1>(r2), zz12 = quad_bcast<2>(r2), zzz12 = quad_bcast<3>(r2);
+    // level 3: ppp = pp_ pp | q_ = u1 pp | zz3 = zz12 pp
+    auto r3 = quad_pick(q, pp_, A2(u1), A2(zz12), A2(zz12)) * pp;
+    auto ppp = quad_bcast<0>(r3), q_ = quad_bcast<1>(r3), zz3 = quad_bcast<2>(r3);
+    auto x3 = rr - (ppp + mul_small<2>(q_));
+    // level 4: t = s1 ppp | zzz3 = zzz12 ppp | y' = r (q_ - x3)
+    auto d = q_ - x3;
+    using B4 = decltype(d);
+    auto r4 = quad_pick(q, A2(s1), A2(zzz12), r, r) * quad_pick(q, B4(ppp), B4(ppp), d, d);
+    g1x o;
+    o.x = x3;
+    o.y = quad_bcast<2>(r4) - quad_bcast<0>(r4);
+    o.zz = zz3;
+    o.zzz = quad_bcast<1>(r4);
+    return o;
+}
+
+// tree over the block's 64 quads (256 lanes): sh[0] = sum
+__device__ __forceinline__ void block_tree_sum_q4(g1x* sh, uint32_t lt, uint32_t q, const g1x& mine) {
+    if (q == 0) sh[lt] = mine;
     __syncthreads();
-    for (uint32_t d = nthreads >> 1; d >= 1; d >>= 1) {
-        if (t < d) sh[t] = g1x_add(sh[t], sh[t + d]);
+    for (uint32_t d = 32; d >= 1; d >>= 1) {
+        if (lt < d) {
+            g1x r = g1x_add_q4(sh[lt], sh[lt + d], q);
+            if (q == 0) sh[lt] = r;
+        }
         __syncthreads();
     }
 }
-// sum_{b} (b+1) * S_b over CH consecutive buckets per thread (running-sum trick + base * run), then a
-// tree over the block's 256 threads: one partial sum per block.
+// sum_{b} (b+1) * S_b over CH consecutive buckets per quad (running-sum trick + base * run), then a
+// tree over the block's 64 quads: one partial sum per block.
 __global__ void __launch_bounds__(256) k_bucket_chunks(const uint32_t* part_all, size_t part_stride, const uint32_t* cnt_all,
                                                        const uint32_t* off_all, uint32_t B, uint32_t CH, uint32_t* out_all,
                                                        uint32_t nchunks) {
-    __shared__ g1x sh[256];
-    uint32_t col = blockIdx.y;
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ g1x sh[64];
+    const uint32_t col = blockIdx.y, q = threadIdx.x & 3, lt = threadIdx.x >> 2;
+    const uint32_t t = blockIdx.x * 64 + lt;
     g1x acc = g1x_identity();
     if (t < nchunks) {
         const uint32_t* cnt = cnt_all + (size_t)col * B;
@@ -485,31 +580,54 @@ __global__ void __launch_bounds__(256) k_bucket_chunks(const uint32_t* part_all,
         g1x run = g1x_identity();
         for (int j = (int)CH - 1; j >= 0; --j) {
             uint32_t b = base + (uint32_t)j;
-            if (b < B && cnt[b]) run = g1x_add(run, g1x_load_raw(part + (size_t)off[b] * 32));
-            acc = g1x_add(acc, run);
+            if (b < B && cnt[b]) run = g1x_add_q4(run, g1x_load_raw(part + (size_t)off[b] * 32), q);
+            acc = g1x_add_q4(acc, run, q);
         }
         // + base * run
         g1x d = run;
         uint32_t m = base;
         while (m) {
-            if (m & 1) acc = g1x_add(acc, d);
+            if (m & 1) acc = g1x_add_q4(acc, d, q);
             m >>= 1;
-            if (m) d = g1x_double(d);
+            if (m) d = g1x_double_q4(d, q);
         }
     }
-    block_tree_sum(sh, threadIdx.x, 256, acc);
+    block_tree_sum_q4(sh, lt, q, acc);
     if (threadIdx.x == 0) g1x_store_raw(out_all + ((size_t)col * gridDim.x + blockIdx.x) * 32, sh[0]);
 }
 
-__global__ void __launch_bounds__(64) k_final_sum(const uint32_t* in_all, uint32_t count, uint32_t* out_all) {
+__global__ void __launch_bounds__(256) k_final_sum(const uint32_t* in_all, uint32_t count, uint32_t* out_all) {
     __shared__ g1x sh[64];
-    uint32_t col = blockIdx.x, t = threadIdx.x;
+    const uint32_t col = blockIdx.x, q = threadIdx.x & 3, lt = threadIdx.x >> 2;
     const uint32_t* in = in_all + (size_t)col * count * 32;
     g1x acc = g1x_identity();
-    for (uint32_t i = t; i < count; i += 64) acc = g1x_add(acc, g1x_load_raw(in + (size_t)i * 32));
-    block_tree_sum(sh, t, 64, acc);
-    if (t == 0) g1j_store_abi(out_all + (size_t)col * 24, g1x_to_jacobian(sh[0]));   // the ABI result: halo2curves G1 (R = 2^256)
+    for (uint32_t i = lt; i < count; i += 64) acc = g1x_add_q4(acc, g1x_load_raw(in + (size_t)i * 32), q);
+    block_tree_sum_q4(sh, lt, q, acc);
+    if (threadIdx.x == 0) g1j_store_abi(out_all + (size_t)col * 24, g1x_to_jacobian(sh[0]));   // the ABI result: halo2curves G1 (R = 2^256)
 }
+// self-check of the quad-cooperative operations against the one-lane ones (tests/test_gpu_msm.py): for pair i of XYZZ points
+// (a, b): out[i] = {a + b, 2a} by g1x_add / g1x_double and by the quad versions, 4 x 128 B
+__global__ void k_quad_selfcheck(const uint32_t* pts, uint32_t npairs, uint32_t* out) {
+    uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t i = lane >> 2, q = lane & 3;
+    if (i >= npairs) return;
+    g1x a = g1x_load_raw(pts + (size_t)i * 64), b = g1x_load_raw(pts + (size_t)i * 64 + 32);
+    g1x s4 = g1x_add_q4(a, b, q), d4 = g1x_double_q4(a, q);
+    if (q == 0) {
+        g1x_store_raw(out + (size_t)i * 128, g1x_add(a, b));
+        g1x_store_raw(out + (size_t)i * 128 + 32, g1x_double(a));
+    }
+    if (q == (i & 3)) {   // any lane of the quad holds the result
+        g1x_store_raw(out + (size_t)i * 128 + 64, s4);
+        g1x_store_raw(out + (size_t)i * 128 + 96, d4);
+    }
+}
+extern "C" int zkt_quad_selfcheck(zkhip_ctx* ctx, const void* d_pts, uint32_t npairs, void* d_out) {
+    hipLaunchKernelGGL(k_quad_selfcheck, dim3(div_up((size_t)npairs * 4, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)d_pts, npairs, (uint32_t*)d_out);
+    ZK_LAUNCH_CHECK();
+    return ZKHIP_OK;
+}
+
 __global__ void k_set_identity(uint32_t* out_all, uint32_t ncols) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < ncols) g1j_store_abi(out_all + (size_t)t * 24, g1j_identity());
@@ -573,7 +691,7 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
     ZK_TRY(ctx->get_scratch("msm_pB", ncols * pstride0 * 128, &d_pB));
     uint32_t CH = B > 8192 ? B / 8192 : 1;
     uint32_t nchunks = (B + CH - 1) / CH;
-    uint32_t nchunk_blocks = div_up(nchunks, 256);
+    uint32_t nchunk_blocks = div_up(nchunks, 64);   // 64 quads per block
     ZK_TRY(ctx->get_scratch("msm_chunks", ncols * (size_t)nchunk_blocks * 128, &d_chunks));
 
     std::vector<const void*> h_ptrs(2 * ncols);
@@ -652,7 +770,7 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
     { ProfScope ps(ctx, "msm_tail");
     hipLaunchKernelGGL(k_bucket_chunks, dim3(nchunk_blocks, (unsigned)ncols), dim3(256), 0, st, (const uint32_t*)cur_p, pstride0,
                        cur_cnt, cur_off, B, CH, (uint32_t*)d_chunks, nchunks);
-    hipLaunchKernelGGL(k_final_sum, dim3((unsigned)ncols), dim3(64), 0, st, (const uint32_t*)d_chunks, nchunk_blocks, (uint32_t*)d_out); }
+    hipLaunchKernelGGL(k_final_sum, dim3((unsigned)ncols), dim3(256), 0, st, (const uint32_t*)d_chunks, nchunk_blocks, (uint32_t*)d_out); }
     ZK_LAUNCH_CHECK();
     return ZKHIP_OK;
 }

@@ -229,11 +229,16 @@ class GpuBackend:
         aff = self.ffi.g1_batch_to_affine(jac_rows)
         return [(aff[j], self.ffi.g1_to_bytes(aff[j])) for j in range(aff.shape[0])]
 
+    def commit_begin(self, cols, lagrange):
+        """launches the MSMs of a batch; commit_end waits for them.  Host work placed between the two overlaps the GPU."""
+        return self.partial_commit(cols, lagrange, 0, cols[0].shape[0]) if cols else None
+
+    def commit_end(self, token):
+        return self.finish(self.ctx.to_host(token)) if token is not None else []
+
     def commit(self, cols, lagrange):
         """one host round trip per batch (the Fiat-Shamir sync point)"""
-        if not cols:
-            return []
-        return self.finish(self.ctx.to_host(self.partial_commit(cols, lagrange, 0, cols[0].shape[0])))
+        return self.commit_end(self.commit_begin(cols, lagrange))
 
     def lagrange_to_coeff(self, cols):
         self.domain.lagrange_to_coeff_device(cols)
@@ -337,21 +342,29 @@ class ShardedCommit:
         return getattr(self.inner, name)
 
     def commit(self, cols, lagrange):
+        return self.commit_end(self.commit_begin(cols, lagrange))
+
+    def commit_begin(self, cols, lagrange):
         if not cols:
+            return None
+        n = cols[0].shape[0]
+        lo, hi = self.rank * n // self.world, (self.rank + 1) * n // self.world
+        return (self.inner.partial_commit(cols, lagrange, lo, hi - lo), len(cols))
+
+    def commit_end(self, token):
+        if token is None:
             return []
         import torch
 
-        n = cols[0].shape[0]
-        lo, hi = self.rank * n // self.world, (self.rank + 1) * n // self.world
-        part = self.inner.partial_commit(cols, lagrange, lo, hi - lo)
+        part, ncols = token
         if not torch.is_tensor(part):
             part = torch.from_numpy(np.ascontiguousarray(part).view(np.int64))
         outs = [torch.empty_like(part) for _ in range(self.world)]
         self.dist.all_gather(outs, part)
-        parts = [o.cpu().numpy().view(np.uint64).reshape(len(cols), 12) for o in outs]
+        parts = [o.cpu().numpy().view(np.uint64).reshape(ncols, 12) for o in outs]
         total = parts[0].copy()
         for p in parts[1:]:
-            for j in range(len(cols)):
+            for j in range(ncols):
                 total[j] = self.inner.g1_add(total[j], p[j])
         return self.inner.finish(total)
 
@@ -578,10 +591,10 @@ class Prover:
         h = b.evaluate_h(kw)
         h = b.divide_and_to_coeff(h)
         pieces = b.split(h, n, dom.quotient_poly_degree)
-        t5 = absorb("quotient", b.commit(pieces, lagrange=False))
-        x = challenge("x", t1 + t2 + t3 + t4 + t5)
+        quotient_commit = b.commit_begin(pieces, lagrange=False)
         # 5b. evaluations at x * omega^rot of everything the verifier queries (create_proof's eval_polynomial calls), in
-        #     upstream's query order: advice, permutation products, lookups, fixed, sigma, vanishing (h, random poly)
+        #     upstream's query order: advice, permutation products, lookups, fixed, sigma, vanishing (h, random poly).
+        #     The query list does not depend on x: it is assembled while the quotient commitment is still running.
         polys = {}
         for i_, c_ in enumerate(adv_coeff[:sh.n_advice]):
             polys[("advice", i_)] = c_
@@ -594,8 +607,6 @@ class Prover:
         for i_ in range(L):
             polys[("lookup_z", i_)], polys[("lookup_a", i_)], polys[("lookup_s", i_)] = look_z[i_], perm_in[i_], perm_tab[i_]
         polys[("random", 0)] = rand_poly[0]
-        xn = pow(x, n, R)
-        polys[("h", 0)] = b.lincomb(pieces, [pow(xn, i_, R) for i_ in range(len(pieces))], None)   # sum_i x^(n i) h_i(X)
         last_rot = -(bf + 1)
         qlist = [(("advice", col), rot) for kind, col, rot in sh.queries() if kind == "advice"]
         for i_ in range(len(perm_z)):
@@ -607,6 +618,10 @@ class Prover:
         qlist += [(("fixed", col), rot) for kind, col, rot in sh.queries() if kind == "fixed"]
         qlist += [(("sigma", i_), 0) for i_ in range(len(self.sigma_coeff))]
         qlist += [(("h", 0), 0), (("random", 0), 0)]
+        t5 = absorb("quotient", b.commit_end(quotient_commit))
+        x = challenge("x", t1 + t2 + t3 + t4 + t5)
+        xn = pow(x, n, R)
+        polys[("h", 0)] = b.lincomb(pieces, [pow(xn, i_, R) for i_ in range(len(pieces))], None)   # sum_i x^(n i) h_i(X)
         points = [x * pow(self.omega, rot % n, R) % R for _, rot in qlist]
         flat = b.eval_polys_at([polys[key] for key, _ in qlist], points)
         evals = {q_: from_mont_host(flat[i_]) for i_, q_ in enumerate(qlist)}

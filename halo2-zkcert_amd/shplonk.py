@@ -96,7 +96,8 @@ class ProverSHPLONK:
         y = squeeze("shplonk_y")
         v = squeeze("shplonk_v")
         sets, super_points = construct_intermediate_sets(queries)
-        numerators, interpolants = [], []
+        # host arithmetic first (a few hundred field operations), then every launch back to back
+        interpolants, jobs = [], []
         for rs in sets:
             low = [0] * len(rs.points)
             coeffs, yp, r_set = [], 1, []
@@ -107,19 +108,20 @@ class ProverSHPLONK:
                 coeffs.append(yp)
                 yp = yp * y % R
             interpolants.append(r_set)
-            numerators.append(b.lincomb([polys[key] for key, _ in rs.commitments], coeffs, low))
+            jobs.append(([polys[key] for key, _ in rs.commitments], coeffs, low))
         vs = [pow(v, i, R) for i in range(len(sets))]
-        srcs, roots, weights = [], [], []
+        src_set, roots, weights = [], [], []
         for i, rs in enumerate(sets):
             for r in rs.points:
                 den = 1
                 for s_ in rs.points:
                     if s_ != r:
                         den = den * (r - s_) % R
-                srcs.append(numerators[i])
+                src_set.append(i)
                 roots.append(r)
                 weights.append(vs[i] * _inv(den) % R)
-        h_x = b.lincomb(b.divide_by_linear(srcs, roots), weights, None)
+        numerators = [b.lincomb(*job) for job in jobs]
+        h_x = b.lincomb(b.divide_by_linear([numerators[i] for i in src_set], roots), weights, None)
         h1 = b.commit([h_x], lagrange=False)
         write_points("shplonk_h1", h1)
         u = squeeze("shplonk_u")

@@ -173,3 +173,37 @@ def test_large_msm_trapdoor_property(zk, oracle, k):
     assert (ffi.g1_to_affine(out2[0]) == exp).all()
     dom.free()
     p.free()
+
+
+def test_quad_cooperative_point_ops(zk, oracle):
+    """The 4-lane cooperative XYZZ addition / doubling of the MSM tail against the one-lane versions, including P + P,
+    P + (-P), identity operands and non-trivial ZZ / ZZZ."""
+    import ctypes as C
+
+    ffi, ctx = zk
+    zo = oracle
+    rng = np.random.default_rng(5)
+    P_MOD = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
+    R261 = pow(2, 261, P_MOD)
+
+    def xyzz(k, z):   # k*G in XYZZ coordinates with Z = z, raw R' (2^261) form limbs
+        if k == 0:
+            return [0, R261, 0, 0]
+        x, y = zo.affine_to_ints(zo.g1_to_affine(zo.g1_mul_gen(zo.fr_from_int(k))).reshape(1, 8))[0]
+        zz, zzz = z * z % P_MOD, z * z * z % P_MOD
+        return [v * R261 % P_MOD for v in (x * zz % P_MOD, y * zzz % P_MOD, zz, zzz)]
+
+    cases = [(3, 1, 5, 1), (3, 7, 3, 11), (3, 7, P_MOD and -3, 11), (0, 1, 9, 4), (9, 4, 0, 1), (0, 1, 0, 1)]
+    cases += [(int(rng.integers(1, 1 << 40)), int(rng.integers(2, 1 << 60)), int(rng.integers(1, 1 << 40)), int(rng.integers(2, 1 << 60))) for _ in range(58)]
+    R_ORDER = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+    flat = []
+    for ka, za, kb, zb in cases:
+        flat += xyzz(ka % R_ORDER, za) + xyzz(kb % R_ORDER, zb)
+    arr = np.array([[(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)] for v in flat], dtype=np.uint64)
+    d_in = ctx.to_device(arr)
+    d_out = ctx.empty(len(cases) * 16)
+    assert ffi.lib().zkt_quad_selfcheck(ctx.h, C.c_void_p(d_in.data_ptr()), C.c_uint32(len(cases)), C.c_void_p(d_out.data_ptr())) == 0
+    out = ctx.to_host(d_out).reshape(len(cases), 4, 4, 4)
+    for i, c in enumerate(cases):
+        assert (out[i, 0] == out[i, 2]).all(), ("add", c)
+        assert (out[i, 1] == out[i, 3]).all(), ("double", c, (out[i, 1] == out[i, 3]).all(axis=1))
