@@ -551,6 +551,26 @@ __device__ inline g1x g1x_add_q4(const g1x& p, const g1x& g, uint32_t q) {
     return o;
 }
 
+// Rounds >= 1 when there are too few segments to fill the chip: one quad per segment (latency-bound regime).
+__global__ void __launch_bounds__(256) k_accum_jac_q4(const uint32_t* in_all, size_t in_stride, const uint32_t* cnt_all,
+                                                      const uint32_t* off_all, const uint32_t* segoff_all, uint32_t B,
+                                                      uint32_t seg, uint32_t* out_all, size_t out_stride) {
+    uint32_t col = blockIdx.y;
+    const uint32_t* segoff = segoff_all + (size_t)col * (B + 4);
+    uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t t = lane >> 2, q = lane & 3;
+    if (t >= segoff[B]) return;
+    const uint32_t* cnt = cnt_all + (size_t)col * B;
+    const uint32_t* off = off_all + (size_t)col * (B + 4);
+    const uint32_t* in = in_all + (size_t)col * in_stride * 32;
+    uint32_t b = find_bucket(segoff, B, t);
+    uint32_t s = t - segoff[b];
+    uint32_t lo = off[b] + s * seg, hi = min(lo + seg, off[b] + cnt[b]);
+    g1x acc = g1x_load_raw(in + (size_t)lo * 32);
+    for (uint32_t j = lo + 1; j < hi; ++j) acc = g1x_add_q4(acc, g1x_load_raw(in + (size_t)j * 32), q);
+    if (q == 0) g1x_store_raw(out_all + ((size_t)col * out_stride + t) * 32, acc);
+}
+
 // tree over the block's 64 quads (256 lanes): sh[0] = sum
 __device__ __forceinline__ void block_tree_sum_q4(g1x* sh, uint32_t lt, uint32_t q, const g1x& mine) {
     if (q == 0) sh[lt] = mine;
@@ -757,8 +777,12 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
         size_t nb = bound / seg + B + 1;
         if (nb > pstride0) nb = pstride0;
         { ProfScope ps(ctx, "msm_accum_jac");
-        hipLaunchKernelGGL(k_accum_jac, dim3(div_up(nb, 256), (unsigned)ncols), dim3(256), 0, st, (const uint32_t*)cur_p, pstride0,
-                           cur_cnt, cur_off, (const uint32_t*)nxt_off, B, seg, nxt_p, pstride0); }
+        if (nb * ncols < (size_t)160 * 1024)   // under ~2.5 waves per SIMD the round is a latency chain: 4 lanes per segment
+            hipLaunchKernelGGL(k_accum_jac_q4, dim3(div_up(nb * 4, 256), (unsigned)ncols), dim3(256), 0, st, (const uint32_t*)cur_p, pstride0,
+                               cur_cnt, cur_off, (const uint32_t*)nxt_off, B, seg, nxt_p, pstride0);
+        else
+            hipLaunchKernelGGL(k_accum_jac, dim3(div_up(nb, 256), (unsigned)ncols), dim3(256), 0, st, (const uint32_t*)cur_p, pstride0,
+                               cur_cnt, cur_off, (const uint32_t*)nxt_off, B, seg, nxt_p, pstride0); }
         bound = nb;
         std::swap(cur_p, nxt_p);
         const uint32_t* tc = cur_cnt; const uint32_t* to = cur_off;
