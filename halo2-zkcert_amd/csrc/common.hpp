@@ -47,6 +47,8 @@ struct zkhip_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    void* h_pinned = nullptr;   // 64 KiB of pinned host memory for the small device->host reads on the critical path
+    static constexpr size_t PINNED_BYTES = 64 * 1024;
     std::map<std::string, zk::Scratch> scratch;
     // Twiddle tables keyed by (log_n, omega).  w^e for any e < 2^log_n is lo[e & (2^h - 1)] * hi[e >> h]
     // (two tables of ~sqrt(n) entries: L2-resident, against a 16 * n-byte table that every strided NTT pass

@@ -99,6 +99,7 @@ int zkhip_init(zkhip_ctx** out, int device_id) {
     c->stream = c->own_stream;
     ZK_HIP(hipEventCreate(&c->ev0));
     ZK_HIP(hipEventCreate(&c->ev1));
+    ZK_HIP(hipHostMalloc(&c->h_pinned, zkhip_ctx::PINNED_BYTES, hipHostMallocDefault));
     *out = c;
     return ZKHIP_OK;
 }
@@ -116,6 +117,7 @@ void zkhip_destroy(zkhip_ctx* c) {
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     delete c;
 }
 
@@ -190,6 +192,18 @@ void zkhip_g1_batch_to_affine(const uint64_t* xyz, size_t n, uint64_t* out_xy) {
         }
         g1a_store_abi(out_xy + 8 * i, a);
     }
+}
+int zkhip_commitments_read(zkhip_ctx* c, const void* d_xyz, size_t n, uint64_t* out_xy, uint8_t* out_bytes) {
+    if (!c || (n && (!d_xyz || !out_xy))) { set_error("zkhip_commitments_read: null argument"); return ZKHIP_EINVAL; }
+    if (n == 0) return ZKHIP_OK;
+    std::vector<uint64_t> big;
+    uint64_t* jac = (uint64_t*)c->h_pinned;
+    if (n * 96 > zkhip_ctx::PINNED_BYTES) { big.resize(12 * n); jac = big.data(); }
+    ZK_HIP(hipMemcpyAsync(jac, d_xyz, n * 96, hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(hipStreamSynchronize(c->stream));
+    zkhip_g1_batch_to_affine(jac, n, out_xy);
+    if (out_bytes) for (size_t i = 0; i < n; ++i) zkhip_g1_to_bytes(out_xy + 8 * i, out_bytes + 32 * i);
+    return ZKHIP_OK;
 }
 void zkhip_g1_add(const uint64_t a[12], const uint64_t b[12], uint64_t out[12]) {
     g1j_store_abi(out, g1j_add(g1j_load_abi(a), g1j_load_abi(b)));

@@ -727,7 +727,9 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
     }
     dim3 gn(div_up(n, 256), (unsigned)ncols);
     dim3 gt(div_up(items, SORT_TILE) + g.P, (unsigned)ncols);
-    std::vector<uint32_t> h_max(ncols);
+    std::vector<uint32_t> h_max_big;
+    uint32_t* h_max = (uint32_t*)ctx->h_pinned;
+    if (ncols * 4 > zkhip_ctx::PINNED_BYTES) { h_max_big.resize(ncols); h_max = h_max_big.data(); }
     { ProfScope ps(ctx, "msm_digits");
     hipLaunchKernelGGL(k_sort_hi<false>, gn, dim3(256), 0, st, (const uint32_t* const*)d_colptrs, n, first, srs->n, g, d_part_cnt, d_part_cursor,
                        (const uint32_t*)d_part_off, (uint32_t*)d_tmp_entry, (uint16_t*)d_tmp_key, items);
@@ -739,7 +741,7 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
                        (uint32_t*)d_entries); }
     { ProfScope ps(ctx, "msm_plan");
     ZK_TRY(launch_plan(ctx, (unsigned)ncols, (const uint32_t*)d_cnt, B, seg, (uint32_t*)d_off, (uint32_t*)d_cntA, (uint32_t*)d_offA, (uint32_t*)d_max)); }
-    ZK_HIP(hipMemcpyAsync(h_max.data(), d_max, ncols * 4, hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipMemcpyAsync(h_max, d_max, ncols * 4, hipMemcpyDeviceToHost, st));
     { ProfScope ps(ctx, "msm_digits");
     hipLaunchKernelGGL(k_sort_lo<true>, gt, dim3(256), 0, st, (const uint32_t*)d_part_off, (const uint32_t*)d_tile_start, g,
                        (const uint32_t*)d_tmp_entry, (const uint16_t*)d_tmp_key, items, d_cnt, (const uint32_t*)d_off, d_cursor,
@@ -747,7 +749,7 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
     ZK_LAUNCH_CHECK();
     ZK_HIP(hipStreamSynchronize(st));
     uint32_t maxcnt = 0;
-    for (uint32_t v : h_max) maxcnt = std::max(maxcnt, v);
+    for (size_t j = 0; j < ncols; ++j) maxcnt = std::max(maxcnt, h_max[j]);
     if (maxcnt == 0) {
         hipLaunchKernelGGL(k_set_identity, dim3(div_up(ncols, 64)), dim3(64), 0, st, (uint32_t*)d_out, (uint32_t)ncols);
         ZK_LAUNCH_CHECK();

@@ -236,9 +236,9 @@ extern "C" int zkhip_permute_expression_pair_device(zkhip_ctx* ctx, uint32_t k, 
     hipLaunchKernelGGL(k_pe_finish, dim3(g), dim3(256), 0, st, (const uint32_t*)dA, (const uint32_t*)d_left, rep_flag, rep_rank, totals, n, usable,
                        (const uint32_t*)d_blind_in, (const uint32_t*)d_blind_tab, (uint32_t*)d_perm_in, (uint32_t*)d_perm_tab, err);
     ZK_LAUNCH_CHECK();
-    uint32_t h_err = 0;
-    ZK_HIP(hipMemcpyAsync(&h_err, err, 4, hipMemcpyDeviceToHost, st));
+    uint32_t* h_err = (uint32_t*)ctx->h_pinned;
+    ZK_HIP(hipMemcpyAsync(h_err, err, 4, hipMemcpyDeviceToHost, st));
     ZK_HIP(hipStreamSynchronize(st));
-    if (h_err) { set_error("permute_expression_pair: an input value is not in the table (ConstraintSystemFailure)"); return ZKHIP_ECONSTRAINT; }
+    if (*h_err) { set_error("permute_expression_pair: an input value is not in the table (ConstraintSystemFailure)"); return ZKHIP_ECONSTRAINT; }
     return ZKHIP_OK;
 }

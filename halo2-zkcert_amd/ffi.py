@@ -58,7 +58,7 @@ SYMBOLS = [
     "zkhip_profile_enable", "zkhip_profile_read",
     "zkhip_srs_load", "zkhip_srs_load_device", "zkhip_srs_free", "zkhip_srs_len", "zkhip_srs_window", "zkhip_kzg_setup", "zkhip_srs_read",
     "zkhip_msm_g1", "zkhip_msm_g1_batch_device", "zkhip_msm_g1_batch_range_device", "zkhip_msm_g1_multi_device", "zkhip_g1_add", "zkhip_g1_to_affine", "zkhip_g1_batch_to_affine",
-    "zkhip_g1_to_bytes",
+    "zkhip_g1_to_bytes", "zkhip_commitments_read",
     "zkhip_fft", "zkhip_fft_batch_device",
     "zkhip_domain_new", "zkhip_domain_free", "zkhip_domain_k", "zkhip_domain_extended_k", "zkhip_domain_quotient_poly_degree",
     "zkhip_domain_constants", "zkhip_lagrange_to_coeff_device", "zkhip_coeff_to_lagrange_device",
@@ -380,6 +380,16 @@ def g1_batch_to_affine(xyz_rows):
     out = np.zeros((xyz_rows.shape[0], 8), dtype=np.uint64)
     lib().zkhip_g1_batch_to_affine(_p(xyz_rows), C.c_size_t(xyz_rows.shape[0]), _p(out))
     return out
+
+
+def commitments_read(ctx, d_xyz):
+    """(ncols, 12) device Jacobian sums -> [(affine (8,) u64, 32 compressed bytes)] with one sync and one inversion"""
+    n = d_xyz.shape[0]
+    out = np.zeros((n, 8), dtype=np.uint64)
+    byts = (C.c_uint8 * (32 * n))()
+    _check(lib().zkhip_commitments_read(ctx.h, C.c_void_p(d_xyz.data_ptr()), C.c_size_t(n), _p(out), byts))
+    raw = bytes(byts)
+    return [(out[j], raw[32 * j:32 * j + 32]) for j in range(n)]
 
 
 def g1_add(a, b):

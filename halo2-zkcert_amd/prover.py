@@ -107,6 +107,8 @@ class CircuitShape:
 
     def queries(self):
         """Distinct (kind, column, rotation) queries of the gates and lookups (what create_proof evaluates at x)."""
+        if getattr(self, "_queries", None) is not None:
+            return self._queries
         seen, out = set(), []
 
         def walk(e):
@@ -126,6 +128,7 @@ class CircuitShape:
                 walk(e)
         for t, i in self.perm_columns:
             walk((t, i, 0))
+        self._queries = out
         return out
 
     def counts(self, dom_extended_k):
@@ -234,7 +237,7 @@ class GpuBackend:
         return self.partial_commit(cols, lagrange, 0, cols[0].shape[0]) if cols else None
 
     def commit_end(self, token):
-        return self.finish(self.ctx.to_host(token)) if token is not None else []
+        return self.ffi.commitments_read(self.ctx, token) if token is not None else []
 
     def commit(self, cols, lagrange):
         """one host round trip per batch (the Fiat-Shamir sync point)"""

@@ -68,6 +68,21 @@ def lagrange_interpolate(points, evals):
     return out
 
 
+def lagrange_basis(points):
+    """coefficient lists of the m Lagrange basis polynomials over `points` (depends on the points only)"""
+    m = len(points)
+    basis = []
+    for i in range(m):
+        num, den = [1], 1
+        for j in range(m):
+            if j != i:
+                num = [(a - points[j] * b) % R for a, b in zip([0] + num, num + [0])]
+                den = den * (points[i] - points[j]) % R
+        c = _inv(den)
+        basis.append([nd * c % R for nd in num])
+    return basis
+
+
 def evaluate_vanishing_polynomial(roots, z):
     acc = 1
     for r in roots:
@@ -101,8 +116,10 @@ class ProverSHPLONK:
         for rs in sets:
             low = [0] * len(rs.points)
             coeffs, yp, r_set = [], 1, []
+            basis = lagrange_basis(rs.points)
+            m = len(rs.points)
             for key, evals in rs.commitments:
-                r_ij = lagrange_interpolate(rs.points, evals)
+                r_ij = [sum(evals[i] * basis[i][d] for i in range(m)) % R for d in range(m)]
                 r_set.append(r_ij)
                 low = [(a + yp * c) % R for a, c in zip(low, r_ij)]
                 coeffs.append(yp)

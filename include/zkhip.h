@@ -108,6 +108,9 @@ void zkhip_g1_to_affine(const uint64_t xyz[12], uint64_t out_xy[8]);
 void zkhip_g1_batch_to_affine(const uint64_t* xyz, size_t n, uint64_t* out_xy);
 /* G1Affine::to_bytes (32-byte compressed) */
 void zkhip_g1_to_bytes(const uint64_t xy[8], uint8_t out[32]);
+/* What create_proof does with a batch of commitments: the n Jacobian results of zkhip_msm_g1_*_device (device memory) ->
+ * host, batch_normalize, and (if out_bytes != NULL) the 32-byte form transcript.write_point consumes.  One stream sync. */
+int  zkhip_commitments_read(zkhip_ctx* ctx, const void* d_xyz, size_t n, uint64_t* out_xy, uint8_t* out_bytes);
 
 /* ---- NTT: halo2curves fft::best_fft(a, omega, log_n): in place, natural order in and out ---- */
 int  zkhip_fft(zkhip_ctx* ctx, uint64_t* a, const uint64_t omega[4], uint32_t log_n);
