@@ -84,4 +84,15 @@ struct ProfScope {
     ~ProfScope() { if (c->prof_on) c->prof_end(); }
 };
 
+// Waits for a stream by polling: hipStreamSynchronize sleeps on an interrupt and wakes tens of microseconds late, and the prover
+// has a dozen Fiat-Shamir round trips per proof on its critical path.  Bounded spin, then the blocking wait.
+static inline hipError_t stream_wait(hipStream_t st) {
+    for (int i = 0; i < 2000000; ++i) {
+        hipError_t e = hipStreamQuery(st);
+        if (e != hipErrorNotReady) return e;
+    }
+    (void)hipGetLastError();
+    return hipStreamSynchronize(st);
+}
+
 static inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }

@@ -151,7 +151,7 @@ int zkhip_memcpy_h2d(zkhip_ctx* c, void* dst, const void* src, size_t bytes) {
 int zkhip_memcpy_d2h(zkhip_ctx* c, void* dst, const void* src, size_t bytes) {
     if (!c) { set_error("null ctx"); return ZKHIP_EINVAL; }
     ZK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
-    ZK_HIP(hipStreamSynchronize(c->stream));
+    ZK_HIP(stream_wait(c->stream));
     return ZKHIP_OK;
 }
 int zkhip_timer_start(zkhip_ctx* c) {
@@ -200,7 +200,7 @@ int zkhip_commitments_read(zkhip_ctx* c, const void* d_xyz, size_t n, uint64_t* 
     uint64_t* jac = (uint64_t*)c->h_pinned;
     if (n * 96 > zkhip_ctx::PINNED_BYTES) { big.resize(12 * n); jac = big.data(); }
     ZK_HIP(hipMemcpyAsync(jac, d_xyz, n * 96, hipMemcpyDeviceToHost, c->stream));
-    ZK_HIP(hipStreamSynchronize(c->stream));
+    ZK_HIP(stream_wait(c->stream));
     zkhip_g1_batch_to_affine(jac, n, out_xy);
     if (out_bytes) for (size_t i = 0; i < n; ++i) zkhip_g1_to_bytes(out_xy + 8 * i, out_bytes + 32 * i);
     return ZKHIP_OK;

@@ -433,7 +433,9 @@ __global__ void __launch_bounds__(256) k_accum_affine(const uint32_t* const* tab
     const uint32_t* table = tables[col];
     uint32_t b = find_bucket(segoff, B, t);
     uint32_t s = t - segoff[b];
-    uint32_t lo = off[b] + s * seg, hi = min(lo + seg, off[b] + cnt[b]);
+    // the bucket's ceil(cnt / seg) segments are of equal length (within one): lanes of a wave then run nearly the same trip count
+    const uint32_t cb = cnt[b], nsb = segoff[b + 1] - segoff[b], len = (cb + nsb - 1) / nsb;
+    uint32_t lo = off[b] + s * len, hi = min(lo + len, off[b] + cb);
     g1x acc = g1x_identity();
     for (uint32_t j = lo; j < hi; ++j) {
         uint32_t e = entries[j];
@@ -454,7 +456,9 @@ __global__ void __launch_bounds__(256) k_accum_jac(const uint32_t* in_all, size_
     const uint32_t* in = in_all + (size_t)col * in_stride * 32;
     uint32_t b = find_bucket(segoff, B, t);
     uint32_t s = t - segoff[b];
-    uint32_t lo = off[b] + s * seg, hi = min(lo + seg, off[b] + cnt[b]);
+    // the bucket's ceil(cnt / seg) segments are of equal length (within one): lanes of a wave then run nearly the same trip count
+    const uint32_t cb = cnt[b], nsb = segoff[b + 1] - segoff[b], len = (cb + nsb - 1) / nsb;
+    uint32_t lo = off[b] + s * len, hi = min(lo + len, off[b] + cb);
     g1x acc = g1x_load_raw(in + (size_t)lo * 32);
     for (uint32_t j = lo + 1; j < hi; ++j) acc = g1x_add(acc, g1x_load_raw(in + (size_t)j * 32));
     g1x_store_raw(out_all + ((size_t)col * out_stride + t) * 32, acc);
@@ -565,7 +569,9 @@ __global__ void __launch_bounds__(256) k_accum_jac_q4(const uint32_t* in_all, si
     const uint32_t* in = in_all + (size_t)col * in_stride * 32;
     uint32_t b = find_bucket(segoff, B, t);
     uint32_t s = t - segoff[b];
-    uint32_t lo = off[b] + s * seg, hi = min(lo + seg, off[b] + cnt[b]);
+    // the bucket's ceil(cnt / seg) segments are of equal length (within one): lanes of a wave then run nearly the same trip count
+    const uint32_t cb = cnt[b], nsb = segoff[b + 1] - segoff[b], len = (cb + nsb - 1) / nsb;
+    uint32_t lo = off[b] + s * len, hi = min(lo + len, off[b] + cb);
     g1x acc = g1x_load_raw(in + (size_t)lo * 32);
     for (uint32_t j = lo + 1; j < hi; ++j) acc = g1x_add_q4(acc, g1x_load_raw(in + (size_t)j * 32), q);
     if (q == 0) g1x_store_raw(out_all + ((size_t)col * out_stride + t) * 32, acc);
@@ -724,6 +730,7 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
         size_t target_threads = (size_t)256 * 4 * 64 * 4;
         size_t sgl = (ncols * items) / target_threads;
         if (sgl > seg) seg = (uint32_t)std::min<size_t>(sgl, 64);
+        if (const char* e = getenv("ZKHIP_MSM_SEG")) { int v = atoi(e); if (v >= 2 && v <= 256) seg = (uint32_t)v; }
     }
     dim3 gn(div_up(n, 256), (unsigned)ncols);
     dim3 gt(div_up(items, SORT_TILE) + g.P, (unsigned)ncols);
@@ -747,7 +754,7 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
                        (const uint32_t*)d_tmp_entry, (const uint16_t*)d_tmp_key, items, d_cnt, (const uint32_t*)d_off, d_cursor,
                        (uint32_t*)d_entries); }
     ZK_LAUNCH_CHECK();
-    ZK_HIP(hipStreamSynchronize(st));
+    ZK_HIP(stream_wait(st));
     uint32_t maxcnt = 0;
     for (size_t j = 0; j < ncols; ++j) maxcnt = std::max(maxcnt, h_max[j]);
     if (maxcnt == 0) {

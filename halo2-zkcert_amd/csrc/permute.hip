@@ -238,7 +238,7 @@ extern "C" int zkhip_permute_expression_pair_device(zkhip_ctx* ctx, uint32_t k, 
     ZK_LAUNCH_CHECK();
     uint32_t* h_err = (uint32_t*)ctx->h_pinned;
     ZK_HIP(hipMemcpyAsync(h_err, err, 4, hipMemcpyDeviceToHost, st));
-    ZK_HIP(hipStreamSynchronize(st));
+    ZK_HIP(stream_wait(st));
     if (*h_err) { set_error("permute_expression_pair: an input value is not in the table (ConstraintSystemFailure)"); return ZKHIP_ECONSTRAINT; }
     return ZKHIP_OK;
 }

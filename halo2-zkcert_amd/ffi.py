@@ -143,6 +143,12 @@ class Context:
         return self.torch.from_numpy(arr.view(np.int64)).to(self.device)
 
     def to_host(self, t):
+        """device tensor -> host uint64 array; small results (the Fiat-Shamir round trips) go through the library's polled copy"""
+        nbytes = t.numel() * t.element_size()
+        if nbytes <= (1 << 16) and t.is_contiguous():
+            out = np.empty(t.shape, dtype=np.uint64)
+            _check(lib().zkhip_memcpy_d2h(self.h, _p(out), C.c_void_p(t.data_ptr()), C.c_size_t(nbytes)))
+            return out
         return t.cpu().numpy().view(np.uint64)
 
     def synchronize(self):
@@ -317,6 +323,35 @@ class ParamsKZG:
             _check(lib().zkhip_srs_load(ctx.h, _p(b), C.c_size_t(b.shape[0]), C.byref(h)))
             out.append(h)
         return cls(ctx, k, out[0], out[1])
+
+    # halo2_proofs ParamsKZG::write / ::read (poly/kzg/commitment.rs, SerdeFormat::RawBytes) [UPSTREAM-RECALL]: the file the
+    # reference keeps under PARAMS_DIR as kzg_bn254_{k}.srs (/root/reference/src/bin/cli.rs:222): k as u32 LE, g (n points),
+    # g_lagrange (n points), g2 and s_g2; a G1 point is its x and y as 4 LE u64 Montgomery limbs each — byte for byte the
+    # form zkhip_srs_load takes — and a G2 point 128 bytes, which the prover never touches (kept opaque for write()).
+    @classmethod
+    def read(cls, ctx, path):
+        with open(path, "rb") as f:
+            k = int.from_bytes(f.read(4), "little")
+            if not 1 <= k <= 28:
+                raise ZkhipError(f"{path}: k = {k} is not a KZG parameter file")
+            n = 1 << k
+            raw = f.read(2 * n * 64)
+            g2 = f.read(256)
+        if len(raw) != 2 * n * 64 or len(g2) != 256:
+            raise ZkhipError(f"{path}: truncated ({len(raw)} point bytes, {len(g2)} G2 bytes)")
+        pts = np.frombuffer(raw, dtype="<u8").reshape(2, n, 8)
+        p = cls.from_bases(ctx, k, g_xy=pts[0], g_lagrange_xy=pts[1])
+        p.g2_bytes = g2
+        return p
+
+    def write(self, path):
+        with open(path, "wb") as f:
+            f.write(int(self.k).to_bytes(4, "little"))
+            for h in (self.g, self.g_lagrange):
+                for first in range(0, self.n, 1 << 16):
+                    cnt = min(1 << 16, self.n - first)
+                    f.write(self.read_bases(h, first, cnt).astype("<u8").tobytes())
+            f.write(getattr(self, "g2_bytes", bytes(256)))
 
     def window(self):
         c, w = C.c_uint32(), C.c_uint32()
