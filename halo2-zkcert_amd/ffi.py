@@ -514,9 +514,16 @@ class EvalhPack:
         return C.cast(arr, C.c_void_p)
 
     def graph(self, g, to_mont):
-        consts = _u64(to_mont(g.constants)).reshape(-1, 4)
-        rots = np.array(g.rotations if g.rotations else [0], dtype=np.int32)
-        code = np.array(g.code_words(), dtype=np.int32)
+        # the marshalled form of a finished graph is cached on it (graphs are built once at keygen)
+        key = (len(g.constants), len(g.rotations), len(g.calculations))
+        cached = getattr(g, "_zk_packed", None)
+        if cached is not None and cached[0] == key:
+            consts, rots, code = cached[1]
+        else:
+            consts = _u64(to_mont(g.constants)).reshape(-1, 4)
+            rots = np.array(g.rotations if g.rotations else [0], dtype=np.int32)
+            code = np.array(g.code_words(), dtype=np.int32)
+            g._zk_packed = (key, (consts, rots, code))
         self.keep += [consts, rots, code]
         return ZkGraph(consts.ctypes.data, rots.ctypes.data, code.ctypes.data, len(g.constants), len(g.rotations), len(code),
                        len(g.calculations), g.num_intermediates)

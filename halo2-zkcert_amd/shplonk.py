@@ -111,8 +111,8 @@ class ProverSHPLONK:
         y = squeeze("shplonk_y")
         v = squeeze("shplonk_v")
         sets, super_points = construct_intermediate_sets(queries)
-        # host arithmetic first (a few hundred field operations), then every launch back to back
-        interpolants, jobs = [], []
+        # each set's numerator is launched as soon as its interpolants exist, so the device works while the host prepares the next
+        interpolants, numerators = [], []
         for rs in sets:
             low = [0] * len(rs.points)
             coeffs, yp, r_set = [], 1, []
@@ -125,7 +125,7 @@ class ProverSHPLONK:
                 coeffs.append(yp)
                 yp = yp * y % R
             interpolants.append(r_set)
-            jobs.append(([polys[key] for key, _ in rs.commitments], coeffs, low))
+            numerators.append(b.lincomb([polys[key] for key, _ in rs.commitments], coeffs, low))
         vs = [pow(v, i, R) for i in range(len(sets))]
         src_set, roots, weights = [], [], []
         for i, rs in enumerate(sets):
@@ -137,7 +137,6 @@ class ProverSHPLONK:
                 src_set.append(i)
                 roots.append(r)
                 weights.append(vs[i] * _inv(den) % R)
-        numerators = [b.lincomb(*job) for job in jobs]
         h_x = b.lincomb(b.divide_by_linear([numerators[i] for i in src_set], roots), weights, None)
         h1 = b.commit([h_x], lagrange=False)
         write_points("shplonk_h1", h1)
