@@ -418,30 +418,71 @@ __device__ __forceinline__ uint32_t find_bucket(const uint32_t* off, uint32_t B,
     return lo;
 }
 
-// Round 0: segment sums of (sign, precomputed affine point) pairs.
+// Partial sums travel between the MSM kernels as the accumulator's 4 x 9 limbs, unreduced (144 B): writing one is 9 stores and
+// no arithmetic, which matters in round 0 where a lane flushes in the middle of its run while the rest of the wave waits.
+#define PART_WORDS 36
+__device__ __forceinline__ void g1x_store_loose(uint32_t* p, const g1x& v) {
+    const fe* c[4] = {&v.x.v, &v.y.v, &v.zz.v, &v.zzz.v};
+    uint32_t w[PART_WORDS];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < 9; ++i) w[k * 9 + i] = c[k]->l[i];
+#pragma unroll
+    for (int q = 0; q < PART_WORDS / 4; ++q) reinterpret_cast<uint4*>(p)[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+}
+__device__ __forceinline__ g1x g1x_load_loose(const uint32_t* p) {
+    uint32_t w[PART_WORDS];
+#pragma unroll
+    for (int q = 0; q < PART_WORDS / 4; ++q) {
+        uint4 x = reinterpret_cast<const uint4*>(p)[q];
+        w[4 * q] = x.x; w[4 * q + 1] = x.y; w[4 * q + 2] = x.z; w[4 * q + 3] = x.w;
+    }
+    g1x v;
+    fe* c[4] = {&v.x.v, &v.y.v, &v.zz.v, &v.zzz.v};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < 9; ++i) c[k]->l[i] = w[k * 9 + i];
+    return v;
+}
+
+// Round 0, lane-balanced: lane t sums the L consecutive sorted entries [t L, (t+1) L) whatever buckets they belong to, and
+// writes one partial per bucket it touches (partial t - floor(off[b] / L) of bucket b).  Every lane of a wave runs the same
+// trip count, where per-bucket segments left ~20 % of the lanes idle behind the longest segment.
+// npart[b] = number of lanes touching bucket b.
+__global__ void k_lane_parts(const uint32_t* cnt_all, const uint32_t* off_all, uint32_t B, uint32_t L, uint32_t* npart_all) {
+    uint32_t col = blockIdx.y, b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    uint32_t c = cnt_all[(size_t)col * B + b], o = off_all[(size_t)col * (B + 4) + b];
+    npart_all[(size_t)col * B + b] = c ? (o + c - 1) / L - o / L + 1 : 0;
+}
 __global__ void __launch_bounds__(256) k_accum_affine(const uint32_t* const* tables, const uint32_t* entries_all, size_t items,
-                                                      const uint32_t* cnt_all, const uint32_t* off_all,
-                                                      const uint32_t* segoff_all, uint32_t B, uint32_t seg,
+                                                      const uint32_t* off_all, const uint32_t* segoff_all, uint32_t B, uint32_t L,
                                                       uint32_t* partial_all, size_t partial_stride) {
     uint32_t col = blockIdx.y;
+    const uint32_t* off = off_all + (size_t)col * (B + 4);
     const uint32_t* segoff = segoff_all + (size_t)col * (B + 4);
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= segoff[B]) return;
-    const uint32_t* cnt = cnt_all + (size_t)col * B;
-    const uint32_t* off = off_all + (size_t)col * (B + 4);
+    const uint32_t total = off[B];
+    if ((uint64_t)t * L >= total) return;
+    const uint32_t start = t * L, end = min(start + L, total);
     const uint32_t* entries = entries_all + (size_t)col * items;
     const uint32_t* table = tables[col];
-    uint32_t b = find_bucket(segoff, B, t);
-    uint32_t s = t - segoff[b];
-    // the bucket's ceil(cnt / seg) segments are of equal length (within one): lanes of a wave then run nearly the same trip count
-    const uint32_t cb = cnt[b], nsb = segoff[b + 1] - segoff[b], len = (cb + nsb - 1) / nsb;
-    uint32_t lo = off[b] + s * len, hi = min(lo + len, off[b] + cb);
+    uint32_t* out = partial_all + (size_t)col * partial_stride * PART_WORDS;
+    uint32_t b = find_bucket(off, B, start);
+    uint32_t bend = off[b + 1];
     g1x acc = g1x_identity();
-    for (uint32_t j = lo; j < hi; ++j) {
+    for (uint32_t j = start; j < end; ++j) {
+        if (j >= bend) {   // the run crosses into the next non-empty bucket
+            g1x_store_loose(out + (size_t)(segoff[b] + t - off[b] / L) * PART_WORDS, acc);
+            do { ++b; bend = off[b + 1]; } while (bend <= j);
+            acc = g1x_identity();
+        }
         uint32_t e = entries[j];
         acc = g1x_add_mixed(acc, g1a_load_raw_cneg(table + (size_t)(e & 0x7fffffffu) * 16, (e >> 31) != 0));
     }
-    g1x_store_raw(partial_all + ((size_t)col * partial_stride + t) * 32, acc);
+    g1x_store_loose(out + (size_t)(segoff[b] + t - off[b] / L) * PART_WORDS, acc);
 }
 // Rounds >= 1: segment sums of Jacobian partials.
 __global__ void __launch_bounds__(256) k_accum_jac(const uint32_t* in_all, size_t in_stride, const uint32_t* cnt_all,
@@ -453,15 +494,15 @@ __global__ void __launch_bounds__(256) k_accum_jac(const uint32_t* in_all, size_
     if (t >= segoff[B]) return;
     const uint32_t* cnt = cnt_all + (size_t)col * B;
     const uint32_t* off = off_all + (size_t)col * (B + 4);
-    const uint32_t* in = in_all + (size_t)col * in_stride * 32;
+    const uint32_t* in = in_all + (size_t)col * in_stride * PART_WORDS;
     uint32_t b = find_bucket(segoff, B, t);
     uint32_t s = t - segoff[b];
     // the bucket's ceil(cnt / seg) segments are of equal length (within one): lanes of a wave then run nearly the same trip count
     const uint32_t cb = cnt[b], nsb = segoff[b + 1] - segoff[b], len = (cb + nsb - 1) / nsb;
     uint32_t lo = off[b] + s * len, hi = min(lo + len, off[b] + cb);
-    g1x acc = g1x_load_raw(in + (size_t)lo * 32);
-    for (uint32_t j = lo + 1; j < hi; ++j) acc = g1x_add(acc, g1x_load_raw(in + (size_t)j * 32));
-    g1x_store_raw(out_all + ((size_t)col * out_stride + t) * 32, acc);
+    g1x acc = g1x_load_loose(in + (size_t)lo * PART_WORDS);
+    for (uint32_t j = lo + 1; j < hi; ++j) acc = g1x_add(acc, g1x_load_loose(in + (size_t)j * PART_WORDS));
+    g1x_store_loose(out_all + ((size_t)col * out_stride + t) * PART_WORDS, acc);
 }
 
 // ---- quad-cooperative XYZZ arithmetic for the latency-bound tail -------------------------------------------------
@@ -566,15 +607,15 @@ __global__ void __launch_bounds__(256) k_accum_jac_q4(const uint32_t* in_all, si
     if (t >= segoff[B]) return;
     const uint32_t* cnt = cnt_all + (size_t)col * B;
     const uint32_t* off = off_all + (size_t)col * (B + 4);
-    const uint32_t* in = in_all + (size_t)col * in_stride * 32;
+    const uint32_t* in = in_all + (size_t)col * in_stride * PART_WORDS;
     uint32_t b = find_bucket(segoff, B, t);
     uint32_t s = t - segoff[b];
     // the bucket's ceil(cnt / seg) segments are of equal length (within one): lanes of a wave then run nearly the same trip count
     const uint32_t cb = cnt[b], nsb = segoff[b + 1] - segoff[b], len = (cb + nsb - 1) / nsb;
     uint32_t lo = off[b] + s * len, hi = min(lo + len, off[b] + cb);
-    g1x acc = g1x_load_raw(in + (size_t)lo * 32);
-    for (uint32_t j = lo + 1; j < hi; ++j) acc = g1x_add_q4(acc, g1x_load_raw(in + (size_t)j * 32), q);
-    if (q == 0) g1x_store_raw(out_all + ((size_t)col * out_stride + t) * 32, acc);
+    g1x acc = g1x_load_loose(in + (size_t)lo * PART_WORDS);
+    for (uint32_t j = lo + 1; j < hi; ++j) acc = g1x_add_q4(acc, g1x_load_loose(in + (size_t)j * PART_WORDS), q);
+    if (q == 0) g1x_store_loose(out_all + ((size_t)col * out_stride + t) * PART_WORDS, acc);
 }
 
 // tree over the block's 64 quads (256 lanes): sh[0] = sum
@@ -601,12 +642,15 @@ __global__ void __launch_bounds__(256) k_bucket_chunks(const uint32_t* part_all,
     if (t < nchunks) {
         const uint32_t* cnt = cnt_all + (size_t)col * B;
         const uint32_t* off = off_all + (size_t)col * (B + 4);
-        const uint32_t* part = part_all + (size_t)col * part_stride * 32;
+        const uint32_t* part = part_all + (size_t)col * part_stride * PART_WORDS;
         uint32_t base = t * CH;
         g1x run = g1x_identity();
         for (int j = (int)CH - 1; j >= 0; --j) {
             uint32_t b = base + (uint32_t)j;
-            if (b < B && cnt[b]) run = g1x_add_q4(run, g1x_load_raw(part + (size_t)off[b] * 32), q);
+            if (b < B) {   // the bucket's (few) partial sums are folded here: no separate reduction round for them
+                const uint32_t c = cnt[b], o = off[b];
+                for (uint32_t i = 0; i < c; ++i) run = g1x_add_q4(run, g1x_load_loose(part + (size_t)(o + i) * PART_WORDS), q);
+            }
             acc = g1x_add_q4(acc, run, q);
         }
         // + base * run
@@ -713,8 +757,8 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
     ZK_TRY(ctx->get_scratch("msm_cntB", ncols * B * 4, &d_cntB));
     ZK_TRY(ctx->get_scratch("msm_offA", ncols * (B + 4) * 4, &d_offA));
     ZK_TRY(ctx->get_scratch("msm_offB", ncols * (B + 4) * 4, &d_offB));
-    ZK_TRY(ctx->get_scratch("msm_pA", ncols * pstride0 * 128, &d_pA));
-    ZK_TRY(ctx->get_scratch("msm_pB", ncols * pstride0 * 128, &d_pB));
+    ZK_TRY(ctx->get_scratch("msm_pA", ncols * pstride0 * PART_WORDS * 4, &d_pA));
+    ZK_TRY(ctx->get_scratch("msm_pB", ncols * pstride0 * PART_WORDS * 4, &d_pB));
     uint32_t CH = B > 8192 ? B / 8192 : 1;
     uint32_t nchunks = (B + CH - 1) / CH;
     uint32_t nchunk_blocks = div_up(nchunks, 64);   // 64 quads per block
@@ -730,7 +774,7 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
         size_t target_threads = (size_t)256 * 4 * 64 * 4;
         size_t sgl = (ncols * items) / target_threads;
         if (sgl > seg) seg = (uint32_t)std::min<size_t>(sgl, 64);
-        if (const char* e = getenv("ZKHIP_MSM_SEG")) { int v = atoi(e); if (v >= 2 && v <= 256) seg = (uint32_t)v; }
+        if (const char* e = getenv("ZKHIP_MSM_SEG")) { int v = atoi(e); if (v >= (int)seg0_min && v <= 256) seg = (uint32_t)v; }
     }
     dim3 gn(div_up(n, 256), (unsigned)ncols);
     dim3 gt(div_up(items, SORT_TILE) + g.P, (unsigned)ncols);
@@ -746,40 +790,44 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
     hipLaunchKernelGGL(k_sort_lo<false>, gt, dim3(256), 0, st, (const uint32_t*)d_part_off, (const uint32_t*)d_tile_start, g,
                        (const uint32_t*)d_tmp_entry, (const uint16_t*)d_tmp_key, items, d_cnt, (const uint32_t*)d_off, d_cursor,
                        (uint32_t*)d_entries); }
+    // plan: bucket offsets, then the number of round-0 lanes touching each bucket (= its partial sums) and their offsets
+    const uint32_t L = seg;
     { ProfScope ps(ctx, "msm_plan");
-    ZK_TRY(launch_plan(ctx, (unsigned)ncols, (const uint32_t*)d_cnt, B, seg, (uint32_t*)d_off, (uint32_t*)d_cntA, (uint32_t*)d_offA, (uint32_t*)d_max)); }
+    ZK_TRY(launch_plan(ctx, (unsigned)ncols, (const uint32_t*)d_cnt, B, 1, (uint32_t*)d_off, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr));
+    hipLaunchKernelGGL(k_lane_parts, dim3(div_up(B, 256), (unsigned)ncols), dim3(256), 0, st, (const uint32_t*)d_cnt, (const uint32_t*)d_off, B, L,
+                       (uint32_t*)d_cntA);
+    ZK_TRY(launch_plan(ctx, (unsigned)ncols, (const uint32_t*)d_cntA, B, 1, (uint32_t*)d_offA, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)d_max)); }
     ZK_HIP(hipMemcpyAsync(h_max, d_max, ncols * 4, hipMemcpyDeviceToHost, st));
     { ProfScope ps(ctx, "msm_digits");
     hipLaunchKernelGGL(k_sort_lo<true>, gt, dim3(256), 0, st, (const uint32_t*)d_part_off, (const uint32_t*)d_tile_start, g,
                        (const uint32_t*)d_tmp_entry, (const uint16_t*)d_tmp_key, items, d_cnt, (const uint32_t*)d_off, d_cursor,
                        (uint32_t*)d_entries); }
+    // round 0 does not need the maximum: it is issued before the host waits for it
+    { ProfScope ps(ctx, "msm_accum_affine");
+    hipLaunchKernelGGL(k_accum_affine, dim3(div_up(div_up(items, L), 256), (unsigned)ncols), dim3(256), 0, st,
+                       (const uint32_t* const*)((const void**)d_colptrs + ncols), (const uint32_t*)d_entries, items, (const uint32_t*)d_off,
+                       (const uint32_t*)d_offA, B, L, (uint32_t*)d_pA, pstride0); }
     ZK_LAUNCH_CHECK();
     ZK_HIP(stream_wait(st));
-    uint32_t maxcnt = 0;
+    uint32_t maxcnt = 0;   // most partial sums in one bucket
     for (size_t j = 0; j < ncols; ++j) maxcnt = std::max(maxcnt, h_max[j]);
     if (maxcnt == 0) {
         hipLaunchKernelGGL(k_set_identity, dim3(div_up(ncols, 64)), dim3(64), 0, st, (uint32_t*)d_out, (uint32_t)ncols);
         ZK_LAUNCH_CHECK();
         return ZKHIP_OK;
     }
-    // round 0 (its plan was computed together with the bucket offsets)
-    const uint32_t* cur_cnt = (const uint32_t*)d_cnt;
-    const uint32_t* cur_off = (const uint32_t*)d_off;
-    uint32_t* nxt_cnt = (uint32_t*)d_cntA;
-    uint32_t* nxt_off = (uint32_t*)d_offA;
-    size_t bound = items / seg + B + 1;
-    if (bound > pstride0) bound = pstride0;
-    { ProfScope ps(ctx, "msm_accum_affine");
-    hipLaunchKernelGGL(k_accum_affine, dim3(div_up(bound, 256), (unsigned)ncols), dim3(256), 0, st,
-                       (const uint32_t* const*)((const void**)d_colptrs + ncols),
-                       (const uint32_t*)d_entries, items, cur_cnt, cur_off, (const uint32_t*)nxt_off, B, seg, (uint32_t*)d_pA,
-                       pstride0); }
+    const uint32_t* cur_cnt = (const uint32_t*)d_cntA;
+    const uint32_t* cur_off = (const uint32_t*)d_offA;
+    uint32_t* nxt_cnt = (uint32_t*)d_cntB;
+    uint32_t* nxt_off = (uint32_t*)d_offB;
     uint32_t* cur_p = (uint32_t*)d_pA;
     uint32_t* nxt_p = (uint32_t*)d_pB;
-    cur_cnt = nxt_cnt; cur_off = nxt_off;
-    nxt_cnt = (uint32_t*)d_cntB; nxt_off = (uint32_t*)d_offB;
-    maxcnt = (maxcnt + seg - 1) / seg;
-    while (maxcnt > 1) {
+    size_t bound = items / L + B + 1;
+    if (bound > pstride0) bound = pstride0;
+    // the tail folds up to tail_parts partial sums per bucket itself; heavier buckets (skewed scalars) go through reduction rounds
+    uint32_t tail_parts = 8;
+    if (const char* e = getenv("ZKHIP_MSM_TAILPARTS")) { int v = atoi(e); if (v >= 1 && v <= 64) tail_parts = (uint32_t)v; }
+    while (maxcnt > tail_parts) {
         seg = maxcnt <= 16 ? maxcnt : 8;
         { ProfScope ps(ctx, "msm_plan");
         ZK_TRY(launch_plan(ctx, (unsigned)ncols, cur_cnt, B, seg, (uint32_t*)nullptr, nxt_cnt, nxt_off, (uint32_t*)nullptr)); }
@@ -797,7 +845,6 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
         const uint32_t* tc = cur_cnt; const uint32_t* to = cur_off;
         cur_cnt = nxt_cnt; cur_off = nxt_off;
         nxt_cnt = (uint32_t*)tc; nxt_off = (uint32_t*)to;
-        if (nxt_cnt == (uint32_t*)d_cnt) { nxt_cnt = (uint32_t*)d_cntB; nxt_off = (uint32_t*)d_offB; }
         maxcnt = (maxcnt + seg - 1) / seg;
     }
     { ProfScope ps(ctx, "msm_tail");
