@@ -117,7 +117,7 @@ __device__ __forceinline__ void tile_ntt(fe* tile, uint32_t s, uint32_t logT, co
             // w^(j << (m-1-st)) = bf[j << (bf_bits - st)]   (tw.bf_shift = bf_bits; s <= bf_bits + 1)
             if (j != 0) bw = tile_el(tile[i1]) * load_raw<Fr>(tw.bf + ((size_t)j << (tw.bf_shift - st)) * 8);
             else if (st == 0) bw = el2<Fr>(tile[i1]);   // fresh loads are < 2p: twiddle 1 needs no product
-            else bw = reduce(tile_el(tile[i1]));         // twiddle 1 later on: contract so the +3p/stage bound holds
+            else bw = canonical(tile_el(tile[i1]));      // twiddle 1 later on: contract (conditional subtractions, no product) so the +3p/stage bound holds
             fe sum, dif;
 #pragma unroll
             for (int q = 0; q < 9; ++q) {
