@@ -170,13 +170,9 @@ static int divide_round(zkhip_ctx* ctx, size_t n, const std::vector<KdEntry>& en
     return ZKHIP_OK;
 }
 
-extern "C" {
-
-int zkhip_linear_combination_device(zkhip_ctx* ctx, size_t n, const void* const* d_polys, size_t npolys, const uint64_t* coeffs,
-                                    const uint64_t* low, size_t nlow, void* d_out) {
-    if (!ctx || !d_out || (npolys && (!d_polys || !coeffs)) || (nlow && !low)) { set_error("zkhip_linear_combination_device: null argument"); return ZKHIP_EINVAL; }
-    if (nlow > n || nlow > LC_LOW_MAX) { set_error("zkhip_linear_combination_device: nlow = %zu unsupported (<= min(n, %d))", nlow, LC_LOW_MAX); return ZKHIP_EINVAL; }
-    if (n == 0) return ZKHIP_OK;
+// out = sum_j c_j polys[j] - low with the scalars already in R' form (raw) and low in ABI scale
+static int lincomb_raw(zkhip_ctx* ctx, size_t n, const void* const* d_polys, size_t npolys, const fe32* coeffs_raw, const fe32* low_abi,
+                       size_t nlow, void* d_out) {
     ProfScope ps(ctx, "linear_combination");
     size_t done = 0;
     do {
@@ -186,15 +182,260 @@ int zkhip_linear_combination_device(zkhip_ctx* ctx, size_t n, const void* const*
         memset(&A, 0, sizeof A);
         for (uint32_t j = 0; j < cnt; ++j) {
             A.p[j] = (const uint32_t*)d_polys[done + j];
-            A.c[j] = abi_to_raw(coeffs + 4 * (done + j));
+            A.c[j] = coeffs_raw[done + j];
         }
-        if (last) for (size_t j = 0; j < nlow; ++j) A.low[j] = mem_load(low + 4 * j);
+        if (last) for (size_t j = 0; j < nlow; ++j) A.low[j] = low_abi[j];
         hipLaunchKernelGGL(k_lincomb, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, A, cnt, n, last ? (uint32_t)nlow : 0u, done ? 1 : 0,
                            (uint32_t*)d_out);
         done += cnt;
     } while (done < npolys);
     ZK_LAUNCH_CHECK();
     return ZKHIP_OK;
+}
+
+// ------------------------------------------------------------------ ProverSHPLONK::create_proof, host side
+// Field values on the host: R' form, canonical.
+namespace {
+struct HF { fe v; };
+inline HF hf(const el1<Fr>& e) { return HF{e.v}; }
+inline el1<Fr> E(const HF& a) { return el1<Fr>(a.v); }
+inline HF hmul(const HF& a, const HF& b) { return hf(canonical(E(a) * E(b))); }
+inline HF hadd(const HF& a, const HF& b) { return hf(canonical(E(a) + E(b))); }
+inline HF hsub(const HF& a, const HF& b) { return hf(canonical(E(a) - E(b))); }
+inline HF hzero() { return hf(zero<Fr>()); }
+inline HF hone() { return hf(one<Fr>()); }
+inline HF hf_from_abi(const uint64_t* p) { return hf(canonical(from_abi<Fr>(mem_load(p)))); }
+inline fe32 hf_raw(const HF& a) { return fe_pack(a.v); }                 // what the kernels take as a scalar
+inline fe32 hf_abi(const HF& a) { return to_abi(E(a)); }                 // polynomial-coefficient scale
+inline bool hf_is_zero(const HF& a) { return fe_is_zero_exact(a.v); }
+// one Fermat inversion for the whole list (Montgomery's trick); zeros are not expected
+void hf_batch_invert(std::vector<HF>& xs) {
+    std::vector<HF> pre(xs.size());
+    HF acc = hone();
+    for (size_t i = 0; i < xs.size(); ++i) { pre[i] = acc; acc = hmul(acc, xs[i]); }
+    HF iv = hf(canonical(inv<Fr>(el2<Fr>(E(acc)))));
+    for (size_t i = xs.size(); i-- > 0;) { HF t = hmul(iv, pre[i]); iv = hmul(iv, xs[i]); xs[i] = t; }
+}
+struct Words { uint32_t w[8]; };
+inline Words canon_words(const HF& a) { fe32 m = to_canonical_words(E(a)); Words r; for (int i = 0; i < 8; ++i) r.w[i] = m.w[i]; return r; }
+inline bool words_less(const Words& a, const Words& b) {
+    for (int i = 7; i >= 0; --i) if (a.w[i] != b.w[i]) return a.w[i] < b.w[i];
+    return false;
+}
+struct RotSet {
+    std::vector<uint32_t> points;                 // indices into the unique point list, ascending by field value
+    std::vector<uint32_t> commits;                // polynomial indices, query order
+    std::vector<std::vector<HF>> evals;           // [commit][point]
+    std::vector<std::vector<HF>> interp;          // [commit][degree]: the low-degree equivalent R_ij
+    std::vector<HF> inv_den;                      // 1 / prod_{s != r} (r - s) per point
+};
+}  // namespace
+
+extern "C" {
+
+int zkhip_shplonk_open(zkhip_ctx* ctx, const zkhip_srs* srs, size_t n, const void* const* d_polys, size_t npolys, const uint32_t* query_poly,
+                       const uint64_t* query_points, const uint64_t* query_evals, size_t nq, const zk_transcript* tr, uint64_t h1_xy[8],
+                       uint64_t h2_xy[8]) {
+    if (!ctx || !srs || !d_polys || !query_poly || !query_points || !query_evals || !tr || !tr->write_point || !tr->squeeze_challenge || !h1_xy || !h2_xy) {
+        set_error("zkhip_shplonk_open: null argument");
+        return ZKHIP_EINVAL;
+    }
+    if (nq == 0 || n == 0 || n > zkhip_srs_len(srs)) { set_error("zkhip_shplonk_open: bad sizes (n = %zu, queries = %zu)", n, nq); return ZKHIP_EINVAL; }
+    // ---- construct_intermediate_sets: unique points (by value), the point set of every commitment, sets in first-appearance order
+    std::vector<HF> upts;
+    std::vector<Words> uwords;
+    std::vector<uint32_t> q_pt(nq);
+    for (size_t i = 0; i < nq; ++i) {
+        if (query_poly[i] >= npolys) { set_error("zkhip_shplonk_open: query %zu names polynomial %u of %zu", i, query_poly[i], npolys); return ZKHIP_EINVAL; }
+        HF pnt = hf_from_abi(query_points + 4 * i);
+        Words w = canon_words(pnt);
+        uint32_t j = 0;
+        for (; j < upts.size(); ++j) if (memcmp(uwords[j].w, w.w, 32) == 0) break;
+        if (j == upts.size()) { upts.push_back(pnt); uwords.push_back(w); }
+        q_pt[i] = j;
+    }
+    const uint32_t np = (uint32_t)upts.size();
+    if (np > LC_LOW_MAX) { set_error("zkhip_shplonk_open: %u distinct points (max %d)", np, LC_LOW_MAX); return ZKHIP_EINVAL; }
+    std::vector<uint32_t> order(np);            // point indices ascending by value = the super point set
+    for (uint32_t i = 0; i < np; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return words_less(uwords[a], uwords[b]); });
+    std::vector<uint32_t> rank(np);
+    for (uint32_t i = 0; i < np; ++i) rank[order[i]] = i;
+    struct Commit { uint32_t poly; std::vector<std::pair<uint32_t, HF>> q; };   // (point, eval), points distinct
+    std::vector<Commit> commits;
+    for (size_t i = 0; i < nq; ++i) {
+        size_t c = 0;
+        for (; c < commits.size(); ++c) if (commits[c].poly == query_poly[i]) break;
+        if (c == commits.size()) commits.push_back(Commit{query_poly[i], {}});
+        bool dup = false;
+        for (auto& pe : commits[c].q) dup |= pe.first == q_pt[i];
+        if (!dup) commits[c].q.push_back({q_pt[i], hf_from_abi(query_evals + 4 * i)});
+    }
+    std::vector<RotSet> sets;
+    for (auto& cm : commits) {
+        std::sort(cm.q.begin(), cm.q.end(), [&](const std::pair<uint32_t, HF>& a, const std::pair<uint32_t, HF>& b) { return rank[a.first] < rank[b.first]; });
+        std::vector<uint32_t> pts;
+        std::vector<HF> ev;
+        for (auto& pe : cm.q) { pts.push_back(pe.first); ev.push_back(pe.second); }
+        size_t s_ = 0;
+        for (; s_ < sets.size(); ++s_) if (sets[s_].points == pts) break;
+        if (s_ == sets.size()) { sets.push_back(RotSet()); sets.back().points = pts; }
+        sets[s_].commits.push_back(cm.poly);
+        sets[s_].evals.push_back(ev);
+    }
+    const size_t nsets = sets.size();
+    // ---- y, v
+    uint64_t ch[4];
+    tr->squeeze_challenge(tr->user, ch);
+    const HF y = hf_from_abi(ch);
+    tr->squeeze_challenge(tr->user, ch);
+    const HF v = hf_from_abi(ch);
+    // ---- Lagrange denominators of every set in one inversion; interpolants R_ij; numerators
+    {
+        std::vector<HF> dens;
+        for (auto& rs : sets)
+            for (uint32_t a : rs.points) {
+                HF d = hone();
+                for (uint32_t b : rs.points) if (b != a) d = hmul(d, hsub(upts[a], upts[b]));
+                dens.push_back(d);
+            }
+        hf_batch_invert(dens);
+        size_t o = 0;
+        for (auto& rs : sets) { rs.inv_den.assign(dens.begin() + o, dens.begin() + o + rs.points.size()); o += rs.points.size(); }
+    }
+    size_t total_roots = 0;
+    for (auto& rs : sets) total_roots += rs.points.size();
+    void *d_num, *d_quot, *d_hx, *d_lx, *d_com;
+    ZK_TRY(ctx->get_scratch("sp_num", nsets * n * 32, &d_num));
+    ZK_TRY(ctx->get_scratch("sp_quot", total_roots * n * 32, &d_quot));
+    ZK_TRY(ctx->get_scratch("sp_hx", n * 32, &d_hx));
+    ZK_TRY(ctx->get_scratch("sp_lx", n * 32, &d_lx));
+    ZK_TRY(ctx->get_scratch("sp_com", 96, &d_com));
+    for (size_t si = 0; si < nsets; ++si) {
+        RotSet& rs = sets[si];
+        const size_t m = rs.points.size();
+        // basis_i(X) = inv_den_i * prod_{j != i} (X - x_j), coefficients ascending
+        std::vector<std::vector<HF>> basis(m);
+        for (size_t i = 0; i < m; ++i) {
+            std::vector<HF> num(1, hone());
+            for (size_t j = 0; j < m; ++j) {
+                if (j == i) continue;
+                std::vector<HF> nx(num.size() + 1, hzero());
+                for (size_t d = 0; d < num.size(); ++d) { nx[d + 1] = hadd(nx[d + 1], num[d]); nx[d] = hsub(nx[d], hmul(upts[rs.points[j]], num[d])); }
+                num.swap(nx);
+            }
+            for (auto& c : num) c = hmul(c, rs.inv_den[i]);
+            basis[i] = num;
+        }
+        std::vector<HF> low(m, hzero());
+        std::vector<fe32> coeffs;
+        std::vector<const void*> ptrs;
+        HF yp = hone();
+        for (size_t ci = 0; ci < rs.commits.size(); ++ci) {
+            std::vector<HF> r(m, hzero());
+            for (size_t i = 0; i < m; ++i)
+                for (size_t d = 0; d < m; ++d) r[d] = hadd(r[d], hmul(rs.evals[ci][i], basis[i][d]));
+            for (size_t d = 0; d < m; ++d) low[d] = hadd(low[d], hmul(yp, r[d]));
+            rs.interp.push_back(r);
+            coeffs.push_back(hf_raw(yp));
+            ptrs.push_back(d_polys[rs.commits[ci]]);
+            yp = hmul(yp, y);
+        }
+        std::vector<fe32> low_abi(m);
+        for (size_t d = 0; d < m; ++d) low_abi[d] = hf_abi(low[d]);
+        ZK_TRY(lincomb_raw(ctx, n, ptrs.data(), ptrs.size(), coeffs.data(), low_abi.data(), m, (char*)d_num + si * n * 32));
+    }
+    // ---- all divisions in one pass (partial fractions), then h(X) = sum_i v^i sum_r Q_ir / prod_{s != r} (r - s)
+    std::vector<HF> vpow(nsets);
+    {
+        HF acc = hone();
+        for (size_t i = 0; i < nsets; ++i) { vpow[i] = acc; acc = hmul(acc, v); }
+    }
+    {
+        std::vector<KdEntry> ents;
+        std::vector<fe32> weights;
+        std::vector<const void*> ptrs;
+        size_t o = 0;
+        for (size_t si = 0; si < nsets; ++si)
+            for (size_t i = 0; i < sets[si].points.size(); ++i, ++o) {
+                KdEntry e;
+                e.src = (const uint32_t*)((char*)d_num + si * n * 32);
+                e.dst = (uint32_t*)((char*)d_quot + o * n * 32);
+                e.r = hf_raw(upts[sets[si].points[i]]);
+                ents.push_back(e);
+                weights.push_back(hf_raw(hmul(vpow[si], sets[si].inv_den[i])));
+                ptrs.push_back(e.dst);
+            }
+        { ProfScope ps(ctx, "kate_division"); ZK_TRY(divide_round(ctx, n, ents)); }
+        ZK_TRY(lincomb_raw(ctx, n, ptrs.data(), ptrs.size(), weights.data(), nullptr, 0, d_hx));
+    }
+    uint8_t bytes[32];
+    {
+        const void* col[1] = {d_hx};
+        ZK_TRY(zkhip_msm_g1_batch_device(ctx, srs, col, 1, n, d_com));
+        ZK_TRY(zkhip_commitments_read(ctx, d_com, 1, h1_xy, bytes));
+        tr->write_point(tr->user, bytes, h1_xy);
+    }
+    // ---- u; L(X) = sum_i v^i z_i sum_j y^j (P_ij(X) - R_ij(u)) - Z_T(u) h(X), all scaled by 1 / z_0; h'(X) = L(X) / (X - u)
+    tr->squeeze_challenge(tr->user, ch);
+    const HF u = hf_from_abi(ch);
+    std::vector<HF> zdiff(nsets);
+    HF zt = hone();
+    for (uint32_t a = 0; a < np; ++a) zt = hmul(zt, hsub(u, upts[a]));
+    for (size_t si = 0; si < nsets; ++si) {
+        HF z = hone();
+        for (uint32_t a = 0; a < np; ++a) {
+            bool in_set = false;
+            for (uint32_t b : sets[si].points) in_set |= b == a;
+            if (!in_set) z = hmul(z, hsub(u, upts[a]));
+        }
+        zdiff[si] = z;
+    }
+    if (hf_is_zero(zdiff[0])) { set_error("zkhip_shplonk_open: the challenge u hit an opening point"); return ZKHIP_EINVAL; }
+    std::vector<HF> one_inv(1, zdiff[0]);
+    hf_batch_invert(one_inv);
+    const HF inv0 = one_inv[0];
+    {
+        std::vector<fe32> coeffs;
+        std::vector<const void*> ptrs;
+        HF konst = hzero();
+        for (size_t si = 0; si < nsets; ++si) {
+            HF yp = hone();
+            const HF scale = hmul(hmul(vpow[si], zdiff[si]), inv0);
+            for (size_t ci = 0; ci < sets[si].commits.size(); ++ci) {
+                HF c = hmul(scale, yp);
+                HF ru = hzero();   // R_ij(u) by Horner
+                for (size_t d = sets[si].interp[ci].size(); d-- > 0;) ru = hadd(hmul(ru, u), sets[si].interp[ci][d]);
+                konst = hadd(konst, hmul(c, ru));
+                coeffs.push_back(hf_raw(c));
+                ptrs.push_back(d_polys[sets[si].commits[ci]]);
+                yp = hmul(yp, y);
+            }
+        }
+        coeffs.push_back(hf_raw(hsub(hzero(), hmul(zt, inv0))));
+        ptrs.push_back(d_hx);
+        fe32 low_abi = hf_abi(konst);
+        ZK_TRY(lincomb_raw(ctx, n, ptrs.data(), ptrs.size(), coeffs.data(), &low_abi, 1, d_lx));
+        std::vector<KdEntry> ents(1);
+        ents[0].src = (const uint32_t*)d_lx; ents[0].dst = (uint32_t*)d_lx; ents[0].r = hf_raw(u);
+        { ProfScope ps(ctx, "kate_division"); ZK_TRY(divide_round(ctx, n, ents)); }
+        const void* col[1] = {d_lx};
+        ZK_TRY(zkhip_msm_g1_batch_device(ctx, srs, col, 1, n, d_com));
+        ZK_TRY(zkhip_commitments_read(ctx, d_com, 1, h2_xy, bytes));
+        tr->write_point(tr->user, bytes, h2_xy);
+    }
+    return ZKHIP_OK;
+}
+
+int zkhip_linear_combination_device(zkhip_ctx* ctx, size_t n, const void* const* d_polys, size_t npolys, const uint64_t* coeffs,
+                                    const uint64_t* low, size_t nlow, void* d_out) {
+    if (!ctx || !d_out || (npolys && (!d_polys || !coeffs)) || (nlow && !low)) { set_error("zkhip_linear_combination_device: null argument"); return ZKHIP_EINVAL; }
+    if (nlow > n || nlow > LC_LOW_MAX) { set_error("zkhip_linear_combination_device: nlow = %zu unsupported (<= min(n, %d))", nlow, LC_LOW_MAX); return ZKHIP_EINVAL; }
+    if (n == 0) return ZKHIP_OK;
+    std::vector<fe32> cf(npolys ? npolys : 1), lw(nlow ? nlow : 1);
+    for (size_t j = 0; j < npolys; ++j) cf[j] = abi_to_raw(coeffs + 4 * j);
+    for (size_t j = 0; j < nlow; ++j) lw[j] = mem_load(low + 4 * j);
+    return lincomb_raw(ctx, n, d_polys, npolys, cf.data(), lw.data(), nlow, d_out);
 }
 
 int zkhip_divide_by_linear_device(zkhip_ctx* ctx, size_t n, const void* const* d_src, void* const* d_dst, size_t npolys, const uint64_t* roots) {

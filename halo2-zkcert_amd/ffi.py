@@ -67,7 +67,7 @@ SYMBOLS = [
     "zkhip_evaluate_h_device", "zkhip_synth_fill_device",
     "zkhip_batch_invert_device", "zkhip_eval_polynomial_device", "zkhip_eval_polynomials_at_device", "zkhip_permutation_products_device",
     "zkhip_permute_expression_pair_device", "zkhip_lookup_product_device", "zkhip_grand_products_device",
-    "zkhip_linear_combination_device", "zkhip_divide_by_linear_device", "zkhip_kate_division_device",
+    "zkhip_linear_combination_device", "zkhip_divide_by_linear_device", "zkhip_kate_division_device", "zkhip_shplonk_open",
 ]
 
 
@@ -283,6 +283,38 @@ def kate_division_device(ctx, polys, roots):
     counts = np.array([len(r) for r in roots], dtype=np.uint32)
     flat = _u64(np.concatenate([_u64(r).reshape(-1, 4) for r in roots if len(r)])) if counts.sum() else np.zeros((1, 4), dtype=np.uint64)
     _check(lib().zkhip_kate_division_device(ctx.h, C.c_size_t(n), _ptr_array(polys), C.c_size_t(len(polys)), _p(counts), _p(flat)))
+
+
+WRITE_POINT_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint64))
+SQUEEZE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint64))
+
+
+class ZkTranscript(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("write_point", WRITE_POINT_FN), ("squeeze_challenge", SQUEEZE_FN)]
+
+
+def shplonk_open(ctx, params, polys, query_poly, query_points, query_evals, write_point, squeeze_challenge):
+    """ProverSHPLONK::create_proof in the library.  polys: device polynomials; query_poly: index per query; query_points /
+    query_evals: (nq, 4) ABI arrays; write_point(bytes32, xy (8,) uint64 array); squeeze_challenge() -> (4,) ABI limbs.
+    Returns (h1_xy, h2_xy)."""
+    nq = len(query_poly)
+    qp = np.ascontiguousarray(query_poly, dtype=np.uint32)
+    pts = _u64(query_points).reshape(nq, 4)
+    evs = _u64(query_evals).reshape(nq, 4)
+
+    def _wp(user, b, xy):
+        write_point(bytes(bytearray(b[i] for i in range(32))), np.array([xy[i] for i in range(8)], dtype=np.uint64))
+
+    def _sq(user, out):
+        limbs = squeeze_challenge()
+        for i in range(4):
+            out[i] = int(limbs[i])
+
+    t = ZkTranscript(None, WRITE_POINT_FN(_wp), SQUEEZE_FN(_sq))
+    h1, h2 = np.zeros(8, dtype=np.uint64), np.zeros(8, dtype=np.uint64)
+    _check(lib().zkhip_shplonk_open(ctx.h, params.g, C.c_size_t(polys[0].shape[0]), _ptr_array(polys), C.c_size_t(len(polys)), _p(qp), _p(pts),
+                                    _p(evs), C.c_size_t(nq), C.byref(t), _p(h1), _p(h2)))
+    return h1, h2
 
 
 def lookup_product_device(ctx, k, cin, ctab, pin, ptab, beta, gamma, blinding_factors, blinding):

@@ -213,6 +213,33 @@ class GpuBackend:
         """-> new polynomials srcs[j] / (X - roots[j])"""
         return self.ffi.divide_by_linear_device(self.ctx, srcs, self.fr_many(roots))
 
+    def multiopen(self, polys, queries, flat_evals, squeeze, write_points):
+        """ProverSHPLONK::create_proof inside the library (zkhip_shplonk_open); the transcript stays with the caller.
+        queries: [(key, point int, eval int)]; flat_evals: the same evaluations as (nq, 4) ABI rows."""
+        keys = list(polys)
+        index = {key: i for i, key in enumerate(keys)}
+        mont = {}
+        for _, pt, _ in queries:
+            if pt not in mont:
+                mont[pt] = fr_from_int_host(pt)
+        got = {}
+        tags_sq = iter(("shplonk_y", "shplonk_v", "shplonk_u"))
+        tags_wp = iter(("shplonk_h1", "shplonk_h2"))
+
+        def sq():
+            tag = next(tags_sq)
+            got[tag] = squeeze(tag)
+            return fr_from_int_host(got[tag])
+
+        def wp(byts, xy):
+            tag = next(tags_wp)
+            got[tag] = (xy, byts)
+            write_points(tag, [(xy, byts)])
+
+        self.ffi.shplonk_open(self.ctx, self.params, [polys[key] for key in keys], [index[key] for key, _, _ in queries],
+                              np.stack([mont[pt] for _, pt, _ in queries]), flat_evals, wp, sq)
+        return dict(y=got["shplonk_y"], v=got["shplonk_v"], u=got["shplonk_u"], h1=got["shplonk_h1"], h2=got["shplonk_h2"])
+
     def kate_division(self, polys, roots):
         """in place: polys[j] /= prod (X - r), r in roots[j] (canonical ints)"""
         self.ffi.kate_division_device(self.ctx, polys, [self.fr_many(r) for r in roots])
@@ -342,6 +369,8 @@ class ShardedCommit:
         self.inner, self.rank, self.world, self.dist = inner, rank, world, dist
 
     def __getattr__(self, name):
+        if name == "multiopen":      # the library's one-call multi-open commits unsharded: use the host-side prover over commit()
+            raise AttributeError(name)
         return getattr(self.inner, name)
 
     def commit(self, cols, lagrange):
@@ -636,8 +665,11 @@ class Prover:
         # 6. SHPLONK multi-open of all of them: two more commitments
         def write_points(tag, pts):
             tx.extend(absorb(tag, pts))
-        opening = ShplonkProver(b).create_proof(polys, [(key, pt, evals[(key, rot)]) for (key, rot), pt in zip(qlist, points)],
-                                                lambda tag: challenge(tag, tx), write_points)
+        queries = [(key, pt, evals[(key, rot)]) for (key, rot), pt in zip(qlist, points)]
+        if hasattr(b, "multiopen"):      # the library's ProverSHPLONK (host arithmetic in C++)
+            opening = b.multiopen(polys, queries, flat, lambda tag: challenge(tag, tx), write_points)
+        else:
+            opening = ShplonkProver(b).create_proof(polys, queries, lambda tag: challenge(tag, tx), write_points)
         trace["challenges"] = dict(theta=theta, beta=beta, gamma=gamma, y=y, x=x, shplonk_y=opening["y"], shplonk_v=opening["v"],
                                    shplonk_u=opening["u"])
         trace["opening"] = opening

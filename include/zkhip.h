@@ -239,6 +239,21 @@ int  zkhip_divide_by_linear_device(zkhip_ctx* ctx, size_t n, const void* const* 
  * coefficients are zero, i.e. the result is already "resized to n". */
 int  zkhip_kate_division_device(zkhip_ctx* ctx, size_t n, void* const* d_polys, size_t npolys, const uint32_t* nroots, const uint64_t* roots);
 
+/* ProverSHPLONK::create_proof (poly/kzg/multiopen/shplonk/prover.rs) in one call, with the transcript as callbacks in the
+ * order upstream uses it: squeeze y, squeeze v, write_point(h), squeeze u, write_point(h').  Query i opens polynomial
+ * d_polys[query_poly[i]] (n coefficients, device) at query_points[i] with value query_evals[i] (host arrays, nq x 4 u64, ABI form;
+ * the caller has computed the evaluations, e.g. with zkhip_eval_polynomials_at_device).  Rotation sets are formed as in
+ * construct_intermediate_sets (commitments in query order, points ascending).  Scalars cross the callbacks in ABI form, points
+ * as 32 compressed bytes and as affine (x, y).  At most 8 distinct points. */
+typedef struct zk_transcript {
+    void* user;
+    void (*write_point)(void* user, const uint8_t bytes32[32], const uint64_t xy[8]);
+    void (*squeeze_challenge)(void* user, uint64_t out[4]);
+} zk_transcript;
+int  zkhip_shplonk_open(zkhip_ctx* ctx, const zkhip_srs* srs, size_t n, const void* const* d_polys, size_t npolys, const uint32_t* query_poly,
+                        const uint64_t* query_points, const uint64_t* query_evals, size_t nq, const zk_transcript* transcript,
+                        uint64_t h1_xy[8], uint64_t h2_xy[8]);
+
 /* ---- synthetic tables (bench / tests): element i of a column = raw253(seed, i) taken as the
  * Montgomery limbs (oracle/pyref.py synth_raw253) ---- */
 int  zkhip_synth_fill_device(zkhip_ctx* ctx, void* d_out, size_t n, uint64_t seed, uint64_t first_index);

@@ -109,3 +109,24 @@ def test_divide_by_linear_vs_oracle(zk, oracle, n, count):
         assert (ctx.to_host(outs[j]) == zo.kate_division(srcs[j % len(srcs)], roots[j:j + 1])).all()
     for q, d in zip(srcs, dev):
         assert (ctx.to_host(d) == q).all()          # sources untouched
+
+
+def test_native_multiopen_golden(zk, oracle):
+    """zkhip_shplonk_open (rotation sets, interpolation, partial fractions and the transcript order in C++) against the golden
+    commitments, which the generator checked with the verifier equation."""
+    import halo2_zkcert_amd.prover as pv
+
+    ffi, ctx = zk
+    zo = oracle
+    g, F = _case(zo)
+    b = pv.GpuBackend(ctx, ffi)
+    b.setup(g["k"], 3, H(g["s"]))
+    polys = {i: ctx.to_device(F(c)) for i, c in enumerate(g["polys"])}
+    queries = [(i, H(pt), H(e)) for i, pt, e in g["queries"]]
+    flat = zo.fr_arr_from_ints([e for _, _, e in queries])
+    ch = {"shplonk_y": H(g["y"]), "shplonk_v": H(g["v"]), "shplonk_u": H(g["u"])}
+    order = []
+    pr = b.multiopen(polys, queries, flat, lambda t: (order.append(t), ch[t])[1], lambda t, pts: order.append(t))
+    assert order == ["shplonk_y", "shplonk_v", "shplonk_h1", "shplonk_u", "shplonk_h2"]
+    for got, exp in ((pr["h1"], g["h1"]), (pr["h2"], g["h2"])):
+        assert zo.affine_to_ints(np.asarray(got[0]).reshape(1, 8))[0] == (H(exp[0]), H(exp[1]))
