@@ -459,6 +459,39 @@ ZK_HD inline el2<P> inv(const el2<P>& a) {
     return pow_words<P>(a, e);
 }
 
+// Host-side inverse by the binary extended Euclidean algorithm (~1.5 us against ~40 us for the Fermat chain on one core):
+// the Fiat-Shamir round trips normalise a batch of commitments on the host, with the GPU waiting.  0 -> 0.
+template <class P>
+inline el2<P> inv_host(const el2<P>& a) {
+    typedef unsigned __int128 u128;
+    struct U256 { uint64_t w[4]; };
+    auto from_words = [](const fe32& m) { U256 r; for (int i = 0; i < 4; ++i) r.w[i] = (uint64_t)m.w[2 * i] | ((uint64_t)m.w[2 * i + 1] << 32); return r; };
+    auto is_one = [](const U256& x) { return x.w[0] == 1 && !(x.w[1] | x.w[2] | x.w[3]); };
+    auto is_zero_ = [](const U256& x) { return !(x.w[0] | x.w[1] | x.w[2] | x.w[3]); };
+    auto geq = [](const U256& x, const U256& y) { for (int i = 3; i >= 0; --i) if (x.w[i] != y.w[i]) return x.w[i] > y.w[i]; return true; };
+    auto add = [](U256& x, const U256& y) { u128 c = 0; for (int i = 0; i < 4; ++i) { c += (u128)x.w[i] + y.w[i]; x.w[i] = (uint64_t)c; c >>= 64; } };
+    auto sub = [](U256& x, const U256& y) { uint64_t b = 0; for (int i = 0; i < 4; ++i) { u128 d = (u128)x.w[i] - y.w[i] - b; x.w[i] = (uint64_t)d; b = (uint64_t)(d >> 64) & 1; } };
+    auto shr1 = [](U256& x) { for (int i = 0; i < 3; ++i) x.w[i] = (x.w[i] >> 1) | (x.w[i + 1] << 63); x.w[3] >>= 1; };
+    fe pm;
+    for (int i = 0; i < 9; ++i) pm.l[i] = P::M[i];
+    const U256 p = from_words(fe_pack(pm));
+    U256 u = from_words(fe_pack(fe_canonical<P>(a.v))), v = p, b = {{1, 0, 0, 0}}, c = {{0, 0, 0, 0}};
+    if (is_zero_(u)) return el2<P>(fe_zero());
+    auto halve = [&](U256& x) { if (x.w[0] & 1) add(x, p); shr1(x); };          // x / 2 mod p (x + p < 2^255)
+    auto submod = [&](U256& x, const U256& y) { if (!geq(x, y)) add(x, p); sub(x, y); };
+    while (!is_one(u) && !is_one(v)) {
+        while (!(u.w[0] & 1)) { shr1(u); halve(b); }
+        while (!(v.w[0] & 1)) { shr1(v); halve(c); }
+        if (geq(u, v)) { sub(u, v); submod(b, c); } else { sub(v, u); submod(c, b); }
+    }
+    const U256 y = is_one(u) ? b : c;     // (a R')^-1 as an integer: a^-1 R' = y R'^2 = mont(mont(y, R'^2), R'^2)
+    fe32 m;
+    for (int i = 0; i < 4; ++i) { m.w[2 * i] = (uint32_t)y.w[i]; m.w[2 * i + 1] = (uint32_t)(y.w[i] >> 32); }
+    fe r2;
+    for (int i = 0; i < 9; ++i) r2.l[i] = P::R2[i];
+    return el2<P>(fe_mul_raw<P>(fe_mul_raw<P>(fe_split<0>(m), r2), r2));
+}
+
 // Fr constants as canonical integer words (halo2curves src/bn256/fr.rs): 2^28-th root of unity, ZETA, DELTA.
 constexpr uint32_t FR_S = 28;
 constexpr uint32_t FR_ROOT_OF_UNITY[8] = {0x60c37c9cu, 0xd34f1ed9u, 0xd39329c8u, 0x3215cf6du,

@@ -180,7 +180,7 @@ void zkhip_g1_batch_to_affine(const uint64_t* xyz, size_t n, uint64_t* out_xy) {
         pre[i] = acc;
         if (!g1j_is_id(p[i])) acc = acc * p[i].z;
     }
-    el2<Fq> iv = inv<Fq>(acc);
+    el2<Fq> iv = inv_host<Fq>(acc);
     for (size_t i = n; i-- > 0;) {
         g1a a = g1a_identity();
         if (!g1j_is_id(p[i])) {

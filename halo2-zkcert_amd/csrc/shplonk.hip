@@ -213,7 +213,7 @@ void hf_batch_invert(std::vector<HF>& xs) {
     std::vector<HF> pre(xs.size());
     HF acc = hone();
     for (size_t i = 0; i < xs.size(); ++i) { pre[i] = acc; acc = hmul(acc, xs[i]); }
-    HF iv = hf(canonical(inv<Fr>(el2<Fr>(E(acc)))));
+    HF iv = hf(canonical(inv_host<Fr>(el2<Fr>(E(acc)))));
     for (size_t i = xs.size(); i-- > 0;) { HF t = hmul(iv, pre[i]); iv = hmul(iv, xs[i]); xs[i] = t; }
 }
 struct Words { uint32_t w[8]; };

@@ -215,11 +215,11 @@ class GpuBackend:
 
     def multiopen(self, polys, queries, flat_evals, squeeze, write_points):
         """ProverSHPLONK::create_proof inside the library (zkhip_shplonk_open); the transcript stays with the caller.
-        queries: [(key, point int, eval int)]; flat_evals: the same evaluations as (nq, 4) ABI rows."""
+        queries: [(key, point int)]; flat_evals: their evaluations as (nq, 4) ABI rows."""
         keys = list(polys)
         index = {key: i for i, key in enumerate(keys)}
         mont = {}
-        for _, pt, _ in queries:
+        for _, pt in queries:
             if pt not in mont:
                 mont[pt] = fr_from_int_host(pt)
         got = {}
@@ -236,8 +236,8 @@ class GpuBackend:
             got[tag] = (xy, byts)
             write_points(tag, [(xy, byts)])
 
-        self.ffi.shplonk_open(self.ctx, self.params, [polys[key] for key in keys], [index[key] for key, _, _ in queries],
-                              np.stack([mont[pt] for _, pt, _ in queries]), flat_evals, wp, sq)
+        self.ffi.shplonk_open(self.ctx, self.params, [polys[key] for key in keys], [index[key] for key, _ in queries],
+                              np.stack([mont[pt] for _, pt in queries]), flat_evals, wp, sq)
         return dict(y=got["shplonk_y"], v=got["shplonk_v"], u=got["shplonk_u"], h1=got["shplonk_h1"], h2=got["shplonk_h2"])
 
     def kate_division(self, polys, roots):
@@ -405,6 +405,11 @@ def from_mont_host(limbs):
     """Montgomery limbs (4 x u64) -> canonical int"""
     v = sum(int(limbs[i]) << (64 * i) for i in range(4))
     return v * R_INV_256 % R
+
+
+def eval_ints(trace):
+    """(key, rotation) -> canonical int for every evaluation of a proof trace"""
+    return {q_: from_mont_host(row) for q_, row in trace["evals"]}
 
 
 def splitmix64(x):
@@ -656,19 +661,18 @@ class Prover:
         polys[("h", 0)] = b.lincomb(pieces, [pow(xn, i_, R) for i_ in range(len(pieces))], None)   # sum_i x^(n i) h_i(X)
         points = [x * pow(self.omega, rot % n, R) % R for _, rot in qlist]
         flat = b.eval_polys_at([polys[key] for key, _ in qlist], points)
-        evals = {q_: from_mont_host(flat[i_]) for i_, q_ in enumerate(qlist)}
         trace["evals"] = [(q_, flat[i_]) for i_, q_ in enumerate(qlist)]
-        trace["eval_ints"] = evals
         trace["query_list"] = qlist
         # the transcript receives every evaluation except h's (the verifier recomputes it)
         tx = t1 + t2 + t3 + t4 + t5 + [flat[i_].tobytes() for i_, q_ in enumerate(qlist) if q_[0][0] != "h"]
         # 6. SHPLONK multi-open of all of them: two more commitments
         def write_points(tag, pts):
             tx.extend(absorb(tag, pts))
-        queries = [(key, pt, evals[(key, rot)]) for (key, rot), pt in zip(qlist, points)]
-        if hasattr(b, "multiopen"):      # the library's ProverSHPLONK (host arithmetic in C++)
-            opening = b.multiopen(polys, queries, flat, lambda tag: challenge(tag, tx), write_points)
+        if hasattr(b, "multiopen"):      # the library's ProverSHPLONK (host arithmetic in C++; evaluations stay in ABI form)
+            opening = b.multiopen(polys, [(key, pt) for (key, _), pt in zip(qlist, points)], flat, lambda tag: challenge(tag, tx), write_points)
         else:
+            evals = eval_ints(trace)
+            queries = [(key, pt, evals[(key, rot)]) for (key, rot), pt in zip(qlist, points)]
             opening = ShplonkProver(b).create_proof(polys, queries, lambda tag: challenge(tag, tx), write_points)
         trace["challenges"] = dict(theta=theta, beta=beta, gamma=gamma, y=y, x=x, shplonk_y=opening["y"], shplonk_v=opening["v"],
                                    shplonk_u=opening["u"])

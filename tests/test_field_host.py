@@ -49,6 +49,8 @@ def test_mul_inv_chain(zt, oracle, field):
         assert to(o) == (t * t - mm) % m
         getattr(zt, f"zkt_{field}_inv")(zo.p(A), zo.p(o))
         assert to(o) == (pow(a, -1, m) if a else 0)
+        getattr(zt, f"zkt_{field}_inv_host")(zo.p(A), zo.p(o))      # binary extended Euclid used on the host paths
+        assert to(o) == (pow(a, -1, m) if a else 0)
 
 
 def test_conversions(zt, oracle):

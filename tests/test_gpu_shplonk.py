@@ -126,7 +126,7 @@ def test_native_multiopen_golden(zk, oracle):
     flat = zo.fr_arr_from_ints([e for _, _, e in queries])
     ch = {"shplonk_y": H(g["y"]), "shplonk_v": H(g["v"]), "shplonk_u": H(g["u"])}
     order = []
-    pr = b.multiopen(polys, queries, flat, lambda t: (order.append(t), ch[t])[1], lambda t, pts: order.append(t))
+    pr = b.multiopen(polys, [(i, pt) for i, pt, _ in queries], flat, lambda t: (order.append(t), ch[t])[1], lambda t, pts: order.append(t))
     assert order == ["shplonk_y", "shplonk_v", "shplonk_h1", "shplonk_u", "shplonk_h2"]
     for got, exp in ((pr["h1"], g["h1"]), (pr["h2"], g["h2"])):
         assert zo.affine_to_ints(np.asarray(got[0]).reshape(1, 8))[0] == (H(exp[0]), H(exp[1]))

@@ -34,7 +34,9 @@ def verify_trace(prover, wit, trace, srs_trapdoor=0x1D5C0FFEE, tamper=None):
     for i, c in enumerate(b.commit(prover.sigma_coeff, lagrange=False)):
         coms[("sigma", i)] = _pts([c[0]])[0]
     h_pieces = _pts(pts["quotient"])
-    evals = {q: v for q, v in trace["eval_ints"].items() if q[0] != ("h", 0)}
+    import halo2_zkcert_amd.prover as pv
+
+    evals = {q: v for q, v in pv.eval_ints(trace).items() if q[0] != ("h", 0)}
     instance = [zo.fr_arr_to_ints(b.to_host(c)) for c in wit["instance"]]
     h1, h2 = _pts(pts["shplonk_h1"])[0], _pts(pts["shplonk_h2"])[0]
     if tamper:
