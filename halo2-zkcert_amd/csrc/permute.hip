@@ -60,8 +60,10 @@ __global__ void k_pe_keys(const uint32_t* col, size_t n, size_t usable, uint32_t
 // Bitonic network: for (k = 2; k <= n; k <<= 1) for (j = k >> 1; j > 0; j >>= 1) compare-exchange(i, i ^ j), ascending iff (i & k) == 0.
 // k_bitonic_tile runs, inside one 2048-element tile held in LDS, every step (k, j) with k_lo <= k <= k_hi and j < 2048
 // (for k > 2048 only the j < 2048 tail of that k).
-__global__ void __launch_bounds__(256) k_bitonic_tile(uint32_t* keys, uint32_t k_lo, uint32_t k_hi) {
+// blockIdx.y selects one of several equally sized key arrays laid out back to back (the input and the table column sort together)
+__global__ void __launch_bounds__(256) k_bitonic_tile(uint32_t* keys_all, size_t n, uint32_t k_lo, uint32_t k_hi) {
     __shared__ key256 t[BT_TILE];
+    uint32_t* keys = keys_all + (size_t)blockIdx.y * n * 8;
     const uint32_t tid = threadIdx.x;
     const size_t base = (size_t)blockIdx.x * BT_TILE;
     for (uint32_t e = tid; e < BT_TILE; e += 256) t[e] = key_load(keys + (base + e) * 8);
@@ -81,7 +83,8 @@ __global__ void __launch_bounds__(256) k_bitonic_tile(uint32_t* keys, uint32_t k
     for (uint32_t e = tid; e < BT_TILE; e += 256) key_store(keys + (base + e) * 8, t[e]);
 }
 // one global step (k, j) with j >= 2048
-__global__ void k_bitonic_global(uint32_t* keys, size_t n, uint32_t k, uint32_t j) {
+__global__ void k_bitonic_global(uint32_t* keys_all, size_t n, uint32_t k, uint32_t j) {
+    uint32_t* keys = keys_all + (size_t)blockIdx.y * n * 8;
     size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (p >= n / 2) return;
     size_t i = ((p & ~((size_t)j - 1)) << 1) | (p & ((size_t)j - 1));
@@ -91,15 +94,37 @@ __global__ void k_bitonic_global(uint32_t* keys, size_t n, uint32_t k, uint32_t 
     if (key_less(b, a) == asc) { key_store(keys + i * 8, b); key_store(keys + l * 8, a); }
 }
 
-static int bitonic_sort(zkhip_ctx* ctx, void* d_keys, size_t n) {
+// two global steps (k, j) and (k, j / 2) in one pass: each thread owns the four keys i + {0, j/2, j, 3j/2}
+__global__ void k_bitonic_global2(uint32_t* keys_all, size_t n, uint32_t k, uint32_t j) {
+    uint32_t* keys = keys_all + (size_t)blockIdx.y * n * 8;
+    size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (p >= n / 4) return;
+    const size_t h = j >> 1;
+    size_t i = ((p & ~(h - 1)) << 2) | (p & (h - 1));   // bits j and j/2 clear
+    bool asc = ((i & k) == 0);
+    key256 a = key_load(keys + i * 8), b = key_load(keys + (i + h) * 8), c = key_load(keys + (i + j) * 8), d = key_load(keys + (i + j + h) * 8);
+    auto cx = [&](key256& x, key256& y) { if (key_less(y, x) == asc) { key256 t = x; x = y; y = t; } };
+    cx(a, c); cx(b, d);   // step j
+    cx(a, b); cx(c, d);   // step j / 2
+    key_store(keys + i * 8, a); key_store(keys + (i + h) * 8, b); key_store(keys + (i + j) * 8, c); key_store(keys + (i + j + h) * 8, d);
+}
+
+static int bitonic_sort(zkhip_ctx* ctx, void* d_keys, size_t n, unsigned narrays) {
     hipStream_t st = ctx->stream;
     if (n < BT_TILE || (n & (n - 1))) { set_error("bitonic_sort: n must be a power of two >= %u", BT_TILE); return ZKHIP_EINVAL; }
     unsigned tiles = (unsigned)(n / BT_TILE);
-    hipLaunchKernelGGL(k_bitonic_tile, dim3(tiles), dim3(256), 0, st, (uint32_t*)d_keys, 2u, BT_TILE);
+    hipLaunchKernelGGL(k_bitonic_tile, dim3(tiles, narrays), dim3(256), 0, st, (uint32_t*)d_keys, n, 2u, BT_TILE);
     for (size_t k = 2 * BT_TILE; k <= n; k <<= 1) {
-        for (size_t j = k >> 1; j >= BT_TILE; j >>= 1)
-            hipLaunchKernelGGL(k_bitonic_global, dim3(div_up(n / 2, 256)), dim3(256), 0, st, (uint32_t*)d_keys, n, (uint32_t)k, (uint32_t)j);
-        hipLaunchKernelGGL(k_bitonic_tile, dim3(tiles), dim3(256), 0, st, (uint32_t*)d_keys, (uint32_t)k, (uint32_t)k);
+        for (size_t j = k >> 1; j >= BT_TILE;) {
+            if ((j >> 1) >= BT_TILE) {
+                hipLaunchKernelGGL(k_bitonic_global2, dim3(div_up(n / 4, 256), narrays), dim3(256), 0, st, (uint32_t*)d_keys, n, (uint32_t)k, (uint32_t)j);
+                j >>= 2;
+            } else {
+                hipLaunchKernelGGL(k_bitonic_global, dim3(div_up(n / 2, 256), narrays), dim3(256), 0, st, (uint32_t*)d_keys, n, (uint32_t)k, (uint32_t)j);
+                j >>= 1;
+            }
+        }
+        hipLaunchKernelGGL(k_bitonic_tile, dim3(tiles, narrays), dim3(256), 0, st, (uint32_t*)d_keys, n, (uint32_t)k, (uint32_t)k);
     }
     ZK_LAUNCH_CHECK();
     return ZKHIP_OK;
@@ -211,8 +236,8 @@ extern "C" int zkhip_permute_expression_pair_device(zkhip_ctx* ctx, uint32_t k, 
     size_t usable = n - (blinding_factors + 1);
     hipStream_t st = ctx->stream;
     void *dA, *dT, *d_flags, *d_ranks, *d_left, *d_misc;
-    ZK_TRY(ctx->get_scratch("pe_keys_a", np * 32, &dA));
-    ZK_TRY(ctx->get_scratch("pe_keys_t", np * 32, &dT));
+    ZK_TRY(ctx->get_scratch("pe_keys", 2 * np * 32, &dA));   // input keys, then table keys: sorted by the same launches
+    dT = (char*)dA + np * 32;
     ZK_TRY(ctx->get_scratch("pe_flags", 2 * n * 4, &d_flags));
     ZK_TRY(ctx->get_scratch("pe_ranks", 2 * n * 4, &d_ranks));
     ZK_TRY(ctx->get_scratch("pe_left", n * 32, &d_left));
@@ -225,8 +250,7 @@ extern "C" int zkhip_permute_expression_pair_device(zkhip_ctx* ctx, uint32_t k, 
     unsigned g = div_up(n, 256);
     hipLaunchKernelGGL(k_pe_keys, dim3(div_up(np, 256)), dim3(256), 0, st, (const uint32_t*)d_input, np, usable, (uint32_t*)dA);
     hipLaunchKernelGGL(k_pe_keys, dim3(div_up(np, 256)), dim3(256), 0, st, (const uint32_t*)d_table, np, usable, (uint32_t*)dT);
-    ZK_TRY(bitonic_sort(ctx, dA, np));
-    ZK_TRY(bitonic_sort(ctx, dT, np));
+    ZK_TRY(bitonic_sort(ctx, dA, np, 2));
     hipLaunchKernelGGL(k_fill_u32, dim3(g), dim3(256), 0, st, left_flag, n, 1u);
     ZK_HIP(hipMemsetAsync(rep_flag, 0, n * 4, st));
     hipLaunchKernelGGL(k_pe_mark, dim3(div_up(usable, 256)), dim3(256), 0, st, (const uint32_t*)dA, (const uint32_t*)dT, usable, rep_flag, left_flag, err);

@@ -659,7 +659,8 @@ class Prover:
         x = challenge("x", t1 + t2 + t3 + t4 + t5)
         xn = pow(x, n, R)
         polys[("h", 0)] = b.lincomb(pieces, [pow(xn, i_, R) for i_ in range(len(pieces))], None)   # sum_i x^(n i) h_i(X)
-        points = [x * pow(self.omega, rot % n, R) % R for _, rot in qlist]
+        rot_point = {rot: x * pow(self.omega, rot % n, R) % R for rot in {rot for _, rot in qlist}}
+        points = [rot_point[rot] for _, rot in qlist]
         flat = b.eval_polys_at([polys[key] for key, _ in qlist], points)
         trace["evals"] = [(q_, flat[i_]) for i_, q_ in enumerate(qlist)]
         trace["query_list"] = qlist
