@@ -34,9 +34,12 @@ static uint32_t pick_window(size_t n) {
     }
     uint32_t lg = 0;
     while (((size_t)1 << lg) < n) ++lg;
+    // measured on MI355X (profiles/): 2^17 -> 16 (16 windows), 2^19 -> 17 (15 windows, 15 * 17 = 255 bits: no short top window
+    // whose few digit values would pile a third of the points into four buckets), 2^22 -> 19 (14 windows; the sort's low
+    // radix pass holds at most 2^11 bins, so 19 is the largest supported)
     int c = (int)lg - 1;
     if (c < 3) c = 3;
-    if (c > 18) c = 18;
+    if (c > 16) c = lg >= 20 ? 19 : 17;
     return (uint32_t)c;
 }
 
@@ -816,6 +819,7 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
         ZK_LAUNCH_CHECK();
         return ZKHIP_OK;
     }
+    if (getenv("ZKHIP_MSM_DEBUG")) fprintf(stderr, "msm: n=%zu ncols=%zu c=%u W=%u L=%u max partials per bucket=%u\n", n, ncols, c, W, L, maxcnt);
     const uint32_t* cur_cnt = (const uint32_t*)d_cntA;
     const uint32_t* cur_off = (const uint32_t*)d_offA;
     uint32_t* nxt_cnt = (uint32_t*)d_cntB;
