@@ -66,6 +66,7 @@ struct zkhip_ctx {
 
     // optional per-kernel HIP-event timing on the launch stream (zkhip_profile_*)
     bool prof_on = false;
+    std::string prof_only;   // if non-empty, only spans of this name are recorded (keeps the event traffic off the timed path)
     struct ProfSpan { const char* name; hipEvent_t e0, e1; };
     std::vector<ProfSpan> prof_spans;
     std::vector<hipEvent_t> prof_pool;
@@ -80,8 +81,11 @@ struct zkhip_ctx {
 // RAII span around one kernel launch (no-op unless profiling is enabled)
 struct ProfScope {
     zkhip_ctx* c;
-    ProfScope(zkhip_ctx* ctx, const char* name) : c(ctx) { if (c->prof_on) c->prof_begin(name); }
-    ~ProfScope() { if (c->prof_on) c->prof_end(); }
+    bool active;
+    ProfScope(zkhip_ctx* ctx, const char* name) : c(ctx), active(ctx->prof_on && (ctx->prof_only.empty() || ctx->prof_only == name)) {
+        if (active) c->prof_begin(name);
+    }
+    ~ProfScope() { if (active) c->prof_end(); }
 };
 
 // Waits for a stream by polling: hipStreamSynchronize sleeps on an interrupt and wakes tens of microseconds late, and the prover

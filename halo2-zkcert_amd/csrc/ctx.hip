@@ -65,6 +65,11 @@ int zkhip_profile_enable(zkhip_ctx* c, int on) {
     c->prof_on = on != 0;
     return ZKHIP_OK;
 }
+int zkhip_profile_select(zkhip_ctx* c, const char* kernel) {
+    if (!c) { set_error("null ctx"); return ZKHIP_EINVAL; }
+    c->prof_only = kernel ? kernel : "";
+    return ZKHIP_OK;
+}
 int zkhip_profile_read(zkhip_ctx* c, const char* kernel, double* total_ms, uint64_t* launches) {
     if (!c || !kernel || !total_ms || !launches) { set_error("zkhip_profile_read: null argument"); return ZKHIP_EINVAL; }
     ZK_HIP(hipStreamSynchronize(c->stream));

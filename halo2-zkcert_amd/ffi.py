@@ -55,7 +55,7 @@ class ZkEvalhArgs(C.Structure):
 SYMBOLS = [
     "zkhip_init", "zkhip_destroy", "zkhip_last_error", "zkhip_set_stream", "zkhip_synchronize", "zkhip_malloc", "zkhip_free",
     "zkhip_memcpy_h2d", "zkhip_memcpy_d2h", "zkhip_timer_start", "zkhip_timer_stop_ms",
-    "zkhip_profile_enable", "zkhip_profile_read",
+    "zkhip_profile_enable", "zkhip_profile_select", "zkhip_profile_read",
     "zkhip_srs_load", "zkhip_srs_load_device", "zkhip_srs_free", "zkhip_srs_len", "zkhip_srs_window", "zkhip_kzg_setup", "zkhip_srs_read",
     "zkhip_msm_g1", "zkhip_msm_g1_batch_device", "zkhip_msm_g1_batch_range_device", "zkhip_msm_g1_multi_device", "zkhip_g1_add", "zkhip_g1_to_affine", "zkhip_g1_batch_to_affine",
     "zkhip_g1_to_bytes", "zkhip_commitments_read",
@@ -164,6 +164,10 @@ class Context:
 
     def profile_enable(self, on=True):
         _check(lib().zkhip_profile_enable(self.h, C.c_int(1 if on else 0)))
+
+    def profile_select(self, kernel=None):
+        """record only this kernel's spans (None = all)"""
+        _check(lib().zkhip_profile_select(self.h, kernel.encode() if kernel else None))
 
     def profile_read(self, kernel):
         """(total_ms, launches) of the named kernel since profile_enable, from HIP events on its stream."""

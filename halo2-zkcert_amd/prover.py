@@ -150,6 +150,11 @@ class GpuBackend:
     def __init__(self, ctx, ffi):
         self.ctx, self.ffi = ctx, ffi
         self.torch = ctx.torch
+        # the proof's dependent chain runs on a high-priority stream, the coset NTTs that overlap it on a normal one: the
+        # latency-bound MSM phases then get their CUs first and the NTTs fill what is idle
+        if self.torch.cuda.current_stream(ctx.device) == self.torch.cuda.default_stream(ctx.device):
+            self.torch.cuda.set_stream(self.torch.cuda.Stream(device=ctx.device, priority=-1))
+            ctx.use_torch_stream()
         self.main = self.torch.cuda.current_stream(ctx.device)
         self.side = self.torch.cuda.Stream(device=ctx.device)
 

@@ -64,6 +64,9 @@ int  zkhip_timer_stop_ms(zkhip_ctx* ctx, float* ms);   /* synchronises */
  * the launch stream.  Names: "msm_digits", "msm_plan", "msm_accum_affine", "msm_accum_jac", "msm_tail",
  * "ntt_strided", "ntt_final", "sweep", "grand_product", "batch_invert", "eval_polynomial".  zkhip_profile_enable also clears the record. */
 int  zkhip_profile_enable(zkhip_ctx* ctx, int on);
+/* Restrict the recording to one kernel name (NULL = all): a proof issues ~60 timed spans, and their event records cost ~4 % of
+ * a 10 ms proof, so a benchmark times only the kernel it reports live and takes the full breakdown in a separate pass. */
+int  zkhip_profile_select(zkhip_ctx* ctx, const char* kernel);
 int  zkhip_profile_read(zkhip_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches);
 
 /* ---- SRS: ParamsKZG::{g, g_lagrange} (halo2_proofs src/poly/kzg/commitment.rs) ----
