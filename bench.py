@@ -171,10 +171,10 @@ def main():
                                                                    else f"{world} independent proofs, one per GPU, no collective")},
             "roofline": {"kernel": "msm_accum_affine (k_accum_affine)", "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0,
                          "unit": "GB/s", "frac": round(achieved / 8000.0, 5),
-                         # HBM bytes per launch from the PMC passes committed in profiles/r01_v4_pmc_fetch_write.csv
-                         # (FETCH_SIZE + WRITE_SIZE of k_accum_affine over 64 column-MSMs: 162.9 MB + 14.5 MB per 2^17 x 16-window
-                         # column = 84.6 B per (pair, window)), scaled to this launch shape; not re-measured live.
-                         "traffic": round(84.6 * (pairs_per_step / max(acc["launches_per_step"], 1)) * windows),
+                         # HBM bytes per launch from the PMC passes committed in profiles/r01_v5_pmc_fetch_write.csv
+                         # (FETCH_SIZE + WRITE_SIZE of k_accum_affine over 112 column-MSMs: 172.2 MB + 19.8 MB per 2^17 x 16-window
+                         # column = 91.6 B per (pair, window)), scaled to this launch shape; not re-measured live.
+                         "traffic": round(91.6 * (pairs_per_step / max(acc["launches_per_step"], 1)) * windows),
                          "algorithmic_bytes_per_launch": round(alg_bytes_per_launch),
                          "avg_launch_ms": round(avg_launch_s * 1000.0, 4),
                          "note": "MSM is integer-multiply bound, not HBM bound: see int_roofline and DESIGN.md"},
