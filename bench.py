@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--shape", default="rsa", choices=["rsa", "sha256"], help="circuit shape (BASELINE configs[1] / configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shard-msm", action="store_true", help="N > 1: split one proof (strong scaling) instead of one proof per GPU")
+    ap.add_argument("--python-schedule", action="store_true",
+                    help="drive the proof from prover.py over the small entry points instead of zkhip_create_proof (same proof)")
     args = ap.parse_args()
 
     import torch
@@ -104,8 +106,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # one step = one create_proof: the library's own schedule (zkhip_create_proof, transcript through callbacks) unless the proof
+    # is sharded over ranks or --python-schedule asks for the Python one (identical proofs: tests/test_gpu_prover.py)
+    native = not shard and not args.python_schedule
+    prove = prover.prove_native if native else prover.prove
     for _ in range(args.warmup):
-        prover.prove(wit)
+        prove(wit)
     # Live HIP-event timing inside the timed region covers the dominant kernel only (every recorded span costs two event
     # records on the launch stream: ~60 spans are ~4 % of a 10 ms proof); the full per-kernel breakdown comes from extra,
     # untimed passes afterwards.
@@ -115,7 +121,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        trace = prover.prove(wit)
+        trace = prove(wit)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -131,7 +137,7 @@ def main():
     ctx.profile_select(None)
     ctx.profile_enable(True)
     for _ in range(extra):
-        prover.prove(wit)
+        prove(wit)
     for name in ("msm_digits", "msm_plan", "msm_accum_affine", "msm_accum_jac", "msm_tail", "ntt_strided", "ntt_final", "sweep",
                  "lookup_permute", "grand_product", "eval_polynomial", "linear_combination", "kate_division"):
         ms, launches = ctx.profile_read(name)
@@ -167,6 +173,7 @@ def main():
                                    "BLAKE2b stand-in transcript",
                        "k": shape.k, "advice": shape.n_advice, "fixed": shape.n_fixed, "lookups": len(shape.lookups),
                        "perm_columns": len(shape.perm_columns), "degree": shape.degree,
+                       "host": "zkhip_create_proof (schedule in the library, transcript callbacks)" if native else "prover.py (Python schedule over the C ABI)",
                        "parallelism": "1 GPU" if world == 1 else (f"one proof, MSM point-range sharded x{world}, NTT/sweep replicated" if shard
                                                                    else f"{world} independent proofs, one per GPU, no collective")},
             "roofline": {"kernel": "msm_accum_affine (k_accum_affine)", "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0,

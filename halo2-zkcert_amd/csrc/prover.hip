@@ -1,0 +1,324 @@
+// prover.hip — halo2_proofs::plonk::create_proof as one library call over the kernels of this library.
+//
+// Mirrors the order of operations of plonk/prover.rs create_proof [UPSTREAM-RECALL; crate pinned at
+// /root/reference/Cargo.lock:1320-1322; reached from gen_snark_shplonk at /root/reference/src/helpers.rs:233,299 and
+// src/bin/cli.rs:320,343,369,462] from the point where the witness columns exist (witness synthesis is the circuit's job):
+//   advice commitments -> theta -> lookup compression + permute_expression_pair + commitments -> beta, gamma ->
+//   permutation / lookup grand products + commitments -> random polynomial commitment -> y -> quotient (coset NTTs, sweep,
+//   division, split) + commitments -> x -> evaluations -> SHPLONK multi-open.
+// The transcript stays with the caller: commitments, evaluations and challenges cross three callbacks, in upstream's order.
+// Everything here is host orchestration (no kernels): the point of having it in the library is that a proof of 2^17 rows is
+// ~9 ms of GPU work, and an interpreted host adds a millisecond of gaps between ~250 launches.
+// halo2-zkcert_amd/prover.py is the same schedule in Python over the small entry points (and the form the oracle backend runs).
+#include <vector>
+
+#include "common.hpp"
+#include "hostfield.hpp"
+using namespace zk;
+
+namespace {
+struct SideStream {
+    hipStream_t side = nullptr;
+    hipEvent_t ev = nullptr;
+};
+// Work issued between begin() and end() runs on a second stream, ordered after everything already issued on the main one
+// (the coset NTTs of finished columns beside the latency-bound MSM phases); join() makes the main stream wait for it.
+struct Overlap {
+    zkhip_ctx* ctx;
+    hipStream_t main, side;
+    hipEvent_t ev;
+    int begin() {
+        ZK_HIP(hipEventRecord(ev, main));
+        ZK_HIP(hipStreamWaitEvent(side, ev, 0));
+        ctx->stream = side;
+        return ZKHIP_OK;
+    }
+    void end() { ctx->stream = main; }
+    int join() {
+        ZK_HIP(hipEventRecord(ev, side));
+        ZK_HIP(hipStreamWaitEvent(main, ev, 0));
+        return ZKHIP_OK;
+    }
+};
+struct StreamGuard {   // whatever happens, the context leaves on its main stream
+    zkhip_ctx* ctx;
+    hipStream_t main;
+    ~StreamGuard() { ctx->stream = main; }
+};
+inline void abi_of(const HF& a, uint64_t out[4]) { fe32 m = hf_abi(a); memcpy(out, m.w, 32); }
+}  // namespace
+
+extern "C" int zkhip_create_proof(zkhip_ctx* ctx, const zk_proving_key* pk, const void* const* d_advice, const void* const* d_instance,
+                                  uint64_t blinding_seed, const zk_transcript* tr, zk_proof_out* out) {
+    if (!ctx || !pk || !tr || !tr->write_point || !tr->squeeze_challenge || !tr->write_scalar || (pk->n_advice && !d_advice) ||
+        (pk->n_instance && !d_instance)) {
+        set_error("zkhip_create_proof: null argument");
+        return ZKHIP_EINVAL;
+    }
+    if (!pk->g || !pk->g_lagrange || !pk->domain) { set_error("zkhip_create_proof: proving key without SRS / domain"); return ZKHIP_EINVAL; }
+    const uint32_t k = pk->k, bf = pk->blinding_factors;
+    const size_t n = (size_t)1 << k;
+    const uint32_t ek = zkhip_domain_extended_k(pk->domain), qd = zkhip_domain_quotient_poly_degree(pk->domain);
+    const size_t en = (size_t)1 << ek;
+    const uint32_t A = pk->n_advice, I = pk->n_instance, F = pk->n_fixed, L = pk->n_lookups, P = pk->n_perm_columns;
+    if (pk->cs_degree < 3) { set_error("zkhip_create_proof: cs_degree %u < 3", pk->cs_degree); return ZKHIP_EINVAL; }
+    const uint32_t chunk = pk->cs_degree - 2;
+    const uint32_t Zp = P ? (P + chunk - 1) / chunk : 0;
+    if (zkhip_domain_k(pk->domain) != k || zkhip_srs_len(pk->g) < n || zkhip_srs_len(pk->g_lagrange) < n) {
+        set_error("zkhip_create_proof: SRS / domain do not match k = %u", k);
+        return ZKHIP_EINVAL;
+    }
+    uint64_t omega_abi[4], ext_omega_abi[4], g_coset_abi[4];
+    zkhip_domain_constants(pk->domain, omega_abi, ext_omega_abi, g_coset_abi);
+
+    // second stream for the overlapped coset NTTs (owned by the context, created on first use)
+    static thread_local SideStream ss;   // one prover thread per context in this library's model
+    if (!ss.side) {
+        ZK_HIP(hipStreamCreateWithFlags(&ss.side, hipStreamNonBlocking));
+        ZK_HIP(hipEventCreateWithFlags(&ss.ev, hipEventDisableTiming));
+    }
+    Overlap ov{ctx, ctx->stream, ss.side, ss.ev};
+    StreamGuard guard{ctx, ctx->stream};
+    hipStream_t st = ctx->stream;
+
+    // ---- workspace (library-owned, reused across proofs)
+    char *w_coeff, *w_ext, *w_rand, *w_comp, *w_blind, *w_perm_l, *w_perm_c, *w_ext_perm, *w_z, *w_ext_z, *w_h, *w_hpoly, *w_evals, *w_com;
+    const size_t NB = n * 32, EB = en * 32;
+    auto ws = [&](const char* name, size_t bytes, char** p) { void* q; int rc = ctx->get_scratch(name, bytes ? bytes : 32, &q); *p = (char*)q; return rc; };
+    ZK_TRY(ws("cp_coeff", (A + I) * NB, &w_coeff));
+    ZK_TRY(ws("cp_ext", (A + I) * EB, &w_ext));
+    ZK_TRY(ws("cp_rand", NB, &w_rand));
+    ZK_TRY(ws("cp_comp", 2 * L * NB, &w_comp));
+    ZK_TRY(ws("cp_blind", (2 * L * (bf + 1) + (Zp + L) * bf + 8) * 32, &w_blind));
+    ZK_TRY(ws("cp_perm_l", 2 * L * NB, &w_perm_l));
+    ZK_TRY(ws("cp_perm_c", 2 * L * NB, &w_perm_c));
+    ZK_TRY(ws("cp_ext_perm", 2 * L * EB, &w_ext_perm));
+    ZK_TRY(ws("cp_z", (Zp + L) * NB, &w_z));
+    ZK_TRY(ws("cp_ext_z", (Zp + L) * EB, &w_ext_z));
+    ZK_TRY(ws("cp_h", EB, &w_h));
+    ZK_TRY(ws("cp_hpoly", NB, &w_hpoly));
+    const size_t max_q = (size_t)pk->n_advice_queries + pk->n_fixed_queries + 3 * Zp + 5 * L + P + 2;
+    ZK_TRY(ws("cp_evals", max_q * 32, &w_evals));
+    ZK_TRY(ws("cp_com", (A + 2 * L + Zp + L + qd + 2) * 96, &w_com));
+
+    uint64_t ch[4];
+    std::vector<uint64_t> xy;
+    std::vector<uint8_t> by;
+    // commit a batch: MSMs, read back, hand every point to the transcript (skip_last: committed now, written later)
+    auto commit = [&](const std::vector<const void*>& cols, const std::vector<const zkhip_srs*>& bases, size_t hold_back,
+                      std::vector<uint64_t>* held_xy, std::vector<uint8_t>* held_by) -> int {
+        const size_t m = cols.size();
+        if (!m) return ZKHIP_OK;
+        ZK_TRY(zkhip_msm_g1_multi_device(ctx, bases.data(), cols.data(), m, 0, n, w_com));
+        xy.resize(8 * m);
+        by.resize(32 * m);
+        ZK_TRY(zkhip_commitments_read(ctx, w_com, m, xy.data(), by.data()));
+        for (size_t j = 0; j + hold_back < m; ++j) tr->write_point(tr->user, by.data() + 32 * j, xy.data() + 8 * j);
+        if (hold_back && held_xy) { held_xy->assign(xy.begin() + 8 * (m - hold_back), xy.end()); held_by->assign(by.begin() + 32 * (m - hold_back), by.end()); }
+        return ZKHIP_OK;
+    };
+
+    // ---- 1. advice (+ the vanishing argument's random polynomial, which depends on no challenge) ; coset NTTs of advice/instance overlap
+    ZK_TRY(zkhip_synth_fill_device(ctx, w_rand, n, blinding_seed + 380, 0));
+    std::vector<void*> coeff_ptrs(A + I), ext_ptrs(A + I);
+    for (uint32_t j = 0; j < A + I; ++j) { coeff_ptrs[j] = w_coeff + j * NB; ext_ptrs[j] = w_ext + j * EB; }
+    ZK_TRY(ov.begin());
+    for (uint32_t j = 0; j < A + I; ++j)
+        ZK_HIP(hipMemcpyAsync(coeff_ptrs[j], j < A ? d_advice[j] : d_instance[j - A], NB, hipMemcpyDeviceToDevice, ctx->stream));
+    if (A + I) {
+        ZK_TRY(zkhip_lagrange_to_coeff_device(ctx, pk->domain, coeff_ptrs.data(), A + I));
+        ZK_TRY(zkhip_coeff_to_extended_device(ctx, pk->domain, (const void* const*)coeff_ptrs.data(), n, ext_ptrs.data(), A + I));
+    }
+    ov.end();
+    std::vector<uint64_t> rand_xy;
+    std::vector<uint8_t> rand_by;
+    {
+        std::vector<const void*> cols(d_advice, d_advice + A);
+        std::vector<const zkhip_srs*> bases(A, pk->g_lagrange);
+        cols.push_back(w_rand);
+        bases.push_back(pk->g);
+        ZK_TRY(commit(cols, bases, 1, &rand_xy, &rand_by));
+    }
+    tr->squeeze_challenge(tr->user, ch);
+    uint64_t theta[4];
+    memcpy(theta, ch, 32);
+
+    // ---- 2. lookups: compression (the sweep interpreter on the Lagrange domain), permuted columns, their commitments
+    std::vector<void*> perm_c(2 * L), ext_perm(2 * L);
+    for (uint32_t i = 0; i < L; ++i) {
+        for (int side = 0; side < 2; ++side) {
+            zk_evalh_args a;
+            memset(&a, 0, sizeof a);
+            a.k = k; a.extended_k = k; a.cs_degree = 3; a.blinding_factors = 0;
+            memcpy(a.theta, theta, 32);
+            a.n_fixed = F; a.n_advice = A; a.n_instance = I;
+            a.fixed_cosets = (const uint64_t* const*)pk->fixed_lagrange;
+            a.advice_cosets = (const uint64_t* const*)d_advice;
+            a.instance_cosets = (const uint64_t* const*)d_instance;
+            a.custom_gates = side ? pk->lookup_table_compress[i] : pk->lookup_input_compress[i];
+            ZK_TRY(zkhip_evaluate_h_device(ctx, &a, w_comp + (2 * i + side) * NB));
+        }
+        char* bi = w_blind + (2 * i) * (bf + 1) * 32;
+        char* bt = w_blind + (2 * i + 1) * (bf + 1) * 32;
+        ZK_TRY(zkhip_synth_fill_device(ctx, bi, bf + 1, blinding_seed + 300 + i, 0));
+        ZK_TRY(zkhip_synth_fill_device(ctx, bt, bf + 1, blinding_seed + 320 + i, 0));
+        ZK_TRY(zkhip_permute_expression_pair_device(ctx, k, bf, w_comp + (2 * i) * NB, w_comp + (2 * i + 1) * NB, bi, bt, w_perm_l + i * NB,
+                                                    w_perm_l + (L + i) * NB));
+    }
+    for (uint32_t j = 0; j < 2 * L; ++j) { perm_c[j] = w_perm_c + j * NB; ext_perm[j] = w_ext_perm + j * EB; }
+    if (L) {
+        ZK_HIP(hipMemcpyAsync(w_perm_c, w_perm_l, 2 * L * NB, hipMemcpyDeviceToDevice, st));
+        ZK_TRY(zkhip_lagrange_to_coeff_device(ctx, pk->domain, perm_c.data(), 2 * L));
+        ZK_TRY(ov.begin());
+        ZK_TRY(zkhip_coeff_to_extended_device(ctx, pk->domain, (const void* const*)perm_c.data(), n, ext_perm.data(), 2 * L));
+        ov.end();
+        std::vector<const void*> cols(perm_c.begin(), perm_c.end());
+        std::vector<const zkhip_srs*> bases(2 * L, pk->g);
+        ZK_TRY(commit(cols, bases, 0, nullptr, nullptr));
+    }
+    uint64_t beta[4], gamma[4];
+    tr->squeeze_challenge(tr->user, beta);
+    tr->squeeze_challenge(tr->user, gamma);
+
+    // ---- 3. grand products: permutation sets, then lookups; commitments in coefficient form
+    std::vector<void*> z_ptrs(Zp + L), ext_z(Zp + L);   // [perm sets..., lookups...]
+    for (uint32_t j = 0; j < Zp + L; ++j) z_ptrs[j] = w_z + j * NB;
+    {
+        std::vector<const void*> values(P), ci(L), ct(L), pi(L), pt(L);
+        for (uint32_t j = 0; j < P; ++j) {
+            const uint32_t t = pk->perm_column_type[j], c = pk->perm_column_index[j];
+            values[j] = t == 0 ? d_advice[c] : t == 1 ? pk->fixed_lagrange[c] : d_instance[c];
+        }
+        for (uint32_t i = 0; i < L; ++i) {
+            ci[i] = w_comp + (2 * i) * NB; ct[i] = w_comp + (2 * i + 1) * NB;
+            pi[i] = w_perm_l + i * NB; pt[i] = w_perm_l + (L + i) * NB;
+        }
+        char* pb = w_blind + 2 * L * (bf + 1) * 32;
+        char* lb = pb + (size_t)Zp * bf * 32;
+        if (Zp) ZK_TRY(zkhip_synth_fill_device(ctx, pb, (size_t)Zp * bf, blinding_seed + 340, 0));
+        ZK_TRY(zkhip_synth_fill_device(ctx, lb, (size_t)(L ? L : 1) * bf, blinding_seed + 360, 0));
+        ZK_TRY(zkhip_grand_products_device(ctx, k, beta, gamma, bf, values.data(), pk->sigma_lagrange, P, chunk, pb, z_ptrs.data(), L, ci.data(),
+                                           ct.data(), pi.data(), pt.data(), lb, z_ptrs.data() + Zp));
+    }
+    if (Zp + L) {
+        ZK_TRY(zkhip_lagrange_to_coeff_device(ctx, pk->domain, z_ptrs.data(), Zp + L));
+        // extended forms in the order the sweep wants them: lookups first, then permutation sets (as the Python schedule)
+        std::vector<const void*> src(Zp + L);
+        for (uint32_t i = 0; i < L; ++i) { src[i] = z_ptrs[Zp + i]; ext_z[i] = w_ext_z + i * EB; }
+        for (uint32_t s_ = 0; s_ < Zp; ++s_) { src[L + s_] = z_ptrs[s_]; ext_z[L + s_] = w_ext_z + (L + s_) * EB; }
+        ZK_TRY(ov.begin());
+        ZK_TRY(zkhip_coeff_to_extended_device(ctx, pk->domain, src.data(), n, ext_z.data(), Zp + L));
+        ov.end();
+        std::vector<const void*> cols(z_ptrs.begin(), z_ptrs.end());
+        std::vector<const zkhip_srs*> bases(Zp + L, pk->g);
+        ZK_TRY(commit(cols, bases, 0, nullptr, nullptr));
+    }
+    // ---- 4. the random polynomial enters the transcript here
+    tr->write_point(tr->user, rand_by.data(), rand_xy.data());
+    uint64_t y[4];
+    tr->squeeze_challenge(tr->user, y);
+
+    // ---- 5. quotient: sweep over the extended coset, division by the vanishing polynomial, back to coefficients, pieces
+    ZK_TRY(ov.join());
+    {
+        zk_evalh_args a;
+        memset(&a, 0, sizeof a);
+        a.k = k; a.extended_k = ek; a.cs_degree = pk->cs_degree; a.blinding_factors = bf;
+        memcpy(a.extended_omega, ext_omega_abi, 32); memcpy(a.g_coset, g_coset_abi, 32); memcpy(a.delta, pk->delta, 32);
+        memcpy(a.beta, beta, 32); memcpy(a.gamma, gamma, 32); memcpy(a.theta, theta, 32); memcpy(a.y, y, 32);
+        a.n_fixed = F; a.n_advice = A; a.n_instance = I;
+        a.fixed_cosets = (const uint64_t* const*)pk->fixed_cosets;
+        a.advice_cosets = (const uint64_t* const*)ext_ptrs.data();
+        a.instance_cosets = (const uint64_t* const*)(ext_ptrs.data() + A);
+        a.l0 = (const uint64_t*)pk->l0; a.l_last = (const uint64_t*)pk->l_last; a.l_active_row = (const uint64_t*)pk->l_active_row;
+        a.custom_gates = pk->custom_gates;
+        a.n_perm_columns = P; a.n_perm_sets = Zp;
+        a.perm_column_type = pk->perm_column_type; a.perm_column_index = pk->perm_column_index;
+        a.perm_sigma_cosets = (const uint64_t* const*)pk->sigma_cosets;
+        a.perm_product_cosets = (const uint64_t* const*)(ext_z.data() + L);
+        a.n_lookups = L;
+        a.lookup_graphs = pk->lookup_graphs;
+        a.lookup_product_cosets = (const uint64_t* const*)ext_z.data();
+        a.lookup_input_cosets = (const uint64_t* const*)ext_perm.data();
+        a.lookup_table_cosets = (const uint64_t* const*)(ext_perm.data() + L);
+        ZK_TRY(zkhip_evaluate_h_device(ctx, &a, w_h));
+    }
+    ZK_TRY(zkhip_divide_by_vanishing_device(ctx, pk->domain, w_h));
+    {
+        void* hp[1] = {w_h};
+        ZK_TRY(zkhip_extended_to_coeff_device(ctx, pk->domain, hp, 1));
+    }
+    std::vector<const void*> pieces(qd);
+    for (uint32_t i = 0; i < qd; ++i) pieces[i] = w_h + i * NB;
+    {
+        std::vector<const zkhip_srs*> bases(qd, pk->g);
+        ZK_TRY(commit(pieces, bases, 0, nullptr, nullptr));
+    }
+    tr->squeeze_challenge(tr->user, ch);
+    const HF x = hf_from_abi(ch);
+
+    // ---- 5b. evaluations at x * omega^rotation in upstream's query order; h(X) = sum_i x^(n i) h_i(X)
+    {
+        const HF xn = hpow(x, n);
+        std::vector<uint64_t> cf(4 * qd);
+        HF acc = hone();
+        for (uint32_t i = 0; i < qd; ++i) { abi_of(acc, cf.data() + 4 * i); acc = hmul(acc, xn); }
+        ZK_TRY(zkhip_linear_combination_device(ctx, n, pieces.data(), qd, cf.data(), nullptr, 0, w_hpoly));
+    }
+    // polynomial table for the multi-open: advice, fixed, sigma, perm_z, lookup (z, a, s) per lookup, random, h
+    std::vector<const void*> polys;
+    const uint32_t o_adv = 0, o_fix = A, o_sig = A + F, o_pz = A + F + P, o_lk = o_pz + Zp, o_rand = o_lk + 3 * L, o_h = o_rand + 1;
+    for (uint32_t j = 0; j < A; ++j) polys.push_back(coeff_ptrs[j]);
+    for (uint32_t j = 0; j < F; ++j) polys.push_back(pk->fixed_coeff[j]);
+    for (uint32_t j = 0; j < P; ++j) polys.push_back(pk->sigma_coeff[j]);
+    for (uint32_t j = 0; j < Zp; ++j) polys.push_back(z_ptrs[j]);
+    for (uint32_t i = 0; i < L; ++i) { polys.push_back(z_ptrs[Zp + i]); polys.push_back(perm_c[i]); polys.push_back(perm_c[L + i]); }
+    polys.push_back(w_rand);
+    polys.push_back(w_hpoly);
+    std::vector<uint32_t> q_poly;
+    std::vector<int32_t> q_rot;
+    auto q = [&](uint32_t poly, int32_t rot) { q_poly.push_back(poly); q_rot.push_back(rot); };
+    const int32_t last_rot = -(int32_t)(bf + 1);
+    for (uint32_t j = 0; j < pk->n_advice_queries; ++j) q(o_adv + pk->advice_query_column[j], pk->advice_query_rotation[j]);
+    for (uint32_t s_ = 0; s_ < Zp; ++s_) { q(o_pz + s_, 0); q(o_pz + s_, 1); }
+    for (uint32_t s_ = Zp; s_-- > 1;) q(o_pz + s_ - 1, last_rot);
+    for (uint32_t i = 0; i < L; ++i) { q(o_lk + 3 * i, 0); q(o_lk + 3 * i + 1, 0); q(o_lk + 3 * i + 2, 0); q(o_lk + 3 * i + 1, -1); q(o_lk + 3 * i, 1); }
+    for (uint32_t j = 0; j < pk->n_fixed_queries; ++j) q(o_fix + pk->fixed_query_column[j], pk->fixed_query_rotation[j]);
+    for (uint32_t j = 0; j < P; ++j) q(o_sig + j, 0);
+    q(o_h, 0);
+    q(o_rand, 0);
+    const size_t nq = q_poly.size();
+    if (nq > max_q) { set_error("zkhip_create_proof: query count"); return ZKHIP_EINVAL; }
+    std::vector<uint64_t> q_points(4 * nq), q_evals(4 * nq);
+    {
+        const HF omega = hf_from_abi(omega_abi);
+        std::vector<std::pair<int32_t, HF>> cache;
+        for (size_t i = 0; i < nq; ++i) {
+            const int32_t r = q_rot[i];
+            const HF* hit = nullptr;
+            for (auto& c : cache) if (c.first == r) hit = &c.second;
+            if (!hit) {
+                cache.push_back({r, hmul(x, hpow(omega, (uint64_t)(((int64_t)r % (int64_t)n + (int64_t)n) % (int64_t)n)))});
+                hit = &cache.back().second;
+            }
+            abi_of(*hit, q_points.data() + 4 * i);
+        }
+        std::vector<const void*> qp(nq);
+        for (size_t i = 0; i < nq; ++i) qp[i] = polys[q_poly[i]];
+        ZK_TRY(zkhip_eval_polynomials_at_device(ctx, qp.data(), nq, n, q_points.data(), w_evals));
+        ZK_TRY(zkhip_memcpy_d2h(ctx, q_evals.data(), w_evals, nq * 32));
+    }
+    for (size_t i = 0; i < nq; ++i)
+        if (q_poly[i] != o_h) tr->write_scalar(tr->user, q_evals.data() + 4 * i);   // the verifier recomputes h(x)
+    if (out) {
+        out->d_h = w_h;
+        out->n_evals = nq;
+        if (out->evals && out->evals_cap >= nq) memcpy(out->evals, q_evals.data(), nq * 32);
+        if (out->eval_poly && out->evals_cap >= nq) memcpy(out->eval_poly, q_poly.data(), nq * 4);
+        if (out->eval_rotation && out->evals_cap >= nq) memcpy(out->eval_rotation, q_rot.data(), nq * 4);
+    }
+    // ---- 6. SHPLONK multi-open of all of them
+    uint64_t h1[8], h2[8];
+    ZK_TRY(zkhip_shplonk_open(ctx, pk->g, n, polys.data(), polys.size(), q_poly.data(), q_points.data(), q_evals.data(), nq, tr, h1, h2));
+    return ZKHIP_OK;
+}

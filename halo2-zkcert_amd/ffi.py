@@ -68,6 +68,7 @@ SYMBOLS = [
     "zkhip_batch_invert_device", "zkhip_eval_polynomial_device", "zkhip_eval_polynomials_at_device", "zkhip_permutation_products_device",
     "zkhip_permute_expression_pair_device", "zkhip_lookup_product_device", "zkhip_grand_products_device",
     "zkhip_linear_combination_device", "zkhip_divide_by_linear_device", "zkhip_kate_division_device", "zkhip_shplonk_open",
+    "zkhip_create_proof",
 ]
 
 
@@ -144,6 +145,8 @@ class Context:
 
     def to_host(self, t):
         """device tensor -> host uint64 array; small results (the Fiat-Shamir round trips) go through the library's polled copy"""
+        if isinstance(t, np.ndarray):
+            return t
         nbytes = t.numel() * t.element_size()
         if nbytes <= (1 << 16) and t.is_contiguous():
             out = np.empty(t.shape, dtype=np.uint64)
@@ -291,10 +294,49 @@ def kate_division_device(ctx, polys, roots):
 
 WRITE_POINT_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint64))
 SQUEEZE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint64))
+WRITE_SCALAR_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint64))
 
 
 class ZkTranscript(C.Structure):
-    _fields_ = [("user", C.c_void_p), ("write_point", WRITE_POINT_FN), ("squeeze_challenge", SQUEEZE_FN)]
+    _fields_ = [("user", C.c_void_p), ("write_point", WRITE_POINT_FN), ("squeeze_challenge", SQUEEZE_FN), ("write_scalar", WRITE_SCALAR_FN)]
+
+
+def make_transcript(write_point, squeeze_challenge, write_scalar=None):
+    """zk_transcript over Python callables: write_point(bytes32, xy (8,) uint64), squeeze_challenge() -> 4 ABI limbs,
+    write_scalar((4,) uint64 ABI limbs).  Keep the returned object alive for the duration of the call."""
+    def _wp(user, b, xy):
+        write_point(bytes(bytearray(b[i] for i in range(32))), np.array([xy[i] for i in range(8)], dtype=np.uint64))
+
+    def _sq(user, out):
+        limbs = squeeze_challenge()
+        for i in range(4):
+            out[i] = int(limbs[i])
+
+    def _ws(user, sc):
+        write_scalar(np.array([sc[i] for i in range(4)], dtype=np.uint64))
+
+    return ZkTranscript(None, WRITE_POINT_FN(_wp), SQUEEZE_FN(_sq), WRITE_SCALAR_FN(_ws) if write_scalar else WRITE_SCALAR_FN())
+
+
+class ZkProvingKey(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("cs_degree", C.c_uint32), ("blinding_factors", C.c_uint32),
+                ("n_fixed", C.c_uint32), ("n_advice", C.c_uint32), ("n_instance", C.c_uint32), ("n_lookups", C.c_uint32),
+                ("n_perm_columns", C.c_uint32),
+                ("g", C.c_void_p), ("g_lagrange", C.c_void_p), ("domain", C.c_void_p),
+                ("fixed_lagrange", C.c_void_p), ("fixed_coeff", C.c_void_p), ("fixed_cosets", C.c_void_p),
+                ("sigma_lagrange", C.c_void_p), ("sigma_coeff", C.c_void_p), ("sigma_cosets", C.c_void_p),
+                ("l0", C.c_void_p), ("l_last", C.c_void_p), ("l_active_row", C.c_void_p),
+                ("custom_gates", ZkGraph), ("lookup_graphs", C.c_void_p), ("lookup_input_compress", C.c_void_p),
+                ("lookup_table_compress", C.c_void_p), ("perm_column_type", C.c_void_p), ("perm_column_index", C.c_void_p),
+                ("n_advice_queries", C.c_uint32), ("n_fixed_queries", C.c_uint32),
+                ("advice_query_column", C.c_void_p), ("advice_query_rotation", C.c_void_p),
+                ("fixed_query_column", C.c_void_p), ("fixed_query_rotation", C.c_void_p),
+                ("delta", C.c_uint64 * 4)]
+
+
+class ZkProofOut(C.Structure):
+    _fields_ = [("d_h", C.c_void_p), ("evals", C.c_void_p), ("eval_poly", C.c_void_p), ("eval_rotation", C.c_void_p),
+                ("evals_cap", C.c_size_t), ("n_evals", C.c_size_t)]
 
 
 def shplonk_open(ctx, params, polys, query_poly, query_points, query_evals, write_point, squeeze_challenge):
@@ -306,15 +348,7 @@ def shplonk_open(ctx, params, polys, query_poly, query_points, query_evals, writ
     pts = _u64(query_points).reshape(nq, 4)
     evs = _u64(query_evals).reshape(nq, 4)
 
-    def _wp(user, b, xy):
-        write_point(bytes(bytearray(b[i] for i in range(32))), np.array([xy[i] for i in range(8)], dtype=np.uint64))
-
-    def _sq(user, out):
-        limbs = squeeze_challenge()
-        for i in range(4):
-            out[i] = int(limbs[i])
-
-    t = ZkTranscript(None, WRITE_POINT_FN(_wp), SQUEEZE_FN(_sq))
+    t = make_transcript(write_point, squeeze_challenge)
     h1, h2 = np.zeros(8, dtype=np.uint64), np.zeros(8, dtype=np.uint64)
     _check(lib().zkhip_shplonk_open(ctx.h, params.g, C.c_size_t(polys[0].shape[0]), _ptr_array(polys), C.c_size_t(len(polys)), _p(qp), _p(pts),
                                     _p(evs), C.c_size_t(nq), C.byref(t), _p(h1), _p(h2)))

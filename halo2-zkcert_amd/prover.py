@@ -565,6 +565,128 @@ class Prover:
             return dict(advice=advice, instance=instance, base=base)
         return dict(advice=advice, instance=instance, base=base)
 
+    def _query_list(self):
+        """[(key, rotation)] in upstream's query order (what create_proof evaluates at x and SHPLONK opens)"""
+        sh = self.shape
+        L, Zp = len(sh.lookups), sh.n_perm_sets
+        last_rot = -(sh.blinding_factors + 1)
+        qlist = [(("advice", col), rot) for kind, col, rot in sh.queries() if kind == "advice"]
+        for i_ in range(Zp):
+            qlist += [(("perm_z", i_), 0), (("perm_z", i_), 1)]
+        for i_ in reversed(range(Zp - 1)):
+            qlist.append((("perm_z", i_), last_rot))
+        for i_ in range(L):
+            qlist += [(("lookup_z", i_), 0), (("lookup_a", i_), 0), (("lookup_s", i_), 0), (("lookup_a", i_), -1), (("lookup_z", i_), 1)]
+        qlist += [(("fixed", col), rot) for kind, col, rot in sh.queries() if kind == "fixed"]
+        qlist += [(("sigma", i_), 0) for i_ in range(len(sh.perm_columns))]
+        qlist += [(("h", 0), 0), (("random", 0), 0)]
+        return qlist
+
+    def _native_key(self):
+        """zk_proving_key for zkhip_create_proof (built once; the arrays it points to are kept alive on self)"""
+        if getattr(self, "_npk", None) is not None:
+            return self._npk
+        import ctypes as C
+
+        ffi, sh, b = self.b.ffi, self.shape, self.b
+        keep = []
+
+        def ptrs(tensors):
+            arr = (C.c_void_p * max(1, len(tensors)))(*[t.data_ptr() for t in tensors])
+            keep.append((arr, tensors))
+            return C.cast(arr, C.c_void_p)
+
+        def arr(values, dtype):
+            a = np.array(list(values) or [0], dtype=dtype)
+            keep.append(a)
+            return a.ctypes.data
+
+        pack = ffi.EvalhPack()
+        keep.append(pack)
+
+        def graphs(gs):
+            ga = (ffi.ZkGraph * max(1, len(gs)))(*[pack.graph(g, b.fr_many) for g in gs])
+            keep.append(ga)
+            return C.cast(ga, C.c_void_p)
+
+        pk = ffi.ZkProvingKey()
+        pk.k, pk.cs_degree, pk.blinding_factors = sh.k, sh.degree, sh.blinding_factors
+        pk.n_fixed, pk.n_advice, pk.n_instance = len(self.fixed_lagrange), sh.n_advice, sh.n_instance
+        pk.n_lookups, pk.n_perm_columns = len(sh.lookups), len(sh.perm_columns)
+        pk.g, pk.g_lagrange, pk.domain = b.params.g, b.params.g_lagrange, b.domain.h
+        pk.fixed_lagrange, pk.fixed_coeff, pk.fixed_cosets = ptrs(self.fixed_lagrange), ptrs(self.fixed_coeff), ptrs(self.fixed_cosets)
+        pk.sigma_lagrange, pk.sigma_coeff, pk.sigma_cosets = ptrs(self.sigma_lagrange), ptrs(self.sigma_coeff), ptrs(self.sigma_cosets)
+        pk.l0, pk.l_last, pk.l_active_row = self.l0.data_ptr(), self.l_last.data_ptr(), self.l_active.data_ptr()
+        pk.custom_gates = pack.graph(self.gates_graph, b.fr_many)
+        pk.lookup_graphs = graphs(self.lookup_graphs)
+        pk.lookup_input_compress = graphs([p_[0] for p_ in self.compress_graphs])
+        pk.lookup_table_compress = graphs([p_[1] for p_ in self.compress_graphs])
+        tmap = {"advice": 0, "fixed": 1, "instance": 2}
+        pk.perm_column_type = arr((tmap[t] for t, _ in sh.perm_columns), np.uint32)
+        pk.perm_column_index = arr((i for _, i in sh.perm_columns), np.uint32)
+        aq = [(c, r) for kind, c, r in sh.queries() if kind == "advice"]
+        fq = [(c, r) for kind, c, r in sh.queries() if kind == "fixed"]
+        pk.n_advice_queries, pk.n_fixed_queries = len(aq), len(fq)
+        pk.advice_query_column, pk.advice_query_rotation = arr((c for c, _ in aq), np.uint32), arr((r for _, r in aq), np.int32)
+        pk.fixed_query_column, pk.fixed_query_rotation = arr((c for c, _ in fq), np.uint32), arr((r for _, r in fq), np.int32)
+        pk.delta = (C.c_uint64 * 4)(*[int(v) for v in b.fr(DELTA)])
+        self._npk, self._npk_keep = pk, keep
+        return pk
+
+    def prove_native(self, wit):
+        """The same pass through zkhip_create_proof (the schedule and all host arithmetic in the library); this side keeps
+        the transcript.  Returns the same trace as prove()."""
+        import ctypes as C
+
+        sh, b, n = self.shape, self.b, self.n
+        ffi, ctx = b.ffi, b.ctx
+        pk = self._native_key()
+        L, Zp, A = len(sh.lookups), sh.n_perm_sets, sh.n_advice
+        qd = self.dom.quotient_poly_degree
+        point_tags = ["advice"] * A + ["lookup_permuted"] * (2 * L) + ["products"] * (Zp + L) + ["random_poly"] + ["quotient"] * qd \
+            + ["shplonk_h1", "shplonk_h2"]
+        squeeze_tags = ["theta", "beta", "gamma", "y", "x", "shplonk_y", "shplonk_v", "shplonk_u"]
+        trace = {"commitments": [], "challenges": {}, "points": {}}
+        tx, state = [], dict(p=0, s=0)
+
+        def write_point(byts, xy):
+            tag = point_tags[state["p"]]
+            state["p"] += 1
+            trace["commitments"].append((tag, byts.hex()))
+            trace["points"].setdefault(tag, []).append(xy)
+            tx.append(byts)
+
+        def squeeze():
+            tag = squeeze_tags[state["s"]]
+            state["s"] += 1
+            c = challenge(tag, tx)
+            trace["challenges"][tag] = c
+            return fr_from_int_host(c)
+
+        def write_scalar(limbs):
+            tx.append(limbs.tobytes())
+
+        t = ffi.make_transcript(write_point, squeeze, write_scalar)
+        qlist = self._query_list()
+        evals = np.zeros((len(qlist), 4), dtype=np.uint64)
+        out = ffi.ZkProofOut()
+        out.evals, out.evals_cap = evals.ctypes.data, len(qlist)
+        adv = (C.c_void_p * max(1, A))(*[c_.data_ptr() for c_ in wit["advice"]])
+        ins = (C.c_void_p * max(1, sh.n_instance))(*[c_.data_ptr() for c_ in wit["instance"]])
+        ctx.use_torch_stream()
+        rc = ffi.lib().zkhip_create_proof(ctx.h, C.byref(pk), adv, ins, C.c_uint64(wit["base"]), C.byref(t), C.byref(out))
+        if rc != 0:
+            raise ffi.ZkhipError(f"zkhip_create_proof: {rc}: {ffi.lib().zkhip_last_error().decode()}")
+        assert out.n_evals == len(qlist) and state["p"] == len(point_tags) and state["s"] == len(squeeze_tags)
+        trace["evals"] = [(q_, evals[i_]) for i_, q_ in enumerate(qlist)]
+        trace["query_list"] = qlist
+        h = np.empty((qd * n, 4), dtype=np.uint64)
+        ffi._check(ffi.lib().zkhip_memcpy_d2h(ctx.h, h.ctypes.data_as(C.c_void_p), C.c_void_p(out.d_h), C.c_size_t(qd * n * 32)))
+        trace["h_pieces"] = [h[i_ * n:(i_ + 1) * n] for i_ in range(qd)]
+        trace["opening"] = dict(y=trace["challenges"]["shplonk_y"], v=trace["challenges"]["shplonk_v"], u=trace["challenges"]["shplonk_u"])
+        trace["n_commitments"] = len(trace["commitments"])
+        return trace
+
     def prove(self, wit):
         """One pass.  Returns the transcript trace: every commitment's bytes and the challenges."""
         sh, b, n, dom = self.shape, self.b, self.n, self.dom
@@ -649,17 +771,7 @@ class Prover:
         for i_ in range(L):
             polys[("lookup_z", i_)], polys[("lookup_a", i_)], polys[("lookup_s", i_)] = look_z[i_], perm_in[i_], perm_tab[i_]
         polys[("random", 0)] = rand_poly[0]
-        last_rot = -(bf + 1)
-        qlist = [(("advice", col), rot) for kind, col, rot in sh.queries() if kind == "advice"]
-        for i_ in range(len(perm_z)):
-            qlist += [(("perm_z", i_), 0), (("perm_z", i_), 1)]
-        for i_ in reversed(range(len(perm_z) - 1)):
-            qlist.append((("perm_z", i_), last_rot))
-        for i_ in range(L):
-            qlist += [(("lookup_z", i_), 0), (("lookup_a", i_), 0), (("lookup_s", i_), 0), (("lookup_a", i_), -1), (("lookup_z", i_), 1)]
-        qlist += [(("fixed", col), rot) for kind, col, rot in sh.queries() if kind == "fixed"]
-        qlist += [(("sigma", i_), 0) for i_ in range(len(self.sigma_coeff))]
-        qlist += [(("h", 0), 0), (("random", 0), 0)]
+        qlist = self._query_list()
         t5 = absorb("quotient", b.commit_end(quotient_commit))
         x = challenge("x", t1 + t2 + t3 + t4 + t5)
         xn = pow(x, n, R)

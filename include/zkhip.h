@@ -252,10 +252,49 @@ typedef struct zk_transcript {
     void* user;
     void (*write_point)(void* user, const uint8_t bytes32[32], const uint64_t xy[8]);
     void (*squeeze_challenge)(void* user, uint64_t out[4]);
+    void (*write_scalar)(void* user, const uint64_t scalar[4]);   /* evaluations (zkhip_create_proof only; may be NULL for shplonk_open) */
 } zk_transcript;
 int  zkhip_shplonk_open(zkhip_ctx* ctx, const zkhip_srs* srs, size_t n, const void* const* d_polys, size_t npolys, const uint32_t* query_poly,
                         const uint64_t* query_points, const uint64_t* query_evals, size_t nq, const zk_transcript* transcript,
                         uint64_t h1_xy[8], uint64_t h2_xy[8]);
+
+/* ---- halo2_proofs::plonk::create_proof in one call (plonk/prover.rs; reached from gen_snark_shplonk at
+ * /root/reference/src/helpers.rs:233,299 and src/bin/cli.rs:320,343,369,462), from the point where the witness columns exist.
+ * zk_proving_key is what keygen leaves on the device: every array is a HOST array of DEVICE columns unless noted.
+ * Transcript order (upstream's): advice points, squeeze theta, permuted-lookup points, squeeze beta, gamma, product points
+ * (permutation sets, then lookups), the random-polynomial point, squeeze y, quotient piece points, squeeze x, the evaluations
+ * (advice queries, permutation products, lookups, fixed queries, sigma, random polynomial — h(x) is NOT written), then SHPLONK
+ * (squeeze y', v', point h, squeeze u, point h').  The blinding rows / random polynomial upstream draws from its rng come from the
+ * library's counter generator seeded with blinding_seed (zkhip_synth_fill_device seeds +300.., +320.., +340, +360, +380). */
+typedef struct zk_proving_key {
+    uint32_t k, cs_degree, blinding_factors;
+    uint32_t n_fixed, n_advice, n_instance, n_lookups, n_perm_columns;
+    const zkhip_srs* g;
+    const zkhip_srs* g_lagrange;
+    const zkhip_domain* domain;
+    const void* const* fixed_lagrange; const void* const* fixed_coeff; const void* const* fixed_cosets;   /* n_fixed */
+    const void* const* sigma_lagrange; const void* const* sigma_coeff; const void* const* sigma_cosets;   /* n_perm_columns */
+    const void* l0; const void* l_last; const void* l_active_row;                                         /* DEVICE, extended */
+    zk_graph custom_gates;
+    const zk_graph* lookup_graphs;            /* HOST, n_lookups: the lookup argument's input/table product graphs (evaluate_h) */
+    const zk_graph* lookup_input_compress;    /* HOST, n_lookups: theta-compression of the input expressions */
+    const zk_graph* lookup_table_compress;    /* HOST, n_lookups */
+    const uint32_t* perm_column_type;         /* HOST: 0 advice, 1 fixed, 2 instance */
+    const uint32_t* perm_column_index;
+    uint32_t n_advice_queries, n_fixed_queries;                                     /* cs.advice_queries / cs.fixed_queries order */
+    const uint32_t* advice_query_column; const int32_t* advice_query_rotation;      /* HOST */
+    const uint32_t* fixed_query_column; const int32_t* fixed_query_rotation;        /* HOST */
+    uint64_t delta[4];                                                              /* Fr::DELTA, ABI form */
+} zk_proving_key;
+typedef struct zk_proof_out {
+    const void* d_h;          /* the quotient in coefficient form (quotient_poly_degree * n elements, library-owned, valid until the next proof) */
+    uint64_t* evals;          /* caller's HOST buffer, evals_cap x 4 (may be NULL): every opened evaluation, h's included, in query order */
+    uint32_t* eval_poly;      /* caller's HOST buffers, evals_cap each (may be NULL): polynomial table index and rotation per evaluation */
+    int32_t* eval_rotation;
+    size_t evals_cap, n_evals;
+} zk_proof_out;
+int  zkhip_create_proof(zkhip_ctx* ctx, const zk_proving_key* pk, const void* const* d_advice, const void* const* d_instance,
+                        uint64_t blinding_seed, const zk_transcript* transcript, zk_proof_out* out);
 
 /* ---- synthetic tables (bench / tests): element i of a column = raw253(seed, i) taken as the
  * Montgomery limbs (oracle/pyref.py synth_raw253) ---- */
