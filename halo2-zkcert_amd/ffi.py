@@ -305,15 +305,13 @@ def make_transcript(write_point, squeeze_challenge, write_scalar=None):
     """zk_transcript over Python callables: write_point(bytes32, xy (8,) uint64), squeeze_challenge() -> 4 ABI limbs,
     write_scalar((4,) uint64 ABI limbs).  Keep the returned object alive for the duration of the call."""
     def _wp(user, b, xy):
-        write_point(bytes(bytearray(b[i] for i in range(32))), np.array([xy[i] for i in range(8)], dtype=np.uint64))
+        write_point(C.string_at(b, 32), np.frombuffer(C.string_at(xy, 64), dtype=np.uint64))
 
     def _sq(user, out):
-        limbs = squeeze_challenge()
-        for i in range(4):
-            out[i] = int(limbs[i])
+        C.memmove(out, np.ascontiguousarray(squeeze_challenge(), dtype=np.uint64).ctypes.data, 32)
 
     def _ws(user, sc):
-        write_scalar(np.array([sc[i] for i in range(4)], dtype=np.uint64))
+        write_scalar(np.frombuffer(C.string_at(sc, 32), dtype=np.uint64))
 
     return ZkTranscript(None, WRITE_POINT_FN(_wp), SQUEEZE_FN(_sq), WRITE_SCALAR_FN(_ws) if write_scalar else WRITE_SCALAR_FN())
 
