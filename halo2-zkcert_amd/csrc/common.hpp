@@ -47,6 +47,8 @@ struct zkhip_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t side_stream = nullptr;   // zkhip_create_proof's second stream (coset NTTs beside the MSM phases), created on first use
+    hipEvent_t side_event = nullptr;
     void* h_pinned = nullptr;   // 64 KiB of pinned host memory for the small device->host reads on the critical path
     static constexpr size_t PINNED_BYTES = 64 * 1024;
     std::map<std::string, zk::Scratch> scratch;

@@ -122,6 +122,8 @@ void zkhip_destroy(zkhip_ctx* c) {
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
+    if (c->side_event) (void)hipEventDestroy(c->side_event);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     delete c;
 }

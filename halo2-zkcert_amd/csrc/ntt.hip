@@ -17,6 +17,7 @@
 // Bound: integer multiply (one Fr product per butterfly + one per element per non-final pass);
 // HBM traffic is 64 B per element per pass.
 #include <algorithm>
+#include <mutex>
 
 #include "common.hpp"
 using namespace zk;
@@ -245,12 +246,14 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
     const zkhip_ctx::Twiddle* twh;
     ZK_TRY(ctx->get_twiddles(omega, m, &twh));
     TwDev tw{(const uint32_t*)twh->d_lo, (const uint32_t*)twh->d_hi, (const uint32_t*)twh->d_bf, twh->h, twh->bf_bits};
-    static bool lds_attr_set = false;
-    if (!lds_attr_set) {
-        ZK_HIP(hipFuncSetAttribute((const void*)k_ntt_strided, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NTT_TILE * sizeof(fe))));
-        ZK_HIP(hipFuncSetAttribute((const void*)k_ntt_final, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NTT_TILE * sizeof(fe))));
-        lds_attr_set = true;
-    }
+    static std::once_flag lds_attr_once;   // 72 KiB of dynamic LDS needs the opt-in once per process
+    hipError_t attr_err = hipSuccess;
+    std::call_once(lds_attr_once, [&] {
+        attr_err = hipFuncSetAttribute((const void*)k_ntt_strided, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NTT_TILE * sizeof(fe)));
+        if (attr_err == hipSuccess)
+            attr_err = hipFuncSetAttribute((const void*)k_ntt_final, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NTT_TILE * sizeof(fe)));
+    });
+    ZK_HIP(attr_err);
     // pass plan
     // Up to 9 bits per pass (T = 4..8 elements per contiguous run).  Measured on MI355X: 6-bit passes with
     // 1 KiB runs are 7 % SLOWER at 2^24 than 8/9-bit passes — the kernels are bound by per-element work

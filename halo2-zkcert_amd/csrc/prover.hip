@@ -17,10 +17,6 @@
 using namespace zk;
 
 namespace {
-struct SideStream {
-    hipStream_t side = nullptr;
-    hipEvent_t ev = nullptr;
-};
 // Work issued between begin() and end() runs on a second stream, ordered after everything already issued on the main one
 // (the coset NTTs of finished columns beside the latency-bound MSM phases); join() makes the main stream wait for it.
 struct Overlap {
@@ -72,12 +68,11 @@ extern "C" int zkhip_create_proof(zkhip_ctx* ctx, const zk_proving_key* pk, cons
     zkhip_domain_constants(pk->domain, omega_abi, ext_omega_abi, g_coset_abi);
 
     // second stream for the overlapped coset NTTs (owned by the context, created on first use)
-    static thread_local SideStream ss;   // one prover thread per context in this library's model
-    if (!ss.side) {
-        ZK_HIP(hipStreamCreateWithFlags(&ss.side, hipStreamNonBlocking));
-        ZK_HIP(hipEventCreateWithFlags(&ss.ev, hipEventDisableTiming));
+    if (!ctx->side_stream) {
+        ZK_HIP(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+        ZK_HIP(hipEventCreateWithFlags(&ctx->side_event, hipEventDisableTiming));
     }
-    Overlap ov{ctx, ctx->stream, ss.side, ss.ev};
+    Overlap ov{ctx, ctx->stream, ctx->side_stream, ctx->side_event};
     StreamGuard guard{ctx, ctx->stream};
     hipStream_t st = ctx->stream;
 
