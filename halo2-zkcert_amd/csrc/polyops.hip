@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(PO_BLOCK) k_batch_invert(uint32_t* a, size_t n
     // every lane of wave 0 inverts the root (same cost as one lane; avoids a broadcast)
     __shared__ fe root_inv;
     if (t < 64) {
-        el2<Fr> r = inv<Fr>(el2<Fr>(tree[1]));
+        el2<Fr> r = inv_euclid<Fr>(el2<Fr>(tree[1]));   // one value, the same in all 64 lanes: binary Euclid beats the 380-product Fermat chain
         if (t == 0) root_inv = r.v;
     }
     __syncthreads();

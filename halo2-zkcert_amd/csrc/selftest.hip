@@ -30,6 +30,8 @@ void zkt_fq_chain(const uint64_t* a, const uint64_t* b, uint64_t* o) { t_chain<F
 void zkt_fr_chain(const uint64_t* a, const uint64_t* b, uint64_t* o) { t_chain<Fr>(a, b, o); }
 void zkt_fq_inv(const uint64_t* a, uint64_t* o) { t_inv<Fq>(a, o); }
 void zkt_fr_inv(const uint64_t* a, uint64_t* o) { t_inv<Fr>(a, o); }
+void zkt_fq_inv_euclid(const uint64_t* a, uint64_t* o) { mem_store(o, to_abi(inv_euclid<Fq>(from_abi<Fq>(mem_load(a))))); }
+void zkt_fr_inv_euclid(const uint64_t* a, uint64_t* o) { mem_store(o, to_abi(inv_euclid<Fr>(from_abi<Fr>(mem_load(a))))); }
 void zkt_fq_inv_host(const uint64_t* a, uint64_t* o) { mem_store(o, to_abi(inv_host<Fq>(from_abi<Fq>(mem_load(a))))); }
 void zkt_fr_inv_host(const uint64_t* a, uint64_t* o) { mem_store(o, to_abi(inv_host<Fr>(from_abi<Fr>(mem_load(a))))); }
 void zkt_fr_raw_roundtrip(const uint64_t* a, uint64_t* o) { store_raw<Fr>(o, load_raw<Fr>(a)); }

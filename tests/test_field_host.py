@@ -51,6 +51,8 @@ def test_mul_inv_chain(zt, oracle, field):
         assert to(o) == (pow(a, -1, m) if a else 0)
         getattr(zt, f"zkt_{field}_inv_host")(zo.p(A), zo.p(o))      # binary extended Euclid used on the host paths
         assert to(o) == (pow(a, -1, m) if a else 0)
+        getattr(zt, f"zkt_{field}_inv_euclid")(zo.p(A), zo.p(o))    # the 8 x u32 version the batch-inversion kernel runs
+        assert to(o) == (pow(a, -1, m) if a else 0)
 
 
 def test_conversions(zt, oracle):
