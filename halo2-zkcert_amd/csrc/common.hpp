@@ -47,6 +47,7 @@ struct zkhip_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_read = nullptr;   // marks a small device->host read in the middle of a launch sequence (see event_wait)
     hipStream_t side_stream = nullptr;   // zkhip_create_proof's second stream (coset NTTs beside the MSM phases), created on first use
     hipEvent_t side_event = nullptr;
     void* h_pinned = nullptr;   // 64 KiB of pinned host memory for the small device->host reads on the critical path
@@ -99,6 +100,17 @@ static inline hipError_t stream_wait(hipStream_t st) {
     }
     (void)hipGetLastError();
     return hipStreamSynchronize(st);
+}
+
+// Waits (polling) for an event recorded right after a small read-back, not for the whole stream: the kernels issued after the
+// event keep running while the host acts on the value, so the next launches queue up behind them without a bubble.
+static inline hipError_t event_wait(hipEvent_t ev) {
+    for (int i = 0; i < 2000000; ++i) {
+        hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+    }
+    (void)hipGetLastError();
+    return hipEventSynchronize(ev);
 }
 
 static inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }

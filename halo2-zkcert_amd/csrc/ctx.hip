@@ -104,6 +104,7 @@ int zkhip_init(zkhip_ctx** out, int device_id) {
     c->stream = c->own_stream;
     ZK_HIP(hipEventCreate(&c->ev0));
     ZK_HIP(hipEventCreate(&c->ev1));
+    ZK_HIP(hipEventCreateWithFlags(&c->ev_read, hipEventDisableTiming));
     ZK_HIP(hipHostMalloc(&c->h_pinned, zkhip_ctx::PINNED_BYTES, hipHostMallocDefault));
     *out = c;
     return ZKHIP_OK;
@@ -121,6 +122,7 @@ void zkhip_destroy(zkhip_ctx* c) {
     for (auto e : c->prof_pool) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev_read) (void)hipEventDestroy(c->ev_read);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->side_event) (void)hipEventDestroy(c->side_event);

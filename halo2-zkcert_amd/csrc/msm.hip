@@ -801,6 +801,7 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
                        (uint32_t*)d_cntA);
     ZK_TRY(launch_plan(ctx, (unsigned)ncols, (const uint32_t*)d_cntA, B, 1, (uint32_t*)d_offA, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)d_max)); }
     ZK_HIP(hipMemcpyAsync(h_max, d_max, ncols * 4, hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipEventRecord(ctx->ev_read, st));
     { ProfScope ps(ctx, "msm_digits");
     hipLaunchKernelGGL(k_sort_lo<true>, gt, dim3(256), 0, st, (const uint32_t*)d_part_off, (const uint32_t*)d_tile_start, g,
                        (const uint32_t*)d_tmp_entry, (const uint16_t*)d_tmp_key, items, d_cnt, (const uint32_t*)d_off, d_cursor,
@@ -811,7 +812,8 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
                        (const uint32_t* const*)((const void**)d_colptrs + ncols), (const uint32_t*)d_entries, items, (const uint32_t*)d_off,
                        (const uint32_t*)d_offA, B, L, (uint32_t*)d_pA, pstride0); }
     ZK_LAUNCH_CHECK();
-    ZK_HIP(stream_wait(st));
+    if (h_max_big.empty()) ZK_HIP(event_wait(ctx->ev_read));   // only the read-back: the scatter and round 0 are still running
+    else ZK_HIP(stream_wait(st));                               // pageable destination: wait for everything
     uint32_t maxcnt = 0;   // most partial sums in one bucket
     for (size_t j = 0; j < ncols; ++j) maxcnt = std::max(maxcnt, h_max[j]);
     if (maxcnt == 0) {
