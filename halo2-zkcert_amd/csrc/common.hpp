@@ -113,4 +113,8 @@ static inline hipError_t event_wait(hipEvent_t ev) {
     return hipEventSynchronize(ev);
 }
 
+namespace zk {
+int permute_expression_pair_async(zkhip_ctx* ctx, uint32_t k, uint32_t blinding_factors, const void* d_input, const void* d_table,
+                                  const void* d_blind_in, const void* d_blind_tab, void* d_perm_in, void* d_perm_tab, uint32_t* d_err_flag);
+}
 static inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }

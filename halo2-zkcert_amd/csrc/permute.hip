@@ -225,10 +225,30 @@ __global__ void k_pe_finish(const uint32_t* A, const uint32_t* leftover, const u
     store_from_canonical(perm_tab + row * 8, key_load(leftover + (size_t)idx * 8));
 }
 
+namespace zk {
+// Asynchronous form for the library's own schedule: the failure flag (non-zero = ConstraintSystemFailure) is OR-ed into *d_err_flag,
+// which the caller zeroes beforehand and reads at its next synchronisation point.
+int permute_expression_pair_async(zkhip_ctx* ctx, uint32_t k, uint32_t blinding_factors, const void* d_input, const void* d_table,
+                                  const void* d_blind_in, const void* d_blind_tab, void* d_perm_in, void* d_perm_tab, uint32_t* d_err_flag);
+}
 extern "C" int zkhip_permute_expression_pair_device(zkhip_ctx* ctx, uint32_t k, uint32_t blinding_factors, const void* d_input,
                                                     const void* d_table, const void* d_blind_in, const void* d_blind_tab,
                                                     void* d_perm_in, void* d_perm_tab) {
-    if (!ctx || !d_input || !d_table || !d_blind_in || !d_blind_tab || !d_perm_in || !d_perm_tab) { set_error("zkhip_permute_expression_pair_device: null argument"); return ZKHIP_EINVAL; }
+    if (!ctx) { set_error("zkhip_permute_expression_pair_device: null argument"); return ZKHIP_EINVAL; }
+    void* d_err;
+    ZK_TRY(ctx->get_scratch("pe_err", 16, &d_err));
+    ZK_HIP(hipMemsetAsync(d_err, 0, 16, ctx->stream));
+    ZK_TRY(zk::permute_expression_pair_async(ctx, k, blinding_factors, d_input, d_table, d_blind_in, d_blind_tab, d_perm_in, d_perm_tab,
+                                             (uint32_t*)d_err));
+    uint32_t* h_err = (uint32_t*)ctx->h_pinned;
+    ZK_HIP(hipMemcpyAsync(h_err, d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(stream_wait(ctx->stream));
+    if (*h_err) { set_error("permute_expression_pair: an input value is not in the table (ConstraintSystemFailure)"); return ZKHIP_ECONSTRAINT; }
+    return ZKHIP_OK;
+}
+int zk::permute_expression_pair_async(zkhip_ctx* ctx, uint32_t k, uint32_t blinding_factors, const void* d_input, const void* d_table,
+                                      const void* d_blind_in, const void* d_blind_tab, void* d_perm_in, void* d_perm_tab, uint32_t* err) {
+    if (!ctx || !d_input || !d_table || !d_blind_in || !d_blind_tab || !d_perm_in || !d_perm_tab || !err) { set_error("zkhip_permute_expression_pair_device: null argument"); return ZKHIP_EINVAL; }
     if (k < 1 || k > 26) { set_error("zkhip_permute_expression_pair_device: k = %u unsupported (1..26)", k); return ZKHIP_EINVAL; }
     size_t n = (size_t)1 << k;
     size_t np = std::max(n, (size_t)BT_TILE);   // sort size: short columns are padded with sentinels to one tile
@@ -241,10 +261,10 @@ extern "C" int zkhip_permute_expression_pair_device(zkhip_ctx* ctx, uint32_t k, 
     ZK_TRY(ctx->get_scratch("pe_flags", 2 * n * 4, &d_flags));
     ZK_TRY(ctx->get_scratch("pe_ranks", 2 * n * 4, &d_ranks));
     ZK_TRY(ctx->get_scratch("pe_left", n * 32, &d_left));
-    ZK_TRY(ctx->get_scratch("pe_misc", 16, &d_misc));   // totals[2], err
+    ZK_TRY(ctx->get_scratch("pe_misc", 16, &d_misc));   // totals[2]
     uint32_t* rep_flag = (uint32_t*)d_flags; uint32_t* left_flag = rep_flag + n;
     uint32_t* rep_rank = (uint32_t*)d_ranks; uint32_t* left_rank = rep_rank + n;
-    uint32_t* totals = (uint32_t*)d_misc; uint32_t* err = totals + 2;
+    uint32_t* totals = (uint32_t*)d_misc;
     ProfScope ps(ctx, "lookup_permute");
     ZK_HIP(hipMemsetAsync(d_misc, 0, 16, st));
     unsigned g = div_up(n, 256);
@@ -260,9 +280,5 @@ extern "C" int zkhip_permute_expression_pair_device(zkhip_ctx* ctx, uint32_t k, 
     hipLaunchKernelGGL(k_pe_finish, dim3(g), dim3(256), 0, st, (const uint32_t*)dA, (const uint32_t*)d_left, rep_flag, rep_rank, totals, n, usable,
                        (const uint32_t*)d_blind_in, (const uint32_t*)d_blind_tab, (uint32_t*)d_perm_in, (uint32_t*)d_perm_tab, err);
     ZK_LAUNCH_CHECK();
-    uint32_t* h_err = (uint32_t*)ctx->h_pinned;
-    ZK_HIP(hipMemcpyAsync(h_err, err, 4, hipMemcpyDeviceToHost, st));
-    ZK_HIP(stream_wait(st));
-    if (*h_err) { set_error("permute_expression_pair: an input value is not in the table (ConstraintSystemFailure)"); return ZKHIP_ECONSTRAINT; }
     return ZKHIP_OK;
 }

@@ -140,6 +140,9 @@ extern "C" int zkhip_create_proof(zkhip_ctx* ctx, const zk_proving_key* pk, cons
 
     // ---- 2. lookups: compression (the sweep interpreter on the Lagrange domain), permuted columns, their commitments
     std::vector<void*> perm_c(2 * L), ext_perm(2 * L);
+    char* w_perr;   // one failure flag for all lookups, read after the permuted columns' commitment (no extra sync)
+    ZK_TRY(ws("cp_perr", 16, &w_perr));
+    if (L) ZK_HIP(hipMemsetAsync(w_perr, 0, 16, st));
     for (uint32_t i = 0; i < L; ++i) {
         for (int side = 0; side < 2; ++side) {
             zk_evalh_args a;
@@ -157,8 +160,8 @@ extern "C" int zkhip_create_proof(zkhip_ctx* ctx, const zk_proving_key* pk, cons
         char* bt = w_blind + (2 * i + 1) * (bf + 1) * 32;
         ZK_TRY(zkhip_synth_fill_device(ctx, bi, bf + 1, blinding_seed + 300 + i, 0));
         ZK_TRY(zkhip_synth_fill_device(ctx, bt, bf + 1, blinding_seed + 320 + i, 0));
-        ZK_TRY(zkhip_permute_expression_pair_device(ctx, k, bf, w_comp + (2 * i) * NB, w_comp + (2 * i + 1) * NB, bi, bt, w_perm_l + i * NB,
-                                                    w_perm_l + (L + i) * NB));
+        ZK_TRY(zk::permute_expression_pair_async(ctx, k, bf, w_comp + (2 * i) * NB, w_comp + (2 * i + 1) * NB, bi, bt, w_perm_l + i * NB,
+                                                 w_perm_l + (L + i) * NB, (uint32_t*)w_perr));
     }
     for (uint32_t j = 0; j < 2 * L; ++j) { perm_c[j] = w_perm_c + j * NB; ext_perm[j] = w_ext_perm + j * EB; }
     if (L) {
@@ -169,7 +172,15 @@ extern "C" int zkhip_create_proof(zkhip_ctx* ctx, const zk_proving_key* pk, cons
         ov.end();
         std::vector<const void*> cols(perm_c.begin(), perm_c.end());
         std::vector<const zkhip_srs*> bases(2 * L, pk->g);
-        ZK_TRY(commit(cols, bases, 0, nullptr, nullptr));
+        // the failure flag rides on the commitment's read-back: it must be known before anything enters the transcript
+        uint32_t* h_err = (uint32_t*)((char*)ctx->h_pinned + zkhip_ctx::PINNED_BYTES - 16);
+        ZK_TRY(zkhip_msm_g1_multi_device(ctx, bases.data(), cols.data(), cols.size(), 0, n, w_com));
+        ZK_HIP(hipMemcpyAsync(h_err, w_perr, 4, hipMemcpyDeviceToHost, st));
+        xy.resize(8 * cols.size());
+        by.resize(32 * cols.size());
+        ZK_TRY(zkhip_commitments_read(ctx, w_com, cols.size(), xy.data(), by.data()));
+        if (*h_err) { set_error("permute_expression_pair: an input value is not in the table (ConstraintSystemFailure)"); return ZKHIP_ECONSTRAINT; }
+        for (size_t j = 0; j < cols.size(); ++j) tr->write_point(tr->user, by.data() + 32 * j, xy.data() + 8 * j);
     }
     uint64_t beta[4], gamma[4];
     tr->squeeze_challenge(tr->user, beta);

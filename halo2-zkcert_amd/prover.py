@@ -675,6 +675,8 @@ class Prover:
         ins = (C.c_void_p * max(1, sh.n_instance))(*[c_.data_ptr() for c_ in wit["instance"]])
         ctx.use_torch_stream()
         rc = ffi.lib().zkhip_create_proof(ctx.h, C.byref(pk), adv, ins, C.c_uint64(wit["base"]), C.byref(t), C.byref(out))
+        if rc == ffi.ECONSTRAINT:
+            raise ffi.ConstraintSystemFailure(ffi.lib().zkhip_last_error().decode())
         if rc != 0:
             raise ffi.ZkhipError(f"zkhip_create_proof: {rc}: {ffi.lib().zkhip_last_error().decode()}")
         assert out.n_evals == len(qlist) and state["p"] == len(point_tags) and state["s"] == len(squeeze_tags)

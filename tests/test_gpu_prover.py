@@ -147,3 +147,22 @@ def test_native_create_proof_sha_shape(zk, oracle):
     ta, tb = gp.prove(w), gp.prove_native(w)
     assert ta["commitments"] == tb["commitments"] and ta["challenges"] == tb["challenges"]
     assert all((ea == eb).all() for (_, ea), (_, eb) in zip(ta["evals"], tb["evals"]))
+
+
+def test_native_create_proof_reports_unsatisfiable_lookup(zk, oracle):
+    """a lookup input that is not in the table: ConstraintSystemFailure from both schedules, nothing half-written afterwards"""
+    ffi, ctx = zk
+    zo = oracle
+    sh = pv.CircuitShape.small(7)
+    gp = pv.Prover(pv.GpuBackend(ctx, ffi), sh, satisfiable=True)
+    w = gp.witness(0)
+    good = gp.prove_native(w)["commitments"]
+    bad = dict(w)
+    col = w["advice"][sh.n_basic].clone()
+    col[3] = ctx.to_device(zo.fr_arr_from_ints([0x123456789]))[0]
+    bad["advice"] = w["advice"][:sh.n_basic] + [col] + w["advice"][sh.n_basic + 1:]
+    with pytest.raises(ffi.ConstraintSystemFailure):
+        gp.prove_native(bad)
+    with pytest.raises(ffi.ConstraintSystemFailure):
+        gp.prove(bad)
+    assert gp.prove_native(w)["commitments"] == good
