@@ -299,7 +299,19 @@ __device__ __forceinline__ uint32_t ceil_div_magic(uint32_t v, uint32_t seg, uin
 //                 off_out = exclusive scan of cnt_out (B + 1 entries each); max_out[col] = max cnt_in.
 #define PLAN_PER 8
 #define PLAN_BLOCK (256 * PLAN_PER)
-__device__ __forceinline__ void plan_load(const uint32_t* cnt_in, uint32_t B, uint32_t lo, uint32_t v[PLAN_PER]) {
+// lane mode (lane_off != null): the scanned quantity is not cnt_in[b] but the number of round-0 lanes of width L touching bucket b,
+// floor((off + cnt - 1) / L) - floor(off / L) + 1, from the bucket offsets of the previous scan
+__device__ __forceinline__ void plan_load(const uint32_t* cnt_in, uint32_t B, uint32_t lo, uint32_t v[PLAN_PER], const uint32_t* lane_off = nullptr,
+                                          uint32_t lane_L = 0) {
+    if (lane_off) {
+#pragma unroll
+        for (int q = 0; q < PLAN_PER; ++q) {
+            uint32_t c = lo + q < B ? cnt_in[lo + q] : 0u;
+            uint32_t o = lo + q < B ? lane_off[lo + q] : 0u;
+            v[q] = c ? (o + c - 1) / lane_L - o / lane_L + 1 : 0u;
+        }
+        return;
+    }
     if (lo + PLAN_PER <= B) {
 #pragma unroll
         for (int q = 0; q < PLAN_PER / 4; ++q) {
@@ -312,11 +324,12 @@ __device__ __forceinline__ void plan_load(const uint32_t* cnt_in, uint32_t B, ui
     }
 }
 __global__ void __launch_bounds__(256) k_plan_sums(const uint32_t* cnt_in_all, uint32_t B, uint32_t seg, uint32_t seg_magic,
-                                                   uint32_t* sums_all /* [col][nblk][4] */) {
+                                                   uint32_t* sums_all /* [col][nblk][4] */, const uint32_t* lane_off_all, uint32_t lane_L) {
     __shared__ uint32_t w_a[4], w_b[4], w_m[4];
     uint32_t col = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     uint32_t v[PLAN_PER];
-    plan_load(cnt_in_all + (size_t)col * B, B, blockIdx.x * PLAN_BLOCK + t * PLAN_PER, v);
+    plan_load(cnt_in_all + (size_t)col * B, B, blockIdx.x * PLAN_BLOCK + t * PLAN_PER, v,
+              lane_off_all ? lane_off_all + (size_t)col * (B + 4) : nullptr, lane_L);
     uint32_t sa = 0, sb = 0, m = 0;
 #pragma unroll
     for (int q = 0; q < PLAN_PER; ++q) { sa += v[q]; sb += ceil_div_magic(v[q], seg, seg_magic); m = max(m, v[q]); }
@@ -333,7 +346,7 @@ __global__ void __launch_bounds__(256) k_plan_sums(const uint32_t* cnt_in_all, u
 }
 __global__ void __launch_bounds__(256) k_plan_apply(const uint32_t* cnt_in_all, uint32_t B, uint32_t seg, uint32_t seg_magic,
                                                     const uint32_t* sums_all, uint32_t* off_in_all, uint32_t* cnt_out_all,
-                                                    uint32_t* off_out_all, uint32_t* max_out) {
+                                                    uint32_t* off_out_all, uint32_t* max_out, const uint32_t* lane_off_all, uint32_t lane_L) {
     __shared__ uint32_t w_a[4], w_b[4], s_base[3];
     uint32_t col = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6, nblk = gridDim.x;
     const uint32_t* sums = sums_all + (size_t)col * nblk * 4;
@@ -361,7 +374,7 @@ __global__ void __launch_bounds__(256) k_plan_apply(const uint32_t* cnt_in_all, 
     }
     uint32_t lo = blockIdx.x * PLAN_BLOCK + t * PLAN_PER;
     uint32_t v[PLAN_PER], sv[PLAN_PER];
-    plan_load(cnt_in_all + (size_t)col * B, B, lo, v);
+    plan_load(cnt_in_all + (size_t)col * B, B, lo, v, lane_off_all ? lane_off_all + (size_t)col * (B + 4) : nullptr, lane_L);
     uint32_t sa = 0, sb = 0;
 #pragma unroll
     for (int q = 0; q < PLAN_PER; ++q) { sv[q] = ceil_div_magic(v[q], seg, seg_magic); sa += v[q]; sb += sv[q]; }
@@ -400,14 +413,14 @@ __global__ void __launch_bounds__(256) k_plan_apply(const uint32_t* cnt_in_all, 
     }
 }
 static int launch_plan(zkhip_ctx* ctx, unsigned ncols, const uint32_t* cnt_in, uint32_t B, uint32_t seg, uint32_t* off_in,
-                       uint32_t* cnt_out, uint32_t* off_out, uint32_t* max_out) {
+                       uint32_t* cnt_out, uint32_t* off_out, uint32_t* max_out, const uint32_t* lane_off = nullptr, uint32_t lane_L = 0) {
     uint32_t magic = seg > 1 ? (uint32_t)((((uint64_t)1 << 32) + seg - 1) / seg) : 0;
     unsigned nblk = div_up(B, PLAN_BLOCK);
     void* d_sums;
     ZK_TRY(ctx->get_scratch("msm_plan_sums", (size_t)ncols * nblk * 16, &d_sums));
-    hipLaunchKernelGGL(k_plan_sums, dim3(nblk, ncols), dim3(256), 0, ctx->stream, cnt_in, B, seg, magic, (uint32_t*)d_sums);
+    hipLaunchKernelGGL(k_plan_sums, dim3(nblk, ncols), dim3(256), 0, ctx->stream, cnt_in, B, seg, magic, (uint32_t*)d_sums, lane_off, lane_L);
     hipLaunchKernelGGL(k_plan_apply, dim3(nblk, ncols), dim3(256), 0, ctx->stream, cnt_in, B, seg, magic, (const uint32_t*)d_sums, off_in,
-                       cnt_out, off_out, max_out);
+                       cnt_out, off_out, max_out, lane_off, lane_L);
     return ZKHIP_OK;
 }
 
@@ -453,13 +466,6 @@ __device__ __forceinline__ g1x g1x_load_loose(const uint32_t* p) {
 // Round 0, lane-balanced: lane t sums the L consecutive sorted entries [t L, (t+1) L) whatever buckets they belong to, and
 // writes one partial per bucket it touches (partial t - floor(off[b] / L) of bucket b).  Every lane of a wave runs the same
 // trip count, where per-bucket segments left ~20 % of the lanes idle behind the longest segment.
-// npart[b] = number of lanes touching bucket b.
-__global__ void k_lane_parts(const uint32_t* cnt_all, const uint32_t* off_all, uint32_t B, uint32_t L, uint32_t* npart_all) {
-    uint32_t col = blockIdx.y, b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    uint32_t c = cnt_all[(size_t)col * B + b], o = off_all[(size_t)col * (B + 4) + b];
-    npart_all[(size_t)col * B + b] = c ? (o + c - 1) / L - o / L + 1 : 0;
-}
 __global__ void __launch_bounds__(256) k_accum_affine(const uint32_t* const* tables, const uint32_t* entries_all, size_t items,
                                                       const uint32_t* off_all, const uint32_t* segoff_all, uint32_t B, uint32_t L,
                                                       uint32_t* partial_all, size_t partial_stride) {
@@ -797,9 +803,9 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
     const uint32_t L = seg;
     { ProfScope ps(ctx, "msm_plan");
     ZK_TRY(launch_plan(ctx, (unsigned)ncols, (const uint32_t*)d_cnt, B, 1, (uint32_t*)d_off, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr));
-    hipLaunchKernelGGL(k_lane_parts, dim3(div_up(B, 256), (unsigned)ncols), dim3(256), 0, st, (const uint32_t*)d_cnt, (const uint32_t*)d_off, B, L,
-                       (uint32_t*)d_cntA);
-    ZK_TRY(launch_plan(ctx, (unsigned)ncols, (const uint32_t*)d_cntA, B, 1, (uint32_t*)d_offA, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)d_max)); }
+    // second scan, in lane mode: scans npart[b] (computed on the fly from cnt and off), writes it to cntA, its offsets to offA
+    ZK_TRY(launch_plan(ctx, (unsigned)ncols, (const uint32_t*)d_cnt, B, 1, (uint32_t*)d_offA, (uint32_t*)d_cntA, (uint32_t*)nullptr, (uint32_t*)d_max,
+                       (const uint32_t*)d_off, L)); }
     ZK_HIP(hipMemcpyAsync(h_max, d_max, ncols * 4, hipMemcpyDeviceToHost, st));
     ZK_HIP(hipEventRecord(ctx->ev_read, st));
     { ProfScope ps(ctx, "msm_digits");
