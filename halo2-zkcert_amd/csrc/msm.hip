@@ -627,26 +627,41 @@ __global__ void __launch_bounds__(256) k_accum_jac_q4(const uint32_t* in_all, si
     if (q == 0) g1x_store_loose(out_all + ((size_t)col * out_stride + t) * PART_WORDS, acc);
 }
 
-// tree over the block's 64 quads (256 lanes): sh[0] = sum
-__device__ __forceinline__ void block_tree_sum_q4(g1x* sh, uint32_t lt, uint32_t q, const g1x& mine) {
+// The tail in two shapes: LANES = 4 (quad-cooperative; the latency regime of a few columns) and LANES = 1 (one lane per chunk; a
+// wide batch has enough chunks to fill the chip, where the quads' 4x lane usage would cost throughput).
+template <int LANES>
+__device__ __forceinline__ g1x tail_add(const g1x& a, const g1x& b, uint32_t q) {
+    if (LANES == 4) return g1x_add_q4(a, b, q);
+    return g1x_add(a, b);
+}
+template <int LANES>
+__device__ __forceinline__ g1x tail_double(const g1x& a, uint32_t q) {
+    if (LANES == 4) return g1x_double_q4(a, q);
+    return g1x_double(a);
+}
+// tree over the block's 256 / LANES logical threads: sh[0] = sum
+template <int LANES>
+__device__ __forceinline__ void block_tree_sum_t(g1x* sh, uint32_t lt, uint32_t q, const g1x& mine) {
     if (q == 0) sh[lt] = mine;
     __syncthreads();
-    for (uint32_t d = 32; d >= 1; d >>= 1) {
+    for (uint32_t d = 128 / LANES; d >= 1; d >>= 1) {
         if (lt < d) {
-            g1x r = g1x_add_q4(sh[lt], sh[lt + d], q);
+            g1x r = tail_add<LANES>(sh[lt], sh[lt + d], q);
             if (q == 0) sh[lt] = r;
         }
         __syncthreads();
     }
 }
-// sum_{b} (b+1) * S_b over CH consecutive buckets per quad (running-sum trick + base * run), then a
-// tree over the block's 64 quads: one partial sum per block.
+// sum_{b} (b+1) * S_b over CH consecutive buckets per logical thread (running-sum trick + base * run), then a
+// tree over the block: one partial sum per block.
+template <int LANES>
 __global__ void __launch_bounds__(256) k_bucket_chunks(const uint32_t* part_all, size_t part_stride, const uint32_t* cnt_all,
                                                        const uint32_t* off_all, uint32_t B, uint32_t CH, uint32_t* out_all,
                                                        uint32_t nchunks) {
-    __shared__ g1x sh[64];
-    const uint32_t col = blockIdx.y, q = threadIdx.x & 3, lt = threadIdx.x >> 2;
-    const uint32_t t = blockIdx.x * 64 + lt;
+    constexpr uint32_t PER_BLOCK = 256 / LANES;
+    __shared__ g1x sh[PER_BLOCK];
+    const uint32_t col = blockIdx.y, q = threadIdx.x % LANES, lt = threadIdx.x / LANES;
+    const uint32_t t = blockIdx.x * PER_BLOCK + lt;
     g1x acc = g1x_identity();
     if (t < nchunks) {
         const uint32_t* cnt = cnt_all + (size_t)col * B;
@@ -658,20 +673,20 @@ __global__ void __launch_bounds__(256) k_bucket_chunks(const uint32_t* part_all,
             uint32_t b = base + (uint32_t)j;
             if (b < B) {   // the bucket's (few) partial sums are folded here: no separate reduction round for them
                 const uint32_t c = cnt[b], o = off[b];
-                for (uint32_t i = 0; i < c; ++i) run = g1x_add_q4(run, g1x_load_loose(part + (size_t)(o + i) * PART_WORDS), q);
+                for (uint32_t i = 0; i < c; ++i) run = tail_add<LANES>(run, g1x_load_loose(part + (size_t)(o + i) * PART_WORDS), q);
             }
-            acc = g1x_add_q4(acc, run, q);
+            acc = tail_add<LANES>(acc, run, q);
         }
         // + base * run
         g1x d = run;
         uint32_t m = base;
         while (m) {
-            if (m & 1) acc = g1x_add_q4(acc, d, q);
+            if (m & 1) acc = tail_add<LANES>(acc, d, q);
             m >>= 1;
-            if (m) d = g1x_double_q4(d, q);
+            if (m) d = tail_double<LANES>(d, q);
         }
     }
-    block_tree_sum_q4(sh, lt, q, acc);
+    block_tree_sum_t<LANES>(sh, lt, q, acc);
     if (threadIdx.x == 0) g1x_store_raw(out_all + ((size_t)col * gridDim.x + blockIdx.x) * 32, sh[0]);
 }
 
@@ -681,7 +696,7 @@ __global__ void __launch_bounds__(256) k_final_sum(const uint32_t* in_all, uint3
     const uint32_t* in = in_all + (size_t)col * count * 32;
     g1x acc = g1x_identity();
     for (uint32_t i = lt; i < count; i += 64) acc = g1x_add_q4(acc, g1x_load_raw(in + (size_t)i * 32), q);
-    block_tree_sum_q4(sh, lt, q, acc);
+    block_tree_sum_t<4>(sh, lt, q, acc);
     if (threadIdx.x == 0) g1j_store_abi(out_all + (size_t)col * 24, g1x_to_jacobian(sh[0]));   // the ABI result: halo2curves G1 (R = 2^256)
 }
 // self-check of the quad-cooperative operations against the one-lane ones (tests/test_gpu_msm.py): for pair i of XYZZ points
@@ -770,7 +785,10 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
     ZK_TRY(ctx->get_scratch("msm_pB", ncols * pstride0 * PART_WORDS * 4, &d_pB));
     uint32_t CH = B > 8192 ? B / 8192 : 1;
     uint32_t nchunks = (B + CH - 1) / CH;
-    uint32_t nchunk_blocks = div_up(nchunks, 64);   // 64 quads per block
+    // a wide batch has enough chunks to fill the chip with one lane each; otherwise four lanes share every point operation
+    bool wide_tail = (size_t)nchunks * ncols >= (size_t)48 * 1024;   // measured crossover: 6-8 columns at 8192 chunks
+    if (const char* e = getenv("ZKHIP_MSM_WIDETAIL")) wide_tail = atoi(e) != 0;
+    uint32_t nchunk_blocks = div_up(nchunks, wide_tail ? 256 : 64);
     ZK_TRY(ctx->get_scratch("msm_chunks", ncols * (size_t)nchunk_blocks * 128, &d_chunks));
 
     std::vector<const void*> h_ptrs(2 * ncols);
@@ -860,8 +878,12 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
         maxcnt = (maxcnt + seg - 1) / seg;
     }
     { ProfScope ps(ctx, "msm_tail");
-    hipLaunchKernelGGL(k_bucket_chunks, dim3(nchunk_blocks, (unsigned)ncols), dim3(256), 0, st, (const uint32_t*)cur_p, pstride0,
-                       cur_cnt, cur_off, B, CH, (uint32_t*)d_chunks, nchunks);
+    if (wide_tail)
+        hipLaunchKernelGGL(k_bucket_chunks<1>, dim3(nchunk_blocks, (unsigned)ncols), dim3(256), 0, st, (const uint32_t*)cur_p, pstride0,
+                           cur_cnt, cur_off, B, CH, (uint32_t*)d_chunks, nchunks);
+    else
+        hipLaunchKernelGGL(k_bucket_chunks<4>, dim3(nchunk_blocks, (unsigned)ncols), dim3(256), 0, st, (const uint32_t*)cur_p, pstride0,
+                           cur_cnt, cur_off, B, CH, (uint32_t*)d_chunks, nchunks);
     hipLaunchKernelGGL(k_final_sum, dim3((unsigned)ncols), dim3(256), 0, st, (const uint32_t*)d_chunks, nchunk_blocks, (uint32_t*)d_out); }
     ZK_LAUNCH_CHECK();
     return ZKHIP_OK;
