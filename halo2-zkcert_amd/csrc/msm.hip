@@ -155,7 +155,7 @@ int srs_build_raw(zkhip_ctx* ctx, const void* d_bases_raw, size_t n, zkhip_srs**
 // Each pass counts, reserves contiguous space with ONE returning global atomic per (tile, bin) — a wave
 // touches consecutive counters — and scatters with ranks from LDS atomics.  Per-pair global atomics and the
 // 4-byte scatter over the whole n*W range, which made the first version memory-bound at 2^22, are gone.
-struct SortGeom { uint32_t c, W, B, HB, LB, P; };
+struct SortGeom { uint32_t c, W, B, HB, LB, P, tile; };   // tile: pairs of one partition handled by one workgroup of the low pass
 #define SORT_TILE 4096u
 
 __device__ __forceinline__ void digit_at(const uint32_t* sl, uint32_t w, uint32_t c, uint32_t half, uint32_t mask, uint32_t& carry,
@@ -222,12 +222,12 @@ __global__ void __launch_bounds__(256) k_sort_hi(const uint32_t* const* scalar_c
     }
 }
 
-// part_off = exclusive scan of part_cnt (P + 1 entries); tile_start = exclusive scan of ceil(part_cnt / SORT_TILE).
-__global__ void __launch_bounds__(128) k_part_scan(const uint32_t* part_cnt_all, uint32_t P, uint32_t* part_off_all, uint32_t* tile_start_all) {
+// part_off = exclusive scan of part_cnt (P + 1 entries); tile_start = exclusive scan of ceil(part_cnt / tile).
+__global__ void __launch_bounds__(128) k_part_scan(const uint32_t* part_cnt_all, uint32_t P, uint32_t tile, uint32_t* part_off_all, uint32_t* tile_start_all) {
     __shared__ uint32_t a[128], b[128];
     uint32_t col = blockIdx.x, t = threadIdx.x;
     uint32_t v = t < P ? part_cnt_all[(size_t)col * 128 + t] : 0u;
-    uint32_t tl = (v + SORT_TILE - 1) / SORT_TILE;
+    uint32_t tl = (v + tile - 1) / tile;
     a[t] = v; b[t] = tl;
     __syncthreads();
     for (uint32_t d = 1; d < 128; d <<= 1) {
@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(128) k_part_scan(const uint32_t* part_cnt_all,
     if (t == P - 1) { po[P] = a[t]; ts[P] = b[t]; }
 }
 
-// One 4096-pair tile of one partition.  SCATTER = false: cnt[bucket] += ...; SCATTER = true: entries sorted by bucket.
+// One tile (g.tile pairs) of one partition.  SCATTER = false: cnt[bucket] += ...; SCATTER = true: entries sorted by bucket.
 template <bool SCATTER>
 __global__ void __launch_bounds__(256) k_sort_lo(const uint32_t* part_off_all, const uint32_t* tile_start_all, SortGeom g,
                                                  const uint32_t* tmp_entry_all, const uint16_t* tmp_key_all, size_t items,
@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(256) k_sort_lo(const uint32_t* part_off_all, c
         if (ts[mid] <= blk) lo_p = mid; else hi_p = mid;
     }
     const uint32_t p = lo_p;
-    const uint32_t beg = po[p] + (blk - ts[p]) * SORT_TILE, end = min(beg + SORT_TILE, po[p + 1]);
+    const uint32_t beg = po[p] + (blk - ts[p]) * g.tile, end = min(beg + g.tile, po[p + 1]);
     const uint32_t nbins = 1u << g.LB;
     for (uint32_t j = tid; j < nbins; j += 256) hist[j] = 0;
     __syncthreads();
@@ -759,6 +759,10 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
     g.HB = KB > 8 ? 7 : KB / 2;
     g.LB = KB - g.HB;
     g.P = 1u << g.HB;
+    // Measured at 2^22 (2^11 bins): tiles of 16k / 32k / 64k pairs, which lengthen the scatter's contiguous runs from 8 to
+    // 32-128 bytes, are 18-26 % SLOWER than 4096-pair tiles — the low pass is bound by its LDS rank atomics, not by run length.
+    g.tile = SORT_TILE;
+    if (const char* e = getenv("ZKHIP_SORT_TILE")) { int v = atoi(e); if (v >= 1024 && v <= (1 << 20)) g.tile = (uint32_t)v; }
     if (g.LB > 11) { set_error("zkhip_msm: window c = %u unsupported by the sort (max 19)", c); return ZKHIP_EINVAL; }
     ZK_TRY(ctx->get_scratch("msm_colptrs", 2 * ncols * sizeof(void*), &d_colptrs));
     // zeroed every call: part_cnt[128] + part_cursor[128] + cnt[B] + cursor[B] per column
@@ -804,14 +808,14 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
         if (const char* e = getenv("ZKHIP_MSM_SEG")) { int v = atoi(e); if (v >= (int)seg0_min && v <= 256) seg = (uint32_t)v; }
     }
     dim3 gn(div_up(n, 256), (unsigned)ncols);
-    dim3 gt(div_up(items, SORT_TILE) + g.P, (unsigned)ncols);
+    dim3 gt(div_up(items, g.tile) + g.P, (unsigned)ncols);
     std::vector<uint32_t> h_max_big;
     uint32_t* h_max = (uint32_t*)ctx->h_pinned;
     if (ncols * 4 > zkhip_ctx::PINNED_BYTES) { h_max_big.resize(ncols); h_max = h_max_big.data(); }
     { ProfScope ps(ctx, "msm_digits");
     hipLaunchKernelGGL(k_sort_hi<false>, gn, dim3(256), 0, st, (const uint32_t* const*)d_colptrs, n, first, srs->n, g, d_part_cnt, d_part_cursor,
                        (const uint32_t*)d_part_off, (uint32_t*)d_tmp_entry, (uint16_t*)d_tmp_key, items);
-    hipLaunchKernelGGL(k_part_scan, dim3((unsigned)ncols), dim3(128), 0, st, (const uint32_t*)d_part_cnt, g.P, d_part_off, d_tile_start);
+    hipLaunchKernelGGL(k_part_scan, dim3((unsigned)ncols), dim3(128), 0, st, (const uint32_t*)d_part_cnt, g.P, g.tile, d_part_off, d_tile_start);
     hipLaunchKernelGGL(k_sort_hi<true>, gn, dim3(256), 0, st, (const uint32_t* const*)d_colptrs, n, first, srs->n, g, d_part_cnt, d_part_cursor,
                        (const uint32_t*)d_part_off, (uint32_t*)d_tmp_entry, (uint16_t*)d_tmp_key, items);
     hipLaunchKernelGGL(k_sort_lo<false>, gt, dim3(256), 0, st, (const uint32_t*)d_part_off, (const uint32_t*)d_tile_start, g,
