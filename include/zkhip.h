@@ -62,7 +62,8 @@ int  zkhip_timer_stop_ms(zkhip_ctx* ctx, float* ms);   /* synchronises */
 
 /* Per-kernel timing: while enabled, every launch of the named kernels is bracketed by HIP events on
  * the launch stream.  Names: "msm_digits", "msm_plan", "msm_accum_affine", "msm_accum_jac", "msm_tail",
- * "ntt_strided", "ntt_final", "sweep", "grand_product", "batch_invert", "eval_polynomial".  zkhip_profile_enable also clears the record. */
+ * "ntt_strided", "ntt_final", "sweep", "lookup_permute", "grand_product", "batch_invert", "eval_polynomial",
+ * "linear_combination", "kate_division".  zkhip_profile_enable also clears the record. */
 int  zkhip_profile_enable(zkhip_ctx* ctx, int on);
 /* Restrict the recording to one kernel name (NULL = all): a proof issues ~60 timed spans, and their event records cost ~4 % of
  * a 10 ms proof, so a benchmark times only the kernel it reports live and takes the full breakdown in a separate pass. */
