@@ -17,6 +17,7 @@
 //    depth O(log), not O(count).
 //  * Integer-multiply bound: 8 * 171 + 2 * 126 = 1620 v_mad_u64_u32 per (pair, window).
 #include <algorithm>
+#include <mutex>
 
 #include "common.hpp"
 using namespace zk;
@@ -151,12 +152,15 @@ int srs_build_raw(zkhip_ctx* ctx, const void* d_bases_raw, size_t n, zkhip_srs**
 // zero for every canonical scalar < r < 2^254.  The n*W (digit, point) pairs are grouped by bucket |d| - 1
 // with a two-level most-significant-digit radix partition whose histograms live in LDS:
 //   hi pass: 256 scalars (256 W pairs) per block, P = 2^HB partitions by the top bits of the bucket;
-//   lo pass: 4096-pair tiles inside one partition, 2^LB bins by the low bits.
+//   lo pass: 4096-pair tiles inside one partition, 2^LB bins by the low bits; the scatter is staged through LDS so that a wave
+//            stores each bin's run with consecutive lanes.
 // Each pass counts, reserves contiguous space with ONE returning global atomic per (tile, bin) — a wave
 // touches consecutive counters — and scatters with ranks from LDS atomics.  Per-pair global atomics and the
 // 4-byte scatter over the whole n*W range, which made the first version memory-bound at 2^22, are gone.
 struct SortGeom { uint32_t c, W, B, HB, LB, P, tile; };   // tile: pairs of one partition handled by one workgroup of the low pass
 #define SORT_TILE 4096u
+
+extern __shared__ uint32_t sort_lds[];   // staging area of the two scatter kernels
 
 __device__ __forceinline__ void digit_at(const uint32_t* sl, uint32_t w, uint32_t c, uint32_t half, uint32_t mask, uint32_t& carry,
                                          uint32_t& mag, uint32_t& neg) {
@@ -174,8 +178,9 @@ __global__ void __launch_bounds__(256) k_sort_hi(const uint32_t* const* scalar_c
                                                  uint32_t* part_cnt_all, uint32_t* part_cursor_all, const uint32_t* part_off_all,
                                                  uint32_t* tmp_entry_all, uint16_t* tmp_key_all, size_t items) {
     __shared__ uint32_t sl[256][9];
-    __shared__ uint32_t hist[128], base[128];
+    __shared__ uint32_t hist[128], base[128], cnt_of[128];
     const uint32_t tid = threadIdx.x, col = blockIdx.y;
+    const bool staged = SCATTER && g.W <= 24;   // 256 W pairs x 7 bytes of dynamic LDS
     size_t i = blockIdx.x * (size_t)256 + tid;
     const bool live = i < n;
     if (tid < 128) hist[tid] = 0;
@@ -203,22 +208,60 @@ __global__ void __launch_bounds__(256) k_sort_hi(const uint32_t* const* scalar_c
     if (tid < g.P) {
         uint32_t h = hist[tid];
         base[tid] = h ? part_off_all[(size_t)col * 132 + tid] + atomicAdd(&part_cursor_all[(size_t)col * 128 + tid], h) : 0u;
+        cnt_of[tid] = h;
         hist[tid] = 0;
     }
     __syncthreads();
+    uint32_t* tmp_entry = tmp_entry_all + (size_t)col * items;
+    uint16_t* tmp_key = tmp_key_all + (size_t)col * items;
+    if (!staged) {   // many windows (tiny sizes): the block's pairs do not fit in LDS, store them one by one
+        if (live) {
+            uint32_t carry = 0, mag, neg;
+            for (uint32_t w = 0; w < g.W; ++w) {
+                digit_at(sl[tid], w, g.c, half, mask, carry, mag, neg);
+                if (mag) {
+                    uint32_t b = mag - 1, p = b >> g.LB;
+                    uint32_t pos = base[p] + atomicAdd(&hist[p], 1u);
+                    tmp_entry[pos] = (uint32_t)(w * srs_n + first + i) | (neg << 31);
+                    tmp_key[pos] = (uint16_t)(b & lomask);
+                }
+            }
+        }
+        return;
+    }
+    // staged: group the block's pairs by partition inside LDS, then store every partition's run with consecutive lanes
+    __shared__ uint32_t lst[129];
+    uint32_t* st_e = sort_lds;                                                // [256 W]
+    uint16_t* st_k = reinterpret_cast<uint16_t*>(st_e + 256 * g.W);           // [256 W]
+    uint8_t* st_p = reinterpret_cast<uint8_t*>(st_k + 256 * g.W);             // [256 W]
+    if (tid == 0) {   // <= 128 partitions: a serial scan is cheaper than a barrier tree
+        uint32_t run = 0;
+        for (uint32_t p = 0; p < g.P; ++p) { lst[p] = run; run += cnt_of[p]; }
+        lst[g.P] = run;
+    }
+    __syncthreads();
+    if (tid < g.P) hist[tid] = lst[tid];
+    __syncthreads();
     if (live) {
-        uint32_t* tmp_entry = tmp_entry_all + (size_t)col * items;
-        uint16_t* tmp_key = tmp_key_all + (size_t)col * items;
         uint32_t carry = 0, mag, neg;
         for (uint32_t w = 0; w < g.W; ++w) {
             digit_at(sl[tid], w, g.c, half, mask, carry, mag, neg);
             if (mag) {
                 uint32_t b = mag - 1, p = b >> g.LB;
-                uint32_t pos = base[p] + atomicAdd(&hist[p], 1u);
-                tmp_entry[pos] = (uint32_t)(w * srs_n + first + i) | (neg << 31);
-                tmp_key[pos] = (uint16_t)(b & lomask);
+                uint32_t slot = atomicAdd(&hist[p], 1u);
+                st_e[slot] = (uint32_t)(w * srs_n + first + i) | (neg << 31);
+                st_k[slot] = (uint16_t)(b & lomask);
+                st_p[slot] = (uint8_t)p;
             }
         }
+    }
+    __syncthreads();
+    const uint32_t total = lst[g.P];
+    for (uint32_t s_ = tid; s_ < total; s_ += 256) {
+        uint32_t p = st_p[s_];
+        uint32_t pos = base[p] + (s_ - lst[p]);
+        tmp_entry[pos] = st_e[s_];
+        tmp_key[pos] = st_k[s_];
     }
 }
 
@@ -242,12 +285,10 @@ __global__ void __launch_bounds__(128) k_part_scan(const uint32_t* part_cnt_all,
     if (t == P - 1) { po[P] = a[t]; ts[P] = b[t]; }
 }
 
-// One tile (g.tile pairs) of one partition.  SCATTER = false: cnt[bucket] += ...; SCATTER = true: entries sorted by bucket.
-template <bool SCATTER>
-__global__ void __launch_bounds__(256) k_sort_lo(const uint32_t* part_off_all, const uint32_t* tile_start_all, SortGeom g,
-                                                 const uint32_t* tmp_entry_all, const uint16_t* tmp_key_all, size_t items,
-                                                 uint32_t* cnt_all, const uint32_t* off_all, uint32_t* cursor_all, uint32_t* entries_all) {
-    __shared__ uint32_t hist[2048], base[2048];
+// One tile (g.tile pairs) of one partition: cnt[bucket] += the tile's histogram.
+__global__ void __launch_bounds__(256) k_sort_lo_count(const uint32_t* part_off_all, const uint32_t* tile_start_all, SortGeom g,
+                                                       const uint16_t* tmp_key_all, size_t items, uint32_t* cnt_all) {
+    __shared__ uint32_t hist[2048];
     const uint32_t tid = threadIdx.x, col = blockIdx.y, blk = blockIdx.x;
     const uint32_t* po = part_off_all + (size_t)col * 132;
     const uint32_t* ts = tile_start_all + (size_t)col * 132;
@@ -265,26 +306,78 @@ __global__ void __launch_bounds__(256) k_sort_lo(const uint32_t* part_off_all, c
     const uint16_t* tmp_key = tmp_key_all + (size_t)col * items;
     for (uint32_t j = beg + tid; j < end; j += 256) atomicAdd(&hist[tmp_key[j]], 1u);
     __syncthreads();
+    uint32_t* cnt = cnt_all + (size_t)col * g.B;
     const uint32_t bucket0 = p << g.LB;
-    if (!SCATTER) {
-        uint32_t* cnt = cnt_all + (size_t)col * g.B;
-        for (uint32_t j = tid; j < nbins; j += 256)
-            if (hist[j]) atomicAdd(&cnt[bucket0 + j], hist[j]);
-        return;
+    for (uint32_t j = tid; j < nbins; j += 256)
+        if (hist[j]) atomicAdd(&cnt[bucket0 + j], hist[j]);
+}
+
+// The final scatter, staged: a tile's pairs are first grouped by bin inside LDS (ranks from LDS atomics), then written out in
+// bin order, so that the lanes of a wave store to consecutive addresses within every bin's run (the direct version issued one
+// isolated 4-byte store per pair: each cost a whole memory sector).
+__global__ void __launch_bounds__(256) k_sort_lo_staged(const uint32_t* part_off_all, const uint32_t* tile_start_all, SortGeom g,
+                                                        const uint32_t* tmp_entry_all, const uint16_t* tmp_key_all, size_t items,
+                                                        const uint32_t* off_all, uint32_t* cursor_all, uint32_t* entries_all) {
+    __shared__ uint32_t w_tot[4];
+    const uint32_t tid = threadIdx.x, col = blockIdx.y, blk = blockIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t* po = part_off_all + (size_t)col * 132;
+    const uint32_t* ts = tile_start_all + (size_t)col * 132;
+    if (blk >= ts[g.P]) return;
+    uint32_t lo_p = 0, hi_p = g.P;   // largest p with ts[p] <= blk
+    while (hi_p - lo_p > 1) {
+        uint32_t mid = (lo_p + hi_p) >> 1;
+        if (ts[mid] <= blk) lo_p = mid; else hi_p = mid;
     }
+    const uint32_t p = lo_p;
+    const uint32_t beg = po[p] + (blk - ts[p]) * g.tile, end = min(beg + g.tile, po[p + 1]), cnt = end - beg;
+    const uint32_t nbins = 1u << g.LB;
+    uint32_t* hist = sort_lds;                 // [nbins] counts, then running cursors
+    uint32_t* base = hist + nbins;             // [nbins] global position of the bin's run
+    uint32_t* lst = base + nbins;              // [nbins] start of the bin inside the staged tile
+    uint32_t* st_e = lst + nbins;              // [tile] staged entries
+    uint16_t* st_k = reinterpret_cast<uint16_t*>(st_e + g.tile);   // [tile] their bins
+    for (uint32_t j = tid; j < nbins; j += 256) hist[j] = 0;
+    __syncthreads();
+    const uint16_t* tmp_key = tmp_key_all + (size_t)col * items;
+    for (uint32_t j = beg + tid; j < end; j += 256) atomicAdd(&hist[tmp_key[j]], 1u);
+    __syncthreads();
+    // exclusive scan of the counts (8 bins per thread for 2048 bins), and one returning global atomic per non-empty bin
+    const uint32_t bucket0 = p << g.LB;
     const uint32_t* off = off_all + (size_t)col * (g.B + 4);
     uint32_t* cursor = cursor_all + (size_t)col * g.B;
-    for (uint32_t j = tid; j < nbins; j += 256) {
-        uint32_t h = hist[j];
-        base[j] = h ? off[bucket0 + j] + atomicAdd(&cursor[bucket0 + j], h) : 0u;
-        hist[j] = 0;
+    const uint32_t per = (nbins + 255) / 256;
+    uint32_t my = 0;
+    for (uint32_t q = 0; q < per; ++q) { uint32_t j = tid * per + q; if (j < nbins) my += hist[j]; }
+    uint32_t inc = my;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { uint32_t u = __shfl_up(inc, d); if ((int)lane >= d) inc += u; }
+    if (lane == 63) w_tot[wave] = inc;
+    __syncthreads();
+    uint32_t run = inc - my;
+    for (uint32_t w = 0; w < wave; ++w) run += w_tot[w];
+    for (uint32_t q = 0; q < per; ++q) {
+        uint32_t j = tid * per + q;
+        if (j < nbins) {
+            uint32_t h = hist[j];
+            base[j] = h ? off[bucket0 + j] + atomicAdd(&cursor[bucket0 + j], h) : 0u;
+            lst[j] = run;
+            hist[j] = run;
+            run += h;
+        }
     }
     __syncthreads();
     const uint32_t* tmp_entry = tmp_entry_all + (size_t)col * items;
-    uint32_t* entries = entries_all + (size_t)col * items;
     for (uint32_t j = beg + tid; j < end; j += 256) {
         uint32_t key = tmp_key[j];
-        entries[base[key] + atomicAdd(&hist[key], 1u)] = tmp_entry[j];
+        uint32_t slot = atomicAdd(&hist[key], 1u);
+        st_e[slot] = tmp_entry[j];
+        st_k[slot] = (uint16_t)key;
+    }
+    __syncthreads();
+    uint32_t* entries = entries_all + (size_t)col * items;
+    for (uint32_t i = tid; i < cnt; i += 256) {
+        uint32_t key = st_k[i];
+        entries[base[key] + (i - lst[key])] = st_e[i];
     }
 }
 
@@ -816,11 +909,10 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
     hipLaunchKernelGGL(k_sort_hi<false>, gn, dim3(256), 0, st, (const uint32_t* const*)d_colptrs, n, first, srs->n, g, d_part_cnt, d_part_cursor,
                        (const uint32_t*)d_part_off, (uint32_t*)d_tmp_entry, (uint16_t*)d_tmp_key, items);
     hipLaunchKernelGGL(k_part_scan, dim3((unsigned)ncols), dim3(128), 0, st, (const uint32_t*)d_part_cnt, g.P, g.tile, d_part_off, d_tile_start);
-    hipLaunchKernelGGL(k_sort_hi<true>, gn, dim3(256), 0, st, (const uint32_t* const*)d_colptrs, n, first, srs->n, g, d_part_cnt, d_part_cursor,
+    hipLaunchKernelGGL(k_sort_hi<true>, gn, dim3(256), g.W <= 24 ? (size_t)256 * g.W * 7 + 16 : 0, st, (const uint32_t* const*)d_colptrs, n, first, srs->n, g, d_part_cnt, d_part_cursor,
                        (const uint32_t*)d_part_off, (uint32_t*)d_tmp_entry, (uint16_t*)d_tmp_key, items);
-    hipLaunchKernelGGL(k_sort_lo<false>, gt, dim3(256), 0, st, (const uint32_t*)d_part_off, (const uint32_t*)d_tile_start, g,
-                       (const uint32_t*)d_tmp_entry, (const uint16_t*)d_tmp_key, items, d_cnt, (const uint32_t*)d_off, d_cursor,
-                       (uint32_t*)d_entries); }
+    hipLaunchKernelGGL(k_sort_lo_count, gt, dim3(256), 0, st, (const uint32_t*)d_part_off, (const uint32_t*)d_tile_start, g,
+                       (const uint16_t*)d_tmp_key, items, d_cnt); }
     // plan: bucket offsets, then the number of round-0 lanes touching each bucket (= its partial sums) and their offsets
     const uint32_t L = seg;
     { ProfScope ps(ctx, "msm_plan");
@@ -831,9 +923,15 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
     ZK_HIP(hipMemcpyAsync(h_max, d_max, ncols * 4, hipMemcpyDeviceToHost, st));
     ZK_HIP(hipEventRecord(ctx->ev_read, st));
     { ProfScope ps(ctx, "msm_digits");
-    hipLaunchKernelGGL(k_sort_lo<true>, gt, dim3(256), 0, st, (const uint32_t*)d_part_off, (const uint32_t*)d_tile_start, g,
-                       (const uint32_t*)d_tmp_entry, (const uint16_t*)d_tmp_key, items, d_cnt, (const uint32_t*)d_off, d_cursor,
-                       (uint32_t*)d_entries); }
+    {
+        const size_t lds = (size_t)3 * (1u << g.LB) * 4 + (size_t)g.tile * 6;
+        static std::once_flag attr_once;
+        hipError_t attr_err = hipSuccess;
+        std::call_once(attr_once, [&] { attr_err = hipFuncSetAttribute((const void*)k_sort_lo_staged, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); });
+        ZK_HIP(attr_err);
+        hipLaunchKernelGGL(k_sort_lo_staged, gt, dim3(256), lds, st, (const uint32_t*)d_part_off, (const uint32_t*)d_tile_start, g,
+                           (const uint32_t*)d_tmp_entry, (const uint16_t*)d_tmp_key, items, (const uint32_t*)d_off, d_cursor, (uint32_t*)d_entries);
+    } }
     // round 0 does not need the maximum: it is issued before the host waits for it
     { ProfScope ps(ctx, "msm_accum_affine");
     hipLaunchKernelGGL(k_accum_affine, dim3(div_up(div_up(items, L), 256), (unsigned)ncols), dim3(256), 0, st,
