@@ -633,9 +633,10 @@ class Prover:
         self._npk, self._npk_keep = pk, keep
         return pk
 
-    def prove_native(self, wit):
+    def prove_native(self, wit, fetch_h=False):
         """The same pass through zkhip_create_proof (the schedule and all host arithmetic in the library); this side keeps
-        the transcript.  Returns the same trace as prove()."""
+        the transcript.  Returns the same trace as prove(); the quotient's coefficients are copied to the host only on request
+        (fetch_h: 96 n bytes over PCIe, for tests)."""
         import ctypes as C
 
         sh, b, n = self.shape, self.b, self.n
@@ -682,9 +683,11 @@ class Prover:
         assert out.n_evals == len(qlist) and state["p"] == len(point_tags) and state["s"] == len(squeeze_tags)
         trace["evals"] = [(q_, evals[i_]) for i_, q_ in enumerate(qlist)]
         trace["query_list"] = qlist
-        h = np.empty((qd * n, 4), dtype=np.uint64)
-        ffi._check(ffi.lib().zkhip_memcpy_d2h(ctx.h, h.ctypes.data_as(C.c_void_p), C.c_void_p(out.d_h), C.c_size_t(qd * n * 32)))
-        trace["h_pieces"] = [h[i_ * n:(i_ + 1) * n] for i_ in range(qd)]
+        trace["h_pieces"] = None
+        if fetch_h:
+            h = np.empty((qd * n, 4), dtype=np.uint64)
+            ffi._check(ffi.lib().zkhip_memcpy_d2h(ctx.h, h.ctypes.data_as(C.c_void_p), C.c_void_p(out.d_h), C.c_size_t(qd * n * 32)))
+            trace["h_pieces"] = [h[i_ * n:(i_ + 1) * n] for i_ in range(qd)]
         trace["opening"] = dict(y=trace["challenges"]["shplonk_y"], v=trace["challenges"]["shplonk_v"], u=trace["challenges"]["shplonk_u"])
         trace["n_commitments"] = len(trace["commitments"])
         return trace

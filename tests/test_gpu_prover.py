@@ -116,7 +116,7 @@ def test_native_create_proof_matches_schedule(zk, oracle, k):
     gp = pv.Prover(pv.GpuBackend(ctx, ffi), sh, satisfiable=True)
     w = gp.witness(4)
     ta = gp.prove(w)
-    tb = gp.prove_native(w)
+    tb = gp.prove_native(w, fetch_h=True)
     assert ta["commitments"] == tb["commitments"]
     assert ta["challenges"] == tb["challenges"]
     assert [q for q, _ in ta["evals"]] == [q for q, _ in tb["evals"]]
