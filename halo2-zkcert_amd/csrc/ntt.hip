@@ -146,11 +146,13 @@ __device__ __forceinline__ fe load_in(const uint32_t* src, uint32_t i, uint32_t 
 }
 
 // Non-final pass: position = (hi << (s + lo_bits)) | (digit << lo_bits) | lo.
-__global__ void __launch_bounds__(256) k_ntt_strided(const uint32_t* const* srcs, uint32_t* const* dsts, uint32_t m, uint32_t s,
-                                                      uint32_t lo_bits, uint32_t logT, uint32_t n_in, TwDev tw, NttScale sc) {
+// One workgroup transforms the same tile position of `group` polynomials one after the other: the Cooley-Tukey twiddles
+// w^(lo * r << hi_bits) of its 8 outputs per thread depend on the position only, so they are built once (two table loads and a
+// product each) and reused — a quarter of the pass's products when every polynomial pays for them.
+__global__ void __launch_bounds__(256) k_ntt_strided(const uint32_t* const* srcs, uint32_t* const* dsts, uint32_t npolys, uint32_t group,
+                                                      uint32_t m, uint32_t s, uint32_t lo_bits, uint32_t logT, uint32_t n_in, TwDev tw,
+                                                      NttScale sc) {
     fe* tile = reinterpret_cast<fe*>(ntt_lds);
-    const uint32_t* src = srcs[blockIdx.y];
-    uint32_t* dst = dsts[blockIdx.y];
     uint32_t T = 1u << logT, rows = 1u << s;
     uint32_t hi_bits = m - s - lo_bits;
     uint32_t tiles_lo = 1u << (lo_bits - logT);
@@ -158,20 +160,33 @@ __global__ void __launch_bounds__(256) k_ntt_strided(const uint32_t* const* srcs
     uint32_t lo0 = lo_tile << logT;
     uint32_t base = (hi << (s + lo_bits)) | lo0;
     uint32_t cnt = rows * T;
-    for (uint32_t e = threadIdx.x; e < cnt; e += blockDim.x) {
-        uint32_t tl = e & (T - 1), j = e >> logT;
-        uint32_t pos = base | (j << lo_bits) | tl;
-        tile[bitrev(j, s) * T + tl] = load_in(src, pos, n_in, sc);
-    }
-    tile_ntt(tile, s, logT, tw);
-    for (uint32_t e = threadIdx.x; e < cnt; e += blockDim.x) {
+    fe twr[NTT_TILE / 256];   // this thread's output twiddles (the exponent-0 ones are the field's one: a product is cheaper than a branch here)
+#pragma clang loop unroll(full)
+    for (uint32_t it = 0; it < NTT_TILE / 256; ++it) {
+        uint32_t e = threadIdx.x + it * 256;
         uint32_t tl = e & (T - 1), r = e >> logT;
-        uint32_t lo = lo0 | tl;
-        tile_el v(tile[r * T + tl]);
-        uint32_t ex = (lo * r) << hi_bits;  // < n
-        void* out = dst + (size_t)(base | (r << lo_bits) | tl) * 8;
-        if (ex != 0) store_raw<Fr>(out, v * twiddle_at(tw, ex));
-        else store_raw<Fr>(out, v);
+        twr[it] = (e < cnt ? twiddle_at(tw, ((lo0 | tl) * r) << hi_bits) : el2<Fr>(one<Fr>())).v;
+    }
+    const uint32_t p0 = blockIdx.y * group, p1 = min(npolys, p0 + group);
+    for (uint32_t pi = p0; pi < p1; ++pi) {
+        const uint32_t* src = srcs[pi];
+        uint32_t* dst = dsts[pi];
+        for (uint32_t e = threadIdx.x; e < cnt; e += blockDim.x) {
+            uint32_t tl = e & (T - 1), j = e >> logT;
+            uint32_t pos = base | (j << lo_bits) | tl;
+            tile[bitrev(j, s) * T + tl] = load_in(src, pos, n_in, sc);
+        }
+        tile_ntt(tile, s, logT, tw);
+#pragma clang loop unroll(full)
+        for (uint32_t it = 0; it < NTT_TILE / 256; ++it) {
+            uint32_t e = threadIdx.x + it * 256;
+            if (e < cnt) {
+                uint32_t tl = e & (T - 1), r = e >> logT;
+                tile_el v(tile[r * T + tl]);
+                store_raw<Fr>(dst + (size_t)(base | (r << lo_bits) | tl) * 8, v * el2<Fr>(twr[it]));
+            }
+        }
+        __syncthreads();   // the tile is reloaded for the next polynomial
     }
 }
 
@@ -286,9 +301,14 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
         scq.use_post = 0;
         uint32_t** out = (q + 2 == np) ? d_tmp : d_dst;
         unsigned blocks = (unsigned)(n >> (s + logT));
+        // polynomials per workgroup: as many as keep >= 512 workgroups in the launch (two per CU; measured crossover)
+        uint32_t group = 1;
+        while (group < npolys && (size_t)blocks * ((npolys + 2 * group - 1) / (2 * group)) >= 512) group *= 2;
+        if (const char* e = getenv("ZKHIP_NTT_GROUP")) { int v = atoi(e); if (v >= 1 && v <= 64) group = (uint32_t)v; }
         ProfScope ps(ctx, "ntt_strided");
-        hipLaunchKernelGGL(k_ntt_strided, dim3(blocks, (unsigned)npolys), dim3(256), NTT_TILE * sizeof(fe), st, (const uint32_t* const*)cur_src,
-                           (uint32_t* const*)out, m, s, lo_bits, logT, q == 0 ? n_in : (uint32_t)n, tw, scq);
+        hipLaunchKernelGGL(k_ntt_strided, dim3(blocks, (unsigned)((npolys + group - 1) / group)), dim3(256), NTT_TILE * sizeof(fe), st,
+                           (const uint32_t* const*)cur_src, (uint32_t* const*)out, (uint32_t)npolys, group, m, s, lo_bits, logT,
+                           q == 0 ? n_in : (uint32_t)n, tw, scq);
         cur_src = (const uint32_t**)out;
     }
     {
