@@ -19,9 +19,9 @@ and the evaluations of every queried polynomial at x * omega^rotation.
 The lookup argument's permuted columns are computed for real too (permute_expression_pair: a sort), which is why
 the synthetic lookup-advice columns draw their values from the table column: the lookup has to be satisfiable.
 
-What is NOT here ("next" rows): witness synthesis and the real Poseidon/Keccak transcript.  The witness is
-replaced by synthetic columns of the right shape and the transcript by BLAKE2b over the same commitment / evaluation bytes, so
-every Fiat-Shamir host round trip of the real prover is still on the critical path.
+What is NOT here ("next" rows): witness synthesis and the Poseidon / Keccak transcripts of snark-verifier.  The
+witness is replaced by synthetic columns of the right shape; the transcript is halo2's own Blake2bWrite (Blake2bTranscript below),
+so every Fiat-Shamir host round trip of the real prover is on the critical path.
 
 The schedule is written against a small backend interface so the same code drives the HIP library
 (GpuBackend, here) and, in tests/ and bench.py's cpu_baseline leg only, the CPU oracle.
@@ -136,6 +136,38 @@ class CircuitShape:
         q = self.degree - 1
         return dict(msm=A + 3 * L + Zp + 1 + q + 2, intt_n=A + I + 3 * L + Zp, ntt_ext=A + I + 3 * L + Zp, intt_ext=1,
                     sweep_rows=1 << dom_extended_k)
+
+
+Q_MOD = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47   # Fq
+Q_INV_256 = pow(1 << 256, -1, Q_MOD)
+
+
+class Blake2bTranscript:
+    """halo2_proofs transcript.rs Blake2bWrite<_, G1Affine, Challenge255<_>> [UPSTREAM-RECALL; crate pinned at
+    /root/reference/Cargo.lock:1320-1322]: a BLAKE2b-512 state personalised "Halo2-Transcript"; a point is absorbed as prefix 1
+    and its canonical x and y (32 little-endian bytes each), a scalar as prefix 2 and its canonical 32 bytes; a challenge is
+    prefix 0 followed by the 64-byte digest of a clone of the state, reduced into Fr as a little-endian integer.
+    (The reference's own commands use snark-verifier's Poseidon / Keccak transcripts, whose constants are not available here:
+    this is the transcript halo2 itself ships.)"""
+
+    def __init__(self):
+        self.state = hashlib.blake2b(digest_size=64, person=b"Halo2-Transcript")
+
+    @staticmethod
+    def _canon(limbs, inv, mod):
+        v = int(limbs[0]) | int(limbs[1]) << 64 | int(limbs[2]) << 128 | int(limbs[3]) << 192
+        return (v * inv % mod).to_bytes(32, "little")
+
+    def write_point(self, xy):
+        """xy: affine point, 8 Montgomery limbs (x, y); the identity is (0, 0)"""
+        self.state.update(b"\x01" + self._canon(xy[:4], Q_INV_256, Q_MOD) + self._canon(xy[4:], Q_INV_256, Q_MOD))
+
+    def write_scalar(self, limbs):
+        self.state.update(b"\x02" + self._canon(limbs, R_INV_256, R))
+
+    def squeeze(self):
+        self.state.update(b"\x00")
+        return int.from_bytes(self.state.copy().digest(), "little") % R
 
 
 def challenge(tag, commitment_bytes):
@@ -648,24 +680,23 @@ class Prover:
             + ["shplonk_h1", "shplonk_h2"]
         squeeze_tags = ["theta", "beta", "gamma", "y", "x", "shplonk_y", "shplonk_v", "shplonk_u"]
         trace = {"commitments": [], "challenges": {}, "points": {}}
-        tx, state = [], dict(p=0, s=0)
+        ts, state = Blake2bTranscript(), dict(p=0, s=0)
 
         def write_point(byts, xy):
             tag = point_tags[state["p"]]
             state["p"] += 1
             trace["commitments"].append((tag, byts.hex()))
             trace["points"].setdefault(tag, []).append(xy)
-            tx.append(byts)
+            ts.write_point(xy)
 
         def squeeze():
             tag = squeeze_tags[state["s"]]
             state["s"] += 1
-            c = challenge(tag, tx)
+            c = ts.squeeze()
             trace["challenges"][tag] = c
             return fr_from_int_host(c)
 
-        def write_scalar(limbs):
-            tx.append(limbs.tobytes())
+        write_scalar = ts.write_scalar
 
         t = ffi.make_transcript(write_point, squeeze, write_scalar)
         qlist = self._query_list()
@@ -698,11 +729,14 @@ class Prover:
         base = wit["base"]
         L, Zp = len(sh.lookups), sh.n_perm_sets
         trace = {"commitments": [], "challenges": {}, "points": {}}
+        ts = Blake2bTranscript()
 
         def absorb(tag, pts):
             byts = [p[1] for p in pts]
             trace["points"].setdefault(tag, []).extend(p[0] for p in pts)
             trace["commitments"] += [(tag, x.hex()) for x in byts]
+            for p_ in pts:
+                ts.write_point(p_[0])
             return byts
 
         # 1. advice commitments (Lagrange basis).  The vanishing argument's random polynomial does not depend on
@@ -718,7 +752,7 @@ class Prover:
             ext_adv = b.coeff_to_extended(adv_coeff)
         c1 = b.commit(advice + rand_poly, lagrange=[True] * len(advice) + [False])
         t1 = absorb("advice", c1[:len(advice)])
-        theta = challenge("theta", t1)
+        theta = ts.squeeze()
         # 2. lookups: theta-compress the input / table expressions, permute_expression_pair (sort; blinding rows are
         #    seeded stand-ins for the rng); commit the permuted pair in coefficient form
         bf = sh.blinding_factors
@@ -732,7 +766,7 @@ class Prover:
         with b.overlap():
             ext_perm = b.coeff_to_extended(perm_in + perm_tab)
         t2 = absorb("lookup_permuted", b.commit(perm_in + perm_tab, lagrange=False)) if L else []
-        beta, gamma = challenge("beta", t1 + t2), challenge("gamma", t1 + t2)
+        beta, gamma = ts.squeeze(), ts.squeeze()
         # 3. grand products: permutation (chunks of degree-2 columns) and one per lookup; blinding rows are seeded stand-ins
         cols = {"advice": wit["advice"], "fixed": self.fixed_lagrange, "instance": wit["instance"]}
         perm_values = [cols[t][i] for t, i in sh.perm_columns]
@@ -745,7 +779,7 @@ class Prover:
         t3 = absorb("products", b.commit(perm_z + look_z, lagrange=False))
         # 4. vanishing argument's random polynomial (committed in pass 1)
         t4 = absorb("random_poly", c1[len(advice):])
-        y = challenge("y", t1 + t2 + t3 + t4)
+        y = ts.squeeze()
         # 5. quotient: everything is on the extended coset by now; sweep, divide, back to coefficients
         b.join()
         adv_c, ins_c = ext_adv[:sh.n_advice], ext_adv[sh.n_advice:]
@@ -778,7 +812,7 @@ class Prover:
         polys[("random", 0)] = rand_poly[0]
         qlist = self._query_list()
         t5 = absorb("quotient", b.commit_end(quotient_commit))
-        x = challenge("x", t1 + t2 + t3 + t4 + t5)
+        x = ts.squeeze()
         xn = pow(x, n, R)
         polys[("h", 0)] = b.lincomb(pieces, [pow(xn, i_, R) for i_ in range(len(pieces))], None)   # sum_i x^(n i) h_i(X)
         rot_point = {rot: x * pow(self.omega, rot % n, R) % R for rot in {rot for _, rot in qlist}}
@@ -787,16 +821,16 @@ class Prover:
         trace["evals"] = [(q_, flat[i_]) for i_, q_ in enumerate(qlist)]
         trace["query_list"] = qlist
         # the transcript receives every evaluation except h's (the verifier recomputes it)
-        tx = t1 + t2 + t3 + t4 + t5 + [flat[i_].tobytes() for i_, q_ in enumerate(qlist) if q_[0][0] != "h"]
+        for i_, q_ in enumerate(qlist):
+            if q_[0][0] != "h":
+                ts.write_scalar(flat[i_])
         # 6. SHPLONK multi-open of all of them: two more commitments
-        def write_points(tag, pts):
-            tx.extend(absorb(tag, pts))
         if hasattr(b, "multiopen"):      # the library's ProverSHPLONK (host arithmetic in C++; evaluations stay in ABI form)
-            opening = b.multiopen(polys, [(key, pt) for (key, _), pt in zip(qlist, points)], flat, lambda tag: challenge(tag, tx), write_points)
+            opening = b.multiopen(polys, [(key, pt) for (key, _), pt in zip(qlist, points)], flat, lambda tag: ts.squeeze(), absorb)
         else:
             evals = eval_ints(trace)
             queries = [(key, pt, evals[(key, rot)]) for (key, rot), pt in zip(qlist, points)]
-            opening = ShplonkProver(b).create_proof(polys, queries, lambda tag: challenge(tag, tx), write_points)
+            opening = ShplonkProver(b).create_proof(polys, queries, lambda tag: ts.squeeze(), absorb)
         trace["challenges"] = dict(theta=theta, beta=beta, gamma=gamma, y=y, x=x, shplonk_y=opening["y"], shplonk_v=opening["v"],
                                    shplonk_u=opening["u"])
         trace["opening"] = opening

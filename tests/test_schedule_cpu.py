@@ -75,3 +75,24 @@ def test_unsatisfied_witness_is_rejected(oracle):
     src = p.copy_pairs[0][0]
     wit["advice"][sh.perm_columns[src // p.n][1]][src % p.n] = zo.fr_from_int(777)   # breaks a copy (and the gate using it)
     assert not verify_trace(p, wit, p.prove(wit))
+
+
+def test_blake2b_transcript_layout(oracle):
+    """Blake2bWrite as restated in prover.Blake2bTranscript: personalisation, prefixes, canonical little-endian encodings,
+    challenge = 64-byte digest of a state clone reduced mod r (recomputed here with hashlib directly)."""
+    import hashlib
+
+    zo = oracle
+    g = zo.g1_to_affine(zo.g1_mul_gen(zo.fr_from_int(5)))                    # 5 G, Montgomery limbs
+    gx, gy = zo.affine_to_ints(g.reshape(1, 8))[0]
+    s = 0x1234567890ABCDEF1234567890ABCDEF
+    t = pv.Blake2bTranscript()
+    t.write_point(g)
+    t.write_scalar(zo.fr_from_int(s))
+    c1 = t.squeeze()
+    c2 = t.squeeze()
+    h = hashlib.blake2b(digest_size=64, person=b"Halo2-Transcript")
+    h.update(b"\x01" + gx.to_bytes(32, "little") + gy.to_bytes(32, "little") + b"\x02" + s.to_bytes(32, "little") + b"\x00")
+    assert c1 == int.from_bytes(h.digest(), "little") % pv.R
+    h.update(b"\x00")
+    assert c2 == int.from_bytes(h.digest(), "little") % pv.R and c1 != c2
