@@ -39,6 +39,29 @@ def verify_trace(prover, wit, trace, srs_trapdoor=0x1D5C0FFEE, tamper=None):
     evals = {q: v for q, v in pv.eval_ints(trace).items() if q[0] != ("h", 0)}
     instance = [zo.fr_arr_to_ints(b.to_host(c)) for c in wit["instance"]]
     h1, h2 = _pts(pts["shplonk_h1"])[0], _pts(pts["shplonk_h2"])[0]
+    # the verifier's side of Fiat-Shamir: replay the transcript over the proof and require the prover's challenges
+    import halo2_zkcert_amd.prover as pv2
+
+    ts = pv2.Blake2bTranscript()
+    ch = trace["challenges"]
+    for a in pts["advice"]:
+        ts.write_point(a)
+    assert ts.squeeze() == ch["theta"]
+    for a in pts.get("lookup_permuted", []):
+        ts.write_point(a)
+    assert ts.squeeze() == ch["beta"] and ts.squeeze() == ch["gamma"]
+    for a in pts["products"] + pts["random_poly"]:
+        ts.write_point(a)
+    assert ts.squeeze() == ch["y"]
+    for a in pts["quotient"]:
+        ts.write_point(a)
+    assert ts.squeeze() == ch["x"]
+    for q, row in trace["evals"]:
+        if q[0] != ("h", 0):
+            ts.write_scalar(row)
+    assert ts.squeeze() == ch["shplonk_y"] and ts.squeeze() == ch["shplonk_v"]
+    ts.write_point(pts["shplonk_h1"][0])
+    assert ts.squeeze() == ch["shplonk_u"]
     if tamper:
         tamper(evals, coms, instance)
     return P.plonk_verify(vk, instance, coms, h_pieces, evals, trace["query_list"], trace["challenges"], h1, h2, srs_trapdoor)
