@@ -170,7 +170,7 @@ def main():
                                    f"1 iNTT_2^{prover.dom.extended_k} + 1 sweep over 2^{prover.dom.extended_k} rows + lookup compression, "
                                    f"{shape.n_perm_sets}+{len(shape.lookups)} grand products, evaluations at x; "
                                    "lookup permute (sort) and SHPLONK multi-open computed; " + ("synthetic SATISFIABLE instance (gates, copy constraints, lookup hold: the output is a valid proof, see tests/test_gpu_prover.py::test_rsa_k17_valid_proof); " if args.shape == "rsa" else "uniform synthetic witness; ") +
-                                   "halo2 Blake2bWrite transcript (restated; the reference's commands use Poseidon / Keccak)",
+                                   "halo2 Blake2bWrite transcript (restated, in the library; the reference's commands use Poseidon / Keccak)",
                        "k": shape.k, "advice": shape.n_advice, "fixed": shape.n_fixed, "lookups": len(shape.lookups),
                        "perm_columns": len(shape.perm_columns), "degree": shape.degree,
                        "host": "zkhip_create_proof (schedule in the library, transcript callbacks)" if native else "prover.py (Python schedule over the C ABI)",

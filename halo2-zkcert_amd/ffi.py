@@ -69,6 +69,8 @@ SYMBOLS = [
     "zkhip_permute_expression_pair_device", "zkhip_lookup_product_device", "zkhip_grand_products_device",
     "zkhip_linear_combination_device", "zkhip_divide_by_linear_device", "zkhip_kate_division_device", "zkhip_shplonk_open",
     "zkhip_create_proof",
+    "zkhip_blake2b_transcript_new", "zkhip_blake2b_transcript_free", "zkhip_blake2b_transcript_callbacks", "zkhip_blake2b_transcript_proof",
+    "zkhip_blake2b_transcript_points", "zkhip_blake2b_transcript_challenges",
 ]
 
 
@@ -86,6 +88,10 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.zkhip_last_error.restype = C.c_char_p
         L.zkhip_srs_len.restype = C.c_size_t
+        L.zkhip_blake2b_transcript_new.restype = C.c_void_p
+        L.zkhip_blake2b_transcript_callbacks.restype = C.c_void_p
+        for f in ("zkhip_blake2b_transcript_proof", "zkhip_blake2b_transcript_points", "zkhip_blake2b_transcript_challenges"):
+            getattr(L, f).restype = C.c_size_t
         for f in ("zkhip_domain_k", "zkhip_domain_extended_k", "zkhip_domain_quotient_poly_degree"):
             getattr(L, f).restype = C.c_uint32
         _LIB = L
@@ -314,6 +320,34 @@ def make_transcript(write_point, squeeze_challenge, write_scalar=None):
         write_scalar(np.frombuffer(C.string_at(sc, 32), dtype=np.uint64))
 
     return ZkTranscript(None, WRITE_POINT_FN(_wp), SQUEEZE_FN(_sq), WRITE_SCALAR_FN(_ws) if write_scalar else WRITE_SCALAR_FN())
+
+
+class NativeTranscript:
+    """The library's Blake2bWrite (zkhip_blake2b_transcript_*): no Python in the proof's critical path."""
+
+    def __init__(self):
+        self.h = C.c_void_p(lib().zkhip_blake2b_transcript_new())
+        self.callbacks = C.c_void_p(lib().zkhip_blake2b_transcript_callbacks(self.h))
+
+    def __del__(self):
+        if getattr(self, "h", None) and self.h.value and lib is not None:
+            lib().zkhip_blake2b_transcript_free(self.h)
+            self.h = C.c_void_p()
+
+    def proof(self):
+        p = C.POINTER(C.c_uint8)()
+        n = lib().zkhip_blake2b_transcript_proof(self.h, C.byref(p))
+        return C.string_at(p, n) if n else b""
+
+    def points(self):
+        p = C.POINTER(C.c_uint64)()
+        n = lib().zkhip_blake2b_transcript_points(self.h, C.byref(p))
+        return np.frombuffer(C.string_at(p, n * 64), dtype=np.uint64).reshape(n, 8) if n else np.zeros((0, 8), dtype=np.uint64)
+
+    def challenges(self):
+        p = C.POINTER(C.c_uint64)()
+        n = lib().zkhip_blake2b_transcript_challenges(self.h, C.byref(p))
+        return np.frombuffer(C.string_at(p, n * 32), dtype=np.uint64).reshape(n, 4) if n else np.zeros((0, 4), dtype=np.uint64)
 
 
 class ZkProvingKey(C.Structure):

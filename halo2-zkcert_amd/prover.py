@@ -665,10 +665,12 @@ class Prover:
         self._npk, self._npk_keep = pk, keep
         return pk
 
-    def prove_native(self, wit, fetch_h=False):
-        """The same pass through zkhip_create_proof (the schedule and all host arithmetic in the library); this side keeps
-        the transcript.  Returns the same trace as prove(); the quotient's coefficients are copied to the host only on request
-        (fetch_h: 96 n bytes over PCIe, for tests)."""
+    def prove_native(self, wit, fetch_h=False, python_transcript=False):
+        """The same pass through zkhip_create_proof (the schedule and all host arithmetic in the library).  The transcript is the
+        library's Blake2bWrite (no Python between the launches) or, with python_transcript, Blake2bTranscript through callbacks
+        (identical challenges: tests/test_schedule_cpu.py).  Returns the same trace as prove() plus trace["proof"], the bytes
+        Blake2bWrite's writer received; the quotient's coefficients are copied to the host only on request (fetch_h: 96 n bytes
+        over PCIe, for tests)."""
         import ctypes as C
 
         sh, b, n = self.shape, self.b, self.n
@@ -698,7 +700,13 @@ class Prover:
 
         write_scalar = ts.write_scalar
 
-        t = ffi.make_transcript(write_point, squeeze, write_scalar)
+        nt = None
+        if python_transcript:
+            t = ffi.make_transcript(write_point, squeeze, write_scalar)
+            t_ref = C.byref(t)
+        else:
+            nt = ffi.NativeTranscript()
+            t_ref = nt.callbacks
         qlist = self._query_list()
         evals = np.zeros((len(qlist), 4), dtype=np.uint64)
         out = ffi.ZkProofOut()
@@ -706,12 +714,30 @@ class Prover:
         adv = (C.c_void_p * max(1, A))(*[c_.data_ptr() for c_ in wit["advice"]])
         ins = (C.c_void_p * max(1, sh.n_instance))(*[c_.data_ptr() for c_ in wit["instance"]])
         ctx.use_torch_stream()
-        rc = ffi.lib().zkhip_create_proof(ctx.h, C.byref(pk), adv, ins, C.c_uint64(wit["base"]), C.byref(t), C.byref(out))
+        rc = ffi.lib().zkhip_create_proof(ctx.h, C.byref(pk), adv, ins, C.c_uint64(wit["base"]), t_ref, C.byref(out))
         if rc == ffi.ECONSTRAINT:
             raise ffi.ConstraintSystemFailure(ffi.lib().zkhip_last_error().decode())
         if rc != 0:
             raise ffi.ZkhipError(f"zkhip_create_proof: {rc}: {ffi.lib().zkhip_last_error().decode()}")
-        assert out.n_evals == len(qlist) and state["p"] == len(point_tags) and state["s"] == len(squeeze_tags)
+        if nt is not None:   # rebuild the trace from what the library's transcript recorded
+            proof, pts, chs = nt.proof(), nt.points(), nt.challenges()
+            trace["proof"] = proof
+            assert len(pts) == len(point_tags) and len(chs) == len(squeeze_tags)
+            off = 0
+            n_eval_written = len(qlist) - 1
+            for i_, tag in enumerate(point_tags):
+                if tag == "shplonk_h1":
+                    off += 32 * n_eval_written      # the evaluations sit between the quotient pieces and the SHPLONK points
+                byts = proof[off:off + 32]
+                off += 32
+                trace["commitments"].append((tag, byts.hex()))
+                trace["points"].setdefault(tag, []).append(pts[i_])
+            assert off == len(proof)
+            for tag, limbs in zip(squeeze_tags, chs):
+                trace["challenges"][tag] = from_mont_host(limbs)
+        else:
+            assert state["p"] == len(point_tags) and state["s"] == len(squeeze_tags)
+        assert out.n_evals == len(qlist)
         trace["evals"] = [(q_, evals[i_]) for i_, q_ in enumerate(qlist)]
         trace["query_list"] = qlist
         trace["h_pieces"] = None

@@ -297,6 +297,18 @@ typedef struct zk_proof_out {
 int  zkhip_create_proof(zkhip_ctx* ctx, const zk_proving_key* pk, const void* const* d_advice, const void* const* d_instance,
                         uint64_t blinding_seed, const zk_transcript* transcript, zk_proof_out* out);
 
+/* ---- a ready-made transcript: halo2_proofs transcript.rs Blake2bWrite<Vec<u8>, G1Affine, Challenge255<_>> on the host
+ * (BLAKE2b-512 personalised "Halo2-Transcript"; point = prefix 1 + canonical x, y; scalar = prefix 2 + canonical bytes; challenge =
+ * prefix 0, digest of a state copy, reduced mod r).  Its writer's bytes — compressed points and scalars in transcript order — are
+ * the proof.  A Rust caller passes callbacks into its own transcript instead. */
+typedef struct zkhip_blake2b_transcript zkhip_blake2b_transcript;
+zkhip_blake2b_transcript* zkhip_blake2b_transcript_new(void);
+void zkhip_blake2b_transcript_free(zkhip_blake2b_transcript* t);
+const zk_transcript* zkhip_blake2b_transcript_callbacks(zkhip_blake2b_transcript* t);
+size_t zkhip_blake2b_transcript_proof(const zkhip_blake2b_transcript* t, const uint8_t** bytes);          /* -> length */
+size_t zkhip_blake2b_transcript_points(const zkhip_blake2b_transcript* t, const uint64_t** xy);           /* -> count; 8 u64 each */
+size_t zkhip_blake2b_transcript_challenges(const zkhip_blake2b_transcript* t, const uint64_t** limbs);    /* -> count; 4 u64 each (ABI) */
+
 /* ---- synthetic tables (bench / tests): element i of a column = raw253(seed, i) taken as the
  * Montgomery limbs (oracle/pyref.py synth_raw253) ---- */
 int  zkhip_synth_fill_device(zkhip_ctx* ctx, void* d_out, size_t n, uint64_t seed, uint64_t first_index);

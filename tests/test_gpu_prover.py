@@ -117,6 +117,11 @@ def test_native_create_proof_matches_schedule(zk, oracle, k):
     w = gp.witness(4)
     ta = gp.prove(w)
     tb = gp.prove_native(w, fetch_h=True)
+    tc = gp.prove_native(w, python_transcript=True)
+    assert tb["commitments"] == tc["commitments"] and tb["challenges"] == tc["challenges"]
+    # the proof bytes: every commitment (32 B compressed) and evaluation (32 B canonical) in transcript order
+    nq = len(tb["evals"]) - 1
+    assert len(tb["proof"]) == 32 * (tb["n_commitments"] + nq)
     assert ta["commitments"] == tb["commitments"]
     assert ta["challenges"] == tb["challenges"]
     assert [q for q, _ in ta["evals"]] == [q for q, _ in tb["evals"]]

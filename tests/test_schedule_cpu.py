@@ -96,3 +96,38 @@ def test_blake2b_transcript_layout(oracle):
     assert c1 == int.from_bytes(h.digest(), "little") % pv.R
     h.update(b"\x00")
     assert c2 == int.from_bytes(h.digest(), "little") % pv.R and c1 != c2
+
+
+def test_native_blake2b_transcript_matches_python(oracle):
+    """The library's Blake2bWrite (its own BLAKE2b) against prover.Blake2bTranscript (hashlib) on a mixed sequence that crosses
+    several 128-byte blocks: same challenges, and the proof bytes are the compressed points and canonical scalars in order."""
+    import ctypes as C
+
+    import halo2_zkcert_amd.ffi as ffi
+
+    zo = oracle
+    nt = ffi.NativeTranscript()
+    cb = ffi.ZkTranscript.from_address(nt.callbacks.value)
+    py = pv.Blake2bTranscript()
+    expect_proof = b""
+    got, exp = [], []
+    for i in range(1, 30):
+        pt = zo.g1_to_affine(zo.g1_mul_gen(zo.fr_from_int(i * 7 + 1)))
+        byts = zo.g1_to_bytes(pt)
+        cb.write_point(cb.user, (C.c_uint8 * 32)(*byts), pt.ctypes.data_as(C.POINTER(C.c_uint64)))
+        py.write_point(pt)
+        expect_proof += byts
+        if i % 3 == 0:
+            s = zo.fr_from_int(pow(i, 50, pv.R))
+            cb.write_scalar(cb.user, s.ctypes.data_as(C.POINTER(C.c_uint64)))
+            py.write_scalar(s)
+            expect_proof += zo.fr_to_int(s).to_bytes(32, "little")
+        if i % 4 == 0:
+            out = (C.c_uint64 * 4)()
+            cb.squeeze_challenge(cb.user, out)
+            got.append(zo.fr_to_int(np.array(list(out), dtype=np.uint64)))
+            exp.append(py.squeeze())
+    assert got == exp and len(got) == 7
+    assert nt.proof() == expect_proof
+    assert [zo.fr_to_int(c) for c in nt.challenges()] == exp
+    assert nt.points().shape == (29, 8)
