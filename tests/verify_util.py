@@ -39,6 +39,12 @@ def verify_trace(prover, wit, trace, srs_trapdoor=0x1D5C0FFEE, tamper=None):
     evals = {q: v for q, v in pv.eval_ints(trace).items() if q[0] != ("h", 0)}
     instance = [zo.fr_arr_to_ints(b.to_host(c)) for c in wit["instance"]]
     h1, h2 = _pts(pts["shplonk_h1"])[0], _pts(pts["shplonk_h2"])[0]
+    # the proof's bytes are the compressed forms of the points the transcript absorbed
+    seen = {}
+    for tag, hx in trace["commitments"]:
+        i = seen.get(tag, 0)
+        seen[tag] = i + 1
+        assert zo.g1_to_bytes(np.asarray(pts[tag][i], dtype=np.uint64)).hex() == hx, (tag, i)
     # the verifier's side of Fiat-Shamir: replay the transcript over the proof and require the prover's challenges
     import halo2_zkcert_amd.prover as pv2
 
