@@ -207,8 +207,14 @@ int zkhip_commitments_read(zkhip_ctx* c, const void* d_xyz, size_t n, uint64_t* 
     if (n == 0) return ZKHIP_OK;
     std::vector<uint64_t> big;
     uint64_t* jac = (uint64_t*)c->h_pinned;
-    if (n * 96 > zkhip_ctx::PINNED_BYTES) { big.resize(12 * n); jac = big.data(); }
-    ZK_HIP(hipMemcpyAsync(jac, d_xyz, n * 96, hipMemcpyDeviceToHost, c->stream));
+    const char* lo = (const char*)c->h_pinned;
+    if ((const char*)d_xyz >= lo && (const char*)d_xyz + n * 96 <= lo + zkhip_ctx::PINNED_BYTES) {
+        // the MSM wrote its results straight into the context's pinned (device-visible) host buffer: nothing to copy
+        jac = (uint64_t*)d_xyz;
+    } else {
+        if (n * 96 > zkhip_ctx::PINNED_BYTES) { big.resize(12 * n); jac = big.data(); }
+        ZK_HIP(hipMemcpyAsync(jac, d_xyz, n * 96, hipMemcpyDeviceToHost, c->stream));
+    }
     ZK_HIP(stream_wait(c->stream));
     zkhip_g1_batch_to_affine(jac, n, out_xy);
     if (out_bytes) for (size_t i = 0; i < n; ++i) zkhip_g1_to_bytes(out_xy + 8 * i, out_bytes + 32 * i);

@@ -95,6 +95,9 @@ extern "C" int zkhip_create_proof(zkhip_ctx* ctx, const zk_proving_key* pk, cons
     const size_t max_q = (size_t)pk->n_advice_queries + pk->n_fixed_queries + 3 * Zp + 5 * L + P + 2;
     ZK_TRY(ws("cp_evals", max_q * 32, &w_evals));
     ZK_TRY(ws("cp_com", (A + 2 * L + Zp + L + qd + 2) * 96, &w_com));
+    // commitments are latency-critical read-backs: let the MSM's last kernel store them straight into pinned host memory
+    // (4 KiB in, past the small read-back slots) when they fit
+    if ((A + 2 * L + Zp + L + qd + 2) * 96 + 4096 + 64 <= zkhip_ctx::PINNED_BYTES) w_com = (char*)ctx->h_pinned + 4096;
 
     uint64_t ch[4];
     std::vector<uint64_t> xy;

@@ -285,6 +285,7 @@ int zkhip_shplonk_open(zkhip_ctx* ctx, const zkhip_srs* srs, size_t n, const voi
     ZK_TRY(ctx->get_scratch("sp_hx", n * 32, &d_hx));
     ZK_TRY(ctx->get_scratch("sp_lx", n * 32, &d_lx));
     ZK_TRY(ctx->get_scratch("sp_com", 96, &d_com));
+    d_com = (char*)ctx->h_pinned + 2048;   // straight into pinned host memory: no read-back copy
     for (size_t si = 0; si < nsets; ++si) {
         RotSet& rs = sets[si];
         const size_t m = rs.points.size();
