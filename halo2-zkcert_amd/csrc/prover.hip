@@ -314,8 +314,17 @@ extern "C" int zkhip_create_proof(zkhip_ctx* ctx, const zk_proving_key* pk, cons
         }
         std::vector<const void*> qp(nq);
         for (size_t i = 0; i < nq; ++i) qp[i] = polys[q_poly[i]];
-        ZK_TRY(zkhip_eval_polynomials_at_device(ctx, qp.data(), nq, n, q_points.data(), w_evals));
-        ZK_TRY(zkhip_memcpy_d2h(ctx, q_evals.data(), w_evals, nq * 32));
+        // the evaluations are the next read-back: the kernel stores them into pinned host memory when they fit
+        char* ev_out = w_evals;
+        const bool ev_pinned = nq * 32 + 32768 + 64 <= zkhip_ctx::PINNED_BYTES;
+        if (ev_pinned) ev_out = (char*)ctx->h_pinned + 32768;
+        ZK_TRY(zkhip_eval_polynomials_at_device(ctx, qp.data(), nq, n, q_points.data(), ev_out));
+        if (ev_pinned) {
+            ZK_HIP(stream_wait(ctx->stream));
+            memcpy(q_evals.data(), ev_out, nq * 32);
+        } else {
+            ZK_TRY(zkhip_memcpy_d2h(ctx, q_evals.data(), w_evals, nq * 32));
+        }
     }
     for (size_t i = 0; i < nq; ++i)
         if (q_poly[i] != o_h) tr->write_scalar(tr->user, q_evals.data() + 4 * i);   // the verifier recomputes h(x)
