@@ -902,9 +902,12 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
     }
     dim3 gn(div_up(n, 256), (unsigned)ncols);
     dim3 gt(div_up(items, g.tile) + g.P, (unsigned)ncols);
+    // the "heaviest bucket" read-back: the plan kernel stores it straight into pinned host memory (slot at 1 KiB) when it fits
     std::vector<uint32_t> h_max_big;
     uint32_t* h_max = (uint32_t*)ctx->h_pinned;
-    if (ncols * 4 > zkhip_ctx::PINNED_BYTES) { h_max_big.resize(ncols); h_max = h_max_big.data(); }
+    const bool max_pinned = ncols * 4 <= 1024;
+    if (max_pinned) { h_max = (uint32_t*)((char*)ctx->h_pinned + 1024); d_max = h_max; }
+    else if (ncols * 4 > zkhip_ctx::PINNED_BYTES) { h_max_big.resize(ncols); h_max = h_max_big.data(); }
     { ProfScope ps(ctx, "msm_digits");
     hipLaunchKernelGGL(k_sort_hi<false>, gn, dim3(256), 0, st, (const uint32_t* const*)d_colptrs, n, first, srs->n, g, d_part_cnt, d_part_cursor,
                        (const uint32_t*)d_part_off, (uint32_t*)d_tmp_entry, (uint16_t*)d_tmp_key, items);
@@ -920,7 +923,7 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
     // second scan, in lane mode: scans npart[b] (computed on the fly from cnt and off), writes it to cntA, its offsets to offA
     ZK_TRY(launch_plan(ctx, (unsigned)ncols, (const uint32_t*)d_cnt, B, 1, (uint32_t*)d_offA, (uint32_t*)d_cntA, (uint32_t*)nullptr, (uint32_t*)d_max,
                        (const uint32_t*)d_off, L)); }
-    ZK_HIP(hipMemcpyAsync(h_max, d_max, ncols * 4, hipMemcpyDeviceToHost, st));
+    if (!max_pinned) ZK_HIP(hipMemcpyAsync(h_max, d_max, ncols * 4, hipMemcpyDeviceToHost, st));
     ZK_HIP(hipEventRecord(ctx->ev_read, st));
     { ProfScope ps(ctx, "msm_digits");
     {
