@@ -50,6 +50,13 @@ struct zkhip_ctx {
     hipEvent_t ev_read = nullptr;   // marks a small device->host read in the middle of a launch sequence (see event_wait)
     hipStream_t side_stream = nullptr;   // zkhip_create_proof's second stream (coset NTTs beside the MSM phases), created on first use
     hipEvent_t side_event = nullptr;
+    // Small host->device uploads of host temporaries (pointer tables, lowered programs): the bytes are copied into a pinned ring
+    // and the asynchronous copy reads from there, so the call neither blocks on the stream nor keeps the caller's buffer alive.
+    // The ring is 8 MiB against ~100 KiB staged per proof; wrapping around synchronises the device.
+    void* stage_ring = nullptr;
+    size_t stage_off = 0;
+    static constexpr size_t STAGE_BYTES = 8u << 20;
+    int upload(void* d_dst, const void* src, size_t bytes);
     void* h_pinned = nullptr;   // 64 KiB of pinned host memory for the small device->host reads on the critical path
     static constexpr size_t PINNED_BYTES = 64 * 1024;
     std::map<std::string, zk::Scratch> scratch;

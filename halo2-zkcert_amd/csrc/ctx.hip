@@ -40,6 +40,25 @@ int zkhip_ctx::get_scratch(const char* name, size_t bytes, void** out) {
     return ZKHIP_OK;
 }
 
+int zkhip_ctx::upload(void* d_dst, const void* src, size_t bytes) {
+    if (!bytes) return ZKHIP_OK;
+    if (bytes > STAGE_BYTES / 4) {   // too large to stage: the classic blocking form
+        ZK_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, stream));
+        ZK_HIP(hipStreamSynchronize(stream));
+        return ZKHIP_OK;
+    }
+    if (!stage_ring) ZK_HIP(hipHostMalloc(&stage_ring, STAGE_BYTES, hipHostMallocDefault));
+    size_t at = (stage_off + 63) & ~(size_t)63;
+    if (at + bytes > STAGE_BYTES) {
+        ZK_HIP(hipDeviceSynchronize());   // every earlier staged copy has been consumed
+        at = 0;
+    }
+    memcpy((char*)stage_ring + at, src, bytes);
+    stage_off = at + bytes;
+    ZK_HIP(hipMemcpyAsync(d_dst, (char*)stage_ring + at, bytes, hipMemcpyHostToDevice, stream));
+    return ZKHIP_OK;
+}
+
 hipEvent_t zkhip_ctx::prof_event() {
     if (!prof_pool.empty()) { hipEvent_t e = prof_pool.back(); prof_pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
@@ -127,6 +146,7 @@ void zkhip_destroy(zkhip_ctx* c) {
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->side_event) (void)hipEventDestroy(c->side_event);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->stage_ring) (void)hipHostFree(c->stage_ring);
     delete c;
 }
 

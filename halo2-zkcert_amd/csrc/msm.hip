@@ -890,7 +890,7 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
 
     std::vector<const void*> h_ptrs(2 * ncols);
     for (size_t j = 0; j < ncols; ++j) { h_ptrs[j] = d_cols_host[j]; h_ptrs[ncols + j] = srs_per_col[j]->d_table; }
-    ZK_HIP(hipMemcpyAsync(d_colptrs, h_ptrs.data(), 2 * ncols * sizeof(void*), hipMemcpyHostToDevice, st));
+    ZK_TRY(ctx->upload(d_colptrs, h_ptrs.data(), 2 * ncols * sizeof(void*)));
     ZK_HIP(hipMemsetAsync(d_zero, 0, zero_words * 4, st));
     // Round-0 segment length depends on the problem size only: aim for ~2 waves per SIMD over the chip.
     uint32_t seg = seg0_min;

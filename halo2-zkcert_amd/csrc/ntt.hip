@@ -287,7 +287,7 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
     }
     std::vector<const void*> all(3 * npolys);
     for (size_t i = 0; i < npolys; ++i) { all[i] = srcs[i]; all[npolys + i] = dsts[i]; all[2 * npolys + i] = np > 1 ? tmp_host[i] : dsts[i]; }
-    ZK_HIP(hipMemcpyAsync(d_ptrs, all.data(), 3 * npolys * sizeof(void*), hipMemcpyHostToDevice, st));
+    ZK_TRY(ctx->upload(d_ptrs, all.data(), 3 * npolys * sizeof(void*)));
     NttScale sc = sc_in;
     uint32_t lo_bits = m;
     // passes 1..np-1: in place on dst, except that the first reads src and the last non-final writes tmp

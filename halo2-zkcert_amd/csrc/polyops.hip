@@ -287,7 +287,7 @@ static int running_products(zkhip_ctx* ctx, const void* d_terms, uint32_t nseg, 
     ZK_TRY(ctx->get_scratch("po_pre", (size_t)nseg * nblk * 32, &d_pre));
     ZK_TRY(ctx->get_scratch("po_first", (size_t)nseg * 32, &d_first));
     ZK_TRY(ctx->get_scratch("po_zptr", (size_t)nseg * sizeof(void*), &d_zptr));
-    ZK_HIP(hipMemcpyAsync(d_zptr, z_out_host, nseg * sizeof(void*), hipMemcpyHostToDevice, st));
+    ZK_TRY(ctx->upload(d_zptr, z_out_host, nseg * sizeof(void*)));
     hipLaunchKernelGGL(k_rp_local, dim3(nblk, nseg), dim3(PO_BLOCK), 0, st, (const uint32_t*)d_terms, n, (uint32_t*)d_local, (uint32_t*)d_tot, nblk);
     hipLaunchKernelGGL(k_rp_blocks, dim3(nseg), dim3(1024), 0, st, (const uint32_t*)d_tot, (uint32_t*)d_pre, nblk);
     if (chain) hipLaunchKernelGGL(k_rp_chain, dim3(1), dim3(64), 0, st, (const uint32_t*)d_local, (const uint32_t*)d_pre, n, nblk, nseg, nchain,
@@ -321,9 +321,8 @@ static int eval_at(zkhip_ctx* ctx, const void* const* d_polys, size_t npolys, si
     ZK_TRY(ctx->get_scratch("po_eval_xs", npolys * 32, &d_xs));
     std::vector<fe32> xs(npolys);
     for (size_t j = 0; j < npolys; ++j) xs[j] = abi_to_raw(xs_host + 4 * j);
-    ZK_HIP(hipMemcpyAsync(d_ptrs, d_polys, npolys * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
-    ZK_HIP(hipMemcpyAsync(d_xs, xs.data(), npolys * 32, hipMemcpyHostToDevice, ctx->stream));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));   // xs is a host temporary
+    ZK_TRY(ctx->upload(d_ptrs, d_polys, npolys * sizeof(void*)));
+    ZK_TRY(ctx->upload(d_xs, xs.data(), npolys * 32));
     ProfScope ps(ctx, "eval_polynomial");
     hipLaunchKernelGGL(k_eval_tiles, dim3(nblk, (unsigned)npolys), dim3(PO_BLOCK), 0, ctx->stream, (const uint32_t* const*)d_ptrs, n,
                        (const uint32_t*)d_xs, (uint32_t*)d_part, nblk);
@@ -370,9 +369,8 @@ int zkhip_permutation_products_device(zkhip_ctx* ctx, uint32_t k, const void* co
     ZK_TRY(ctx->get_scratch("po_terms", (size_t)nsets * n * 32, &d_terms));
     std::vector<const void*> ptrs(2 * ncols);
     for (size_t j = 0; j < ncols; ++j) { ptrs[j] = d_values[j]; ptrs[ncols + j] = d_sigmas[j]; }
-    ZK_HIP(hipMemcpyAsync(d_ptrs, ptrs.data(), 2 * ncols * sizeof(void*), hipMemcpyHostToDevice, st));
-    ZK_HIP(hipMemcpyAsync(d_dbeta, dbeta.data(), ncols * 32, hipMemcpyHostToDevice, st));
-    ZK_HIP(hipStreamSynchronize(st));   // host temporaries
+    ZK_TRY(ctx->upload(d_ptrs, ptrs.data(), 2 * ncols * sizeof(void*)));
+    ZK_TRY(ctx->upload(d_dbeta, dbeta.data(), ncols * 32));
     PermParams P;
     P.values = (const uint32_t* const*)d_ptrs;
     P.sigmas = (const uint32_t* const*)((const void**)d_ptrs + ncols);
@@ -454,9 +452,8 @@ int zkhip_grand_products_device(zkhip_ctx* ctx, uint32_t k, const uint64_t beta[
         ZK_TRY(ctx->get_scratch("po_perm_dbeta", ncols * 32, &d_dbeta));
         std::vector<const void*> ptrs(2 * ncols);
         for (size_t j = 0; j < ncols; ++j) { ptrs[j] = d_values[j]; ptrs[ncols + j] = d_sigmas[j]; }
-        ZK_HIP(hipMemcpyAsync(d_ptrs, ptrs.data(), 2 * ncols * sizeof(void*), hipMemcpyHostToDevice, st));
-        ZK_HIP(hipMemcpyAsync(d_dbeta, dbeta.data(), ncols * 32, hipMemcpyHostToDevice, st));
-        ZK_HIP(hipStreamSynchronize(st));   // host temporaries
+        ZK_TRY(ctx->upload(d_ptrs, ptrs.data(), 2 * ncols * sizeof(void*)));
+        ZK_TRY(ctx->upload(d_dbeta, dbeta.data(), ncols * 32));
         P.values = (const uint32_t* const*)d_ptrs;
         P.sigmas = (const uint32_t* const*)((const void**)d_ptrs + ncols);
         P.ncols = (uint32_t)ncols; P.chunk_len = chunk_len;

@@ -479,8 +479,7 @@ extern "C" int zkhip_evaluate_h_device(zkhip_ctx* ctx, const zk_evalh_args* A, v
     put(nullptr, 0);
     void* d_blob;
     ZK_TRY(ctx->get_scratch("sweep_blob", blob.size() + 64, &d_blob));
-    ZK_HIP(hipMemcpyAsync(d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice, st));
-    ZK_HIP(hipStreamSynchronize(st));  // blob is a host temporary
+    ZK_TRY(ctx->upload(d_blob, blob.data(), blob.size()));   // staged: no stream synchronisation for the host temporary
 
     SweepParams P;
     memset(&P, 0, sizeof P);
