@@ -98,9 +98,9 @@ def test_domain_vs_oracle(zk, oracle, j, k):
     dom.free()
 
 
-@pytest.mark.parametrize("k,j", [(17, 4), (19, 5)])
+@pytest.mark.parametrize("k,j", [(17, 4), (19, 5), (22, 4)])
 def test_full_size_round_trip_and_point_checks(zk, oracle, k, j):
-    """BASELINE sizes (2^17 -> 2^19, 2^19 -> 2^21 extended): size-independent properties.
+    """BASELINE sizes (2^17 -> 2^19, 2^19 -> 2^21, 2^22 -> 2^24 extended): size-independent properties.
     (1) extended_to_coeff(coeff_to_extended(p)) == p; (2) three extended evaluations equal Horner on
     the host at the coset points; (3) coeff_to_lagrange(lagrange_to_coeff(v)) == v."""
     ffi, ctx = zk
