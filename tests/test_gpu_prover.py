@@ -171,3 +171,23 @@ def test_native_create_proof_reports_unsatisfiable_lookup(zk, oracle):
     with pytest.raises(ffi.ConstraintSystemFailure):
         gp.prove(bad)
     assert gp.prove_native(w)["commitments"] == good
+
+
+def test_agg_k22_pass_properties(zk, oracle):
+    """BASELINE configs[3] size (k = 22, the aggregation circuit's): one zkhip_create_proof pass on a satisfiable instance.
+    Size-independent checks: the quotient pieces' commitments equal [piece(s)] G from the pieces' own coefficients (SRS trapdoor),
+    the proof is deterministic, and its byte length is what the transcript order dictates."""
+    ffi, ctx = zk
+    zo = oracle
+    s = 0x1D5C0FFEE
+    gp = pv.Prover(pv.GpuBackend(ctx, ffi), pv.CircuitShape.rsa(22), srs_trapdoor=s, satisfiable=True)
+    w = gp.witness(0)
+    t1 = gp.prove_native(w, fetch_h=True)
+    sm = zo.fr_from_int(s)
+    qc = [c for tag, c in t1["commitments"] if tag == "quotient"]
+    assert len(qc) == 3
+    for piece, c in zip(t1["h_pieces"], qc):
+        assert zo.g1_to_bytes(zo.g1_mul_gen(zo.eval_polynomial(piece, sm))).hex() == c
+    t2 = gp.prove_native(w)
+    assert t2["proof"] == t1["proof"] and len(t1["proof"]) == 32 * (t1["n_commitments"] + len(t1["evals"]) - 1)
+    del gp, w
