@@ -940,6 +940,10 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
     hipLaunchKernelGGL(k_accum_affine, dim3(div_up(div_up(items, L), 256), (unsigned)ncols), dim3(256), 0, st,
                        (const uint32_t* const*)((const void**)d_colptrs + ncols), (const uint32_t*)d_entries, items, (const uint32_t*)d_off,
                        (const uint32_t*)d_offA, B, L, (uint32_t*)d_pA, pstride0); }
+    if (ctx->accum_mark) {   // a caller wants to start overlapped work when the throughput-bound part of this MSM is over
+        ZK_HIP(hipEventRecord(ctx->accum_mark, st));
+        ctx->accum_mark = nullptr;
+    }
     ZK_LAUNCH_CHECK();
     if (h_max_big.empty()) ZK_HIP(event_wait(ctx->ev_read));   // only the read-back: the scatter and round 0 are still running
     else ZK_HIP(stream_wait(st));                               // pageable destination: wait for everything

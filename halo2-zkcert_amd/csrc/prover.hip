@@ -29,6 +29,19 @@ struct Overlap {
         ctx->stream = side;
         return ZKHIP_OK;
     }
+    // The same, but the side stream starts when the MSM launched since arm() has finished its bucket accumulation (the MSM records
+    // the event there): the overlapped NTTs then fill the MSM's latency-bound tail, the host round trip and the start of the next
+    // phase instead of competing with the accumulation for the whole chip.
+    // Measured: at 2^17 this is worth 2 % of the proof and lifts the accumulation from 0.54 to 0.60 of the mad peak; at 2^19 / 2^22,
+    // where tails are negligible and the accumulation leaves issue slots free, starting the NTTs at once is 3-9 % better (late = false).
+    bool late;
+    void arm() { ctx->accum_mark = late ? ev : nullptr; if (!late) (void)hipEventRecord(ev, main); }
+    int begin_marked() {
+        if (late && ctx->accum_mark) { ctx->accum_mark = nullptr; ZK_HIP(hipEventRecord(ev, main)); }   // no MSM consumed it: mark now
+        ZK_HIP(hipStreamWaitEvent(side, ev, 0));
+        ctx->stream = side;
+        return ZKHIP_OK;
+    }
     void end() { ctx->stream = main; }
     int join() {
         ZK_HIP(hipEventRecord(ev, side));
@@ -72,7 +85,7 @@ extern "C" int zkhip_create_proof(zkhip_ctx* ctx, const zk_proving_key* pk, cons
         ZK_HIP(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
         ZK_HIP(hipEventCreateWithFlags(&ctx->side_event, hipEventDisableTiming));
     }
-    Overlap ov{ctx, ctx->stream, ctx->side_stream, ctx->side_event};
+    Overlap ov{ctx, ctx->stream, ctx->side_stream, ctx->side_event, k <= 18};
     StreamGuard guard{ctx, ctx->stream};
     hipStream_t st = ctx->stream;
 
@@ -103,11 +116,12 @@ extern "C" int zkhip_create_proof(zkhip_ctx* ctx, const zk_proving_key* pk, cons
     std::vector<uint64_t> xy;
     std::vector<uint8_t> by;
     // commit a batch: MSMs, read back, hand every point to the transcript (skip_last: committed now, written later)
-    auto commit = [&](const std::vector<const void*>& cols, const std::vector<const zkhip_srs*>& bases, size_t hold_back,
-                      std::vector<uint64_t>* held_xy, std::vector<uint8_t>* held_by) -> int {
-        const size_t m = cols.size();
+    auto commit_launch = [&](const std::vector<const void*>& cols, const std::vector<const zkhip_srs*>& bases) -> int {
+        if (cols.empty()) return ZKHIP_OK;
+        return zkhip_msm_g1_multi_device(ctx, bases.data(), cols.data(), cols.size(), 0, n, w_com);
+    };
+    auto commit_read = [&](size_t m, size_t hold_back, std::vector<uint64_t>* held_xy, std::vector<uint8_t>* held_by) -> int {
         if (!m) return ZKHIP_OK;
-        ZK_TRY(zkhip_msm_g1_multi_device(ctx, bases.data(), cols.data(), m, 0, n, w_com));
         xy.resize(8 * m);
         by.resize(32 * m);
         ZK_TRY(zkhip_commitments_read(ctx, w_com, m, xy.data(), by.data()));
@@ -115,19 +129,16 @@ extern "C" int zkhip_create_proof(zkhip_ctx* ctx, const zk_proving_key* pk, cons
         if (hold_back && held_xy) { held_xy->assign(xy.begin() + 8 * (m - hold_back), xy.end()); held_by->assign(by.begin() + 32 * (m - hold_back), by.end()); }
         return ZKHIP_OK;
     };
+    auto commit = [&](const std::vector<const void*>& cols, const std::vector<const zkhip_srs*>& bases, size_t hold_back,
+                      std::vector<uint64_t>* held_xy, std::vector<uint8_t>* held_by) -> int {
+        ZK_TRY(commit_launch(cols, bases));
+        return commit_read(cols.size(), hold_back, held_xy, held_by);
+    };
 
     // ---- 1. advice (+ the vanishing argument's random polynomial, which depends on no challenge) ; coset NTTs of advice/instance overlap
     ZK_TRY(zkhip_synth_fill_device(ctx, w_rand, n, blinding_seed + 380, 0));
     std::vector<void*> coeff_ptrs(A + I), ext_ptrs(A + I);
     for (uint32_t j = 0; j < A + I; ++j) { coeff_ptrs[j] = w_coeff + j * NB; ext_ptrs[j] = w_ext + j * EB; }
-    ZK_TRY(ov.begin());
-    for (uint32_t j = 0; j < A + I; ++j)
-        ZK_HIP(hipMemcpyAsync(coeff_ptrs[j], j < A ? d_advice[j] : d_instance[j - A], NB, hipMemcpyDeviceToDevice, ctx->stream));
-    if (A + I) {
-        ZK_TRY(zkhip_lagrange_to_coeff_device(ctx, pk->domain, coeff_ptrs.data(), A + I));
-        ZK_TRY(zkhip_coeff_to_extended_device(ctx, pk->domain, (const void* const*)coeff_ptrs.data(), n, ext_ptrs.data(), A + I));
-    }
-    ov.end();
     std::vector<uint64_t> rand_xy;
     std::vector<uint8_t> rand_by;
     {
@@ -135,7 +146,17 @@ extern "C" int zkhip_create_proof(zkhip_ctx* ctx, const zk_proving_key* pk, cons
         std::vector<const zkhip_srs*> bases(A, pk->g_lagrange);
         cols.push_back(w_rand);
         bases.push_back(pk->g);
-        ZK_TRY(commit(cols, bases, 1, &rand_xy, &rand_by));
+        ov.arm();
+        ZK_TRY(commit_launch(cols, bases));
+        ZK_TRY(ov.begin_marked());
+        for (uint32_t j = 0; j < A + I; ++j)
+            ZK_HIP(hipMemcpyAsync(coeff_ptrs[j], j < A ? d_advice[j] : d_instance[j - A], NB, hipMemcpyDeviceToDevice, ctx->stream));
+        if (A + I) {
+            ZK_TRY(zkhip_lagrange_to_coeff_device(ctx, pk->domain, coeff_ptrs.data(), A + I));
+            ZK_TRY(zkhip_coeff_to_extended_device(ctx, pk->domain, (const void* const*)coeff_ptrs.data(), n, ext_ptrs.data(), A + I));
+        }
+        ov.end();
+        ZK_TRY(commit_read(cols.size(), 1, &rand_xy, &rand_by));
     }
     tr->squeeze_challenge(tr->user, ch);
     uint64_t theta[4];
@@ -170,15 +191,16 @@ extern "C" int zkhip_create_proof(zkhip_ctx* ctx, const zk_proving_key* pk, cons
     if (L) {
         ZK_HIP(hipMemcpyAsync(w_perm_c, w_perm_l, 2 * L * NB, hipMemcpyDeviceToDevice, st));
         ZK_TRY(zkhip_lagrange_to_coeff_device(ctx, pk->domain, perm_c.data(), 2 * L));
-        ZK_TRY(ov.begin());
-        ZK_TRY(zkhip_coeff_to_extended_device(ctx, pk->domain, (const void* const*)perm_c.data(), n, ext_perm.data(), 2 * L));
-        ov.end();
         std::vector<const void*> cols(perm_c.begin(), perm_c.end());
         std::vector<const zkhip_srs*> bases(2 * L, pk->g);
         // the failure flag rides on the commitment's read-back: it must be known before anything enters the transcript
         uint32_t* h_err = (uint32_t*)((char*)ctx->h_pinned + zkhip_ctx::PINNED_BYTES - 16);
+        ov.arm();
         ZK_TRY(zkhip_msm_g1_multi_device(ctx, bases.data(), cols.data(), cols.size(), 0, n, w_com));
         ZK_HIP(hipMemcpyAsync(h_err, w_perr, 4, hipMemcpyDeviceToHost, st));
+        ZK_TRY(ov.begin_marked());
+        ZK_TRY(zkhip_coeff_to_extended_device(ctx, pk->domain, (const void* const*)perm_c.data(), n, ext_perm.data(), 2 * L));
+        ov.end();
         xy.resize(8 * cols.size());
         by.resize(32 * cols.size());
         ZK_TRY(zkhip_commitments_read(ctx, w_com, cols.size(), xy.data(), by.data()));
@@ -215,12 +237,14 @@ extern "C" int zkhip_create_proof(zkhip_ctx* ctx, const zk_proving_key* pk, cons
         std::vector<const void*> src(Zp + L);
         for (uint32_t i = 0; i < L; ++i) { src[i] = z_ptrs[Zp + i]; ext_z[i] = w_ext_z + i * EB; }
         for (uint32_t s_ = 0; s_ < Zp; ++s_) { src[L + s_] = z_ptrs[s_]; ext_z[L + s_] = w_ext_z + (L + s_) * EB; }
-        ZK_TRY(ov.begin());
-        ZK_TRY(zkhip_coeff_to_extended_device(ctx, pk->domain, src.data(), n, ext_z.data(), Zp + L));
-        ov.end();
         std::vector<const void*> cols(z_ptrs.begin(), z_ptrs.end());
         std::vector<const zkhip_srs*> bases(Zp + L, pk->g);
-        ZK_TRY(commit(cols, bases, 0, nullptr, nullptr));
+        ov.arm();
+        ZK_TRY(commit_launch(cols, bases));
+        ZK_TRY(ov.begin_marked());
+        ZK_TRY(zkhip_coeff_to_extended_device(ctx, pk->domain, src.data(), n, ext_z.data(), Zp + L));
+        ov.end();
+        ZK_TRY(commit_read(cols.size(), 0, nullptr, nullptr));
     }
     // ---- 4. the random polynomial enters the transcript here
     tr->write_point(tr->user, rand_by.data(), rand_xy.data());
