@@ -881,6 +881,7 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
     ZK_TRY(ctx->get_scratch("msm_pA", ncols * pstride0 * PART_WORDS * 4, &d_pA));
     ZK_TRY(ctx->get_scratch("msm_pB", ncols * pstride0 * PART_WORDS * 4, &d_pB));
     uint32_t CH = B > 8192 ? B / 8192 : 1;
+    if (const char* e = getenv("ZKHIP_MSM_CH")) { int v = atoi(e); if (v >= 1 && v <= 256) CH = (uint32_t)v; }
     uint32_t nchunks = (B + CH - 1) / CH;
     // a wide batch has enough chunks to fill the chip with one lane each; otherwise four lanes share every point operation
     bool wide_tail = (size_t)nchunks * ncols >= (size_t)48 * 1024;   // measured crossover: 6-8 columns at 8192 chunks
