@@ -61,6 +61,7 @@ struct zkhip_ctx {
     void* h_pinned = nullptr;   // 64 KiB of pinned host memory for the small device->host reads on the critical path
     static constexpr size_t PINNED_BYTES = 64 * 1024;
     std::map<std::string, zk::Scratch> scratch;
+    std::map<std::string, void*> persistent;   // named device buffers that outlive a call (keygen-like derived data), freed with the context
     // Twiddle tables keyed by (log_n, omega).  w^e for any e < 2^log_n is lo[e & (2^h - 1)] * hi[e >> h]
     // (two tables of ~sqrt(n) entries: L2-resident, against a 16 * n-byte table that every strided NTT pass
     // would gather from at random); bf[j] = w^(j * n / 2048) are the butterfly twiddles of one tile.
@@ -123,6 +124,9 @@ static inline hipError_t event_wait(hipEvent_t ev) {
 
 namespace zk {
 int permute_expression_pair_async(zkhip_ctx* ctx, uint32_t k, uint32_t blinding_factors, const void* d_input, const void* d_table,
-                                  const void* d_blind_in, const void* d_blind_tab, void* d_perm_in, void* d_perm_tab, uint32_t* d_err_flag);
+                                  const void* d_blind_in, const void* d_blind_tab, void* d_perm_in, void* d_perm_tab, uint32_t* d_err_flag,
+                                  const void* d_sorted_table_keys);
+int permute_sorted_table_keys(zkhip_ctx* ctx, uint64_t key_id, uint32_t slot, uint32_t k, uint32_t blinding_factors, const void* d_table,
+                              const void** d_keys);
 }
 static inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }

@@ -135,6 +135,8 @@ void zkhip_destroy(zkhip_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto& kv : c->scratch)
         if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+    for (auto& kv : c->persistent)
+        if (kv.second) (void)hipFree(kv.second);
     for (auto& t : c->twiddles)
         if (t.d_lo) (void)hipFree(t.d_lo);   // lo, hi and bf share one allocation
     for (auto& sp : c->prof_spans) { (void)hipEventDestroy(sp.e0); (void)hipEventDestroy(sp.e1); }

@@ -229,7 +229,10 @@ namespace zk {
 // Asynchronous form for the library's own schedule: the failure flag (non-zero = ConstraintSystemFailure) is OR-ed into *d_err_flag,
 // which the caller zeroes beforehand and reads at its next synchronisation point.
 int permute_expression_pair_async(zkhip_ctx* ctx, uint32_t k, uint32_t blinding_factors, const void* d_input, const void* d_table,
-                                  const void* d_blind_in, const void* d_blind_tab, void* d_perm_in, void* d_perm_tab, uint32_t* d_err_flag);
+                                  const void* d_blind_in, const void* d_blind_tab, void* d_perm_in, void* d_perm_tab, uint32_t* d_err_flag,
+                                  const void* d_sorted_table_keys);
+int permute_sorted_table_keys(zkhip_ctx* ctx, uint64_t key_id, uint32_t slot, uint32_t k, uint32_t blinding_factors, const void* d_table,
+                              const void** d_keys);
 }
 extern "C" int zkhip_permute_expression_pair_device(zkhip_ctx* ctx, uint32_t k, uint32_t blinding_factors, const void* d_input,
                                                     const void* d_table, const void* d_blind_in, const void* d_blind_tab,
@@ -239,15 +242,36 @@ extern "C" int zkhip_permute_expression_pair_device(zkhip_ctx* ctx, uint32_t k, 
     ZK_TRY(ctx->get_scratch("pe_err", 16, &d_err));
     ZK_HIP(hipMemsetAsync(d_err, 0, 16, ctx->stream));
     ZK_TRY(zk::permute_expression_pair_async(ctx, k, blinding_factors, d_input, d_table, d_blind_in, d_blind_tab, d_perm_in, d_perm_tab,
-                                             (uint32_t*)d_err));
+                                             (uint32_t*)d_err, nullptr));
     uint32_t* h_err = (uint32_t*)ctx->h_pinned;
     ZK_HIP(hipMemcpyAsync(h_err, d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(stream_wait(ctx->stream));
     if (*h_err) { set_error("permute_expression_pair: an input value is not in the table (ConstraintSystemFailure)"); return ZKHIP_ECONSTRAINT; }
     return ZKHIP_OK;
 }
+// The sorted canonical keys of a table column that never changes (a fixed column used as a single-expression lookup table: the
+// range table of halo2-lib), computed once per (proving key id, lookup, k, blinding_factors) and kept by the context.
+int zk::permute_sorted_table_keys(zkhip_ctx* ctx, uint64_t key_id, uint32_t slot, uint32_t k, uint32_t blinding_factors, const void* d_table,
+                                  const void** d_keys) {
+    char name[96];
+    snprintf(name, sizeof name, "pe_table_keys:%llx:%u:%u:%u", (unsigned long long)key_id, slot, k, blinding_factors);
+    auto it = ctx->persistent.find(name);
+    if (it != ctx->persistent.end()) { *d_keys = it->second; return ZKHIP_OK; }
+    size_t n = (size_t)1 << k, np = std::max(n, (size_t)BT_TILE), usable = n - (blinding_factors + 1);
+    void* d = nullptr;
+    hipError_t e = hipMalloc(&d, np * 32);
+    if (e != hipSuccess) { (void)hipGetLastError(); set_error("hipMalloc(%zu) for the sorted table keys failed: %s", np * 32, hipGetErrorString(e)); return ZKHIP_ENOMEM; }
+    hipLaunchKernelGGL(k_pe_keys, dim3(div_up(np, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)d_table, np, usable, (uint32_t*)d);
+    int rc = bitonic_sort(ctx, d, np, 1);
+    if (rc != ZKHIP_OK) { (void)hipFree(d); return rc; }
+    ctx->persistent[name] = d;
+    *d_keys = d;
+    return ZKHIP_OK;
+}
+
 int zk::permute_expression_pair_async(zkhip_ctx* ctx, uint32_t k, uint32_t blinding_factors, const void* d_input, const void* d_table,
-                                      const void* d_blind_in, const void* d_blind_tab, void* d_perm_in, void* d_perm_tab, uint32_t* err) {
+                                      const void* d_blind_in, const void* d_blind_tab, void* d_perm_in, void* d_perm_tab, uint32_t* err,
+                                      const void* d_sorted_table_keys) {
     if (!ctx || !d_input || !d_table || !d_blind_in || !d_blind_tab || !d_perm_in || !d_perm_tab || !err) { set_error("zkhip_permute_expression_pair_device: null argument"); return ZKHIP_EINVAL; }
     if (k < 1 || k > 26) { set_error("zkhip_permute_expression_pair_device: k = %u unsupported (1..26)", k); return ZKHIP_EINVAL; }
     size_t n = (size_t)1 << k;
@@ -269,8 +293,13 @@ int zk::permute_expression_pair_async(zkhip_ctx* ctx, uint32_t k, uint32_t blind
     ZK_HIP(hipMemsetAsync(d_misc, 0, 16, st));
     unsigned g = div_up(n, 256);
     hipLaunchKernelGGL(k_pe_keys, dim3(div_up(np, 256)), dim3(256), 0, st, (const uint32_t*)d_input, np, usable, (uint32_t*)dA);
-    hipLaunchKernelGGL(k_pe_keys, dim3(div_up(np, 256)), dim3(256), 0, st, (const uint32_t*)d_table, np, usable, (uint32_t*)dT);
-    ZK_TRY(bitonic_sort(ctx, dA, np, 2));
+    if (d_sorted_table_keys) {   // a fixed table sorted once at first use: only the input column is sorted per proof
+        dT = const_cast<void*>(d_sorted_table_keys);
+        ZK_TRY(bitonic_sort(ctx, dA, np, 1));
+    } else {
+        hipLaunchKernelGGL(k_pe_keys, dim3(div_up(np, 256)), dim3(256), 0, st, (const uint32_t*)d_table, np, usable, (uint32_t*)dT);
+        ZK_TRY(bitonic_sort(ctx, dA, np, 2));
+    }
     hipLaunchKernelGGL(k_fill_u32, dim3(g), dim3(256), 0, st, left_flag, n, 1u);
     ZK_HIP(hipMemsetAsync(rep_flag, 0, n * 4, st));
     hipLaunchKernelGGL(k_pe_mark, dim3(div_up(usable, 256)), dim3(256), 0, st, (const uint32_t*)dA, (const uint32_t*)dT, usable, rep_flag, left_flag, err);

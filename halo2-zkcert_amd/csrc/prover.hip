@@ -167,8 +167,13 @@ extern "C" int zkhip_create_proof(zkhip_ctx* ctx, const zk_proving_key* pk, cons
     char* w_perr;   // one failure flag for all lookups, read after the permuted columns' commitment (no extra sync)
     ZK_TRY(ws("cp_perr", 16, &w_perr));
     if (L) ZK_HIP(hipMemsetAsync(w_perr, 0, 16, st));
+    std::vector<const void*> comp_in(L), comp_tab(L);   // the theta-compressed input / table columns (Lagrange form)
     for (uint32_t i = 0; i < L; ++i) {
+        const int32_t in_col = pk->lookup_input_advice_column ? pk->lookup_input_advice_column[i] : -1;
+        const int32_t tab_col = pk->lookup_table_fixed_column ? pk->lookup_table_fixed_column[i] : -1;
         for (int side = 0; side < 2; ++side) {
+            if (side == 0 && in_col >= 0 && (uint32_t)in_col < A) { comp_in[i] = d_advice[in_col]; continue; }     // a single column: itself
+            if (side == 1 && tab_col >= 0 && (uint32_t)tab_col < F) { comp_tab[i] = pk->fixed_lagrange[tab_col]; continue; }
             zk_evalh_args a;
             memset(&a, 0, sizeof a);
             a.k = k; a.extended_k = k; a.cs_degree = 3; a.blinding_factors = 0;
@@ -179,13 +184,17 @@ extern "C" int zkhip_create_proof(zkhip_ctx* ctx, const zk_proving_key* pk, cons
             a.instance_cosets = (const uint64_t* const*)d_instance;
             a.custom_gates = side ? pk->lookup_table_compress[i] : pk->lookup_input_compress[i];
             ZK_TRY(zkhip_evaluate_h_device(ctx, &a, w_comp + (2 * i + side) * NB));
+            (side ? comp_tab[i] : comp_in[i]) = w_comp + (2 * i + side) * NB;
         }
+        const void* sorted_keys = nullptr;
+        if (pk->key_id && tab_col >= 0 && (uint32_t)tab_col < F)
+            ZK_TRY(zk::permute_sorted_table_keys(ctx, pk->key_id, i, k, bf, comp_tab[i], &sorted_keys));
         char* bi = w_blind + (2 * i) * (bf + 1) * 32;
         char* bt = w_blind + (2 * i + 1) * (bf + 1) * 32;
         ZK_TRY(zkhip_synth_fill_device(ctx, bi, bf + 1, blinding_seed + 300 + i, 0));
         ZK_TRY(zkhip_synth_fill_device(ctx, bt, bf + 1, blinding_seed + 320 + i, 0));
-        ZK_TRY(zk::permute_expression_pair_async(ctx, k, bf, w_comp + (2 * i) * NB, w_comp + (2 * i + 1) * NB, bi, bt, w_perm_l + i * NB,
-                                                 w_perm_l + (L + i) * NB, (uint32_t*)w_perr));
+        ZK_TRY(zk::permute_expression_pair_async(ctx, k, bf, comp_in[i], comp_tab[i], bi, bt, w_perm_l + i * NB, w_perm_l + (L + i) * NB,
+                                                 (uint32_t*)w_perr, sorted_keys));
     }
     for (uint32_t j = 0; j < 2 * L; ++j) { perm_c[j] = w_perm_c + j * NB; ext_perm[j] = w_ext_perm + j * EB; }
     if (L) {
@@ -221,7 +230,7 @@ extern "C" int zkhip_create_proof(zkhip_ctx* ctx, const zk_proving_key* pk, cons
             values[j] = t == 0 ? d_advice[c] : t == 1 ? pk->fixed_lagrange[c] : d_instance[c];
         }
         for (uint32_t i = 0; i < L; ++i) {
-            ci[i] = w_comp + (2 * i) * NB; ct[i] = w_comp + (2 * i + 1) * NB;
+            ci[i] = comp_in[i]; ct[i] = comp_tab[i];
             pi[i] = w_perm_l + i * NB; pt[i] = w_perm_l + (L + i) * NB;
         }
         char* pb = w_blind + 2 * L * (bf + 1) * 32;

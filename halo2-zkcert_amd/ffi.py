@@ -359,7 +359,9 @@ class ZkProvingKey(C.Structure):
                 ("sigma_lagrange", C.c_void_p), ("sigma_coeff", C.c_void_p), ("sigma_cosets", C.c_void_p),
                 ("l0", C.c_void_p), ("l_last", C.c_void_p), ("l_active_row", C.c_void_p),
                 ("custom_gates", ZkGraph), ("lookup_graphs", C.c_void_p), ("lookup_input_compress", C.c_void_p),
-                ("lookup_table_compress", C.c_void_p), ("perm_column_type", C.c_void_p), ("perm_column_index", C.c_void_p),
+                ("lookup_table_compress", C.c_void_p), ("lookup_input_advice_column", C.c_void_p),
+                ("lookup_table_fixed_column", C.c_void_p), ("key_id", C.c_uint64), ("perm_column_type", C.c_void_p),
+                ("perm_column_index", C.c_void_p),
                 ("n_advice_queries", C.c_uint32), ("n_fixed_queries", C.c_uint32),
                 ("advice_query_column", C.c_void_p), ("advice_query_rotation", C.c_void_p),
                 ("fixed_query_column", C.c_void_p), ("fixed_query_rotation", C.c_void_p),

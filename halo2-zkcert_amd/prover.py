@@ -28,6 +28,7 @@ The schedule is written against a small backend interface so the same code drive
 """
 import contextlib
 import hashlib
+import os
 
 import numpy as np
 
@@ -501,6 +502,7 @@ DELTA = 0x09226B6E22C6F0CA64EC26AAD4C86E715B5F898E5E963F25870E56BBE533E9A2
 
 class Prover:
     """Keygen-shaped setup once, then prove() = one create_proof-shaped pass (the benchmark step)."""
+    _key_counter = 0
 
     def __init__(self, backend, shape, srs_trapdoor=0x1D5C0FFEE, satisfiable=False):
         """satisfiable=True (halo2-lib shaped circuits only): selectors, copy constraints and witness are built so that every
@@ -683,6 +685,11 @@ class Prover:
         pk.lookup_graphs = graphs(self.lookup_graphs)
         pk.lookup_input_compress = graphs([p_[0] for p_ in self.compress_graphs])
         pk.lookup_table_compress = graphs([p_[1] for p_ in self.compress_graphs])
+        single = lambda exprs, kind: exprs[0][1] if len(exprs) == 1 and exprs[0][0] == kind and exprs[0][2] == 0 else -1
+        pk.lookup_input_advice_column = arr((single(ins_, "advice") for ins_, _ in sh.lookups), np.int32)
+        pk.lookup_table_fixed_column = arr((single(tabs_, "fixed") for _, tabs_ in sh.lookups), np.int32)
+        Prover._key_counter += 1
+        pk.key_id = (os.getpid() << 32) | Prover._key_counter     # unique per proving key in this process: keys the sorted-table cache
         tmap = {"advice": 0, "fixed": 1, "instance": 2}
         pk.perm_column_type = arr((tmap[t] for t, _ in sh.perm_columns), np.uint32)
         pk.perm_column_index = arr((i for _, i in sh.perm_columns), np.uint32)

@@ -280,6 +280,14 @@ typedef struct zk_proving_key {
     const zk_graph* lookup_graphs;            /* HOST, n_lookups: the lookup argument's input/table product graphs (evaluate_h) */
     const zk_graph* lookup_input_compress;    /* HOST, n_lookups: theta-compression of the input expressions */
     const zk_graph* lookup_table_compress;    /* HOST, n_lookups */
+    /* Optional shortcuts (HOST arrays of n_lookups entries, or NULL): when lookup i's input is exactly one advice column at rotation 0,
+     * lookup_input_advice_column[i] is its index (else -1) and no compression pass runs; when its table is exactly one FIXED column at
+     * rotation 0 (halo2-lib's range table), lookup_table_fixed_column[i] is its index (else -1): no compression pass, and — if key_id
+     * is non-zero — the column is sorted once and the sorted form kept by the context under (key_id, i) instead of being sorted in
+     * every proof.  key_id must then be unique per proving key (fixed-column contents) for the life of the context. */
+    const int32_t* lookup_input_advice_column;
+    const int32_t* lookup_table_fixed_column;
+    uint64_t key_id;
     const uint32_t* perm_column_type;         /* HOST: 0 advice, 1 fixed, 2 instance */
     const uint32_t* perm_column_index;
     uint32_t n_advice_queries, n_fixed_queries;                                     /* cs.advice_queries / cs.fixed_queries order */
