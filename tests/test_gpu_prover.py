@@ -191,3 +191,29 @@ def test_agg_k22_pass_properties(zk, oracle):
     t2 = gp.prove_native(w)
     assert t2["proof"] == t1["proof"] and len(t1["proof"]) == 32 * (t1["n_commitments"] + len(t1["evals"]) - 1)
     del gp, w
+
+
+def test_native_create_proof_two_expression_lookup(zk, oracle):
+    """A lookup with two input and two table expressions: the theta-compression passes run (no single-column shortcut, no cached
+    table); the native schedule equals the Python one and the oracle backend's."""
+    ffi, ctx = zk
+    k = 8
+    sh = pv.CircuitShape.small(k)
+    A = lambda c, r: ("advice", c, r)
+    sh.lookups = [([A(sh.n_basic, 0), A(0, 0)], [("fixed", sh.n_fixed - 1, 0), ("fixed", sh.n_basic, 0)])]
+    sh._queries = None
+    gp = pv.Prover(pv.GpuBackend(ctx, ffi), sh)
+    cp = pv.Prover(OracleBackend(8), sh)
+    n = 1 << k
+    idx = (np.arange(n, dtype=np.int64) * 37 + 11) % (n // 2)
+
+    def wit(p):   # (input_1, input_2)[row] = (table_1, table_2)[idx[row]]: a satisfiable two-column lookup
+        w = p.witness(5)
+        w["advice"][sh.n_basic] = p.b.gather(p.fixed_lagrange[sh.n_fixed - 1], idx)
+        w["advice"][0] = p.b.gather(p.fixed_lagrange[sh.n_basic], idx)
+        return w
+
+    wg, wc = wit(gp), wit(cp)
+    ta, tb, tc = gp.prove(wg), gp.prove_native(wg), cp.prove(wc)
+    assert ta["commitments"] == tb["commitments"] == tc["commitments"]
+    assert ta["challenges"] == tb["challenges"] == tc["challenges"]
