@@ -85,7 +85,9 @@ extern "C" int zkhip_create_proof(zkhip_ctx* ctx, const zk_proving_key* pk, cons
         ZK_HIP(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
         ZK_HIP(hipEventCreateWithFlags(&ctx->side_event, hipEventDisableTiming));
     }
-    Overlap ov{ctx, ctx->stream, ctx->side_stream, ctx->side_event, k <= 18};
+    bool late = k <= 18;
+    if (const char* e = getenv("ZKHIP_LATE_OVERLAP")) late = atoi(e) != 0;
+    Overlap ov{ctx, ctx->stream, ctx->side_stream, ctx->side_event, late};
     StreamGuard guard{ctx, ctx->stream};
     hipStream_t st = ctx->stream;
 
