@@ -130,7 +130,124 @@ void t_squeeze(void* user, uint64_t out[4]) {
 }
 }  // namespace
 
+// ------------------------------------------------------------------ EVM transcript
+// snark-verifier system/halo2/transcript/evm.rs EvmTranscript<G1Affine, NativeLoader, _, Vec<u8>> [UPSTREAM-RECALL; crate pinned at
+// /root/reference/Cargo.lock:2714-2716; the transcript behind gen_evm_proof_shplonk, /root/reference/src/bin/cli.rs:519]:
+// a byte buffer; a point appends its canonical x and y as 32 BIG-endian bytes each, a scalar its 32 big-endian bytes; a challenge is
+// Keccak-256 of the buffer (plus one 0x01 byte when the buffer is exactly 32 bytes, i.e. two squeezes in a row), read as a
+// big-endian integer mod r, and the digest becomes the new buffer.  The proof stream receives the same 64 / 32 bytes.
+namespace {
+struct Keccak256 {
+    static void f1600(uint64_t st[25]) {
+        static const uint64_t RC[24] = {0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
+                                        0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
+                                        0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+                                        0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
+                                        0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+                                        0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+        static const int ROT[24] = {1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44};
+        static const int PIL[24] = {10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1};
+        auto rotl = [](uint64_t x, int n) { return (x << n) | (x >> (64 - n)); };
+        for (int r = 0; r < 24; ++r) {
+            uint64_t bc[5];
+            for (int i = 0; i < 5; ++i) bc[i] = st[i] ^ st[i + 5] ^ st[i + 10] ^ st[i + 15] ^ st[i + 20];
+            for (int i = 0; i < 5; ++i) { uint64_t t = bc[(i + 4) % 5] ^ rotl(bc[(i + 1) % 5], 1); for (int j = 0; j < 25; j += 5) st[j + i] ^= t; }
+            uint64_t t = st[1];
+            for (int i = 0; i < 24; ++i) { int j = PIL[i]; uint64_t b = st[j]; st[j] = rotl(t, ROT[i]); t = b; }
+            for (int j = 0; j < 25; j += 5) {
+                for (int i = 0; i < 5; ++i) bc[i] = st[j + i];
+                for (int i = 0; i < 5; ++i) st[j + i] ^= (~bc[(i + 1) % 5]) & bc[(i + 2) % 5];
+            }
+            st[0] ^= RC[r];
+        }
+    }
+    // pad = 0x01 for Keccak-256 (Ethereum), 0x06 for SHA3-256 (used by the self-check against hashlib)
+    static void digest(const uint8_t* in, size_t len, uint8_t pad, uint8_t out[32]) {
+        const size_t rate = 136;
+        uint64_t st[25] = {0};
+        uint8_t block[136];
+        while (len >= rate) {
+            for (size_t i = 0; i < rate / 8; ++i) { uint64_t w; memcpy(&w, in + 8 * i, 8); st[i] ^= w; }
+            f1600(st);
+            in += rate; len -= rate;
+        }
+        memset(block, 0, rate);
+        memcpy(block, in, len);
+        block[len] ^= pad;
+        block[rate - 1] ^= 0x80;
+        for (size_t i = 0; i < rate / 8; ++i) { uint64_t w; memcpy(&w, block + 8 * i, 8); st[i] ^= w; }
+        f1600(st);
+        memcpy(out, st, 32);
+    }
+};
+}  // namespace
+
+struct zkhip_evm_transcript {
+    zk_transcript cb;
+    std::vector<uint8_t> buf, proof;
+    std::vector<uint64_t> points_xy, challenges;
+};
+
+namespace {
+inline void be32(const fe32& canon, uint8_t out[32]) {
+    const uint8_t* le = (const uint8_t*)canon.w;
+    for (int i = 0; i < 32; ++i) out[i] = le[31 - i];
+}
+void e_write_point(void* user, const uint8_t*, const uint64_t xy[8]) {
+    auto* t = (zkhip_evm_transcript*)user;
+    uint8_t b[64];
+    be32(abi_to_canonical_words<Fq>(mem_load(xy)), b);
+    be32(abi_to_canonical_words<Fq>(mem_load(xy + 4)), b + 32);
+    t->buf.insert(t->buf.end(), b, b + 64);
+    t->proof.insert(t->proof.end(), b, b + 64);
+    t->points_xy.insert(t->points_xy.end(), xy, xy + 8);
+}
+void e_write_scalar(void* user, const uint64_t scalar[4]) {
+    auto* t = (zkhip_evm_transcript*)user;
+    uint8_t b[32];
+    be32(abi_to_canonical_words<Fr>(mem_load(scalar)), b);
+    t->buf.insert(t->buf.end(), b, b + 32);
+    t->proof.insert(t->proof.end(), b, b + 32);
+}
+void e_squeeze(void* user, uint64_t out[4]) {
+    auto* t = (zkhip_evm_transcript*)user;
+    if (t->buf.size() == 32) t->buf.push_back(1);
+    uint8_t d[32];
+    Keccak256::digest(t->buf.data(), t->buf.size(), 0x01, d);
+    t->buf.assign(d, d + 32);
+    uint32_t w[8];   // the digest as a big-endian integer -> little-endian words -> mod r (from_canonical_words reduces)
+    for (int i = 0; i < 8; ++i) w[i] = ((uint32_t)d[31 - 4 * i]) | ((uint32_t)d[30 - 4 * i] << 8) | ((uint32_t)d[29 - 4 * i] << 16) | ((uint32_t)d[28 - 4 * i] << 24);
+    fe32 abi = hf_abi(hf(canonical(from_canonical_words<Fr>(w))));
+    memcpy(out, abi.w, 32);
+    t->challenges.insert(t->challenges.end(), out, out + 4);
+}
+}  // namespace
+
 extern "C" {
+
+zkhip_evm_transcript* zkhip_evm_transcript_new(void) {
+    auto* t = new zkhip_evm_transcript();
+    t->cb.user = t;
+    t->cb.write_point = e_write_point;
+    t->cb.squeeze_challenge = e_squeeze;
+    t->cb.write_scalar = e_write_scalar;
+    return t;
+}
+void zkhip_evm_transcript_free(zkhip_evm_transcript* t) { delete t; }
+const zk_transcript* zkhip_evm_transcript_callbacks(zkhip_evm_transcript* t) { return t ? &t->cb : nullptr; }
+size_t zkhip_evm_transcript_proof(const zkhip_evm_transcript* t, const uint8_t** bytes) {
+    if (!t) return 0;
+    if (bytes) *bytes = t->proof.data();
+    return t->proof.size();
+}
+size_t zkhip_evm_transcript_challenges(const zkhip_evm_transcript* t, const uint64_t** limbs) {
+    if (!t) return 0;
+    if (limbs) *limbs = t->challenges.data();
+    return t->challenges.size() / 4;
+}
+/* Keccak-f[1600] sponge with a caller-chosen padding byte (0x01 Keccak-256, 0x06 SHA3-256): exposed so that the permutation can be
+ * checked against a library implementation of SHA3-256 */
+void zkhip_keccak256(const uint8_t* in, size_t len, uint8_t pad, uint8_t out[32]) { Keccak256::digest(in, len, pad, out); }
 
 zkhip_blake2b_transcript* zkhip_blake2b_transcript_new(void) {
     auto* t = new zkhip_blake2b_transcript();

@@ -71,6 +71,8 @@ SYMBOLS = [
     "zkhip_create_proof",
     "zkhip_blake2b_transcript_new", "zkhip_blake2b_transcript_free", "zkhip_blake2b_transcript_callbacks", "zkhip_blake2b_transcript_proof",
     "zkhip_blake2b_transcript_points", "zkhip_blake2b_transcript_challenges",
+    "zkhip_evm_transcript_new", "zkhip_evm_transcript_free", "zkhip_evm_transcript_callbacks", "zkhip_evm_transcript_proof",
+    "zkhip_evm_transcript_challenges", "zkhip_keccak256",
 ]
 
 
@@ -88,6 +90,10 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.zkhip_last_error.restype = C.c_char_p
         L.zkhip_srs_len.restype = C.c_size_t
+        L.zkhip_evm_transcript_new.restype = C.c_void_p
+        L.zkhip_evm_transcript_callbacks.restype = C.c_void_p
+        L.zkhip_evm_transcript_proof.restype = C.c_size_t
+        L.zkhip_evm_transcript_challenges.restype = C.c_size_t
         L.zkhip_blake2b_transcript_new.restype = C.c_void_p
         L.zkhip_blake2b_transcript_callbacks.restype = C.c_void_p
         for f in ("zkhip_blake2b_transcript_proof", "zkhip_blake2b_transcript_points", "zkhip_blake2b_transcript_challenges"):
@@ -348,6 +354,35 @@ class NativeTranscript:
         p = C.POINTER(C.c_uint64)()
         n = lib().zkhip_blake2b_transcript_challenges(self.h, C.byref(p))
         return np.frombuffer(C.string_at(p, n * 32), dtype=np.uint64).reshape(n, 4) if n else np.zeros((0, 4), dtype=np.uint64)
+
+
+class EvmTranscript:
+    """The library's EvmTranscript (Keccak-256; snark-verifier's transcript for EVM proofs)."""
+
+    def __init__(self):
+        self.h = C.c_void_p(lib().zkhip_evm_transcript_new())
+        self.callbacks = C.c_void_p(lib().zkhip_evm_transcript_callbacks(self.h))
+
+    def __del__(self):
+        if getattr(self, "h", None) and self.h.value and lib is not None:
+            lib().zkhip_evm_transcript_free(self.h)
+            self.h = C.c_void_p()
+
+    def proof(self):
+        p = C.POINTER(C.c_uint8)()
+        n = lib().zkhip_evm_transcript_proof(self.h, C.byref(p))
+        return C.string_at(p, n) if n else b""
+
+    def challenges(self):
+        p = C.POINTER(C.c_uint64)()
+        n = lib().zkhip_evm_transcript_challenges(self.h, C.byref(p))
+        return np.frombuffer(C.string_at(p, n * 32), dtype=np.uint64).reshape(n, 4) if n else np.zeros((0, 4), dtype=np.uint64)
+
+
+def keccak256(data, pad=0x01):
+    out = (C.c_uint8 * 32)()
+    lib().zkhip_keccak256(data, C.c_size_t(len(data)), C.c_uint8(pad), out)
+    return bytes(out)
 
 
 class ZkProvingKey(C.Structure):

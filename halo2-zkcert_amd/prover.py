@@ -702,11 +702,12 @@ class Prover:
         self._npk, self._npk_keep = pk, keep
         return pk
 
-    def prove_native(self, wit, fetch_h=False, python_transcript=False):
+    def prove_native(self, wit, fetch_h=False, python_transcript=False, evm=False):
         """The same pass through zkhip_create_proof (the schedule and all host arithmetic in the library).  The transcript is the
         library's Blake2bWrite (no Python between the launches) or, with python_transcript, Blake2bTranscript through callbacks
-        (identical challenges: tests/test_schedule_cpu.py).  Returns the same trace as prove() plus trace["proof"], the bytes
-        Blake2bWrite's writer received; the quotient's coefficients are copied to the host only on request (fetch_h: 96 n bytes
+        (identical challenges: tests/test_schedule_cpu.py); with evm it is the library's EvmTranscript (Keccak-256; points are
+        64 big-endian bytes in the proof, and the challenges differ from the Blake2b ones).  Returns the same trace as prove()
+        plus trace["proof"], the bytes the transcript's writer received; the quotient's coefficients are copied to the host only on request (fetch_h: 96 n bytes
         over PCIe, for tests)."""
         import ctypes as C
 
@@ -742,7 +743,7 @@ class Prover:
             t = ffi.make_transcript(write_point, squeeze, write_scalar)
             t_ref = C.byref(t)
         else:
-            nt = ffi.NativeTranscript()
+            nt = ffi.EvmTranscript() if evm else ffi.NativeTranscript()
             t_ref = nt.callbacks
         qlist = self._query_list()
         evals = np.zeros((len(qlist), 4), dtype=np.uint64)
@@ -757,18 +758,25 @@ class Prover:
         if rc != 0:
             raise ffi.ZkhipError(f"zkhip_create_proof: {rc}: {ffi.lib().zkhip_last_error().decode()}")
         if nt is not None:   # rebuild the trace from what the library's transcript recorded
-            proof, pts, chs = nt.proof(), nt.points(), nt.challenges()
+            proof, chs = nt.proof(), nt.challenges()
             trace["proof"] = proof
-            assert len(pts) == len(point_tags) and len(chs) == len(squeeze_tags)
+            psize = 64 if evm else 32
+            pts = None if evm else nt.points()
+            assert len(chs) == len(squeeze_tags)
             off = 0
             n_eval_written = len(qlist) - 1
             for i_, tag in enumerate(point_tags):
                 if tag == "shplonk_h1":
                     off += 32 * n_eval_written      # the evaluations sit between the quotient pieces and the SHPLONK points
-                byts = proof[off:off + 32]
-                off += 32
+                byts = proof[off:off + psize]
+                off += psize
                 trace["commitments"].append((tag, byts.hex()))
-                trace["points"].setdefault(tag, []).append(pts[i_])
+                if evm:   # big-endian canonical coordinates -> Montgomery limbs
+                    xy = [int.from_bytes(byts[:32], "big"), int.from_bytes(byts[32:], "big")]
+                    limbs = [(v * (1 << 256) % Q_MOD >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for v in xy for j in range(4)]
+                    trace["points"].setdefault(tag, []).append(np.array(limbs, dtype=np.uint64))
+                else:
+                    trace["points"].setdefault(tag, []).append(pts[i_])
             assert off == len(proof)
             for tag, limbs in zip(squeeze_tags, chs):
                 trace["challenges"][tag] = from_mont_host(limbs)

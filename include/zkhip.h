@@ -317,6 +317,17 @@ size_t zkhip_blake2b_transcript_proof(const zkhip_blake2b_transcript* t, const u
 size_t zkhip_blake2b_transcript_points(const zkhip_blake2b_transcript* t, const uint64_t** xy);           /* -> count; 8 u64 each */
 size_t zkhip_blake2b_transcript_challenges(const zkhip_blake2b_transcript* t, const uint64_t** limbs);    /* -> count; 4 u64 each (ABI) */
 
+/* ---- and snark-verifier's EvmTranscript (system/halo2/transcript/evm.rs; behind gen_evm_proof_shplonk, /root/reference/src/bin/cli.rs:519):
+ * Keccak-256 over a byte buffer of big-endian coordinates / scalars; the proof stream holds points as 64 bytes (x, y big-endian) and
+ * scalars as 32 big-endian bytes.  The identity point cannot be written (upstream returns an error; here its (0, 0) is written). */
+typedef struct zkhip_evm_transcript zkhip_evm_transcript;
+zkhip_evm_transcript* zkhip_evm_transcript_new(void);
+void zkhip_evm_transcript_free(zkhip_evm_transcript* t);
+const zk_transcript* zkhip_evm_transcript_callbacks(zkhip_evm_transcript* t);
+size_t zkhip_evm_transcript_proof(const zkhip_evm_transcript* t, const uint8_t** bytes);          /* -> length */
+size_t zkhip_evm_transcript_challenges(const zkhip_evm_transcript* t, const uint64_t** limbs);    /* -> count; 4 u64 each (ABI) */
+void zkhip_keccak256(const uint8_t* in, size_t len, uint8_t pad /* 0x01 Keccak-256, 0x06 SHA3-256 */, uint8_t out[32]);
+
 /* ---- synthetic tables (bench / tests): element i of a column = raw253(seed, i) taken as the
  * Montgomery limbs (oracle/pyref.py synth_raw253) ---- */
 int  zkhip_synth_fill_device(zkhip_ctx* ctx, void* d_out, size_t n, uint64_t seed, uint64_t first_index);

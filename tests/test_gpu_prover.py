@@ -217,3 +217,52 @@ def test_native_create_proof_two_expression_lookup(zk, oracle):
     ta, tb, tc = gp.prove(wg), gp.prove_native(wg), cp.prove(wc)
     assert ta["commitments"] == tb["commitments"] == tc["commitments"]
     assert ta["challenges"] == tb["challenges"] == tc["challenges"]
+
+
+def test_native_create_proof_evm_transcript(zk, oracle):
+    """zkhip_create_proof over the library's EvmTranscript (Keccak-256): a different Fiat-Shamir, so different challenges, but the
+    first-phase commitments are the same points, the proof has the EVM layout (64-byte points, 32-byte scalars), the quotient
+    commitments satisfy the SRS-trapdoor identity, and the SHPLONK opening verifies for the Keccak challenges."""
+    import pyref as P
+
+    ffi, ctx = zk
+    zo = oracle
+    s = 0x1D5C0FFEE
+    sh = pv.CircuitShape.small(7)
+    gp = pv.Prover(pv.GpuBackend(ctx, ffi), sh, srs_trapdoor=s, satisfiable=True)
+    w = gp.witness(1)
+    tb = gp.prove_native(w)
+    te = gp.prove_native(w, evm=True, fetch_h=True)
+    assert te["challenges"]["theta"] != tb["challenges"]["theta"]
+    nq = len(te["evals"]) - 1
+    assert len(te["proof"]) == 64 * te["n_commitments"] + 32 * nq
+    adv_b = [np.asarray(p_) for p_ in tb["points"]["advice"]]
+    adv_e = [np.asarray(p_) for p_ in te["points"]["advice"]]
+    assert all((a == b).all() for a, b in zip(adv_b, adv_e))          # advice commitments precede every challenge
+    sm = zo.fr_from_int(s)
+    for piece, pt in zip(te["h_pieces"], te["points"]["quotient"]):
+        assert zo.g1_to_bytes(zo.g1_mul_gen(zo.eval_polynomial(piece, sm))) == zo.g1_to_bytes(np.asarray(pt, dtype=np.uint64))
+    # the multi-open under the Keccak challenges: pyref's verifier equation with this trace's points / evaluations
+    from verify_util import _pts
+    coms = {}
+    for i, p_ in enumerate(_pts(te["points"]["advice"])):
+        coms[("advice", i)] = p_
+    L = len(sh.lookups)
+    lp = _pts(te["points"].get("lookup_permuted", []))
+    for i in range(L):
+        coms[("lookup_a", i)], coms[("lookup_s", i)] = lp[i], lp[L + i]
+    prods = _pts(te["points"]["products"])
+    for i in range(sh.n_perm_sets):
+        coms[("perm_z", i)] = prods[i]
+    for i in range(L):
+        coms[("lookup_z", i)] = prods[sh.n_perm_sets + i]
+    coms[("random", 0)] = _pts(te["points"]["random_poly"])[0]
+    for i, c in enumerate(gp.b.commit(gp.fixed_coeff, lagrange=False)):
+        coms[("fixed", i)] = _pts([c[0]])[0]
+    for i, c in enumerate(gp.b.commit(gp.sigma_coeff, lagrange=False)):
+        coms[("sigma", i)] = _pts([c[0]])[0]
+    vk = dict(k=sh.k, degree=sh.degree, blinding_factors=sh.blinding_factors, gates=sh.gates, lookups=sh.lookups, perm_columns=sh.perm_columns)
+    evals = {q: v for q, v in pv.eval_ints(te).items() if q[0] != ("h", 0)}
+    instance = [zo.fr_arr_to_ints(gp.b.to_host(c)) for c in w["instance"]]
+    h1, h2 = _pts(te["points"]["shplonk_h1"])[0], _pts(te["points"]["shplonk_h2"])[0]
+    assert P.plonk_verify(vk, instance, coms, _pts(te["points"]["quotient"]), evals, te["query_list"], te["challenges"], h1, h2, s)

@@ -131,3 +131,52 @@ def test_native_blake2b_transcript_matches_python(oracle):
     assert nt.proof() == expect_proof
     assert [zo.fr_to_int(c) for c in nt.challenges()] == exp
     assert nt.points().shape == (29, 8)
+
+
+def test_keccak_and_evm_transcript(oracle):
+    """(1) The library's Keccak-f[1600] sponge with SHA-3 padding equals hashlib.sha3_256 on many lengths: the permutation is pinned,
+    so Keccak-256 (padding 0x01) is too.  (2) zkhip_evm_transcript_*: buffer layout (big-endian coordinates / scalars), the extra 0x01
+    byte on back-to-back squeezes, digest-becomes-buffer, big-endian reduction — recomputed here with the same Keccak."""
+    import ctypes as C
+    import hashlib
+
+    import halo2_zkcert_amd.ffi as ffi
+
+    zo = oracle
+    for n in (0, 1, 31, 32, 33, 64, 135, 136, 137, 271, 272, 273, 1000):
+        data = bytes((i * 131 + n) & 0xFF for i in range(n))
+        assert ffi.keccak256(data, 0x06) == hashlib.sha3_256(data).digest(), n
+    assert ffi.keccak256(b"", 0x01).hex() == "c5d2460186f7233c927e7db2dcc703c0e500b653ca82273b7bfad8045d85a470"   # Keccak-256("")
+    et = ffi.EvmTranscript()
+    cb = ffi.ZkTranscript.from_address(et.callbacks.value)
+    buf, proof, exp = b"", b"", []
+
+    def squeeze_ref():
+        nonlocal buf
+        data = buf + (b"\x01" if len(buf) == 32 else b"")
+        buf = ffi.keccak256(data, 0x01)
+        return int.from_bytes(buf, "big") % pv.R
+
+    got = []
+    for i in range(1, 9):
+        pt = zo.g1_to_affine(zo.g1_mul_gen(zo.fr_from_int(i * 13 + 2)))
+        x, y = zo.affine_to_ints(pt.reshape(1, 8))[0]
+        cb.write_point(cb.user, (C.c_uint8 * 32)(), pt.ctypes.data_as(C.POINTER(C.c_uint64)))
+        enc = x.to_bytes(32, "big") + y.to_bytes(32, "big")
+        buf += enc
+        proof += enc
+        if i % 2 == 0:
+            s = pow(i, 40, pv.R)
+            sm = zo.fr_from_int(s)
+            cb.write_scalar(cb.user, sm.ctypes.data_as(C.POINTER(C.c_uint64)))
+            buf += s.to_bytes(32, "big")
+            proof += s.to_bytes(32, "big")
+        if i % 3 == 0:
+            for _ in range(2):      # two squeezes in a row: the second hashes digest || 0x01
+                out = (C.c_uint64 * 4)()
+                cb.squeeze_challenge(cb.user, out)
+                got.append(zo.fr_to_int(np.array(list(out), dtype=np.uint64)))
+                exp.append(squeeze_ref())
+    assert got == exp and len(got) == 4
+    assert et.proof() == proof
+    assert [zo.fr_to_int(c) for c in et.challenges()] == exp
