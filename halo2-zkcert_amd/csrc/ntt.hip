@@ -137,10 +137,12 @@ __device__ __forceinline__ void tile_ntt(fe* tile, uint32_t s, uint32_t logT, co
 __device__ __forceinline__ fe load_in(const uint32_t* src, uint32_t i, uint32_t n_in, const NttScale& sc) {
     if (i >= n_in) return fe_zero();
     el1<Fr> v = load_raw<Fr>(src + (size_t)i * 8);
-    if (sc.use_pre) {
+    if (sc.use_pre) {   // one product with a selected factor (pre[0] is the field's one): no divergence over i mod 3
         uint32_t r = i % 3;
-        if (r == 1) return (v * el2<Fr>(sc.pre[1])).v;
-        if (r == 2) return (v * el2<Fr>(sc.pre[2])).v;
+        fe w;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) w.l[q] = r == 0 ? sc.pre[0].l[q] : (r == 1 ? sc.pre[1].l[q] : sc.pre[2].l[q]);
+        return (v * el2<Fr>(w)).v;
     }
     return v.v;
 }
@@ -232,6 +234,191 @@ __global__ void __launch_bounds__(256) k_ntt_final(const uint32_t* const* srcs, 
     }
 }
 
+// ------------------------------------------------------------------ register-tiled variants (full 2048-element tiles)
+// The same tile transform with three radix-2 stages at a time held in registers: thread t owns 8 elements whose row indices
+// differ in one 3-bit field ("slot"), runs the stages whose partner bit lies in that field, and only then exchanges through
+// LDS — ceil(s/3) - 1 round trips and barriers per tile instead of s, and the first load / last store go straight between
+// HBM and registers.  Group i covers stages [3i, e_i), e_i = min(3i+3, s); its slot field is the row bits [e_i-3, e_i), so a
+// short last group simply carries 3 - g passive bits.  Logical tile index L = row * T + tl as above; the LDS element index is
+// L with a few high bits XORed into low ones (Swz) so that the 32 lanes of an access, which differ in bits on both sides of the
+// slot field, land in 32 different banks (an element is 9 dwords, 9 is odd).
+struct Swz { uint32_t sh, mk, ts; };
+__device__ __forceinline__ uint32_t swz(uint32_t L, const Swz& z) { return L ^ (((L >> z.sh) & z.mk) << z.ts); }
+// thread index -> logical index with a zero 3-bit slot field at bit p
+__device__ __forceinline__ uint32_t place(uint32_t t, uint32_t p) { return (t & ((1u << p) - 1)) | ((t >> p) << (p + 3)); }
+
+__device__ __forceinline__ void bfly(fe& a, fe& b, const el2<Fr>& bw) {   // (a, b) <- (a + bw, a - bw + 3p)
+    fe sum, dif;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        sum.l[q] = a.l[q] + bw.v.l[q];
+        dif.l[q] = a.l[q] + kp_spread<Fr>(3, q) - bw.v.l[q];
+    }
+    fe_normalize(sum);
+    fe_normalize(dif);
+    a = sum;
+    b = dif;
+}
+
+// stages 0..2 on freshly loaded values (< 2p); slot = row bits 0..2, so the twiddle exponents are compile-time:
+// stage u pairs (q, q | 1 << u) with w_{2^(u+1)}^(q mod 2^u).  5 products for 12 butterflies.
+__device__ __forceinline__ void stages_first(fe (&v)[8], const TwDev& tw) {
+#pragma unroll
+    for (int q = 0; q < 8; q += 2) bfly(v[q], v[q + 1], el2<Fr>(v[q + 1]));
+    el2<Fr> w4 = load_raw<Fr>(tw.bf + ((size_t)1 << (tw.bf_shift - 1)) * 8);
+#pragma unroll
+    for (int h = 0; h < 8; h += 4) {
+        bfly(v[h], v[h + 2], canonical(tile_el(v[h + 2])));
+        bfly(v[h + 1], v[h + 3], tile_el(v[h + 3]) * w4);
+    }
+    bfly(v[0], v[4], canonical(tile_el(v[4])));
+    bfly(v[1], v[5], tile_el(v[5]) * load_raw<Fr>(tw.bf + ((size_t)1 << (tw.bf_shift - 2)) * 8));
+    bfly(v[2], v[6], tile_el(v[6]) * w4);
+    bfly(v[3], v[7], tile_el(v[7]) * load_raw<Fr>(tw.bf + ((size_t)3 << (tw.bf_shift - 2)) * 8));
+}
+
+// stages [e - G_, e) with the slot at row bits [e-3, e); rho0 = this thread's row index with a zero slot field.
+// The twiddle of a pair depends on the row bits below the partner bit only: 2^(3-G_+u) distinct ones in stage u.
+template <int G_, int U_>
+__device__ __forceinline__ void stage_general(fe (&v)[8], uint32_t rho0, uint32_t e, const TwDev& tw) {
+    constexpr int pb = 3 - G_ + U_;   // partner bit inside the slot
+    const uint32_t st = e - G_ + U_;
+    const uint32_t msk = (1u << st) - 1;
+#pragma unroll
+    for (int lb = 0; lb < (1 << pb); ++lb) {
+        uint32_t j = (rho0 | ((uint32_t)lb << (e - 3))) & msk;
+        el2<Fr> w = load_raw<Fr>(tw.bf + ((size_t)j << (tw.bf_shift - st)) * 8);
+#pragma unroll
+        for (int hb = 0; hb < (4 >> pb); ++hb) {
+            const int q0 = lb | (hb << (pb + 1)), q1 = q0 | (1 << pb);
+            bfly(v[q0], v[q1], tile_el(v[q1]) * w);
+        }
+    }
+}
+template <int G_>
+__device__ __forceinline__ void stages_general(fe (&v)[8], uint32_t rho0, uint32_t e, const TwDev& tw) {
+    stage_general<G_, 0>(v, rho0, e, tw);
+    if constexpr (G_ > 1) stage_general<G_, 1>(v, rho0, e, tw);
+    if constexpr (G_ > 2) stage_general<G_, 2>(v, rho0, e, tw);
+}
+
+// groups 1.. of a tile whose group 0 is already done in v (slot at logical bit logT, held by the thread that place() would
+// number t_first); leaves v in the last group's ownership (slot at logical bit logT + s - 3) and returns that thread's
+// logical base index.
+__device__ __forceinline__ uint32_t tile_rest(fe (&v)[8], fe* tile, uint32_t s, uint32_t logT, const Swz& z, const TwDev& tw,
+                                              uint32_t t_first) {
+    const uint32_t t = threadIdx.x;
+    uint32_t p_prev = logT;
+    const uint32_t G = (s + 2) / 3;
+#pragma clang loop unroll(disable)
+    for (uint32_t i = 1; i < G; ++i) {
+        uint32_t e = min(3 * i + 3, s), g = e - 3 * i, p = logT + e - 3;
+        uint32_t Lw = place(i == 1 ? t_first : t, p_prev);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) tile[swz(Lw | ((uint32_t)q << p_prev), z)] = v[q];
+        __syncthreads();
+        uint32_t Lr = place(t, p);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = tile[swz(Lr | ((uint32_t)q << p), z)];
+        uint32_t rho0 = Lr >> logT;
+        if (g == 3) stages_general<3>(v, rho0, e, tw);
+        else if (g == 2) stages_general<2>(v, rho0, e, tw);
+        else stages_general<1>(v, rho0, e, tw);
+        p_prev = p;
+    }
+    return place(G == 1 ? t_first : t, p_prev);
+}
+
+__global__ void __launch_bounds__(256) k_ntt_strided_r8(const uint32_t* const* srcs, uint32_t* const* dsts, uint32_t npolys, uint32_t group,
+                                                         uint32_t m, uint32_t s, uint32_t lo_bits, uint32_t logT, uint32_t n_in, TwDev tw,
+                                                         NttScale sc, Swz z) {
+    fe* tile = reinterpret_cast<fe*>(ntt_lds);
+    const uint32_t T = 1u << logT, t = threadIdx.x;
+    uint32_t hi_bits = m - s - lo_bits;
+    uint32_t tiles_lo = 1u << (lo_bits - logT);
+    uint32_t lo_tile = blockIdx.x & (tiles_lo - 1), hi = blockIdx.x >> (lo_bits - logT);
+    uint32_t lo0 = lo_tile << logT;
+    uint32_t base = (hi << (s + lo_bits)) | lo0;
+    // ownership at the store: slot at logical bit p_last
+    const uint32_t p_last = logT + s - 3;
+    const uint32_t L_last = place(t, p_last);
+    fe twr[8];
+#pragma clang loop unroll(full)
+    for (int q = 0; q < 8; ++q) {
+        uint32_t L = L_last | ((uint32_t)q << p_last);
+        uint32_t tl = L & (T - 1), r = L >> logT;
+        twr[q] = twiddle_at(tw, ((lo0 | tl) * r) << hi_bits).v;
+    }
+    // ownership at the load: slot = row bits 0..2; row rho <-> digit j = bitrev(rho, s)
+    const uint32_t tl0 = t & (T - 1), rest0 = t >> logT;
+    const uint32_t jrest = bitrev(rest0, s - 3);
+    const uint32_t p0 = blockIdx.y * group, p1 = min(npolys, p0 + group);
+    for (uint32_t pi = p0; pi < p1; ++pi) {
+        const uint32_t* src = srcs[pi];
+        uint32_t* dst = dsts[pi];
+        fe v[8];
+#pragma clang loop unroll(full)
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t qr = ((q & 1) << 2) | (q & 2) | (q >> 2);   // bitrev3
+            uint32_t j = (qr << (s - 3)) | jrest;
+            v[q] = load_in(src, base | (j << lo_bits) | tl0, n_in, sc);
+        }
+        stages_first(v, tw);
+        tile_rest(v, tile, s, logT, z, tw, t);
+#pragma clang loop unroll(full)
+        for (int q = 0; q < 8; ++q) {
+            uint32_t L = L_last | ((uint32_t)q << p_last);
+            uint32_t tl = L & (T - 1), r = L >> logT;
+            store_raw<Fr>(dst + (size_t)(base | (r << lo_bits) | tl) * 8, tile_el(v[q]) * el2<Fr>(twr[q]));
+        }
+        __syncthreads();   // the tile is rewritten for the next polynomial
+    }
+}
+
+__global__ void __launch_bounds__(256, 2) k_ntt_final_r8(const uint32_t* const* srcs, uint32_t* const* dsts, uint32_t m, uint32_t s,
+                                                       uint32_t logT, uint32_t n_in, TwDev tw, NttScale sc, NttDigits dg, Swz z) {
+    fe* tile = reinterpret_cast<fe*>(ntt_lds);
+    const uint32_t* src = srcs[blockIdx.y];
+    uint32_t* dst = dsts[blockIdx.y];
+    const uint32_t T = 1u << logT, t = threadIdx.x;
+    uint32_t hi_bits = m - s;
+    uint32_t s1 = dg.np > 1 ? dg.sw[0] : 0;
+    uint32_t rest_bits = hi_bits - s1;
+    uint32_t rest = blockIdx.x & ((1u << rest_bits) - 1);
+    uint32_t k1_0 = (blockIdx.x >> rest_bits) << logT;
+    // load: lanes run along j (contiguous in memory); thread = (jl, tl), its 8 values j = jl | qq << (s-3) are the rows
+    // rho = bitrev(jl, s-3) * 8 + bitrev3(qq)
+    fe v[8];
+    const uint32_t jl = t & ((1u << (s - 3)) - 1), tl0 = t >> (s - 3);
+    const uint32_t row0 = ((k1_0 + tl0) << rest_bits) | rest;
+#pragma clang loop unroll(full)
+    for (int q = 0; q < 8; ++q) {
+        const uint32_t qr = ((q & 1) << 2) | (q & 2) | (q >> 2);
+        v[q] = load_in(src, (row0 << s) | (qr << (s - 3)) | jl, n_in, sc);
+    }
+    stages_first(v, tw);
+    // group 0's ownership in the common (tl, rest-of-row) thread numbering
+    const uint32_t L_last = tile_rest(v, tile, s, logT, z, tw, tl0 | (bitrev(jl, s - 3) << logT));
+    uint32_t kbase = 0, shift_out = s1, rb = rest_bits;
+    for (uint32_t q = 1; q + 1 < dg.np; ++q) {
+        uint32_t w = dg.sw[q];
+        rb -= w;
+        uint32_t d = (rest >> rb) & ((1u << w) - 1);
+        kbase |= d << shift_out;
+        shift_out += w;
+    }
+    const uint32_t p_last = logT + s - 3;
+#pragma clang loop unroll(full)
+    for (int q = 0; q < 8; ++q) {
+        uint32_t L = L_last | ((uint32_t)q << p_last);
+        uint32_t tl = L & (T - 1), r = L >> logT;
+        uint32_t k = (r << hi_bits) | kbase | (k1_0 + tl);
+        void* out = dst + (size_t)k * 8;
+        if (sc.use_post) store_raw<Fr>(out, tile_el(v[q]) * el2<Fr>(sc.post[k % 3]));
+        else store_raw<Fr>(out, tile_el(v[q]));
+    }
+}
+
 __global__ void k_mul_periodic(uint32_t* a, size_t n, const uint32_t* tev, uint32_t period_mask) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -265,8 +452,8 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
     hipError_t attr_err = hipSuccess;
     std::call_once(lds_attr_once, [&] {
         attr_err = hipFuncSetAttribute((const void*)k_ntt_strided, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NTT_TILE * sizeof(fe)));
-        if (attr_err == hipSuccess)
-            attr_err = hipFuncSetAttribute((const void*)k_ntt_final, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NTT_TILE * sizeof(fe)));
+        for (const void* f : {(const void*)k_ntt_final, (const void*)k_ntt_strided_r8, (const void*)k_ntt_final_r8})
+            if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NTT_TILE * sizeof(fe)));
     });
     ZK_HIP(attr_err);
     // pass plan
@@ -279,6 +466,17 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
     if (np > 6) { set_error("ntt: too many passes"); return ZKHIP_EINVAL; }
     uint32_t sw[6] = {0, 0, 0, 0, 0, 0};
     for (uint32_t q = 0; q < np; ++q) sw[q] = m / np + (q < m % np ? 1 : 0);
+    // register-tiled kernels: every pass on full 2048-element tiles (true whenever np > 1 with the default plan)
+    bool r8 = np > 1 && twh->bf_bits >= 2;
+    {
+        uint32_t lb = m;
+        for (uint32_t q = 0; q < np && r8; ++q) {
+            lb -= sw[q];
+            uint32_t avail = q + 1 < np ? lb : sw[0];
+            if (sw[q] < 3 || sw[q] > ilog2(NTT_TILE) || avail < ilog2(NTT_TILE) - sw[q]) r8 = false;
+        }
+    }
+    if (const char* e = getenv("ZKHIP_NTT_R8")) r8 = r8 && atoi(e) != 0;
     std::vector<void*> tmp_host(npolys);
     if (np > 1) {
         void* d_tmpbuf;
@@ -306,6 +504,12 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
         while (group < npolys && (size_t)blocks * ((npolys + 2 * group - 1) / (2 * group)) >= 512) group *= 2;
         if (const char* e = getenv("ZKHIP_NTT_GROUP")) { int v = atoi(e); if (v >= 1 && v <= 64) group = (uint32_t)v; }
         ProfScope ps(ctx, "ntt_strided");
+        if (r8) {
+            Swz z{logT + 3, logT < 5 ? (1u << (5 - logT)) - 1 : 0u, logT};
+            hipLaunchKernelGGL(k_ntt_strided_r8, dim3(blocks, (unsigned)((npolys + group - 1) / group)), dim3(256), NTT_TILE * sizeof(fe),
+                               st, (const uint32_t* const*)cur_src, (uint32_t* const*)out, (uint32_t)npolys, group, m, s, lo_bits, logT,
+                               q == 0 ? n_in : (uint32_t)n, tw, scq, z);
+        } else
         hipLaunchKernelGGL(k_ntt_strided, dim3(blocks, (unsigned)((npolys + group - 1) / group)), dim3(256), NTT_TILE * sizeof(fe), st,
                            (const uint32_t* const*)cur_src, (uint32_t* const*)out, (uint32_t)npolys, group, m, s, lo_bits, logT,
                            q == 0 ? n_in : (uint32_t)n, tw, scq);
@@ -322,6 +526,11 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
         for (int i = 0; i < 6; ++i) dg.sw[i] = sw[i];
         unsigned blocks = (unsigned)(n >> (s + logT));
         ProfScope ps(ctx, "ntt_final");
+        if (r8) {
+            Swz z{6, 31, 0};
+            hipLaunchKernelGGL(k_ntt_final_r8, dim3(blocks, (unsigned)npolys), dim3(256), NTT_TILE * sizeof(fe), st,
+                               (const uint32_t* const*)cur_src, (uint32_t* const*)d_dst, m, s, logT, (uint32_t)n, tw, scq, dg, z);
+        } else
         hipLaunchKernelGGL(k_ntt_final, dim3(blocks, (unsigned)npolys), dim3(256), NTT_TILE * sizeof(fe), st, (const uint32_t* const*)cur_src,
                            (uint32_t* const*)d_dst, m, s, logT, np == 1 ? n_in : (uint32_t)n, tw, scq, dg);
     }

@@ -30,13 +30,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ks", default="17,19,22")
     ap.add_argument("--ncols", default="1,4")
+    ap.add_argument("--skip-msm", action="store_true")
     args = ap.parse_args()
     ctx = ffi.Context(0)
     for k in [int(x) for x in args.ks.split(",")]:
         n = 1 << k
         params = ffi.ParamsKZG.setup(ctx, k, pv.fr_from_int_host(0x1234567))
         c, W = params.window()
-        for ncols in [int(x) for x in args.ncols.split(",")]:
+        for ncols in ([] if args.skip_msm else [int(x) for x in args.ncols.split(",")]):
             cols = [ctx.synth_fill(n, 100 + j) for j in range(ncols)]
             ms = timeit(ctx, lambda: ctx.to_host(params.commit_batch_device(cols)))
             ctx.profile_enable(True)
