@@ -137,12 +137,10 @@ __device__ __forceinline__ void tile_ntt(fe* tile, uint32_t s, uint32_t logT, co
 __device__ __forceinline__ fe load_in(const uint32_t* src, uint32_t i, uint32_t n_in, const NttScale& sc) {
     if (i >= n_in) return fe_zero();
     el1<Fr> v = load_raw<Fr>(src + (size_t)i * 8);
-    if (sc.use_pre) {   // one product with a selected factor (pre[0] is the field's one): no divergence over i mod 3
+    if (sc.use_pre) {
         uint32_t r = i % 3;
-        fe w;
-#pragma unroll
-        for (int q = 0; q < 9; ++q) w.l[q] = r == 0 ? sc.pre[0].l[q] : (r == 1 ? sc.pre[1].l[q] : sc.pre[2].l[q]);
-        return (v * el2<Fr>(w)).v;
+        if (r == 1) return (v * el2<Fr>(sc.pre[1])).v;
+        if (r == 2) return (v * el2<Fr>(sc.pre[2])).v;
     }
     return v.v;
 }
@@ -329,49 +327,46 @@ __device__ __forceinline__ uint32_t tile_rest(fe (&v)[8], fe* tile, uint32_t s, 
     return place(G == 1 ? t_first : t, p_prev);
 }
 
-__global__ void __launch_bounds__(256) k_ntt_strided_r8(const uint32_t* const* srcs, uint32_t* const* dsts, uint32_t npolys, uint32_t group,
-                                                         uint32_t m, uint32_t s, uint32_t lo_bits, uint32_t logT, uint32_t n_in, TwDev tw,
-                                                         NttScale sc, Swz z) {
+// table[pos] = w^((lo * r) << hi_bits) for pos = (r << lo_bits) | lo: the Cooley-Tukey twiddle of a non-final pass's output at
+// tile-relative position pos (independent of the outer digits).  Built once per (omega, log_n, pass) and kept: with 288 GB of
+// HBM a 32-byte-per-element table (512 MiB at 2^24) is cheaper than the 72 registers per thread that caching the twiddles of a
+// workgroup cost (one wave per SIMD instead of two) or the product per element that rebuilding them costs.
+__global__ void k_pass_twiddles(uint32_t* table, uint32_t count, uint32_t lo_bits, uint32_t hi_bits, TwDev tw) {
+    uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= count) return;
+    uint32_t lo = pos & ((1u << lo_bits) - 1), r = pos >> lo_bits;
+    store_raw<Fr>(table + (size_t)pos * 8, twiddle_at(tw, (lo * r) << hi_bits));
+}
+
+__global__ void __launch_bounds__(256, 2) k_ntt_strided_r8(const uint32_t* const* srcs, uint32_t* const* dsts, uint32_t m, uint32_t s,
+                                                            uint32_t lo_bits, uint32_t logT, uint32_t n_in, TwDev tw, NttScale sc, Swz z,
+                                                            const uint32_t* __restrict__ ptab) {
     fe* tile = reinterpret_cast<fe*>(ntt_lds);
     const uint32_t T = 1u << logT, t = threadIdx.x;
-    uint32_t hi_bits = m - s - lo_bits;
     uint32_t tiles_lo = 1u << (lo_bits - logT);
     uint32_t lo_tile = blockIdx.x & (tiles_lo - 1), hi = blockIdx.x >> (lo_bits - logT);
     uint32_t lo0 = lo_tile << logT;
     uint32_t base = (hi << (s + lo_bits)) | lo0;
-    // ownership at the store: slot at logical bit p_last
+    const uint32_t* src = srcs[blockIdx.y];
+    uint32_t* dst = dsts[blockIdx.y];
+    // ownership at the load: slot = row bits 0..2; row rho <-> digit j = bitrev(rho, s)
+    const uint32_t tl0 = t & (T - 1), jrest = bitrev(t >> logT, s - 3);
+    fe v[8];
+#pragma clang loop unroll(full)
+    for (int q = 0; q < 8; ++q) {
+        const uint32_t qr = ((q & 1) << 2) | (q & 2) | (q >> 2);   // bitrev3
+        uint32_t j = (qr << (s - 3)) | jrest;
+        v[q] = load_in(src, base | (j << lo_bits) | tl0, n_in, sc);
+    }
+    stages_first(v, tw);
+    const uint32_t L_last = tile_rest(v, tile, s, logT, z, tw, t);
     const uint32_t p_last = logT + s - 3;
-    const uint32_t L_last = place(t, p_last);
-    fe twr[8];
 #pragma clang loop unroll(full)
     for (int q = 0; q < 8; ++q) {
         uint32_t L = L_last | ((uint32_t)q << p_last);
         uint32_t tl = L & (T - 1), r = L >> logT;
-        twr[q] = twiddle_at(tw, ((lo0 | tl) * r) << hi_bits).v;
-    }
-    // ownership at the load: slot = row bits 0..2; row rho <-> digit j = bitrev(rho, s)
-    const uint32_t tl0 = t & (T - 1), rest0 = t >> logT;
-    const uint32_t jrest = bitrev(rest0, s - 3);
-    const uint32_t p0 = blockIdx.y * group, p1 = min(npolys, p0 + group);
-    for (uint32_t pi = p0; pi < p1; ++pi) {
-        const uint32_t* src = srcs[pi];
-        uint32_t* dst = dsts[pi];
-        fe v[8];
-#pragma clang loop unroll(full)
-        for (int q = 0; q < 8; ++q) {
-            const uint32_t qr = ((q & 1) << 2) | (q & 2) | (q >> 2);   // bitrev3
-            uint32_t j = (qr << (s - 3)) | jrest;
-            v[q] = load_in(src, base | (j << lo_bits) | tl0, n_in, sc);
-        }
-        stages_first(v, tw);
-        tile_rest(v, tile, s, logT, z, tw, t);
-#pragma clang loop unroll(full)
-        for (int q = 0; q < 8; ++q) {
-            uint32_t L = L_last | ((uint32_t)q << p_last);
-            uint32_t tl = L & (T - 1), r = L >> logT;
-            store_raw<Fr>(dst + (size_t)(base | (r << lo_bits) | tl) * 8, tile_el(v[q]) * el2<Fr>(twr[q]));
-        }
-        __syncthreads();   // the tile is rewritten for the next polynomial
+        uint32_t rel = (r << lo_bits) | lo0 | tl;
+        store_raw<Fr>(dst + ((size_t)(hi << (s + lo_bits)) | rel) * 8, tile_el(v[q]) * load_raw<Fr>(ptab + (size_t)rel * 8));
     }
 }
 
@@ -427,6 +422,26 @@ __global__ void k_mul_periodic(uint32_t* a, size_t n, const uint32_t* tev, uint3
 
 // ------------------------------------------------------------------ host driver
 static uint32_t ilog2(uint32_t v) { uint32_t l = 0; while ((1u << (l + 1)) <= v) ++l; return l; }
+
+// the per-pass output twiddle table of a non-final pass (see k_pass_twiddles), cached in the context for its lifetime
+static int pass_twiddles(zkhip_ctx* ctx, const zkhip_ctx::Twiddle* twh, const TwDev& tw, uint32_t q, uint32_t s, uint32_t lo_bits,
+                         const void** out) {
+    char name[160];
+    snprintf(name, sizeof name, "ntt_pass_tw:%016llx%016llx%016llx%016llx:%u:%u:%u:%u", (unsigned long long)twh->omega[3],
+             (unsigned long long)twh->omega[2], (unsigned long long)twh->omega[1], (unsigned long long)twh->omega[0], twh->log_n, q, s, lo_bits);
+    auto it = ctx->persistent.find(name);
+    if (it != ctx->persistent.end()) { *out = it->second; return ZKHIP_OK; }
+    uint32_t count = 1u << (s + lo_bits), hi_bits = twh->log_n - s - lo_bits;
+    void* d;
+    hipError_t e = hipMalloc(&d, (size_t)count * 32);
+    if (e != hipSuccess) { (void)hipGetLastError(); set_error("hipMalloc pass twiddles: %s", hipGetErrorString(e)); return ZKHIP_ENOMEM; }
+    hipLaunchKernelGGL(k_pass_twiddles, dim3(div_up((size_t)count, 256)), dim3(256), 0, ctx->stream, (uint32_t*)d, count, lo_bits, hi_bits, tw);
+    ZK_LAUNCH_CHECK();
+    ZK_HIP(hipStreamSynchronize(ctx->stream));   // one-time: other streams of the context read the table too
+    ctx->persistent[name] = d;
+    *out = d;
+    return ZKHIP_OK;
+}
 
 // srcs/dsts: host arrays of device pointers (src[i] may equal dst[i]); src has n_in valid elements.
 static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, size_t npolys, const uint64_t omega[4],
@@ -506,9 +521,11 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
         ProfScope ps(ctx, "ntt_strided");
         if (r8) {
             Swz z{logT + 3, logT < 5 ? (1u << (5 - logT)) - 1 : 0u, logT};
-            hipLaunchKernelGGL(k_ntt_strided_r8, dim3(blocks, (unsigned)((npolys + group - 1) / group)), dim3(256), NTT_TILE * sizeof(fe),
-                               st, (const uint32_t* const*)cur_src, (uint32_t* const*)out, (uint32_t)npolys, group, m, s, lo_bits, logT,
-                               q == 0 ? n_in : (uint32_t)n, tw, scq, z);
+            const void* ptab;
+            ZK_TRY(pass_twiddles(ctx, twh, tw, q, s, lo_bits, &ptab));
+            hipLaunchKernelGGL(k_ntt_strided_r8, dim3(blocks, (unsigned)npolys), dim3(256), NTT_TILE * sizeof(fe), st,
+                               (const uint32_t* const*)cur_src, (uint32_t* const*)out, m, s, lo_bits, logT, q == 0 ? n_in : (uint32_t)n, tw,
+                               scq, z, (const uint32_t*)ptab);
         } else
         hipLaunchKernelGGL(k_ntt_strided, dim3(blocks, (unsigned)((npolys + group - 1) / group)), dim3(256), NTT_TILE * sizeof(fe), st,
                            (const uint32_t* const*)cur_src, (uint32_t* const*)out, (uint32_t)npolys, group, m, s, lo_bits, logT,
