@@ -46,6 +46,20 @@ def test_fft_vs_oracle(zk, oracle, log_n):
     assert (ctx.best_fft(a, w, log_n) == zo.best_fft(a, w, log_n, 8)).all()
 
 
+@pytest.mark.parametrize("log_n,smax,r8", [(13, "9", "0"), (16, "9", "0"), (18, "6", "1"), (12, "4", "1"), (15, "5", "1"),
+                                            (14, "7", "1"), (20, "11", "1"), (21, "11", "1"), (19, "10", "1")])
+def test_fft_tile_plans(zk, oracle, monkeypatch, log_n, smax, r8):
+    """every shape of the tile transform: the stage-per-barrier kernels (ZKHIP_NTT_R8=0) and the register-tiled ones with stage
+    groups 3+1, 3+2, 3+3, 3+3+1 ... 3+3+3+2 (ZKHIP_NTT_SMAX changes the digits of the pass plan; both are read per call)"""
+    ffi, ctx = zk
+    zo = oracle
+    monkeypatch.setenv("ZKHIP_NTT_SMAX", smax)
+    monkeypatch.setenv("ZKHIP_NTT_R8", r8)
+    a = zo.synth_raw253(3200 + log_n, 1 << log_n)
+    w = zo.root_of_unity(log_n)
+    assert (ctx.best_fft(a, w, log_n) == zo.best_fft(a, w, log_n, 8)).all()
+
+
 def test_fft_batch_device(zk, oracle):
     ffi, ctx = zk
     zo = oracle
