@@ -88,8 +88,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
+        # test hooks (a 1-GPU box can still run the N > 1 control flow): ZKHIP_BENCH_ONE_DEVICE=1 puts every rank on device 0,
+        # ZKHIP_BENCH_DIST_BACKEND=gloo replaces RCCL, which refuses two ranks on one device
+        if os.environ.get("ZKHIP_BENCH_ONE_DEVICE") == "1":
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        be = os.environ.get("ZKHIP_BENCH_DIST_BACKEND", "nccl")
+        if be == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(be)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
