@@ -381,6 +381,81 @@ __global__ void __launch_bounds__(256) k_sort_lo_staged(const uint32_t* part_off
     }
 }
 
+// The same pass for the default 4096-pair tile with ONE LDS atomic per pair: the counting atomic's return value is the pair's
+// rank inside its bin, kept in registers (16 pairs per thread) until the bins' starts are known.
+__global__ void __launch_bounds__(256) k_sort_lo_staged16(const uint32_t* part_off_all, const uint32_t* tile_start_all, SortGeom g,
+                                                          const uint32_t* tmp_entry_all, const uint16_t* tmp_key_all, size_t items,
+                                                          const uint32_t* off_all, uint32_t* cursor_all, uint32_t* entries_all) {
+    __shared__ uint32_t w_tot[4];
+    const uint32_t tid = threadIdx.x, col = blockIdx.y, blk = blockIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t* po = part_off_all + (size_t)col * 132;
+    const uint32_t* ts = tile_start_all + (size_t)col * 132;
+    if (blk >= ts[g.P]) return;
+    uint32_t lo_p = 0, hi_p = g.P;   // largest p with ts[p] <= blk
+    while (hi_p - lo_p > 1) {
+        uint32_t mid = (lo_p + hi_p) >> 1;
+        if (ts[mid] <= blk) lo_p = mid; else hi_p = mid;
+    }
+    const uint32_t p = lo_p;
+    const uint32_t beg = po[p] + (blk - ts[p]) * SORT_TILE, end = min(beg + SORT_TILE, po[p + 1]), cnt = end - beg;
+    const uint32_t nbins = 1u << g.LB;
+    uint32_t* hist = sort_lds;                 // [nbins] counts
+    uint32_t* base = hist + nbins;             // [nbins] global position of the bin's run
+    uint32_t* lst = base + nbins;              // [nbins] start of the bin inside the staged tile
+    uint32_t* st_e = lst + nbins;              // [tile] staged entries
+    uint16_t* st_k = reinterpret_cast<uint16_t*>(st_e + SORT_TILE);   // [tile] their bins
+    for (uint32_t j = tid; j < nbins; j += 256) hist[j] = 0;
+    __syncthreads();
+    const uint16_t* tmp_key = tmp_key_all + (size_t)col * items;
+    uint32_t keys[16], ranks[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        uint32_t j = beg + tid + q * 256;
+        keys[q] = j < end ? tmp_key[j] : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) ranks[q] = keys[q] != 0xFFFFFFFFu ? atomicAdd(&hist[keys[q]], 1u) : 0u;
+    __syncthreads();
+    const uint32_t bucket0 = p << g.LB;
+    const uint32_t* off = off_all + (size_t)col * (g.B + 4);
+    uint32_t* cursor = cursor_all + (size_t)col * g.B;
+    const uint32_t per = (nbins + 255) / 256;
+    uint32_t my = 0;
+    for (uint32_t q = 0; q < per; ++q) { uint32_t j = tid * per + q; if (j < nbins) my += hist[j]; }
+    uint32_t inc = my;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { uint32_t u = __shfl_up(inc, d); if ((int)lane >= d) inc += u; }
+    if (lane == 63) w_tot[wave] = inc;
+    __syncthreads();
+    uint32_t run = inc - my;
+    for (uint32_t w = 0; w < wave; ++w) run += w_tot[w];
+    for (uint32_t q = 0; q < per; ++q) {
+        uint32_t j = tid * per + q;
+        if (j < nbins) {
+            uint32_t h = hist[j];
+            base[j] = h ? off[bucket0 + j] + atomicAdd(&cursor[bucket0 + j], h) : 0u;
+            lst[j] = run;
+            run += h;
+        }
+    }
+    __syncthreads();
+    const uint32_t* tmp_entry = tmp_entry_all + (size_t)col * items;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        if (keys[q] != 0xFFFFFFFFu) {
+            uint32_t slot = lst[keys[q]] + ranks[q];
+            st_e[slot] = tmp_entry[beg + tid + q * 256];
+            st_k[slot] = (uint16_t)keys[q];
+        }
+    }
+    __syncthreads();
+    uint32_t* entries = entries_all + (size_t)col * items;
+    for (uint32_t i = tid; i < cnt; i += 256) {
+        uint32_t key = st_k[i];
+        entries[base[key] + (i - lst[key])] = st_e[i];
+    }
+}
+
 // ceil(v / seg) without a hardware divide: seg_magic = ceil(2^32 / seg); exact for v * seg < 2^32 (v < 2^26, seg <= 64).
 __device__ __forceinline__ uint32_t ceil_div_magic(uint32_t v, uint32_t seg, uint32_t seg_magic) {
     return seg == 1 ? v : __umulhi(v + seg - 1, seg_magic);
@@ -933,6 +1008,11 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
         hipError_t attr_err = hipSuccess;
         std::call_once(attr_once, [&] { attr_err = hipFuncSetAttribute((const void*)k_sort_lo_staged, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); });
         ZK_HIP(attr_err);
+        static const bool one_atomic = !(getenv("ZKHIP_SORT_ONE_ATOMIC") && atoi(getenv("ZKHIP_SORT_ONE_ATOMIC")) == 0);
+        if (g.tile == SORT_TILE && one_atomic)
+            hipLaunchKernelGGL(k_sort_lo_staged16, gt, dim3(256), lds, st, (const uint32_t*)d_part_off, (const uint32_t*)d_tile_start, g,
+                               (const uint32_t*)d_tmp_entry, (const uint16_t*)d_tmp_key, items, (const uint32_t*)d_off, d_cursor, (uint32_t*)d_entries);
+        else
         hipLaunchKernelGGL(k_sort_lo_staged, gt, dim3(256), lds, st, (const uint32_t*)d_part_off, (const uint32_t*)d_tile_start, g,
                            (const uint32_t*)d_tmp_entry, (const uint16_t*)d_tmp_key, items, (const uint32_t*)d_off, d_cursor, (uint32_t*)d_entries);
     } }
