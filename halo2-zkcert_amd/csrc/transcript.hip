@@ -116,8 +116,8 @@ void t_squeeze(void* user, uint64_t out[4]) {
     uint32_t lo[8], hi[8];
     memcpy(lo, d, 32);
     memcpy(hi, d + 32, 32);
-    const HF two256 = hf(canonical(from_canonical_words<Fr>(hi)));               // hi (< 2^256, reduced by the product with R'^2)
-    const HF low = hf(canonical(from_canonical_words<Fr>(lo)));
+    const HF two256 = hf_from_canonical_words(hi);               // hi (< 2^256, reduced by the product with R'^2)
+    const HF low = hf_from_canonical_words(lo);
     static const HF r256 = [] {                                                  // 2^256 mod r
         HF v = hone();
         for (int i = 0; i < 256; ++i) v = hadd(v, v);
@@ -217,7 +217,7 @@ void e_squeeze(void* user, uint64_t out[4]) {
     t->buf.assign(d, d + 32);
     uint32_t w[8];   // the digest as a big-endian integer -> little-endian words -> mod r (from_canonical_words reduces)
     for (int i = 0; i < 8; ++i) w[i] = ((uint32_t)d[31 - 4 * i]) | ((uint32_t)d[30 - 4 * i] << 8) | ((uint32_t)d[29 - 4 * i] << 16) | ((uint32_t)d[28 - 4 * i] << 24);
-    fe32 abi = hf_abi(hf(canonical(from_canonical_words<Fr>(w))));
+    fe32 abi = hf_abi(hf_from_canonical_words(w));
     memcpy(out, abi.w, 32);
     t->challenges.insert(t->challenges.end(), out, out + 4);
 }

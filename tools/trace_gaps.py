@@ -25,17 +25,19 @@ if len(starts) >= 2 * per_pass:
 t0, t1 = rows[0][0], max(r[1] for r in rows)
 busy, cur_s, cur_e = 0, rows[0][0], rows[0][1]
 gaps = []
+prev = rows[0][2]
 for s, e, name, st in rows[1:]:
     if s > cur_e:
         busy += cur_e - cur_s
-        gaps.append((s - cur_e, cur_e - t0, name))
+        gaps.append((s - cur_e, cur_e - t0, name, prev))
         cur_s, cur_e = s, e
     else:
         cur_e = max(cur_e, e)
+    prev = name
 busy += cur_e - cur_s
 print(f"span {(t1 - t0) / 1e6:.3f} ms, busy {busy / 1e6:.3f} ms, idle {(t1 - t0 - busy) / 1e6:.3f} ms in {len(gaps)} gaps, {len(rows)} kernels")
-for g, at, name in sorted(gaps, reverse=True)[:25]:
-    print(f"  gap {g / 1e3:8.1f} us at +{at / 1e6:7.3f} ms before {name[:60]}")
+for g, at, name, prev in sorted(gaps, reverse=True)[:25]:
+    print(f"  gap {g / 1e3:8.1f} us at +{at / 1e6:7.3f} ms after {prev[:28]:28s} before {name[:40]}")
 tot = {}
 for s, e, name, st in rows:
     tot[name] = tot.get(name, 0) + e - s
