@@ -47,6 +47,7 @@ struct zkhip_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    uint32_t max_seq = 0;           // tag of the last MSM's polled read-back (msm.hip)
     hipEvent_t ev_read = nullptr;   // marks a small device->host read in the middle of a launch sequence (see event_wait)
     hipEvent_t accum_mark = nullptr;     // if set, the next MSM records it right after its bucket-accumulation launch (and clears it)
     hipStream_t side_stream = nullptr;   // zkhip_create_proof's second stream (coset NTTs beside the MSM phases), created on first use

@@ -2,6 +2,7 @@
 #include <stdarg.h>
 
 #include "common.hpp"
+#include "hostfield.hpp"
 
 namespace zk {
 static thread_local char g_err[512] = "";
@@ -203,25 +204,40 @@ void zkhip_g1_to_affine(const uint64_t xyz[12], uint64_t out_xy[8]) {
 }
 // n points with ONE field inversion (Montgomery's trick): the per-batch host step between the MSM and the transcript
 void zkhip_g1_batch_to_affine(const uint64_t* xyz, size_t n, uint64_t* out_xy) {
-    std::vector<g1j> p(n);
-    std::vector<el2<Fq>> pre(n);
-    el2<Fq> acc = one<Fq>();
+    // on the critical path of every Fiat-Shamir round trip: native 4 x 64-bit Montgomery (hostfield.hpp), the ABI form as it is
+    using namespace hostmont;
+    const uint64_t* P = hostfq::P;
+    const uint64_t INV = hostfq::INV;
+    struct Q { uint64_t w[4]; };
+    std::vector<Q> pre(n);
+    std::vector<uint64_t> in(xyz, xyz + 12 * n);   // canonical copies (the library's own results already are)
+    for (size_t i = 0; i < 3 * n; ++i) while (geq(&in[4 * i], P)) sub_mod(&in[4 * i], P);
+    xyz = in.data();
+    Q acc;
+    memcpy(acc.w, hostfq::ONE, 32);
+    auto is_id = [&](size_t i) { const uint64_t* z = xyz + 12 * i + 8; return (z[0] | z[1] | z[2] | z[3]) == 0; };
     for (size_t i = 0; i < n; ++i) {
-        p[i] = g1j_load_abi(xyz + 12 * i);
         pre[i] = acc;
-        if (!g1j_is_id(p[i])) acc = acc * p[i].z;
+        if (!is_id(i)) mul(acc.w, acc.w, xyz + 12 * i + 8, P, INV);
     }
-    el2<Fq> iv = inv_host<Fq>(acc);
+    Q iv;
+    {
+        fe32 m;
+        for (int i = 0; i < 4; ++i) { m.w[2 * i] = (uint32_t)acc.w[i]; m.w[2 * i + 1] = (uint32_t)(acc.w[i] >> 32); }
+        fe32 o = to_abi(inv_host<Fq>(from_abi<Fq>(m)));
+        for (int i = 0; i < 4; ++i) iv.w[i] = o.w[2 * i] | ((uint64_t)o.w[2 * i + 1] << 32);
+    }
     for (size_t i = n; i-- > 0;) {
-        g1a a = g1a_identity();
-        if (!g1j_is_id(p[i])) {
-            el2<Fq> zi = iv * pre[i];
-            iv = iv * p[i].z;
-            auto zi2 = sqr(zi);
-            a.x = p[i].x * zi2;
-            a.y = p[i].y * (zi2 * zi);
-        }
-        g1a_store_abi(out_xy + 8 * i, a);
+        uint64_t* o = out_xy + 8 * i;
+        if (is_id(i)) { memset(o, 0, 64); continue; }
+        const uint64_t* pt = xyz + 12 * i;
+        Q zi, zi2, zi3;
+        mul(zi.w, iv.w, pre[i].w, P, INV);
+        mul(iv.w, iv.w, pt + 8, P, INV);
+        mul(zi2.w, zi.w, zi.w, P, INV);
+        mul(zi3.w, zi2.w, zi.w, P, INV);
+        mul(o, pt, zi2.w, P, INV);
+        mul(o + 4, pt + 4, zi3.w, P, INV);
     }
 }
 int zkhip_commitments_read(zkhip_ctx* c, const void* d_xyz, size_t n, uint64_t* out_xy, uint8_t* out_bytes) {

@@ -11,53 +11,59 @@
 namespace zk {
 struct HF { uint64_t w[4]; };
 
-namespace hostfr {
-constexpr uint64_t P[4] = {0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
-constexpr uint64_t INV = 0xc2e1f593efffffffull;   // -p^-1 mod 2^64
-constexpr uint64_t ONE[4] = {0xac96341c4ffffffbull, 0x36fc76959f60cd29ull, 0x666ea36f7879462eull, 0x0e0a77c19a07df2full};   // 2^256 mod p
+// generic 4 x 64-bit Montgomery core (modulus P < 2^254, INV = -P^-1 mod 2^64); values canonical
+namespace hostmont {
 typedef unsigned __int128 u128;
-inline bool geq_p(const uint64_t* a) {
+inline bool geq(const uint64_t* a, const uint64_t* P) {
     for (int i = 3; i >= 0; --i) if (a[i] != P[i]) return a[i] > P[i];
     return true;
 }
-inline void sub_p(uint64_t* a) {
+inline void sub_mod(uint64_t* a, const uint64_t* P) {
     u128 br = 0;
     for (int i = 0; i < 4; ++i) { u128 d = (u128)a[i] - P[i] - (uint64_t)br; a[i] = (uint64_t)d; br = (d >> 64) & 1; }
 }
-}  // namespace hostfr
-
-inline HF hmul(const HF& a, const HF& b) {   // CIOS: a * b / 2^256 mod p
-    using namespace hostfr;
+inline void mul(uint64_t* r, const uint64_t* a, const uint64_t* b, const uint64_t* P, uint64_t INV) {   // CIOS: a * b / 2^256 mod P
     uint64_t t[6] = {0, 0, 0, 0, 0, 0};
     for (int i = 0; i < 4; ++i) {
         u128 c = 0;
-        for (int j = 0; j < 4; ++j) { c += (u128)a.w[j] * b.w[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
+        for (int j = 0; j < 4; ++j) { c += (u128)a[j] * b[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
         c += t[4]; t[4] = (uint64_t)c; t[5] = (uint64_t)(c >> 64);
         const uint64_t m = t[0] * INV;
         c = ((u128)m * P[0] + t[0]) >> 64;
         for (int j = 1; j < 4; ++j) { c += (u128)m * P[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
         c += t[4]; t[3] = (uint64_t)c; t[4] = t[5] + (uint64_t)(c >> 64);
     }
-    HF r{{t[0], t[1], t[2], t[3]}};
-    if (t[4] || geq_p(r.w)) sub_p(r.w);
-    return r;
+    for (int i = 0; i < 4; ++i) r[i] = t[i];
+    if (t[4] || geq(r, P)) sub_mod(r, P);
 }
-inline HF hadd(const HF& a, const HF& b) {
-    using namespace hostfr;
-    HF r;
+inline void add(uint64_t* r, const uint64_t* a, const uint64_t* b, const uint64_t* P) {
     u128 c = 0;
-    for (int i = 0; i < 4; ++i) { c += (u128)a.w[i] + b.w[i]; r.w[i] = (uint64_t)c; c >>= 64; }
-    if (c || geq_p(r.w)) sub_p(r.w);   // p < 2^254: no carry out in fact
-    return r;
+    for (int i = 0; i < 4; ++i) { c += (u128)a[i] + b[i]; r[i] = (uint64_t)c; c >>= 64; }
+    if (c || geq(r, P)) sub_mod(r, P);   // P < 2^254: no carry out in fact
 }
-inline HF hsub(const HF& a, const HF& b) {
-    using namespace hostfr;
-    HF r;
+inline void sub(uint64_t* r, const uint64_t* a, const uint64_t* b, const uint64_t* P) {
     u128 br = 0;
-    for (int i = 0; i < 4; ++i) { u128 d = (u128)a.w[i] - b.w[i] - (uint64_t)br; r.w[i] = (uint64_t)d; br = (d >> 64) & 1; }
-    if (br) { u128 c = 0; for (int i = 0; i < 4; ++i) { c += (u128)r.w[i] + P[i]; r.w[i] = (uint64_t)c; c >>= 64; } }
-    return r;
+    for (int i = 0; i < 4; ++i) { u128 d = (u128)a[i] - b[i] - (uint64_t)br; r[i] = (uint64_t)d; br = (d >> 64) & 1; }
+    if (br) { u128 c = 0; for (int i = 0; i < 4; ++i) { c += (u128)r[i] + P[i]; r[i] = (uint64_t)c; c >>= 64; } }
 }
+}  // namespace hostmont
+
+namespace hostfr {
+constexpr uint64_t P[4] = {0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
+constexpr uint64_t INV = 0xc2e1f593efffffffull;   // -p^-1 mod 2^64
+constexpr uint64_t ONE[4] = {0xac96341c4ffffffbull, 0x36fc76959f60cd29ull, 0x666ea36f7879462eull, 0x0e0a77c19a07df2full};   // 2^256 mod p
+inline bool geq_p(const uint64_t* a) { return hostmont::geq(a, P); }
+inline void sub_p(uint64_t* a) { hostmont::sub_mod(a, P); }
+}  // namespace hostfr
+namespace hostfq {
+constexpr uint64_t P[4] = {0x3c208c16d87cfd47ull, 0x97816a916871ca8dull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
+constexpr uint64_t INV = 0x87d20782e4866389ull;
+constexpr uint64_t ONE[4] = {0xd35d438dc58f0d9dull, 0x0a78eb28f5c70b3dull, 0x666ea36f7879462cull, 0x0e0a77c19a07df2full};
+}  // namespace hostfq
+
+inline HF hmul(const HF& a, const HF& b) { HF r; hostmont::mul(r.w, a.w, b.w, hostfr::P, hostfr::INV); return r; }
+inline HF hadd(const HF& a, const HF& b) { HF r; hostmont::add(r.w, a.w, b.w, hostfr::P); return r; }
+inline HF hsub(const HF& a, const HF& b) { HF r; hostmont::sub(r.w, a.w, b.w, hostfr::P); return r; }
 inline HF hzero() { return HF{{0, 0, 0, 0}}; }
 inline HF hone() { return HF{{hostfr::ONE[0], hostfr::ONE[1], hostfr::ONE[2], hostfr::ONE[3]}}; }
 inline HF hf_from_abi(const uint64_t* p) {   // the ABI form is this form; callers' values are canonical, reduce anyway

@@ -514,7 +514,8 @@ __global__ void __launch_bounds__(256) k_plan_sums(const uint32_t* cnt_in_all, u
 }
 __global__ void __launch_bounds__(256) k_plan_apply(const uint32_t* cnt_in_all, uint32_t B, uint32_t seg, uint32_t seg_magic,
                                                     const uint32_t* sums_all, uint32_t* off_in_all, uint32_t* cnt_out_all,
-                                                    uint32_t* off_out_all, uint32_t* max_out, const uint32_t* lane_off_all, uint32_t lane_L) {
+                                                    uint32_t* off_out_all, uint32_t* max_out, const uint32_t* lane_off_all, uint32_t lane_L,
+                                                    uint32_t max_tag) {
     __shared__ uint32_t w_a[4], w_b[4], s_base[3];
     uint32_t col = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6, nblk = gridDim.x;
     const uint32_t* sums = sums_all + (size_t)col * nblk * 4;
@@ -536,7 +537,12 @@ __global__ void __launch_bounds__(256) k_plan_apply(const uint32_t* cnt_in_all, 
             if (blockIdx.x == nblk - 1) {
                 if (off_in_all) off_in_all[(size_t)col * (B + 4) + B] = ta;
                 if (off_out_all) off_out_all[(size_t)col * (B + 4) + B] = tb;
-                if (max_out) max_out[col] = bm;
+                // max_tag != 0: max_out is pinned host memory the host polls — one 8-byte system-scope store carries the value and
+                // the tag of this call, so the host needs neither an event nor the end of the kernel to read it
+                if (max_out && max_tag)
+                    __hip_atomic_store(reinterpret_cast<uint64_t*>(max_out) + col, ((uint64_t)max_tag << 32) | bm, __ATOMIC_RELEASE,
+                                       __HIP_MEMORY_SCOPE_SYSTEM);
+                else if (max_out) max_out[col] = bm;
             }
         }
     }
@@ -581,14 +587,15 @@ __global__ void __launch_bounds__(256) k_plan_apply(const uint32_t* cnt_in_all, 
     }
 }
 static int launch_plan(zkhip_ctx* ctx, unsigned ncols, const uint32_t* cnt_in, uint32_t B, uint32_t seg, uint32_t* off_in,
-                       uint32_t* cnt_out, uint32_t* off_out, uint32_t* max_out, const uint32_t* lane_off = nullptr, uint32_t lane_L = 0) {
+                       uint32_t* cnt_out, uint32_t* off_out, uint32_t* max_out, const uint32_t* lane_off = nullptr, uint32_t lane_L = 0,
+                       uint32_t max_tag = 0) {
     uint32_t magic = seg > 1 ? (uint32_t)((((uint64_t)1 << 32) + seg - 1) / seg) : 0;
     unsigned nblk = div_up(B, PLAN_BLOCK);
     void* d_sums;
     ZK_TRY(ctx->get_scratch("msm_plan_sums", (size_t)ncols * nblk * 16, &d_sums));
     hipLaunchKernelGGL(k_plan_sums, dim3(nblk, ncols), dim3(256), 0, ctx->stream, cnt_in, B, seg, magic, (uint32_t*)d_sums, lane_off, lane_L);
     hipLaunchKernelGGL(k_plan_apply, dim3(nblk, ncols), dim3(256), 0, ctx->stream, cnt_in, B, seg, magic, (const uint32_t*)d_sums, off_in,
-                       cnt_out, off_out, max_out, lane_off, lane_L);
+                       cnt_out, off_out, max_out, lane_off, lane_L, max_tag);
     return ZKHIP_OK;
 }
 
@@ -981,7 +988,8 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
     // the "heaviest bucket" read-back: the plan kernel stores it straight into pinned host memory (slot at 1 KiB) when it fits
     std::vector<uint32_t> h_max_big;
     uint32_t* h_max = (uint32_t*)ctx->h_pinned;
-    const bool max_pinned = ncols * 4 <= 1024;
+    const bool max_pinned = ncols * 8 <= 1024;   // 8-byte slots: (tag of this call << 32) | value, polled by the host
+    const uint32_t max_tag = max_pinned ? (++ctx->max_seq ? ctx->max_seq : ++ctx->max_seq) : 0;
     if (max_pinned) { h_max = (uint32_t*)((char*)ctx->h_pinned + 1024); d_max = h_max; }
     else if (ncols * 4 > zkhip_ctx::PINNED_BYTES) { h_max_big.resize(ncols); h_max = h_max_big.data(); }
     { ProfScope ps(ctx, "msm_digits");
@@ -998,9 +1006,11 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
     ZK_TRY(launch_plan(ctx, (unsigned)ncols, (const uint32_t*)d_cnt, B, 1, (uint32_t*)d_off, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr));
     // second scan, in lane mode: scans npart[b] (computed on the fly from cnt and off), writes it to cntA, its offsets to offA
     ZK_TRY(launch_plan(ctx, (unsigned)ncols, (const uint32_t*)d_cnt, B, 1, (uint32_t*)d_offA, (uint32_t*)d_cntA, (uint32_t*)nullptr, (uint32_t*)d_max,
-                       (const uint32_t*)d_off, L)); }
-    if (!max_pinned) ZK_HIP(hipMemcpyAsync(h_max, d_max, ncols * 4, hipMemcpyDeviceToHost, st));
-    ZK_HIP(hipEventRecord(ctx->ev_read, st));
+                       (const uint32_t*)d_off, L, max_tag)); }
+    if (!max_pinned) {
+        ZK_HIP(hipMemcpyAsync(h_max, d_max, ncols * 4, hipMemcpyDeviceToHost, st));
+        ZK_HIP(hipEventRecord(ctx->ev_read, st));
+    }
     { ProfScope ps(ctx, "msm_digits");
     {
         const size_t lds = (size_t)3 * (1u << g.LB) * 4 + (size_t)g.tile * 6;
@@ -1026,10 +1036,27 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
         ctx->accum_mark = nullptr;
     }
     ZK_LAUNCH_CHECK();
-    if (h_max_big.empty()) ZK_HIP(event_wait(ctx->ev_read));   // only the read-back: the scatter and round 0 are still running
-    else ZK_HIP(stream_wait(st));                               // pageable destination: wait for everything
     uint32_t maxcnt = 0;   // most partial sums in one bucket
-    for (size_t j = 0; j < ncols; ++j) maxcnt = std::max(maxcnt, h_max[j]);
+    if (max_pinned) {
+        // poll the tagged slots: no event, no marker packet between the plan and the scatter (a marker costs ~15 us of idle GPU)
+        const volatile uint64_t* slots = (const volatile uint64_t*)h_max;
+        for (size_t j = 0; j < ncols; ++j) {
+            uint64_t v = slots[j];
+            for (uint64_t spin = 0; (uint32_t)(v >> 32) != max_tag; ++spin) {
+                if ((spin & 0xFFFFF) == 0xFFFFF) {   // a failed launch would never publish: look at the stream now and then
+                    hipError_t e = hipStreamQuery(st);
+                    if (e != hipSuccess && e != hipErrorNotReady) ZK_HIP(e);
+                    if (e == hipSuccess && (uint32_t)(slots[j] >> 32) != max_tag) { set_error("msm: plan read-back never arrived"); return ZKHIP_EHIP; }
+                }
+                v = slots[j];
+            }
+            maxcnt = std::max(maxcnt, (uint32_t)v);
+        }
+    } else {
+        if (h_max_big.empty()) ZK_HIP(event_wait(ctx->ev_read));   // only the read-back: the scatter and round 0 are still running
+        else ZK_HIP(stream_wait(st));                               // pageable destination: wait for everything
+        for (size_t j = 0; j < ncols; ++j) maxcnt = std::max(maxcnt, h_max[j]);
+    }
     if (maxcnt == 0) {
         hipLaunchKernelGGL(k_set_identity, dim3(div_up(ncols, 64)), dim3(64), 0, st, (uint32_t*)d_out, (uint32_t)ncols);
         ZK_LAUNCH_CHECK();
