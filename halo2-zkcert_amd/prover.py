@@ -213,7 +213,18 @@ class GpuBackend:
         self.main.wait_event(ev)
 
     def setup(self, k, degree, s_int):
-        self.params = self.ffi.ParamsKZG.setup(self.ctx, k, self.fr(s_int))
+        # params_file (set by a caller that mirrors the reference's `gen_srs(k)` under PARAMS_DIR, /root/reference/src/bin/cli.rs:222):
+        # read the SRS file if it is there, otherwise generate the synthetic one and leave it there for the next run
+        pf = getattr(self, "params_file", None)
+        if pf and os.path.exists(pf):
+            self.params = self.ffi.ParamsKZG.read(self.ctx, pf)
+            if self.params.k != k:
+                raise ValueError(f"{pf}: k = {self.params.k}, expected {k}")
+        else:
+            self.params = self.ffi.ParamsKZG.setup(self.ctx, k, self.fr(s_int))
+            if pf:
+                os.makedirs(os.path.dirname(pf) or ".", exist_ok=True)
+                self.params.write(pf)
         self.domain = self.ffi.EvaluationDomain(self.ctx, degree, k)
         return self.domain
 

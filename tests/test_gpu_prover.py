@@ -266,3 +266,27 @@ def test_native_create_proof_evm_transcript(zk, oracle):
     instance = [zo.fr_arr_to_ints(gp.b.to_host(c)) for c in w["instance"]]
     h1, h2 = _pts(te["points"]["shplonk_h1"])[0], _pts(te["points"]["shplonk_h2"])[0]
     assert P.plonk_verify(vk, instance, coms, _pts(te["points"]["quotient"]), evals, te["query_list"], te["challenges"], h1, h2, s)
+
+
+def test_cli_shaped_driver_and_srs_file_round_trip(zk, tmp_path, capsys):
+    """tools/zkcert_cli.py (the reference CLI's command / argument names, /root/reference/src/bin/cli.rs:95-211): the first run
+    generates the SRS and leaves kzg_bn254_<k>.srs under --params-path, the second reads it back — same proof bytes; the EVM
+    command's proof has the 64-byte point layout."""
+    import importlib.util
+    import json
+    import os
+
+    spec = importlib.util.spec_from_file_location("zkcert_cli", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "zkcert_cli.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    params = str(tmp_path / "params")
+    outs = []
+    for name in ("a.proof", "b.proof"):
+        cli.main(["prove-rsa", "--k", "9", "--params-path", params, "--proof-path", str(tmp_path / name)])
+        outs.append(json.loads(capsys.readouterr().out.strip().splitlines()[-1]))
+    assert os.path.getsize(os.path.join(params, "kzg_bn254_9.srs")) == 4 + 2 * 512 * 64 + 256
+    a, b = (tmp_path / "a.proof").read_bytes(), (tmp_path / "b.proof").read_bytes()
+    assert a == b and len(a) == outs[0]["proof_bytes"] and len(a) % 32 == 0
+    cli.main(["gen-x509-agg-evm-proof", "--agg-k", "9", "--params-path", params, "--agg-proof-path", str(tmp_path / "e.proof")])
+    e = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert e["transcript"] == "evm-keccak" and e["proof_bytes"] > len(a)
