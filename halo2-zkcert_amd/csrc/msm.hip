@@ -469,9 +469,20 @@ __device__ __forceinline__ uint32_t ceil_div_magic(uint32_t v, uint32_t seg, uin
 #define PLAN_BLOCK (256 * PLAN_PER)
 // lane mode (lane_off != null): the scanned quantity is not cnt_in[b] but the number of round-0 lanes of width L touching bucket b,
 // floor((off + cnt - 1) / L) - floor(off / L) + 1, from the bucket offsets of the previous scan
+// Round-0 lane width actually used for a column with `total` non-zero digits out of `items` slots.  The host picks L for dense
+// scalars (about four waves per SIMD over the launch); columns of small values (lookup inputs, bit columns: most digits zero)
+// would leave a few hundred lanes running L dependent additions each, so the width shrinks with the column's real entry count —
+// never below what keeps the lanes within the launched grid and the partial sums within their buffer (sized for L >= 8).
+__device__ __forceinline__ uint32_t lane_len(uint32_t total, uint32_t items, uint32_t L, uint32_t ncols) {
+    uint64_t a = ((uint64_t)total * L + items - 1) / items;
+    uint64_t b = ((uint64_t)total * ncols + 262143) / 262144;
+    uint32_t l = (uint32_t)(a > b ? a : b);
+    return min(L, max(2u, l));
+}
 __device__ __forceinline__ void plan_load(const uint32_t* cnt_in, uint32_t B, uint32_t lo, uint32_t v[PLAN_PER], const uint32_t* lane_off = nullptr,
-                                          uint32_t lane_L = 0) {
+                                          uint32_t lane_L = 0, uint32_t lane_items = 0) {
     if (lane_off) {
+        if (lane_items) lane_L = lane_len(lane_off[B], lane_items, lane_L, gridDim.y);
 #pragma unroll
         for (int q = 0; q < PLAN_PER; ++q) {
             uint32_t c = lo + q < B ? cnt_in[lo + q] : 0u;
@@ -492,12 +503,13 @@ __device__ __forceinline__ void plan_load(const uint32_t* cnt_in, uint32_t B, ui
     }
 }
 __global__ void __launch_bounds__(256) k_plan_sums(const uint32_t* cnt_in_all, uint32_t B, uint32_t seg, uint32_t seg_magic,
-                                                   uint32_t* sums_all /* [col][nblk][4] */, const uint32_t* lane_off_all, uint32_t lane_L) {
+                                                   uint32_t* sums_all /* [col][nblk][4] */, const uint32_t* lane_off_all, uint32_t lane_L,
+                                                   uint32_t lane_items) {
     __shared__ uint32_t w_a[4], w_b[4], w_m[4];
     uint32_t col = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     uint32_t v[PLAN_PER];
     plan_load(cnt_in_all + (size_t)col * B, B, blockIdx.x * PLAN_BLOCK + t * PLAN_PER, v,
-              lane_off_all ? lane_off_all + (size_t)col * (B + 4) : nullptr, lane_L);
+              lane_off_all ? lane_off_all + (size_t)col * (B + 4) : nullptr, lane_L, lane_items);
     uint32_t sa = 0, sb = 0, m = 0;
 #pragma unroll
     for (int q = 0; q < PLAN_PER; ++q) { sa += v[q]; sb += ceil_div_magic(v[q], seg, seg_magic); m = max(m, v[q]); }
@@ -515,7 +527,7 @@ __global__ void __launch_bounds__(256) k_plan_sums(const uint32_t* cnt_in_all, u
 __global__ void __launch_bounds__(256) k_plan_apply(const uint32_t* cnt_in_all, uint32_t B, uint32_t seg, uint32_t seg_magic,
                                                     const uint32_t* sums_all, uint32_t* off_in_all, uint32_t* cnt_out_all,
                                                     uint32_t* off_out_all, uint32_t* max_out, const uint32_t* lane_off_all, uint32_t lane_L,
-                                                    uint32_t max_tag) {
+                                                    uint32_t max_tag, uint32_t lane_items) {
     __shared__ uint32_t w_a[4], w_b[4], s_base[3];
     uint32_t col = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6, nblk = gridDim.x;
     const uint32_t* sums = sums_all + (size_t)col * nblk * 4;
@@ -548,7 +560,7 @@ __global__ void __launch_bounds__(256) k_plan_apply(const uint32_t* cnt_in_all, 
     }
     uint32_t lo = blockIdx.x * PLAN_BLOCK + t * PLAN_PER;
     uint32_t v[PLAN_PER], sv[PLAN_PER];
-    plan_load(cnt_in_all + (size_t)col * B, B, lo, v, lane_off_all ? lane_off_all + (size_t)col * (B + 4) : nullptr, lane_L);
+    plan_load(cnt_in_all + (size_t)col * B, B, lo, v, lane_off_all ? lane_off_all + (size_t)col * (B + 4) : nullptr, lane_L, lane_items);
     uint32_t sa = 0, sb = 0;
 #pragma unroll
     for (int q = 0; q < PLAN_PER; ++q) { sv[q] = ceil_div_magic(v[q], seg, seg_magic); sa += v[q]; sb += sv[q]; }
@@ -588,14 +600,14 @@ __global__ void __launch_bounds__(256) k_plan_apply(const uint32_t* cnt_in_all, 
 }
 static int launch_plan(zkhip_ctx* ctx, unsigned ncols, const uint32_t* cnt_in, uint32_t B, uint32_t seg, uint32_t* off_in,
                        uint32_t* cnt_out, uint32_t* off_out, uint32_t* max_out, const uint32_t* lane_off = nullptr, uint32_t lane_L = 0,
-                       uint32_t max_tag = 0) {
+                       uint32_t max_tag = 0, uint32_t lane_items = 0) {
     uint32_t magic = seg > 1 ? (uint32_t)((((uint64_t)1 << 32) + seg - 1) / seg) : 0;
     unsigned nblk = div_up(B, PLAN_BLOCK);
     void* d_sums;
     ZK_TRY(ctx->get_scratch("msm_plan_sums", (size_t)ncols * nblk * 16, &d_sums));
-    hipLaunchKernelGGL(k_plan_sums, dim3(nblk, ncols), dim3(256), 0, ctx->stream, cnt_in, B, seg, magic, (uint32_t*)d_sums, lane_off, lane_L);
+    hipLaunchKernelGGL(k_plan_sums, dim3(nblk, ncols), dim3(256), 0, ctx->stream, cnt_in, B, seg, magic, (uint32_t*)d_sums, lane_off, lane_L, lane_items);
     hipLaunchKernelGGL(k_plan_apply, dim3(nblk, ncols), dim3(256), 0, ctx->stream, cnt_in, B, seg, magic, (const uint32_t*)d_sums, off_in,
-                       cnt_out, off_out, max_out, lane_off, lane_L, max_tag);
+                       cnt_out, off_out, max_out, lane_off, lane_L, max_tag, lane_items);
     return ZKHIP_OK;
 }
 
@@ -643,12 +655,13 @@ __device__ __forceinline__ g1x g1x_load_loose(const uint32_t* p) {
 // trip count, where per-bucket segments left ~20 % of the lanes idle behind the longest segment.
 __global__ void __launch_bounds__(256) k_accum_affine(const uint32_t* const* tables, const uint32_t* entries_all, size_t items,
                                                       const uint32_t* off_all, const uint32_t* segoff_all, uint32_t B, uint32_t L,
-                                                      uint32_t* partial_all, size_t partial_stride) {
+                                                      uint32_t* partial_all, size_t partial_stride, uint32_t adaptive) {
     uint32_t col = blockIdx.y;
     const uint32_t* off = off_all + (size_t)col * (B + 4);
     const uint32_t* segoff = segoff_all + (size_t)col * (B + 4);
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t total = off[B];
+    if (adaptive) L = lane_len(total, (uint32_t)items, L, gridDim.y);
     if ((uint64_t)t * L >= total) return;
     const uint32_t start = t * L, end = min(start + L, total);
     const uint32_t* entries = entries_all + (size_t)col * items;
@@ -1002,11 +1015,12 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
                        (const uint16_t*)d_tmp_key, items, d_cnt); }
     // plan: bucket offsets, then the number of round-0 lanes touching each bucket (= its partial sums) and their offsets
     const uint32_t L = seg;
+    static const bool adaptive_L = !(getenv("ZKHIP_MSM_ADAPTIVE_L") && atoi(getenv("ZKHIP_MSM_ADAPTIVE_L")) == 0);
     { ProfScope ps(ctx, "msm_plan");
     ZK_TRY(launch_plan(ctx, (unsigned)ncols, (const uint32_t*)d_cnt, B, 1, (uint32_t*)d_off, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr));
     // second scan, in lane mode: scans npart[b] (computed on the fly from cnt and off), writes it to cntA, its offsets to offA
     ZK_TRY(launch_plan(ctx, (unsigned)ncols, (const uint32_t*)d_cnt, B, 1, (uint32_t*)d_offA, (uint32_t*)d_cntA, (uint32_t*)nullptr, (uint32_t*)d_max,
-                       (const uint32_t*)d_off, L, max_tag)); }
+                       (const uint32_t*)d_off, L, max_tag, adaptive_L ? (uint32_t)items : 0u)); }
     if (!max_pinned) {
         ZK_HIP(hipMemcpyAsync(h_max, d_max, ncols * 4, hipMemcpyDeviceToHost, st));
         ZK_HIP(hipEventRecord(ctx->ev_read, st));
@@ -1030,7 +1044,7 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
     { ProfScope ps(ctx, "msm_accum_affine");
     hipLaunchKernelGGL(k_accum_affine, dim3(div_up(div_up(items, L), 256), (unsigned)ncols), dim3(256), 0, st,
                        (const uint32_t* const*)((const void**)d_colptrs + ncols), (const uint32_t*)d_entries, items, (const uint32_t*)d_off,
-                       (const uint32_t*)d_offA, B, L, (uint32_t*)d_pA, pstride0); }
+                       (const uint32_t*)d_offA, B, L, (uint32_t*)d_pA, pstride0, adaptive_L ? 1u : 0u); }
     if (ctx->accum_mark) {   // a caller wants to start overlapped work when the throughput-bound part of this MSM is over
         ZK_HIP(hipEventRecord(ctx->accum_mark, st));
         ctx->accum_mark = nullptr;
