@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--k", type=int, default=17)
     ap.add_argument("--shape", default="rsa", choices=["rsa", "sha256"], help="circuit shape (BASELINE configs[1] / configs[2])")
+    ap.add_argument("--witness", default="uniform", choices=["uniform", "survey"],
+                    help="sha256 shape only: uniform field elements (worst case) or SURVEY.md 8(d)'s mix of 90 %% bits / 10 %% 32-bit words")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shard-msm", action="store_true", help="N > 1: split one proof (strong scaling) instead of one proof per GPU")
     ap.add_argument("--shard-ntt", action="store_true", help="with --shard-msm: also distribute the coset NTTs by polynomial (all-gather)")
@@ -108,7 +110,7 @@ def main():
     if shard:
         backend = pv.ShardedCommit(backend, rank, world, dist, shard_ntt=args.shard_ntt)
     prover = pv.Prover(backend, shape, satisfiable=args.shape == "rsa")   # rsa shape: a satisfiable instance, i.e. a valid proof
-    wit = prover.witness(0 if (shard or world == 1) else rank)   # one independent proof per rank unless sharding one
+    wit = prover.witness(0 if (shard or world == 1) else rank, dist=args.witness)   # one independent proof per rank unless sharding one
     n = 1 << shape.k
     counts = shape.counts(prover.dom.extended_k)
 
@@ -180,7 +182,7 @@ def main():
                                    f"{counts['intt_n']} iNTT_2^{shape.k} + {counts['ntt_ext']} NTT_2^{prover.dom.extended_k} + "
                                    f"1 iNTT_2^{prover.dom.extended_k} + 1 sweep over 2^{prover.dom.extended_k} rows + lookup compression, "
                                    f"{shape.n_perm_sets}+{len(shape.lookups)} grand products, evaluations at x; "
-                                   "lookup permute (sort) and SHPLONK multi-open computed; " + ("synthetic SATISFIABLE instance (gates, copy constraints, lookup hold: the output is a valid proof, see tests/test_gpu_prover.py::test_rsa_k17_valid_proof); " if args.shape == "rsa" else "uniform synthetic witness; ") +
+                                   "lookup permute (sort) and SHPLONK multi-open computed; " + ("synthetic SATISFIABLE instance (gates, copy constraints, lookup hold: the output is a valid proof, see tests/test_gpu_prover.py::test_rsa_k17_valid_proof); " if args.shape == "rsa" else ("uniform synthetic witness; " if args.witness == "uniform" else "synthetic witness with SURVEY 8(d)'s value mix (90 % bits, 10 % words < 2^32); ")) +
                                    "halo2 Blake2bWrite transcript (restated, in the library; the reference's commands use Poseidon / Keccak)",
                        "k": shape.k, "advice": shape.n_advice, "fixed": shape.n_fixed, "lookups": len(shape.lookups),
                        "perm_columns": len(shape.perm_columns), "degree": shape.degree,
@@ -199,6 +201,8 @@ def main():
             "int_roofline": {"kernel": "msm_accum_affine", "bound": "v_mad_u64_u32 issue", "achieved": round(int_achieved, 2), "peak": 29.8,
                              "unit": "Tmad/s", "frac": round(int_achieved / 29.8, 4), "window_bits": c_bits, "windows": windows},
             "kernels_ms_per_step": kernels,
+            **({"int_roofline_note": "sparse-digit witness: most (scalar, window) pairs are zero digits and are skipped, so the dense-pair "
+                                      "mad count behind int_roofline / roofline.achieved does not describe this run"} if args.witness == "survey" else {}),
             "kernels_note": f"per-kernel HIP-event times from {extra} extra untimed passes; roofline/int_roofline use the dominant kernel's events recorded inside the timed region",
         }
         # The metric names three configurations; `value` is configs[1] (RSA k=17).  The other two are timed here with a few steps each
@@ -207,11 +211,13 @@ def main():
         if world == 1 and not args.no_other_configs and args.k == 17 and args.shape == "rsa":
             others = {}
             del prover, wit, trace
-            for name, shp, sat in (("sha256_shaped_k19", pv.CircuitShape.sha256(19), False), ("aggregation_shaped_k22", pv.CircuitShape.rsa(22), True)):
+            for name, shp, sat, dist in (("sha256_shaped_k19", pv.CircuitShape.sha256(19), False, "uniform"),
+                                         ("sha256_shaped_k19_bit_witness", pv.CircuitShape.sha256(19), False, "survey"),
+                                         ("aggregation_shaped_k22", pv.CircuitShape.rsa(22), True, "uniform")):
                 try:
                     torch.cuda.empty_cache()
                     p2 = pv.Prover(pv.GpuBackend(ctx, ffi), shp, satisfiable=sat)
-                    w2 = p2.witness(0)
+                    w2 = p2.witness(0, dist=dist)
                     p2.prove_native(w2)
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()

@@ -279,6 +279,25 @@ __global__ void k_synth_fill(uint32_t* out, size_t n, uint64_t seed, uint64_t fi
     mem_store(out + i * 8, synth_raw253(seed, first + i));
 }
 
+// small-valued synthetic column (bit / word columns of the SHA-256 circuit, limb columns): element i is a bit with
+// probability bits_per_mille / 1000, otherwise a word of word_bits bits; stored as the Montgomery limbs of that integer.
+__global__ void k_synth_small(uint32_t* out, size_t n, uint64_t seed, uint64_t first, uint32_t bits_per_mille, uint32_t word_bits) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t h = splitmix64(seed + (first + i) * 0x2545F4914F6CDD1Dull);
+    uint64_t hi = h >> 32;
+    uint64_t v = (h & 0xFFFFFFFFull) % 1000 < bits_per_mille ? (hi & 1) : (word_bits >= 32 ? hi : (hi & ((1ull << word_bits) - 1)));
+    mem_store(out + i * 8, to_abi(from_u64<Fr>(v)));
+}
+extern "C" int zkhip_synth_small_device(zkhip_ctx* c, void* d_out, size_t n, uint64_t seed, uint64_t first, uint32_t bits_per_mille,
+                                        uint32_t word_bits) {
+    if (!c || !d_out || bits_per_mille > 1000 || word_bits == 0 || word_bits > 32) { set_error("zkhip_synth_small_device: bad argument"); return ZKHIP_EINVAL; }
+    if (n == 0) return ZKHIP_OK;
+    hipLaunchKernelGGL(k_synth_small, dim3(div_up(n, 256)), dim3(256), 0, c->stream, (uint32_t*)d_out, n, seed, first, bits_per_mille, word_bits);
+    ZK_LAUNCH_CHECK();
+    return ZKHIP_OK;
+}
+
 extern "C" int zkhip_synth_fill_device(zkhip_ctx* c, void* d_out, size_t n, uint64_t seed, uint64_t first) {
     if (!c || !d_out) { set_error("zkhip_synth_fill_device: bad argument"); return ZKHIP_EINVAL; }
     if (n == 0) return ZKHIP_OK;

@@ -64,7 +64,7 @@ SYMBOLS = [
     "zkhip_domain_constants", "zkhip_lagrange_to_coeff_device", "zkhip_coeff_to_lagrange_device",
     "zkhip_coeff_to_extended_device", "zkhip_extended_to_coeff_device", "zkhip_divide_by_vanishing_device",
     "zkhip_lagrange_to_coeff", "zkhip_coeff_to_extended", "zkhip_extended_to_coeff",
-    "zkhip_evaluate_h_device", "zkhip_synth_fill_device",
+    "zkhip_evaluate_h_device", "zkhip_synth_fill_device", "zkhip_synth_small_device",
     "zkhip_batch_invert_device", "zkhip_eval_polynomial_device", "zkhip_eval_polynomials_at_device", "zkhip_permutation_products_device",
     "zkhip_permute_expression_pair_device", "zkhip_lookup_product_device", "zkhip_grand_products_device",
     "zkhip_linear_combination_device", "zkhip_divide_by_linear_device", "zkhip_kate_division_device", "zkhip_shplonk_open",
@@ -193,6 +193,13 @@ class Context:
     def synth_fill(self, n, seed, first=0):
         t = self.empty(n)
         _check(lib().zkhip_synth_fill_device(self.h, C.c_void_p(t.data_ptr()), C.c_size_t(n), C.c_uint64(seed), C.c_uint64(first)))
+        return t
+
+    def synth_small(self, n, seed, bits_per_mille=900, word_bits=32, first=0):
+        """a column of small values: bits with probability bits_per_mille / 1000, else word_bits-bit words (zkhip.h)"""
+        t = self.empty(n)
+        _check(lib().zkhip_synth_small_device(self.h, C.c_void_p(t.data_ptr()), C.c_size_t(n), C.c_uint64(seed), C.c_uint64(first),
+                                              C.c_uint32(bits_per_mille), C.c_uint32(word_bits)))
         return t
 
     # ---- best_fft ----

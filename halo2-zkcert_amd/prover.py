@@ -238,6 +238,9 @@ class GpuBackend:
     def synth(self, n, seed):
         return self.ctx.synth_fill(n, seed)
 
+    def synth_small(self, n, seed, bits_per_mille, word_bits):
+        return self.ctx.synth_small(n, seed, bits_per_mille, word_bits)
+
     def gather(self, col, idx):
         """col[idx] (idx: host int64 array) — witness construction only"""
         return col[self.torch.from_numpy(idx).to(col.device)].contiguous()
@@ -617,13 +620,18 @@ class Prover:
             g.add_calculation(ev.OP_HORNER, [(ev.VS_CONSTANT, 0, 0), (ev.VS_THETA, 0, 0), r_])
             self._fill_graphs.append(g)
 
-    def witness(self, proof_seed):
+    def witness(self, proof_seed, dist="uniform"):
         """Synthetic advice / instance tables in Lagrange form, resident on the device (untimed).  Lookup-advice columns
         take their values from the table column (about two occurrences of each of the first n/2 table rows), so the
-        lookup argument is satisfiable like a real range check's."""
+        lookup argument is satisfiable like a real range check's.  dist: "uniform" = uniform field elements (the worst case for
+        the commitments); "survey" = SURVEY.md 8(d)'s value mix for the SHA-256 bit circuit, 90 % bits and 10 % words < 2^32 (not
+        for satisfiable instances, whose advice is determined by the gates)."""
         sh, n = self.shape, self.n
         base = sh.seed * 1000 + proof_seed * 100000
-        advice = [self.b.synth(n, base + 1 + i) for i in range(sh.n_basic)]
+        if dist == "survey" and not self.satisfiable:
+            advice = [self.b.synth_small(n, base + 1 + i, 900, 32) for i in range(sh.n_basic)]
+        else:
+            advice = [self.b.synth(n, base + 1 + i) for i in range(sh.n_basic)]
         for j in range(sh.n_lookup):
             idx = (splitmix64(np.arange(n, dtype=np.uint64) + np.uint64(((base + 20 + j) << 32) & 0xFFFFFFFFFFFFFFFF)) % np.uint64(n // 2)).astype(np.int64)
             advice.append(self.b.gather(self.fixed_lagrange[sh.n_fixed - 1], idx))

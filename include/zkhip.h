@@ -331,6 +331,11 @@ void zkhip_keccak256(const uint8_t* in, size_t len, uint8_t pad /* 0x01 Keccak-2
 /* ---- synthetic tables (bench / tests): element i of a column = raw253(seed, i) taken as the
  * Montgomery limbs (oracle/pyref.py synth_raw253) ---- */
 int  zkhip_synth_fill_device(zkhip_ctx* ctx, void* d_out, size_t n, uint64_t seed, uint64_t first_index);
+/* small-valued column (the witness-shaped distributions of SURVEY.md 8(d): bit / word columns): with h = splitmix64(seed +
+ * (first_index + i) * 0x2545F4914F6CDD1D), element i is the integer (h >> 32) & 1 if (h mod 2^32) mod 1000 < bits_per_mille,
+ * else (h >> 32) mod 2^word_bits (1 <= word_bits <= 32), stored in Montgomery form */
+int  zkhip_synth_small_device(zkhip_ctx* ctx, void* d_out, size_t n, uint64_t seed, uint64_t first_index, uint32_t bits_per_mille,
+                              uint32_t word_bits);
 
 #ifdef __cplusplus
 }

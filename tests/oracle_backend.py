@@ -35,6 +35,16 @@ class OracleBackend:
     def synth(self, n, seed):
         return zo.synth_raw253(seed, n)
 
+    def synth_small(self, n, seed, bits_per_mille, word_bits):
+        """include/zkhip.h zkhip_synth_small_device, restated with numpy"""
+        import numpy as np
+        from halo2_zkcert_amd.prover import splitmix64
+        with np.errstate(over="ignore"):
+            h = splitmix64(np.uint64(seed) + np.arange(n, dtype=np.uint64) * np.uint64(0x2545F4914F6CDD1D))
+        lo, hi = h & np.uint64(0xFFFFFFFF), h >> np.uint64(32)
+        v = np.where(lo % np.uint64(1000) < np.uint64(bits_per_mille), hi & np.uint64(1), hi & np.uint64((1 << word_bits) - 1))
+        return zo.fr_arr_from_ints([int(x) for x in v])
+
     def gather(self, col, idx):
         return np.ascontiguousarray(col[idx])
 

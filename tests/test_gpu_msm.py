@@ -105,6 +105,28 @@ def test_commit_skewed_scalars(zk, oracle, params12, kind):
     assert (aff(zk, p.commit(sc)) == exp).all()
 
 
+def test_synth_small_columns_and_their_commitments(zk, oracle, params12):
+    """zkhip_synth_small_device (SURVEY 8(d)'s bit / word columns) against its numpy restatement, and a batch of such columns —
+    the sparse-digit path: device-adaptive lane width, one heavy bucket — against the oracle's MSM."""
+    from oracle_backend import OracleBackend
+
+    ffi, ctx = zk
+    zo = oracle
+    p, _ = params12
+    n = 4096
+    ob = OracleBackend()
+    cols_d = [ctx.synth_small(n, 900 + j, bpm, wb) for j, (bpm, wb) in enumerate([(900, 32), (1000, 1), (0, 16), (500, 8)])]
+    cols_h = [ob.synth_small(n, 900 + j, bpm, wb) for j, (bpm, wb) in enumerate([(900, 32), (1000, 1), (0, 16), (500, 8)])]
+    for d, h in zip(cols_d, cols_h):
+        assert (ctx.to_host(d) == h).all()
+    ints = zo.fr_arr_to_ints(cols_h[0])
+    assert max(ints) < 1 << 32 and 0.85 < sum(1 for v in ints if v < 2) / n < 0.95
+    out = ctx.to_host(p.commit_batch_device(cols_d, lagrange=True))
+    bases = p.read_bases(p.g_lagrange, 0, n)
+    for j, c in enumerate(cols_h):
+        assert (ffi.g1_to_affine(out[j]) == zo.g1_to_affine(zo.best_multiexp(c, bases, 8))).all()
+
+
 def test_commit_batch_device(zk, oracle, params12):
     ffi, ctx = zk
     zo = oracle
