@@ -856,22 +856,28 @@ __global__ void __launch_bounds__(256) k_bucket_chunks(const uint32_t* part_all,
         const uint32_t* off = off_all + (size_t)col * (B + 4);
         const uint32_t* part = part_all + (size_t)col * part_stride * PART_WORDS;
         uint32_t base = t * CH;
-        g1x run = g1x_identity();
-        for (int j = (int)CH - 1; j >= 0; --j) {
-            uint32_t b = base + (uint32_t)j;
-            if (b < B) {   // the bucket's (few) partial sums are folded here: no separate reduction round for them
-                const uint32_t c = cnt[b], o = off[b];
-                for (uint32_t i = 0; i < c; ++i) run = tail_add<LANES>(run, g1x_load_loose(part + (size_t)(o + i) * PART_WORDS), q);
+        // a chunk without partial sums contributes nothing (columns of small values leave most windows empty), and inside a chunk
+        // the running sum is the identity until the first non-empty bucket from the top
+        if (off[min(base + CH, B)] != off[base]) {
+            g1x run = g1x_identity();
+            bool have = false;
+            for (int j = (int)CH - 1; j >= 0; --j) {
+                uint32_t b = base + (uint32_t)j;
+                if (b < B) {   // the bucket's (few) partial sums are folded here: no separate reduction round for them
+                    const uint32_t c = cnt[b], o = off[b];
+                    for (uint32_t i = 0; i < c; ++i) run = tail_add<LANES>(run, g1x_load_loose(part + (size_t)(o + i) * PART_WORDS), q);
+                    have |= c != 0;
+                }
+                if (have) acc = tail_add<LANES>(acc, run, q);
             }
-            acc = tail_add<LANES>(acc, run, q);
-        }
-        // + base * run
-        g1x d = run;
-        uint32_t m = base;
-        while (m) {
-            if (m & 1) acc = tail_add<LANES>(acc, d, q);
-            m >>= 1;
-            if (m) d = tail_double<LANES>(d, q);
+            // + base * run
+            g1x d = run;
+            uint32_t m = base;
+            while (m) {
+                if (m & 1) acc = tail_add<LANES>(acc, d, q);
+                m >>= 1;
+                if (m) d = tail_double<LANES>(d, q);
+            }
         }
     }
     block_tree_sum_t<LANES>(sh, lt, q, acc);
