@@ -174,7 +174,7 @@ def test_full_size_trapdoor_property(zk, oracle, k):
     p.free()
 
 
-@pytest.mark.parametrize("k", [20, 22])
+@pytest.mark.parametrize("k", [20, 22] + ([24] if __import__("os").environ.get("ZKHIP_TEST_HUGE") else []))   # 2^24: ~1 min, 20 GB
 def test_large_msm_trapdoor_property(zk, oracle, k):
     """BASELINE configs[2..3] sizes (2^20, 2^22 points; window c = 18): commit(coeffs) == [p(s)] G,
     commit_lagrange(evals) == commit(iNTT(evals)).  Size-independent, O(n) host work."""

@@ -112,7 +112,7 @@ def test_domain_vs_oracle(zk, oracle, j, k):
     dom.free()
 
 
-@pytest.mark.parametrize("k,j", [(17, 4), (19, 5), (22, 4)])
+@pytest.mark.parametrize("k,j", [(17, 4), (19, 5), (22, 4)] + ([(24, 4)] if __import__("os").environ.get("ZKHIP_TEST_HUGE") else []))   # 2^26 extended: 4 passes
 def test_full_size_round_trip_and_point_checks(zk, oracle, k, j):
     """BASELINE sizes (2^17 -> 2^19, 2^19 -> 2^21, 2^22 -> 2^24 extended): size-independent properties.
     (1) extended_to_coeff(coeff_to_extended(p)) == p; (2) three extended evaluations equal Horner on
