@@ -383,6 +383,7 @@ __global__ void __launch_bounds__(256) k_sort_lo_staged(const uint32_t* part_off
 
 // The same pass for the default 4096-pair tile with ONE LDS atomic per pair: the counting atomic's return value is the pair's
 // rank inside its bin, kept in registers (16 pairs per thread) until the bins' starts are known.
+template <int PER_T>
 __global__ void __launch_bounds__(256) k_sort_lo_staged16(const uint32_t* part_off_all, const uint32_t* tile_start_all, SortGeom g,
                                                           const uint32_t* tmp_entry_all, const uint16_t* tmp_key_all, size_t items,
                                                           const uint32_t* off_all, uint32_t* cursor_all, uint32_t* entries_all) {
@@ -397,24 +398,24 @@ __global__ void __launch_bounds__(256) k_sort_lo_staged16(const uint32_t* part_o
         if (ts[mid] <= blk) lo_p = mid; else hi_p = mid;
     }
     const uint32_t p = lo_p;
-    const uint32_t beg = po[p] + (blk - ts[p]) * SORT_TILE, end = min(beg + SORT_TILE, po[p + 1]), cnt = end - beg;
+    const uint32_t beg = po[p] + (blk - ts[p]) * (PER_T * 256u), end = min(beg + (PER_T * 256u), po[p + 1]), cnt = end - beg;
     const uint32_t nbins = 1u << g.LB;
     uint32_t* hist = sort_lds;                 // [nbins] counts
     uint32_t* base = hist + nbins;             // [nbins] global position of the bin's run
     uint32_t* lst = base + nbins;              // [nbins] start of the bin inside the staged tile
     uint32_t* st_e = lst + nbins;              // [tile] staged entries
-    uint16_t* st_k = reinterpret_cast<uint16_t*>(st_e + SORT_TILE);   // [tile] their bins
+    uint16_t* st_k = reinterpret_cast<uint16_t*>(st_e + (PER_T * 256u));   // [tile] their bins
     for (uint32_t j = tid; j < nbins; j += 256) hist[j] = 0;
     __syncthreads();
     const uint16_t* tmp_key = tmp_key_all + (size_t)col * items;
-    uint32_t keys[16], ranks[16];
+    uint32_t keys[PER_T], ranks[PER_T];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
+    for (int q = 0; q < PER_T; ++q) {
         uint32_t j = beg + tid + q * 256;
         keys[q] = j < end ? tmp_key[j] : 0xFFFFFFFFu;
     }
 #pragma unroll
-    for (int q = 0; q < 16; ++q) ranks[q] = keys[q] != 0xFFFFFFFFu ? atomicAdd(&hist[keys[q]], 1u) : 0u;
+    for (int q = 0; q < PER_T; ++q) ranks[q] = keys[q] != 0xFFFFFFFFu ? atomicAdd(&hist[keys[q]], 1u) : 0u;
     __syncthreads();
     const uint32_t bucket0 = p << g.LB;
     const uint32_t* off = off_all + (size_t)col * (g.B + 4);
@@ -441,7 +442,7 @@ __global__ void __launch_bounds__(256) k_sort_lo_staged16(const uint32_t* part_o
     __syncthreads();
     const uint32_t* tmp_entry = tmp_entry_all + (size_t)col * items;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
+    for (int q = 0; q < PER_T; ++q) {
         if (keys[q] != 0xFFFFFFFFu) {
             uint32_t slot = lst[keys[q]] + ranks[q];
             st_e[slot] = tmp_entry[beg + tid + q * 256];
@@ -955,7 +956,7 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
     g.P = 1u << g.HB;
     // Measured at 2^22 (2^11 bins): tiles of 16k / 32k / 64k pairs, which lengthen the scatter's contiguous runs from 8 to
     // 32-128 bytes, are 18-26 % SLOWER than 4096-pair tiles — the low pass is bound by its LDS rank atomics, not by run length.
-    g.tile = SORT_TILE;
+    g.tile = g.LB >= 11 ? 2 * SORT_TILE : SORT_TILE;   // 2048 bins (c = 19, n >= 2^20): 8192-pair tiles, 16-byte runs (digits -13 % at 2^22)
     if (const char* e = getenv("ZKHIP_SORT_TILE")) { int v = atoi(e); if (v >= 1024 && v <= (1 << 20)) g.tile = (uint32_t)v; }
     if (g.LB > 11) { set_error("zkhip_msm: window c = %u unsupported by the sort (max 19)", c); return ZKHIP_EINVAL; }
     ZK_TRY(ctx->get_scratch("msm_colptrs", 2 * ncols * sizeof(void*), &d_colptrs));
@@ -1036,11 +1037,17 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
         const size_t lds = (size_t)3 * (1u << g.LB) * 4 + (size_t)g.tile * 6;
         static std::once_flag attr_once;
         hipError_t attr_err = hipSuccess;
-        std::call_once(attr_once, [&] { attr_err = hipFuncSetAttribute((const void*)k_sort_lo_staged, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); });
+        std::call_once(attr_once, [&] {
+            attr_err = hipFuncSetAttribute((const void*)k_sort_lo_staged, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)k_sort_lo_staged16<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        });
         ZK_HIP(attr_err);
         static const bool one_atomic = !(getenv("ZKHIP_SORT_ONE_ATOMIC") && atoi(getenv("ZKHIP_SORT_ONE_ATOMIC")) == 0);
-        if (g.tile == SORT_TILE && one_atomic)
-            hipLaunchKernelGGL(k_sort_lo_staged16, gt, dim3(256), lds, st, (const uint32_t*)d_part_off, (const uint32_t*)d_tile_start, g,
+        if (g.tile == 8192 && one_atomic)
+            hipLaunchKernelGGL(k_sort_lo_staged16<32>, gt, dim3(256), lds, st, (const uint32_t*)d_part_off, (const uint32_t*)d_tile_start, g,
+                               (const uint32_t*)d_tmp_entry, (const uint16_t*)d_tmp_key, items, (const uint32_t*)d_off, d_cursor, (uint32_t*)d_entries);
+        else if (g.tile == SORT_TILE && one_atomic)
+            hipLaunchKernelGGL(k_sort_lo_staged16<16>, gt, dim3(256), lds, st, (const uint32_t*)d_part_off, (const uint32_t*)d_tile_start, g,
                                (const uint32_t*)d_tmp_entry, (const uint16_t*)d_tmp_key, items, (const uint32_t*)d_off, d_cursor, (uint32_t*)d_entries);
         else
         hipLaunchKernelGGL(k_sort_lo_staged, gt, dim3(256), lds, st, (const uint32_t*)d_part_off, (const uint32_t*)d_tile_start, g,
