@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shard-msm", action="store_true", help="N > 1: split one proof (strong scaling) instead of one proof per GPU")
     ap.add_argument("--shard-ntt", action="store_true", help="with --shard-msm: also distribute the coset NTTs by polynomial (all-gather)")
+    ap.add_argument("--shard-sweep", action="store_true", help="with --shard-msm: also evaluate the quotient sweep by row range (all-gather of h)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short extra runs of the metric's other two configurations (SHA256-shaped k=19, aggregation-shaped k=22)")
     ap.add_argument("--python-schedule", action="store_true",
@@ -108,7 +109,7 @@ def main():
     backend = pv.GpuBackend(ctx, ffi)
     shard = world > 1 and args.shard_msm
     if shard:
-        backend = pv.ShardedCommit(backend, rank, world, dist, shard_ntt=args.shard_ntt)
+        backend = pv.ShardedCommit(backend, rank, world, dist, shard_ntt=args.shard_ntt, shard_sweep=args.shard_sweep)
     prover = pv.Prover(backend, shape, satisfiable=args.shape == "rsa")   # rsa shape: a satisfiable instance, i.e. a valid proof
     wit = prover.witness(0 if (shard or world == 1) else rank, dist=args.witness)   # one independent proof per rank unless sharding one
     n = 1 << shape.k
@@ -187,7 +188,7 @@ def main():
                        "k": shape.k, "advice": shape.n_advice, "fixed": shape.n_fixed, "lookups": len(shape.lookups),
                        "perm_columns": len(shape.perm_columns), "degree": shape.degree,
                        "host": "zkhip_create_proof (schedule in the library, transcript callbacks)" if native else "prover.py (Python schedule over the C ABI)",
-                       "parallelism": "1 GPU" if world == 1 else (f"one proof, MSM point-range sharded x{world}, " + ("coset NTTs by polynomial + all-gather, sweep replicated" if args.shard_ntt else "NTT/sweep replicated") if shard
+                       "parallelism": "1 GPU" if world == 1 else (f"one proof, MSM point-range sharded x{world}, " + ("coset NTTs by polynomial + all-gather, " if args.shard_ntt else "NTTs replicated, ") + ("sweep by row range + all-gather" if args.shard_sweep else "sweep replicated") if shard
                                                                    else f"{world} independent proofs, one per GPU, no collective")},
             "roofline": {"kernel": "msm_accum_affine (k_accum_affine)", "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0,
                          "unit": "GB/s", "frac": round(achieved / 8000.0, 5),

@@ -273,6 +273,7 @@ struct SweepParams {
     const uint32_t* const* cols;   // fixed ++ advice ++ instance (ABI form)
     uint32_t* out;
     uint32_t isize_mask, rot_scale, nslots, final_reduce;
+    uint32_t row0;                 // first row of this launch (row-range entry point: out[0] is row0's value)
     Section gates;
     // permutation
     uint32_t n_perm_sets, n_perm_cols, chunk_len; int32_t last_rot;
@@ -360,7 +361,7 @@ __device__ __forceinline__ elc ldc(const uint32_t* col, uint32_t row) { return l
 __device__ __forceinline__ el1<Fr> ldk(const SweepParams& P, uint32_t idx) { return load_raw<Fr>(P.consts + (size_t)idx * 8); }
 
 __global__ void __launch_bounds__(128) k_sweep(SweepParams P) {
-    uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;  // isize is a multiple of the block size
+    uint32_t row = P.row0 + blockIdx.x * blockDim.x + threadIdx.x;  // the row count is a multiple of the block size
     const el1<Fr> y = ldk(P, P.c_y);
     elv value(fe_zero());
     run_section(P, P.gates, row, value.v, y.v);
@@ -420,11 +421,19 @@ __global__ void __launch_bounds__(128) k_sweep(SweepParams P) {
     }
     // back to the ABI form; the host sets final_reduce when the gate program alone could leave > 88 p
     if (P.final_reduce) value = reduce(value);
-    store_div32<Fr>(P.out + (size_t)row * 8, el<Fr, 88 * U>(value.v));
+    store_div32<Fr>(P.out + (size_t)(row - P.row0) * 8, el<Fr, 88 * U>(value.v));
 }
 
 // ------------------------------------------------------------------ entry point
+static int evaluate_h_rows(zkhip_ctx* ctx, const zk_evalh_args* A, size_t first_row, size_t n_rows, void* d_out);
 extern "C" int zkhip_evaluate_h_device(zkhip_ctx* ctx, const zk_evalh_args* A, void* d_out) {
+    if (!A) { set_error("zkhip_evaluate_h_device: null argument"); return ZKHIP_EINVAL; }
+    return evaluate_h_rows(ctx, A, 0, (size_t)1 << (A->extended_k <= 26 ? A->extended_k : 0), d_out);
+}
+extern "C" int zkhip_evaluate_h_rows_device(zkhip_ctx* ctx, const zk_evalh_args* A, size_t first_row, size_t n_rows, void* d_out) {
+    return evaluate_h_rows(ctx, A, first_row, n_rows, d_out);
+}
+static int evaluate_h_rows(zkhip_ctx* ctx, const zk_evalh_args* A, size_t first_row, size_t n_rows, void* d_out) {
     if (!ctx || !A || !d_out) { set_error("zkhip_evaluate_h_device: null argument"); return ZKHIP_EINVAL; }
     if (A->extended_k < A->k || A->extended_k > 26 || A->extended_k < 6) { set_error("zkhip_evaluate_h_device: extended_k = %u unsupported (6..26)", A->extended_k); return ZKHIP_EINVAL; }
     if (A->n_perm_sets && A->cs_degree < 3) { set_error("zkhip_evaluate_h_device: cs_degree < 3 with a permutation argument"); return ZKHIP_EINVAL; }
@@ -492,6 +501,7 @@ extern "C" int zkhip_evaluate_h_device(zkhip_ctx* ctx, const zk_evalh_args* A, v
     P.cols = (const uint32_t* const*)(b + o_cols);
     P.out = (uint32_t*)d_out;
     P.isize_mask = (uint32_t)isize - 1;
+    P.row0 = (uint32_t)first_row;
     P.rot_scale = 1u << (A->extended_k - A->k);
     P.nslots = L.max_slots;
     P.gates = gates;
@@ -516,12 +526,16 @@ extern "C" int zkhip_evaluate_h_device(zkhip_ctx* ctx, const zk_evalh_args* A, v
         P.xt_hi = (const uint32_t*)xt->d_hi;
         P.xt_h = xt->h;
     }
-    const unsigned block = isize >= 128 ? 128 : 64;
+    const unsigned block = n_rows % 128 == 0 ? 128 : 64;
+    if (first_row + n_rows > isize || n_rows == 0 || n_rows % 64) {
+        set_error("zkhip_evaluate_h_rows_device: rows [%zu, %zu) out of the extended domain or not a multiple of 64", first_row, first_row + n_rows);
+        return ZKHIP_EINVAL;
+    }
     size_t lds = (size_t)std::max<uint32_t>(L.max_slots, 1) * 9 * 4 * block;
     if (lds > 160 * 1024) { set_error("zkhip_evaluate_h_device: %u live intermediates exceed the LDS budget", L.max_slots); return ZKHIP_EPROGRAM; }
     if (lds > 64 * 1024) ZK_HIP(hipFuncSetAttribute((const void*)k_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ProfScope ps(ctx, "sweep");
-    hipLaunchKernelGGL(k_sweep, dim3((unsigned)(isize / block)), dim3(block), lds, st, P);
+    hipLaunchKernelGGL(k_sweep, dim3((unsigned)(n_rows / block)), dim3(block), lds, st, P);
     ZK_LAUNCH_CHECK();
     return ZKHIP_OK;
 }

@@ -64,7 +64,7 @@ SYMBOLS = [
     "zkhip_domain_constants", "zkhip_lagrange_to_coeff_device", "zkhip_coeff_to_lagrange_device",
     "zkhip_coeff_to_extended_device", "zkhip_extended_to_coeff_device", "zkhip_divide_by_vanishing_device",
     "zkhip_lagrange_to_coeff", "zkhip_coeff_to_extended", "zkhip_extended_to_coeff",
-    "zkhip_evaluate_h_device", "zkhip_synth_fill_device", "zkhip_synth_small_device",
+    "zkhip_evaluate_h_device", "zkhip_evaluate_h_rows_device", "zkhip_synth_fill_device", "zkhip_synth_small_device",
     "zkhip_batch_invert_device", "zkhip_eval_polynomial_device", "zkhip_eval_polynomials_at_device", "zkhip_permutation_products_device",
     "zkhip_permute_expression_pair_device", "zkhip_lookup_product_device", "zkhip_grand_products_device",
     "zkhip_linear_combination_device", "zkhip_divide_by_linear_device", "zkhip_kate_division_device", "zkhip_shplonk_open",
@@ -708,6 +708,13 @@ class EvalhPack:
                                                                                    self._ptrs(lookup_s))
         self.args = a
         return a
+
+
+def evaluate_h_rows(ctx, pack, first_row, n_rows):
+    """rows [first_row, first_row + n_rows) of evaluate_h (zkhip_evaluate_h_rows_device) -> (n_rows, 4) device tensor"""
+    out = ctx.empty(n_rows)
+    _check(lib().zkhip_evaluate_h_rows_device(ctx.h, C.byref(pack.args), C.c_size_t(first_row), C.c_size_t(n_rows), C.c_void_p(out.data_ptr())))
+    return out
 
 
 def evaluate_h(ctx, pack, extended_n):

@@ -187,6 +187,9 @@ typedef struct {
 
 /* d_out: extended_n x 4 u64 (device).  Asynchronous. */
 int  zkhip_evaluate_h_device(zkhip_ctx* ctx, const zk_evalh_args* args, void* d_out);
+/* the same for the extended rows [first_row, first_row + n_rows) only (n_rows a multiple of 64; d_out holds n_rows elements): the
+ * row-sharded sweep of a proof spread over several GPUs — the columns are complete on every GPU, rotations wrap as usual */
+int  zkhip_evaluate_h_rows_device(zkhip_ctx* ctx, const zk_evalh_args* args, size_t first_row, size_t n_rows, void* d_out);
 
 /* ---- grand products and evaluations: the O(n) field work of create_proof between the commitments ----
  * All columns are DEVICE arrays of n = 2^k ABI field elements; pointer lists are HOST arrays.  Asynchronous.

@@ -114,6 +114,10 @@ class OracleBackend:
         pack.build(**kw)
         return zo.evaluate_h(pack, self.domain.extended_n, self.threads)
 
+    def evaluate_h_rows(self, kw, first_row, n_rows):
+        """the row range of the full sweep (the oracle has no partial entry point: it is the checker, not the shard)"""
+        return self.evaluate_h(kw)[first_row:first_row + n_rows].copy()
+
     def divide_and_to_coeff(self, h):
         h = self.domain.divide_by_vanishing_poly(h)
         return self.domain.extended_to_coeff_full(h, self.threads)

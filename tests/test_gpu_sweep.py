@@ -82,6 +82,26 @@ def test_evaluate_h_vs_oracle(zk, oracle, cfg):
     assert (got == exp).all()
 
 
+def test_evaluate_h_row_ranges(zk, oracle):
+    """zkhip_evaluate_h_rows_device (one rank's share of a row-sharded sweep): uneven 64-multiples of the extended rows, glued
+    together, are the full sweep — rotations read across the range boundaries and wrap around the domain; bad ranges are refused."""
+    ffi, ctx = zk
+    zo = oracle
+    dom, kw = random_circuit(zo, k=8, degree=4, bf=6, n_adv=4, n_fix=3, n_lookups=1, n_perm=6, seed=11)
+    opack = zo.EvalhPack()
+    opack.build(**kw)
+    exp = zo.evaluate_h(opack, dom.extended_n, 8)
+    pack = ffi.EvalhPack()
+    pack.build(**_to_device_kw(ctx, kw))
+    en = dom.extended_n
+    cuts = [0, 64, 64 + 128, en // 2, en - 192, en]
+    parts = [ctx.to_host(ffi.evaluate_h_rows(ctx, pack, a, b - a)) for a, b in zip(cuts, cuts[1:])]
+    assert (np.concatenate(parts) == exp).all()
+    for first, cnt in ((0, 100), (en - 64, 128), (0, 0)):
+        with pytest.raises(ffi.ZkhipError):
+            ffi.evaluate_h_rows(ctx, pack, first, cnt)
+
+
 def test_evaluate_h_rejects_malformed_program(zk, oracle):
     ffi, ctx = zk
     zo = oracle
