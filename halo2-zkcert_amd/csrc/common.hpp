@@ -123,7 +123,9 @@ static inline hipError_t event_wait(hipEvent_t ev) {
     return hipEventSynchronize(ev);
 }
 
+struct zkhip_domain;
 namespace zk {
+int lagrange_to_coeff_oop(zkhip_ctx* ctx, const zkhip_domain* d, const void* const* srcs, void* const* dsts, size_t npolys);
 int permute_expression_pair_async(zkhip_ctx* ctx, uint32_t k, uint32_t blinding_factors, const void* d_input, const void* d_table,
                                   const void* d_blind_in, const void* d_blind_tab, void* d_perm_in, void* d_perm_tab, uint32_t* d_err_flag,
                                   const void* d_sorted_table_keys);

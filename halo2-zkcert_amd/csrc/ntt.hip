@@ -658,6 +658,18 @@ int zkhip_lagrange_to_coeff_device(zkhip_ctx* ctx, const zkhip_domain* d, void* 
     sc.post[0] = sc.post[1] = sc.post[2] = d->ifft_divisor.v;
     return ntt_run(ctx, (const void* const*)polys, polys, npolys, d->omega_inv_abi, d->k, 1u << d->k, sc);
 }
+}  // extern "C" (reopened below)
+// lagrange_to_coeff from src to dst (src untouched): the prover keeps the Lagrange form too, so this replaces a copy + in-place pass
+namespace zk {
+int lagrange_to_coeff_oop(zkhip_ctx* ctx, const zkhip_domain* d, const void* const* srcs, void* const* dsts, size_t npolys) {
+    if (!ctx || !d || !srcs || !dsts) { set_error("lagrange_to_coeff_oop: null argument"); return ZKHIP_EINVAL; }
+    NttScale sc = no_scale();
+    sc.use_post = 1;
+    sc.post[0] = sc.post[1] = sc.post[2] = d->ifft_divisor.v;
+    return ntt_run(ctx, srcs, dsts, npolys, d->omega_inv_abi, d->k, 1u << d->k, sc);
+}
+}  // namespace zk
+extern "C" {
 int zkhip_coeff_to_extended_device(zkhip_ctx* ctx, const zkhip_domain* d, const void* const* in, size_t n_in, void* const* out,
                                    size_t npolys) {
     if (!ctx || !d || !in || !out) { set_error("zkhip_coeff_to_extended_device: null argument"); return ZKHIP_EINVAL; }

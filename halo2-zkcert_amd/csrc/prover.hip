@@ -151,10 +151,10 @@ extern "C" int zkhip_create_proof(zkhip_ctx* ctx, const zk_proving_key* pk, cons
         ov.arm();
         ZK_TRY(commit_launch(cols, bases));
         ZK_TRY(ov.begin_marked());
-        for (uint32_t j = 0; j < A + I; ++j)
-            ZK_HIP(hipMemcpyAsync(coeff_ptrs[j], j < A ? d_advice[j] : d_instance[j - A], NB, hipMemcpyDeviceToDevice, ctx->stream));
         if (A + I) {
-            ZK_TRY(zkhip_lagrange_to_coeff_device(ctx, pk->domain, coeff_ptrs.data(), A + I));
+            std::vector<const void*> lag(A + I);   // out of place: the witness columns stay in Lagrange form, no copy
+            for (uint32_t j = 0; j < A + I; ++j) lag[j] = j < A ? d_advice[j] : d_instance[j - A];
+            ZK_TRY(zk::lagrange_to_coeff_oop(ctx, pk->domain, lag.data(), coeff_ptrs.data(), A + I));
             ZK_TRY(zkhip_coeff_to_extended_device(ctx, pk->domain, (const void* const*)coeff_ptrs.data(), n, ext_ptrs.data(), A + I));
         }
         ov.end();
@@ -200,8 +200,11 @@ extern "C" int zkhip_create_proof(zkhip_ctx* ctx, const zk_proving_key* pk, cons
     }
     for (uint32_t j = 0; j < 2 * L; ++j) { perm_c[j] = w_perm_c + j * NB; ext_perm[j] = w_ext_perm + j * EB; }
     if (L) {
-        ZK_HIP(hipMemcpyAsync(w_perm_c, w_perm_l, 2 * L * NB, hipMemcpyDeviceToDevice, st));
-        ZK_TRY(zkhip_lagrange_to_coeff_device(ctx, pk->domain, perm_c.data(), 2 * L));
+        {
+            std::vector<const void*> lag(2 * L);
+            for (uint32_t j = 0; j < 2 * L; ++j) lag[j] = w_perm_l + j * NB;
+            ZK_TRY(zk::lagrange_to_coeff_oop(ctx, pk->domain, lag.data(), perm_c.data(), 2 * L));
+        }
         std::vector<const void*> cols(perm_c.begin(), perm_c.end());
         std::vector<const zkhip_srs*> bases(2 * L, pk->g);
         // the failure flag rides on the commitment's read-back: it must be known before anything enters the transcript
