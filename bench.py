@@ -63,8 +63,8 @@ def cpu_baseline(shape, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--k", type=int, default=17)
     ap.add_argument("--shape", default="rsa", choices=["rsa", "sha256"], help="circuit shape (BASELINE configs[1] / configs[2])")
     ap.add_argument("--witness", default="uniform", choices=["uniform", "survey"],
