@@ -225,6 +225,42 @@ __global__ void k_pe_finish(const uint32_t* A, const uint32_t* leftover, const u
     store_from_canonical(perm_tab + row * 8, key_load(leftover + (size_t)idx * 8));
 }
 
+// ---- fast path for a table whose sorted keys are already there (a fixed range table): every input value must occur in the table,
+// so its position in the SORTED TABLE is a small integer sort key — one binary search per row, then a counting sort, instead of a
+// bitonic network over 256-bit keys.
+// rank[row] = first sorted-table index holding the row's value (err |= 1 if there is none); hist[rank]++
+__global__ void k_pe_rank(const uint32_t* input, const uint32_t* T, size_t usable, uint32_t* rank, uint32_t* hist, uint32_t* err) {
+    size_t row = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (row >= usable) return;
+    fe32 m = abi_to_canonical_words<Fr>(mem_load(input + row * 8));
+    key256 a;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a.w[i] = m.w[i];
+    size_t lo = 0, hi = usable;   // first table entry >= a
+    while (lo < hi) {
+        size_t mid = (lo + hi) >> 1;
+        if (key_less(key_load(T + mid * 8), a)) lo = mid + 1; else hi = mid;
+    }
+    if (lo >= usable || !key_eq(key_load(T + lo * 8), a)) { atomicOr(err, 1u); rank[row] = 0xffffffffu; return; }
+    rank[row] = (uint32_t)lo;
+    atomicAdd(&hist[lo], 1u);
+}
+// index t plays two roles: as a ROW it scatters its key to its place in the sorted input (start[rank] + arrival order; equal keys
+// are interchangeable) and flags the place as a repeat unless it is the run's first; as a TABLE SLOT it is left over iff no row
+// took its value
+__global__ void k_pe_place(const uint32_t* T, const uint32_t* rank, const uint32_t* hist, const uint32_t* start, uint32_t* cursor,
+                           size_t usable, uint32_t* A_sorted, uint32_t* rep_flag, uint32_t* left_flag) {
+    size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (t >= usable) return;
+    left_flag[t] = hist[t] ? 0u : 1u;
+    uint32_t r = rank[t];
+    if (r == 0xffffffffu) return;   // not in the table: the failure flag is already set, the outputs are void
+    uint32_t s0 = start[r];
+    uint32_t pos = s0 + atomicAdd(&cursor[r], 1u);
+    key_store(A_sorted + (size_t)pos * 8, key_load(T + (size_t)r * 8));
+    rep_flag[pos] = pos != s0 ? 1u : 0u;
+}
+
 namespace zk {
 // Asynchronous form for the library's own schedule: the failure flag (non-zero = ConstraintSystemFailure) is OR-ed into *d_err_flag,
 // which the caller zeroes beforehand and reads at its next synchronisation point.
@@ -285,13 +321,27 @@ int zk::permute_expression_pair_async(zkhip_ctx* ctx, uint32_t k, uint32_t blind
     ZK_TRY(ctx->get_scratch("pe_flags", 2 * n * 4, &d_flags));
     ZK_TRY(ctx->get_scratch("pe_ranks", 2 * n * 4, &d_ranks));
     ZK_TRY(ctx->get_scratch("pe_left", n * 32, &d_left));
-    ZK_TRY(ctx->get_scratch("pe_misc", 16, &d_misc));   // totals[2]
+    ZK_TRY(ctx->get_scratch("pe_misc", 16, &d_misc));   // totals[2] (+ one unused total of the rank path)
     uint32_t* rep_flag = (uint32_t*)d_flags; uint32_t* left_flag = rep_flag + n;
     uint32_t* rep_rank = (uint32_t*)d_ranks; uint32_t* left_rank = rep_rank + n;
     uint32_t* totals = (uint32_t*)d_misc;
     ProfScope ps(ctx, "lookup_permute");
     ZK_HIP(hipMemsetAsync(d_misc, 0, 16, st));
     unsigned g = div_up(n, 256);
+    static const bool rank_sort = !(getenv("ZKHIP_PERMUTE_RANK_SORT") && atoi(getenv("ZKHIP_PERMUTE_RANK_SORT")) == 0);
+    if (d_sorted_table_keys && rank_sort) {
+        // a fixed table sorted once at first use: rank every row in it and counting-sort the ranks (see k_pe_rank)
+        dT = const_cast<void*>(d_sorted_table_keys);
+        void* d_cnt;
+        ZK_TRY(ctx->get_scratch("pe_rank", 4 * n * 4, &d_cnt));   // rank, hist, cursor, start
+        uint32_t* rank = (uint32_t*)d_cnt; uint32_t* hist = rank + n; uint32_t* cursor = hist + n; uint32_t* start = cursor + n;
+        ZK_HIP(hipMemsetAsync(hist, 0, 2 * n * 4, st));
+        ZK_HIP(hipMemsetAsync(rep_flag, 0, n * 4, st));
+        hipLaunchKernelGGL(k_pe_rank, dim3(div_up(usable, 256)), dim3(256), 0, st, (const uint32_t*)d_input, (const uint32_t*)dT, usable, rank, hist, err);
+        ZK_TRY(scan_u32(ctx, hist, usable, start, totals + 2, "pe_sums_h"));
+        hipLaunchKernelGGL(k_pe_place, dim3(div_up(usable, 256)), dim3(256), 0, st, (const uint32_t*)dT, rank, hist, start, cursor, usable,
+                           (uint32_t*)dA, rep_flag, left_flag);
+    } else {
     hipLaunchKernelGGL(k_pe_keys, dim3(div_up(np, 256)), dim3(256), 0, st, (const uint32_t*)d_input, np, usable, (uint32_t*)dA);
     if (d_sorted_table_keys) {   // a fixed table sorted once at first use: only the input column is sorted per proof
         dT = const_cast<void*>(d_sorted_table_keys);
@@ -303,6 +353,7 @@ int zk::permute_expression_pair_async(zkhip_ctx* ctx, uint32_t k, uint32_t blind
     hipLaunchKernelGGL(k_fill_u32, dim3(g), dim3(256), 0, st, left_flag, n, 1u);
     ZK_HIP(hipMemsetAsync(rep_flag, 0, n * 4, st));
     hipLaunchKernelGGL(k_pe_mark, dim3(div_up(usable, 256)), dim3(256), 0, st, (const uint32_t*)dA, (const uint32_t*)dT, usable, rep_flag, left_flag, err);
+    }
     ZK_TRY(scan_u32(ctx, rep_flag, usable, rep_rank, totals, "pe_sums_a"));
     ZK_TRY(scan_u32(ctx, left_flag, usable, left_rank, totals + 1, "pe_sums_b"));
     hipLaunchKernelGGL(k_pe_compact, dim3(div_up(usable, 256)), dim3(256), 0, st, (const uint32_t*)dT, left_flag, left_rank, usable, (uint32_t*)d_left);
