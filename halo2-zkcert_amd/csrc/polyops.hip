@@ -220,25 +220,28 @@ __global__ void __launch_bounds__(256) k_lookup_terms(const uint32_t* a, const u
 // ------------------------------------------------------------------ evaluation at a point
 // partial[poly][blk] = sum_{i in tile} c_i x^(i - tile_start)   (coefficients loaded raw: the sum is linear in them)
 // xs: raw R'-form points, one per polynomial
+// PER coefficients per thread: the block tree (8 levels of a product and a squaring by every thread) is a fixed cost per thread, so
+// long polynomials use 32 (1.5 products per coefficient instead of 2.6)
+template <int PER>
 __global__ void __launch_bounds__(PO_BLOCK) k_eval_tiles(const uint32_t* const* polys, size_t n, const uint32_t* xs, uint32_t* partial_all, uint32_t nblk) {
     __shared__ fe sc[PO_BLOCK];
     const uint32_t t = threadIdx.x, poly = blockIdx.y;
     const uint32_t* c = polys[poly];
     const el2<Fr> x = load_raw<Fr>(xs + (size_t)poly * 8);
-    const size_t lo = (size_t)blockIdx.x * PO_TILE + (size_t)t * PO_PER;
-    // Horner over this thread's 8 coefficients
+    const size_t lo = (size_t)blockIdx.x * (PER * PO_BLOCK) + (size_t)t * PER;
+    // Horner over this thread's PER coefficients
     el<Fr, 4 * U> acc = zero<Fr>();
 #pragma unroll
-    for (int j = PO_PER - 1; j >= 0; --j) {
+    for (int j = PER - 1; j >= 0; --j) {
         el1<Fr> cj = zero<Fr>();
         if (lo + j < n) cj = load_raw<Fr>(c + (lo + j) * 8);
         acc = acc * x + cj;
     }
     sc[t] = acc.v;
-    // x^8, then pairwise: left + right * x^(8 * span)
+    // x^PER, then pairwise: left + right * x^(PER * span)
     el2<Fr> xp = x;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) xp = sqr(xp);
+    for (int q = 1; q < PER; q <<= 1) xp = sqr(xp);
     __syncthreads();
     for (uint32_t span = 1; span < PO_BLOCK; span <<= 1) {
         if ((t & (2 * span - 1)) == 0) sc[t] = (el<Fr, 4 * U>(sc[t]) + el<Fr, 4 * U>(sc[t + span]) * xp).v;   // < 4p + 2p: contract below
@@ -249,12 +252,12 @@ __global__ void __launch_bounds__(PO_BLOCK) k_eval_tiles(const uint32_t* const* 
     }
     if (t == 0) store_raw<Fr>(partial_all + ((size_t)poly * nblk + blockIdx.x) * 8, el2<Fr>(sc[0]));
 }
-// out[poly] = sum_b partial[poly][b] * x^(2048 b), one block per polynomial
-__global__ void __launch_bounds__(PO_BLOCK) k_eval_final(const uint32_t* partial_all, uint32_t nblk, const uint32_t* xs, uint32_t* out) {
+// out[poly] = sum_b partial[poly][b] * x^(tile b), one block per polynomial
+__global__ void __launch_bounds__(PO_BLOCK) k_eval_final(const uint32_t* partial_all, uint32_t nblk, const uint32_t* xs, uint32_t* out, uint32_t tile) {
     __shared__ fe sc[PO_BLOCK];
     const uint32_t t = threadIdx.x, poly = blockIdx.x;
     const uint32_t* part = partial_all + (size_t)poly * nblk * 8;
-    el2<Fr> xt = pow_u64<Fr>(el2<Fr>(load_raw<Fr>(xs + (size_t)poly * 8)), PO_TILE);   // x^2048
+    el2<Fr> xt = pow_u64<Fr>(el2<Fr>(load_raw<Fr>(xs + (size_t)poly * 8)), tile);   // x^tile
     el2<Fr> step = pow_u64<Fr>(xt, PO_BLOCK);                        // x^(2048 * 256)
     el2<Fr> xw = pow_u64<Fr>(xt, t);                                 // x^(2048 t)
     el<Fr, 4 * U> acc = zero<Fr>();
@@ -314,7 +317,8 @@ int zkhip_batch_invert_device(zkhip_ctx* ctx, void* d_a, size_t n) {
 static int eval_at(zkhip_ctx* ctx, const void* const* d_polys, size_t npolys, size_t n, const uint64_t* xs_host, void* d_out) {
     if (npolys == 0) return ZKHIP_OK;
     if (n == 0) { ZK_HIP(hipMemsetAsync(d_out, 0, npolys * 32, ctx->stream)); return ZKHIP_OK; }
-    uint32_t nblk = div_up(n, PO_TILE);
+    const uint32_t per = n >= ((size_t)1 << 16) ? 32 : PO_PER, tile = per * PO_BLOCK;
+    uint32_t nblk = div_up(n, tile);
     void *d_ptrs, *d_part, *d_xs;
     ZK_TRY(ctx->get_scratch("po_eval_ptrs", npolys * sizeof(void*), &d_ptrs));
     ZK_TRY(ctx->get_scratch("po_eval_part", npolys * (size_t)nblk * 32, &d_part));
@@ -324,10 +328,14 @@ static int eval_at(zkhip_ctx* ctx, const void* const* d_polys, size_t npolys, si
     ZK_TRY(ctx->upload(d_ptrs, d_polys, npolys * sizeof(void*)));
     ZK_TRY(ctx->upload(d_xs, xs.data(), npolys * 32));
     ProfScope ps(ctx, "eval_polynomial");
-    hipLaunchKernelGGL(k_eval_tiles, dim3(nblk, (unsigned)npolys), dim3(PO_BLOCK), 0, ctx->stream, (const uint32_t* const*)d_ptrs, n,
-                       (const uint32_t*)d_xs, (uint32_t*)d_part, nblk);
+    if (per == 32)
+        hipLaunchKernelGGL(k_eval_tiles<32>, dim3(nblk, (unsigned)npolys), dim3(PO_BLOCK), 0, ctx->stream, (const uint32_t* const*)d_ptrs, n,
+                           (const uint32_t*)d_xs, (uint32_t*)d_part, nblk);
+    else
+        hipLaunchKernelGGL(k_eval_tiles<PO_PER>, dim3(nblk, (unsigned)npolys), dim3(PO_BLOCK), 0, ctx->stream, (const uint32_t* const*)d_ptrs, n,
+                           (const uint32_t*)d_xs, (uint32_t*)d_part, nblk);
     hipLaunchKernelGGL(k_eval_final, dim3((unsigned)npolys), dim3(PO_BLOCK), 0, ctx->stream, (const uint32_t*)d_part, nblk, (const uint32_t*)d_xs,
-                       (uint32_t*)d_out);
+                       (uint32_t*)d_out, tile);
     ZK_LAUNCH_CHECK();
     return ZKHIP_OK;
 }
