@@ -31,16 +31,17 @@ struct zkhip_srs {
 static uint32_t pick_window(size_t n) {
     if (const char* e = getenv("ZKHIP_MSM_C")) {
         int v = atoi(e);
-        if (v >= 2 && v <= 19) return (uint32_t)v;
+        if (v >= 2 && v <= 20) return (uint32_t)v;
     }
     uint32_t lg = 0;
     while (((size_t)1 << lg) < n) ++lg;
     // measured on MI355X (profiles/): 2^17 -> 16 (16 windows), 2^19 -> 17 (15 windows, 15 * 17 = 255 bits: no short top window
-    // whose few digit values would pile a third of the points into four buckets), 2^22 -> 19 (14 windows; the sort's low
-    // radix pass holds at most 2^11 bins, so 19 is the largest supported)
+    // whose few digit values would pile a third of the points into four buckets), 2^20..2^21 -> 19 (14 windows), >= 2^22 -> 20
+    // (13 windows and a 14-bit top window: -6 % against 19, whose 7-bit top window fills 64 buckets with 1/14 of all pairs and
+    // forces reduction rounds; the sort's passes hold 2^8 partitions x 2^11 bins, so 20 is the largest supported)
     int c = (int)lg - 1;
     if (c < 3) c = 3;
-    if (c > 16) c = lg >= 20 ? 19 : 17;
+    if (c > 16) c = lg >= 22 ? 20 : (lg >= 20 ? 19 : 17);
     return (uint32_t)c;
 }
 
@@ -159,6 +160,8 @@ int srs_build_raw(zkhip_ctx* ctx, const void* d_bases_raw, size_t n, zkhip_srs**
 // 4-byte scatter over the whole n*W range, which made the first version memory-bound at 2^22, are gone.
 struct SortGeom { uint32_t c, W, B, HB, LB, P, tile; };   // tile: pairs of one partition handled by one workgroup of the low pass
 #define SORT_TILE 4096u
+#define SORT_MAXP 256u     // partitions of the high radix pass (HB <= 8)
+#define SORT_PSTRIDE 260u  // part_off / tile_start: P + 1 entries per column, padded
 
 extern __shared__ uint32_t sort_lds[];   // staging area of the two scatter kernels
 
@@ -178,12 +181,12 @@ __global__ void __launch_bounds__(256) k_sort_hi(const uint32_t* const* scalar_c
                                                  uint32_t* part_cnt_all, uint32_t* part_cursor_all, const uint32_t* part_off_all,
                                                  uint32_t* tmp_entry_all, uint16_t* tmp_key_all, size_t items) {
     __shared__ uint32_t sl[256][9];
-    __shared__ uint32_t hist[128], base[128], cnt_of[128];
+    __shared__ uint32_t hist[SORT_MAXP], base[SORT_MAXP], cnt_of[SORT_MAXP];
     const uint32_t tid = threadIdx.x, col = blockIdx.y;
     const bool staged = SCATTER && g.W <= 24;   // 256 W pairs x 7 bytes of dynamic LDS
     size_t i = blockIdx.x * (size_t)256 + tid;
     const bool live = i < n;
-    if (tid < 128) hist[tid] = 0;
+    hist[tid] = 0;   // 256 threads, SORT_MAXP = 256
     if (live) {
         fe32 sc = abi_to_canonical_words<Fr>(mem_load(scalar_cols[col] + (first + i) * 8));
 #pragma unroll
@@ -200,14 +203,14 @@ __global__ void __launch_bounds__(256) k_sort_hi(const uint32_t* const* scalar_c
         }
     }
     __syncthreads();
-    uint32_t* part_cnt = part_cnt_all + (size_t)col * 128;
+    uint32_t* part_cnt = part_cnt_all + (size_t)col * SORT_MAXP;
     if (!SCATTER) {
         if (tid < g.P && hist[tid]) atomicAdd(&part_cnt[tid], hist[tid]);
         return;
     }
     if (tid < g.P) {
         uint32_t h = hist[tid];
-        base[tid] = h ? part_off_all[(size_t)col * 132 + tid] + atomicAdd(&part_cursor_all[(size_t)col * 128 + tid], h) : 0u;
+        base[tid] = h ? part_off_all[(size_t)col * SORT_PSTRIDE + tid] + atomicAdd(&part_cursor_all[(size_t)col * SORT_MAXP + tid], h) : 0u;
         cnt_of[tid] = h;
         hist[tid] = 0;
     }
@@ -230,11 +233,11 @@ __global__ void __launch_bounds__(256) k_sort_hi(const uint32_t* const* scalar_c
         return;
     }
     // staged: group the block's pairs by partition inside LDS, then store every partition's run with consecutive lanes
-    __shared__ uint32_t lst[129];
+    __shared__ uint32_t lst[SORT_MAXP + 1];
     uint32_t* st_e = sort_lds;                                                // [256 W]
     uint16_t* st_k = reinterpret_cast<uint16_t*>(st_e + 256 * g.W);           // [256 W]
     uint8_t* st_p = reinterpret_cast<uint8_t*>(st_k + 256 * g.W);             // [256 W]
-    if (tid == 0) {   // <= 128 partitions: a serial scan is cheaper than a barrier tree
+    if (tid == 0) {   // <= 256 partitions: a serial scan is cheaper than a barrier tree
         uint32_t run = 0;
         for (uint32_t p = 0; p < g.P; ++p) { lst[p] = run; run += cnt_of[p]; }
         lst[g.P] = run;
@@ -266,21 +269,21 @@ __global__ void __launch_bounds__(256) k_sort_hi(const uint32_t* const* scalar_c
 }
 
 // part_off = exclusive scan of part_cnt (P + 1 entries); tile_start = exclusive scan of ceil(part_cnt / tile).
-__global__ void __launch_bounds__(128) k_part_scan(const uint32_t* part_cnt_all, uint32_t P, uint32_t tile, uint32_t* part_off_all, uint32_t* tile_start_all) {
-    __shared__ uint32_t a[128], b[128];
+__global__ void __launch_bounds__(SORT_MAXP) k_part_scan(const uint32_t* part_cnt_all, uint32_t P, uint32_t tile, uint32_t* part_off_all, uint32_t* tile_start_all) {
+    __shared__ uint32_t a[SORT_MAXP], b[SORT_MAXP];
     uint32_t col = blockIdx.x, t = threadIdx.x;
-    uint32_t v = t < P ? part_cnt_all[(size_t)col * 128 + t] : 0u;
+    uint32_t v = t < P ? part_cnt_all[(size_t)col * SORT_MAXP + t] : 0u;
     uint32_t tl = (v + tile - 1) / tile;
     a[t] = v; b[t] = tl;
     __syncthreads();
-    for (uint32_t d = 1; d < 128; d <<= 1) {
+    for (uint32_t d = 1; d < SORT_MAXP; d <<= 1) {
         uint32_t x = t >= d ? a[t - d] : 0u, y = t >= d ? b[t - d] : 0u;
         __syncthreads();
         a[t] += x; b[t] += y;
         __syncthreads();
     }
-    uint32_t* po = part_off_all + (size_t)col * 132;
-    uint32_t* ts = tile_start_all + (size_t)col * 132;
+    uint32_t* po = part_off_all + (size_t)col * SORT_PSTRIDE;
+    uint32_t* ts = tile_start_all + (size_t)col * SORT_PSTRIDE;
     if (t < P) { po[t] = a[t] - v; ts[t] = b[t] - tl; }
     if (t == P - 1) { po[P] = a[t]; ts[P] = b[t]; }
 }
@@ -290,8 +293,8 @@ __global__ void __launch_bounds__(256) k_sort_lo_count(const uint32_t* part_off_
                                                        const uint16_t* tmp_key_all, size_t items, uint32_t* cnt_all) {
     __shared__ uint32_t hist[2048];
     const uint32_t tid = threadIdx.x, col = blockIdx.y, blk = blockIdx.x;
-    const uint32_t* po = part_off_all + (size_t)col * 132;
-    const uint32_t* ts = tile_start_all + (size_t)col * 132;
+    const uint32_t* po = part_off_all + (size_t)col * SORT_PSTRIDE;
+    const uint32_t* ts = tile_start_all + (size_t)col * SORT_PSTRIDE;
     if (blk >= ts[g.P]) return;
     uint32_t lo_p = 0, hi_p = g.P;   // largest p with ts[p] <= blk
     while (hi_p - lo_p > 1) {
@@ -320,8 +323,8 @@ __global__ void __launch_bounds__(256) k_sort_lo_staged(const uint32_t* part_off
                                                         const uint32_t* off_all, uint32_t* cursor_all, uint32_t* entries_all) {
     __shared__ uint32_t w_tot[4];
     const uint32_t tid = threadIdx.x, col = blockIdx.y, blk = blockIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t* po = part_off_all + (size_t)col * 132;
-    const uint32_t* ts = tile_start_all + (size_t)col * 132;
+    const uint32_t* po = part_off_all + (size_t)col * SORT_PSTRIDE;
+    const uint32_t* ts = tile_start_all + (size_t)col * SORT_PSTRIDE;
     if (blk >= ts[g.P]) return;
     uint32_t lo_p = 0, hi_p = g.P;   // largest p with ts[p] <= blk
     while (hi_p - lo_p > 1) {
@@ -389,8 +392,8 @@ __global__ void __launch_bounds__(256) k_sort_lo_staged16(const uint32_t* part_o
                                                           const uint32_t* off_all, uint32_t* cursor_all, uint32_t* entries_all) {
     __shared__ uint32_t w_tot[4];
     const uint32_t tid = threadIdx.x, col = blockIdx.y, blk = blockIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t* po = part_off_all + (size_t)col * 132;
-    const uint32_t* ts = tile_start_all + (size_t)col * 132;
+    const uint32_t* po = part_off_all + (size_t)col * SORT_PSTRIDE;
+    const uint32_t* ts = tile_start_all + (size_t)col * SORT_PSTRIDE;
     if (blk >= ts[g.P]) return;
     uint32_t lo_p = 0, hi_p = g.P;   // largest p with ts[p] <= blk
     while (hi_p - lo_p > 1) {
@@ -951,26 +954,26 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
     SortGeom g;
     g.c = c; g.W = W; g.B = B;
     const uint32_t KB = c - 1;
-    g.HB = KB > 8 ? 7 : KB / 2;
+    g.HB = KB > 18 ? 8 : (KB > 8 ? 7 : KB / 2);
     g.LB = KB - g.HB;
     g.P = 1u << g.HB;
     // Measured at 2^22 (2^11 bins): tiles of 16k / 32k / 64k pairs, which lengthen the scatter's contiguous runs from 8 to
     // 32-128 bytes, are 18-26 % SLOWER than 4096-pair tiles — the low pass is bound by its LDS rank atomics, not by run length.
     g.tile = g.LB >= 11 ? 2 * SORT_TILE : SORT_TILE;   // 2048 bins (c = 19, n >= 2^20): 8192-pair tiles, 16-byte runs (digits -13 % at 2^22)
     if (const char* e = getenv("ZKHIP_SORT_TILE")) { int v = atoi(e); if (v >= 1024 && v <= (1 << 20)) g.tile = (uint32_t)v; }
-    if (g.LB > 11) { set_error("zkhip_msm: window c = %u unsupported by the sort (max 19)", c); return ZKHIP_EINVAL; }
+    if (g.LB > 11) { set_error("zkhip_msm: window c = %u unsupported by the sort (max 20)", c); return ZKHIP_EINVAL; }
     ZK_TRY(ctx->get_scratch("msm_colptrs", 2 * ncols * sizeof(void*), &d_colptrs));
-    // zeroed every call: part_cnt[128] + part_cursor[128] + cnt[B] + cursor[B] per column
-    const size_t zero_words = ncols * (256 + 2 * (size_t)B);
+    // zeroed every call: part_cnt[SORT_MAXP] + part_cursor[SORT_MAXP] + cnt[B] + cursor[B] per column
+    const size_t zero_words = ncols * (2 * (size_t)SORT_MAXP + 2 * (size_t)B);
     ZK_TRY(ctx->get_scratch("msm_zero", zero_words * 4, &d_zero));
     uint32_t* d_part_cnt = (uint32_t*)d_zero;
-    uint32_t* d_part_cursor = d_part_cnt + ncols * 128;
-    uint32_t* d_cnt = d_part_cursor + ncols * 128;
+    uint32_t* d_part_cursor = d_part_cnt + ncols * SORT_MAXP;
+    uint32_t* d_cnt = d_part_cursor + ncols * SORT_MAXP;
     uint32_t* d_cursor = d_cnt + ncols * (size_t)B;
     void* d_part;
-    ZK_TRY(ctx->get_scratch("msm_part", ncols * 264 * 4, &d_part));   // part_off[132] + tile_start[132] per column
+    ZK_TRY(ctx->get_scratch("msm_part", ncols * 2 * SORT_PSTRIDE * 4, &d_part));   // part_off + tile_start, SORT_PSTRIDE each per column
     uint32_t* d_part_off = (uint32_t*)d_part;
-    uint32_t* d_tile_start = d_part_off + ncols * 132;
+    uint32_t* d_tile_start = d_part_off + ncols * SORT_PSTRIDE;
     ZK_TRY(ctx->get_scratch("msm_off", ncols * (B + 4) * 4, &d_off));
     ZK_TRY(ctx->get_scratch("msm_tmp_entry", ncols * items * 4, &d_tmp_entry));
     ZK_TRY(ctx->get_scratch("msm_tmp_key", ncols * items * 2, &d_tmp_key));
@@ -1015,7 +1018,7 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
     { ProfScope ps(ctx, "msm_digits");
     hipLaunchKernelGGL(k_sort_hi<false>, gn, dim3(256), 0, st, (const uint32_t* const*)d_colptrs, n, first, srs->n, g, d_part_cnt, d_part_cursor,
                        (const uint32_t*)d_part_off, (uint32_t*)d_tmp_entry, (uint16_t*)d_tmp_key, items);
-    hipLaunchKernelGGL(k_part_scan, dim3((unsigned)ncols), dim3(128), 0, st, (const uint32_t*)d_part_cnt, g.P, g.tile, d_part_off, d_tile_start);
+    hipLaunchKernelGGL(k_part_scan, dim3((unsigned)ncols), dim3(SORT_MAXP), 0, st, (const uint32_t*)d_part_cnt, g.P, g.tile, d_part_off, d_tile_start);
     hipLaunchKernelGGL(k_sort_hi<true>, gn, dim3(256), g.W <= 24 ? (size_t)256 * g.W * 7 + 16 : 0, st, (const uint32_t* const*)d_colptrs, n, first, srs->n, g, d_part_cnt, d_part_cursor,
                        (const uint32_t*)d_part_off, (uint32_t*)d_tmp_entry, (uint16_t*)d_tmp_key, items);
     hipLaunchKernelGGL(k_sort_lo_count, gt, dim3(256), 0, st, (const uint32_t*)d_part_off, (const uint32_t*)d_tile_start, g,
