@@ -954,7 +954,8 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
     SortGeom g;
     g.c = c; g.W = W; g.B = B;
     const uint32_t KB = c - 1;
-    g.HB = KB > 18 ? 8 : (KB > 8 ? 7 : KB / 2);
+    g.HB = KB >= 18 ? 8 : (KB > 8 ? 7 : KB / 2);   // 256 partitions from c = 19 (measured: digits -14 % at 2^20, -8 % at 2^21)
+    if (const char* e = getenv("ZKHIP_SORT_HB")) { int v = atoi(e); if (v >= 1 && v <= 8 && v < (int)KB && (int)KB - v <= 11) g.HB = (uint32_t)v; }
     g.LB = KB - g.HB;
     g.P = 1u << g.HB;
     // Measured at 2^22 (2^11 bins): tiles of 16k / 32k / 64k pairs, which lengthen the scatter's contiguous runs from 8 to
