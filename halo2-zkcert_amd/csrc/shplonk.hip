@@ -40,6 +40,13 @@ __global__ void __launch_bounds__(256) k_lincomb(const LcArgs A, uint32_t npolys
     el1<Fr> acc = zero<Fr>();
     if (accumulate) acc = load_raw<Fr>(out + i * 8);
     uint32_t j = 0;
+    for (; j + 8 <= npolys; j += 8) {   // eight loads in flight, one contraction per eight terms (8 x 2p + p < 126 p)
+        auto t = load_raw<Fr>(A.p[j] + i * 8) * el1<Fr>(sc[j]) + load_raw<Fr>(A.p[j + 1] + i * 8) * el1<Fr>(sc[j + 1]) +
+                 load_raw<Fr>(A.p[j + 2] + i * 8) * el1<Fr>(sc[j + 2]) + load_raw<Fr>(A.p[j + 3] + i * 8) * el1<Fr>(sc[j + 3]) +
+                 load_raw<Fr>(A.p[j + 4] + i * 8) * el1<Fr>(sc[j + 4]) + load_raw<Fr>(A.p[j + 5] + i * 8) * el1<Fr>(sc[j + 5]) +
+                 load_raw<Fr>(A.p[j + 6] + i * 8) * el1<Fr>(sc[j + 6]) + load_raw<Fr>(A.p[j + 7] + i * 8) * el1<Fr>(sc[j + 7]);
+        acc = canonical(acc + t);
+    }
     for (; j + 4 <= npolys; j += 4) {
         auto t = load_raw<Fr>(A.p[j] + i * 8) * el1<Fr>(sc[j]) + load_raw<Fr>(A.p[j + 1] + i * 8) * el1<Fr>(sc[j + 1]) +
                  load_raw<Fr>(A.p[j + 2] + i * 8) * el1<Fr>(sc[j + 2]) + load_raw<Fr>(A.p[j + 3] + i * 8) * el1<Fr>(sc[j + 3]);
