@@ -17,7 +17,9 @@
 #include "hostfield.hpp"
 using namespace zk;
 
-#define SP_PER 8
+#define SP_PER 16
+#define SP_PER_LOG 4
+#define SP_TILE_LOG 12
 #define SP_BLOCK 256
 #define SP_TILE (SP_PER * SP_BLOCK)
 #define LC_MAX 64   // polynomials per linear-combination launch
@@ -96,7 +98,7 @@ __global__ void __launch_bounds__(SP_BLOCK) k_kd_totals(const KdArgs K, size_t n
     sc[t] = canonical(s).v;
     el2<Fr> m = r;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) m = sqr(m);   // r^8
+    for (int q = 0; q < SP_PER_LOG; ++q) m = sqr(m);   // r^SP_PER
     __syncthreads();
     suffix_scan_256(sc, t, m);
     if (t == 0) mem_store(tot_all + ((size_t)e * nblk + blockIdx.x) * 8, fe_pack(sc[0]));
@@ -108,7 +110,7 @@ __global__ void __launch_bounds__(SP_BLOCK) k_kd_carries(const KdArgs K, uint32_
     const uint32_t* tot = tot_all + (size_t)e * nblk * 8;
     uint32_t* carry = carry_all + (size_t)e * nblk * 8;
     el2<Fr> M = el1<Fr>(fe_split<0>(K.e[e].r));
-    for (int q = 0; q < 11; ++q) M = sqr(M);   // r^2048
+    for (int q = 0; q < SP_TILE_LOG; ++q) M = sqr(M);   // r^SP_TILE
     const uint32_t c = (nblk + SP_BLOCK - 1) / SP_BLOCK;
     const uint32_t lo = min(nblk, t * c), hi = min(nblk, lo + c);
     el<Fr, 4 * U> s = zero<Fr>();
@@ -133,7 +135,7 @@ __global__ void __launch_bounds__(SP_BLOCK) k_kd_apply(const KdArgs K, size_t n,
     const size_t lo = (size_t)blockIdx.x * SP_TILE + (size_t)t * SP_PER;
     el1<Fr> v[SP_PER];
     el<Fr, 4 * U> s = zero<Fr>();
-#pragma unroll
+#pragma clang loop unroll(full)
     for (int j = SP_PER - 1; j >= 0; --j) {
         v[j] = zero<Fr>();
         if (lo + j < n) v[j] = load_raw<Fr>(a + (lo + j) * 8);
@@ -141,7 +143,7 @@ __global__ void __launch_bounds__(SP_BLOCK) k_kd_apply(const KdArgs K, size_t n,
     }
     el2<Fr> m = r;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) m = sqr(m);   // r^8
+    for (int q = 0; q < SP_PER_LOG; ++q) m = sqr(m);   // r^SP_PER
     const el1<Fr> cb = load_raw<Fr>(carry_all + ((size_t)e * nblk + blockIdx.x) * 8);
     el1<Fr> agg = canonical(s);
     if (t == SP_BLOCK - 1) agg = canonical(agg + cb * m);   // the tile's carry enters above its last thread
@@ -149,7 +151,7 @@ __global__ void __launch_bounds__(SP_BLOCK) k_kd_apply(const KdArgs K, size_t n,
     __syncthreads();
     suffix_scan_256(sc, t, m);
     s = (t + 1 < SP_BLOCK) ? el1<Fr>(sc[t + 1]) : cb;
-#pragma unroll
+#pragma clang loop unroll(full)
     for (int j = SP_PER - 1; j >= 0; --j) {
         if (lo + j < n) store_raw<Fr>(dst + (lo + j) * 8, s);
         s = s * r + v[j];
