@@ -338,7 +338,11 @@ __global__ void k_pass_twiddles(uint32_t* table, uint32_t count, uint32_t lo_bit
     store_raw<Fr>(table + (size_t)pos * 8, twiddle_at(tw, (lo * r) << hi_bits));
 }
 
-__global__ void __launch_bounds__(256, 2) k_ntt_strided_r8(const uint32_t* const* srcs, uint32_t* const* dsts, uint32_t m, uint32_t s,
+// the polynomials of a launch, by value in the kernel arguments: no pointer table to upload (an upload is a blit kernel on the
+// stream, ~7 us of it per call); longer batches go in launches of NTT_MAXP
+#define NTT_MAXP 16
+struct NttPtrs { const uint32_t* src[NTT_MAXP]; uint32_t* dst[NTT_MAXP]; };
+__global__ void __launch_bounds__(256, 2) k_ntt_strided_r8(const NttPtrs PT, uint32_t m, uint32_t s,
                                                             uint32_t lo_bits, uint32_t logT, uint32_t n_in, TwDev tw, NttScale sc, Swz z,
                                                             const uint32_t* __restrict__ ptab) {
     fe* tile = reinterpret_cast<fe*>(ntt_lds);
@@ -347,8 +351,8 @@ __global__ void __launch_bounds__(256, 2) k_ntt_strided_r8(const uint32_t* const
     uint32_t lo_tile = blockIdx.x & (tiles_lo - 1), hi = blockIdx.x >> (lo_bits - logT);
     uint32_t lo0 = lo_tile << logT;
     uint32_t base = (hi << (s + lo_bits)) | lo0;
-    const uint32_t* src = srcs[blockIdx.y];
-    uint32_t* dst = dsts[blockIdx.y];
+    const uint32_t* src = PT.src[blockIdx.y];
+    uint32_t* dst = PT.dst[blockIdx.y];
     // ownership at the load: slot = row bits 0..2; row rho <-> digit j = bitrev(rho, s)
     const uint32_t tl0 = t & (T - 1), jrest = bitrev(t >> logT, s - 3);
     fe v[8];
@@ -370,11 +374,11 @@ __global__ void __launch_bounds__(256, 2) k_ntt_strided_r8(const uint32_t* const
     }
 }
 
-__global__ void __launch_bounds__(256, 2) k_ntt_final_r8(const uint32_t* const* srcs, uint32_t* const* dsts, uint32_t m, uint32_t s,
+__global__ void __launch_bounds__(256, 2) k_ntt_final_r8(const NttPtrs PT, uint32_t m, uint32_t s,
                                                        uint32_t logT, uint32_t n_in, TwDev tw, NttScale sc, NttDigits dg, Swz z) {
     fe* tile = reinterpret_cast<fe*>(ntt_lds);
-    const uint32_t* src = srcs[blockIdx.y];
-    uint32_t* dst = dsts[blockIdx.y];
+    const uint32_t* src = PT.src[blockIdx.y];
+    uint32_t* dst = PT.dst[blockIdx.y];
     const uint32_t T = 1u << logT, t = threadIdx.x;
     uint32_t hi_bits = m - s;
     uint32_t s1 = dg.np > 1 ? dg.sw[0] : 0;
@@ -500,7 +504,7 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
     }
     std::vector<const void*> all(3 * npolys);
     for (size_t i = 0; i < npolys; ++i) { all[i] = srcs[i]; all[npolys + i] = dsts[i]; all[2 * npolys + i] = np > 1 ? tmp_host[i] : dsts[i]; }
-    ZK_TRY(ctx->upload(d_ptrs, all.data(), 3 * npolys * sizeof(void*)));
+    if (!r8) ZK_TRY(ctx->upload(d_ptrs, all.data(), 3 * npolys * sizeof(void*)));   // the r8 kernels get their pointers by value
     NttScale sc = sc_in;
     uint32_t lo_bits = m;
     // passes 1..np-1: in place on dst, except that the first reads src and the last non-final writes tmp
@@ -523,9 +527,16 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
             Swz z{logT + 3, logT < 5 ? (1u << (5 - logT)) - 1 : 0u, logT};
             const void* ptab;
             ZK_TRY(pass_twiddles(ctx, twh, tw, q, s, lo_bits, &ptab));
-            hipLaunchKernelGGL(k_ntt_strided_r8, dim3(blocks, (unsigned)npolys), dim3(256), NTT_TILE * sizeof(fe), st,
-                               (const uint32_t* const*)cur_src, (uint32_t* const*)out, m, s, lo_bits, logT, q == 0 ? n_in : (uint32_t)n, tw,
-                               scq, z, (const uint32_t*)ptab);
+            // host views of this pass's sources / destinations (the same choice as cur_src / out below)
+            const void* const* hs = q == 0 ? all.data() : all.data() + npolys;
+            const void* const* hd = (q + 2 == np) ? all.data() + 2 * npolys : all.data() + npolys;
+            for (size_t p0 = 0; p0 < npolys; p0 += NTT_MAXP) {
+                NttPtrs PT;
+                const size_t cnt = std::min<size_t>(NTT_MAXP, npolys - p0);
+                for (size_t i = 0; i < cnt; ++i) { PT.src[i] = (const uint32_t*)hs[p0 + i]; PT.dst[i] = (uint32_t*)hd[p0 + i]; }
+                hipLaunchKernelGGL(k_ntt_strided_r8, dim3(blocks, (unsigned)cnt), dim3(256), NTT_TILE * sizeof(fe), st, PT, m, s, lo_bits, logT,
+                                   q == 0 ? n_in : (uint32_t)n, tw, scq, z, (const uint32_t*)ptab);
+            }
         } else
         hipLaunchKernelGGL(k_ntt_strided, dim3(blocks, (unsigned)((npolys + group - 1) / group)), dim3(256), NTT_TILE * sizeof(fe), st,
                            (const uint32_t* const*)cur_src, (uint32_t* const*)out, (uint32_t)npolys, group, m, s, lo_bits, logT,
@@ -545,8 +556,14 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
         ProfScope ps(ctx, "ntt_final");
         if (r8) {
             Swz z{6, 31, 0};
-            hipLaunchKernelGGL(k_ntt_final_r8, dim3(blocks, (unsigned)npolys), dim3(256), NTT_TILE * sizeof(fe), st,
-                               (const uint32_t* const*)cur_src, (uint32_t* const*)d_dst, m, s, logT, (uint32_t)n, tw, scq, dg, z);
+            const void* const* hs = all.data() + 2 * npolys;   // np > 1: the last non-final pass wrote tmp
+            for (size_t p0 = 0; p0 < npolys; p0 += NTT_MAXP) {
+                NttPtrs PT;
+                const size_t cnt = std::min<size_t>(NTT_MAXP, npolys - p0);
+                for (size_t i = 0; i < cnt; ++i) { PT.src[i] = (const uint32_t*)hs[p0 + i]; PT.dst[i] = (uint32_t*)all[npolys + p0 + i]; }
+                hipLaunchKernelGGL(k_ntt_final_r8, dim3(blocks, (unsigned)cnt), dim3(256), NTT_TILE * sizeof(fe), st, PT, m, s, logT, (uint32_t)n, tw,
+                                   scq, dg, z);
+            }
         } else
         hipLaunchKernelGGL(k_ntt_final, dim3(blocks, (unsigned)npolys), dim3(256), NTT_TILE * sizeof(fe), st, (const uint32_t* const*)cur_src,
                            (uint32_t* const*)d_dst, m, s, logT, np == 1 ? n_in : (uint32_t)n, tw, scq, dg);
