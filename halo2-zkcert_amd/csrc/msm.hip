@@ -158,6 +158,10 @@ int srs_build_raw(zkhip_ctx* ctx, const void* d_bases_raw, size_t n, zkhip_srs**
 // Each pass counts, reserves contiguous space with ONE returning global atomic per (tile, bin) — a wave
 // touches consecutive counters — and scatters with ranks from LDS atomics.  Per-pair global atomics and the
 // 4-byte scatter over the whole n*W range, which made the first version memory-bound at 2^22, are gone.
+// column pointers of a batch of <= 16 columns travel by value in the kernel arguments (dev == nullptr); longer batches through a
+// device table
+struct ColPtrs { const uint32_t* const* dev; const uint32_t* val[16]; };
+__device__ __forceinline__ const uint32_t* col_ptr(const ColPtrs& c, uint32_t col) { return c.dev ? c.dev[col] : c.val[col]; }
 struct SortGeom { uint32_t c, W, B, HB, LB, P, tile; };   // tile: pairs of one partition handled by one workgroup of the low pass
 #define SORT_TILE 4096u
 #define SORT_MAXP 256u     // partitions of the high radix pass (HB <= 8)
@@ -177,7 +181,7 @@ __device__ __forceinline__ void digit_at(const uint32_t* sl, uint32_t w, uint32_
 // SCATTER = false: part_cnt[p] += pairs of this block in partition p.
 // SCATTER = true : tmp_entry / tmp_key get the pairs grouped by partition (part_off from k_part_scan).
 template <bool SCATTER>
-__global__ void __launch_bounds__(256) k_sort_hi(const uint32_t* const* scalar_cols, size_t n, size_t first, size_t srs_n, SortGeom g,
+__global__ void __launch_bounds__(256) k_sort_hi(const ColPtrs scalar_cols, size_t n, size_t first, size_t srs_n, SortGeom g,
                                                  uint32_t* part_cnt_all, uint32_t* part_cursor_all, const uint32_t* part_off_all,
                                                  uint32_t* tmp_entry_all, uint16_t* tmp_key_all, size_t items) {
     __shared__ uint32_t sl[256][9];
@@ -188,7 +192,7 @@ __global__ void __launch_bounds__(256) k_sort_hi(const uint32_t* const* scalar_c
     const bool live = i < n;
     hist[tid] = 0;   // 256 threads, SORT_MAXP = 256
     if (live) {
-        fe32 sc = abi_to_canonical_words<Fr>(mem_load(scalar_cols[col] + (first + i) * 8));
+        fe32 sc = abi_to_canonical_words<Fr>(mem_load(col_ptr(scalar_cols, col) + (first + i) * 8));
 #pragma unroll
         for (int j = 0; j < 8; ++j) sl[tid][j] = sc.w[j];
         sl[tid][8] = 0;
@@ -657,7 +661,7 @@ __device__ __forceinline__ g1x g1x_load_loose(const uint32_t* p) {
 // Round 0, lane-balanced: lane t sums the L consecutive sorted entries [t L, (t+1) L) whatever buckets they belong to, and
 // writes one partial per bucket it touches (partial t - floor(off[b] / L) of bucket b).  Every lane of a wave runs the same
 // trip count, where per-bucket segments left ~20 % of the lanes idle behind the longest segment.
-__global__ void __launch_bounds__(256) k_accum_affine(const uint32_t* const* tables, const uint32_t* entries_all, size_t items,
+__global__ void __launch_bounds__(256) k_accum_affine(const ColPtrs tables, const uint32_t* entries_all, size_t items,
                                                       const uint32_t* off_all, const uint32_t* segoff_all, uint32_t B, uint32_t L,
                                                       uint32_t* partial_all, size_t partial_stride, uint32_t adaptive) {
     uint32_t col = blockIdx.y;
@@ -669,7 +673,7 @@ __global__ void __launch_bounds__(256) k_accum_affine(const uint32_t* const* tab
     if ((uint64_t)t * L >= total) return;
     const uint32_t start = t * L, end = min(start + L, total);
     const uint32_t* entries = entries_all + (size_t)col * items;
-    const uint32_t* table = tables[col];
+    const uint32_t* table = col_ptr(tables, col);
     uint32_t* out = partial_all + (size_t)col * partial_stride * PART_WORDS;
     uint32_t b = find_bucket(off, B, start);
     uint32_t bend = off[b + 1];
@@ -997,7 +1001,15 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
 
     std::vector<const void*> h_ptrs(2 * ncols);
     for (size_t j = 0; j < ncols; ++j) { h_ptrs[j] = d_cols_host[j]; h_ptrs[ncols + j] = srs_per_col[j]->d_table; }
-    ZK_TRY(ctx->upload(d_colptrs, h_ptrs.data(), 2 * ncols * sizeof(void*)));
+    ColPtrs cp_scalars, cp_tables;
+    if (ncols <= 16) {
+        cp_scalars.dev = cp_tables.dev = nullptr;
+        for (size_t j = 0; j < ncols; ++j) { cp_scalars.val[j] = (const uint32_t*)h_ptrs[j]; cp_tables.val[j] = (const uint32_t*)h_ptrs[ncols + j]; }
+    } else {
+        ZK_TRY(ctx->upload(d_colptrs, h_ptrs.data(), 2 * ncols * sizeof(void*)));
+        cp_scalars.dev = (const uint32_t* const*)d_colptrs;
+        cp_tables.dev = (const uint32_t* const*)((const void**)d_colptrs + ncols);
+    }
     ZK_HIP(hipMemsetAsync(d_zero, 0, zero_words * 4, st));
     // Round-0 segment length depends on the problem size only: aim for ~2 waves per SIMD over the chip.
     uint32_t seg = seg0_min;
@@ -1017,10 +1029,10 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
     if (max_pinned) { h_max = (uint32_t*)((char*)ctx->h_pinned + 1024); d_max = h_max; }
     else if (ncols * 4 > zkhip_ctx::PINNED_BYTES) { h_max_big.resize(ncols); h_max = h_max_big.data(); }
     { ProfScope ps(ctx, "msm_digits");
-    hipLaunchKernelGGL(k_sort_hi<false>, gn, dim3(256), 0, st, (const uint32_t* const*)d_colptrs, n, first, srs->n, g, d_part_cnt, d_part_cursor,
+    hipLaunchKernelGGL(k_sort_hi<false>, gn, dim3(256), 0, st, cp_scalars, n, first, srs->n, g, d_part_cnt, d_part_cursor,
                        (const uint32_t*)d_part_off, (uint32_t*)d_tmp_entry, (uint16_t*)d_tmp_key, items);
     hipLaunchKernelGGL(k_part_scan, dim3((unsigned)ncols), dim3(SORT_MAXP), 0, st, (const uint32_t*)d_part_cnt, g.P, g.tile, d_part_off, d_tile_start);
-    hipLaunchKernelGGL(k_sort_hi<true>, gn, dim3(256), g.W <= 24 ? (size_t)256 * g.W * 7 + 16 : 0, st, (const uint32_t* const*)d_colptrs, n, first, srs->n, g, d_part_cnt, d_part_cursor,
+    hipLaunchKernelGGL(k_sort_hi<true>, gn, dim3(256), g.W <= 24 ? (size_t)256 * g.W * 7 + 16 : 0, st, cp_scalars, n, first, srs->n, g, d_part_cnt, d_part_cursor,
                        (const uint32_t*)d_part_off, (uint32_t*)d_tmp_entry, (uint16_t*)d_tmp_key, items);
     hipLaunchKernelGGL(k_sort_lo_count, gt, dim3(256), 0, st, (const uint32_t*)d_part_off, (const uint32_t*)d_tile_start, g,
                        (const uint16_t*)d_tmp_key, items, d_cnt); }
@@ -1060,7 +1072,7 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
     // round 0 does not need the maximum: it is issued before the host waits for it
     { ProfScope ps(ctx, "msm_accum_affine");
     hipLaunchKernelGGL(k_accum_affine, dim3(div_up(div_up(items, L), 256), (unsigned)ncols), dim3(256), 0, st,
-                       (const uint32_t* const*)((const void**)d_colptrs + ncols), (const uint32_t*)d_entries, items, (const uint32_t*)d_off,
+                       cp_tables, (const uint32_t*)d_entries, items, (const uint32_t*)d_off,
                        (const uint32_t*)d_offA, B, L, (uint32_t*)d_pA, pstride0, adaptive_L ? 1u : 0u); }
     if (ctx->accum_mark) {   // a caller wants to start overlapped work when the throughput-bound part of this MSM is over
         ZK_HIP(hipEventRecord(ctx->accum_mark, st));
