@@ -220,14 +220,20 @@ __global__ void __launch_bounds__(256) k_lookup_terms(const uint32_t* a, const u
 // ------------------------------------------------------------------ evaluation at a point
 // partial[poly][blk] = sum_{i in tile} c_i x^(i - tile_start)   (coefficients loaded raw: the sum is linear in them)
 // xs: raw R'-form points, one per polynomial
+// (polynomial, point) pairs of a launch: by value in the kernel arguments for <= EV_MAX pairs (dev pointers null), so that the
+// evaluations — on the critical path right after the challenge x — need no upload
+#define EV_MAX 48
+struct EvArgs { const uint32_t* const* polys; const uint32_t* xs; const uint32_t* p[EV_MAX]; fe32 x[EV_MAX]; };
+__device__ __forceinline__ const uint32_t* ev_poly(const EvArgs& A, uint32_t i) { return A.polys ? A.polys[i] : A.p[i]; }
+__device__ __forceinline__ el1<Fr> ev_x(const EvArgs& A, uint32_t i) { return A.xs ? load_raw<Fr>(A.xs + (size_t)i * 8) : el1<Fr>(fe_split<0>(A.x[i])); }
 // PER coefficients per thread: the block tree (8 levels of a product and a squaring by every thread) is a fixed cost per thread, so
 // long polynomials use 32 (1.5 products per coefficient instead of 2.6)
 template <int PER>
-__global__ void __launch_bounds__(PO_BLOCK) k_eval_tiles(const uint32_t* const* polys, size_t n, const uint32_t* xs, uint32_t* partial_all, uint32_t nblk) {
+__global__ void __launch_bounds__(PO_BLOCK) k_eval_tiles(const EvArgs A, size_t n, uint32_t* partial_all, uint32_t nblk) {
     __shared__ fe sc[PO_BLOCK];
     const uint32_t t = threadIdx.x, poly = blockIdx.y;
-    const uint32_t* c = polys[poly];
-    const el2<Fr> x = load_raw<Fr>(xs + (size_t)poly * 8);
+    const uint32_t* c = ev_poly(A, poly);
+    const el2<Fr> x = ev_x(A, poly);
     const size_t lo = (size_t)blockIdx.x * (PER * PO_BLOCK) + (size_t)t * PER;
     // Horner over this thread's PER coefficients
     el<Fr, 4 * U> acc = zero<Fr>();
@@ -253,11 +259,11 @@ __global__ void __launch_bounds__(PO_BLOCK) k_eval_tiles(const uint32_t* const* 
     if (t == 0) store_raw<Fr>(partial_all + ((size_t)poly * nblk + blockIdx.x) * 8, el2<Fr>(sc[0]));
 }
 // out[poly] = sum_b partial[poly][b] * x^(tile b), one block per polynomial
-__global__ void __launch_bounds__(PO_BLOCK) k_eval_final(const uint32_t* partial_all, uint32_t nblk, const uint32_t* xs, uint32_t* out, uint32_t tile) {
+__global__ void __launch_bounds__(PO_BLOCK) k_eval_final(const EvArgs A, const uint32_t* partial_all, uint32_t nblk, uint32_t* out, uint32_t tile) {
     __shared__ fe sc[PO_BLOCK];
     const uint32_t t = threadIdx.x, poly = blockIdx.x;
     const uint32_t* part = partial_all + (size_t)poly * nblk * 8;
-    el2<Fr> xt = pow_u64<Fr>(el2<Fr>(load_raw<Fr>(xs + (size_t)poly * 8)), tile);   // x^tile
+    el2<Fr> xt = pow_u64<Fr>(el2<Fr>(ev_x(A, poly)), tile);   // x^tile
     el2<Fr> step = pow_u64<Fr>(xt, PO_BLOCK);                        // x^(2048 * 256)
     el2<Fr> xw = pow_u64<Fr>(xt, t);                                 // x^(2048 t)
     el<Fr, 4 * U> acc = zero<Fr>();
@@ -325,17 +331,22 @@ static int eval_at(zkhip_ctx* ctx, const void* const* d_polys, size_t npolys, si
     ZK_TRY(ctx->get_scratch("po_eval_xs", npolys * 32, &d_xs));
     std::vector<fe32> xs(npolys);
     for (size_t j = 0; j < npolys; ++j) xs[j] = abi_to_raw(xs_host + 4 * j);
-    ZK_TRY(ctx->upload(d_ptrs, d_polys, npolys * sizeof(void*)));
-    ZK_TRY(ctx->upload(d_xs, xs.data(), npolys * 32));
+    EvArgs A;
+    static const bool by_value = !(getenv("ZKHIP_EVAL_BYVAL") && atoi(getenv("ZKHIP_EVAL_BYVAL")) == 0);
+    if (npolys <= EV_MAX && by_value) {
+        A.polys = nullptr; A.xs = nullptr;
+        for (size_t j = 0; j < npolys; ++j) { A.p[j] = (const uint32_t*)d_polys[j]; A.x[j] = xs[j]; }
+    } else {
+        ZK_TRY(ctx->upload(d_ptrs, d_polys, npolys * sizeof(void*)));
+        ZK_TRY(ctx->upload(d_xs, xs.data(), npolys * 32));
+        A.polys = (const uint32_t* const*)d_ptrs; A.xs = (const uint32_t*)d_xs;
+    }
     ProfScope ps(ctx, "eval_polynomial");
     if (per == 32)
-        hipLaunchKernelGGL(k_eval_tiles<32>, dim3(nblk, (unsigned)npolys), dim3(PO_BLOCK), 0, ctx->stream, (const uint32_t* const*)d_ptrs, n,
-                           (const uint32_t*)d_xs, (uint32_t*)d_part, nblk);
+        hipLaunchKernelGGL(k_eval_tiles<32>, dim3(nblk, (unsigned)npolys), dim3(PO_BLOCK), 0, ctx->stream, A, n, (uint32_t*)d_part, nblk);
     else
-        hipLaunchKernelGGL(k_eval_tiles<PO_PER>, dim3(nblk, (unsigned)npolys), dim3(PO_BLOCK), 0, ctx->stream, (const uint32_t* const*)d_ptrs, n,
-                           (const uint32_t*)d_xs, (uint32_t*)d_part, nblk);
-    hipLaunchKernelGGL(k_eval_final, dim3((unsigned)npolys), dim3(PO_BLOCK), 0, ctx->stream, (const uint32_t*)d_part, nblk, (const uint32_t*)d_xs,
-                       (uint32_t*)d_out, tile);
+        hipLaunchKernelGGL(k_eval_tiles<PO_PER>, dim3(nblk, (unsigned)npolys), dim3(PO_BLOCK), 0, ctx->stream, A, n, (uint32_t*)d_part, nblk);
+    hipLaunchKernelGGL(k_eval_final, dim3((unsigned)npolys), dim3(PO_BLOCK), 0, ctx->stream, A, (const uint32_t*)d_part, nblk, (uint32_t*)d_out, tile);
     ZK_LAUNCH_CHECK();
     return ZKHIP_OK;
 }
