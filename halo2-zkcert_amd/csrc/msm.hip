@@ -1014,9 +1014,15 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
     // Round-0 segment length depends on the problem size only: aim for ~2 waves per SIMD over the chip.
     uint32_t seg = seg0_min;
     {
+        // about four waves per SIMD over the launch, as a power of two (L = 24 / 40 cost 2-3 % of a 2^17 proof against 16 / 32: the
+        // lane index arithmetic divides by L) and at least 16 (at 8 a single column's buckets collect more than 8 partial sums each
+        // and every MSM pays reduction rounds)
         size_t target_threads = (size_t)256 * 4 * 64 * 4;
         size_t sgl = (ncols * items) / target_threads;
-        if (sgl > seg) seg = (uint32_t)std::min<size_t>(sgl, 64);
+        if (sgl >= 8) {   // smaller launches are latency chains: keep the lanes short (8)
+            seg = 16;
+            while (seg < 64 && (size_t)seg * 2 <= sgl) seg *= 2;
+        }
         if (const char* e = getenv("ZKHIP_MSM_SEG")) { int v = atoi(e); if (v >= (int)seg0_min && v <= 256) seg = (uint32_t)v; }
     }
     dim3 gn(div_up(n, 256), (unsigned)ncols);
