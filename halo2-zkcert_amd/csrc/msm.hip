@@ -1021,7 +1021,8 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
         size_t sgl = (ncols * items) / target_threads;
         if (sgl >= 8) {   // smaller launches are latency chains: keep the lanes short (8)
             seg = 16;
-            while (seg < 64 && (size_t)seg * 2 <= sgl) seg *= 2;
+            const uint32_t cap = n >= ((size_t)1 << 20) ? 64 : 32;   // measured: 2^18-2^19 prefer 16-32 (-3 %), 2^20-2^22 64
+            while (seg < cap && (size_t)seg * 2 <= sgl) seg *= 2;
         }
         if (const char* e = getenv("ZKHIP_MSM_SEG")) { int v = atoi(e); if (v >= (int)seg0_min && v <= 256) seg = (uint32_t)v; }
     }
