@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <deque>
 #include <map>
 #include <string>
 #include <vector>
@@ -42,8 +43,19 @@ struct Scratch {
 
 }  // namespace zk
 
+// Tuning knobs: environment variables (ZKHIP_*) read ONCE when the context is created, or set afterwards with
+// zkhip_set_option — never looked up on the hot path.  0 / -1 = "use the measured default".
+struct zkhip_options {
+    int msm_c = 0, msm_seg = 0, msm_tailparts = 0, msm_ch = 0, msm_widetail = -1, msm_adaptive_l = 1, msm_debug = 0;
+    int sort_hb = 0, sort_tile = 0, sort_one_atomic = 1;
+    int ntt_smax = 0, ntt_r8 = 1, ntt_group = 0;
+    int permute_rank_sort = 1, eval_byval = 1, late_overlap = -1;
+    int graphs = 1;
+};
+
 struct zkhip_ctx {
     int device = 0;
+    zkhip_options opt;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -75,7 +87,7 @@ struct zkhip_ctx {
         void* d_bf;          // min(1024, n/2) entries: w^(j * n / 2^bf_bits'), see ntt.hip
         uint32_t bf_bits;    // bf has 2^bf_bits entries, bf[j] = w^(j << (log_n - 1 - bf_bits))
     };
-    std::vector<Twiddle> twiddles;
+    std::deque<Twiddle> twiddles;   // a deque: the pointers handed out stay valid however many tables are cached
 
     // optional per-kernel HIP-event timing on the launch stream (zkhip_profile_*)
     bool prof_on = false;

@@ -107,6 +107,39 @@ int zkhip_profile_read(zkhip_ctx* c, const char* kernel, double* total_ms, uint6
     return ZKHIP_OK;
 }
 
+namespace {
+struct OptName { const char* env; const char* name; int zkhip_options::*field; };
+const OptName OPTIONS[] = {
+    {"ZKHIP_MSM_C", "msm_c", &zkhip_options::msm_c}, {"ZKHIP_MSM_SEG", "msm_seg", &zkhip_options::msm_seg},
+    {"ZKHIP_MSM_TAILPARTS", "msm_tailparts", &zkhip_options::msm_tailparts}, {"ZKHIP_MSM_CH", "msm_ch", &zkhip_options::msm_ch},
+    {"ZKHIP_MSM_WIDETAIL", "msm_widetail", &zkhip_options::msm_widetail}, {"ZKHIP_MSM_ADAPTIVE_L", "msm_adaptive_l", &zkhip_options::msm_adaptive_l},
+    {"ZKHIP_MSM_DEBUG", "msm_debug", &zkhip_options::msm_debug}, {"ZKHIP_SORT_HB", "sort_hb", &zkhip_options::sort_hb},
+    {"ZKHIP_SORT_TILE", "sort_tile", &zkhip_options::sort_tile}, {"ZKHIP_SORT_ONE_ATOMIC", "sort_one_atomic", &zkhip_options::sort_one_atomic},
+    {"ZKHIP_NTT_SMAX", "ntt_smax", &zkhip_options::ntt_smax}, {"ZKHIP_NTT_R8", "ntt_r8", &zkhip_options::ntt_r8},
+    {"ZKHIP_NTT_GROUP", "ntt_group", &zkhip_options::ntt_group}, {"ZKHIP_PERMUTE_RANK_SORT", "permute_rank_sort", &zkhip_options::permute_rank_sort},
+    {"ZKHIP_EVAL_BYVAL", "eval_byval", &zkhip_options::eval_byval}, {"ZKHIP_LATE_OVERLAP", "late_overlap", &zkhip_options::late_overlap},
+    {"ZKHIP_GRAPHS", "graphs", &zkhip_options::graphs},
+};
+}  // namespace
+
+int zkhip_set_option(zkhip_ctx* c, const char* name, int value) {
+    if (!c || !name) { set_error("zkhip_set_option: null argument"); return ZKHIP_EINVAL; }
+    for (const auto& o : OPTIONS)
+        if (strcmp(o.name, name) == 0 || strcmp(o.env, name) == 0) { c->opt.*(o.field) = value; return ZKHIP_OK; }
+    set_error("zkhip_set_option: unknown option '%s'", name);
+    return ZKHIP_EINVAL;
+}
+
+static int init_device_state(zkhip_ctx* c) {
+    ZK_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    ZK_HIP(hipEventCreate(&c->ev0));
+    ZK_HIP(hipEventCreate(&c->ev1));
+    ZK_HIP(hipEventCreateWithFlags(&c->ev_read, hipEventDisableTiming));
+    ZK_HIP(hipHostMalloc(&c->h_pinned, zkhip_ctx::PINNED_BYTES, hipHostMallocDefault));
+    return ZKHIP_OK;
+}
+
 int zkhip_init(zkhip_ctx** out, int device_id) {
     if (!out) { set_error("zkhip_init: out is NULL"); return ZKHIP_EINVAL; }
     int ndev = 0;
@@ -120,12 +153,11 @@ int zkhip_init(zkhip_ctx** out, int device_id) {
     ZK_HIP(hipSetDevice(device_id));
     zkhip_ctx* c = new zkhip_ctx();
     c->device = device_id;
-    ZK_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
-    c->stream = c->own_stream;
-    ZK_HIP(hipEventCreate(&c->ev0));
-    ZK_HIP(hipEventCreate(&c->ev1));
-    ZK_HIP(hipEventCreateWithFlags(&c->ev_read, hipEventDisableTiming));
-    ZK_HIP(hipHostMalloc(&c->h_pinned, zkhip_ctx::PINNED_BYTES, hipHostMallocDefault));
+    // the tuning knobs: read here, once (a getenv per MSM was measurable against a 0.3 ms column commitment)
+    for (const auto& o : OPTIONS)
+        if (const char* v = getenv(o.env)) c->opt.*(o.field) = atoi(v);
+    int rc = init_device_state(c);
+    if (rc != ZKHIP_OK) { zkhip_destroy(c); return rc; }   // nothing half-built survives a failed init (the message is kept)
     *out = c;
     return ZKHIP_OK;
 }
@@ -156,6 +188,24 @@ void zkhip_destroy(zkhip_ctx* c) {
 int zkhip_set_stream(zkhip_ctx* c, void* s) {
     if (!c) { set_error("null ctx"); return ZKHIP_EINVAL; }
     c->stream = (s == ZKHIP_OWN_STREAM) ? c->own_stream : (hipStream_t)s;
+    return ZKHIP_OK;
+}
+// Scratch buffers are keyed by the stream they were used on (two streams may run the same kind of call at once), so a caller that
+// hands over many short-lived streams accumulates them: this frees every scratch buffer that does not belong to the current, own or
+// side stream.  Synchronises the device.
+int zkhip_trim(zkhip_ctx* c) {
+    if (!c) { set_error("null ctx"); return ZKHIP_EINVAL; }
+    ZK_HIP(hipDeviceSynchronize());
+    char keep[3][32];
+    snprintf(keep[0], 32, "@%p", (void*)c->stream);
+    snprintf(keep[1], 32, "@%p", (void*)c->own_stream);
+    snprintf(keep[2], 32, "@%p", (void*)c->side_stream);
+    for (auto it = c->scratch.begin(); it != c->scratch.end();) {
+        const std::string& k = it->first;
+        bool live = false;
+        for (auto& kp : keep) { size_t L = strlen(kp); if (k.size() >= L && k.compare(k.size() - L, L, kp) == 0) live = true; }
+        if (!live) { if (it->second.ptr) (void)hipFree(it->second.ptr); it = c->scratch.erase(it); } else ++it;
+    }
     return ZKHIP_OK;
 }
 int zkhip_synchronize(zkhip_ctx* c) {

@@ -28,11 +28,8 @@ struct zkhip_srs {
     void* d_table = nullptr;  // [W][n] affine, Montgomery
 };
 
-static uint32_t pick_window(size_t n) {
-    if (const char* e = getenv("ZKHIP_MSM_C")) {
-        int v = atoi(e);
-        if (v >= 2 && v <= 20) return (uint32_t)v;
-    }
+static uint32_t pick_window(const zkhip_ctx* ctx, size_t n) {
+    if (ctx->opt.msm_c >= 2 && ctx->opt.msm_c <= 20) return (uint32_t)ctx->opt.msm_c;
     uint32_t lg = 0;
     while (((size_t)1 << lg) < n) ++lg;
     // measured on MI355X (profiles/): 2^17 -> 16 (16 windows), 2^19 -> 17 (15 windows, 15 * 17 = 255 bits: no short top window
@@ -116,7 +113,7 @@ static int srs_build(zkhip_ctx* ctx, const void* d_bases, size_t n, zkhip_srs** 
     if (n == 0 || n > ((size_t)1 << 26)) { set_error("zkhip_srs_load: n = %zu out of range (1..2^26)", n); return ZKHIP_EINVAL; }
     zkhip_srs* s = new zkhip_srs();
     s->n = n;
-    s->c = pick_window(n);
+    s->c = pick_window(ctx, n);
     s->W = (255 + s->c - 1) / s->c;
     s->B = 1u << (s->c - 1);
     if ((size_t)s->W * n >= ((size_t)1 << 31)) { delete s; set_error("zkhip_srs_load: W*n overflows the 31-bit pair index"); return ZKHIP_EINVAL; }
@@ -959,13 +956,13 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
     g.c = c; g.W = W; g.B = B;
     const uint32_t KB = c - 1;
     g.HB = KB >= 18 ? 8 : (KB > 8 ? 7 : KB / 2);   // 256 partitions from c = 19 (measured: digits -14 % at 2^20, -8 % at 2^21)
-    if (const char* e = getenv("ZKHIP_SORT_HB")) { int v = atoi(e); if (v >= 1 && v <= 8 && v < (int)KB && (int)KB - v <= 11) g.HB = (uint32_t)v; }
+    { int v = ctx->opt.sort_hb; if (v >= 1 && v <= 8 && v < (int)KB && (int)KB - v <= 11) g.HB = (uint32_t)v; }
     g.LB = KB - g.HB;
     g.P = 1u << g.HB;
     // Measured at 2^22 (2^11 bins): tiles of 16k / 32k / 64k pairs, which lengthen the scatter's contiguous runs from 8 to
     // 32-128 bytes, are 18-26 % SLOWER than 4096-pair tiles — the low pass is bound by its LDS rank atomics, not by run length.
     g.tile = g.LB >= 11 ? 2 * SORT_TILE : SORT_TILE;   // 2048 bins (c = 19, n >= 2^20): 8192-pair tiles, 16-byte runs (digits -13 % at 2^22)
-    if (const char* e = getenv("ZKHIP_SORT_TILE")) { int v = atoi(e); if (v >= 1024 && v <= (1 << 20)) g.tile = (uint32_t)v; }
+    { int v = ctx->opt.sort_tile; if (v >= 1024 && v <= (1 << 20)) g.tile = (uint32_t)v; }
     if (g.LB > 11) { set_error("zkhip_msm: window c = %u unsupported by the sort (max 20)", c); return ZKHIP_EINVAL; }
     ZK_TRY(ctx->get_scratch("msm_colptrs", 2 * ncols * sizeof(void*), &d_colptrs));
     // zeroed every call: part_cnt[SORT_MAXP] + part_cursor[SORT_MAXP] + cnt[B] + cursor[B] per column
@@ -991,11 +988,11 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
     ZK_TRY(ctx->get_scratch("msm_pA", ncols * pstride0 * PART_WORDS * 4, &d_pA));
     ZK_TRY(ctx->get_scratch("msm_pB", ncols * pstride0 * PART_WORDS * 4, &d_pB));
     uint32_t CH = B > 8192 ? B / 8192 : 1;
-    if (const char* e = getenv("ZKHIP_MSM_CH")) { int v = atoi(e); if (v >= 1 && v <= 256) CH = (uint32_t)v; }
+    { int v = ctx->opt.msm_ch; if (v >= 1 && v <= 256) CH = (uint32_t)v; }
     uint32_t nchunks = (B + CH - 1) / CH;
     // a wide batch has enough chunks to fill the chip with one lane each; otherwise four lanes share every point operation
     bool wide_tail = (size_t)nchunks * ncols >= (size_t)48 * 1024;   // measured crossover: 6-8 columns at 8192 chunks
-    if (const char* e = getenv("ZKHIP_MSM_WIDETAIL")) wide_tail = atoi(e) != 0;
+    if (ctx->opt.msm_widetail >= 0) wide_tail = ctx->opt.msm_widetail != 0;
     uint32_t nchunk_blocks = div_up(nchunks, wide_tail ? 256 : 64);
     ZK_TRY(ctx->get_scratch("msm_chunks", ncols * (size_t)nchunk_blocks * 128, &d_chunks));
 
@@ -1024,7 +1021,7 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
             const uint32_t cap = n >= ((size_t)1 << 20) ? 64 : 32;   // measured: 2^18-2^19 prefer 16-32 (-3 %), 2^20-2^22 64
             while (seg < cap && (size_t)seg * 2 <= sgl) seg *= 2;
         }
-        if (const char* e = getenv("ZKHIP_MSM_SEG")) { int v = atoi(e); if (v >= (int)seg0_min && v <= 256) seg = (uint32_t)v; }
+        { int v = ctx->opt.msm_seg; if (v >= (int)seg0_min && v <= 256) seg = (uint32_t)v; }
     }
     dim3 gn(div_up(n, 256), (unsigned)ncols);
     dim3 gt(div_up(items, g.tile) + g.P, (unsigned)ncols);
@@ -1045,7 +1042,7 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
                        (const uint16_t*)d_tmp_key, items, d_cnt); }
     // plan: bucket offsets, then the number of round-0 lanes touching each bucket (= its partial sums) and their offsets
     const uint32_t L = seg;
-    static const bool adaptive_L = !(getenv("ZKHIP_MSM_ADAPTIVE_L") && atoi(getenv("ZKHIP_MSM_ADAPTIVE_L")) == 0);
+    const bool adaptive_L = ctx->opt.msm_adaptive_l != 0;
     { ProfScope ps(ctx, "msm_plan");
     ZK_TRY(launch_plan(ctx, (unsigned)ncols, (const uint32_t*)d_cnt, B, 1, (uint32_t*)d_off, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr));
     // second scan, in lane mode: scans npart[b] (computed on the fly from cnt and off), writes it to cntA, its offsets to offA
@@ -1065,7 +1062,7 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
             if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)k_sort_lo_staged16<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         });
         ZK_HIP(attr_err);
-        static const bool one_atomic = !(getenv("ZKHIP_SORT_ONE_ATOMIC") && atoi(getenv("ZKHIP_SORT_ONE_ATOMIC")) == 0);
+        const bool one_atomic = ctx->opt.sort_one_atomic != 0;
         if (g.tile == 8192 && one_atomic)
             hipLaunchKernelGGL(k_sort_lo_staged16<32>, gt, dim3(256), lds, st, (const uint32_t*)d_part_off, (const uint32_t*)d_tile_start, g,
                                (const uint32_t*)d_tmp_entry, (const uint16_t*)d_tmp_key, items, (const uint32_t*)d_off, d_cursor, (uint32_t*)d_entries);
@@ -1112,7 +1109,7 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
         ZK_LAUNCH_CHECK();
         return ZKHIP_OK;
     }
-    if (getenv("ZKHIP_MSM_DEBUG")) fprintf(stderr, "msm: n=%zu ncols=%zu c=%u W=%u L=%u max partials per bucket=%u\n", n, ncols, c, W, L, maxcnt);
+    if (ctx->opt.msm_debug) fprintf(stderr, "msm: n=%zu ncols=%zu c=%u W=%u L=%u max partials per bucket=%u\n", n, ncols, c, W, L, maxcnt);
     const uint32_t* cur_cnt = (const uint32_t*)d_cntA;
     const uint32_t* cur_off = (const uint32_t*)d_offA;
     uint32_t* nxt_cnt = (uint32_t*)d_cntB;
@@ -1123,7 +1120,7 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
     if (bound > pstride0) bound = pstride0;
     // the tail folds up to tail_parts partial sums per bucket itself; heavier buckets (skewed scalars) go through reduction rounds
     uint32_t tail_parts = 8;
-    if (const char* e = getenv("ZKHIP_MSM_TAILPARTS")) { int v = atoi(e); if (v >= 1 && v <= 64) tail_parts = (uint32_t)v; }
+    { int v = ctx->opt.msm_tailparts; if (v >= 1 && v <= 64) tail_parts = (uint32_t)v; }
     while (maxcnt > tail_parts) {
         seg = maxcnt <= 16 ? maxcnt : 8;
         { ProfScope ps(ctx, "msm_plan");

@@ -73,7 +73,6 @@ int zkhip_ctx::get_twiddles(const uint64_t omega[4], uint32_t log_n, const Twidd
     launch(t.d_bf, n_bf, w_bf);
     ZK_LAUNCH_CHECK();
     ZK_HIP(hipStreamSynchronize(stream));   // one-time: the tables are shared by every stream of the context
-    twiddles.reserve(64);                   // pointers handed out stay valid
     twiddles.push_back(t);
     *out = &twiddles.back();
     return ZKHIP_OK;
@@ -480,7 +479,7 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
     // 1 KiB runs are 7 % SLOWER at 2^24 than 8/9-bit passes — the kernels are bound by per-element work
     // (butterfly products, the inter-pass twiddle, canonical stores), not by the run length.
     uint32_t smax = 9;
-    if (const char* e = getenv("ZKHIP_NTT_SMAX")) { int v = atoi(e); if (v >= 4 && v <= 11) smax = (uint32_t)v; }
+    { int v = ctx->opt.ntt_smax; if (v >= 4 && v <= 11) smax = (uint32_t)v; }
     uint32_t np = m <= 11 ? 1 : (m + smax - 1) / smax;
     if (np > 6) { set_error("ntt: too many passes"); return ZKHIP_EINVAL; }
     uint32_t sw[6] = {0, 0, 0, 0, 0, 0};
@@ -495,7 +494,7 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
             if (sw[q] < 3 || sw[q] > ilog2(NTT_TILE) || avail < ilog2(NTT_TILE) - sw[q]) r8 = false;
         }
     }
-    if (const char* e = getenv("ZKHIP_NTT_R8")) r8 = r8 && atoi(e) != 0;
+    r8 = r8 && ctx->opt.ntt_r8 != 0;
     std::vector<void*> tmp_host(npolys);
     if (np > 1) {
         void* d_tmpbuf;
@@ -521,7 +520,7 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
         // polynomials per workgroup: as many as keep >= 512 workgroups in the launch (two per CU; measured crossover)
         uint32_t group = 1;
         while (group < npolys && (size_t)blocks * ((npolys + 2 * group - 1) / (2 * group)) >= 512) group *= 2;
-        if (const char* e = getenv("ZKHIP_NTT_GROUP")) { int v = atoi(e); if (v >= 1 && v <= 64) group = (uint32_t)v; }
+        { int v = ctx->opt.ntt_group; if (v >= 1 && v <= 64) group = (uint32_t)v; }
         ProfScope ps(ctx, "ntt_strided");
         if (r8) {
             Swz z{logT + 3, logT < 5 ? (1u << (5 - logT)) - 1 : 0u, logT};

@@ -328,7 +328,7 @@ int zk::permute_expression_pair_async(zkhip_ctx* ctx, uint32_t k, uint32_t blind
     ProfScope ps(ctx, "lookup_permute");
     ZK_HIP(hipMemsetAsync(d_misc, 0, 16, st));
     unsigned g = div_up(n, 256);
-    static const bool rank_sort = !(getenv("ZKHIP_PERMUTE_RANK_SORT") && atoi(getenv("ZKHIP_PERMUTE_RANK_SORT")) == 0);
+    const bool rank_sort = ctx->opt.permute_rank_sort != 0;
     if (d_sorted_table_keys && rank_sort) {
         // a fixed table sorted once at first use: rank every row in it and counting-sort the ranks (see k_pe_rank)
         dT = const_cast<void*>(d_sorted_table_keys);

@@ -332,7 +332,7 @@ static int eval_at(zkhip_ctx* ctx, const void* const* d_polys, size_t npolys, si
     std::vector<fe32> xs(npolys);
     for (size_t j = 0; j < npolys; ++j) xs[j] = abi_to_raw(xs_host + 4 * j);
     EvArgs A;
-    static const bool by_value = !(getenv("ZKHIP_EVAL_BYVAL") && atoi(getenv("ZKHIP_EVAL_BYVAL")) == 0);
+    const bool by_value = ctx->opt.eval_byval != 0;
     if (npolys <= EV_MAX && by_value) {
         A.polys = nullptr; A.xs = nullptr;
         for (size_t j = 0; j < npolys; ++j) { A.p[j] = (const uint32_t*)d_polys[j]; A.x[j] = xs[j]; }

@@ -59,11 +59,24 @@ inline void abi_of(const HF& a, uint64_t out[4]) { fe32 m = hf_abi(a); memcpy(ou
 
 extern "C" int zkhip_create_proof(zkhip_ctx* ctx, const zk_proving_key* pk, const void* const* d_advice, const void* const* d_instance,
                                   uint64_t blinding_seed, const zk_transcript* tr, zk_proof_out* out) {
-    if (!ctx || !pk || !tr || !tr->write_point || !tr->squeeze_challenge || !tr->write_scalar || (pk->n_advice && !d_advice) ||
-        (pk->n_instance && !d_instance)) {
+    zk_proof_inputs in;
+    memset(&in, 0, sizeof in);
+    in.advice = d_advice;
+    in.d_instance = d_instance;
+    in.blinding_seed = blinding_seed;
+    if (pk && pk->n_instance && !d_instance) { set_error("zkhip_create_proof: null argument"); return ZKHIP_EINVAL; }
+    return zkhip_create_proof_ex(ctx, pk, &in, tr, out);
+}
+
+extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, const zk_proof_inputs* in, const zk_transcript* tr,
+                                     zk_proof_out* out) {
+    if (!ctx || !pk || !in || !tr || !tr->write_point || !tr->squeeze_challenge || !tr->write_scalar || (pk->n_advice && !in->advice) ||
+        (pk->n_instance && !in->d_instance && !(in->instance_values && in->instance_len))) {
         set_error("zkhip_create_proof: null argument");
         return ZKHIP_EINVAL;
     }
+    const uint64_t blinding_seed = in->blinding_seed;
+    const zk_blinding* bl = in->blinding;
     if (!pk->g || !pk->g_lagrange || !pk->domain) { set_error("zkhip_create_proof: proving key without SRS / domain"); return ZKHIP_EINVAL; }
     const uint32_t k = pk->k, bf = pk->blinding_factors;
     const size_t n = (size_t)1 << k;
@@ -85,8 +98,7 @@ extern "C" int zkhip_create_proof(zkhip_ctx* ctx, const zk_proving_key* pk, cons
         ZK_HIP(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
         ZK_HIP(hipEventCreateWithFlags(&ctx->side_event, hipEventDisableTiming));
     }
-    bool late = k <= 18;
-    if (const char* e = getenv("ZKHIP_LATE_OVERLAP")) late = atoi(e) != 0;
+    const bool late = ctx->opt.late_overlap >= 0 ? ctx->opt.late_overlap != 0 : k <= 18;
     Overlap ov{ctx, ctx->stream, ctx->side_stream, ctx->side_event, late};
     StreamGuard guard{ctx, ctx->stream};
     hipStream_t st = ctx->stream;
@@ -98,6 +110,42 @@ extern "C" int zkhip_create_proof(zkhip_ctx* ctx, const zk_proving_key* pk, cons
     ZK_TRY(ws("cp_coeff", (A + I) * NB, &w_coeff));
     ZK_TRY(ws("cp_ext", (A + I) * EB, &w_ext));
     ZK_TRY(ws("cp_rand", NB, &w_rand));
+    // host-side inputs (a Rust caller's Vec<Fr> columns, its instance values, its rng draws) are uploaded into library-owned columns
+    char *w_adv_in = nullptr, *w_ins_in = nullptr;
+    if (in->advice_on_host && A) ZK_TRY(ws("cp_adv_in", (size_t)A * NB, &w_adv_in));
+    if (!in->d_instance && I) ZK_TRY(ws("cp_ins_in", (size_t)I * NB, &w_ins_in));
+    std::vector<const void*> adv_cols(A), ins_cols(I);
+    for (uint32_t j = 0; j < A; ++j) {
+        if (in->advice_on_host) {
+            // plain asynchronous copies on the proof's stream: from pinned memory they run at link rate and the first MSM starts when
+            // they have landed; from pageable memory the runtime stages them (slower, still correct)
+            ZK_HIP(hipMemcpyAsync(w_adv_in + j * NB, in->advice[j], NB, hipMemcpyHostToDevice, st));
+            adv_cols[j] = w_adv_in + j * NB;
+        } else {
+            adv_cols[j] = in->advice[j];
+        }
+    }
+    for (uint32_t j = 0; j < I; ++j) {
+        if (in->d_instance) { ins_cols[j] = in->d_instance[j]; continue; }
+        const size_t len = in->instance_len[j];
+        if (len > n) { set_error("zkhip_create_proof: instance column %u has %zu values > n", j, len); return ZKHIP_EINVAL; }
+        ZK_HIP(hipMemsetAsync(w_ins_in + j * NB, 0, NB, st));
+        if (len) ZK_TRY(ctx->upload(w_ins_in + j * NB, in->instance_values[j], len * 32));
+        ins_cols[j] = w_ins_in + j * NB;
+    }
+    const void* const* d_advice = adv_cols.data();
+    const void* const* d_instance = ins_cols.data();
+    // the caller's rng draws (or the seeded stand-ins)
+    auto blind_rows = [&](const void* src, size_t offset_elems, size_t count, char* dst, uint64_t seed) -> int {
+        if (!count) return ZKHIP_OK;
+        if (bl && src) {
+            const char* from = (const char*)src + offset_elems * 32;
+            if (bl->on_host) return ctx->upload(dst, from, count * 32);
+            ZK_HIP(hipMemcpyAsync(dst, from, count * 32, hipMemcpyDeviceToDevice, ctx->stream));
+            return ZKHIP_OK;
+        }
+        return zkhip_synth_fill_device(ctx, dst, count, seed, 0);
+    };
     ZK_TRY(ws("cp_comp", 2 * L * NB, &w_comp));
     ZK_TRY(ws("cp_blind", (2 * L * (bf + 1) + (Zp + L) * bf + 8) * 32, &w_blind));
     ZK_TRY(ws("cp_perm_l", 2 * L * NB, &w_perm_l));
@@ -138,7 +186,19 @@ extern "C" int zkhip_create_proof(zkhip_ctx* ctx, const zk_proving_key* pk, cons
     };
 
     // ---- 1. advice (+ the vanishing argument's random polynomial, which depends on no challenge) ; coset NTTs of advice/instance overlap
-    ZK_TRY(zkhip_synth_fill_device(ctx, w_rand, n, blinding_seed + 380, 0));
+    if (bl && bl->random_poly) {
+        if (bl->on_host) ZK_HIP(hipMemcpyAsync(w_rand, bl->random_poly, NB, hipMemcpyHostToDevice, st));
+        else ZK_HIP(hipMemcpyAsync(w_rand, bl->random_poly, NB, hipMemcpyDeviceToDevice, st));
+    } else {
+        ZK_TRY(zkhip_synth_fill_device(ctx, w_rand, n, blinding_seed + 380, 0));
+    }
+    // vk.hash_into(transcript), then every instance value (KZG: hashed, not committed) — upstream's first transcript operations
+    if (tr->common_scalar) {
+        if (pk->vk_transcript_repr) tr->common_scalar(tr->user, pk->vk_transcript_repr);
+        if (in->instance_values)
+            for (uint32_t j = 0; j < I; ++j)
+                for (uint32_t i = 0; i < in->instance_len[j]; ++i) tr->common_scalar(tr->user, in->instance_values[j] + 4 * i);
+    }
     std::vector<void*> coeff_ptrs(A + I), ext_ptrs(A + I);
     for (uint32_t j = 0; j < A + I; ++j) { coeff_ptrs[j] = w_coeff + j * NB; ext_ptrs[j] = w_ext + j * EB; }
     std::vector<uint64_t> rand_xy;
@@ -193,8 +253,8 @@ extern "C" int zkhip_create_proof(zkhip_ctx* ctx, const zk_proving_key* pk, cons
             ZK_TRY(zk::permute_sorted_table_keys(ctx, pk->key_id, i, k, bf, comp_tab[i], &sorted_keys));
         char* bi = w_blind + (2 * i) * (bf + 1) * 32;
         char* bt = w_blind + (2 * i + 1) * (bf + 1) * 32;
-        ZK_TRY(zkhip_synth_fill_device(ctx, bi, bf + 1, blinding_seed + 300 + i, 0));
-        ZK_TRY(zkhip_synth_fill_device(ctx, bt, bf + 1, blinding_seed + 320 + i, 0));
+        ZK_TRY(blind_rows(bl ? bl->lookup_permuted : nullptr, (size_t)(2 * i) * (bf + 1), bf + 1, bi, blinding_seed + 300 + i));
+        ZK_TRY(blind_rows(bl ? bl->lookup_permuted : nullptr, (size_t)(2 * i + 1) * (bf + 1), bf + 1, bt, blinding_seed + 320 + i));
         ZK_TRY(zk::permute_expression_pair_async(ctx, k, bf, comp_in[i], comp_tab[i], bi, bt, w_perm_l + i * NB, w_perm_l + (L + i) * NB,
                                                  (uint32_t*)w_perr, sorted_keys));
     }
@@ -205,7 +265,9 @@ extern "C" int zkhip_create_proof(zkhip_ctx* ctx, const zk_proving_key* pk, cons
             for (uint32_t j = 0; j < 2 * L; ++j) lag[j] = w_perm_l + j * NB;
             ZK_TRY(zk::lagrange_to_coeff_oop(ctx, pk->domain, lag.data(), perm_c.data(), 2 * L));
         }
-        std::vector<const void*> cols(perm_c.begin(), perm_c.end());
+        // transcript order (lookup::Argument::commit_permuted per lookup): permuted input, then permuted table, lookup by lookup
+        std::vector<const void*> cols(2 * L);
+        for (uint32_t i = 0; i < L; ++i) { cols[2 * i] = perm_c[i]; cols[2 * i + 1] = perm_c[L + i]; }
         std::vector<const zkhip_srs*> bases(2 * L, pk->g);
         // the failure flag rides on the commitment's read-back: it must be known before anything enters the transcript
         uint32_t* h_err = (uint32_t*)((char*)ctx->h_pinned + zkhip_ctx::PINNED_BYTES - 16);
@@ -240,8 +302,8 @@ extern "C" int zkhip_create_proof(zkhip_ctx* ctx, const zk_proving_key* pk, cons
         }
         char* pb = w_blind + 2 * L * (bf + 1) * 32;
         char* lb = pb + (size_t)Zp * bf * 32;
-        if (Zp) ZK_TRY(zkhip_synth_fill_device(ctx, pb, (size_t)Zp * bf, blinding_seed + 340, 0));
-        ZK_TRY(zkhip_synth_fill_device(ctx, lb, (size_t)(L ? L : 1) * bf, blinding_seed + 360, 0));
+        if (Zp) ZK_TRY(blind_rows(bl ? bl->perm_z : nullptr, 0, (size_t)Zp * bf, pb, blinding_seed + 340));
+        if (L) ZK_TRY(blind_rows(bl ? bl->lookup_z : nullptr, 0, (size_t)L * bf, lb, blinding_seed + 360));
         ZK_TRY(zkhip_grand_products_device(ctx, k, beta, gamma, bf, values.data(), pk->sigma_lagrange, P, chunk, pb, z_ptrs.data(), L, ci.data(),
                                            ct.data(), pi.data(), pt.data(), lb, z_ptrs.data() + Zp));
     }
@@ -324,16 +386,34 @@ extern "C" int zkhip_create_proof(zkhip_ctx* ctx, const zk_proving_key* pk, cons
     polys.push_back(w_hpoly);
     std::vector<uint32_t> q_poly;
     std::vector<int32_t> q_rot;
-    auto q = [&](uint32_t poly, int32_t rot) { q_poly.push_back(poly); q_rot.push_back(rot); };
+    auto q = [&](uint32_t poly, int32_t rot) -> uint32_t { q_poly.push_back(poly); q_rot.push_back(rot); return (uint32_t)q_poly.size() - 1; };
     const int32_t last_rot = -(int32_t)(bf + 1);
-    for (uint32_t j = 0; j < pk->n_advice_queries; ++j) q(o_adv + pk->advice_query_column[j], pk->advice_query_rotation[j]);
-    for (uint32_t s_ = 0; s_ < Zp; ++s_) { q(o_pz + s_, 0); q(o_pz + s_, 1); }
-    for (uint32_t s_ = Zp; s_-- > 1;) q(o_pz + s_ - 1, last_rot);
-    for (uint32_t i = 0; i < L; ++i) { q(o_lk + 3 * i, 0); q(o_lk + 3 * i + 1, 0); q(o_lk + 3 * i + 2, 0); q(o_lk + 3 * i + 1, -1); q(o_lk + 3 * i, 1); }
-    for (uint32_t j = 0; j < pk->n_fixed_queries; ++j) q(o_fix + pk->fixed_query_column[j], pk->fixed_query_rotation[j]);
-    for (uint32_t j = 0; j < P; ++j) q(o_sig + j, 0);
+    // QUERY order (what the multi-open consumes): advice, permutation products, lookups, fixed, sigma, h, random
+    std::vector<uint32_t> i_adv, i_fix, i_sig, i_pz0(Zp), i_pz1(Zp), i_pzl(Zp, ~0u), i_lz0(L), i_la0(L), i_ls0(L), i_lam(L), i_lz1(L);
+    for (uint32_t j = 0; j < pk->n_advice_queries; ++j) i_adv.push_back(q(o_adv + pk->advice_query_column[j], pk->advice_query_rotation[j]));
+    for (uint32_t s_ = 0; s_ < Zp; ++s_) { i_pz0[s_] = q(o_pz + s_, 0); i_pz1[s_] = q(o_pz + s_, 1); }
+    for (uint32_t s_ = Zp; s_-- > 1;) i_pzl[s_ - 1] = q(o_pz + s_ - 1, last_rot);
+    for (uint32_t i = 0; i < L; ++i) {
+        i_lz0[i] = q(o_lk + 3 * i, 0); i_la0[i] = q(o_lk + 3 * i + 1, 0); i_ls0[i] = q(o_lk + 3 * i + 2, 0);
+        i_lam[i] = q(o_lk + 3 * i + 1, -1); i_lz1[i] = q(o_lk + 3 * i, 1);
+    }
+    for (uint32_t j = 0; j < pk->n_fixed_queries; ++j) i_fix.push_back(q(o_fix + pk->fixed_query_column[j], pk->fixed_query_rotation[j]));
+    for (uint32_t j = 0; j < P; ++j) i_sig.push_back(q(o_sig + j, 0));
     q(o_h, 0);
-    q(o_rand, 0);
+    const uint32_t i_rand = q(o_rand, 0);
+    // WRITE order (what the transcript / the proof bytes carry; plonk/prover.rs after squeezing x): advice evals, fixed evals,
+    // vanishing.evaluate (random), pk.permutation.evaluate (sigma), per set z(x), z(wx)[, z(w^last x)], per lookup z(x), z(wx), a'(x),
+    // a'(w^-1 x), s'(x)
+    std::vector<uint32_t> w_order;
+    w_order.insert(w_order.end(), i_adv.begin(), i_adv.end());
+    w_order.insert(w_order.end(), i_fix.begin(), i_fix.end());
+    w_order.push_back(i_rand);
+    w_order.insert(w_order.end(), i_sig.begin(), i_sig.end());
+    for (uint32_t s_ = 0; s_ < Zp; ++s_) {
+        w_order.push_back(i_pz0[s_]); w_order.push_back(i_pz1[s_]);
+        if (s_ + 1 < Zp) w_order.push_back(i_pzl[s_]);
+    }
+    for (uint32_t i = 0; i < L; ++i) { w_order.push_back(i_lz0[i]); w_order.push_back(i_lz1[i]); w_order.push_back(i_la0[i]); w_order.push_back(i_lam[i]); w_order.push_back(i_ls0[i]); }
     const size_t nq = q_poly.size();
     if (nq > max_q) { set_error("zkhip_create_proof: query count"); return ZKHIP_EINVAL; }
     std::vector<uint64_t> q_points(4 * nq), q_evals(4 * nq);
@@ -364,14 +444,14 @@ extern "C" int zkhip_create_proof(zkhip_ctx* ctx, const zk_proving_key* pk, cons
             ZK_TRY(zkhip_memcpy_d2h(ctx, q_evals.data(), w_evals, nq * 32));
         }
     }
-    for (size_t i = 0; i < nq; ++i)
-        if (q_poly[i] != o_h) tr->write_scalar(tr->user, q_evals.data() + 4 * i);   // the verifier recomputes h(x)
+    for (uint32_t i : w_order) tr->write_scalar(tr->user, q_evals.data() + 4 * (size_t)i);   // h(x) is not written: the verifier recomputes it
     if (out) {
         out->d_h = w_h;
         out->n_evals = nq;
         if (out->evals && out->evals_cap >= nq) memcpy(out->evals, q_evals.data(), nq * 32);
         if (out->eval_poly && out->evals_cap >= nq) memcpy(out->eval_poly, q_poly.data(), nq * 4);
         if (out->eval_rotation && out->evals_cap >= nq) memcpy(out->eval_rotation, q_rot.data(), nq * 4);
+        if (out->eval_write_order && out->evals_cap >= nq) memcpy(out->eval_write_order, w_order.data(), w_order.size() * 4);
     }
     // ---- 6. SHPLONK multi-open of all of them
     uint64_t h1[8], h2[8];

@@ -106,6 +106,14 @@ void t_write_scalar(void* user, const uint64_t scalar[4]) {
     t->state.update(msg, 33);
     t->proof.insert(t->proof.end(), msg + 1, msg + 33);
 }
+void t_common_scalar(void* user, const uint64_t scalar[4]) {   // Transcript::common_scalar: absorbed like a written scalar, no proof bytes
+    auto* t = (zkhip_blake2b_transcript*)user;
+    uint8_t msg[33];
+    msg[0] = 2;
+    fe32 s = abi_to_canonical_words<Fr>(mem_load(scalar));
+    memcpy(msg + 1, s.w, 32);
+    t->state.update(msg, 33);
+}
 void t_squeeze(void* user, uint64_t out[4]) {
     auto* t = (zkhip_blake2b_transcript*)user;
     const uint8_t zero = 0;
@@ -209,6 +217,12 @@ void e_write_scalar(void* user, const uint64_t scalar[4]) {
     t->buf.insert(t->buf.end(), b, b + 32);
     t->proof.insert(t->proof.end(), b, b + 32);
 }
+void e_common_scalar(void* user, const uint64_t scalar[4]) {
+    auto* t = (zkhip_evm_transcript*)user;
+    uint8_t b[32];
+    be32(abi_to_canonical_words<Fr>(mem_load(scalar)), b);
+    t->buf.insert(t->buf.end(), b, b + 32);
+}
 void e_squeeze(void* user, uint64_t out[4]) {
     auto* t = (zkhip_evm_transcript*)user;
     if (t->buf.size() == 32) t->buf.push_back(1);
@@ -223,6 +237,142 @@ void e_squeeze(void* user, uint64_t out[4]) {
 }
 }  // namespace
 
+// ------------------------------------------------------------------ Poseidon transcript
+// snark-verifier system/halo2/transcript/halo2.rs PoseidonTranscript<G1Affine, NativeLoader, Vec<u8>, T = 3, RATE = 2, R_F = 8,
+// R_P = 57> over util/hash/poseidon.rs [UPSTREAM-RECALL; crate pinned at /root/reference/Cargo.lock:2675-2693 / 2714-2716; the
+// transcript behind gen_snark_shplonk, /root/reference/src/helpers.rs:233,299 and src/bin/cli.rs:320,343,369,462]:
+//  * the permutation is Poseidon x^5 over BN254 Fr, t = 3, 8 full + 57 partial rounds, round constants and the Cauchy MDS matrix from
+//    the Grain LFSR of the Poseidon reference (field type 1, s-box 0, 254 bits; constants by rejection sampling, the 2t MDS seeds
+//    reduced mod r; first MDS candidate = SECURE_MDS 0).  The generator below reproduces the published permutation vector
+//    poseidonperm_x5_254_3 (tests/golden/poseidon.json) — the permutation is pinned against an external source.  Upstream runs
+//    the "optimized" form (pre-sparse MDS, shifted constants), which computes the same permutation;
+//  * sponge (from recall, not externally pinned): state = [2^64, 0, 0]; absorbed elements are buffered; squeeze() permutes once
+//    per chunk of RATE elements (state[1 + i] += chunk[i]; a short chunk adds 1 at position len + 1), once more on an empty
+//    chunk when the buffer length is a multiple of RATE (including 0), and returns state[1];
+//  * a point is absorbed as its x and y coordinates reduced into Fr (fe_to_fe), a scalar as itself; the proof stream receives the
+//    32-byte compressed point / the 32-byte little-endian scalar.
+namespace {
+struct PoseidonSpec {
+    static constexpr int T = 3, RATE = 2, R_F = 8, R_P = 57;
+    HF rc[R_F + R_P][T];
+    HF mds[T][T];
+    struct Grain {
+        uint8_t st[80];
+        int pos = 0;   // ring buffer start
+        int bit() {
+            auto at = [&](int i) { return st[(pos + i) % 80]; };
+            uint8_t b = at(62) ^ at(51) ^ at(38) ^ at(23) ^ at(13) ^ at(0);
+            st[pos] = b;
+            pos = (pos + 1) % 80;
+            return b;
+        }
+        int filtered() {
+            for (;;) { int a = bit(), b = bit(); if (a) return b; }
+        }
+        void raw(uint32_t w[8]) {   // 254 bits, most significant first
+            memset(w, 0, 32);
+            for (int i = 253; i >= 0; --i) if (filtered()) w[i >> 5] |= 1u << (i & 31);
+        }
+    };
+    static bool less_than_r(const uint32_t w[8]) {
+        for (int i = 3; i >= 0; --i) {
+            uint64_t v = w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+            if (v != hostfr::P[i]) return v < hostfr::P[i];
+        }
+        return false;
+    }
+    PoseidonSpec() {
+        Grain g;
+        int n = 0;
+        auto push = [&](uint32_t v, int bits) { for (int i = bits - 1; i >= 0; --i) g.st[n++] = (v >> i) & 1; };
+        push(1, 2); push(0, 4); push(254, 12); push(T, 12); push(R_F, 10); push(R_P, 10);
+        for (int i = 0; i < 30; ++i) g.st[n++] = 1;
+        for (int i = 0; i < 160; ++i) g.bit();
+        uint32_t w[8];
+        for (int r = 0; r < R_F + R_P; ++r)
+            for (int i = 0; i < T; ++i) {
+                do g.raw(w); while (!less_than_r(w));
+                rc[r][i] = hf_from_canonical_words(w);
+            }
+        HF xs[T], ys[T];
+        for (int i = 0; i < T; ++i) { g.raw(w); xs[i] = hf_from_canonical_words(w); }   // reduced mod r, no rejection
+        for (int i = 0; i < T; ++i) { g.raw(w); ys[i] = hf_from_canonical_words(w); }
+        for (int i = 0; i < T; ++i)
+            for (int j = 0; j < T; ++j) mds[i][j] = hf_invert(hadd(xs[i], ys[j]));
+    }
+    static const PoseidonSpec& get() { static const PoseidonSpec s; return s; }
+    static inline HF pow5(const HF& a) { HF a2 = hmul(a, a); return hmul(hmul(a2, a2), a); }
+    void mix(HF s[T]) const {
+        HF o[T];
+        for (int i = 0; i < T; ++i) {
+            o[i] = hmul(mds[i][0], s[0]);
+            for (int j = 1; j < T; ++j) o[i] = hadd(o[i], hmul(mds[i][j], s[j]));
+        }
+        for (int i = 0; i < T; ++i) s[i] = o[i];
+    }
+    void permute(HF s[T]) const {
+        int r = 0;
+        for (int f = 0; f < R_F / 2; ++f, ++r) { for (int i = 0; i < T; ++i) s[i] = pow5(hadd(s[i], rc[r][i])); mix(s); }
+        for (int p_ = 0; p_ < R_P; ++p_, ++r) { for (int i = 0; i < T; ++i) s[i] = hadd(s[i], rc[r][i]); s[0] = pow5(s[0]); mix(s); }
+        for (int f = 0; f < R_F / 2; ++f, ++r) { for (int i = 0; i < T; ++i) s[i] = pow5(hadd(s[i], rc[r][i])); mix(s); }
+    }
+};
+}  // namespace
+
+struct zkhip_poseidon_transcript {
+    zk_transcript cb;
+    HF state[3];
+    std::vector<HF> buf;
+    std::vector<uint8_t> proof;
+    std::vector<uint64_t> points_xy, challenges;
+};
+
+namespace {
+inline HF fq_coordinate_in_fr(const uint64_t* mont_fq) {   // fe_to_fe: the integer value of an Fq element, reduced mod r
+    fe32 c = abi_to_canonical_words<Fq>(mem_load(mont_fq));
+    return hf_from_canonical_words(c.w);
+}
+void p_absorb_point(zkhip_poseidon_transcript* t, const uint64_t xy[8]) {
+    t->buf.push_back(fq_coordinate_in_fr(xy));
+    t->buf.push_back(fq_coordinate_in_fr(xy + 4));
+}
+void p_write_point(void* user, const uint8_t bytes32[32], const uint64_t xy[8]) {
+    auto* t = (zkhip_poseidon_transcript*)user;
+    p_absorb_point(t, xy);
+    t->proof.insert(t->proof.end(), bytes32, bytes32 + 32);
+    t->points_xy.insert(t->points_xy.end(), xy, xy + 8);
+}
+void p_common_scalar(void* user, const uint64_t scalar[4]) {
+    auto* t = (zkhip_poseidon_transcript*)user;
+    t->buf.push_back(hf_from_abi(scalar));
+}
+void p_write_scalar(void* user, const uint64_t scalar[4]) {
+    auto* t = (zkhip_poseidon_transcript*)user;
+    t->buf.push_back(hf_from_abi(scalar));
+    fe32 s = abi_to_canonical_words<Fr>(mem_load(scalar));
+    const uint8_t* b = (const uint8_t*)s.w;
+    t->proof.insert(t->proof.end(), b, b + 32);
+}
+void p_squeeze(void* user, uint64_t out[4]) {
+    auto* t = (zkhip_poseidon_transcript*)user;
+    const PoseidonSpec& sp = PoseidonSpec::get();
+    constexpr size_t RATE = PoseidonSpec::RATE;
+    const size_t len = t->buf.size();
+    const bool exact = len % RATE == 0;
+    for (size_t off = 0; off < len; off += RATE) {
+        const size_t m = std::min(RATE, len - off);
+        for (size_t i = 0; i < m; ++i) t->state[1 + i] = hadd(t->state[1 + i], t->buf[off + i]);
+        if (m < RATE) t->state[m + 1] = hadd(t->state[m + 1], hone());
+        sp.permute(t->state);
+    }
+    if (exact) { t->state[1] = hadd(t->state[1], hone()); sp.permute(t->state); }
+    t->buf.clear();
+    fe32 abi = hf_abi(t->state[1]);
+    memcpy(out, abi.w, 32);
+    t->challenges.insert(t->challenges.end(), out, out + 4);
+}
+}  // namespace
+
 extern "C" {
 
 zkhip_evm_transcript* zkhip_evm_transcript_new(void) {
@@ -231,6 +381,7 @@ zkhip_evm_transcript* zkhip_evm_transcript_new(void) {
     t->cb.write_point = e_write_point;
     t->cb.squeeze_challenge = e_squeeze;
     t->cb.write_scalar = e_write_scalar;
+    t->cb.common_scalar = e_common_scalar;
     return t;
 }
 void zkhip_evm_transcript_free(zkhip_evm_transcript* t) { delete t; }
@@ -256,6 +407,7 @@ zkhip_blake2b_transcript* zkhip_blake2b_transcript_new(void) {
     t->cb.write_point = t_write_point;
     t->cb.squeeze_challenge = t_squeeze;
     t->cb.write_scalar = t_write_scalar;
+    t->cb.common_scalar = t_common_scalar;
     return t;
 }
 void zkhip_blake2b_transcript_free(zkhip_blake2b_transcript* t) { delete t; }
@@ -274,6 +426,54 @@ size_t zkhip_blake2b_transcript_challenges(const zkhip_blake2b_transcript* t, co
     if (!t) return 0;
     if (limbs) *limbs = t->challenges.data();
     return t->challenges.size() / 4;
+}
+
+zkhip_poseidon_transcript* zkhip_poseidon_transcript_new(void) {
+    auto* t = new zkhip_poseidon_transcript();
+    t->state[0] = HF{{0, 1, 0, 0}};                       // 2^64 as an integer ...
+    t->state[0] = hmul(t->state[0], hf_from_abi(HF{{0x1bb8e645ae216da7ull, 0x53fe3ab1e35c59e3ull, 0x8c49833d53bb8085ull, 0x0216d0b17f4e44a5ull}}.w));   // ... into Montgomery form (x R^2 / R)
+    t->state[1] = t->state[2] = hzero();
+    t->cb.user = t;
+    t->cb.write_point = p_write_point;
+    t->cb.squeeze_challenge = p_squeeze;
+    t->cb.write_scalar = p_write_scalar;
+    t->cb.common_scalar = p_common_scalar;
+    return t;
+}
+void zkhip_poseidon_transcript_free(zkhip_poseidon_transcript* t) { delete t; }
+const zk_transcript* zkhip_poseidon_transcript_callbacks(zkhip_poseidon_transcript* t) { return t ? &t->cb : nullptr; }
+size_t zkhip_poseidon_transcript_proof(const zkhip_poseidon_transcript* t, const uint8_t** bytes) {
+    if (!t) return 0;
+    if (bytes) *bytes = t->proof.data();
+    return t->proof.size();
+}
+size_t zkhip_poseidon_transcript_points(const zkhip_poseidon_transcript* t, const uint64_t** xy) {
+    if (!t) return 0;
+    if (xy) *xy = t->points_xy.data();
+    return t->points_xy.size() / 8;
+}
+size_t zkhip_poseidon_transcript_challenges(const zkhip_poseidon_transcript* t, const uint64_t** limbs) {
+    if (!t) return 0;
+    if (limbs) *limbs = t->challenges.data();
+    return t->challenges.size() / 4;
+}
+/* The bare permutation (state: 3 x 4 u64, ABI form, in place) and the generated parameters (rc: 65 x 3, mds: 3 x 3 row-major; ABI
+ * form): exposed so that the generator can be checked against the published poseidonperm_x5_254_3 vector. */
+void zkhip_poseidon_permute(uint64_t state[12]) {
+    HF s[3];
+    for (int i = 0; i < 3; ++i) s[i] = hf_from_abi(state + 4 * i);
+    PoseidonSpec::get().permute(s);
+    for (int i = 0; i < 3; ++i) { fe32 o = hf_abi(s[i]); memcpy(state + 4 * i, o.w, 32); }
+}
+void zkhip_poseidon_params(uint64_t* rc, uint64_t* mds) {
+    const PoseidonSpec& sp = PoseidonSpec::get();
+    if (rc) for (int r = 0; r < 65; ++r) for (int i = 0; i < 3; ++i) { fe32 o = hf_abi(sp.rc[r][i]); memcpy(rc + 4 * (3 * r + i), o.w, 32); }
+    if (mds) for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { fe32 o = hf_abi(sp.mds[i][j]); memcpy(mds + 4 * (3 * i + j), o.w, 32); }
+}
+size_t zkhip_evm_transcript_points(const zkhip_evm_transcript* t, const uint64_t** xy) {
+    if (!t) return 0;
+    if (xy) *xy = t->points_xy.data();
+    return t->points_xy.size() / 8;
 }
 
 }  // extern "C"

@@ -53,7 +53,7 @@ class ZkEvalhArgs(C.Structure):
 
 # every symbol include/zkhip.h declares (checked by tests/test_abi.py without a GPU)
 SYMBOLS = [
-    "zkhip_init", "zkhip_destroy", "zkhip_last_error", "zkhip_set_stream", "zkhip_synchronize", "zkhip_malloc", "zkhip_free",
+    "zkhip_init", "zkhip_destroy", "zkhip_last_error", "zkhip_set_stream", "zkhip_synchronize", "zkhip_set_option", "zkhip_trim", "zkhip_malloc", "zkhip_free",
     "zkhip_memcpy_h2d", "zkhip_memcpy_d2h", "zkhip_timer_start", "zkhip_timer_stop_ms",
     "zkhip_profile_enable", "zkhip_profile_select", "zkhip_profile_read",
     "zkhip_srs_load", "zkhip_srs_load_device", "zkhip_srs_free", "zkhip_srs_len", "zkhip_srs_window", "zkhip_kzg_setup", "zkhip_srs_read",
@@ -68,11 +68,13 @@ SYMBOLS = [
     "zkhip_batch_invert_device", "zkhip_eval_polynomial_device", "zkhip_eval_polynomials_at_device", "zkhip_permutation_products_device",
     "zkhip_permute_expression_pair_device", "zkhip_lookup_product_device", "zkhip_grand_products_device",
     "zkhip_linear_combination_device", "zkhip_divide_by_linear_device", "zkhip_kate_division_device", "zkhip_shplonk_open",
-    "zkhip_create_proof",
+    "zkhip_create_proof", "zkhip_create_proof_ex",
     "zkhip_blake2b_transcript_new", "zkhip_blake2b_transcript_free", "zkhip_blake2b_transcript_callbacks", "zkhip_blake2b_transcript_proof",
     "zkhip_blake2b_transcript_points", "zkhip_blake2b_transcript_challenges",
     "zkhip_evm_transcript_new", "zkhip_evm_transcript_free", "zkhip_evm_transcript_callbacks", "zkhip_evm_transcript_proof",
-    "zkhip_evm_transcript_challenges", "zkhip_keccak256",
+    "zkhip_evm_transcript_challenges", "zkhip_evm_transcript_points", "zkhip_keccak256",
+    "zkhip_poseidon_transcript_new", "zkhip_poseidon_transcript_free", "zkhip_poseidon_transcript_callbacks", "zkhip_poseidon_transcript_proof",
+    "zkhip_poseidon_transcript_points", "zkhip_poseidon_transcript_challenges", "zkhip_poseidon_permute", "zkhip_poseidon_params",
 ]
 
 
@@ -168,6 +170,13 @@ class Context:
 
     def synchronize(self):
         _check(lib().zkhip_synchronize(self.h))
+
+    def set_option(self, name, value):
+        """a tuning knob by its short ("msm_c") or environment ("ZKHIP_MSM_C") name; the environment itself is read once, in zkhip_init"""
+        _check(lib().zkhip_set_option(self.h, name.encode(), C.c_int(int(value))))
+
+    def trim(self):
+        _check(lib().zkhip_trim(self.h))
 
     def timer_start(self):
         _check(lib().zkhip_timer_start(self.h))
@@ -317,12 +326,13 @@ WRITE_SCALAR_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint64))
 
 
 class ZkTranscript(C.Structure):
-    _fields_ = [("user", C.c_void_p), ("write_point", WRITE_POINT_FN), ("squeeze_challenge", SQUEEZE_FN), ("write_scalar", WRITE_SCALAR_FN)]
+    _fields_ = [("user", C.c_void_p), ("write_point", WRITE_POINT_FN), ("squeeze_challenge", SQUEEZE_FN), ("write_scalar", WRITE_SCALAR_FN),
+                ("common_scalar", WRITE_SCALAR_FN)]
 
 
-def make_transcript(write_point, squeeze_challenge, write_scalar=None):
+def make_transcript(write_point, squeeze_challenge, write_scalar=None, common_scalar=None):
     """zk_transcript over Python callables: write_point(bytes32, xy (8,) uint64), squeeze_challenge() -> 4 ABI limbs,
-    write_scalar((4,) uint64 ABI limbs).  Keep the returned object alive for the duration of the call."""
+    write_scalar / common_scalar((4,) uint64 ABI limbs).  Keep the returned object alive for the duration of the call."""
     def _wp(user, b, xy):
         write_point(C.string_at(b, 32), np.frombuffer(C.string_at(xy, 64), dtype=np.uint64))
 
@@ -332,58 +342,105 @@ def make_transcript(write_point, squeeze_challenge, write_scalar=None):
     def _ws(user, sc):
         write_scalar(np.frombuffer(C.string_at(sc, 32), dtype=np.uint64))
 
-    return ZkTranscript(None, WRITE_POINT_FN(_wp), SQUEEZE_FN(_sq), WRITE_SCALAR_FN(_ws) if write_scalar else WRITE_SCALAR_FN())
+    def _cs(user, sc):
+        common_scalar(np.frombuffer(C.string_at(sc, 32), dtype=np.uint64))
+
+    return ZkTranscript(None, WRITE_POINT_FN(_wp), SQUEEZE_FN(_sq), WRITE_SCALAR_FN(_ws) if write_scalar else WRITE_SCALAR_FN(),
+                        WRITE_SCALAR_FN(_cs) if common_scalar else WRITE_SCALAR_FN())
 
 
-class NativeTranscript:
-    """The library's Blake2bWrite (zkhip_blake2b_transcript_*): no Python in the proof's critical path."""
+class LibTranscript:
+    """One of the library's ready-made transcripts (host code; usable without a GPU):
+      "blake2b"  halo2's Blake2bWrite                      zkhip_blake2b_transcript_*
+      "evm"      snark-verifier's EvmTranscript (Keccak)   zkhip_evm_transcript_*     gen_evm_proof_shplonk, /root/reference/src/bin/cli.rs:519
+      "poseidon" snark-verifier's PoseidonTranscript       zkhip_poseidon_transcript_* gen_snark_shplonk, src/helpers.rs:233,299
+    `callbacks` is the zk_transcript* zkhip_create_proof takes; the methods drive the same object from Python (the Python schedule)."""
 
-    def __init__(self):
-        self.h = C.c_void_p(lib().zkhip_blake2b_transcript_new())
-        self.callbacks = C.c_void_p(lib().zkhip_blake2b_transcript_callbacks(self.h))
+    POINT_BYTES = {"blake2b": 32, "evm": 64, "poseidon": 32}
+
+    def __init__(self, kind="blake2b"):
+        if kind not in self.POINT_BYTES:
+            raise ValueError(kind)
+        self.kind = kind
+        self._pfx = f"zkhip_{kind}_transcript_"
+        self.h = C.c_void_p(self._fn("new")())
+        self.callbacks = C.c_void_p(self._fn("callbacks")(self.h))
+        self._cb = ZkTranscript.from_address(self.callbacks.value)
+
+    def _fn(self, name):
+        f = getattr(lib(), self._pfx + name)
+        if name in ("new", "callbacks"):
+            f.restype = C.c_void_p
+        elif name in ("proof", "points", "challenges"):
+            f.restype = C.c_size_t
+        return f
 
     def __del__(self):
         if getattr(self, "h", None) and self.h.value and lib is not None:
-            lib().zkhip_blake2b_transcript_free(self.h)
+            self._fn("free")(self.h)
             self.h = C.c_void_p()
 
     def proof(self):
         p = C.POINTER(C.c_uint8)()
-        n = lib().zkhip_blake2b_transcript_proof(self.h, C.byref(p))
+        n = self._fn("proof")(self.h, C.byref(p))
         return C.string_at(p, n) if n else b""
 
     def points(self):
         p = C.POINTER(C.c_uint64)()
-        n = lib().zkhip_blake2b_transcript_points(self.h, C.byref(p))
+        n = self._fn("points")(self.h, C.byref(p))
         return np.frombuffer(C.string_at(p, n * 64), dtype=np.uint64).reshape(n, 8) if n else np.zeros((0, 8), dtype=np.uint64)
 
     def challenges(self):
         p = C.POINTER(C.c_uint64)()
-        n = lib().zkhip_blake2b_transcript_challenges(self.h, C.byref(p))
+        n = self._fn("challenges")(self.h, C.byref(p))
         return np.frombuffer(C.string_at(p, n * 32), dtype=np.uint64).reshape(n, 4) if n else np.zeros((0, 4), dtype=np.uint64)
 
+    # ---- the same transcript driven from Python
+    def write_point(self, xy, bytes32=None):
+        xy = _u64(xy)
+        b = bytes32 if bytes32 is not None else g1_to_bytes(xy)
+        self._cb.write_point(self._cb.user, (C.c_uint8 * 32)(*b), xy.ctypes.data_as(C.POINTER(C.c_uint64)))
 
-class EvmTranscript:
+    def write_scalar(self, limbs):
+        limbs = _u64(limbs)
+        self._cb.write_scalar(self._cb.user, limbs.ctypes.data_as(C.POINTER(C.c_uint64)))
+
+    def common_scalar(self, limbs):
+        limbs = _u64(limbs)
+        self._cb.common_scalar(self._cb.user, limbs.ctypes.data_as(C.POINTER(C.c_uint64)))
+
+    def squeeze_limbs(self):
+        out = (C.c_uint64 * 4)()
+        self._cb.squeeze_challenge(self._cb.user, out)
+        return np.array(list(out), dtype=np.uint64)
+
+
+class NativeTranscript(LibTranscript):
+    """The library's Blake2bWrite (zkhip_blake2b_transcript_*): no Python in the proof's critical path."""
+
+    def __init__(self):
+        super().__init__("blake2b")
+
+
+class EvmTranscript(LibTranscript):
     """The library's EvmTranscript (Keccak-256; snark-verifier's transcript for EVM proofs)."""
 
     def __init__(self):
-        self.h = C.c_void_p(lib().zkhip_evm_transcript_new())
-        self.callbacks = C.c_void_p(lib().zkhip_evm_transcript_callbacks(self.h))
+        super().__init__("evm")
 
-    def __del__(self):
-        if getattr(self, "h", None) and self.h.value and lib is not None:
-            lib().zkhip_evm_transcript_free(self.h)
-            self.h = C.c_void_p()
 
-    def proof(self):
-        p = C.POINTER(C.c_uint8)()
-        n = lib().zkhip_evm_transcript_proof(self.h, C.byref(p))
-        return C.string_at(p, n) if n else b""
+class PoseidonTranscript(LibTranscript):
+    """The library's PoseidonTranscript (snark-verifier's native transcript: every gen_snark_shplonk proof of the reference)."""
 
-    def challenges(self):
-        p = C.POINTER(C.c_uint64)()
-        n = lib().zkhip_evm_transcript_challenges(self.h, C.byref(p))
-        return np.frombuffer(C.string_at(p, n * 32), dtype=np.uint64).reshape(n, 4) if n else np.zeros((0, 4), dtype=np.uint64)
+    def __init__(self):
+        super().__init__("poseidon")
+
+
+def poseidon_permute(state_limbs):
+    """the bare Poseidon permutation on 3 ABI elements ((3, 4) uint64) -> (3, 4)"""
+    st = _u64(state_limbs).reshape(3, 4).copy()
+    lib().zkhip_poseidon_permute(_p(st))
+    return st
 
 
 def keccak256(data, pad=0x01):
@@ -407,12 +464,22 @@ class ZkProvingKey(C.Structure):
                 ("n_advice_queries", C.c_uint32), ("n_fixed_queries", C.c_uint32),
                 ("advice_query_column", C.c_void_p), ("advice_query_rotation", C.c_void_p),
                 ("fixed_query_column", C.c_void_p), ("fixed_query_rotation", C.c_void_p),
-                ("delta", C.c_uint64 * 4)]
+                ("delta", C.c_uint64 * 4), ("vk_transcript_repr", C.c_void_p)]
 
 
 class ZkProofOut(C.Structure):
     _fields_ = [("d_h", C.c_void_p), ("evals", C.c_void_p), ("eval_poly", C.c_void_p), ("eval_rotation", C.c_void_p),
-                ("evals_cap", C.c_size_t), ("n_evals", C.c_size_t)]
+                ("eval_write_order", C.c_void_p), ("evals_cap", C.c_size_t), ("n_evals", C.c_size_t)]
+
+
+class ZkBlinding(C.Structure):
+    _fields_ = [("lookup_permuted", C.c_void_p), ("perm_z", C.c_void_p), ("lookup_z", C.c_void_p), ("random_poly", C.c_void_p),
+                ("on_host", C.c_int)]
+
+
+class ZkProofInputs(C.Structure):
+    _fields_ = [("advice", C.c_void_p), ("advice_on_host", C.c_int), ("d_instance", C.c_void_p), ("instance_values", C.c_void_p),
+                ("instance_len", C.c_void_p), ("blinding", C.c_void_p), ("blinding_seed", C.c_uint64)]
 
 
 def shplonk_open(ctx, params, polys, query_poly, query_points, query_evals, write_point, squeeze_challenge):
@@ -443,6 +510,57 @@ def _ptr_array(tensors):
     return (C.c_void_p * max(1, len(tensors)))(*[t.data_ptr() for t in tensors])
 
 
+_FQ = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
+_FR = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+# BN254 G2 generator (EIP-197 / halo2curves bn256 G2 [UPSTREAM-RECALL]); Fq2 = Fq[u] / (u^2 + 1), curve y^2 = x^3 + 3 / (9 + u)
+_G2X = (10857046999023057135944570762232829481370756359578518086990519993285655852781,
+        11559732032986387107991004021392285783925812861821192530917403151452391805634)
+_G2Y = (8495653923123431417604973247489272438418190587263600148770280649306958101930,
+        4082367875863433681332203403145435568316851327593401208105741076214120093531)
+
+
+def _g2_setup_bytes(s_int):
+    """ParamsKZG::setup's G2 half on the host (big-int Fq2 arithmetic; setup time only): g2 and [s] g2 as 2 x 128 RawBytes
+    (x.c0, x.c1, y.c0, y.c1: 4 LE u64 Montgomery limbs each).  Only the verifier's pairing uses them; the file format carries them."""
+    q = _FQ
+    mul = lambda a, b: ((a[0] * b[0] - a[1] * b[1]) % q, (a[0] * b[1] + a[1] * b[0]) % q)
+    add = lambda a, b: ((a[0] + b[0]) % q, (a[1] + b[1]) % q)
+    sub = lambda a, b: ((a[0] - b[0]) % q, (a[1] - b[1]) % q)
+
+    def inv(a):
+        d = pow((a[0] * a[0] + a[1] * a[1]) % q, q - 2, q)
+        return (a[0] * d % q, (-a[1]) * d % q)
+
+    b2 = mul((3, 0), inv((9, 1)))
+    assert mul(_G2Y, _G2Y) == add(mul(mul(_G2X, _G2X), _G2X), b2), "G2 generator not on the twist"
+
+    def padd(p1, p2):      # affine, None = identity
+        if p1 is None:
+            return p2
+        if p2 is None:
+            return p1
+        if p1[0] == p2[0]:
+            if add(p1[1], p2[1]) == (0, 0):
+                return None
+            lam = mul(mul((3, 0), mul(p1[0], p1[0])), inv(add(p1[1], p1[1])))
+        else:
+            lam = mul(sub(p2[1], p1[1]), inv(sub(p2[0], p1[0])))
+        x3 = sub(sub(mul(lam, lam), p1[0]), p2[0])
+        return (x3, sub(mul(lam, sub(p1[0], x3)), p1[1]))
+
+    acc, base, e = None, (_G2X, _G2Y), s_int % _FR
+    while e:
+        if e & 1:
+            acc = padd(acc, base)
+        base = padd(base, base)
+        e >>= 1
+    out = b""
+    for pt in ((_G2X, _G2Y), acc):
+        for c in (pt[0][0], pt[0][1], pt[1][0], pt[1][1]) if pt is not None else (0, 0, 0, 0):
+            out += (c * (1 << 256) % q).to_bytes(32, "little")
+    return out
+
+
 class ParamsKZG:
     """ParamsKZG<Bn256> restricted to what the prover's commitments use: g and g_lagrange."""
 
@@ -455,7 +573,11 @@ class ParamsKZG:
         """ParamsKZG::setup(k, rng) with the trapdoor given (Montgomery Fr limbs)."""
         g, gl = C.c_void_p(), C.c_void_p()
         _check(lib().zkhip_kzg_setup(ctx.h, C.c_uint32(k), _p(_u64(s)), C.byref(g), C.byref(gl)))
-        return cls(ctx, k, g, gl)
+        p = cls(ctx, k, g, gl)
+        sl = _u64(s)
+        s_int = sum(int(sl[i]) << (64 * i) for i in range(4)) * pow(1 << 256, -1, _FR) % _FR
+        p.g2_bytes = _g2_setup_bytes(s_int)      # the real g2 and [s] g2: a file written from these params is a complete ParamsKZG
+        return p
 
     @classmethod
     def from_bases(cls, ctx, k, g_xy=None, g_lagrange_xy=None):
@@ -491,13 +613,16 @@ class ParamsKZG:
         return p
 
     def write(self, path):
+        if getattr(self, "g2_bytes", None) is None or len(self.g2_bytes) != 256:
+            raise ZkhipError("ParamsKZG.write: these params carry no G2 points (loaded from bare bases); refusing to write an SRS file "
+                             "with an identity g2 / s_g2")
         with open(path, "wb") as f:
             f.write(int(self.k).to_bytes(4, "little"))
             for h in (self.g, self.g_lagrange):
                 for first in range(0, self.n, 1 << 16):
                     cnt = min(1 << 16, self.n - first)
                     f.write(self.read_bases(h, first, cnt).astype("<u8").tobytes())
-            f.write(getattr(self, "g2_bytes", bytes(256)))
+            f.write(self.g2_bytes)
 
     def window(self):
         c, w = C.c_uint32(), C.c_uint32()

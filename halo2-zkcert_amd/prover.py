@@ -45,6 +45,7 @@ class CircuitShape:
     def __init__(self, name, k, n_basic_advice, n_lookup_advice, n_instance, degree, blinding_factors, seed, gates=None,
                  n_fixed=None, perm_columns=None):
         self.name, self.k, self.seed = name, k, seed
+        self.layout = "halo2-lib"
         self.n_basic, self.n_lookup = n_basic_advice, n_lookup_advice
         self.n_advice = n_basic_advice + n_lookup_advice
         self.n_instance = n_instance
@@ -99,8 +100,10 @@ class CircuitShape:
             else:               # round-constant addition with a carry bit, degree 5 with two selectors
                 t = ("sum", ("sum", A(c, 0), A(c - 1, 0)), F((c + 1) % n_fixed))
                 gates.append(("prod", ("prod", q, F((c + 5) % n_fixed)), ("prod", t, ("prod", A(c - 3, 0), ("sum", one, ("neg", A(c - 3, 1)))))))
-        return cls(f"sha256_k{k}", k, n_advice, 0, 1, 5, 6, 0x5A256000 + k, gates=gates, n_fixed=n_fixed,
-                   perm_columns=[("advice", 0), ("advice", 1), ("instance", 0)])
+        sh = cls(f"sha256_k{k}", k, n_advice, 0, 1, 5, 6, 0x5A256000 + k, gates=gates, n_fixed=n_fixed,
+                 perm_columns=[("advice", 0), ("advice", 1), ("instance", 0)])
+        sh.layout = "sha"
+        return sh
 
     @classmethod
     def small(cls, k=8):
@@ -166,9 +169,41 @@ class Blake2bTranscript:
     def write_scalar(self, limbs):
         self.state.update(b"\x02" + self._canon(limbs, R_INV_256, R))
 
+    common_scalar = write_scalar      # absorbed the same way; only the proof stream differs (and this class keeps none)
+
     def squeeze(self):
         self.state.update(b"\x00")
         return int.from_bytes(self.state.copy().digest(), "little") % R
+
+
+class LibTranscriptAdapter:
+    """The library's ready-made transcripts (ffi.LibTranscript: "blake2b", "evm", "poseidon") behind the interface the Python schedule
+    uses (write_point / write_scalar / common_scalar on ABI limbs, squeeze() -> canonical int)."""
+
+    def __init__(self, kind):
+        from . import ffi
+
+        self.t = ffi.LibTranscript(kind)
+
+    def write_point(self, xy):
+        self.t.write_point(np.ascontiguousarray(xy, dtype=np.uint64))
+
+    def write_scalar(self, limbs):
+        self.t.write_scalar(limbs)
+
+    def common_scalar(self, limbs):
+        self.t.common_scalar(limbs)
+
+    def squeeze(self):
+        return from_mont_host(self.t.squeeze_limbs())
+
+    def proof(self):
+        return self.t.proof()
+
+
+def make_transcript(kind):
+    """"blake2b-py": Blake2bTranscript above (hashlib); "blake2b" / "evm" / "poseidon": the library's"""
+    return Blake2bTranscript() if kind == "blake2b-py" else LibTranscriptAdapter(kind)
 
 
 def challenge(tag, commitment_bytes):
@@ -214,17 +249,24 @@ class GpuBackend:
 
     def setup(self, k, degree, s_int):
         # params_file (set by a caller that mirrors the reference's `gen_srs(k)` under PARAMS_DIR, /root/reference/src/bin/cli.rs:222):
-        # read the SRS file if it is there, otherwise generate the synthetic one and leave it there for the next run
+        # read that SRS file if it is there (a real kzg_bn254_<k>.srs).  Otherwise generate the synthetic one (a PUBLIC trapdoor:
+        # test / benchmark material only) and keep it beside it under a name the reference never reads, <stem>.synthetic.srs, so that
+        # a later run of the reference CLI in the same directory cannot pick up an SRS whose trapdoor is known.
         pf = getattr(self, "params_file", None)
-        if pf and os.path.exists(pf):
-            self.params = self.ffi.ParamsKZG.read(self.ctx, pf)
+        syn = (pf[:-4] if pf and pf.endswith(".srs") else pf) + ".synthetic.srs" if pf else None
+        src = pf if pf and os.path.exists(pf) else (syn if syn and os.path.exists(syn) else None)
+        if src:
+            self.params = self.ffi.ParamsKZG.read(self.ctx, src)
             if self.params.k != k:
-                raise ValueError(f"{pf}: k = {self.params.k}, expected {k}")
+                raise ValueError(f"{src}: k = {self.params.k}, expected {k}")
+            self.params_source = src
         else:
             self.params = self.ffi.ParamsKZG.setup(self.ctx, k, self.fr(s_int))
-            if pf:
-                os.makedirs(os.path.dirname(pf) or ".", exist_ok=True)
-                self.params.write(pf)
+            self.params_source = "generated"
+            if syn:
+                os.makedirs(os.path.dirname(syn) or ".", exist_ok=True)
+                self.params.write(syn)
+                self.params_source = syn
         self.domain = self.ffi.EvaluationDomain(self.ctx, degree, k)
         return self.domain
 
@@ -577,6 +619,14 @@ class Prover:
                 pair.append(g)
             self.compress_graphs.append(pair)
         self.omega = pow(ROOT_OF_UNITY, 1 << (28 - sh.k), R)
+        # vk.transcript_repr stand-in (upstream: a Blake2b hash of the verifying key's Debug form, absorbed first by vk.hash_into)
+        self.vk_repr = fr_from_int_host(int.from_bytes(hashlib.blake2b(sh.name.encode(), digest_size=64).digest(), "little") % R)
+
+    @property
+    def n_instance_values(self):
+        """values per instance column (the RSA circuit exposes 32 digest bytes, /root/reference/src/helpers.rs:167; the rest of the
+        column is zero as in upstream's instance polynomial)"""
+        return min(32, self.n - (self.shape.blinding_factors + 1))
 
     def _build_satisfiable(self, seed):
         """Selectors, copy constraints and the witness recipe of a satisfiable instance (witness-synthesis stand-in):
@@ -587,6 +637,8 @@ class Prover:
             sweep interpreter on the Lagrange domain.
         Only index arithmetic happens on the host; every field value is produced by the backend."""
         sh, b, n = self.shape, self.b, self.n
+        if sh.layout == "sha":
+            return self._build_satisfiable_sha(seed)
         assert sh.n_basic and sh.gates and len(sh.gates) == sh.n_basic, "satisfiable instances need the halo2-lib gate shape"
         u = n - (sh.blinding_factors + 1)
         one = fr_from_int_host(1)
@@ -610,14 +662,44 @@ class Prover:
         dst_rows = rng.permutation(gate_rows)[:m] + 2                      # `c` inputs when the partner is a basic column
         other_rows = rng.permutation(u)[:m]
         pairs = []
+        inst_used = [0] * sh.n_instance
         for t in range(m):
             pcol = partner_cols[t % len(partner_cols)]
             kind, idx = sh.perm_columns[pcol]
             prow = dst_rows[t] if (kind == "advice" and idx < sh.n_basic) else other_rows[t]
+            if kind == "instance":      # only the first rows of an instance column carry values: one copy per public input, then constants
+                if inst_used[idx] < self.n_instance_values:
+                    prow = inst_used[idx]
+                    inst_used[idx] += 1
+                else:
+                    pcol = col_of[("fixed", sh.n_basic)]
             pairs.append((col_of[("advice", t % sh.n_basic)] * n + int(src_rows[t]), pcol * n + int(prow)))
+        self._set_copy_constraints(pairs)
+        # out = mask * (a(-3) + a(-2) a(-1)) + (1 - mask) * a(0), per basic column; the mask is appended to the fixed columns
+        self._fill_graphs = []
+        A = lambda c, r: ("advice", c, r)
+        for c in range(sh.n_basic):
+            mk = ("fixed", sh.n_fixed, 0)
+            e = ("sum", ("prod", mk, ("sum", A(c, -3), ("prod", A(c, -2), A(c, -1)))), ("prod", ("sum", ("const", 1), ("neg", mk)), A(c, 0)))
+            self._fill_graphs.append((c, self._fill_graph(e)))
+
+    @staticmethod
+    def _fill_graph(e):
+        g = ev.GraphEvaluator()
+        r_ = g.add_expression(e)
+        g.add_calculation(ev.OP_HORNER, [(ev.VS_CONSTANT, 0, 0), (ev.VS_THETA, 0, 0), r_])
+        return g
+
+    def _set_copy_constraints(self, pairs):
+        """sigma = the identity permutation sigma_j(w^i) = delta^j w^i with the cells of every pair swapped (two-cycles);
+        _value_src[cell] = the cell a copy takes its value from (pairs are (destination, source))"""
+        sh, b, n = self.shape, self.b, self.n
+        P = len(sh.perm_columns)
+        one = fr_from_int_host(1)
         perm = np.arange(P * n, dtype=np.int64)
         value_src = np.arange(P * n, dtype=np.int64)
         for p_, q_ in pairs:
+            assert perm[p_] == p_ and perm[q_] == q_, "copy pairs must be disjoint"
             perm[p_], perm[q_] = q_, p_
             value_src[p_] = q_
         self._value_src = value_src
@@ -634,16 +716,61 @@ class Prover:
             self.sigma_lagrange = [c.contiguous() for c in self.sigma_lagrange]
         else:
             self.sigma_lagrange = [np.ascontiguousarray(c) for c in self.sigma_lagrange]
-        # out = mask * (a(-3) + a(-2) a(-1)) + (1 - mask) * a(0), per basic column; the mask is appended to the fixed columns
-        self._fill_graphs = []
+
+    def _build_satisfiable_sha(self, seed):
+        """The SHA-256-bit-circuit shape (CircuitShape.sha256) as a satisfiable instance:
+          * every fixed column (selectors q_* and "round constants" alike — the shape shares them) = the indicator of the ACTIVE rows:
+            even rows in [4, usable - 4), so that a gate's rotations (-3 .. +3) never reach the blinding rows and the one recurrence
+            gate (column c = 1 mod 4: a(c, r+1) = x + y + 4 x y z) does not chain from row to row;
+          * columns c = 0 mod 4 hold bits, c = 1 mod 4 are free on even rows and take the recurrence value on the odd row after an
+            active row, c = 2 mod 4 = the 7-term word recomposition of column c - 2, c = 3 mod 4 = -(a(c-1) + constant) — so every
+            gate vanishes on every active row (and the degree-5 gate with its two selectors too);
+          * copy constraints over the permutation columns (advice 0, advice 1, instance 0): each public input i is copied into a free
+            (even-row) cell of advice 1, and usable/16 odd-row cells of advice 0 (unconstrained by the bit gate) are tied to other
+            free cells of advice 1.
+        Only index arithmetic happens on the host; every field value is produced by the backend."""
+        sh, b, n = self.shape, self.b, self.n
+        u = n - (sh.blinding_factors + 1)
+        one = fr_from_int_host(1)
+        active = np.arange(4, u - 4, 2)
+        sel = np.zeros((n, 4), dtype=np.uint64)
+        sel[active] = one
+        for c in range(sh.n_fixed):
+            self.fixed_lagrange[c] = b.from_host(sel)
+        nxt = np.zeros((n, 4), dtype=np.uint64)
+        nxt[active + 1] = one
+        self._out_mask = b.from_host(nxt)
+        col_of = {pc: j for j, pc in enumerate(sh.perm_columns)}
+        a0, a1, ins = col_of[("advice", 0)], col_of[("advice", 1)], col_of[("instance", 0)]
+        rng = np.random.default_rng(seed)
+        free1 = rng.permutation(active)               # even rows of advice 1: free cells
+        nv = self.n_instance_values
+        m = max(1, min(u // 16, len(free1) - nv))
+        odd0 = rng.permutation(active + 1)[:m]        # odd rows of advice 0: not under the bit gate
+        pairs = [(a1 * n + int(free1[i]), ins * n + i) for i in range(nv)]
+        pairs += [(a0 * n + int(odd0[t]), a1 * n + int(free1[nv + t])) for t in range(m)]
+        # the pairs (advice 0 <- advice 1) take their value from a cell that itself may be a copy of an instance value: order matters
+        # in witness(): advice 1 is gathered first
+        self._set_copy_constraints(pairs)
         A = lambda c, r: ("advice", c, r)
+        mk = ("fixed", sh.n_fixed, 0)
+        keep = ("sum", ("const", 1), ("neg", mk))
+        self._fill_graphs = []
         for c in range(sh.n_basic):
-            mk = ("fixed", sh.n_fixed, 0)
-            e = ("sum", ("prod", mk, ("sum", A(c, -3), ("prod", A(c, -2), A(c, -1)))), ("prod", ("sum", ("const", 1), ("neg", mk)), A(c, 0)))
-            g = ev.GraphEvaluator()
-            r_ = g.add_expression(e)
-            g.add_calculation(ev.OP_HORNER, [(ev.VS_CONSTANT, 0, 0), (ev.VS_THETA, 0, 0), r_])
-            self._fill_graphs.append(g)
+            if c % 4 == 1:
+                x, y, z = A(c, -1), A(c - 1, -1), A(c - 1, 0)
+                val = ("sum", ("sum", x, y), ("scaled", ("prod", ("prod", x, y), z), 4))
+                e = ("sum", ("prod", mk, val), ("prod", keep, A(c, 0)))
+            elif c % 4 == 2:
+                acc = A(c - 2, -3)
+                for r in (-2, -1, 0, 1, 2, 3):
+                    acc = ("sum", ("scaled", acc, 2), A(c - 2, r))
+                e = acc
+            elif c % 4 == 3:
+                e = ("neg", ("sum", A(c - 1, 0), ("fixed", (c + 1) % sh.n_fixed, 0)))
+            else:
+                continue
+            self._fill_graphs.append((c, self._fill_graph(e)))
 
     def witness(self, proof_seed, dist="uniform"):
         """Synthetic advice / instance tables in Lagrange form, resident on the device (untimed).  Lookup-advice columns
@@ -660,18 +787,27 @@ class Prover:
         for j in range(sh.n_lookup):
             idx = (splitmix64(np.arange(n, dtype=np.uint64) + np.uint64(((base + 20 + j) << 32) & 0xFFFFFFFFFFFFFFFF)) % np.uint64(n // 2)).astype(np.int64)
             advice.append(self.b.gather(self.fixed_lagrange[sh.n_fixed - 1], idx))
-        instance = [self.b.synth(n, base + 50 + i) for i in range(sh.n_instance)]
+        # instance columns: n_instance_values public inputs, zero-padded (upstream builds the instance polynomial the same way)
+        nv = self.n_instance_values
+        inst_vals = [self.b.to_host(self.b.synth(nv, base + 50 + i)) for i in range(sh.n_instance)]
+        instance = []
+        for v in inst_vals:
+            col = np.zeros((n, 4), dtype=np.uint64)
+            col[:nv] = v
+            instance.append(self.b.from_host(col))
         if self.satisfiable:
             b = self.b
-            cols = {"advice": advice, "fixed": self.fixed_lagrange, "instance": instance}
-            stack = b.concat([cols[t][i] for t, i in sh.perm_columns])
-            for c in range(sh.n_basic):       # copies: only basic-advice cells take their partner's value
-                j = sh.perm_columns.index(("advice", c))
+            if sh.layout == "sha":
+                for c in range(0, sh.n_basic, 4):      # the bit columns
+                    advice[c] = b.synth_small(n, base + 1 + c, 1000, 1)
+            copy_cols = [(j, i) for j, (t, i) in enumerate(sh.perm_columns) if t == "advice" and i < sh.n_basic]
+            for j, c in (reversed(copy_cols) if sh.layout == "sha" else copy_cols):       # copies: basic-advice cells take their partner's value
+                cols = {"advice": advice, "fixed": self.fixed_lagrange, "instance": instance}
+                stack = b.concat([cols[t][i] for t, i in sh.perm_columns])
                 advice[c] = b.gather(stack, self._value_src[j * n:(j + 1) * n])
-            for c in range(sh.n_basic):       # gate outputs
-                advice[c] = b.compress(self._fill_graphs[c], self.fixed_lagrange + [self._out_mask], advice, instance, 0, sh.k)
-            return dict(advice=advice, instance=instance, base=base)
-        return dict(advice=advice, instance=instance, base=base)
+            for c, g in self._fill_graphs:       # gate outputs
+                advice[c] = b.compress(g, self.fixed_lagrange + [self._out_mask], advice, instance, 0, sh.k)
+        return dict(advice=advice, instance=instance, instance_values=inst_vals, base=base)
 
     def _query_list(self):
         """[(key, rotation)] in upstream's query order (what create_proof evaluates at x and SHPLONK opens)"""
@@ -689,6 +825,26 @@ class Prover:
         qlist += [(("sigma", i_), 0) for i_ in range(len(sh.perm_columns))]
         qlist += [(("h", 0), 0), (("random", 0), 0)]
         return qlist
+
+    def _eval_write_order(self):
+        """[(key, rotation)] in the order upstream WRITES the evaluations to the transcript (plonk/prover.rs after squeezing x
+        [UPSTREAM-RECALL]): advice evals, fixed evals, vanishing's random_eval, the permutation's common (sigma) evals, per
+        permutation set z(x), z(wx) and — all but the last set — z(w^last x), per lookup z(x), z(wx), a'(x), a'(w^-1 x), s'(x).
+        h(x) is not written.  (The multi-open consumes the same evaluations in _query_list()'s order.)"""
+        sh = self.shape
+        L, Zp = len(sh.lookups), sh.n_perm_sets
+        last_rot = -(sh.blinding_factors + 1)
+        w = [(("advice", col), rot) for kind, col, rot in sh.queries() if kind == "advice"]
+        w += [(("fixed", col), rot) for kind, col, rot in sh.queries() if kind == "fixed"]
+        w.append((("random", 0), 0))
+        w += [(("sigma", i_), 0) for i_ in range(len(sh.perm_columns))]
+        for i_ in range(Zp):
+            w += [(("perm_z", i_), 0), (("perm_z", i_), 1)]
+            if i_ + 1 < Zp:
+                w.append((("perm_z", i_), last_rot))
+        for i_ in range(L):
+            w += [(("lookup_z", i_), 0), (("lookup_z", i_), 1), (("lookup_a", i_), 0), (("lookup_a", i_), -1), (("lookup_s", i_), 0)]
+        return w
 
     def _native_key(self):
         """zk_proving_key for zkhip_create_proof (built once; the arrays it points to are kept alive on self)"""
@@ -743,16 +899,22 @@ class Prover:
         pk.advice_query_column, pk.advice_query_rotation = arr((c for c, _ in aq), np.uint32), arr((r for _, r in aq), np.int32)
         pk.fixed_query_column, pk.fixed_query_rotation = arr((c for c, _ in fq), np.uint32), arr((r for _, r in fq), np.int32)
         pk.delta = (C.c_uint64 * 4)(*[int(v) for v in b.fr(DELTA)])
+        pk.vk_transcript_repr = arr(self.vk_repr, np.uint64)
         self._npk, self._npk_keep = pk, keep
         return pk
 
-    def prove_native(self, wit, fetch_h=False, python_transcript=False, evm=False):
-        """The same pass through zkhip_create_proof (the schedule and all host arithmetic in the library).  The transcript is the
-        library's Blake2bWrite (no Python between the launches) or, with python_transcript, Blake2bTranscript through callbacks
-        (identical challenges: tests/test_schedule_cpu.py); with evm it is the library's EvmTranscript (Keccak-256; points are
-        64 big-endian bytes in the proof, and the challenges differ from the Blake2b ones).  Returns the same trace as prove()
-        plus trace["proof"], the bytes the transcript's writer received; the quotient's coefficients are copied to the host only on request (fetch_h: 96 n bytes
-        over PCIe, for tests)."""
+    def prove_native(self, wit, fetch_h=False, python_transcript=False, evm=False, transcript=None, host_inputs=False, blinding=None):
+        """The same pass through zkhip_create_proof_ex (the schedule and all host arithmetic in the library).
+        transcript: "blake2b" (halo2's Blake2bWrite, the default), "poseidon" (snark-verifier's native transcript: what the
+        reference's prove-* commands and the aggregation snark use), "evm" (Keccak-256: gen-x509-agg-evm-proof; points are 64
+        big-endian bytes in the proof) — all three inside the library, no Python between the launches — or, with python_transcript,
+        Blake2bTranscript (hashlib) through callbacks (identical challenges to "blake2b": tests/test_schedule_cpu.py).
+        host_inputs: the advice columns are handed over as pinned HOST arrays (what a Rust caller's Vec<Fr> columns are) and uploaded
+        inside the call; the instance columns are built by the library from the instance values.
+        blinding: None = the library's seeded generator; or dict(lookup_permuted, perm_z, lookup_z, random_poly) of (m, 4) uint64
+        host arrays / device tensors — the caller's rng draws, as upstream's create_proof takes them from its `rng` argument.
+        Returns the same trace as prove() plus trace["proof"], the bytes the transcript's writer received; the quotient's
+        coefficients are copied to the host only on request (fetch_h: 96 n bytes over PCIe, for tests)."""
         import ctypes as C
 
         sh, b, n = self.shape, self.b, self.n
@@ -760,67 +922,97 @@ class Prover:
         pk = self._native_key()
         L, Zp, A = len(sh.lookups), sh.n_perm_sets, sh.n_advice
         qd = self.dom.quotient_poly_degree
+        kind = transcript or ("evm" if evm else "blake2b")
         point_tags = ["advice"] * A + ["lookup_permuted"] * (2 * L) + ["products"] * (Zp + L) + ["random_poly"] + ["quotient"] * qd \
             + ["shplonk_h1", "shplonk_h2"]
         squeeze_tags = ["theta", "beta", "gamma", "y", "x", "shplonk_y", "shplonk_v", "shplonk_u"]
-        trace = {"commitments": [], "challenges": {}, "points": {}}
-        ts, state = Blake2bTranscript(), dict(p=0, s=0)
-
-        def write_point(byts, xy):
-            tag = point_tags[state["p"]]
-            state["p"] += 1
-            trace["commitments"].append((tag, byts.hex()))
-            trace["points"].setdefault(tag, []).append(xy)
-            ts.write_point(xy)
-
-        def squeeze():
-            tag = squeeze_tags[state["s"]]
-            state["s"] += 1
-            c = ts.squeeze()
-            trace["challenges"][tag] = c
-            return fr_from_int_host(c)
-
-        write_scalar = ts.write_scalar
-
+        trace = {"commitments": [], "challenges": {}, "points": {}, "transcript": kind}
         nt = None
+        keep = []
         if python_transcript:
-            t = ffi.make_transcript(write_point, squeeze, write_scalar)
+            ts, state = Blake2bTranscript(), dict(p=0, s=0)
+
+            def write_point(byts, xy):
+                tag = point_tags[state["p"]]
+                state["p"] += 1
+                trace["commitments"].append((tag, byts.hex()))
+                trace["points"].setdefault(tag, []).append(xy)
+                ts.write_point(xy)
+
+            def squeeze():
+                tag = squeeze_tags[state["s"]]
+                state["s"] += 1
+                c = ts.squeeze()
+                trace["challenges"][tag] = c
+                return fr_from_int_host(c)
+
+            t = ffi.make_transcript(write_point, squeeze, ts.write_scalar, ts.common_scalar)
+            keep.append(t)
             t_ref = C.byref(t)
         else:
-            nt = ffi.EvmTranscript() if evm else ffi.NativeTranscript()
+            nt = ffi.LibTranscript(kind)
             t_ref = nt.callbacks
         qlist = self._query_list()
         evals = np.zeros((len(qlist), 4), dtype=np.uint64)
+        worder = np.zeros(len(qlist), dtype=np.uint32)
         out = ffi.ZkProofOut()
-        out.evals, out.evals_cap = evals.ctypes.data, len(qlist)
-        adv = (C.c_void_p * max(1, A))(*[c_.data_ptr() for c_ in wit["advice"]])
-        ins = (C.c_void_p * max(1, sh.n_instance))(*[c_.data_ptr() for c_ in wit["instance"]])
+        out.evals, out.evals_cap, out.eval_write_order = evals.ctypes.data, len(qlist), worder.ctypes.data
+        inp = ffi.ZkProofInputs()
+        if host_inputs:
+            host_adv = wit.get("advice_host")
+            if host_adv is None:
+                host_adv = wit["advice_host"] = [c_.cpu().pin_memory() for c_ in wit["advice"]]
+            adv = (C.c_void_p * max(1, A))(*[c_.data_ptr() for c_ in host_adv])
+            inp.advice_on_host = 1
+            inp.d_instance = None
+        else:
+            adv = (C.c_void_p * max(1, A))(*[c_.data_ptr() for c_ in wit["advice"]])
+            ins = (C.c_void_p * max(1, sh.n_instance))(*[c_.data_ptr() for c_ in wit["instance"]])
+            keep.append(ins)
+            inp.d_instance = C.cast(ins, C.c_void_p)
+        inp.advice = C.cast(adv, C.c_void_p)
+        ivals = [np.ascontiguousarray(v, dtype=np.uint64) for v in wit["instance_values"]]
+        ivp = (C.c_void_p * max(1, len(ivals)))(*[v.ctypes.data for v in ivals])
+        ivl = np.array([len(v) for v in ivals] or [0], dtype=np.uint32)
+        keep += [ivals, ivp, ivl]
+        inp.instance_values, inp.instance_len = C.cast(ivp, C.c_void_p), ivl.ctypes.data
+        inp.blinding_seed = wit["base"]
+        if blinding is not None:
+            bl = ffi.ZkBlinding()
+            on_host = isinstance(blinding["random_poly"], np.ndarray)
+            for name in ("lookup_permuted", "perm_z", "lookup_z", "random_poly"):
+                v = blinding.get(name)
+                if v is None or len(v) == 0:
+                    continue
+                if on_host:
+                    v = np.ascontiguousarray(v, dtype=np.uint64)
+                    setattr(bl, name, v.ctypes.data)
+                else:
+                    setattr(bl, name, v.data_ptr())
+                keep.append(v)
+            bl.on_host = 1 if on_host else 0
+            keep.append(bl)
+            inp.blinding = C.cast(C.pointer(bl), C.c_void_p)
         ctx.use_torch_stream()
-        rc = ffi.lib().zkhip_create_proof(ctx.h, C.byref(pk), adv, ins, C.c_uint64(wit["base"]), t_ref, C.byref(out))
+        rc = ffi.lib().zkhip_create_proof_ex(ctx.h, C.byref(pk), C.byref(inp), t_ref, C.byref(out))
         if rc == ffi.ECONSTRAINT:
             raise ffi.ConstraintSystemFailure(ffi.lib().zkhip_last_error().decode())
         if rc != 0:
             raise ffi.ZkhipError(f"zkhip_create_proof: {rc}: {ffi.lib().zkhip_last_error().decode()}")
+        n_eval_written = len(qlist) - 1
         if nt is not None:   # rebuild the trace from what the library's transcript recorded
-            proof, chs = nt.proof(), nt.challenges()
+            proof, chs, pts = nt.proof(), nt.challenges(), nt.points()
             trace["proof"] = proof
-            psize = 64 if evm else 32
-            pts = None if evm else nt.points()
-            assert len(chs) == len(squeeze_tags)
+            psize = nt.POINT_BYTES[kind]
+            assert len(chs) == len(squeeze_tags) and len(pts) == len(point_tags)
             off = 0
-            n_eval_written = len(qlist) - 1
             for i_, tag in enumerate(point_tags):
                 if tag == "shplonk_h1":
                     off += 32 * n_eval_written      # the evaluations sit between the quotient pieces and the SHPLONK points
                 byts = proof[off:off + psize]
                 off += psize
                 trace["commitments"].append((tag, byts.hex()))
-                if evm:   # big-endian canonical coordinates -> Montgomery limbs
-                    xy = [int.from_bytes(byts[:32], "big"), int.from_bytes(byts[32:], "big")]
-                    limbs = [(v * (1 << 256) % Q_MOD >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for v in xy for j in range(4)]
-                    trace["points"].setdefault(tag, []).append(np.array(limbs, dtype=np.uint64))
-                else:
-                    trace["points"].setdefault(tag, []).append(pts[i_])
+                trace["points"].setdefault(tag, []).append(pts[i_])
             assert off == len(proof)
             for tag, limbs in zip(squeeze_tags, chs):
                 trace["challenges"][tag] = from_mont_host(limbs)
@@ -829,6 +1021,8 @@ class Prover:
         assert out.n_evals == len(qlist)
         trace["evals"] = [(q_, evals[i_]) for i_, q_ in enumerate(qlist)]
         trace["query_list"] = qlist
+        trace["eval_write_order"] = [qlist[i_] for i_ in worder[:n_eval_written]]
+        assert trace["eval_write_order"] == self._eval_write_order()
         trace["h_pieces"] = None
         if fetch_h:
             h = np.empty((qd * n, 4), dtype=np.uint64)
@@ -838,13 +1032,19 @@ class Prover:
         trace["n_commitments"] = len(trace["commitments"])
         return trace
 
-    def prove(self, wit):
-        """One pass.  Returns the transcript trace: every commitment's bytes and the challenges."""
+    def prove(self, wit, transcript="blake2b-py"):
+        """One pass.  Returns the transcript trace: every commitment's bytes and the challenges.  transcript: "blake2b-py"
+        (Blake2bTranscript above), or the library's "blake2b" / "evm" / "poseidon" driven from here (make_transcript)."""
         sh, b, n, dom = self.shape, self.b, self.n, self.dom
         base = wit["base"]
         L, Zp = len(sh.lookups), sh.n_perm_sets
-        trace = {"commitments": [], "challenges": {}, "points": {}}
-        ts = Blake2bTranscript()
+        trace = {"commitments": [], "challenges": {}, "points": {}, "transcript": transcript}
+        ts = make_transcript(transcript)
+        # vk.hash_into(transcript), then every instance value (KZG: instances are hashed, not committed)
+        ts.common_scalar(self.vk_repr)
+        for col in wit["instance_values"]:
+            for v in col:
+                ts.common_scalar(v)
 
         def absorb(tag, pts):
             byts = [p[1] for p in pts]
@@ -880,7 +1080,9 @@ class Prover:
         b.lagrange_to_coeff(perm_in + perm_tab)
         with b.overlap():
             ext_perm = b.coeff_to_extended(perm_in + perm_tab)
-        t2 = absorb("lookup_permuted", b.commit(perm_in + perm_tab, lagrange=False)) if L else []
+        # transcript order: permuted input, permuted table, lookup by lookup (lookup::Argument::commit_permuted per lookup)
+        inter = [c_ for pair in zip(perm_in, perm_tab) for c_ in pair]
+        t2 = absorb("lookup_permuted", b.commit(inter, lagrange=False)) if L else []
         beta, gamma = ts.squeeze(), ts.squeeze()
         # 3. grand products: permutation (chunks of degree-2 columns) and one per lookup; blinding rows are seeded stand-ins
         cols = {"advice": wit["advice"], "fixed": self.fixed_lagrange, "instance": wit["instance"]}
@@ -935,10 +1137,11 @@ class Prover:
         flat = b.eval_polys_at([polys[key] for key, _ in qlist], points)
         trace["evals"] = [(q_, flat[i_]) for i_, q_ in enumerate(qlist)]
         trace["query_list"] = qlist
-        # the transcript receives every evaluation except h's (the verifier recomputes it)
-        for i_, q_ in enumerate(qlist):
-            if q_[0][0] != "h":
-                ts.write_scalar(flat[i_])
+        # the transcript receives every evaluation except h's (the verifier recomputes it), in upstream's WRITE order
+        at = {q_: i_ for i_, q_ in enumerate(qlist)}
+        trace["eval_write_order"] = self._eval_write_order()
+        for q_ in trace["eval_write_order"]:
+            ts.write_scalar(flat[at[q_]])
         # 6. SHPLONK multi-open of all of them: two more commitments
         if hasattr(b, "multiopen"):      # the library's ProverSHPLONK (host arithmetic in C++; evaluations stay in ABI form)
             opening = b.multiopen(polys, [(key, pt) for (key, _), pt in zip(qlist, points)], flat, lambda tag: ts.squeeze(), absorb)
@@ -951,4 +1154,6 @@ class Prover:
         trace["opening"] = opening
         trace["h_pieces"] = pieces
         trace["n_commitments"] = len(trace["commitments"])
+        if hasattr(ts, "proof"):
+            trace["proof"] = ts.proof()
         return trace

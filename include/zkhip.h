@@ -52,6 +52,12 @@ const char* zkhip_last_error(void);
 #define ZKHIP_OWN_STREAM ((void*)(intptr_t)-1)
 int  zkhip_set_stream(zkhip_ctx* ctx, void* hip_stream);
 int  zkhip_synchronize(zkhip_ctx* ctx);
+/* Tuning knobs (DESIGN.md lists them).  The ZKHIP_* environment variables are read once, in zkhip_init; this sets one afterwards
+ * by its environment name ("ZKHIP_MSM_C") or short name ("msm_c").  Options that shape SRS tables (msm_c) apply to tables
+ * built afterwards. */
+int  zkhip_set_option(zkhip_ctx* ctx, const char* name, int value);
+/* Frees the scratch buffers of streams the context no longer uses (scratch is per stream).  Synchronises the device. */
+int  zkhip_trim(zkhip_ctx* ctx);
 int  zkhip_malloc(zkhip_ctx* ctx, size_t bytes, void** dptr);
 int  zkhip_free(zkhip_ctx* ctx, void* dptr);
 int  zkhip_memcpy_h2d(zkhip_ctx* ctx, void* dst, const void* src, size_t bytes);
@@ -257,6 +263,9 @@ typedef struct zk_transcript {
     void (*write_point)(void* user, const uint8_t bytes32[32], const uint64_t xy[8]);
     void (*squeeze_challenge)(void* user, uint64_t out[4]);
     void (*write_scalar)(void* user, const uint64_t scalar[4]);   /* evaluations (zkhip_create_proof only; may be NULL for shplonk_open) */
+    /* Transcript::common_scalar: absorbed, not written to the proof (the verifying key's transcript_repr and the instance values at the
+     * start of create_proof).  May be NULL: then nothing is absorbed there (a caller that has already done it on its own transcript). */
+    void (*common_scalar)(void* user, const uint64_t scalar[4]);
 } zk_transcript;
 int  zkhip_shplonk_open(zkhip_ctx* ctx, const zkhip_srs* srs, size_t n, const void* const* d_polys, size_t npolys, const uint32_t* query_poly,
                         const uint64_t* query_points, const uint64_t* query_evals, size_t nq, const zk_transcript* transcript,
@@ -265,11 +274,13 @@ int  zkhip_shplonk_open(zkhip_ctx* ctx, const zkhip_srs* srs, size_t n, const vo
 /* ---- halo2_proofs::plonk::create_proof in one call (plonk/prover.rs; reached from gen_snark_shplonk at
  * /root/reference/src/helpers.rs:233,299 and src/bin/cli.rs:320,343,369,462), from the point where the witness columns exist.
  * zk_proving_key is what keygen leaves on the device: every array is a HOST array of DEVICE columns unless noted.
- * Transcript order (upstream's): advice points, squeeze theta, permuted-lookup points, squeeze beta, gamma, product points
- * (permutation sets, then lookups), the random-polynomial point, squeeze y, quotient piece points, squeeze x, the evaluations
- * (advice queries, permutation products, lookups, fixed queries, sigma, random polynomial — h(x) is NOT written), then SHPLONK
- * (squeeze y', v', point h, squeeze u, point h').  The blinding rows / random polynomial upstream draws from its rng come from the
- * library's counter generator seeded with blinding_seed (zkhip_synth_fill_device seeds +300.., +320.., +340, +360, +380). */
+ * Transcript order (upstream's plonk/prover.rs [UPSTREAM-RECALL]): common_scalar(vk.transcript_repr), common_scalar(every instance
+ * value), advice points, squeeze theta, per lookup its permuted input and permuted table points, squeeze beta, gamma, product
+ * points (permutation sets, then lookups), the random-polynomial point, squeeze y, quotient piece points, squeeze x, then the
+ * evaluations in the order upstream WRITES them: advice queries, fixed queries, random polynomial, sigma polynomials, per
+ * permutation set z(x), z(wx) and (all but the last set) z(w^last x), per lookup z(x), z(wx), a'(x), a'(w^-1 x), s'(x) —
+ * h(x) is NOT written — then SHPLONK (squeeze y', v', point h, squeeze u, point h').  The multi-open itself takes its queries in
+ * upstream's QUERY order (advice, permutation products, lookups, fixed, sigma, h, random), which is a different order. */
 typedef struct zk_proving_key {
     uint32_t k, cs_degree, blinding_factors;
     uint32_t n_fixed, n_advice, n_instance, n_lookups, n_perm_columns;
@@ -297,14 +308,44 @@ typedef struct zk_proving_key {
     const uint32_t* advice_query_column; const int32_t* advice_query_rotation;      /* HOST */
     const uint32_t* fixed_query_column; const int32_t* fixed_query_rotation;        /* HOST */
     uint64_t delta[4];                                                              /* Fr::DELTA, ABI form */
+    const uint64_t* vk_transcript_repr;       /* HOST, 4 u64 (ABI) or NULL: pk.vk.transcript_repr, absorbed first (vk.hash_into) */
 } zk_proving_key;
 typedef struct zk_proof_out {
     const void* d_h;          /* the quotient in coefficient form (quotient_poly_degree * n elements, library-owned, valid until the next proof) */
-    uint64_t* evals;          /* caller's HOST buffer, evals_cap x 4 (may be NULL): every opened evaluation, h's included, in query order */
+    uint64_t* evals;          /* caller's HOST buffer, evals_cap x 4 (may be NULL): every opened evaluation, h's included, in QUERY order */
     uint32_t* eval_poly;      /* caller's HOST buffers, evals_cap each (may be NULL): polynomial table index and rotation per evaluation */
     int32_t* eval_rotation;
+    uint32_t* eval_write_order; /* caller's HOST buffer, evals_cap (may be NULL): indices into the above in the order the evaluations were
+                                   written to the transcript (n_evals - 1 entries: h(x) is not written) */
     size_t evals_cap, n_evals;
 } zk_proof_out;
+/* What upstream draws from the caller's rng inside create_proof, in the caller's hands (plonk/prover.rs passes `rng` down to
+ * lookup::commit_permuted, permutation::commit, lookup::commit_product and vanishing::commit [UPSTREAM-RECALL]; reached from
+ * gen_snark_shplonk at /root/reference/src/helpers.rs:233 with the sdk's rng).  All four buffers are field elements in ABI form;
+ * either all DEVICE or all HOST (on_host = 1: uploaded by the library).  The blinding rows of the ADVICE columns are already part of
+ * the advice columns the caller hands over (the last blinding_factors + 1 rows of each). */
+typedef struct zk_blinding {
+    const void* lookup_permuted;   /* [lookup][2][blinding_factors + 1]: permuted input rows, then permuted table rows */
+    const void* perm_z;            /* [permutation set][blinding_factors] */
+    const void* lookup_z;          /* [lookup][blinding_factors] */
+    const void* random_poly;       /* the vanishing argument's random polynomial: n coefficients */
+    int on_host;
+} zk_blinding;
+typedef struct zk_proof_inputs {
+    const void* const* advice;                /* n_advice columns of n elements, Lagrange form */
+    int advice_on_host;                       /* 0: DEVICE columns (resident pipeline); 1: HOST columns (the Vec<Fr> a Rust caller holds;
+                                                 uploaded by the library, fastest from pinned memory) */
+    const void* const* d_instance;            /* n_instance DEVICE columns (zero-padded to n), or NULL: built from instance_values */
+    const uint64_t* const* instance_values;   /* HOST, per column instance_len[i] x 4 u64: absorbed with common_scalar in upstream's order
+                                                 (KZG: instances are hashed, not committed); NULL: nothing absorbed */
+    const uint32_t* instance_len;             /* HOST, n_instance */
+    const zk_blinding* blinding;              /* NULL: the library's counter generator seeded with blinding_seed
+                                                 (zkhip_synth_fill_device seeds +300.., +320.., +340, +360, +380) */
+    uint64_t blinding_seed;
+} zk_proof_inputs;
+int  zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, const zk_proof_inputs* in, const zk_transcript* transcript,
+                           zk_proof_out* out);
+/* The resident-pipeline short form: device columns, seeded blinding, no instance absorption. */
 int  zkhip_create_proof(zkhip_ctx* ctx, const zk_proving_key* pk, const void* const* d_advice, const void* const* d_instance,
                         uint64_t blinding_seed, const zk_transcript* transcript, zk_proof_out* out);
 
@@ -329,7 +370,24 @@ void zkhip_evm_transcript_free(zkhip_evm_transcript* t);
 const zk_transcript* zkhip_evm_transcript_callbacks(zkhip_evm_transcript* t);
 size_t zkhip_evm_transcript_proof(const zkhip_evm_transcript* t, const uint8_t** bytes);          /* -> length */
 size_t zkhip_evm_transcript_challenges(const zkhip_evm_transcript* t, const uint64_t** limbs);    /* -> count; 4 u64 each (ABI) */
+size_t zkhip_evm_transcript_points(const zkhip_evm_transcript* t, const uint64_t** xy);           /* -> count; 8 u64 each */
 void zkhip_keccak256(const uint8_t* in, size_t len, uint8_t pad /* 0x01 Keccak-256, 0x06 SHA3-256 */, uint8_t out[32]);
+
+/* ---- and snark-verifier's PoseidonTranscript<G1Affine, NativeLoader, _, T = 3, RATE = 2, R_F = 8, R_P = 57> (system/halo2/transcript/
+ * halo2.rs over util/hash/poseidon.rs) — the transcript behind gen_snark_shplonk, i.e. behind every leaf proof and the aggregation
+ * snark of the reference (/root/reference/src/helpers.rs:233,299; src/bin/cli.rs:320,343,369,462).  The permutation's parameters come
+ * from the Grain LFSR generator of the Poseidon reference and reproduce its published poseidonperm_x5_254_3 vector; the sponge layer
+ * (initial state 2^64, buffering, padding, squeeze = state[1]) is restated from recall.  Proof stream: 32-byte compressed points,
+ * 32-byte little-endian scalars. */
+typedef struct zkhip_poseidon_transcript zkhip_poseidon_transcript;
+zkhip_poseidon_transcript* zkhip_poseidon_transcript_new(void);
+void zkhip_poseidon_transcript_free(zkhip_poseidon_transcript* t);
+const zk_transcript* zkhip_poseidon_transcript_callbacks(zkhip_poseidon_transcript* t);
+size_t zkhip_poseidon_transcript_proof(const zkhip_poseidon_transcript* t, const uint8_t** bytes);          /* -> length */
+size_t zkhip_poseidon_transcript_points(const zkhip_poseidon_transcript* t, const uint64_t** xy);           /* -> count; 8 u64 each */
+size_t zkhip_poseidon_transcript_challenges(const zkhip_poseidon_transcript* t, const uint64_t** limbs);    /* -> count; 4 u64 each (ABI) */
+void zkhip_poseidon_permute(uint64_t state[12]);               /* the bare permutation, 3 ABI elements in place */
+void zkhip_poseidon_params(uint64_t* rc, uint64_t* mds);       /* 65 x 3 round constants, 3 x 3 MDS (row-major), ABI form; either may be NULL */
 
 /* ---- synthetic tables (bench / tests): element i of a column = raw253(seed, i) taken as the
  * Montgomery limbs (oracle/pyref.py synth_raw253) ---- */

@@ -630,8 +630,9 @@ def plonk_expected_h(vk, instance_cols, evals, ch):
         if kind == "instance":      # QUERY_INSTANCE = false for KZG: the verifier evaluates the instance polynomial itself
             if (col, rot) not in inst_cache:
                 pt = x * pow(w, rot % n, R) % R
-                ls = lagrange_basis_at(k, range(n), pt)
-                inst_cache[(col, rot)] = sum(a * b for a, b in zip(instance_cols[col], ls)) % R
+                rows = [i for i, a in enumerate(instance_cols[col]) if a]      # an instance column is a few values, zero-padded
+                ls = lagrange_basis_at(k, rows, pt)
+                inst_cache[(col, rot)] = sum(instance_cols[col][i] * b for i, b in zip(rows, ls)) % R
             return inst_cache[(col, rot)]
         return evals[((kind, col), rot)]
 
@@ -700,3 +701,355 @@ def plonk_verify(vk, instance_cols, commitments, h_pieces, evals, query_list, ch
         queries.append((key, x * pow(w, rot % n, R) % R, ev))
     rs, sp = construct_intermediate_sets(queries)
     return shplonk_verify(coms, rs, sp, ch["shplonk_y"], ch["shplonk_v"], ch["shplonk_u"], h1, h2, s)
+
+
+# ----------------------------------------------------------------------------- point decompression (transcript readers)
+def decompress(b):
+    """inverse of compress(): 32 bytes -> affine (x, y); p = 3 mod 4, so sqrt(a) = a^((p+1)/4)"""
+    b = bytearray(b)
+    if b[31] & 0x80:
+        return (0, 0)
+    sign = (b[31] >> 6) & 1
+    b[31] &= 0x3F
+    x = int.from_bytes(bytes(b), "little")
+    if x >= P:
+        raise ValueError("x not canonical")
+    y2 = (x * x * x + 3) % P
+    y = pow(y2, (P + 1) // 4, P)
+    if y * y % P != y2:
+        raise ValueError("not on the curve")
+    if (y & 1) != sign:
+        y = P - y
+    return (x, y)
+
+
+# ----------------------------------------------------------------------------- Poseidon (snark-verifier's native transcript hash)
+# Parameters: the Grain LFSR generator of the Poseidon reference implementation (hadeshash, generate_parameters_grain.sage) as the
+# `poseidon` crate used by snark-verifier restates it [UPSTREAM-RECALL; /root/reference/Cargo.lock:2068-2070, 2675-2693]:
+# 80-bit state = field type (2 bits, 1 = prime) | s-box (4 bits, 0 = x^alpha) | field size (12) | t (12) | R_F (10) | R_P (10) | 30 ones;
+# 160 warm-up bits; output bits come in pairs (first = 1: keep the second).  Round constants: 254-bit big-endian integers,
+# rejection-sampled below r.  MDS: Cauchy matrix 1 / (x_i + y_j) from 2t further elements reduced mod r (first candidate).
+# PINNED: poseidon_permute([0, 1, 2]) below equals the published test vector poseidonperm_x5_254_3 (POSEIDON_KAT).
+class Grain:
+    def __init__(self, field_bits, t, r_f, r_p, sbox=0, field_type=1):
+        bits = []
+
+        def push(v, n):
+            for i in reversed(range(n)):
+                bits.append((v >> i) & 1)
+
+        push(field_type, 2), push(sbox, 4), push(field_bits, 12), push(t, 12), push(r_f, 10), push(r_p, 10)
+        bits += [1] * 30
+        assert len(bits) == 80
+        self.state, self.nbits = bits, field_bits
+        for _ in range(160):
+            self._new_bit()
+
+    def _new_bit(self):
+        s = self.state
+        b = s[62] ^ s[51] ^ s[38] ^ s[23] ^ s[13] ^ s[0]
+        self.state = s[1:] + [b]
+        return b
+
+    def _filtered(self):
+        while True:
+            a, b = self._new_bit(), self._new_bit()
+            if a:
+                return b
+
+    def _raw(self):
+        v = 0
+        for _ in range(self.nbits):
+            v = (v << 1) | self._filtered()
+        return v
+
+    def next_field_element(self):
+        while True:
+            v = self._raw()
+            if v < R:
+                return v
+
+    def next_field_element_without_rejection(self):
+        return self._raw() % R
+
+
+POSEIDON_T, POSEIDON_RATE, POSEIDON_RF, POSEIDON_RP = 3, 2, 8, 57
+_POSEIDON_SPEC = None
+# hadeshash code/test_vectors.txt, poseidonperm_x5_254_3: permutation of (0, 1, 2)
+POSEIDON_KAT = [0x115CC0F5E7D690413DF64C6B9662E9CF2A3617F2743245519E19607A4417189A,
+                0x0FCA49B798923AB0239DE1C9E7A4A9A2210312B6A2F616D18B5A87F9B628AE29,
+                0x0E7AE82E40091E63CBD4F16A6D16310B3729D4B6E138FCF54110E2867045A30C]
+
+
+def poseidon_spec():
+    """-> (round constants [R_F + R_P][T], mds [T][T])"""
+    global _POSEIDON_SPEC
+    if _POSEIDON_SPEC is None:
+        t = POSEIDON_T
+        g = Grain(254, t, POSEIDON_RF, POSEIDON_RP)
+        rc = [[g.next_field_element() for _ in range(t)] for _ in range(POSEIDON_RF + POSEIDON_RP)]
+        xs = [g.next_field_element_without_rejection() for _ in range(t)]
+        ys = [g.next_field_element_without_rejection() for _ in range(t)]
+        mds = [[pow((xs[i] + ys[j]) % R, R - 2, R) for j in range(t)] for i in range(t)]
+        _POSEIDON_SPEC = (rc, mds)
+    return _POSEIDON_SPEC
+
+
+def poseidon_permute(state):
+    rc, mds = poseidon_spec()
+    t = POSEIDON_T
+    s = list(state)
+    mix = lambda v: [sum(mds[i][j] * v[j] for j in range(t)) % R for i in range(t)]
+    r = 0
+    for _ in range(POSEIDON_RF // 2):
+        s = mix([pow((s[i] + rc[r][i]) % R, 5, R) for i in range(t)])
+        r += 1
+    for _ in range(POSEIDON_RP):
+        s = [(s[i] + rc[r][i]) % R for i in range(t)]
+        s[0] = pow(s[0], 5, R)
+        s = mix(s)
+        r += 1
+    for _ in range(POSEIDON_RF // 2):
+        s = mix([pow((s[i] + rc[r][i]) % R, 5, R) for i in range(t)])
+        r += 1
+    return s
+
+
+class PoseidonSponge:
+    """snark-verifier util/hash/poseidon.rs Poseidon<F, L, T, RATE> [UPSTREAM-RECALL]: initial state (2^64, 0, 0); update() buffers;
+    squeeze() absorbs the buffer in chunks of RATE (a short chunk is padded with a single 1 at position len + 1), permutes once
+    more on an empty chunk if the length was a multiple of RATE, returns state[1]."""
+
+    def __init__(self):
+        self.state = [1 << 64, 0, 0]
+        self.buf = []
+
+    def update(self, elems):
+        self.buf += [e % R for e in elems]
+
+    def _permutation(self, chunk):
+        for i, v in enumerate(chunk):
+            self.state[1 + i] = (self.state[1 + i] + v) % R
+        if len(chunk) < POSEIDON_RATE:
+            self.state[len(chunk) + 1] = (self.state[len(chunk) + 1] + 1) % R
+        self.state = poseidon_permute(self.state)
+
+    def squeeze(self):
+        buf, self.buf = self.buf, []
+        exact = len(buf) % POSEIDON_RATE == 0
+        for o in range(0, len(buf), POSEIDON_RATE):
+            self._permutation(buf[o:o + POSEIDON_RATE])
+        if exact:
+            self._permutation([])
+        return self.state[1]
+
+
+# ----------------------------------------------------------------------------- Keccak-256 (EvmTranscript's hash), pure Python
+_KECCAK_RC = [0x0000000000000001, 0x0000000000008082, 0x800000000000808A, 0x8000000080008000, 0x000000000000808B, 0x0000000080000001,
+              0x8000000080008081, 0x8000000000008009, 0x000000000000008A, 0x0000000000000088, 0x0000000080008009, 0x000000008000000A,
+              0x000000008000808B, 0x800000000000008B, 0x8000000000008089, 0x8000000000008003, 0x8000000000008002, 0x8000000000000080,
+              0x000000000000800A, 0x800000008000000A, 0x8000000080008081, 0x8000000000008080, 0x0000000080000001, 0x8000000080008008]
+_KECCAK_ROT = [[0, 36, 3, 41, 18], [1, 44, 10, 45, 2], [62, 6, 43, 15, 61], [28, 55, 25, 21, 56], [27, 20, 39, 8, 14]]
+
+
+def _keccak_f(A):
+    rol = lambda v, n: ((v << n) | (v >> (64 - n))) & MASK64 if n else v
+    for rc in _KECCAK_RC:
+        C = [A[x][0] ^ A[x][1] ^ A[x][2] ^ A[x][3] ^ A[x][4] for x in range(5)]
+        D = [C[(x - 1) % 5] ^ rol(C[(x + 1) % 5], 1) for x in range(5)]
+        A = [[A[x][y] ^ D[x] for y in range(5)] for x in range(5)]
+        B = [[0] * 5 for _ in range(5)]
+        for x in range(5):
+            for y in range(5):
+                B[y][(2 * x + 3 * y) % 5] = rol(A[x][y], _KECCAK_ROT[x][y])
+        A = [[B[x][y] ^ ((~B[(x + 1) % 5][y]) & B[(x + 2) % 5][y]) for y in range(5)] for x in range(5)]
+        A[0][0] ^= rc
+    return A
+
+
+def keccak256(data, pad=0x01):
+    """pad = 0x01: Keccak-256 (Ethereum); 0x06: SHA3-256 (checked against hashlib in the tests)"""
+    rate = 136
+    msg = bytearray(data)
+    msg.append(pad)
+    while len(msg) % rate:
+        msg.append(0)
+    msg[-1] |= 0x80
+    A = [[0] * 5 for _ in range(5)]
+    for off in range(0, len(msg), rate):
+        for i in range(rate // 8):
+            A[i % 5][i // 5] ^= int.from_bytes(msg[off + 8 * i:off + 8 * i + 8], "little")
+        A = _keccak_f(A)
+    return b"".join(A[i % 5][i // 5].to_bytes(8, "little") for i in range(4))
+
+
+# ----------------------------------------------------------------------------- transcript READERS (the verifier's side)
+# Each consumes proof bytes the way the corresponding upstream TranscriptRead does and derives the challenges itself.
+class TranscriptReader:
+    """kind: "blake2b" (halo2 Blake2bRead), "evm" (snark-verifier EvmTranscript), "poseidon" (snark-verifier PoseidonTranscript)"""
+
+    def __init__(self, kind, proof):
+        import hashlib
+
+        self.kind, self.proof, self.off = kind, bytes(proof), 0
+        if kind == "blake2b":
+            self.h = hashlib.blake2b(digest_size=64, person=b"Halo2-Transcript")
+        elif kind == "evm":
+            self.buf = b""
+        elif kind == "poseidon":
+            self.sp = PoseidonSponge()
+        else:
+            raise ValueError(kind)
+
+    def _take(self, n):
+        if self.off + n > len(self.proof):
+            raise ValueError("proof too short")
+        b = self.proof[self.off:self.off + n]
+        self.off += n
+        return b
+
+    def common_point(self, a):
+        if self.kind == "blake2b":
+            self.h.update(b"\x01" + a[0].to_bytes(32, "little") + a[1].to_bytes(32, "little"))
+        elif self.kind == "evm":
+            self.buf += a[0].to_bytes(32, "big") + a[1].to_bytes(32, "big")
+        else:
+            self.sp.update([a[0] % R, a[1] % R])
+
+    def common_scalar(self, v):
+        if self.kind == "blake2b":
+            self.h.update(b"\x02" + v.to_bytes(32, "little"))
+        elif self.kind == "evm":
+            self.buf += v.to_bytes(32, "big")
+        else:
+            self.sp.update([v])
+
+    def read_point(self):
+        if self.kind == "evm":
+            b = self._take(64)
+            a = (int.from_bytes(b[:32], "big"), int.from_bytes(b[32:], "big"))
+            if a[0] >= P or a[1] >= P or not on_curve(a):
+                raise ValueError("bad point")
+        else:
+            a = decompress(self._take(32))
+        self.common_point(a)
+        return a
+
+    def read_scalar(self):
+        b = self._take(32)
+        v = int.from_bytes(b, "big" if self.kind == "evm" else "little")
+        if v >= R:
+            raise ValueError("scalar not canonical")
+        self.common_scalar(v)
+        return v
+
+    def squeeze(self):
+        if self.kind == "blake2b":
+            self.h.update(b"\x00")
+            return int.from_bytes(self.h.copy().digest(), "little") % R
+        if self.kind == "evm":
+            data = self.buf + (b"\x01" if len(self.buf) == 32 else b"")
+            self.buf = keccak256(data)
+            return int.from_bytes(self.buf, "big") % R
+        return self.sp.squeeze()
+
+    def done(self):
+        return self.off == len(self.proof)
+
+
+def read_plonk_proof(vk, kind, proof, vk_repr, instance_values, advice_queries, fixed_queries):
+    """halo2_proofs plonk/verifier.rs verify_proof's READ ORDER [UPSTREAM-RECALL] over the proof bytes, challenges derived here:
+    vk repr and instance values absorbed; advice points; theta; per lookup (permuted input, permuted table); beta, gamma;
+    permutation products, lookup products; random-polynomial point; y; quotient pieces; x; advice evals, fixed evals, random eval,
+    sigma evals, per permutation set (z(x), z(wx)[, z(w^last x)]), per lookup (z(x), z(wx), a'(x), a'(w^-1 x), s'(x));
+    SHPLONK: y', v', point h, u, point h'.  advice_queries / fixed_queries: [(column, rotation)] in cs order.
+    -> dict(commitments, h_pieces, evals, challenges, h1, h2)"""
+    t = TranscriptReader(kind, proof)
+    if vk_repr is not None:
+        t.common_scalar(vk_repr)
+    for col in instance_values or []:
+        for v in col:
+            t.common_scalar(v)
+    chunk = vk["degree"] - 2
+    n_adv = 1 + max([c for c, _ in advice_queries] + [c for kind_, c in vk["perm_columns"] if kind_ == "advice"] + [-1])
+    n_adv = max(n_adv, vk.get("n_advice", 0))
+    nsets = -(-len(vk["perm_columns"]) // chunk) if vk["perm_columns"] else 0
+    L = len(vk["lookups"])
+    bf = vk["blinding_factors"]
+    coms, evals, ch = {}, {}, {}
+    for i in range(n_adv):
+        coms[("advice", i)] = t.read_point()
+    ch["theta"] = t.squeeze()
+    for i in range(L):
+        coms[("lookup_a", i)] = t.read_point()
+        coms[("lookup_s", i)] = t.read_point()
+    ch["beta"], ch["gamma"] = t.squeeze(), t.squeeze()
+    for i in range(nsets):
+        coms[("perm_z", i)] = t.read_point()
+    for i in range(L):
+        coms[("lookup_z", i)] = t.read_point()
+    coms[("random", 0)] = t.read_point()
+    ch["y"] = t.squeeze()
+    qd = vk["degree"] - 1
+    h_pieces = [t.read_point() for _ in range(qd)]
+    ch["x"] = t.squeeze()
+    for c, r in advice_queries:
+        evals[(("advice", c), r)] = t.read_scalar()
+    for c, r in fixed_queries:
+        evals[(("fixed", c), r)] = t.read_scalar()
+    evals[(("random", 0), 0)] = t.read_scalar()
+    for j in range(len(vk["perm_columns"])):
+        evals[(("sigma", j), 0)] = t.read_scalar()
+    for s_ in range(nsets):
+        evals[(("perm_z", s_), 0)] = t.read_scalar()
+        evals[(("perm_z", s_), 1)] = t.read_scalar()
+        if s_ + 1 < nsets:
+            evals[(("perm_z", s_), -(bf + 1))] = t.read_scalar()
+    for i in range(L):
+        evals[(("lookup_z", i), 0)] = t.read_scalar()
+        evals[(("lookup_z", i), 1)] = t.read_scalar()
+        evals[(("lookup_a", i), 0)] = t.read_scalar()
+        evals[(("lookup_a", i), -1)] = t.read_scalar()
+        evals[(("lookup_s", i), 0)] = t.read_scalar()
+    ch["shplonk_y"], ch["shplonk_v"] = t.squeeze(), t.squeeze()
+    h1 = t.read_point()
+    ch["shplonk_u"] = t.squeeze()
+    h2 = t.read_point()
+    if not t.done():
+        raise ValueError("trailing proof bytes")
+    return dict(commitments=coms, h_pieces=h_pieces, evals=evals, challenges=ch, h1=h1, h2=h2)
+
+
+def multiopen_query_list(vk, advice_queries, fixed_queries):
+    """the verifier's query list in upstream's QUERY order (plonk/verifier.rs: advice, permutation, lookups, fixed, sigma, h, random)"""
+    chunk = vk["degree"] - 2
+    nsets = -(-len(vk["perm_columns"]) // chunk) if vk["perm_columns"] else 0
+    L, bf = len(vk["lookups"]), vk["blinding_factors"]
+    q = [(("advice", c), r) for c, r in advice_queries]
+    for s_ in range(nsets):
+        q += [(("perm_z", s_), 0), (("perm_z", s_), 1)]
+    for s_ in reversed(range(nsets - 1)):
+        q.append((("perm_z", s_), -(bf + 1)))
+    for i in range(L):
+        q += [(("lookup_z", i), 0), (("lookup_a", i), 0), (("lookup_s", i), 0), (("lookup_a", i), -1), (("lookup_z", i), 1)]
+    q += [(("fixed", c), r) for c, r in fixed_queries]
+    q += [(("sigma", j), 0) for j in range(len(vk["perm_columns"]))]
+    q += [(("h", 0), 0), (("random", 0), 0)]
+    return q
+
+
+def verify_proof_bytes(vk, kind, proof, vk_repr, instance_values, instance_cols, fixed_commitments, sigma_commitments, advice_queries,
+                       fixed_queries, s):
+    """The whole verifier over PROOF BYTES: read in upstream's order with the named transcript, challenges re-derived, then the
+    algebraic checks of plonk_verify (the pairing replaced by the SRS trapdoor s).  fixed / sigma commitments: the vk's points."""
+    try:
+        pr = read_plonk_proof(vk, kind, proof, vk_repr, instance_values, advice_queries, fixed_queries)
+    except ValueError:
+        return False
+    coms = dict(pr["commitments"])
+    for i, c in enumerate(fixed_commitments):
+        coms[("fixed", i)] = c
+    for i, c in enumerate(sigma_commitments):
+        coms[("sigma", i)] = c
+    return plonk_verify(vk, instance_cols, coms, pr["h_pieces"], pr["evals"], multiopen_query_list(vk, advice_queries, fixed_queries),
+                        pr["challenges"], pr["h1"], pr["h2"], s)

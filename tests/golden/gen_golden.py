@@ -281,7 +281,37 @@ def shplonk_vectors():
                 division=dict(dividend=[hx(c) for c in prod], roots=[hx(r) for r in roots], quotient=[hx(c) for c in polys[0][:n - 3]] + ["0"] * 3))
 
 
+def poseidon_vectors():
+    """Poseidon (t = 3, R_F = 8, R_P = 57 over BN254 Fr) from pyref's Grain-generated parameters: the published permutation vector, the
+    first / last round constants and the MDS matrix, permutations of edge states, and sponge sequences (empty / short / exact /
+    ragged buffers, repeated squeezes)."""
+    import random
+
+    rc, mds = P.poseidon_spec()
+    rnd = random.Random(0xC0FFEE)
+    perms = []
+    for st in ([0, 0, 0], [1 << 64, 0, 0], [P.R - 1, P.R - 2, P.R - 3], [rnd.randrange(P.R) for _ in range(3)]):
+        perms.append({"in": [hx(v) for v in st], "out": [hx(v) for v in P.poseidon_permute(st)]})
+    sponge = []
+    for lens in ([0], [1], [2], [3, 0, 2], [5, 4, 1]):
+        sp, absorb, sq = P.PoseidonSponge(), [], []
+        for ln in lens:
+            b = [rnd.randrange(P.R) for _ in range(ln)]
+            sp.update(b)
+            absorb.append([hx(v) for v in b])
+            sq.append(hx(sp.squeeze()))
+        sponge.append(dict(absorb=absorb, squeezed=sq))
+    assert P.poseidon_permute([0, 1, 2]) == P.POSEIDON_KAT
+    return dict(source="oracle/pyref.py (Grain LFSR parameters, t=3, R_F=8, R_P=57, BN254 Fr); kat = hadeshash test_vectors.txt poseidonperm_x5_254_3",
+                kat_poseidonperm_x5_254_3=[hx(v) for v in P.POSEIDON_KAT],
+                round_constants_first_last=[hx(v) for v in rc[0] + rc[-1]], mds=[hx(v) for row in mds for v in row],
+                permutations=perms, sponge=sponge)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "poseidon":
+        dump("poseidon.json", poseidon_vectors())
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "products":
         dump("products.json", products_vectors())
         sys.exit(0)

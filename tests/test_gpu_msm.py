@@ -197,6 +197,49 @@ def test_large_msm_trapdoor_property(zk, oracle, k):
     p.free()
 
 
+@pytest.mark.parametrize("k", [18, 19])
+def test_c17_window_path(zk, oracle, k):
+    """2^18 and 2^19 points: the only sizes that select the window c = 17 / W = 15 (15 x 17 = 255 bits, no short top window) —
+    BASELINE configs[2]'s MSM size.  (a) commit(coeffs) == [p(s)] G and commit_lagrange(evals) == commit(iNTT(evals)) (size-independent
+    trapdoor property); (b) a batch of columns with witness-shaped values (bits, 32-bit words, all-equal, zero) against the same
+    identity; (c) the first 4096 points against the CPU oracle's best_multiexp, compared as canonical affine bytes."""
+    ffi, ctx = zk
+    zo = oracle
+    s = zo.fr_from_int(0xC17C17000 + k)
+    p = ffi.ParamsKZG.setup(ctx, k, s)
+    assert p.window() == (17, 15)
+    n = 1 << k
+    col = ctx.synth_fill(n, 0xC0FFEE00 + k)
+    coeffs = ctx.to_host(col)
+    exp = zo.g1_mul_gen(zo.eval_polynomial(coeffs, s))
+    out = ctx.to_host(p.commit_batch_device([col]))
+    assert (ffi.g1_to_affine(out[0]) == exp).all()
+    dom = ffi.EvaluationDomain(ctx, 3, k)
+    ev = col.clone()
+    dom.coeff_to_lagrange_device([ev])
+    out2 = ctx.to_host(p.commit_batch_device([ev], lagrange=True))
+    assert (ffi.g1_to_affine(out2[0]) == exp).all()
+    dom.free()
+    # (b) skewed columns in one batch
+    import torch
+    bits = ctx.synth_small(n, 5, 1000, 1)
+    words = ctx.synth_small(n, 6, 0, 32)
+    same = col[:1].expand(n, 4).contiguous()
+    zero = torch.zeros_like(col)
+    batch = [bits, words, same, zero, col]
+    outs = ctx.to_host(p.commit_batch_device(batch))
+    for c_, o in zip(batch, outs):
+        e = zo.g1_mul_gen(zo.eval_polynomial(ctx.to_host(c_), s))
+        assert ffi.g1_to_bytes(ffi.g1_to_affine(o)) == zo.g1_to_bytes(e)
+    # (c) a point range against the oracle's Pippenger on the same bases
+    m = 4096
+    bases = p.read_bases(p.g, 0, m)
+    part = ctx.to_host(p.commit_batch_device([col], n=m, first=0))
+    ref = zo.g1_to_affine(zo.best_multiexp(coeffs[:m], bases, 8))
+    assert (ffi.g1_to_affine(part[0]) == ref).all()
+    p.free()
+
+
 def test_quad_cooperative_point_ops(zk, oracle):
     """The 4-lane cooperative XYZZ addition / doubling of the MSM tail against the one-lane versions, including P + P,
     P + (-P), identity operands and non-trivial ZZ / ZZZ."""

@@ -48,16 +48,21 @@ def test_fft_vs_oracle(zk, oracle, log_n):
 
 @pytest.mark.parametrize("log_n,smax,r8", [(13, "9", "0"), (16, "9", "0"), (18, "6", "1"), (12, "4", "1"), (15, "5", "1"),
                                             (14, "7", "1"), (20, "11", "1"), (21, "11", "1"), (19, "10", "1")])
-def test_fft_tile_plans(zk, oracle, monkeypatch, log_n, smax, r8):
-    """every shape of the tile transform: the stage-per-barrier kernels (ZKHIP_NTT_R8=0) and the register-tiled ones with stage
-    groups 3+1, 3+2, 3+3, 3+3+1 ... 3+3+3+2 (ZKHIP_NTT_SMAX changes the digits of the pass plan; both are read per call)"""
+def test_fft_tile_plans(zk, oracle, log_n, smax, r8):
+    """every shape of the tile transform: the stage-per-barrier kernels (ntt_r8 = 0) and the register-tiled ones with stage
+    groups 3+1, 3+2, 3+3, 3+3+1 ... 3+3+3+2 (ntt_smax changes the digits of the pass plan; zkhip_set_option, the knobs are
+    no longer read from the environment per call)"""
     ffi, ctx = zk
     zo = oracle
-    monkeypatch.setenv("ZKHIP_NTT_SMAX", smax)
-    monkeypatch.setenv("ZKHIP_NTT_R8", r8)
-    a = zo.synth_raw253(3200 + log_n, 1 << log_n)
-    w = zo.root_of_unity(log_n)
-    assert (ctx.best_fft(a, w, log_n) == zo.best_fft(a, w, log_n, 8)).all()
+    ctx.set_option("ntt_smax", int(smax))
+    ctx.set_option("ZKHIP_NTT_R8", int(r8))      # the environment spelling is accepted too
+    try:
+        a = zo.synth_raw253(3200 + log_n, 1 << log_n)
+        w = zo.root_of_unity(log_n)
+        assert (ctx.best_fft(a, w, log_n) == zo.best_fft(a, w, log_n, 8)).all()
+    finally:
+        ctx.set_option("ntt_smax", 0)
+        ctx.set_option("ntt_r8", 1)
 
 
 def test_fft_batch_device(zk, oracle):

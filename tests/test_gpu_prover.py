@@ -284,9 +284,139 @@ def test_cli_shaped_driver_and_srs_file_round_trip(zk, tmp_path, capsys):
     for name in ("a.proof", "b.proof"):
         cli.main(["prove-rsa", "--k", "9", "--params-path", params, "--proof-path", str(tmp_path / name)])
         outs.append(json.loads(capsys.readouterr().out.strip().splitlines()[-1]))
-    assert os.path.getsize(os.path.join(params, "kzg_bn254_9.srs")) == 4 + 2 * 512 * 64 + 256
+    assert not os.path.exists(os.path.join(params, "kzg_bn254_9.srs"))      # the reference's file name is never written with a synthetic SRS
+    srs = os.path.join(params, "kzg_bn254_9.synthetic.srs")
+    assert os.path.getsize(srs) == 4 + 2 * 512 * 64 + 256 and outs[0]["params"] == srs and outs[0]["transcript"] == "poseidon"
+    assert open(srs, "rb").read()[-256:] != bytes(256)                      # real g2 / [s] g2, not identity points
     a, b = (tmp_path / "a.proof").read_bytes(), (tmp_path / "b.proof").read_bytes()
     assert a == b and len(a) == outs[0]["proof_bytes"] and len(a) % 32 == 0
     cli.main(["gen-x509-agg-evm-proof", "--agg-k", "9", "--params-path", params, "--agg-proof-path", str(tmp_path / "e.proof")])
     e = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
     assert e["transcript"] == "evm-keccak" and e["proof_bytes"] > len(a)
+
+
+# ------------------------------------------------------------------ round 2
+@pytest.mark.parametrize("kind", ["poseidon", "blake2b", "evm"])
+@pytest.mark.parametrize("k", [6, 9])
+def test_native_proof_bytes_verify(zk, oracle, k, kind):
+    """zkhip_create_proof_ex under each of the library's transcripts: the proof BYTES pass the byte-driven verifier (upstream's read
+    order, challenges re-derived by an independent Python transcript), equal the Python schedule's bytes driven through the same
+    library transcript, and — for the oracle backend under Poseidon — the CPU oracle's bytes."""
+    from verify_util import verify_proof
+
+    ffi, ctx = zk
+    sh = pv.CircuitShape.small(k)
+    gp = pv.Prover(pv.GpuBackend(ctx, ffi), sh, satisfiable=True)
+    w = gp.witness(3)
+    tn = gp.prove_native(w, transcript=kind)
+    assert verify_proof(gp, w, tn["proof"], kind)
+    tp = gp.prove(w, transcript=kind)
+    assert tp["proof"] == tn["proof"]
+    if kind == "poseidon":
+        cp = pv.Prover(OracleBackend(8), sh, satisfiable=True)
+        assert cp.prove(cp.witness(3), transcript=kind)["proof"] == tn["proof"]
+    bad = bytearray(tn["proof"])
+    bad[-70] ^= 4
+    assert not verify_proof(gp, w, bytes(bad), kind)
+
+
+def test_rsa_k17_poseidon_proof_bytes_verify(zk, oracle):
+    """BASELINE configs[1] under the transcript the reference's prove-rsa really uses (gen_snark_shplonk = Poseidon,
+    /root/reference/src/bin/cli.rs:320): the k = 17 proof's bytes verify."""
+    from verify_util import verify_proof
+
+    ffi, ctx = zk
+    gp = pv.Prover(pv.GpuBackend(ctx, ffi), pv.CircuitShape.rsa(17), satisfiable=True)
+    w = gp.witness(0)
+    t = gp.prove_native(w, transcript="poseidon")
+    assert t["n_commitments"] == 16 and verify_proof(gp, w, t["proof"], "poseidon")
+
+
+def test_sha_satisfiable_matches_oracle_k11(zk, oracle):
+    """BASELINE configs[2] shape (32 advice / 12 fixed columns, degree 5, no lookup) as a SATISFIABLE instance at a size the oracle
+    finishes in seconds: the GPU proof equals the oracle backend's byte for byte and verifies; a flipped bit in a bit column fails."""
+    from verify_util import verify_proof
+
+    ffi, ctx = zk
+    zo = oracle
+    sh = pv.CircuitShape.sha256(11)
+    gp = pv.Prover(pv.GpuBackend(ctx, ffi), sh, satisfiable=True)
+    cp = pv.Prover(OracleBackend(8), sh, satisfiable=True)
+    wg, wc = gp.witness(1), cp.witness(1)
+    for a, b in zip(wg["advice"], wc["advice"]):
+        assert (ctx.to_host(a) == b).all()
+    tg = gp.prove_native(wg, transcript="poseidon")
+    tc = cp.prove(wc, transcript="poseidon")
+    assert tg["proof"] == tc["proof"]
+    assert verify_proof(gp, wg, tg["proof"], "poseidon")
+    bad = dict(wg)
+    col = wg["advice"][0].clone()
+    col[6] = ctx.to_device(zo.fr_arr_from_ints([2]))[0]          # row 6 is active: b (1 - b) != 0
+    bad["advice"] = [col] + wg["advice"][1:]
+    assert not verify_proof(gp, bad, gp.prove_native(bad, transcript="poseidon")["proof"], "poseidon")
+
+
+def test_sha_k19_satisfiable_proof_verifies(zk, oracle):
+    """BASELINE configs[2] at FULL size (zkevm SHA256 shape, k = 19: 40 MSM_2^19 under the c = 17 window, 34 + 34 NTTs, the
+    2^21-row sweep of 32 degree-<=5 gates): one zkhip_create_proof_ex pass on a satisfiable instance under the reference's
+    transcript (Poseidon, /root/reference/src/bin/cli.rs:369); the proof bytes pass the byte-driven verifier, the quotient commitments
+    satisfy the SRS-trapdoor identity, and the proof is deterministic."""
+    from verify_util import verify_proof
+
+    ffi, ctx = zk
+    zo = oracle
+    s = 0x1D5C0FFEE
+    gp = pv.Prover(pv.GpuBackend(ctx, ffi), pv.CircuitShape.sha256(19), srs_trapdoor=s, satisfiable=True)
+    assert gp.b.params.window() == (17, 15)
+    w = gp.witness(0)
+    t1 = gp.prove_native(w, transcript="poseidon", fetch_h=True)
+    assert t1["n_commitments"] == 40
+    assert verify_proof(gp, w, t1["proof"], "poseidon")
+    sm = zo.fr_from_int(s)
+    qc = [c for tag, c in t1["commitments"] if tag == "quotient"]
+    assert len(qc) == 4
+    for piece, c in zip(t1["h_pieces"], qc):
+        assert zo.g1_to_bytes(zo.g1_mul_gen(zo.eval_polynomial(piece, sm))).hex() == c
+    assert gp.prove_native(w, transcript="poseidon")["proof"] == t1["proof"]
+    gp.b.params.free()
+    del gp, w
+
+
+def test_caller_supplied_blinding_and_host_inputs(zk, oracle):
+    """zkhip_create_proof_ex with the caller's rng draws (upstream's create_proof takes them from its `rng` argument) and with host
+    advice columns (the Vec<Fr> a Rust caller holds):
+      * blinding buffers equal to what the seeded generator produces -> the same proof bytes, from host and from device buffers;
+      * other blinding values -> a different proof that still verifies; host advice / library-built instance columns -> same bytes."""
+    from verify_util import verify_proof
+
+    ffi, ctx = zk
+    sh = pv.CircuitShape.small(8)
+    gp = pv.Prover(pv.GpuBackend(ctx, ffi), sh, satisfiable=True)
+    w = gp.witness(2)
+    base, bf, L, Zp, n = w["base"], sh.blinding_factors, len(sh.lookups), sh.n_perm_sets, 1 << sh.k
+    ref = gp.prove_native(w, transcript="poseidon")["proof"]
+    lp = []
+    for i in range(L):
+        lp += [ctx.to_host(ctx.synth_fill(bf + 1, base + 300 + i)), ctx.to_host(ctx.synth_fill(bf + 1, base + 320 + i))]
+    host = dict(lookup_permuted=np.concatenate(lp), perm_z=ctx.to_host(ctx.synth_fill(Zp * bf, base + 340)),
+                lookup_z=ctx.to_host(ctx.synth_fill(L * bf, base + 360)), random_poly=ctx.to_host(ctx.synth_fill(n, base + 380)))
+    assert gp.prove_native(w, transcript="poseidon", blinding=host)["proof"] == ref
+    dev = {k_: ctx.to_device(v) for k_, v in host.items()}
+    assert gp.prove_native(w, transcript="poseidon", blinding=dev)["proof"] == ref
+    assert gp.prove_native(w, transcript="poseidon", host_inputs=True)["proof"] == ref
+    assert gp.prove_native(w, transcript="poseidon", host_inputs=True, blinding=host)["proof"] == ref
+    other = dict(host)
+    other["perm_z"] = ctx.to_host(ctx.synth_fill(Zp * bf, 987654321))
+    other["random_poly"] = ctx.to_host(ctx.synth_fill(n, 123456789))
+    t = gp.prove_native(w, transcript="poseidon", blinding=other)
+    assert t["proof"] != ref and verify_proof(gp, w, t["proof"], "poseidon")
+
+
+def test_options_are_context_state(zk):
+    """tuning knobs: read from the environment once (zkhip_init), changed with zkhip_set_option, unknown names rejected"""
+    ffi, ctx = zk
+    ctx.set_option("msm_debug", 0)
+    ctx.set_option("ZKHIP_LATE_OVERLAP", -1)
+    with pytest.raises(ffi.ZkhipError):
+        ctx.set_option("no_such_knob", 1)
+    ctx.trim()

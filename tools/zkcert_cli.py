@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """CLI-shaped driver for the proving commands of the reference (argument names of /root/reference/src/bin/cli.rs:95-211),
 hot path only: each command runs `create_proof` for a synthetic circuit of the command's shape on the GPU
-library — there is no witness generation from certificates here — reads or creates `<params-path>/kzg_bn254_<k>.srs` like the
-reference's `gen_srs`, writes the proof bytes to the proof path and prints the timing as one JSON line.
+library — there is no witness generation from certificates here — reads `<params-path>/kzg_bn254_<k>.srs` like the reference's
+`gen_srs` if that file exists, otherwise generates a synthetic SRS (public trapdoor) and keeps it as `kzg_bn254_<k>.synthetic.srs`,
+a name the reference never reads; writes the proof bytes to the proof path and prints the timing as one JSON line.  Transcripts as
+in the reference: Poseidon for the gen_snark_shplonk commands (cli.rs:320,343,369,462), Keccak for gen-x509-agg-evm-proof (cli.rs:519).
 
     python tools/zkcert_cli.py prove-rsa --k 17 --proof-path build/rsa_1.proof
     python tools/zkcert_cli.py prove-unoptimized-sha256 --k 19
@@ -49,17 +51,18 @@ def main(argv=None):
     ctx.synchronize()
     t_setup = time.perf_counter() - t0
     evm = args.cmd == "gen-x509-agg-evm-proof"
+    kind = "evm" if evm else "poseidon"
     times = []
     for _ in range(max(1, args.repeat)):
         ctx.synchronize()
         t0 = time.perf_counter()
-        trace = prover.prove_native(wit, evm=evm)
+        trace = prover.prove_native(wit, transcript=kind)
         times.append(time.perf_counter() - t0)
     os.makedirs(os.path.dirname(args.proof_path) or ".", exist_ok=True)
     with open(args.proof_path, "wb") as f:
         f.write(trace["proof"])
-    print(json.dumps({"command": args.cmd, "circuit": shape.name, "k": args.k, "transcript": "evm-keccak" if evm else "blake2b",
-                      "proof_bytes": len(trace["proof"]), "proof_path": args.proof_path, "params": backend.params_file,
+    print(json.dumps({"command": args.cmd, "circuit": shape.name, "k": args.k, "transcript": "evm-keccak" if evm else "poseidon",
+                      "proof_bytes": len(trace["proof"]), "proof_path": args.proof_path, "params": backend.params_source,
                       "setup_s": round(t_setup, 3), "create_proof_s": [round(t, 6) for t in times]}))
 
 
