@@ -1,0 +1,193 @@
+// comm.hip — one proof over several GPUs: one process per GPU, RCCL over xGMI.
+//
+// The path has three exchange steps and nothing else crosses a GPU boundary:
+//   * MSM by point range: rank r holds the window tables of bases [r n/N, (r+1) n/N) only and sums its slice of every column;
+//     the N x ncols Jacobian partial sums (96 B each) are all-gathered as raw bytes and folded on the device (RCCL has no
+//     curve-point reduction; the payload is latency-sized);
+//   * coset NTTs by polynomial: rank r transforms columns r, r+N, ... of a batch, the extended columns are all-gathered in place;
+//   * quotient sweep by row range: rank r evaluates extended rows [r en/N, (r+1) en/N), h is all-gathered in place.
+// ONE communicator and ONE stream for every collective: the proof issues work on two streams (the main one and the side stream of
+// the overlapped coset NTTs), and collective kernels of two communicators spinning on one device for peers that have scheduled them
+// in the other order is the classic RCCL deadlock.  Every all-gather is therefore enqueued on the communicator's own stream, fenced
+// with events against the stream that produces / consumes the data; the enqueue order is the host's program order, identical on
+// every rank.
+// RCCL is resolved at run time (dlopen of the already-loaded librccl — torch ships its own copy with the same SONAME, and two
+// RCCL / HIP runtimes in one process do not share devices), so the library still loads where RCCL is absent.
+// A second transport stages the same all-gathers through host buffers and a caller-supplied function: bring-up and tests on a
+// one-GPU box (RCCL refuses two ranks per device), or a launcher without RCCL.
+#include <dlfcn.h>
+
+#include "common.hpp"
+using namespace zk;
+
+namespace {
+// the slice of rccl.h this file needs (types only; the symbols come from dlsym)
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclResult_t;
+enum { ncclInt8 = 0 };
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+int load_rccl() {
+    if (g_rccl.lib) return ZKHIP_OK;
+    const char* names[] = {"librccl.so", "librccl.so.1"};
+    void* h = nullptr;
+    for (const char* nm : names) if (!h) h = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);   // the copy the process already uses (torch's)
+    for (const char* nm : names) if (!h) h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { set_error("zkhip_comm: librccl not found (%s)", dlerror()); return ZKHIP_EINVAL; }
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
+    g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(h, "ncclAllGather");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy) {
+        set_error("zkhip_comm: librccl lacks a required symbol");
+        return ZKHIP_EINVAL;
+    }
+    g_rccl.lib = h;
+    return ZKHIP_OK;
+}
+#define ZK_NCCL(expr)                                                                                           \
+    do {                                                                                                        \
+        ncclResult_t _r = (expr);                                                                               \
+        if (_r != 0) {                                                                                          \
+            zk::set_error("%s failed: %s", #expr, g_rccl.GetErrorString ? g_rccl.GetErrorString(_r) : "rccl error"); \
+            return ZKHIP_EHIP;                                                                                  \
+        }                                                                                                       \
+    } while (0)
+
+// out[col] = sum over ranks of parts[rank][col] (Jacobian, ABI form as the MSM's last kernel writes it)
+__global__ void k_fold_partials(const uint32_t* parts, uint32_t nranks, uint32_t ncols, uint32_t* out) {
+    uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= ncols) return;
+    g1j acc = g1j_load_abi((const uint64_t*)(parts + (size_t)col * 24));
+    for (uint32_t r = 1; r < nranks; ++r) acc = g1j_add(acc, g1j_load_abi((const uint64_t*)(parts + ((size_t)r * ncols + col) * 24)));
+    g1j_store_abi((uint64_t*)(out + (size_t)col * 24), acc);
+}
+}  // namespace
+
+namespace zk {
+// recv holds nranks blocks of `bytes`; rank r's block is at r * bytes; d_send may be that block itself (in place)
+int comm_allgather(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t bytes) {
+    zkhip_comm& cm = ctx->comm;
+    if (!cm.nccl && !cm.host_allgather) {   // no communicator: a single rank
+        if (d_send != d_recv) ZK_HIP(hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        return ZKHIP_OK;
+    }
+    if (cm.host_allgather) {
+        // host-staged: D2H of this rank's block, the caller's all-gather over host memory, H2D of the whole buffer
+        const size_t total = bytes * (size_t)cm.nranks;
+        if (cm.stage_bytes < total + bytes) {
+            if (cm.stage) (void)hipHostFree(cm.stage);
+            cm.stage = nullptr;
+            cm.stage_bytes = 0;
+            ZK_HIP(hipHostMalloc(&cm.stage, total + bytes, hipHostMallocDefault));
+            cm.stage_bytes = total + bytes;
+        }
+        char* h_send = (char*)cm.stage + total;
+        ZK_HIP(hipMemcpyAsync(h_send, d_send, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP(hipStreamSynchronize(ctx->stream));
+        int rc = cm.host_allgather(cm.host_user, h_send, cm.stage, bytes);
+        if (rc != 0) { set_error("zkhip_comm: the host all-gather callback returned %d", rc); return ZKHIP_EHIP; }
+        ZK_HIP(hipMemcpyAsync(d_recv, cm.stage, total, hipMemcpyHostToDevice, ctx->stream));
+        ZK_HIP(hipStreamSynchronize(ctx->stream));   // the staging buffer is reused by the next call
+        return ZKHIP_OK;
+    }
+    ncclComm_t c = (ncclComm_t)cm.nccl;
+    if (!c) { set_error("zkhip_comm: no communicator"); return ZKHIP_EINVAL; }
+    ZK_HIP(hipEventRecord(cm.ev_in, ctx->stream));            // the data is produced on the calling stream ...
+    ZK_HIP(hipStreamWaitEvent(cm.stream, cm.ev_in, 0));
+    ZK_NCCL(g_rccl.AllGather(d_send, d_recv, bytes, ncclInt8, c, cm.stream));
+    ZK_HIP(hipEventRecord(cm.ev_out, cm.stream));             // ... and consumed there
+    ZK_HIP(hipStreamWaitEvent(ctx->stream, cm.ev_out, 0));
+    cm.bytes_gathered += bytes * (size_t)(cm.nranks - 1);
+    return ZKHIP_OK;
+}
+
+// the partial sums of a point-range-sharded batch of MSMs -> the sums, on every rank (d_out may be pinned host memory)
+int comm_fold_partials(zkhip_ctx* ctx, const void* d_part, size_t ncols, void* d_out) {
+    zkhip_comm& cm = ctx->comm;
+    void* d_all;
+    ZK_TRY(ctx->get_scratch("comm_parts", (size_t)cm.nranks * ncols * 96, &d_all));
+    ZK_TRY(comm_allgather(ctx, d_part, d_all, ncols * 96));
+    hipLaunchKernelGGL(k_fold_partials, dim3(div_up(ncols, 64)), dim3(64), 0, ctx->stream, (const uint32_t*)d_all, (uint32_t)cm.nranks,
+                       (uint32_t)ncols, (uint32_t*)d_out);
+    ZK_LAUNCH_CHECK();
+    return ZKHIP_OK;
+}
+}  // namespace zk
+
+extern "C" {
+
+int zkhip_comm_unique_id(uint8_t id[128]) {
+    if (!id) { set_error("zkhip_comm_unique_id: null argument"); return ZKHIP_EINVAL; }
+    ZK_TRY(load_rccl());
+    ncclUniqueId a;
+    ZK_NCCL(g_rccl.GetUniqueId(&a));
+    memcpy(id, a.internal, 128);
+    return ZKHIP_OK;
+}
+
+int zkhip_comm_init(zkhip_ctx* ctx, const uint8_t id[128], int rank, int nranks) {
+    if (!ctx || !id || nranks < 1 || rank < 0 || rank >= nranks) { set_error("zkhip_comm_init: bad argument"); return ZKHIP_EINVAL; }
+    if (ctx->comm.nranks > 1) { set_error("zkhip_comm_init: the context already has a communicator"); return ZKHIP_EINVAL; }
+    ZK_TRY(load_rccl());
+    ZK_HIP(hipSetDevice(ctx->device));
+    ncclUniqueId a;
+    memcpy(a.internal, id, 128);
+    ncclComm_t cm = nullptr;
+    ZK_NCCL(g_rccl.CommInitRank(&cm, nranks, a, rank));
+    ctx->comm.nccl = cm;
+    ZK_HIP(hipStreamCreateWithFlags(&ctx->comm.stream, hipStreamNonBlocking));
+    ZK_HIP(hipEventCreateWithFlags(&ctx->comm.ev_in, hipEventDisableTiming));
+    ZK_HIP(hipEventCreateWithFlags(&ctx->comm.ev_out, hipEventDisableTiming));
+    ctx->comm.rank = rank;
+    ctx->comm.nranks = nranks;
+    return ZKHIP_OK;
+}
+
+int zkhip_comm_init_host(zkhip_ctx* ctx, int rank, int nranks, zkhip_host_allgather_fn fn, void* user) {
+    if (!ctx || !fn || nranks < 1 || rank < 0 || rank >= nranks) { set_error("zkhip_comm_init_host: bad argument"); return ZKHIP_EINVAL; }
+    if (ctx->comm.nranks > 1) { set_error("zkhip_comm_init_host: the context already has a communicator"); return ZKHIP_EINVAL; }
+    ctx->comm.host_allgather = fn;
+    ctx->comm.host_user = user;
+    ctx->comm.rank = rank;
+    ctx->comm.nranks = nranks;
+    return ZKHIP_OK;
+}
+
+int zkhip_comm_destroy(zkhip_ctx* ctx) {
+    if (!ctx) { set_error("null ctx"); return ZKHIP_EINVAL; }
+    zkhip_comm& cm = ctx->comm;
+    (void)hipDeviceSynchronize();
+    if (cm.nccl && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)cm.nccl);
+    if (cm.stream) (void)hipStreamDestroy(cm.stream);
+    if (cm.ev_in) (void)hipEventDestroy(cm.ev_in);
+    if (cm.ev_out) (void)hipEventDestroy(cm.ev_out);
+    if (cm.stage) (void)hipHostFree(cm.stage);
+    cm = zkhip_comm();
+    return ZKHIP_OK;
+}
+
+int zkhip_comm_info(const zkhip_ctx* ctx, int* rank, int* nranks, uint64_t* bytes_gathered) {
+    if (!ctx) { set_error("null ctx"); return ZKHIP_EINVAL; }
+    if (rank) *rank = ctx->comm.rank;
+    if (nranks) *nranks = ctx->comm.nranks;
+    if (bytes_gathered) *bytes_gathered = ctx->comm.bytes_gathered;
+    return ZKHIP_OK;
+}
+
+// all-gather of device buffers through the context's communicator (tests; the proof uses it internally)
+int zkhip_comm_allgather_device(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_rank) {
+    if (!ctx || !d_send || !d_recv) { set_error("zkhip_comm_allgather_device: null argument"); return ZKHIP_EINVAL; }
+    return comm_allgather(ctx, d_send, d_recv, bytes_per_rank);
+}
+
+}  // extern "C"

@@ -53,9 +53,24 @@ struct zkhip_options {
     int graphs = 1;
 };
 
+// Multi-GPU state of a context (comm.hip): rank / size, the RCCL communicator with its own stream (or the host-staged transport),
+// and a byte counter for the exchange volume.
+struct zkhip_comm {
+    int rank = 0, nranks = 1;
+    void* nccl = nullptr;
+    hipStream_t stream = nullptr;             // every collective is enqueued here, fenced against the producing / consuming stream
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    zkhip_host_allgather_fn host_allgather = nullptr;
+    void* host_user = nullptr;
+    void* stage = nullptr;        // pinned staging buffer of the host transport
+    size_t stage_bytes = 0;
+    uint64_t bytes_gathered = 0;  // bytes this rank received through RCCL all-gathers
+};
+
 struct zkhip_ctx {
     int device = 0;
     zkhip_options opt;
+    zkhip_comm comm;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -94,6 +109,7 @@ struct zkhip_ctx {
     std::string prof_only;   // if non-empty, only spans of this name are recorded (keeps the event traffic off the timed path)
     struct ProfSpan { const char* name; hipEvent_t e0, e1; };
     std::vector<ProfSpan> prof_spans;
+    uint64_t prof_msm_pairs = 0, prof_msm_dense_pairs = 0;   // (digit, point) pairs accumulated / n W per column, while profiling all kernels
     std::vector<hipEvent_t> prof_pool;
     hipEvent_t prof_event();
     void prof_begin(const char* name);
@@ -137,6 +153,8 @@ static inline hipError_t event_wait(hipEvent_t ev) {
 
 struct zkhip_domain;
 namespace zk {
+int comm_allgather(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t bytes);
+int comm_fold_partials(zkhip_ctx* ctx, const void* d_part, size_t ncols, void* d_out);
 int lagrange_to_coeff_oop(zkhip_ctx* ctx, const zkhip_domain* d, const void* const* srcs, void* const* dsts, size_t npolys);
 int permute_expression_pair_async(zkhip_ctx* ctx, uint32_t k, uint32_t blinding_factors, const void* d_input, const void* d_table,
                                   const void* d_blind_in, const void* d_blind_tab, void* d_perm_in, void* d_perm_tab, uint32_t* d_err_flag,

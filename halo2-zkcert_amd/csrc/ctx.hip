@@ -83,6 +83,14 @@ int zkhip_profile_enable(zkhip_ctx* c, int on) {
     for (auto& sp : c->prof_spans) { c->prof_pool.push_back(sp.e0); c->prof_pool.push_back(sp.e1); }
     c->prof_spans.clear();
     c->prof_on = on != 0;
+    c->prof_msm_pairs = c->prof_msm_dense_pairs = 0;
+    return ZKHIP_OK;
+}
+int zkhip_profile_counter(zkhip_ctx* c, const char* name, uint64_t* value) {
+    if (!c || !name || !value) { set_error("zkhip_profile_counter: null argument"); return ZKHIP_EINVAL; }
+    if (strcmp(name, "msm_pairs") == 0) *value = c->prof_msm_pairs;
+    else if (strcmp(name, "msm_dense_pairs") == 0) *value = c->prof_msm_dense_pairs;
+    else { set_error("zkhip_profile_counter: unknown counter '%s'", name); return ZKHIP_EINVAL; }
     return ZKHIP_OK;
 }
 int zkhip_profile_select(zkhip_ctx* c, const char* kernel) {
@@ -165,7 +173,8 @@ int zkhip_init(zkhip_ctx** out, int device_id) {
 void zkhip_destroy(zkhip_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)zkhip_comm_destroy(c);
     for (auto& kv : c->scratch)
         if (kv.second.ptr) (void)hipFree(kv.second.ptr);
     for (auto& kv : c->persistent)

@@ -23,7 +23,9 @@
 using namespace zk;
 
 struct zkhip_srs {
-    size_t n = 0;
+    size_t n = 0;             // bases held here (the table's row length)
+    size_t first0 = 0;        // global index of base 0 of this handle (a point-range shard of a larger SRS; 0 otherwise)
+    size_t n_total = 0;       // length of the whole SRS
     uint32_t c = 0, W = 0, B = 0;
     void* d_table = nullptr;  // [W][n] affine, Montgomery
 };
@@ -113,6 +115,7 @@ static int srs_build(zkhip_ctx* ctx, const void* d_bases, size_t n, zkhip_srs** 
     if (n == 0 || n > ((size_t)1 << 26)) { set_error("zkhip_srs_load: n = %zu out of range (1..2^26)", n); return ZKHIP_EINVAL; }
     zkhip_srs* s = new zkhip_srs();
     s->n = n;
+    s->n_total = n;
     s->c = pick_window(ctx, n);
     s->W = (255 + s->c - 1) / s->c;
     s->B = 1u << (s->c - 1);
@@ -927,10 +930,9 @@ __global__ void k_set_identity(uint32_t* out_all, uint32_t ncols) {
 }
 
 // ------------------------------------------------------------------ host driver
-// columns hold at least first + n scalars; scalar first + i pairs with base first + i.
-static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const void* const* d_cols_host, size_t ncols, size_t first, size_t n,
-                   void* d_out) {
-    if (!ctx || !srs_per_col || !d_cols_host || !d_out) { set_error("zkhip_msm: null argument"); return ZKHIP_EINVAL; }
+// columns hold at least first + n scalars; scalar first + i pairs with base first + i (indices LOCAL to the handles' tables).
+static int msm_local(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const void* const* d_cols_host, size_t ncols, size_t first, size_t n,
+                     void* d_out) {
     if (ncols == 0) return ZKHIP_OK;
     const zkhip_srs* srs = srs_per_col[0];
     for (size_t j = 0; j < ncols; ++j) {
@@ -1141,6 +1143,16 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
         nxt_cnt = (uint32_t*)tc; nxt_off = (uint32_t*)to;
         maxcnt = (maxcnt + seg - 1) / seg;
     }
+    if (ctx->prof_on && ctx->prof_only.empty()) {
+        // profiling passes only: the number of (non-zero digit, point) pairs the accumulation really processed (zero digits are
+        // skipped, so bit / small-valued witness columns have far fewer than n W) — off[B] of every column, one small read-back
+        std::vector<uint32_t> tot(ncols);
+        for (size_t j = 0; j < ncols; ++j)
+            ZK_HIP(hipMemcpyAsync(&tot[j], (const uint32_t*)d_off + j * (B + 4) + B, 4, hipMemcpyDeviceToHost, st));
+        ZK_HIP(hipStreamSynchronize(st));
+        for (size_t j = 0; j < ncols; ++j) ctx->prof_msm_pairs += tot[j];
+        ctx->prof_msm_dense_pairs += (uint64_t)ncols * items;
+    }
     { ProfScope ps(ctx, "msm_tail");
     if (wide_tail)
         hipLaunchKernelGGL(k_bucket_chunks<1>, dim3(nchunk_blocks, (unsigned)ncols), dim3(256), 0, st, (const uint32_t*)cur_p, pstride0,
@@ -1153,7 +1165,55 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
     return ZKHIP_OK;
 }
 
+// GLOBAL point indices.  Over whole-SRS handles this is msm_local.  Over point-range shards (zkhip_kzg_setup_range /
+// zkhip_srs_load_range) every rank sums the part of [first, first + n) its tables hold — scalar pointers shifted so that local base 0
+// meets its scalar — and, when the context has a communicator, the partial sums are all-gathered and folded (collective call).
+static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const void* const* d_cols_host, size_t ncols, size_t first, size_t n,
+                   void* d_out) {
+    if (!ctx || !srs_per_col || !d_cols_host || !d_out) { set_error("zkhip_msm: null argument"); return ZKHIP_EINVAL; }
+    if (ncols == 0) return ZKHIP_OK;
+    const zkhip_srs* srs = srs_per_col[0];
+    if (!srs) { set_error("zkhip_msm: null SRS for column 0"); return ZKHIP_EINVAL; }
+    bool sharded = false;
+    for (size_t j = 0; j < ncols; ++j) {
+        const zkhip_srs* q = srs_per_col[j];
+        if (!q) { set_error("zkhip_msm: null SRS for column %zu", j); return ZKHIP_EINVAL; }
+        if (q->first0 != srs->first0 || q->n != srs->n || q->n_total != srs->n_total) { set_error("zkhip_msm: the SRS of column %zu covers a different range", j); return ZKHIP_EINVAL; }
+        sharded |= q->n_total != q->n;
+    }
+    if (first + n > srs->n_total) { set_error("zkhip_msm: range [%zu, %zu) exceeds the %zu bases of the SRS", first, first + n, srs->n_total); return ZKHIP_EINVAL; }
+    if (!sharded) return msm_local(ctx, srs_per_col, d_cols_host, ncols, first, n, d_out);
+    const size_t lo = std::max(first, srs->first0), hi = std::min(first + n, srs->first0 + srs->n);
+    const size_t cnt = hi > lo ? hi - lo : 0;
+    const bool collective = ctx->comm.nranks > 1;
+    if (!collective && cnt != n) { set_error("zkhip_msm: range [%zu, %zu) is not inside this shard [%zu, %zu) and the context has no communicator", first, first + n, srs->first0, srs->first0 + srs->n); return ZKHIP_EINVAL; }
+    std::vector<const void*> shifted(ncols);
+    for (size_t j = 0; j < ncols; ++j) shifted[j] = (const char*)d_cols_host[j] + srs->first0 * 32;
+    void* d_part = d_out;
+    if (collective) ZK_TRY(ctx->get_scratch("msm_shard_part", ncols * 96, &d_part));
+    ZK_TRY(msm_local(ctx, srs_per_col, shifted.data(), ncols, cnt ? lo - srs->first0 : 0, cnt, d_part));
+    if (collective) ZK_TRY(zk::comm_fold_partials(ctx, d_part, ncols, d_out));
+    return ZKHIP_OK;
+}
+
+namespace zk {
+int srs_set_range(zkhip_srs* s, size_t first, size_t n_total) { s->first0 = first; s->n_total = n_total; return ZKHIP_OK; }
+}
+
 extern "C" {
+
+int zkhip_srs_load_range(zkhip_ctx* ctx, const uint64_t* bases_xy, size_t n_total, size_t first, size_t count, zkhip_srs** out) {
+    if (!ctx || !bases_xy || !out || count == 0 || first + count > n_total) { set_error("zkhip_srs_load_range: bad argument"); return ZKHIP_EINVAL; }
+    ZK_TRY(zkhip_srs_load(ctx, bases_xy, count, out));
+    (*out)->first0 = first;
+    (*out)->n_total = n_total;
+    return ZKHIP_OK;
+}
+void zkhip_srs_range(const zkhip_srs* s, size_t* first, size_t* count, size_t* n_total) {
+    if (first) *first = s ? s->first0 : 0;
+    if (count) *count = s ? s->n : 0;
+    if (n_total) *n_total = s ? s->n_total : 0;
+}
 
 int zkhip_srs_load_device(zkhip_ctx* ctx, const void* d_bases, size_t n, zkhip_srs** out) {
     if (!ctx || !d_bases || !out) { set_error("zkhip_srs_load_device: null argument"); return ZKHIP_EINVAL; }
@@ -1173,14 +1233,14 @@ void zkhip_srs_free(zkhip_ctx* ctx, zkhip_srs* s) {
     if (s->d_table) (void)hipFree(s->d_table);
     delete s;
 }
-size_t zkhip_srs_len(const zkhip_srs* s) { return s ? s->n : 0; }
+size_t zkhip_srs_len(const zkhip_srs* s) { return s ? s->n_total : 0; }
 void zkhip_srs_window(const zkhip_srs* s, uint32_t* c, uint32_t* windows) {
     if (c) *c = s ? s->c : 0;
     if (windows) *windows = s ? s->W : 0;
 }
 int zkhip_srs_read(zkhip_ctx* ctx, const zkhip_srs* s, size_t first, size_t count, uint64_t* out_xy) {
-    if (!ctx || !s || !out_xy || first + count > s->n) { set_error("zkhip_srs_read: bad range"); return ZKHIP_EINVAL; }
-    ZK_HIP(hipMemcpyAsync(out_xy, (const char*)s->d_table + first * 64, count * 64, hipMemcpyDeviceToHost, ctx->stream));
+    if (!ctx || !s || !out_xy || first < s->first0 || first + count > s->first0 + s->n) { set_error("zkhip_srs_read: range outside this handle's bases"); return ZKHIP_EINVAL; }
+    ZK_HIP(hipMemcpyAsync(out_xy, (const char*)s->d_table + (first - s->first0) * 64, count * 64, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(hipStreamSynchronize(ctx->stream));
     for (size_t i = 0; i < count; ++i) g1a_store_abi(out_xy + 8 * i, g1a_load_raw(out_xy + 8 * i));  // table form -> ABI form
     return ZKHIP_OK;

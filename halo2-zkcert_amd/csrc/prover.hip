@@ -103,12 +103,19 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
     StreamGuard guard{ctx, ctx->stream};
     hipStream_t st = ctx->stream;
 
+    // ---- one proof over several GPUs (comm.hip): MSMs are collective by themselves (sharded SRS handles); here the coset NTTs go by
+    // polynomial and the quotient sweep by row range, both all-gathered in place.  Everything else is replicated: every rank runs this
+    // same schedule on identical inputs and ends with the identical transcript.
+    const size_t NR = (size_t)ctx->comm.nranks, RK = (size_t)ctx->comm.rank;
+    const bool dist = NR > 1;
+    auto pad = [&](size_t cnt) { return dist ? (cnt + NR - 1) / NR * NR : cnt; };   // all-gather rounds of NR columns: pad the column blocks
+
     // ---- workspace (library-owned, reused across proofs)
     char *w_coeff, *w_ext, *w_rand, *w_comp, *w_blind, *w_perm_l, *w_perm_c, *w_ext_perm, *w_z, *w_ext_z, *w_h, *w_hpoly, *w_evals, *w_com;
     const size_t NB = n * 32, EB = en * 32;
     auto ws = [&](const char* name, size_t bytes, char** p) { void* q; int rc = ctx->get_scratch(name, bytes ? bytes : 32, &q); *p = (char*)q; return rc; };
     ZK_TRY(ws("cp_coeff", (A + I) * NB, &w_coeff));
-    ZK_TRY(ws("cp_ext", (A + I) * EB, &w_ext));
+    ZK_TRY(ws("cp_ext", pad(A + I) * EB, &w_ext));
     ZK_TRY(ws("cp_rand", NB, &w_rand));
     // host-side inputs (a Rust caller's Vec<Fr> columns, its instance values, its rng draws) are uploaded into library-owned columns
     char *w_adv_in = nullptr, *w_ins_in = nullptr;
@@ -150,9 +157,9 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
     ZK_TRY(ws("cp_blind", (2 * L * (bf + 1) + (Zp + L) * bf + 8) * 32, &w_blind));
     ZK_TRY(ws("cp_perm_l", 2 * L * NB, &w_perm_l));
     ZK_TRY(ws("cp_perm_c", 2 * L * NB, &w_perm_c));
-    ZK_TRY(ws("cp_ext_perm", 2 * L * EB, &w_ext_perm));
+    ZK_TRY(ws("cp_ext_perm", pad(2 * L) * EB, &w_ext_perm));
     ZK_TRY(ws("cp_z", (Zp + L) * NB, &w_z));
-    ZK_TRY(ws("cp_ext_z", (Zp + L) * EB, &w_ext_z));
+    ZK_TRY(ws("cp_ext_z", pad(Zp + L) * EB, &w_ext_z));
     ZK_TRY(ws("cp_h", EB, &w_h));
     ZK_TRY(ws("cp_hpoly", NB, &w_hpoly));
     const size_t max_q = (size_t)pk->n_advice_queries + pk->n_fixed_queries + 3 * Zp + 5 * L + P + 2;
@@ -161,6 +168,20 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
     // commitments are latency-critical read-backs: let the MSM's last kernel store them straight into pinned host memory
     // (4 KiB in, past the small read-back slots) when they fit
     if ((A + 2 * L + Zp + L + qd + 2) * 96 + 4096 + 64 <= zkhip_ctx::PINNED_BYTES) w_com = (char*)ctx->h_pinned + 4096;
+
+    // coeff_to_extended of `count` polynomials whose outputs are consecutive EB-sized slices of one padded workspace block
+    auto to_extended = [&](const void* const* srcs, void* const* dsts, size_t count) -> int {
+        if (!dist) return zkhip_coeff_to_extended_device(ctx, pk->domain, srcs, n, dsts, count);
+        std::vector<const void*> ms;
+        std::vector<void*> md;
+        for (size_t j = RK; j < count; j += NR) { ms.push_back(srcs[j]); md.push_back(dsts[j]); }
+        if (!ms.empty()) ZK_TRY(zkhip_coeff_to_extended_device(ctx, pk->domain, ms.data(), n, md.data(), ms.size()));
+        for (size_t t = 0; t * NR < count; ++t) {
+            char* block = (char*)dsts[t * NR];
+            ZK_TRY(zk::comm_allgather(ctx, block + RK * EB, block, EB));
+        }
+        return ZKHIP_OK;
+    };
 
     uint64_t ch[4];
     std::vector<uint64_t> xy;
@@ -215,7 +236,7 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
             std::vector<const void*> lag(A + I);   // out of place: the witness columns stay in Lagrange form, no copy
             for (uint32_t j = 0; j < A + I; ++j) lag[j] = j < A ? d_advice[j] : d_instance[j - A];
             ZK_TRY(zk::lagrange_to_coeff_oop(ctx, pk->domain, lag.data(), coeff_ptrs.data(), A + I));
-            ZK_TRY(zkhip_coeff_to_extended_device(ctx, pk->domain, (const void* const*)coeff_ptrs.data(), n, ext_ptrs.data(), A + I));
+            ZK_TRY(to_extended((const void* const*)coeff_ptrs.data(), ext_ptrs.data(), A + I));
         }
         ov.end();
         ZK_TRY(commit_read(cols.size(), 1, &rand_xy, &rand_by));
@@ -275,7 +296,7 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
         ZK_TRY(zkhip_msm_g1_multi_device(ctx, bases.data(), cols.data(), cols.size(), 0, n, w_com));
         ZK_HIP(hipMemcpyAsync(h_err, w_perr, 4, hipMemcpyDeviceToHost, st));
         ZK_TRY(ov.begin_marked());
-        ZK_TRY(zkhip_coeff_to_extended_device(ctx, pk->domain, (const void* const*)perm_c.data(), n, ext_perm.data(), 2 * L));
+        ZK_TRY(to_extended((const void* const*)perm_c.data(), ext_perm.data(), 2 * L));
         ov.end();
         xy.resize(8 * cols.size());
         by.resize(32 * cols.size());
@@ -318,7 +339,7 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
         ov.arm();
         ZK_TRY(commit_launch(cols, bases));
         ZK_TRY(ov.begin_marked());
-        ZK_TRY(zkhip_coeff_to_extended_device(ctx, pk->domain, src.data(), n, ext_z.data(), Zp + L));
+        ZK_TRY(to_extended(src.data(), ext_z.data(), Zp + L));
         ov.end();
         ZK_TRY(commit_read(cols.size(), 0, nullptr, nullptr));
     }
@@ -350,7 +371,13 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
         a.lookup_product_cosets = (const uint64_t* const*)ext_z.data();
         a.lookup_input_cosets = (const uint64_t* const*)ext_perm.data();
         a.lookup_table_cosets = (const uint64_t* const*)(ext_perm.data() + L);
-        ZK_TRY(zkhip_evaluate_h_device(ctx, &a, w_h));
+        if (dist && en % (64 * NR) == 0) {
+            const size_t rows = en / NR;
+            ZK_TRY(zkhip_evaluate_h_rows_device(ctx, &a, RK * rows, rows, w_h + RK * rows * 32));
+            ZK_TRY(zk::comm_allgather(ctx, w_h + RK * rows * 32, w_h, rows * 32));
+        } else {
+            ZK_TRY(zkhip_evaluate_h_device(ctx, &a, w_h));
+        }
     }
     ZK_TRY(zkhip_divide_by_vanishing_device(ctx, pk->domain, w_h));
     {

@@ -68,35 +68,37 @@ extern "C" int zkhip_fixed_base_mul_device(zkhip_ctx* ctx, const void* d_scalars
     return launch_batch_to_affine(ctx, d_jac, d_out_xy, n);
 }
 
-extern "C" int zkhip_kzg_setup(zkhip_ctx* ctx, uint32_t k, const uint64_t s_u[4], zkhip_srs** g, zkhip_srs** g_lagrange) {
+namespace zk { int srs_set_range(zkhip_srs* s, size_t first, size_t n_total); }
+
+extern "C" int zkhip_kzg_setup_range(zkhip_ctx* ctx, uint32_t k, const uint64_t s_u[4], size_t first, size_t count, zkhip_srs** g,
+                                     zkhip_srs** g_lagrange) {
     if (!ctx || !s_u || (!g && !g_lagrange)) { set_error("zkhip_kzg_setup: null argument"); return ZKHIP_EINVAL; }
     if (k > 24) { set_error("zkhip_kzg_setup: k = %u unsupported (max 24)", k); return ZKHIP_EINVAL; }
-    size_t n = (size_t)1 << k;
+    const size_t n = (size_t)1 << k;
+    if (count == 0 || first + count > n) { set_error("zkhip_kzg_setup_range: [%zu, %zu) is not inside [0, 2^%u)", first, first + count, k); return ZKHIP_EINVAL; }
     el2<Fr> s = from_abi<Fr>(mem_load(s_u));
-    std::vector<fe32> sc(n);
+    std::vector<fe32> sc(count);
     void *d_sc, *d_pts;
-    ZK_TRY(ctx->get_scratch("kzg_scalars", n * 32, &d_sc));
-    ZK_TRY(ctx->get_scratch("kzg_points", n * 64, &d_pts));
-    el2<Fr> sn;
-    {
-        el2<Fr> cur = one<Fr>();
-        for (size_t i = 0; i < n; ++i) { sc[i] = to_abi(cur); cur = cur * s; }
-        sn = cur;
-    }
+    ZK_TRY(ctx->get_scratch("kzg_scalars", count * 32, &d_sc));
+    ZK_TRY(ctx->get_scratch("kzg_points", count * 64, &d_pts));
+    const el2<Fr> sn = pow_u64<Fr>(s, (uint64_t)n);
     if (g) {
-        ZK_HIP(hipMemcpyAsync(d_sc, sc.data(), n * 32, hipMemcpyHostToDevice, ctx->stream));
+        el2<Fr> cur = pow_u64<Fr>(s, (uint64_t)first);
+        for (size_t i = 0; i < count; ++i) { sc[i] = to_abi(cur); cur = cur * s; }
+        ZK_HIP(hipMemcpyAsync(d_sc, sc.data(), count * 32, hipMemcpyHostToDevice, ctx->stream));
         ZK_HIP(hipStreamSynchronize(ctx->stream));
-        ZK_TRY(zkhip_fixed_base_mul_device(ctx, d_sc, n, d_pts));
-        ZK_TRY(srs_build_raw(ctx, d_pts, n, g));
+        ZK_TRY(zkhip_fixed_base_mul_device(ctx, d_sc, count, d_pts));
+        ZK_TRY(srs_build_raw(ctx, d_pts, count, g));
+        srs_set_range(*g, first, n);
     }
     if (g_lagrange) {
         // l_i(s) = (s^n - 1)/n * w^i / (s - w^i), batch-inverted
         el2<Fr> omega = from_canonical_words<Fr>(FR_ROOT_OF_UNITY);
         for (uint32_t i = k; i < FR_S; ++i) omega = sqr(omega);
         el2<Fr> num = reduce(sn - one<Fr>()) * inv<Fr>(from_u64<Fr>((uint64_t)n));
-        std::vector<el2<Fr>> den(n), pre(n), val(n);
-        el2<Fr> w = one<Fr>(), acc = one<Fr>();
-        for (size_t i = 0; i < n; ++i) {
+        std::vector<el2<Fr>> den(count), pre(count), val(count);
+        el2<Fr> w = pow_u64<Fr>(omega, (uint64_t)first), acc = one<Fr>();
+        for (size_t i = 0; i < count; ++i) {
             den[i] = reduce(s - w);
             if (is_zero(den[i])) { set_error("zkhip_kzg_setup: s is an n-th root of unity"); return ZKHIP_EINVAL; }
             pre[i] = acc;
@@ -105,15 +107,21 @@ extern "C" int zkhip_kzg_setup(zkhip_ctx* ctx, uint32_t k, const uint64_t s_u[4]
             w = w * omega;
         }
         el2<Fr> iv = inv<Fr>(acc);
-        for (size_t i = n; i-- > 0;) {
+        for (size_t i = count; i-- > 0;) {
             el2<Fr> di = iv * pre[i];
             iv = iv * den[i];
             sc[i] = to_abi(val[i] * di);
         }
-        ZK_HIP(hipMemcpyAsync(d_sc, sc.data(), n * 32, hipMemcpyHostToDevice, ctx->stream));
+        ZK_HIP(hipMemcpyAsync(d_sc, sc.data(), count * 32, hipMemcpyHostToDevice, ctx->stream));
         ZK_HIP(hipStreamSynchronize(ctx->stream));
-        ZK_TRY(zkhip_fixed_base_mul_device(ctx, d_sc, n, d_pts));
-        ZK_TRY(srs_build_raw(ctx, d_pts, n, g_lagrange));
+        ZK_TRY(zkhip_fixed_base_mul_device(ctx, d_sc, count, d_pts));
+        ZK_TRY(srs_build_raw(ctx, d_pts, count, g_lagrange));
+        srs_set_range(*g_lagrange, first, n);
     }
     return ZKHIP_OK;
+}
+
+extern "C" int zkhip_kzg_setup(zkhip_ctx* ctx, uint32_t k, const uint64_t s_u[4], zkhip_srs** g, zkhip_srs** g_lagrange) {
+    if (k > 24) { set_error("zkhip_kzg_setup: k = %u unsupported (max 24)", k); return ZKHIP_EINVAL; }
+    return zkhip_kzg_setup_range(ctx, k, s_u, 0, (size_t)1 << k, g, g_lagrange);
 }

@@ -53,9 +53,11 @@ class ZkEvalhArgs(C.Structure):
 
 # every symbol include/zkhip.h declares (checked by tests/test_abi.py without a GPU)
 SYMBOLS = [
-    "zkhip_init", "zkhip_destroy", "zkhip_last_error", "zkhip_set_stream", "zkhip_synchronize", "zkhip_set_option", "zkhip_trim", "zkhip_malloc", "zkhip_free",
+    "zkhip_init", "zkhip_destroy", "zkhip_last_error", "zkhip_set_stream", "zkhip_synchronize", "zkhip_set_option", "zkhip_trim",
+    "zkhip_comm_unique_id", "zkhip_comm_init", "zkhip_comm_init_host", "zkhip_comm_destroy", "zkhip_comm_info", "zkhip_comm_allgather_device",
+    "zkhip_kzg_setup_range", "zkhip_srs_load_range", "zkhip_srs_range", "zkhip_malloc", "zkhip_free",
     "zkhip_memcpy_h2d", "zkhip_memcpy_d2h", "zkhip_timer_start", "zkhip_timer_stop_ms",
-    "zkhip_profile_enable", "zkhip_profile_select", "zkhip_profile_read",
+    "zkhip_profile_enable", "zkhip_profile_select", "zkhip_profile_read", "zkhip_profile_counter",
     "zkhip_srs_load", "zkhip_srs_load_device", "zkhip_srs_free", "zkhip_srs_len", "zkhip_srs_window", "zkhip_kzg_setup", "zkhip_srs_read",
     "zkhip_msm_g1", "zkhip_msm_g1_batch_device", "zkhip_msm_g1_batch_range_device", "zkhip_msm_g1_multi_device", "zkhip_g1_add", "zkhip_g1_to_affine", "zkhip_g1_batch_to_affine",
     "zkhip_g1_to_bytes", "zkhip_commitments_read",
@@ -178,6 +180,69 @@ class Context:
     def trim(self):
         _check(lib().zkhip_trim(self.h))
 
+    # ---- one proof over several GPUs (zkhip_comm_*): one process per GPU
+    world, rank = 1, 0
+
+    def comm_init(self, rank, world, dist=None, transport=None):
+        """Gives the context its communicator.  transport "rccl" (default): rank 0's ncclUniqueId is broadcast through torch.distributed
+        and every rank joins (ncclCommInitRank inside the library; the all-gathers of a proof then run over xGMI).  transport "host"
+        (ZKHIP_COMM_TRANSPORT=host, or a torch.distributed backend without device support such as gloo): the same all-gathers staged
+        through host memory and torch.distributed — bring-up and tests on a one-GPU box, where RCCL refuses two ranks per device."""
+        import torch
+
+        if transport is None:
+            transport = os.environ.get("ZKHIP_COMM_TRANSPORT") or ("host" if dist is not None and dist.get_backend() == "gloo" else "rccl")
+        if transport == "rccl":
+            ids = [None]
+            if rank == 0:
+                buf = (C.c_uint8 * 128)()
+                _check(lib().zkhip_comm_unique_id(buf))
+                ids = [bytes(buf)]
+            if world > 1:
+                dist.broadcast_object_list(ids, src=0)
+            _check(lib().zkhip_comm_init(self.h, (C.c_uint8 * 128)(*ids[0]), C.c_int(rank), C.c_int(world)))
+        elif transport == "host":
+            def _ag(user, send, recv, nbytes):
+                try:
+                    mine = torch.frombuffer((C.c_uint8 * nbytes).from_address(send), dtype=torch.uint8)
+                    outs = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
+                    if dist.get_backend() == "nccl":
+                        dev = [o.to(self.device) for o in outs]
+                        dist.all_gather(dev, mine.to(self.device))
+                        outs = [d.cpu() for d in dev]
+                    else:
+                        dist.all_gather(outs, mine.clone())
+                    for r, o in enumerate(outs):
+                        C.memmove(recv + r * nbytes, o.numpy().ctypes.data, nbytes)
+                    return 0
+                except Exception as e:   # noqa: BLE001 — never let an exception cross the C boundary
+                    print(f"zkhip host all-gather failed: {e}", flush=True)
+                    return 1
+            self._host_ag = HOST_ALLGATHER_FN(_ag)
+            _check(lib().zkhip_comm_init_host(self.h, C.c_int(rank), C.c_int(world), self._host_ag, None))
+        else:
+            raise ValueError(transport)
+        self.rank, self.world, self.transport = rank, world, transport
+
+    def comm_destroy(self):
+        _check(lib().zkhip_comm_destroy(self.h))
+        self.rank, self.world = 0, 1
+
+    def comm_bytes_gathered(self):
+        v = C.c_uint64()
+        _check(lib().zkhip_comm_info(self.h, None, None, C.byref(v)))
+        return v.value
+
+    def comm_allgather(self, send, recv):
+        """all-gather of device tensors through the context's communicator (recv: world x send)"""
+        _check(lib().zkhip_comm_allgather_device(self.h, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()),
+                                                 C.c_size_t(send.numel() * send.element_size())))
+
+    def shard_range(self, n):
+        """[first, first + count) of n points held by this rank"""
+        lo, hi = self.rank * n // self.world, (self.rank + 1) * n // self.world
+        return lo, hi - lo
+
     def timer_start(self):
         _check(lib().zkhip_timer_start(self.h))
 
@@ -198,6 +263,11 @@ class Context:
         ms, n = C.c_double(), C.c_uint64()
         _check(lib().zkhip_profile_read(self.h, kernel.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def profile_counter(self, name):
+        v = C.c_uint64()
+        _check(lib().zkhip_profile_counter(self.h, name.encode(), C.byref(v)))
+        return v.value
 
     def synth_fill(self, n, seed, first=0):
         t = self.empty(n)
@@ -320,6 +390,7 @@ def kate_division_device(ctx, polys, roots):
     _check(lib().zkhip_kate_division_device(ctx.h, C.c_size_t(n), _ptr_array(polys), C.c_size_t(len(polys)), _p(counts), _p(flat)))
 
 
+HOST_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
 WRITE_POINT_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint64))
 SQUEEZE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint64))
 WRITE_SCALAR_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint64))
@@ -572,7 +643,11 @@ class ParamsKZG:
     def setup(cls, ctx, k, s):
         """ParamsKZG::setup(k, rng) with the trapdoor given (Montgomery Fr limbs)."""
         g, gl = C.c_void_p(), C.c_void_p()
-        _check(lib().zkhip_kzg_setup(ctx.h, C.c_uint32(k), _p(_u64(s)), C.byref(g), C.byref(gl)))
+        if ctx.world > 1:      # a communicator on the context: this rank builds the window tables of its point range only
+            first, count = ctx.shard_range(1 << k)
+            _check(lib().zkhip_kzg_setup_range(ctx.h, C.c_uint32(k), _p(_u64(s)), C.c_size_t(first), C.c_size_t(count), C.byref(g), C.byref(gl)))
+        else:
+            _check(lib().zkhip_kzg_setup(ctx.h, C.c_uint32(k), _p(_u64(s)), C.byref(g), C.byref(gl)))
         p = cls(ctx, k, g, gl)
         sl = _u64(s)
         s_int = sum(int(sl[i]) << (64 * i) for i in range(4)) * pow(1 << 256, -1, _FR) % _FR
@@ -603,6 +678,23 @@ class ParamsKZG:
             if not 1 <= k <= 28:
                 raise ZkhipError(f"{path}: k = {k} is not a KZG parameter file")
             n = 1 << k
+            if ctx.world > 1:      # this rank's slice of both bases only
+                first, count = ctx.shard_range(n)
+                hs = []
+                for b in range(2):
+                    f.seek(4 + (b * n + first) * 64)
+                    raw = f.read(count * 64)
+                    if len(raw) != count * 64:
+                        raise ZkhipError(f"{path}: truncated")
+                    h = C.c_void_p()
+                    _check(lib().zkhip_srs_load_range(ctx.h, _p(np.frombuffer(raw, dtype="<u8").copy()), C.c_size_t(n), C.c_size_t(first),
+                                                      C.c_size_t(count), C.byref(h)))
+                    hs.append(h)
+                f.seek(4 + 2 * n * 64)
+                g2 = f.read(256)
+                p = cls(ctx, k, hs[0], hs[1])
+                p.g2_bytes = g2
+                return p
             raw = f.read(2 * n * 64)
             g2 = f.read(256)
         if len(raw) != 2 * n * 64 or len(g2) != 256:
@@ -613,6 +705,8 @@ class ParamsKZG:
         return p
 
     def write(self, path):
+        if self.ctx.world > 1:
+            raise ZkhipError("ParamsKZG.write: these params are one rank's shard of the SRS")
         if getattr(self, "g2_bytes", None) is None or len(self.g2_bytes) != 256:
             raise ZkhipError("ParamsKZG.write: these params carry no G2 points (loaded from bare bases); refusing to write an SRS file "
                              "with an identity g2 / s_g2")
@@ -623,6 +717,12 @@ class ParamsKZG:
                     cnt = min(1 << 16, self.n - first)
                     f.write(self.read_bases(h, first, cnt).astype("<u8").tobytes())
             f.write(self.g2_bytes)
+
+    def range(self):
+        """(first, count, n_total): the global point range this handle's tables hold (the whole SRS unless sharded)"""
+        a, b, c_ = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        lib().zkhip_srs_range(self.g if self.g is not None else self.g_lagrange, C.byref(a), C.byref(b), C.byref(c_))
+        return a.value, b.value, c_.value
 
     def window(self):
         c, w = C.c_uint32(), C.c_uint32()

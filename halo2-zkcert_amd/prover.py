@@ -76,6 +76,14 @@ class CircuitShape:
         return cls(f"rsa_k{k}", k, basic, 1, 1, 4, 6, 0xC0FFEE00 + k)
 
     @classmethod
+    def agg(cls, k=22, n_basic=3, n_lookup=1):
+        """X509VerifierAggregationCircuit's shape (BASELINE configs[3]; /root/reference/src/bin/cli.rs:464-527): a halo2-lib
+        BaseCircuitBuilder circuit at k = 22 with lookup_bits = k - 1 (cli.rs:475) — vertical-gate advice columns, lookup-advice
+        columns, one constants column, one instance column.  The column counts are what calculate_params(Some(10)) returns for four
+        verified snarks (cli.rs:493), which the reference does not state: parameters here."""
+        return cls(f"agg_k{k}_a{n_basic}+{n_lookup}", k, n_basic, n_lookup, 1, 4, 6, 0xA6600000 + k)
+
+    @classmethod
     def sha256(cls, k=19, n_advice=32, n_fixed=12):
         """zkEVM SHA-256 bit circuit shape: many narrow bit/word columns, fixed q_* and
         round-constant columns, boolean and word-decomposition gates of degree up to 5, no lookup; the two digest words are
@@ -263,7 +271,7 @@ class GpuBackend:
         else:
             self.params = self.ffi.ParamsKZG.setup(self.ctx, k, self.fr(s_int))
             self.params_source = "generated"
-            if syn:
+            if syn and self.ctx.world == 1:      # a sharded context holds 1/N of the tables: nothing to write
                 os.makedirs(os.path.dirname(syn) or ".", exist_ok=True)
                 self.params.write(syn)
                 self.params_source = syn

@@ -75,6 +75,27 @@ int  zkhip_profile_enable(zkhip_ctx* ctx, int on);
  * a 10 ms proof, so a benchmark times only the kernel it reports live and takes the full breakdown in a separate pass. */
 int  zkhip_profile_select(zkhip_ctx* ctx, const char* kernel);
 int  zkhip_profile_read(zkhip_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches);
+/* Work counters accumulated while profiling ALL kernels (no selection): "msm_pairs" = (non-zero digit, point) pairs the MSM
+ * accumulations really processed (zero digits are skipped), "msm_dense_pairs" = n * windows per column. */
+int  zkhip_profile_counter(zkhip_ctx* ctx, const char* name, uint64_t* value);
+
+/* ---- one proof over several GPUs: one process per GPU, RCCL over xGMI ----
+ * zkhip_comm_unique_id (one rank) produces the 128 opaque bytes of an RCCL unique id; the launcher distributes them
+ * (torch.distributed, MPI, a file) and every rank calls zkhip_comm_init.  With a communicator on the context:
+ *   - zkhip_kzg_setup_range / zkhip_srs_load_range give each rank the window tables of its point range only (1/N of the table);
+ *   - every MSM entry point over such an SRS is COLLECTIVE: each rank sums its slice, the ncols x 96-byte partial sums are
+ *     all-gathered and folded on the device, every rank receives the complete sums;
+ *   - zkhip_create_proof_ex additionally distributes the coset NTTs by polynomial and the quotient sweep by row range (all-gather
+ *     of the extended columns and of h in place); every rank must call it with identical inputs and obtains the identical proof.
+ * zkhip_comm_init_host is the same with the all-gathers staged through host memory and a caller-supplied function (bring-up on a
+ * one-GPU box, launchers without RCCL): fn(user, send, recv, bytes) must fill recv[r * bytes ..] with rank r's send block. */
+typedef int (*zkhip_host_allgather_fn)(void* user, const void* send, void* recv, size_t bytes_per_rank);
+int  zkhip_comm_unique_id(uint8_t id[128]);
+int  zkhip_comm_init(zkhip_ctx* ctx, const uint8_t id[128], int rank, int nranks);
+int  zkhip_comm_init_host(zkhip_ctx* ctx, int rank, int nranks, zkhip_host_allgather_fn fn, void* user);
+int  zkhip_comm_destroy(zkhip_ctx* ctx);
+int  zkhip_comm_info(const zkhip_ctx* ctx, int* rank, int* nranks, uint64_t* bytes_gathered);
+int  zkhip_comm_allgather_device(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_rank);
 
 /* ---- SRS: ParamsKZG::{g, g_lagrange} (halo2_proofs src/poly/kzg/commitment.rs) ----
  * Uploaded once; the device keeps, per base, its W window multiples 2^(c*w) * P_i in affine form
@@ -89,6 +110,13 @@ void zkhip_srs_window(const zkhip_srs* srs, uint32_t* c, uint32_t* windows);
 /* ParamsKZG::setup(k, rng) restricted to G1: bases[i] = [s^i] G (monomial) and [l_i(s)] G
  * (Lagrange), generated on the device.  s is a Montgomery Fr.  Either output may be NULL. */
 int  zkhip_kzg_setup(zkhip_ctx* ctx, uint32_t k, const uint64_t s[4], zkhip_srs** g, zkhip_srs** g_lagrange);
+/* The same for the bases [first, first + count) only: one rank's share of a point-range-sharded SRS.  The handle remembers the
+ * range; an MSM over it takes GLOBAL point indices and is collective when the context has a communicator. */
+int  zkhip_kzg_setup_range(zkhip_ctx* ctx, uint32_t k, const uint64_t s[4], size_t first, size_t count, zkhip_srs** g, zkhip_srs** g_lagrange);
+/* bases_xy: the `count` bases [first, first + count) of an SRS of n_total points (e.g. one rank's slice of a params file) */
+int  zkhip_srs_load_range(zkhip_ctx* ctx, const uint64_t* bases_xy, size_t n_total, size_t first, size_t count, zkhip_srs** out);
+/* global range [first, first + count) held by this handle (the whole SRS unless sharded) */
+void zkhip_srs_range(const zkhip_srs* srs, size_t* first, size_t* count, size_t* n_total);
 /* Copies base points [first, first+count) back (affine, Montgomery) — for tests. */
 int  zkhip_srs_read(zkhip_ctx* ctx, const zkhip_srs* srs, size_t first, size_t count, uint64_t* out_xy);
 

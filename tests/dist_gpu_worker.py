@@ -1,0 +1,49 @@
+"""One rank of a multi-process proof on the GPU (TEST INFRASTRUCTURE; launched by tests/test_gpu_distributed.py through
+torch.distributed.run).  Every rank joins the library's communicator (host-staged transport over gloo when the ranks share one
+device — RCCL refuses that — or RCCL when each rank has its own GPU), builds the same satisfiable instance over its shard of the
+SRS, proves with zkhip_create_proof_ex and writes the proof bytes; the test compares them with the single-GPU proof."""
+import json
+import os
+import sys
+
+ROOT = os.environ["ZK_ROOT"]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+
+import torch
+import torch.distributed as dist
+
+import halo2_zkcert_amd.ffi as ffi
+import halo2_zkcert_amd.prover as pv
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+one_device = os.environ.get("ZK_ONE_DEVICE", "1") == "1"
+dev = 0 if one_device else int(os.environ.get("LOCAL_RANK", "0"))
+torch.cuda.set_device(dev)
+if one_device:
+    dist.init_process_group("gloo")
+else:
+    dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+ctx = ffi.Context(dev)
+ctx.comm_init(rank, world, dist)
+out = {"transport": ctx.transport}
+for spec in json.loads(os.environ["ZK_SHAPES"]):
+    if spec[0] == "small":
+        sh = pv.CircuitShape.small(spec[1])
+    elif spec[0] == "sha":
+        sh = pv.CircuitShape.sha256(spec[1], n_advice=12, n_fixed=5)
+    else:
+        sh = pv.CircuitShape.rsa(spec[1])
+    p = pv.Prover(pv.GpuBackend(ctx, ffi), sh, satisfiable=True)
+    first, count, total = p.b.params.range()
+    assert total == 1 << sh.k and (first, count) == ctx.shard_range(total), (first, count, total)
+    w = p.witness(1)
+    tr = p.prove_native(w, transcript=spec[2])
+    tp = p.prove(w, transcript=spec[2])           # the Python schedule over the small entry points: MSMs collective, the rest replicated
+    out[f"{spec[0]}{spec[1]}{spec[2]}"] = dict(native=tr["proof"].hex(), python=tp["proof"].hex())
+    p.b.params.free()
+out["bytes_gathered"] = ctx.comm_bytes_gathered()
+with open(os.path.join(os.environ["ZK_OUT"], f"rank{rank}.json"), "w") as f:
+    json.dump(out, f)
+dist.barrier()
+ctx.comm_destroy()
+dist.destroy_process_group()

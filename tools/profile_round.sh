@@ -1,7 +1,9 @@
 #!/bin/bash
 # Collects the artefacts of one profiles/ generation on the GPU box (run through gpurun from the repo root):
-#   tools/profile_round.sh r01_v8      -> gpurun_out/r01_v8/{bench*.json, kernel_stats.csv, pmc_fetch_write.csv, kernel_bench.txt}
-# rocprofv3 gets the program itself after `--` and the counter passes are separate runs (no trace domains with --pmc).
+#   tools/profile_round.sh r02_v1  -> gpurun_out/r02_v1/{bench.json, kernel_bench.txt, <cfg>_kernel_stats.csv, pmc_<cfg>.csv, valu_<cfg>.csv}
+# rocprofv3 gets the program itself after `--`; counter passes are separate runs (no trace domains beside --pmc).
+# Copy what is to be judged into profiles/ as <tag>_<file> (pmc files keep their `# build=<hash>` header: bench.py quotes the
+# traffic figures only for the build they were measured on).
 set -u
 tag=${1:-prof}
 root=$(pwd)
@@ -9,13 +11,19 @@ out=$root/gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
 python3 bench.py > "$out/bench.json" 2> "$out/bench.err"
-python3 bench.py --k 22 --no-other-configs --steps 5 --no-cpu-baseline > "$out/bench_k22.json" 2>> "$out/bench.err"
-python3 bench.py --k 19 --shape sha256 --no-other-configs --steps 10 --no-cpu-baseline > "$out/bench_sha256_k19.json" 2>> "$out/bench.err"
 python3 tools/kernel_bench.py > "$out/kernel_bench.txt" 2>> "$out/bench.err"
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 "$root/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-other-configs > "$out/stats_bench.json" 2> "$out/stats.err"
-for c in FETCH_SIZE WRITE_SIZE SQ_LDS_BANK_CONFLICT; do
-    rocprofv3 --pmc $c --output-format csv -d "$out/pmc_$c" -- python3 "$root/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs > "$out/pmc_$c.json" 2> "$out/pmc_$c.err"
+for cfg in rsa17 sha19 agg22; do
+    args="--config $cfg --no-other-configs --no-cpu-baseline --steps 3 --warmup 1"
+    rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_$cfg" -- python3 "$root/bench.py" $args > "$out/stats_$cfg.json" 2> "$out/stats_$cfg.err"
+    for c in FETCH_SIZE WRITE_SIZE SQ_LDS_BANK_CONFLICT; do
+        rocprofv3 --pmc $c --output-format csv -d "$out/pmc_${cfg}_$c" -- python3 "$root/bench.py" $args > "$out/pmc_${cfg}_$c.json" 2> "$out/pmc_${cfg}_$c.err"
+    done
+    i=0
+    for set in "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM"; do
+        i=$((i+1))
+        rocprofv3 --pmc $set --output-format csv -d "$out/valu_${cfg}_$i" -- python3 "$root/bench.py" $args > "$out/valu_${cfg}_$i.json" 2> "$out/valu_${cfg}_$i.err"
+    done
 done
 cd "$root"
 python3 tools/summarize_profiles.py "$out"
