@@ -36,6 +36,31 @@ inline void mul(uint64_t* r, const uint64_t* a, const uint64_t* b, const uint64_
     for (int i = 0; i < 4; ++i) r[i] = t[i];
     if (t[4] || geq(r, P)) sub_mod(r, P);
 }
+// a * b as 8 limbs (no reduction), t += that, and the Montgomery reduction of 8 limbs: a dot product of k terms is k wide products and
+// ONE reduction (valid while the sum stays below 2^512 and the result below 2 P: up to 3 products of canonical BN254 elements)
+inline void mul_wide_acc(uint64_t t[8], const uint64_t* a, const uint64_t* b) {
+    u128 carry_out = 0;
+    for (int i = 0; i < 4; ++i) {
+        u128 c = 0;
+        for (int j = 0; j < 4; ++j) { c += (u128)a[j] * b[i] + t[i + j]; t[i + j] = (uint64_t)c; c >>= 64; }
+        for (int k = i + 4; k < 8 && c; ++k) { c += t[k]; t[k] = (uint64_t)c; c >>= 64; }
+        carry_out += c;
+    }
+    (void)carry_out;
+}
+inline void reduce_wide(uint64_t* r, uint64_t t[8], const uint64_t* P, uint64_t INV) {
+    uint64_t top = 0;
+    for (int i = 0; i < 4; ++i) {
+        const uint64_t m = t[i] * INV;
+        u128 c = 0;
+        for (int j = 0; j < 4; ++j) { c += (u128)m * P[j] + t[i + j]; t[i + j] = (uint64_t)c; c >>= 64; }
+        for (int k = i + 4; k < 8; ++k) { c += t[k]; t[k] = (uint64_t)c; c >>= 64; }
+        top += (uint64_t)c;
+    }
+    for (int i = 0; i < 4; ++i) r[i] = t[4 + i];
+    if (top || geq(r, P)) sub_mod(r, P);
+    if (geq(r, P)) sub_mod(r, P);
+}
 inline void add(uint64_t* r, const uint64_t* a, const uint64_t* b, const uint64_t* P) {
     u128 c = 0;
     for (int i = 0; i < 4; ++i) { c += (u128)a[i] + b[i]; r[i] = (uint64_t)c; c >>= 64; }
@@ -64,6 +89,16 @@ constexpr uint64_t ONE[4] = {0xd35d438dc58f0d9dull, 0x0a78eb28f5c70b3dull, 0x666
 inline HF hmul(const HF& a, const HF& b) { HF r; hostmont::mul(r.w, a.w, b.w, hostfr::P, hostfr::INV); return r; }
 inline HF hadd(const HF& a, const HF& b) { HF r; hostmont::add(r.w, a.w, b.w, hostfr::P); return r; }
 inline HF hsub(const HF& a, const HF& b) { HF r; hostmont::sub(r.w, a.w, b.w, hostfr::P); return r; }
+// a0 b0 + a1 b1 + a2 b2 with one reduction
+inline HF hdot3(const HF& a0, const HF& b0, const HF& a1, const HF& b1, const HF& a2, const HF& b2) {
+    uint64_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    hostmont::mul_wide_acc(t, a0.w, b0.w);
+    hostmont::mul_wide_acc(t, a1.w, b1.w);
+    hostmont::mul_wide_acc(t, a2.w, b2.w);
+    HF r;
+    hostmont::reduce_wide(r.w, t, hostfr::P, hostfr::INV);
+    return r;
+}
 inline HF hzero() { return HF{{0, 0, 0, 0}}; }
 inline HF hone() { return HF{{hostfr::ONE[0], hostfr::ONE[1], hostfr::ONE[2], hostfr::ONE[3]}}; }
 inline HF hf_from_abi(const uint64_t* p) {   // the ABI form is this form; callers' values are canonical, reduce anyway

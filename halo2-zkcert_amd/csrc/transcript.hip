@@ -299,21 +299,77 @@ struct PoseidonSpec {
         for (int i = 0; i < T; ++i) { g.raw(w); ys[i] = hf_from_canonical_words(w); }
         for (int i = 0; i < T; ++i)
             for (int j = 0; j < T; ++j) mds[i][j] = hf_invert(hadd(xs[i], ys[j]));
+        build_sparse();
+    }
+    // ---- the partial rounds in sparse form (the optimisation of the Poseidon paper's appendix, derived here directly):
+    // a partial round is x -> M S(x + c) with S the s-box on coordinate 0 only.  Write the running state as x_j = B_j z_j with
+    // B_j = diag(1, B^_j) (B_0 = I): then x_(j+1) = (M B_j) S(z_j + B_j^-1 c_j) because diag(1, .) commutes with S.  Factor
+    // A_j = M B_j = A'_j A''_j with A'_j = diag(1, A^_j) (A^_j = the lower-right block of A_j) and the SPARSE
+    // A''_j = [[A_00, v], [A^_j^-1 w, I]] (v = first row, w = first column of A_j below / right of A_00); z_(j+1) = A''_j S(z_j + c'_j),
+    // B_(j+1) = A'_j.  After the last partial round the dense B_RP is applied once.  Per partial round: one 3-term dot product and
+    // two multiply-adds instead of a dense 3 x 3 product.  permute() == permute_plain() is checked on the published vector and on
+    // random states (tests/test_schedule_cpu.py through zkhip_poseidon_permute).
+    HF sp_c[R_P][T];        // transformed constants c'_j
+    HF sp_row[R_P][T];      // (A_00, v_1, v_2)
+    HF sp_col[R_P][T - 1];  // A^_j^-1 w
+    HF sp_last[T - 1][T - 1];   // B^_RP
+    static void inv2(const HF m[2][2], HF o[2][2]) {
+        const HF det = hsub(hmul(m[0][0], m[1][1]), hmul(m[0][1], m[1][0]));
+        const HF di = hf_invert(det);
+        o[0][0] = hmul(m[1][1], di);
+        o[1][1] = hmul(m[0][0], di);
+        o[0][1] = hmul(hsub(hzero(), m[0][1]), di);
+        o[1][0] = hmul(hsub(hzero(), m[1][0]), di);
+    }
+    void build_sparse() {
+        static_assert(T == 3, "the sparse form below is written for t = 3");
+        HF B[2][2] = {{hone(), hzero()}, {hzero(), hone()}};
+        for (int j = 0; j < R_P; ++j) {
+            const HF* c = rc[R_F / 2 + j];
+            HF Bi[2][2];
+            inv2(B, Bi);
+            sp_c[j][0] = c[0];
+            for (int i = 0; i < 2; ++i) sp_c[j][1 + i] = hadd(hmul(Bi[i][0], c[1]), hmul(Bi[i][1], c[2]));
+            // A = M diag(1, B): first column = M's; A[r][1 + q] = sum_k M[r][1 + k] B[k][q]
+            HF A[3][3];
+            for (int r = 0; r < 3; ++r) {
+                A[r][0] = mds[r][0];
+                for (int q = 0; q < 2; ++q) A[r][1 + q] = hadd(hmul(mds[r][1], B[0][q]), hmul(mds[r][2], B[1][q]));
+            }
+            HF Ah[2][2] = {{A[1][1], A[1][2]}, {A[2][1], A[2][2]}}, Ahi[2][2];
+            inv2(Ah, Ahi);
+            sp_row[j][0] = A[0][0]; sp_row[j][1] = A[0][1]; sp_row[j][2] = A[0][2];
+            for (int i = 0; i < 2; ++i) sp_col[j][i] = hadd(hmul(Ahi[i][0], A[1][0]), hmul(Ahi[i][1], A[2][0]));
+            for (int i = 0; i < 2; ++i) for (int q = 0; q < 2; ++q) B[i][q] = Ah[i][q];
+        }
+        for (int i = 0; i < 2; ++i) for (int q = 0; q < 2; ++q) sp_last[i][q] = B[i][q];
     }
     static const PoseidonSpec& get() { static const PoseidonSpec s; return s; }
     static inline HF pow5(const HF& a) { HF a2 = hmul(a, a); return hmul(hmul(a2, a2), a); }
     void mix(HF s[T]) const {
         HF o[T];
-        for (int i = 0; i < T; ++i) {
-            o[i] = hmul(mds[i][0], s[0]);
-            for (int j = 1; j < T; ++j) o[i] = hadd(o[i], hmul(mds[i][j], s[j]));
-        }
+        for (int i = 0; i < T; ++i) o[i] = hdot3(mds[i][0], s[0], mds[i][1], s[1], mds[i][2], s[2]);
         for (int i = 0; i < T; ++i) s[i] = o[i];
+    }
+    void permute_plain(HF s[T]) const {   // the textbook form: every round a dense MDS product
+        int r = 0;
+        for (int f = 0; f < R_F / 2; ++f, ++r) { for (int i = 0; i < T; ++i) s[i] = pow5(hadd(s[i], rc[r][i])); mix(s); }
+        for (int p_ = 0; p_ < R_P; ++p_, ++r) { for (int i = 0; i < T; ++i) s[i] = hadd(s[i], rc[r][i]); s[0] = pow5(s[0]); mix(s); }
+        for (int f = 0; f < R_F / 2; ++f, ++r) { for (int i = 0; i < T; ++i) s[i] = pow5(hadd(s[i], rc[r][i])); mix(s); }
     }
     void permute(HF s[T]) const {
         int r = 0;
         for (int f = 0; f < R_F / 2; ++f, ++r) { for (int i = 0; i < T; ++i) s[i] = pow5(hadd(s[i], rc[r][i])); mix(s); }
-        for (int p_ = 0; p_ < R_P; ++p_, ++r) { for (int i = 0; i < T; ++i) s[i] = hadd(s[i], rc[r][i]); s[0] = pow5(s[0]); mix(s); }
+        for (int j = 0; j < R_P; ++j, ++r) {
+            const HF x0 = pow5(hadd(s[0], sp_c[j][0])), x1 = hadd(s[1], sp_c[j][1]), x2 = hadd(s[2], sp_c[j][2]);
+            s[0] = hdot3(sp_row[j][0], x0, sp_row[j][1], x1, sp_row[j][2], x2);
+            s[1] = hadd(hmul(sp_col[j][0], x0), x1);
+            s[2] = hadd(hmul(sp_col[j][1], x0), x2);
+        }
+        {
+            const HF y1 = hadd(hmul(sp_last[0][0], s[1]), hmul(sp_last[0][1], s[2])), y2 = hadd(hmul(sp_last[1][0], s[1]), hmul(sp_last[1][1], s[2]));
+            s[1] = y1; s[2] = y2;
+        }
         for (int f = 0; f < R_F / 2; ++f, ++r) { for (int i = 0; i < T; ++i) s[i] = pow5(hadd(s[i], rc[r][i])); mix(s); }
     }
 };
@@ -459,6 +515,12 @@ size_t zkhip_poseidon_transcript_challenges(const zkhip_poseidon_transcript* t, 
 }
 /* The bare permutation (state: 3 x 4 u64, ABI form, in place) and the generated parameters (rc: 65 x 3, mds: 3 x 3 row-major; ABI
  * form): exposed so that the generator can be checked against the published poseidonperm_x5_254_3 vector. */
+void zkhip_poseidon_permute_plain(uint64_t state[12]) {   // textbook rounds (dense MDS everywhere): the cross-check of the sparse form
+    HF s[3];
+    for (int i = 0; i < 3; ++i) s[i] = hf_from_abi(state + 4 * i);
+    PoseidonSpec::get().permute_plain(s);
+    for (int i = 0; i < 3; ++i) { fe32 o = hf_abi(s[i]); memcpy(state + 4 * i, o.w, 32); }
+}
 void zkhip_poseidon_permute(uint64_t state[12]) {
     HF s[3];
     for (int i = 0; i < 3; ++i) s[i] = hf_from_abi(state + 4 * i);

@@ -76,7 +76,7 @@ SYMBOLS = [
     "zkhip_evm_transcript_new", "zkhip_evm_transcript_free", "zkhip_evm_transcript_callbacks", "zkhip_evm_transcript_proof",
     "zkhip_evm_transcript_challenges", "zkhip_evm_transcript_points", "zkhip_keccak256",
     "zkhip_poseidon_transcript_new", "zkhip_poseidon_transcript_free", "zkhip_poseidon_transcript_callbacks", "zkhip_poseidon_transcript_proof",
-    "zkhip_poseidon_transcript_points", "zkhip_poseidon_transcript_challenges", "zkhip_poseidon_permute", "zkhip_poseidon_params",
+    "zkhip_poseidon_transcript_points", "zkhip_poseidon_transcript_challenges", "zkhip_poseidon_permute", "zkhip_poseidon_permute_plain", "zkhip_poseidon_params",
 ]
 
 
@@ -507,10 +507,10 @@ class PoseidonTranscript(LibTranscript):
         super().__init__("poseidon")
 
 
-def poseidon_permute(state_limbs):
-    """the bare Poseidon permutation on 3 ABI elements ((3, 4) uint64) -> (3, 4)"""
+def poseidon_permute(state_limbs, plain=False):
+    """the bare Poseidon permutation on 3 ABI elements ((3, 4) uint64) -> (3, 4); plain: textbook rounds instead of the sparse form"""
     st = _u64(state_limbs).reshape(3, 4).copy()
-    lib().zkhip_poseidon_permute(_p(st))
+    (lib().zkhip_poseidon_permute_plain if plain else lib().zkhip_poseidon_permute)(_p(st))
     return st
 
 

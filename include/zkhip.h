@@ -414,7 +414,8 @@ const zk_transcript* zkhip_poseidon_transcript_callbacks(zkhip_poseidon_transcri
 size_t zkhip_poseidon_transcript_proof(const zkhip_poseidon_transcript* t, const uint8_t** bytes);          /* -> length */
 size_t zkhip_poseidon_transcript_points(const zkhip_poseidon_transcript* t, const uint64_t** xy);           /* -> count; 8 u64 each */
 size_t zkhip_poseidon_transcript_challenges(const zkhip_poseidon_transcript* t, const uint64_t** limbs);    /* -> count; 4 u64 each (ABI) */
-void zkhip_poseidon_permute(uint64_t state[12]);               /* the bare permutation, 3 ABI elements in place */
+void zkhip_poseidon_permute(uint64_t state[12]);               /* the bare permutation, 3 ABI elements in place (partial rounds in sparse form) */
+void zkhip_poseidon_permute_plain(uint64_t state[12]);         /* the same by textbook rounds (dense MDS product in every round) */
 void zkhip_poseidon_params(uint64_t* rc, uint64_t* mds);       /* 65 x 3 round constants, 3 x 3 MDS (row-major), ABI form; either may be NULL */
 
 /* ---- synthetic tables (bench / tests): element i of a column = raw253(seed, i) taken as the
