@@ -73,3 +73,30 @@ def test_missing_library_is_an_error_not_a_fallback(built, monkeypatch, tmp_path
     monkeypatch.setattr(ffi, "LIB_PATH", str(tmp_path / "libzkhip.so"))
     with pytest.raises(ffi.ZkhipError, match="no CPU fallback"):
         ffi.lib()
+
+
+def test_rust_bindings_are_generated_from_the_header(built):
+    """integration/rust/zkhip-sys/src/lib.rs is tools/gen_rust_ffi.py's output for the current include/zkhip.h and declares every
+    exported function; the #[repr(C)] structs list the same fields in the same order as the ctypes structures the tests run on."""
+    import subprocess
+    import sys
+
+    ffi = built
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_rust_ffi.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rs = open(os.path.join(ROOT, "integration", "rust", "zkhip-sys", "src", "lib.rs")).read()
+    for s in ffi.SYMBOLS:
+        assert re.search(rf"\bpub fn {s}\(", rs), s
+    for rust_name, cls in (("zk_graph", ffi.ZkGraph), ("zk_evalh_args", ffi.ZkEvalhArgs), ("zk_transcript", ffi.ZkTranscript),
+                           ("zk_proving_key", ffi.ZkProvingKey), ("zk_proof_out", ffi.ZkProofOut), ("zk_blinding", ffi.ZkBlinding),
+                           ("zk_proof_inputs", ffi.ZkProofInputs)):
+        body = re.search(rf"pub struct {rust_name} \{{(.*?)\n\}}", rs, flags=re.S).group(1)
+        fields = re.findall(r"pub (\w+):", body)
+        assert fields == [f[0] for f in cls._fields_], rust_name
+    # and the same field lists appear, in order, in the C header
+    hdr = open(os.path.join(ROOT, "include", "zkhip.h")).read()
+    for cname, cls in (("zk_proof_inputs", ffi.ZkProofInputs), ("zk_blinding", ffi.ZkBlinding), ("zk_proof_out", ffi.ZkProofOut)):
+        body = re.search(rf"typedef struct {cname} \{{(.*?)\}} {cname};", hdr, flags=re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = re.findall(r"(\w+)\s*(?:\[\d*\])?\s*[;,]", body)
+        assert names == [f[0] for f in cls._fields_], cname

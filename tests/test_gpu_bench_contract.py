@@ -10,21 +10,44 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_prints_one_contract_line():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-other-configs"],
-                       capture_output=True, text=True, timeout=600, cwd=ROOT)
-    assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+def _run(args, env=None, timeout=900):
+    r = subprocess.run([sys.executable] + args, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 1
-    d = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def test_bench_prints_one_contract_line():
+    """the default headline (aggregation-shaped k = 22 under Keccak), one step, no other configurations"""
+    d = _run([os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-other-configs"])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-                "dtype", "data", "config", "roofline", "cpu_baseline"):
+                "dtype", "data", "config", "roofline", "cpu_baseline", "configs", "setup_s", "resident_bytes", "with_h2d", "build"):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is False and d["unit"] == "s"
     assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
-    assert abs(d["value"] * 1000.0 - d["ms_per_step"]) < 1e-3 and 0.002 < d["value"] < 0.1
+    assert d["config"]["headline"] == "agg22" and d["config"]["k"] == 22 and d["config"]["transcript"] == "evm"
+    assert abs(d["value"] * 1000.0 - d["ms_per_step"]) < 1e-3 and 0.05 < d["value"] < 1.0
     rf = d["roofline"]
     assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s") and rf["peak"] == 8000.0
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and rf["avg_launch_ms"] > 0 and rf["traffic"] > 0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and rf["avg_launch_ms"] > 0
+    assert rf["traffic"] is None or rf["traffic"] > 0          # quoted only when profiles/ holds a PMC pass of exactly this build
+    cfg = d["configs"]["agg22"]
+    assert set(cfg["rooflines"]) == {"msm_accum_affine", "ntt", "sweep"}
+    for r in cfg["rooflines"].values():
+        assert 0 < r["frac"] < 1 and r["avg_launch_ms"] > 0 and r["unit"] == "GB/s"
+    assert cfg["with_h2d"]["value"] > d["value"] * 0.9 and cfg["with_h2d"]["h2d_bytes"] == cfg["advice"] * (1 << 22) * 32
+    assert cfg["setup_s"] > 0 and cfg["resident_bytes"] > (6 << 30) and cfg["proof_bytes"] > 1000
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > d["value"] and cb["unit"] == "s" and cb["sample"]
+    assert cb["scale"] == 16.0 and abs(cb["value"] - cb["measured_s"] * 16.0) < 1e-2
+
+
+def test_bench_two_ranks_on_one_device():
+    """the N > 1 control flow of bench.py (one k = 18 proof sharded over 2 ranks through the library's communicator, host-staged
+    transport because both ranks share device 0): a strong-scaling line from rank 0"""
+    env = dict(os.environ, ZKHIP_BENCH_ONE_DEVICE="1", ZKHIP_BENCH_DIST_BACKEND="gloo")
+    d = _run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29577",
+              os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--agg-k", "18"], env=env)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["proofs_per_step"] == 1 and "sharded x2" in d["config"]["parallelism"]
+    assert d["cpu_baseline"] is None and d["value"] > 0

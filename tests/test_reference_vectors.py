@@ -1,0 +1,102 @@
+"""Reference-HELD vectors: tests/golden/reference_vectors.json is printed by integration/rust/refvec from the UNPATCHED crates the
+reference pins (halo2curves e185711, halo2_proofs 4b42325, snark-verifier-sdk 7011e8c) on a machine that has Rust.  No such machine was
+available to the build, so the file is absent and these tests skip; the day it is dropped in, they pin the oracle, the library's host
+code (encodings, transcripts) and — under -m gpu — the HIP kernels against outputs of the reference's own code."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.json")
+pytestmark = pytest.mark.skipif(not os.path.exists(PATH), reason="tests/golden/reference_vectors.json not generated yet (integration/rust/refvec)")
+H = lambda s: int(s, 16)
+
+
+def _load():
+    with open(PATH) as f:
+        return json.load(f)
+
+
+def _synth(zo, seed, n):
+    return zo.synth_raw253(seed, n)
+
+
+def test_constants_and_encodings(oracle):
+    import pyref as P
+
+    import halo2_zkcert_amd.ffi as ffi
+
+    zo = oracle
+    v = _load()["constants"]
+    assert H(v["zeta"]) == P.ZETA and H(v["delta"]) == P.DELTA and H(v["root_of_unity"]) == P.ROOT_OF_UNITY and v["s"] == P.S
+    g = zo.affine_from_ints([(1, 2)])[0]
+    assert ffi.g1_to_bytes(g).hex() == v["generator_compressed"]
+    assert ffi.g1_to_bytes(np.zeros(8, dtype=np.uint64)).hex() == v["identity_compressed"]
+    neg = zo.affine_from_ints([(1, P.P - 2)])[0]
+    assert ffi.g1_to_bytes(neg).hex() == v["neg_g_compressed"]
+    two = zo.g1_to_affine(zo.g1_mul_gen(zo.fr_from_int(2)))
+    assert ffi.g1_to_bytes(two).hex() == v["two_g"]["compressed"] and zo.g1_to_bytes(two).hex() == v["two_g"]["compressed"]
+
+
+def test_transcripts(oracle):
+    import halo2_zkcert_amd.ffi as ffi
+    import halo2_zkcert_amd.prover as pv
+
+    zo = oracle
+    v = _load()["transcripts"]
+    p1 = zo.g1_to_affine(zo.g1_mul_gen(zo.fr_from_int(5)))
+    for kind in ("blake2b", "poseidon", "evm"):
+        t = ffi.LibTranscript(kind)
+        t.common_scalar(zo.fr_from_int(7))
+        t.write_point(p1)
+        t.write_scalar(zo.fr_from_int(0x1234567890ABCDEF))
+        c1, c2 = pv.from_mont_host(t.squeeze_limbs()), pv.from_mont_host(t.squeeze_limbs())
+        assert (c1, c2) == (H(v[kind]["c1"]), H(v[kind]["c2"])), kind
+        assert t.proof().hex() == v[kind]["proof"], kind
+
+
+def test_oracle_msm_fft_domain(oracle):
+    zo = oracle
+    v = _load()
+    for c in v["msm"]:
+        n = 1 << c["k"]
+        mono, _ = zo.kzg_setup_scalars(c["k"], zo.fr_from_int(H(c["srs_trapdoor"])))
+        bases = zo.fixed_base_mul(mono, 4)
+        s = zo.g1_to_affine(zo.best_multiexp(_synth(zo, c["seed"], n), bases, 4))
+        assert zo.g1_to_bytes(s).hex() == c["sum"]["compressed"]
+    for c in v["fft"]:
+        n = 1 << c["k"]
+        a = zo.best_fft(_synth(zo, c["seed"], n), zo.fr_from_int(H(c["omega"])), c["k"], 4)
+        ints = zo.fr_arr_to_ints(a)
+        assert (ints[0], ints[1], ints[-1]) == (H(c["first"]), H(c["second"]), H(c["last"]))
+        if c["all"]:
+            assert ints == [H(x) for x in c["all"]]
+    d = v["domain"]
+    dom = zo.Domain(d["j"], d["k"])
+    assert dom.extended_k == d["extended_k"]
+    coeff = dom.lagrange_to_coeff(_synth(zo, d["seed"], 1 << d["k"]), 4)
+    assert zo.fr_arr_to_ints(coeff) == [H(x) for x in d["coeff"]]
+    assert zo.fr_arr_to_ints(dom.coeff_to_extended(coeff, 4)) == [H(x) for x in d["extended"]]
+
+
+@pytest.mark.gpu
+def test_hip_msm_fft_domain(zk, oracle):
+    ffi, ctx = zk
+    zo = oracle
+    v = _load()
+    for c in v["msm"]:
+        n = 1 << c["k"]
+        p = ffi.ParamsKZG.setup(ctx, c["k"], zo.fr_from_int(H(c["srs_trapdoor"])))
+        s = ffi.g1_to_affine(p.commit(_synth(zo, c["seed"], n)))
+        assert ffi.g1_to_bytes(s).hex() == c["sum"]["compressed"]
+        p.free()
+    for c in v["fft"]:
+        a = ctx.best_fft(_synth(zo, c["seed"], 1 << c["k"]), zo.fr_from_int(H(c["omega"])), c["k"])
+        ints = zo.fr_arr_to_ints(a)
+        assert (ints[0], ints[1], ints[-1]) == (H(c["first"]), H(c["second"]), H(c["last"]))
+    d = v["domain"]
+    dom = ffi.EvaluationDomain(ctx, d["j"], d["k"])
+    coeff = dom.lagrange_to_coeff(_synth(zo, d["seed"], 1 << d["k"]))
+    assert zo.fr_arr_to_ints(coeff) == [H(x) for x in d["coeff"]]
+    assert zo.fr_arr_to_ints(dom.coeff_to_extended(coeff)) == [H(x) for x in d["extended"]]
