@@ -51,6 +51,7 @@ struct zkhip_options {
     int ntt_smax = 0, ntt_r8 = 1, ntt_group = 0;
     int permute_rank_sort = 1, eval_byval = 1, late_overlap = -1;
     int graphs = 1;
+    int host_timing = 0;   // zkhip_create_proof prints its host-side phase times to stderr
 };
 
 // Multi-GPU state of a context (comm.hip): rank / size, the RCCL communicator with its own stream (or the host-staged transport),

@@ -10,6 +10,7 @@
 // Everything here is host orchestration (no kernels): the point of having it in the library is that a proof of 2^17 rows is
 // ~9 ms of GPU work, and an interpreted host adds a millisecond of gaps between ~250 launches.
 // halo2-zkcert_amd/prover.py is the same schedule in Python over the small entry points (and the form the oracle backend runs).
+#include <chrono>
 #include <vector>
 
 #include "common.hpp"
@@ -77,6 +78,12 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
     }
     const uint64_t blinding_seed = in->blinding_seed;
     const zk_blinding* bl = in->blinding;
+    // host-side phase clock (ZKHIP_HOST_TIMING=1): where the host spends the time between the launches of a proof
+    struct Mark { const char* what; std::chrono::steady_clock::time_point t; };
+    std::vector<Mark> marks;
+    const bool timing = ctx->opt.host_timing != 0;
+    auto mark = [&](const char* what) { if (timing) marks.push_back({what, std::chrono::steady_clock::now()}); };
+    mark("start");
     if (!pk->g || !pk->g_lagrange || !pk->domain) { set_error("zkhip_create_proof: proving key without SRS / domain"); return ZKHIP_EINVAL; }
     const uint32_t k = pk->k, bf = pk->blinding_factors;
     const size_t n = (size_t)1 << k;
@@ -213,13 +220,7 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
     } else {
         ZK_TRY(zkhip_synth_fill_device(ctx, w_rand, n, blinding_seed + 380, 0));
     }
-    // vk.hash_into(transcript), then every instance value (KZG: hashed, not committed) — upstream's first transcript operations
-    if (tr->common_scalar) {
-        if (pk->vk_transcript_repr) tr->common_scalar(tr->user, pk->vk_transcript_repr);
-        if (in->instance_values)
-            for (uint32_t j = 0; j < I; ++j)
-                for (uint32_t i = 0; i < in->instance_len[j]; ++i) tr->common_scalar(tr->user, in->instance_values[j] + 4 * i);
-    }
+
     std::vector<void*> coeff_ptrs(A + I), ext_ptrs(A + I);
     for (uint32_t j = 0; j < A + I; ++j) { coeff_ptrs[j] = w_coeff + j * NB; ext_ptrs[j] = w_ext + j * EB; }
     std::vector<uint64_t> rand_xy;
@@ -239,9 +240,21 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
             ZK_TRY(to_extended((const void* const*)coeff_ptrs.data(), ext_ptrs.data(), A + I));
         }
         ov.end();
+        // vk.hash_into(transcript), then every instance value (KZG: hashed, not committed) — upstream's first transcript operations.
+        // Nothing has entered the transcript yet, so they are absorbed HERE, while the GPU works on the advice commitments (a sponge
+        // transcript such as Poseidon spends ~10 us per absorbed pair: 32 instance values would otherwise sit on the critical path).
+        if (tr->common_scalar) {
+            if (pk->vk_transcript_repr) tr->common_scalar(tr->user, pk->vk_transcript_repr);
+            if (in->instance_values)
+                for (uint32_t j = 0; j < I; ++j)
+                    for (uint32_t i = 0; i < in->instance_len[j]; ++i) tr->common_scalar(tr->user, in->instance_values[j] + 4 * i);
+        }
+        mark("vk + instances absorbed (GPU busy)");
         ZK_TRY(commit_read(cols.size(), 1, &rand_xy, &rand_by));
     }
+    mark("advice committed + absorbed");
     tr->squeeze_challenge(tr->user, ch);
+    mark("theta");
     uint64_t theta[4];
     memcpy(theta, ch, 32);
 
@@ -304,9 +317,11 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
         if (*h_err) { set_error("permute_expression_pair: an input value is not in the table (ConstraintSystemFailure)"); return ZKHIP_ECONSTRAINT; }
         for (size_t j = 0; j < cols.size(); ++j) tr->write_point(tr->user, by.data() + 32 * j, xy.data() + 8 * j);
     }
+    mark("permuted committed + absorbed");
     uint64_t beta[4], gamma[4];
     tr->squeeze_challenge(tr->user, beta);
     tr->squeeze_challenge(tr->user, gamma);
+    mark("beta gamma");
 
     // ---- 3. grand products: permutation sets, then lookups; commitments in coefficient form
     std::vector<void*> z_ptrs(Zp + L), ext_z(Zp + L);   // [perm sets..., lookups...]
@@ -344,9 +359,11 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
         ZK_TRY(commit_read(cols.size(), 0, nullptr, nullptr));
     }
     // ---- 4. the random polynomial enters the transcript here
+    mark("products committed + absorbed");
     tr->write_point(tr->user, rand_by.data(), rand_xy.data());
     uint64_t y[4];
     tr->squeeze_challenge(tr->user, y);
+    mark("y");
 
     // ---- 5. quotient: sweep over the extended coset, division by the vanishing polynomial, back to coefficients, pieces
     ZK_TRY(ov.join());
@@ -390,7 +407,9 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
         std::vector<const zkhip_srs*> bases(qd, pk->g);
         ZK_TRY(commit(pieces, bases, 0, nullptr, nullptr));
     }
+    mark("quotient committed + absorbed");
     tr->squeeze_challenge(tr->user, ch);
+    mark("x");
     const HF x = hf_from_abi(ch);
 
     // ---- 5b. evaluations at x * omega^rotation in upstream's query order; h(X) = sum_i x^(n i) h_i(X)
@@ -471,7 +490,9 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
             ZK_TRY(zkhip_memcpy_d2h(ctx, q_evals.data(), w_evals, nq * 32));
         }
     }
+    mark("evaluations read back");
     for (uint32_t i : w_order) tr->write_scalar(tr->user, q_evals.data() + 4 * (size_t)i);   // h(x) is not written: the verifier recomputes it
+    mark("evaluations absorbed");
     if (out) {
         out->d_h = w_h;
         out->n_evals = nq;
@@ -483,5 +504,11 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
     // ---- 6. SHPLONK multi-open of all of them
     uint64_t h1[8], h2[8];
     ZK_TRY(zkhip_shplonk_open(ctx, pk->g, n, polys.data(), polys.size(), q_poly.data(), q_points.data(), q_evals.data(), nq, tr, h1, h2));
+    mark("shplonk done");
+    if (timing) {
+        for (size_t i = 1; i < marks.size(); ++i)
+            fprintf(stderr, "  %8.1f us  (+%7.1f)  %s\n", std::chrono::duration<double, std::micro>(marks[i].t - marks[0].t).count(),
+                    std::chrono::duration<double, std::micro>(marks[i].t - marks[i - 1].t).count(), marks[i].what);
+    }
     return ZKHIP_OK;
 }

@@ -378,10 +378,24 @@ struct PoseidonSpec {
 struct zkhip_poseidon_transcript {
     zk_transcript cb;
     HF state[3];
-    std::vector<HF> buf;
+    // upstream buffers everything absorbed since the last squeeze and permutes chunk by chunk inside squeeze(); the same chunks in
+    // the same order are permuted here as soon as they are complete, so that elements absorbed while the GPU is busy (the
+    // verifying key, the instance values) cost nothing at the next Fiat-Shamir point.  `pending` holds < RATE elements.
+    HF pending[2];
+    size_t n_pending = 0;
+    void absorb(const HF& e);
     std::vector<uint8_t> proof;
     std::vector<uint64_t> points_xy, challenges;
 };
+
+void zkhip_poseidon_transcript::absorb(const HF& e) {
+    pending[n_pending++] = e;
+    if (n_pending == (size_t)PoseidonSpec::RATE) {   // a full chunk: state[1 + i] += chunk[i], permute
+        for (int i = 0; i < PoseidonSpec::RATE; ++i) state[1 + i] = hadd(state[1 + i], pending[i]);
+        n_pending = 0;
+        PoseidonSpec::get().permute(state);
+    }
+}
 
 namespace {
 inline HF fq_coordinate_in_fr(const uint64_t* mont_fq) {   // fe_to_fe: the integer value of an Fq element, reduced mod r
@@ -389,8 +403,8 @@ inline HF fq_coordinate_in_fr(const uint64_t* mont_fq) {   // fe_to_fe: the inte
     return hf_from_canonical_words(c.w);
 }
 void p_absorb_point(zkhip_poseidon_transcript* t, const uint64_t xy[8]) {
-    t->buf.push_back(fq_coordinate_in_fr(xy));
-    t->buf.push_back(fq_coordinate_in_fr(xy + 4));
+    t->absorb(fq_coordinate_in_fr(xy));
+    t->absorb(fq_coordinate_in_fr(xy + 4));
 }
 void p_write_point(void* user, const uint8_t bytes32[32], const uint64_t xy[8]) {
     auto* t = (zkhip_poseidon_transcript*)user;
@@ -400,11 +414,11 @@ void p_write_point(void* user, const uint8_t bytes32[32], const uint64_t xy[8]) 
 }
 void p_common_scalar(void* user, const uint64_t scalar[4]) {
     auto* t = (zkhip_poseidon_transcript*)user;
-    t->buf.push_back(hf_from_abi(scalar));
+    t->absorb(hf_from_abi(scalar));
 }
 void p_write_scalar(void* user, const uint64_t scalar[4]) {
     auto* t = (zkhip_poseidon_transcript*)user;
-    t->buf.push_back(hf_from_abi(scalar));
+    t->absorb(hf_from_abi(scalar));
     fe32 s = abi_to_canonical_words<Fr>(mem_load(scalar));
     const uint8_t* b = (const uint8_t*)s.w;
     t->proof.insert(t->proof.end(), b, b + 32);
@@ -412,17 +426,12 @@ void p_write_scalar(void* user, const uint64_t scalar[4]) {
 void p_squeeze(void* user, uint64_t out[4]) {
     auto* t = (zkhip_poseidon_transcript*)user;
     const PoseidonSpec& sp = PoseidonSpec::get();
-    constexpr size_t RATE = PoseidonSpec::RATE;
-    const size_t len = t->buf.size();
-    const bool exact = len % RATE == 0;
-    for (size_t off = 0; off < len; off += RATE) {
-        const size_t m = std::min(RATE, len - off);
-        for (size_t i = 0; i < m; ++i) t->state[1 + i] = hadd(t->state[1 + i], t->buf[off + i]);
-        if (m < RATE) t->state[m + 1] = hadd(t->state[m + 1], hone());
-        sp.permute(t->state);
-    }
-    if (exact) { t->state[1] = hadd(t->state[1], hone()); sp.permute(t->state); }
-    t->buf.clear();
+    // the last chunk: the pending elements (a short chunk adds 1 at position len + 1); an empty one exactly when the absorbed length
+    // was a multiple of RATE (upstream's `exact`)
+    for (size_t i = 0; i < t->n_pending; ++i) t->state[1 + i] = hadd(t->state[1 + i], t->pending[i]);
+    t->state[t->n_pending + 1] = hadd(t->state[t->n_pending + 1], hone());
+    t->n_pending = 0;
+    sp.permute(t->state);
     fe32 abi = hf_abi(t->state[1]);
     memcpy(out, abi.w, 32);
     t->challenges.insert(t->challenges.end(), out, out + 4);
@@ -489,6 +498,7 @@ zkhip_poseidon_transcript* zkhip_poseidon_transcript_new(void) {
     t->state[0] = HF{{0, 1, 0, 0}};                       // 2^64 as an integer ...
     t->state[0] = hmul(t->state[0], hf_from_abi(HF{{0x1bb8e645ae216da7ull, 0x53fe3ab1e35c59e3ull, 0x8c49833d53bb8085ull, 0x0216d0b17f4e44a5ull}}.w));   // ... into Montgomery form (x R^2 / R)
     t->state[1] = t->state[2] = hzero();
+    t->n_pending = 0;
     t->cb.user = t;
     t->cb.write_point = p_write_point;
     t->cb.squeeze_challenge = p_squeeze;
