@@ -74,15 +74,18 @@ __global__ void k_fold_partials(const uint32_t* parts, uint32_t nranks, uint32_t
 }  // namespace
 
 namespace zk {
-// recv holds nranks blocks of `bytes`; rank r's block is at r * bytes; d_send may be that block itself (in place)
-int comm_allgather(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t bytes) {
+// recv holds nranks blocks of `bytes`; rank r's block is at r * bytes; d_send may be that block itself (in place).
+// comm_allgather_begin enqueues the exchange behind everything already issued on the calling stream and returns; the calling stream
+// does NOT wait for it (it may go on producing the next block: the coset NTT of round t + 1 overlaps the all-gather of round t);
+// comm_allgather_end makes the calling stream wait for every exchange begun so far.  comm_allgather = begin + end.
+int comm_allgather_begin(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t bytes) {
     zkhip_comm& cm = ctx->comm;
     if (!cm.nccl && !cm.host_allgather) {   // no communicator: a single rank
         if (d_send != d_recv) ZK_HIP(hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, ctx->stream));
         return ZKHIP_OK;
     }
     if (cm.host_allgather) {
-        // host-staged: D2H of this rank's block, the caller's all-gather over host memory, H2D of the whole buffer
+        // host-staged (synchronous): D2H of this rank's block, the caller's all-gather over host memory, H2D of the whole buffer
         const size_t total = bytes * (size_t)cm.nranks;
         if (cm.stage_bytes < total + bytes) {
             if (cm.stage) (void)hipHostFree(cm.stage);
@@ -98,17 +101,26 @@ int comm_allgather(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t byte
         if (rc != 0) { set_error("zkhip_comm: the host all-gather callback returned %d", rc); return ZKHIP_EHIP; }
         ZK_HIP(hipMemcpyAsync(d_recv, cm.stage, total, hipMemcpyHostToDevice, ctx->stream));
         ZK_HIP(hipStreamSynchronize(ctx->stream));   // the staging buffer is reused by the next call
+        cm.bytes_gathered += bytes * (size_t)(cm.nranks - 1);
         return ZKHIP_OK;
     }
     ncclComm_t c = (ncclComm_t)cm.nccl;
-    if (!c) { set_error("zkhip_comm: no communicator"); return ZKHIP_EINVAL; }
     ZK_HIP(hipEventRecord(cm.ev_in, ctx->stream));            // the data is produced on the calling stream ...
     ZK_HIP(hipStreamWaitEvent(cm.stream, cm.ev_in, 0));
     ZK_NCCL(g_rccl.AllGather(d_send, d_recv, bytes, ncclInt8, c, cm.stream));
-    ZK_HIP(hipEventRecord(cm.ev_out, cm.stream));             // ... and consumed there
-    ZK_HIP(hipStreamWaitEvent(ctx->stream, cm.ev_out, 0));
     cm.bytes_gathered += bytes * (size_t)(cm.nranks - 1);
     return ZKHIP_OK;
+}
+int comm_allgather_end(zkhip_ctx* ctx) {
+    zkhip_comm& cm = ctx->comm;
+    if (!cm.nccl) return ZKHIP_OK;
+    ZK_HIP(hipEventRecord(cm.ev_out, cm.stream));             // ... and consumed there
+    ZK_HIP(hipStreamWaitEvent(ctx->stream, cm.ev_out, 0));
+    return ZKHIP_OK;
+}
+int comm_allgather(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t bytes) {
+    ZK_TRY(comm_allgather_begin(ctx, d_send, d_recv, bytes));
+    return comm_allgather_end(ctx);
 }
 
 // the partial sums of a point-range-sharded batch of MSMs -> the sums, on every rank (d_out may be pinned host memory)

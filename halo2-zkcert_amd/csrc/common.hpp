@@ -155,6 +155,8 @@ static inline hipError_t event_wait(hipEvent_t ev) {
 struct zkhip_domain;
 namespace zk {
 int comm_allgather(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t bytes);
+int comm_allgather_begin(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t bytes);
+int comm_allgather_end(zkhip_ctx* ctx);
 int comm_fold_partials(zkhip_ctx* ctx, const void* d_part, size_t ncols, void* d_out);
 int lagrange_to_coeff_oop(zkhip_ctx* ctx, const zkhip_domain* d, const void* const* srcs, void* const* dsts, size_t npolys);
 int permute_expression_pair_async(zkhip_ctx* ctx, uint32_t k, uint32_t blinding_factors, const void* d_input, const void* d_table,

@@ -179,14 +179,19 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
     // coeff_to_extended of `count` polynomials whose outputs are consecutive EB-sized slices of one padded workspace block
     auto to_extended = [&](const void* const* srcs, void* const* dsts, size_t count) -> int {
         if (!dist) return zkhip_coeff_to_extended_device(ctx, pk->domain, srcs, n, dsts, count);
-        std::vector<const void*> ms;
-        std::vector<void*> md;
-        for (size_t j = RK; j < count; j += NR) { ms.push_back(srcs[j]); md.push_back(dsts[j]); }
-        if (!ms.empty()) ZK_TRY(zkhip_coeff_to_extended_device(ctx, pk->domain, ms.data(), n, md.data(), ms.size()));
+        // by polynomial, pipelined: rank RK transforms column t NR + RK of round t, then the round's NR columns are all-gathered in
+        // place on the communicator's stream while this stream already transforms the rank's column of round t + 1
         for (size_t t = 0; t * NR < count; ++t) {
+            const size_t j = t * NR + RK;
+            if (j < count) {
+                const void* s1[1] = {srcs[j]};
+                void* d1[1] = {dsts[j]};
+                ZK_TRY(zkhip_coeff_to_extended_device(ctx, pk->domain, s1, n, d1, 1));
+            }
             char* block = (char*)dsts[t * NR];
-            ZK_TRY(zk::comm_allgather(ctx, block + RK * EB, block, EB));
+            ZK_TRY(zk::comm_allgather_begin(ctx, block + RK * EB, block, EB));
         }
+        ZK_TRY(zk::comm_allgather_end(ctx));
         return ZKHIP_OK;
     };
 
