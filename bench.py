@@ -138,6 +138,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="time the headline configuration only")
     ap.add_argument("--other-steps", type=int, default=10)
+    ap.add_argument("--shard", default="auto", choices=["auto", "points", "columns"],
+                    help="N > 1: how the MSMs of the sharded proof are split — by point range with 1/N of the window tables per rank (auto: "
+                         "k >= 20), or by column with whole tables on every rank (auto: k <= 19, where one MSM cannot fill several GPUs)")
     ap.add_argument("--replicas", action="store_true", help="N > 1: N independent proofs, one per GPU (weak scaling) instead of one sharded proof")
     ap.add_argument("--chain", action="store_true", help="N >= 4: BASELINE configs[4] — 2 x RSA + 2 x SHA leaf proofs on 4 ranks, then the sharded aggregation proof")
     ap.add_argument("--python-schedule", action="store_true", help="drive the proof from prover.py over the small entry points (same proof bytes)")
@@ -183,6 +186,10 @@ def main():
         """-> result dict for one configuration (collective: every rank calls it with the same arguments)"""
         shape = make_shape(pv, name, args)
         kind = TRANSCRIPT[name]
+        shard_mode = None
+        if shard:
+            shard_mode = args.shard if args.shard != "auto" else ("points" if shape.k >= 20 else "columns")
+            ctx.comm_shard(shard_mode)
         torch.cuda.empty_cache()
         free0 = torch.cuda.mem_get_info()[0]
         t0 = time.perf_counter()
@@ -317,7 +324,7 @@ def main():
                "k": shape.k, "advice": shape.n_advice, "fixed": shape.n_fixed, "instance_values": prover.n_instance_values, "lookups": len(shape.lookups),
                "perm_columns": len(shape.perm_columns), "degree": shape.degree, "transcript": kind, "proof_bytes": len(trace.get("proof", b"")),
                "setup_s": round(setup_s, 3), "resident_bytes": int(resident), "rooflines": roof, "kernels_ms_per_step": kernels,
-               "traffic_source": traffic_file, "with_h2d": h2d}
+               "traffic_source": traffic_file, "with_h2d": h2d, "msm_shard": shard_mode}
         backend.params.free()
         del prover, wit, trace, backend
         return res, shape
@@ -337,6 +344,8 @@ def main():
             sh_ = make_shape(pv, nm, args)
             pr_ = pv.Prover(pv.GpuBackend(leaf_ctx, ffi), sh_, satisfiable=True)
             leaves.append((pr_, pr_.witness(j if world == 1 else rank), TRANSCRIPT[nm]))
+        if shard:
+            ctx.comm_shard("points" if args.shard == "auto" else args.shard)
         agg = pv.Prover(pv.GpuBackend(ctx, ffi), make_shape(pv, "agg22", args), satisfiable=True)
         agg_w = agg.witness(0)
 
@@ -395,7 +404,7 @@ def main():
             "config": {"workload": head["workload"], "headline": args.config, "k": head["k"], "advice": head["advice"], "fixed": head["fixed"],
                        "lookups": head["lookups"], "perm_columns": head["perm_columns"], "degree": head["degree"], "transcript": head["transcript"],
                        "host": "prover.py (Python schedule over the C ABI)" if args.python_schedule else "zkhip_create_proof_ex (schedule and transcript in the library)",
-                       "parallelism": "1 GPU" if world == 1 else (f"one proof sharded x{world}: MSMs by point range (window tables 1/{world} per rank), coset NTTs by polynomial, sweep by row range; ncclAllGather of partial sums / columns / h inside the library" if shard
+                       "parallelism": "1 GPU" if world == 1 else (f"one proof sharded x{world}: MSMs by {'point range (window tables 1/' + str(world) + ' per rank)' if head.get('msm_shard') == 'points' else 'column (whole tables on every rank)'}, coset NTTs by polynomial, sweep by row range; ncclAllGather of partial sums / columns / h inside the library" if shard
                                                                    else f"{world} independent proofs, one per GPU, no collective")},
             "roofline": {k_: dom[k_] for k_ in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms", "note")},
             "int_roofline": dict(kernel="k_accum_affine", **dom["int_roofline"]),

@@ -188,6 +188,12 @@ int zkhip_comm_destroy(zkhip_ctx* ctx) {
     return ZKHIP_OK;
 }
 
+int zkhip_comm_shard_columns(zkhip_ctx* ctx, int on) {
+    if (!ctx) { set_error("null ctx"); return ZKHIP_EINVAL; }
+    ctx->comm.shard_columns = on != 0;
+    return ZKHIP_OK;
+}
+
 int zkhip_comm_info(const zkhip_ctx* ctx, int* rank, int* nranks, uint64_t* bytes_gathered) {
     if (!ctx) { set_error("null ctx"); return ZKHIP_EINVAL; }
     if (rank) *rank = ctx->comm.rank;

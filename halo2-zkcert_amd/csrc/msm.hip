@@ -1182,6 +1182,26 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
         sharded |= q->n_total != q->n;
     }
     if (first + n > srs->n_total) { set_error("zkhip_msm: range [%zu, %zu) exceeds the %zu bases of the SRS", first, first + n, srs->n_total); return ZKHIP_EINVAL; }
+    if (!sharded && ctx->comm.nranks > 1 && ctx->comm.shard_columns) {
+        // whole-SRS handles on a context with a communicator: the batch is split by COLUMN (independent commitments
+        // round-robin over the GPUs — the better split while one MSM cannot fill several GPUs, k <= 19).  Rank r computes columns
+        // r, r + N, ... completely; the other columns of its partial vector are the identity, so the same all-gather + fold applies.
+        const size_t NR = (size_t)ctx->comm.nranks, RK = (size_t)ctx->comm.rank;
+        void *d_part, *d_mine;
+        ZK_TRY(ctx->get_scratch("msm_shard_part", ncols * 96, &d_part));
+        ZK_TRY(ctx->get_scratch("msm_shard_mine", ncols * 96, &d_mine));
+        std::vector<const zkhip_srs*> my_srs;
+        std::vector<const void*> my_cols;
+        for (size_t j = RK; j < ncols; j += NR) { my_srs.push_back(srs_per_col[j]); my_cols.push_back(d_cols_host[j]); }
+        hipLaunchKernelGGL(k_set_identity, dim3(div_up(ncols, 64)), dim3(64), 0, ctx->stream, (uint32_t*)d_part, (uint32_t)ncols);
+        ZK_LAUNCH_CHECK();
+        if (!my_cols.empty()) {
+            ZK_TRY(msm_local(ctx, my_srs.data(), my_cols.data(), my_cols.size(), first, n, d_mine));
+            for (size_t i = 0, j = RK; j < ncols; ++i, j += NR)
+                ZK_HIP(hipMemcpyAsync((char*)d_part + j * 96, (const char*)d_mine + i * 96, 96, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        return zk::comm_fold_partials(ctx, d_part, ncols, d_out);
+    }
     if (!sharded) return msm_local(ctx, srs_per_col, d_cols_host, ncols, first, n, d_out);
     const size_t lo = std::max(first, srs->first0), hi = std::min(first + n, srs->first0 + srs->n);
     const size_t cnt = hi > lo ? hi - lo : 0;

@@ -435,7 +435,7 @@ extern "C" int zkhip_evaluate_h_rows_device(zkhip_ctx* ctx, const zk_evalh_args*
 }
 static int evaluate_h_rows(zkhip_ctx* ctx, const zk_evalh_args* A, size_t first_row, size_t n_rows, void* d_out) {
     if (!ctx || !A || !d_out) { set_error("zkhip_evaluate_h_device: null argument"); return ZKHIP_EINVAL; }
-    if (A->extended_k < A->k || A->extended_k > 26 || A->extended_k < 6) { set_error("zkhip_evaluate_h_device: extended_k = %u unsupported (6..26)", A->extended_k); return ZKHIP_EINVAL; }
+    if (A->extended_k < A->k || A->extended_k > 26 || A->extended_k < 2) { set_error("zkhip_evaluate_h_device: extended_k = %u unsupported (2..26)", A->extended_k); return ZKHIP_EINVAL; }
     if (A->n_perm_sets && A->cs_degree < 3) { set_error("zkhip_evaluate_h_device: cs_degree < 3 with a permutation argument"); return ZKHIP_EINVAL; }
     if (A->n_fixed + A->n_advice + A->n_instance > 0x3fff) { set_error("zkhip_evaluate_h_device: too many columns"); return ZKHIP_EINVAL; }
     Lowering L;
@@ -526,8 +526,9 @@ static int evaluate_h_rows(zkhip_ctx* ctx, const zk_evalh_args* A, size_t first_
         P.xt_hi = (const uint32_t*)xt->d_hi;
         P.xt_h = xt->h;
     }
-    const unsigned block = n_rows % 128 == 0 ? 128 : 64;
-    if (first_row + n_rows > isize || n_rows == 0 || n_rows % 64) {
+    // one thread per row; domains below 64 rows (k = 4, 5 circuits: the lookup compression runs on 2^k rows) take one partial wave
+    const unsigned block = n_rows % 128 == 0 ? 128 : (n_rows % 64 == 0 ? 64 : (unsigned)n_rows);
+    if (first_row + n_rows > isize || n_rows == 0 || (n_rows % 64 && n_rows > 64)) {
         set_error("zkhip_evaluate_h_rows_device: rows [%zu, %zu) out of the extended domain or not a multiple of 64", first_row, first_row + n_rows);
         return ZKHIP_EINVAL;
     }

@@ -54,7 +54,7 @@ class ZkEvalhArgs(C.Structure):
 # every symbol include/zkhip.h declares (checked by tests/test_abi.py without a GPU)
 SYMBOLS = [
     "zkhip_init", "zkhip_destroy", "zkhip_last_error", "zkhip_set_stream", "zkhip_synchronize", "zkhip_set_option", "zkhip_trim",
-    "zkhip_comm_unique_id", "zkhip_comm_init", "zkhip_comm_init_host", "zkhip_comm_destroy", "zkhip_comm_info", "zkhip_comm_allgather_device",
+    "zkhip_comm_unique_id", "zkhip_comm_init", "zkhip_comm_init_host", "zkhip_comm_destroy", "zkhip_comm_info", "zkhip_comm_allgather_device", "zkhip_comm_shard_columns",
     "zkhip_kzg_setup_range", "zkhip_srs_load_range", "zkhip_srs_range", "zkhip_malloc", "zkhip_free",
     "zkhip_memcpy_h2d", "zkhip_memcpy_d2h", "zkhip_timer_start", "zkhip_timer_stop_ms",
     "zkhip_profile_enable", "zkhip_profile_select", "zkhip_profile_read", "zkhip_profile_counter",
@@ -223,6 +223,16 @@ class Context:
         else:
             raise ValueError(transport)
         self.rank, self.world, self.transport = rank, world, transport
+
+    shard_points = True      # ParamsKZG.setup / .read on a context with a communicator: point-range shards (True) or whole tables
+
+    def comm_shard(self, mode):
+        """how the MSMs of a proof are split over the ranks: "points" — every rank holds 1/N of the window tables and sums its point
+        range of every column (large k); "columns" — every rank holds the whole tables and commits columns r, r + N, ... (k <= 19)"""
+        if mode not in ("points", "columns"):
+            raise ValueError(mode)
+        self.shard_points = mode == "points"
+        _check(lib().zkhip_comm_shard_columns(self.h, C.c_int(0 if self.shard_points else 1)))
 
     def comm_destroy(self):
         _check(lib().zkhip_comm_destroy(self.h))
@@ -643,7 +653,7 @@ class ParamsKZG:
     def setup(cls, ctx, k, s):
         """ParamsKZG::setup(k, rng) with the trapdoor given (Montgomery Fr limbs)."""
         g, gl = C.c_void_p(), C.c_void_p()
-        if ctx.world > 1:      # a communicator on the context: this rank builds the window tables of its point range only
+        if ctx.world > 1 and ctx.shard_points:      # a communicator on the context: this rank builds the window tables of its point range only
             first, count = ctx.shard_range(1 << k)
             _check(lib().zkhip_kzg_setup_range(ctx.h, C.c_uint32(k), _p(_u64(s)), C.c_size_t(first), C.c_size_t(count), C.byref(g), C.byref(gl)))
         else:
@@ -678,7 +688,7 @@ class ParamsKZG:
             if not 1 <= k <= 28:
                 raise ZkhipError(f"{path}: k = {k} is not a KZG parameter file")
             n = 1 << k
-            if ctx.world > 1:      # this rank's slice of both bases only
+            if ctx.world > 1 and ctx.shard_points:      # this rank's slice of both bases only
                 first, count = ctx.shard_range(n)
                 hs = []
                 for b in range(2):
@@ -705,7 +715,7 @@ class ParamsKZG:
         return p
 
     def write(self, path):
-        if self.ctx.world > 1:
+        if self.range()[1] != self.range()[2]:
             raise ZkhipError("ParamsKZG.write: these params are one rank's shard of the SRS")
         if getattr(self, "g2_bytes", None) is None or len(self.g2_bytes) != 256:
             raise ZkhipError("ParamsKZG.write: these params carry no G2 points (loaded from bare bases); refusing to write an SRS file "

@@ -271,7 +271,7 @@ class GpuBackend:
         else:
             self.params = self.ffi.ParamsKZG.setup(self.ctx, k, self.fr(s_int))
             self.params_source = "generated"
-            if syn and self.ctx.world == 1:      # a sharded context holds 1/N of the tables: nothing to write
+            if syn and self.params.range()[1] == self.params.range()[2]:      # a point-range shard holds 1/N of the tables: nothing to write
                 os.makedirs(os.path.dirname(syn) or ".", exist_ok=True)
                 self.params.write(syn)
                 self.params_source = syn

@@ -94,6 +94,11 @@ int  zkhip_comm_unique_id(uint8_t id[128]);
 int  zkhip_comm_init(zkhip_ctx* ctx, const uint8_t id[128], int rank, int nranks);
 int  zkhip_comm_init_host(zkhip_ctx* ctx, int rank, int nranks, zkhip_host_allgather_fn fn, void* user);
 int  zkhip_comm_destroy(zkhip_ctx* ctx);
+/* MSMs over WHOLE-SRS handles (every rank holds the full window tables) on a context with a communicator: on = 1 splits every batch by
+ * column — rank r commits columns r, r + N, ... completely, results all-gathered — the split of choice while one MSM cannot fill
+ * several GPUs (k <= 19: SURVEY.md 8(e)-2, the north star's "independent column commitments shard across the GPUs"); on = 0 (default)
+ * every rank computes every column.  Point-range handles (zkhip_kzg_setup_range) are always split by point range. */
+int  zkhip_comm_shard_columns(zkhip_ctx* ctx, int on);
 int  zkhip_comm_info(const zkhip_ctx* ctx, int* rank, int* nranks, uint64_t* bytes_gathered);
 int  zkhip_comm_allgather_device(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_rank);
 

@@ -25,7 +25,9 @@ else:
     dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
 ctx = ffi.Context(dev)
 ctx.comm_init(rank, world, dist)
-out = {"transport": ctx.transport}
+mode = os.environ.get("ZK_SHARD_MODE", "points")
+ctx.comm_shard(mode)
+out = {"transport": ctx.transport, "shard_mode": mode}
 for spec in json.loads(os.environ["ZK_SHAPES"]):
     if spec[0] == "small":
         sh = pv.CircuitShape.small(spec[1])
@@ -35,7 +37,7 @@ for spec in json.loads(os.environ["ZK_SHAPES"]):
         sh = pv.CircuitShape.rsa(spec[1])
     p = pv.Prover(pv.GpuBackend(ctx, ffi), sh, satisfiable=True)
     first, count, total = p.b.params.range()
-    assert total == 1 << sh.k and (first, count) == ctx.shard_range(total), (first, count, total)
+    assert total == 1 << sh.k and (first, count) == (ctx.shard_range(total) if mode == "points" else (0, total)), (first, count, total)
     w = p.witness(1)
     tr = p.prove_native(w, transcript=spec[2])
     tp = p.prove(w, transcript=spec[2])           # the Python schedule over the small entry points: MSMs collective, the rest replicated

@@ -90,3 +90,20 @@ def test_multi_device_rccl_if_available(zk, tmp_path):
         assert o["transport"] == "rccl" and o["bytes_gathered"] > 0
         for key, hexs in ref.items():
             assert o[key]["native"] == hexs
+
+
+def test_column_round_robin_sharding(zk, tmp_path):
+    """the other MSM split (for k <= 19): every rank holds the WHOLE window tables and commits columns r, r + N, ... of a
+    batch completely; the 96-byte results are all-gathered (non-owners contribute the identity).  Same bytes as the single-GPU proof."""
+    ref = _single_gpu_proofs(zk)
+    env_extra = {"ZK_SHARD_MODE": "columns"}
+    os.environ.update(env_extra)
+    try:
+        outs = _run_workers(tmp_path, 2, True, 29641)
+    finally:
+        for k_ in env_extra:
+            os.environ.pop(k_, None)
+    for o in outs:
+        assert o["shard_mode"] == "columns"
+        for key, hexs in ref.items():
+            assert o[key]["native"] == hexs and o[key]["python"] == hexs, key
