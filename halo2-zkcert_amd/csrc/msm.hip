@@ -191,8 +191,30 @@ __global__ void __launch_bounds__(256) k_sort_hi(const ColPtrs scalar_cols, size
     size_t i = blockIdx.x * (size_t)256 + tid;
     const bool live = i < n;
     hist[tid] = 0;   // 256 threads, SORT_MAXP = 256
+    uint32_t flip = 0;   // the scalar was replaced by r - scalar: every digit's point changes sign
     if (live) {
         fe32 sc = abi_to_canonical_words<Fr>(mem_load(col_ptr(scalar_cols, col) + (first + i) * 8));
+        // Scalars above (r - 1) / 2 are recoded as -(r - s): for uniform scalars nothing changes (the digits of r - s are as dense as
+        // those of s), but witness columns are full of small NEGATIVE values (-1, -x for a limb or a word x), whose canonical form has
+        // every window non-zero while r - s has one or two — they become as cheap as the small positive values, whose zero digits
+        // are skipped.
+        constexpr uint32_t RW[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+        constexpr uint32_t HW[8] = {0xf8000000u, 0xa1f0fac9u, 0x3cdcb848u, 0x9419f424u, 0x40c0ac2eu, 0xdc2822dbu, 0x7098d014u, 0x18322739u};
+        bool gt = false, decided = false;
+#pragma unroll
+        for (int j = 7; j >= 0; --j) {
+            if (!decided && sc.w[j] != HW[j]) { gt = sc.w[j] > HW[j]; decided = true; }
+        }
+        if (gt) {
+            uint32_t borrow = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                uint64_t d = (uint64_t)RW[j] - sc.w[j] - borrow;
+                sc.w[j] = (uint32_t)d;
+                borrow = (uint32_t)(d >> 63);
+            }
+            flip = 1;
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) sl[tid][j] = sc.w[j];
         sl[tid][8] = 0;
@@ -229,7 +251,7 @@ __global__ void __launch_bounds__(256) k_sort_hi(const ColPtrs scalar_cols, size
                 if (mag) {
                     uint32_t b = mag - 1, p = b >> g.LB;
                     uint32_t pos = base[p] + atomicAdd(&hist[p], 1u);
-                    tmp_entry[pos] = (uint32_t)(w * srs_n + first + i) | (neg << 31);
+                    tmp_entry[pos] = (uint32_t)(w * srs_n + first + i) | ((neg ^ flip) << 31);
                     tmp_key[pos] = (uint16_t)(b & lomask);
                 }
             }
@@ -256,7 +278,7 @@ __global__ void __launch_bounds__(256) k_sort_hi(const ColPtrs scalar_cols, size
             if (mag) {
                 uint32_t b = mag - 1, p = b >> g.LB;
                 uint32_t slot = atomicAdd(&hist[p], 1u);
-                st_e[slot] = (uint32_t)(w * srs_n + first + i) | (neg << 31);
+                st_e[slot] = (uint32_t)(w * srs_n + first + i) | ((neg ^ flip) << 31);
                 st_k[slot] = (uint16_t)(b & lomask);
                 st_p[slot] = (uint8_t)p;
             }

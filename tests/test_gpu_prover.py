@@ -471,3 +471,27 @@ def test_smallest_circuits(zk, oracle, k):
     t = gp.prove_native(w, transcript="poseidon")
     assert t["proof"] == cp.prove(cp.witness(0), transcript="poseidon")["proof"]
     assert verify_proof(gp, w, t["proof"], "poseidon")
+
+
+def test_agg_k22_evm_proof_bytes_verify(zk, oracle):
+    """BASELINE configs[3] at FULL size, exactly the headline configuration of bench.py: the aggregation-shaped k = 22 circuit (3 + 1 advice
+    columns, range lookup with lookup_bits = 21, /root/reference/src/bin/cli.rs:475) proved by one zkhip_create_proof_ex call under the
+    Keccak EvmTranscript (gen_evm_proof_shplonk, cli.rs:519); the proof BYTES (64-byte big-endian points, 32-byte scalars) pass the
+    byte-driven verifier, and the caller's-rng path (host blinding buffers, host advice columns) gives another valid proof."""
+    from verify_util import verify_proof
+
+    ffi, ctx = zk
+    sh = pv.CircuitShape.agg(22)
+    gp = pv.Prover(pv.GpuBackend(ctx, ffi), sh, satisfiable=True)
+    assert gp.b.params.window() == (20, 13)
+    w = gp.witness(0)
+    t = gp.prove_native(w, transcript="evm")
+    assert t["n_commitments"] == 16 and len(t["proof"]) == 64 * 16 + 32 * (len(t["evals"]) - 1)
+    assert verify_proof(gp, w, t["proof"], "evm")
+    bf, n = sh.blinding_factors, 1 << sh.k
+    host = dict(lookup_permuted=ctx.to_host(ctx.synth_fill(2 * (bf + 1), 11)), perm_z=ctx.to_host(ctx.synth_fill(sh.n_perm_sets * bf, 12)),
+                lookup_z=ctx.to_host(ctx.synth_fill(bf, 13)), random_poly=ctx.to_host(ctx.synth_fill(n, 14)))
+    t2 = gp.prove_native(w, transcript="evm", blinding=host, host_inputs=True)
+    assert t2["proof"] != t["proof"] and verify_proof(gp, w, t2["proof"], "evm")
+    gp.b.params.free()
+    del gp, w
