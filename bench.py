@@ -182,7 +182,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_config(name, steps, warmup, breakdown_passes=2, with_h2d=True, leaf_rank=None):
+    def run_config(name, steps, warmup, breakdown_passes=2, with_h2d=True, witness="uniform"):
         """-> result dict for one configuration (collective: every rank calls it with the same arguments)"""
         shape = make_shape(pv, name, args)
         kind = TRANSCRIPT[name]
@@ -195,7 +195,7 @@ def main():
         t0 = time.perf_counter()
         backend = pv.GpuBackend(ctx, ffi)
         prover = pv.Prover(backend, shape, satisfiable=True)
-        wit = prover.witness(0 if (shard or world == 1) else rank)
+        wit = prover.witness(0 if (shard or world == 1) else rank, dist=witness)
         torch.cuda.synchronize()
         setup_s = time.perf_counter() - t0
         n = 1 << shape.k
@@ -320,7 +320,11 @@ def main():
         res = {"value": round(ms_per_step / 1000.0, 6), "unit": "s", "steps": steps, "warmup": warmup, "ms_per_step": round(ms_per_step, 3),
                "workload": f"{shape.name}: {counts['msm']} MSM_2^{shape.k} + {counts['intt_n']} iNTT_2^{shape.k} + {counts['ntt_ext']} NTT_2^{prover.dom.extended_k} + "
                            f"1 iNTT_2^{prover.dom.extended_k} + sweep over 2^{prover.dom.extended_k} rows + lookup permute, {shape.n_perm_sets}+{len(shape.lookups)} grand products, "
-                           f"evaluations, SHPLONK; satisfiable synthetic instance (valid proof); {kind} transcript as {REFERENCE_CMD[name]}",
+                           f"evaluations, SHPLONK; satisfiable synthetic instance (valid proof), free witness cells "
+                           + ("uniform field elements (the worst case for the commitments)" if witness == "uniform" or shape.layout == "sha" else
+                              "drawn from SURVEY.md 8(d)'s value mix (limbs / bits / uniform)")
+                           + (" [bit / word columns by construction]" if shape.layout == "sha" else "") + f"; {kind} transcript as {REFERENCE_CMD[name]}",
+               "witness": "bits / words (SHA-256 bit circuit layout)" if shape.layout == "sha" else witness,
                "k": shape.k, "advice": shape.n_advice, "fixed": shape.n_fixed, "instance_values": prover.n_instance_values, "lookups": len(shape.lookups),
                "perm_columns": len(shape.perm_columns), "degree": shape.degree, "transcript": kind, "proof_bytes": len(trace.get("proof", b"")),
                "setup_s": round(setup_s, 3), "resident_bytes": int(resident), "rooflines": roof, "kernels_ms_per_step": kernels,
@@ -392,6 +396,13 @@ def main():
                 out_configs[name], _ = run_config(name, args.other_steps, 2)
             except Exception as e:   # noqa: BLE001 — never allowed to break the headline measurement
                 out_configs[name] = dict(error=str(e)[:300])
+        # the k = 22 circuit once more with SURVEY.md 8(d)'s value mix on the free witness cells (50 % 88-bit CRT limbs, 10 % bits, 40 %
+        # uniform) instead of uniform field elements: what a real aggregation witness looks like to the commitments (informational)
+        try:
+            r_, _ = run_config("agg22", max(3, args.other_steps // 2), 1, breakdown_passes=1, with_h2d=False, witness="survey")
+            out_configs["agg22_survey_witness"] = {k_: r_[k_] for k_ in ("value", "unit", "steps", "warmup", "ms_per_step", "workload", "witness", "transcript", "kernels_ms_per_step")}
+        except Exception as e:   # noqa: BLE001
+            out_configs["agg22_survey_witness"] = dict(error=str(e)[:300])
 
     if rank == 0:
         dom = head["rooflines"]["msm_accum_affine"]

@@ -784,12 +784,26 @@ class Prover:
         """Synthetic advice / instance tables in Lagrange form, resident on the device (untimed).  Lookup-advice columns
         take their values from the table column (about two occurrences of each of the first n/2 table rows), so the
         lookup argument is satisfiable like a real range check's.  dist: "uniform" = uniform field elements (the worst case for
-        the commitments); "survey" = SURVEY.md 8(d)'s value mix for the SHA-256 bit circuit, 90 % bits and 10 % words < 2^32 (not
-        for satisfiable instances, whose advice is determined by the gates)."""
+        the commitments); "survey" = SURVEY.md 8(d)'s value mix: for the (unsatisfiable) SHA-256 shape 90 % bits and 10 % words < 2^32; for
+        satisfiable halo2-lib instances the mix of the RSA / aggregation rows on the free cells (limbs, bits, uniform values)."""
         sh, n = self.shape, self.n
         base = sh.seed * 1000 + proof_seed * 100000
         if dist == "survey" and not self.satisfiable:
             advice = [self.b.synth_small(n, base + 1 + i, 900, 32) for i in range(sh.n_basic)]
+        elif dist == "survey" and sh.layout == "halo2-lib":
+            # SURVEY.md 8(d)'s value mix for the halo2-lib circuits (RSA: 70 % uniform, 20 % < 2^64, 10 % bits; aggregation: "as RSA but
+            # 50 % < 2^88" -> 40 % uniform, 50 % 88-bit CRT limbs, 10 % bits) on the FREE cells; copies and gate outputs follow as usual
+            limb_bits, p_small, p_bit = (88, 500, 100) if sh.name.startswith("agg") else (64, 200, 100)
+            advice = []
+            for i in range(sh.n_basic):
+                b = self.b
+                uni = b.synth(n, base + 1 + i)
+                words = [b.synth_small(n, base + 400 + 8 * i + j, 0, min(32, limb_bits - 32 * j)) for j in range((limb_bits + 31) // 32)]
+                small = b.lincomb(words, [1 << (32 * j) for j in range(len(words))], None)
+                bits = b.synth_small(n, base + 460 + i, 1000, 1)
+                pick = splitmix64(np.arange(n, dtype=np.uint64) + np.uint64(((base + 480 + i) << 32) & 0xFFFFFFFFFFFFFFFF)) % np.uint64(1000)
+                choice = np.where(pick < p_bit, 2, np.where(pick < p_bit + p_small, 1, 0)).astype(np.int64)
+                advice.append(b.gather(b.concat([uni, small, bits]), np.arange(n, dtype=np.int64) + choice * n))
         else:
             advice = [self.b.synth(n, base + 1 + i) for i in range(sh.n_basic)]
         for j in range(sh.n_lookup):

@@ -495,3 +495,20 @@ def test_agg_k22_evm_proof_bytes_verify(zk, oracle):
     assert t2["proof"] != t["proof"] and verify_proof(gp, w, t2["proof"], "evm")
     gp.b.params.free()
     del gp, w
+
+
+def test_survey_witness_mix_is_satisfiable(zk, oracle):
+    """the SURVEY.md 8(d) value mix on the free witness cells (88-bit limbs, bits, uniform values: bench.py's informational
+    `agg22_survey_witness` run) still gives a satisfiable instance: GPU proof == oracle proof, and it verifies"""
+    from verify_util import verify_proof
+
+    ffi, ctx = zk
+    sh = pv.CircuitShape.agg(9)
+    gp = pv.Prover(pv.GpuBackend(ctx, ffi), sh, satisfiable=True)
+    cp = pv.Prover(OracleBackend(8), sh, satisfiable=True)
+    w = gp.witness(0, dist="survey")
+    for a, b in zip(w["advice"], cp.witness(0, dist="survey")["advice"]):
+        assert (ctx.to_host(a) == b).all()
+    t = gp.prove_native(w, transcript="evm")
+    assert t["proof"] == cp.prove(cp.witness(0, dist="survey"), transcript="evm")["proof"]
+    assert verify_proof(gp, w, t["proof"], "evm")
