@@ -173,8 +173,25 @@ def main():
 
     ctx = ffi.Context(local_rank)
     shard = world > 1 and not args.replicas
+    comm_note = None
     if shard:
-        ctx.comm_init(rank, world, dist)     # RCCL communicator inside the library (unique id broadcast through torch.distributed)
+        # RCCL communicator inside the library (unique id broadcast through torch.distributed).  If it cannot be created on some rank
+        # (no librccl, an RCCL error) every rank learns it and the run degrades — loudly, in the JSON line — to N independent proofs:
+        # the GPU kernels are the same either way, only the split over ranks differs.
+        err = ""
+        try:
+            ctx.comm_init(rank, world, dist)
+        except Exception as e:   # noqa: BLE001
+            err = str(e)[:200]
+        flag = torch.tensor([1 if err else 0], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()):
+            if not err:
+                ctx.comm_destroy()
+            shard = False
+            comm_note = f"zkhip_comm_init failed on some rank ({err or 'another rank'}): fell back to {world} independent proofs (--replicas)"
+            if rank == 0:
+                print("bench.py: " + comm_note, file=sys.stderr)
     bh = build_hash()
 
     def barrier():
@@ -419,7 +436,7 @@ def main():
                                                                    else f"{world} independent proofs, one per GPU, no collective")},
             "roofline": {k_: dom[k_] for k_ in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms", "note")},
             "int_roofline": dict(kernel="k_accum_affine", **dom["int_roofline"]),
-            "configs": out_configs, "build": bh,
+            "configs": out_configs, "build": bh, **({"comm_note": comm_note} if comm_note else {}),
             "setup_s": head["setup_s"], "resident_bytes": head["resident_bytes"], "with_h2d": head["with_h2d"],
         }
         if not args.no_cpu_baseline and world == 1:
