@@ -752,7 +752,7 @@ class Prover:
         a0, a1, ins = col_of[("advice", 0)], col_of[("advice", 1)], col_of[("instance", 0)]
         rng = np.random.default_rng(seed)
         free1 = rng.permutation(active)               # even rows of advice 1: free cells
-        nv = self.n_instance_values
+        nv = min(self.n_instance_values, max(1, len(free1) // 2))   # public inputs that are copied into the circuit (tiny circuits: fewer)
         m = max(1, min(u // 16, len(free1) - nv))
         odd0 = rng.permutation(active + 1)[:m]        # odd rows of advice 0: not under the bit gate
         pairs = [(a1 * n + int(free1[i]), ins * n + i) for i in range(nv)]

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
 import halo2_zkcert_amd.ffi as ffi
 import halo2_zkcert_amd.prover as pv
-from verify_util import verify_trace
+from verify_util import verify_proof, verify_trace
 
 
 def main():
@@ -24,16 +24,22 @@ def main():
     t_end = time.time() + args.seconds
     done, seed = 0, 0
     provers = {}
+    kinds = ("poseidon", "evm", "blake2b")
+    shapes = {"small": pv.CircuitShape.small, "sha": lambda k: pv.CircuitShape.sha256(k, n_advice=12, n_fixed=5), "agg": pv.CircuitShape.agg}
     while time.time() < t_end:
         k = args.kmin + seed % (args.kmax - args.kmin + 1)
-        if k not in provers:
-            provers[k] = pv.Prover(pv.GpuBackend(ctx, ffi), pv.CircuitShape.small(k), satisfiable=True)
-        p = provers[k]
-        w = p.witness(seed)
-        t = p.prove_native(w)
-        assert verify_trace(p, w, t), ("verify", k, seed)
+        name = ("small", "sha", "agg")[(seed // 3) % 3]
+        if (name, k) not in provers:
+            provers[(name, k)] = pv.Prover(pv.GpuBackend(ctx, ffi), shapes[name](k), satisfiable=True)
+        p = provers[(name, k)]
+        w = p.witness(seed, dist="survey" if name == "agg" and seed % 2 else "uniform")
+        kind = kinds[seed % 3]
+        t = p.prove_native(w, transcript=kind, host_inputs=seed % 4 == 0)
+        assert verify_proof(p, w, t["proof"], kind), ("verify bytes", name, k, seed, kind)
         if seed % 5 == 0:
-            assert p.prove(w)["commitments"] == t["commitments"], ("schedule mismatch", k, seed)
+            assert p.prove(w, transcript=kind)["proof"] == t["proof"], ("schedule mismatch", name, k, seed)
+        if seed % 7 == 0:
+            assert verify_trace(p, w, p.prove_native(w)), ("verify trace", name, k, seed)
         done += 1
         seed += 1
     print("proof stress ok:", done, "proofs verified")
