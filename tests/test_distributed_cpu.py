@@ -5,6 +5,14 @@ import os
 import subprocess
 import sys
 
+
+def _free_port():
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 WORKER = r'''
@@ -37,7 +45,7 @@ def test_sharded_commit_world2(tmp_path, oracle, shard_ntt, shard_sweep):
     worker.write_text(WORKER)
     env = dict(os.environ, ZK_ROOT=ROOT, ZK_OUT=str(tmp_path), OMP_NUM_THREADS="1", ZK_SHARD_NTT=shard_ntt, ZK_SHARD_SWEEP=shard_sweep)
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
-                           "127.0.0.1", "--master-port", str(29533 + int(shard_ntt) + 2 * int(shard_sweep)), str(worker)], env=env, timeout=600)
+                           "127.0.0.1", "--master-port", str(_free_port()), str(worker)], env=env, timeout=600)
     r0 = json.loads((tmp_path / "rank0.json").read_text())
     r1 = json.loads((tmp_path / "rank1.json").read_text())
     assert r0["commitments"] == r1["commitments"] and r0["challenges"] == r1["challenges"]

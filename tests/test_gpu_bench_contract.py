@@ -7,6 +7,15 @@ import sys
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    """a TCP port that is free right now (the rendezvous of the multi-process tests)"""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -47,7 +56,7 @@ def test_bench_two_ranks_on_one_device():
     """the N > 1 control flow of bench.py (one k = 18 proof sharded over 2 ranks through the library's communicator, host-staged
     transport because both ranks share device 0): a strong-scaling line from rank 0"""
     env = dict(os.environ, ZKHIP_BENCH_ONE_DEVICE="1", ZKHIP_BENCH_DIST_BACKEND="gloo")
-    d = _run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29577",
+    d = _run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
               os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--agg-k", "18"], env=env)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["proofs_per_step"] == 1 and "sharded x2" in d["config"]["parallelism"]
     assert d["cpu_baseline"] is None and d["value"] > 0
@@ -57,6 +66,6 @@ def test_bench_chain_four_ranks_on_one_device():
     """BASELINE configs[4] (`--chain`): leaf proofs on ranks 0-3 (2 x RSA k = 17, 2 x SHA-shaped k = 19, unsharded contexts), barrier,
     then the aggregation-shaped proof (k = 18 here) sharded over the four ranks — control flow on one device (host-staged transport)."""
     env = dict(os.environ, ZKHIP_BENCH_ONE_DEVICE="1", ZKHIP_BENCH_DIST_BACKEND="gloo")
-    d = _run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4", "--master-addr", "127.0.0.1", "--master-port", "29578",
+    d = _run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
               os.path.join(ROOT, "bench.py"), "--gpus", "4", "--chain", "--steps", "1", "--warmup", "1", "--agg-k", "18"], env=env)
     assert d["n_gpus"] == 4 and d["proofs_per_step"] == 5 and "chain" in d["config"]["workload"] and d["value"] > 0

@@ -13,6 +13,15 @@ import pytest
 import halo2_zkcert_amd.prover as pv
 
 pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    """a TCP port that is free right now (the rendezvous of the multi-process tests)"""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHAPES = [["small", 8, "poseidon"], ["sha", 9, "poseidon"], ["small", 7, "evm"]]
 
@@ -32,7 +41,7 @@ def _run_workers(tmp_path, world, one_device, port):
     env = dict(os.environ, ZK_ROOT=ROOT, ZK_OUT=str(tmp_path), ZK_SHAPES=json.dumps(SHAPES), ZK_ONE_DEVICE="1" if one_device else "0",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_gpu_worker.py")]
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_gpu_worker.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     return [json.load(open(tmp_path / f"rank{i}.json")) for i in range(world)]
