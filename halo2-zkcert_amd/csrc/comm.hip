@@ -157,9 +157,14 @@ int zkhip_comm_init(zkhip_ctx* ctx, const uint8_t id[128], int rank, int nranks)
     ncclComm_t cm = nullptr;
     ZK_NCCL(g_rccl.CommInitRank(&cm, nranks, a, rank));
     ctx->comm.nccl = cm;
-    ZK_HIP(hipStreamCreateWithFlags(&ctx->comm.stream, hipStreamNonBlocking));
-    ZK_HIP(hipEventCreateWithFlags(&ctx->comm.ev_in, hipEventDisableTiming));
-    ZK_HIP(hipEventCreateWithFlags(&ctx->comm.ev_out, hipEventDisableTiming));
+    hipError_t e = hipStreamCreateWithFlags(&ctx->comm.stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->comm.ev_in, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->comm.ev_out, hipEventDisableTiming);
+    if (e != hipSuccess) {   // nothing half-built stays behind
+        (void)zkhip_comm_destroy(ctx);
+        set_error("zkhip_comm_init: stream / event creation failed: %s", hipGetErrorString(e));
+        return ZKHIP_EHIP;
+    }
     ctx->comm.rank = rank;
     ctx->comm.nranks = nranks;
     return ZKHIP_OK;

@@ -50,7 +50,6 @@ struct zkhip_options {
     int sort_hb = 0, sort_tile = 0, sort_one_atomic = 1;
     int ntt_smax = 0, ntt_r8 = 1, ntt_group = 0;
     int permute_rank_sort = 1, eval_byval = 1, late_overlap = -1;
-    int graphs = 1;
     int host_timing = 0;   // zkhip_create_proof prints its host-side phase times to stderr
 };
 

@@ -126,7 +126,7 @@ const OptName OPTIONS[] = {
     {"ZKHIP_NTT_SMAX", "ntt_smax", &zkhip_options::ntt_smax}, {"ZKHIP_NTT_R8", "ntt_r8", &zkhip_options::ntt_r8},
     {"ZKHIP_NTT_GROUP", "ntt_group", &zkhip_options::ntt_group}, {"ZKHIP_PERMUTE_RANK_SORT", "permute_rank_sort", &zkhip_options::permute_rank_sort},
     {"ZKHIP_EVAL_BYVAL", "eval_byval", &zkhip_options::eval_byval}, {"ZKHIP_LATE_OVERLAP", "late_overlap", &zkhip_options::late_overlap},
-    {"ZKHIP_GRAPHS", "graphs", &zkhip_options::graphs}, {"ZKHIP_HOST_TIMING", "host_timing", &zkhip_options::host_timing},
+    {"ZKHIP_HOST_TIMING", "host_timing", &zkhip_options::host_timing},
 };
 }  // namespace
 

@@ -295,3 +295,39 @@ def test_params_file_round_trip(zk, oracle, tmp_path):
     g = np.frombuffer(head[4:], dtype="<u8").reshape(1, 8)
     assert zo.affine_to_ints(g)[0] == (1, 2)
     p.free(); q.free()
+
+
+def test_point_range_shard_handles(zk, oracle):
+    """zkhip_kzg_setup_range / zkhip_srs_load_range: a handle that holds the window tables of a point range only.  Without a communicator
+    an MSM over GLOBAL indices inside the shard equals the same range over the whole SRS, the shard's bases read back equal the whole
+    SRS's, and a range that leaves the shard is an error (with a communicator it would be the collective path, tests/test_gpu_distributed.py)."""
+    import ctypes as C
+
+    ffi, ctx = zk
+    zo = oracle
+    k, n = 12, 1 << 12
+    s = zo.fr_from_int(0x5AA5D)
+    whole = ffi.ParamsKZG.setup(ctx, k, s)
+    first, count = 1000, 1500
+    g, gl = C.c_void_p(), C.c_void_p()
+    ffi._check(ffi.lib().zkhip_kzg_setup_range(ctx.h, C.c_uint32(k), ffi._p(ffi._u64(s)), C.c_size_t(first), C.c_size_t(count), C.byref(g), C.byref(gl)))
+    shard = ffi.ParamsKZG(ctx, k, g, gl)
+    assert shard.range() == (first, count, n) and whole.range() == (0, n, n)
+    assert (shard.read_bases(shard.g, first + 7, 20) == whole.read_bases(whole.g, first + 7, 20)).all()
+    assert (shard.read_bases(shard.g_lagrange, first, 5) == whole.read_bases(whole.g_lagrange, first, 5)).all()
+    # the same shard from host bases (a slice of a params file)
+    h = C.c_void_p()
+    bases = whole.read_bases(whole.g, first, count)
+    ffi._check(ffi.lib().zkhip_srs_load_range(ctx.h, ffi._p(bases), C.c_size_t(n), C.c_size_t(first), C.c_size_t(count), C.byref(h)))
+    loaded = ffi.ParamsKZG(ctx, k, h, None)
+    cols = [ctx.synth_fill(n, 91), ctx.synth_fill(n, 92)]
+    lo, m = first + 100, 1200
+    ref = ctx.to_host(whole.commit_batch_device(cols, n=m, first=lo))
+    for p_ in (shard, loaded):
+        got = ctx.to_host(p_.commit_batch_device(cols, n=m, first=lo))
+        assert all((ffi.g1_to_affine(a) == ffi.g1_to_affine(b)).all() for a, b in zip(got, ref))
+    with pytest.raises(ffi.ZkhipError):
+        shard.commit_batch_device(cols, n=m, first=first - 1)      # leaves the shard, and the context has no communicator
+    with pytest.raises(ffi.ZkhipError):
+        shard.read_bases(shard.g, 0, 4)
+    whole.free(); shard.free(); loaded.free()

@@ -10,8 +10,7 @@ root=$(pwd)
 out=$root/gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
-python3 bench.py > "$out/bench.json" 2> "$out/bench.err"
-python3 tools/kernel_bench.py > "$out/kernel_bench.txt" 2>> "$out/bench.err"
+python3 tools/kernel_bench.py > "$out/kernel_bench.txt" 2> "$out/bench.err"
 cd /tmp
 for cfg in rsa17 sha19 agg22; do
     args="--config $cfg --no-other-configs --no-cpu-baseline --steps 3 --warmup 1"
@@ -27,3 +26,7 @@ for cfg in rsa17 sha19 agg22; do
 done
 cd "$root"
 python3 tools/summarize_profiles.py "$out"
+# the bench line last, with this generation's PMC passes in place: bench.py reads roofline.traffic from profiles/*_pmc_<cfg>.csv of the
+# build it runs (matching `# build=` hash)
+for cfg in rsa17 sha19 agg22; do cp "$out/pmc_$cfg.csv" "profiles/${tag}_pmc_$cfg.csv"; done
+python3 bench.py > "$out/bench.json" 2>> "$out/bench.err"
