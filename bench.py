@@ -279,7 +279,7 @@ def main():
                 prover.prove_native(wit, transcript=kind, host_inputs=True)
             torch.cuda.synchronize()
             h2d = dict(value=round((time.perf_counter() - t0) / hs, 6), unit="s", steps=hs, h2d_bytes=shape.n_advice * n * 32,
-                       note="advice columns uploaded from pinned host memory inside the step; never part of `value`")
+                       note="advice columns uploaded from pinned host memory inside the step (copy stream; the random polynomial's commitment and, for many-column circuits, the earlier column groups' commitments overlap the uploads); never part of `value`")
         barrier()
 
         # ---- rooflines (algorithmic bytes: SURVEY.md §8(d)); one rank's share when the proof is sharded

@@ -80,6 +80,8 @@ struct zkhip_ctx {
     hipEvent_t accum_mark = nullptr;     // if set, the next MSM records it right after its bucket-accumulation launch (and clears it)
     hipStream_t side_stream = nullptr;   // zkhip_create_proof's second stream (coset NTTs beside the MSM phases), created on first use
     hipEvent_t side_event = nullptr;
+    hipStream_t copy_stream = nullptr;   // uploads of large host advice columns (zkhip_create_proof_ex, advice_on_host), created on first use
+    hipEvent_t copy_event[4] = {nullptr, nullptr, nullptr, nullptr};   // one per upload group
     // Small host->device uploads of host temporaries (pointer tables, lowered programs): the bytes are copied into a pinned ring
     // and the asynchronous copy reads from there, so the call neither blocks on the stream nor keeps the caller's buffer alive.
     // The ring is 8 MiB against ~100 KiB staged per proof; wrapping around synchronises the device.

@@ -189,6 +189,8 @@ void zkhip_destroy(zkhip_ctx* c) {
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->side_event) (void)hipEventDestroy(c->side_event);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    for (auto e : c->copy_event) if (e) (void)hipEventDestroy(e);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->stage_ring) (void)hipHostFree(c->stage_ring);
     delete c;

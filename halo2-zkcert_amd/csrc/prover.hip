@@ -129,15 +129,32 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
     if (in->advice_on_host && A) ZK_TRY(ws("cp_adv_in", (size_t)A * NB, &w_adv_in));
     if (!in->d_instance && I) ZK_TRY(ws("cp_ins_in", (size_t)I * NB, &w_ins_in));
     std::vector<const void*> adv_cols(A), ins_cols(I);
-    for (uint32_t j = 0; j < A; ++j) {
-        if (in->advice_on_host) {
-            // plain asynchronous copies on the proof's stream: from pinned memory they run at link rate and the first MSM starts when
-            // they have landed; from pageable memory the runtime stages them (slower, still correct)
-            ZK_HIP(hipMemcpyAsync(w_adv_in + j * NB, in->advice[j], NB, hipMemcpyHostToDevice, st));
-            adv_cols[j] = w_adv_in + j * NB;
-        } else {
-            adv_cols[j] = in->advice[j];
+    // Large host columns (>= 64 MiB in all: 512 MiB at k = 22 = 10 ms over PCIe) are uploaded on a copy stream of their own while the
+    // main stream already commits the vanishing argument's random polynomial, which needs none of them (phase 1 below); small ones
+    // ride on the proof's stream.  From pinned memory the copies run at link rate; from pageable memory the runtime stages them.
+    const bool split_upload = in->advice_on_host && A && (size_t)A * NB >= ((size_t)64 << 20);
+    // many columns (the SHA-256 circuit's 32): uploaded and committed in up to 4 groups of >= 8 columns, so that the commitment of group
+    // g runs while group g + 1 is still on the wire; few big columns (the aggregation circuit's 4): one group behind the random polynomial
+    const uint32_t n_groups = split_upload ? std::max<uint32_t>(1, std::min<uint32_t>(4, A / 8)) : 1;
+    auto group_begin = [&](uint32_t g_) { return (uint32_t)((uint64_t)A * g_ / n_groups); };
+    if (split_upload) {
+        if (!ctx->copy_stream) {
+            ZK_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+            for (auto& e : ctx->copy_event) ZK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         }
+        ZK_HIP(hipEventRecord(ctx->copy_event[0], st));   // the upload buffer's last readers (the previous proof) were issued on the main stream
+        ZK_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->copy_event[0], 0));
+    }
+    for (uint32_t g_ = 0; g_ < n_groups; ++g_) {
+        for (uint32_t j = group_begin(g_); j < group_begin(g_ + 1); ++j) {
+            if (in->advice_on_host) {
+                ZK_HIP(hipMemcpyAsync(w_adv_in + j * NB, in->advice[j], NB, hipMemcpyHostToDevice, split_upload ? ctx->copy_stream : st));
+                adv_cols[j] = w_adv_in + j * NB;
+            } else {
+                adv_cols[j] = in->advice[j];
+            }
+        }
+        if (split_upload) ZK_HIP(hipEventRecord(ctx->copy_event[g_], ctx->copy_stream));
     }
     for (uint32_t j = 0; j < I; ++j) {
         if (in->d_instance) { ins_cols[j] = in->d_instance[j]; continue; }
@@ -235,8 +252,22 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
         std::vector<const zkhip_srs*> bases(A, pk->g_lagrange);
         cols.push_back(w_rand);
         bases.push_back(pk->g);
-        ov.arm();
-        ZK_TRY(commit_launch(cols, bases));
+        if (split_upload) {
+            // the random polynomial's commitment first (its slot is the last one of the batch), then — once the uploads have landed —
+            // the advice columns'
+            const void* rc[1] = {w_rand};
+            const zkhip_srs* rb[1] = {pk->g};
+            ZK_TRY(zkhip_msm_g1_multi_device(ctx, rb, rc, 1, 0, n, w_com + (size_t)A * 96));
+            for (uint32_t g_ = 0; g_ < n_groups; ++g_) {
+                const uint32_t j0 = group_begin(g_), j1 = group_begin(g_ + 1);
+                ZK_HIP(hipStreamWaitEvent(st, ctx->copy_event[g_], 0));
+                if (g_ + 1 == n_groups) ov.arm();   // the overlapped NTTs follow the last group's accumulation
+                ZK_TRY(zkhip_msm_g1_multi_device(ctx, bases.data() + j0, cols.data() + j0, j1 - j0, 0, n, w_com + (size_t)j0 * 96));
+            }
+        } else {
+            ov.arm();
+            ZK_TRY(commit_launch(cols, bases));
+        }
         ZK_TRY(ov.begin_marked());
         if (A + I) {
             std::vector<const void*> lag(A + I);   // out of place: the witness columns stay in Lagrange form, no copy

@@ -378,6 +378,8 @@ def test_sha_k19_satisfiable_proof_verifies(zk, oracle):
     for piece, c in zip(t1["h_pieces"], qc):
         assert zo.g1_to_bytes(zo.g1_mul_gen(zo.eval_polynomial(piece, sm))).hex() == c
     assert gp.prove_native(w, transcript="poseidon")["proof"] == t1["proof"]
+    # the 32 advice columns as pinned HOST arrays: uploaded in 4 groups on a copy stream, each group committed while the next is on the wire
+    assert gp.prove_native(w, transcript="poseidon", host_inputs=True)["proof"] == t1["proof"]
     gp.b.params.free()
     del gp, w
 
