@@ -9,7 +9,6 @@ use std::ffi::c_void;
 use std::sync::{Mutex, OnceLock};
 
 use ff::{Field, PrimeField, WithSmallOrderMulGroup};
-use group::Curve;
 use halo2curves::bn256::{Bn256, Fr, G1Affine};
 use halo2curves::zkhip as curves_zkhip;
 use rand_core::RngCore;
@@ -189,8 +188,9 @@ fn device_key(ctx: *mut sys::zkhip_ctx, params: &ParamsKZG<Bn256>, pk: &ProvingK
     let perm_index: Vec<u32> = perm_cols.iter().map(|c| c.index() as u32).collect();
     let adv_q = (cs.advice_queries().iter().map(|(c, _)| c.index() as u32).collect::<Vec<_>>(), cs.advice_queries().iter().map(|(_, r)| r.0).collect::<Vec<_>>());
     let fix_q = (cs.fixed_queries().iter().map(|(c, _)| c.index() as u32).collect::<Vec<_>>(), cs.fixed_queries().iter().map(|(_, r)| r.0).collect::<Vec<_>>());
-    let g = curves_zkhip::srs_handle(&params.get_g()[..n]).expect("zkhip: SRS g");
-    let g_lagrange = curves_zkhip::srs_handle(&params.g_lagrange()[..n]).expect("zkhip: SRS g_lagrange");
+    // ParamsKZG { g, g_lagrange, .. }: pub(crate) fields of poly/kzg/commitment.rs
+    let g = curves_zkhip::srs_handle(&params.g[..n]).expect("zkhip: SRS g");
+    let g_lagrange = curves_zkhip::srs_handle(&params.g_lagrange[..n]).expect("zkhip: SRS g_lagrange");
     let delta = Fr::DELTA;
     let mut delta_w = [0u64; 4];
     unsafe { std::ptr::copy_nonoverlapping(&delta as *const Fr as *const u64, delta_w.as_mut_ptr(), 4) };
@@ -273,11 +273,14 @@ unsafe extern "C" fn cb_squeeze<E: EncodedChallenge<G1Affine>, T: TranscriptWrit
 }
 
 // ---------------------------------------------------------------------------------------------------------------- entry points
-/// bn256 + KZG + SHPLONK with one circuit instance and a single phase: what every command of the reference proves.
-pub fn applicable<Scheme: CommitmentScheme + 'static, P: 'static, E: 'static, T: 'static>(pk: &ProvingKey<Scheme::Curve>, n_instances: usize) -> bool {
+/// bn256 + KZG with one circuit instance and a single phase: what every command of the reference proves.  The multi-open scheme cannot
+/// be told from a type id (`ProverSHPLONK<'params, _>` is not `'static`): the call site in plonk/prover.rs passes `P::SHPLONK`-ness
+/// itself (`is_shplonk`: add `const IS_SHPLONK: bool` to the `Prover` trait, true for `ProverSHPLONK`, or gate the call with a cargo
+/// feature when only SHPLONK is ever used, as in the reference).
+pub fn applicable<Scheme: CommitmentScheme + 'static>(pk: &ProvingKey<Scheme::Curve>, n_instances: usize, is_shplonk: bool) -> bool {
     use std::any::TypeId;
-    TypeId::of::<Scheme>() == TypeId::of::<KZGCommitmentScheme<Bn256>>()
-        && TypeId::of::<P>() == TypeId::of::<crate::poly::kzg::multiopen::ProverSHPLONK<'static, Bn256>>()
+    is_shplonk
+        && TypeId::of::<Scheme>() == TypeId::of::<KZGCommitmentScheme<Bn256>>()
         && n_instances == 1
         && pk.vk.cs().phases().count() == 1
         && curves_zkhip::context().is_some()
