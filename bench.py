@@ -56,11 +56,15 @@ def host_threads():
     return n
 
 
+KERNEL_SOURCES = ("bn254.hpp", "common.hpp", "msm.hip", "ntt.hip", "sweep.hip")
+
+
 def build_hash():
-    """identifies the kernels' source: the PMC traffic figures under profiles/ are only quoted for the build they were measured on"""
+    """identifies the source of the three measured kernels (field arithmetic, MSM, NTT, sweep): the PMC traffic figures under profiles/
+    are only quoted for the kernels they were measured on (host-only files — schedule, transcripts, communicator — do not enter)"""
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "halo2-zkcert_amd", "csrc", "*.h*"))):
-        h.update(open(f, "rb").read())
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, "halo2-zkcert_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
 

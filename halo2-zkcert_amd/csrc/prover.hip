@@ -6,7 +6,10 @@
 //   advice commitments -> theta -> lookup compression + permute_expression_pair + commitments -> beta, gamma ->
 //   permutation / lookup grand products + commitments -> random polynomial commitment -> y -> quotient (coset NTTs, sweep,
 //   division, split) + commitments -> x -> evaluations -> SHPLONK multi-open.
-// The transcript stays with the caller: commitments, evaluations and challenges cross three callbacks, in upstream's order.
+// The transcript stays with the caller: commitments, evaluations, absorbed-only scalars (vk, instances) and challenges cross four
+// callbacks, in upstream's order; the evaluations are WRITTEN in upstream's order and opened in upstream's (different) query order.
+// Inputs (zk_proof_inputs): device or host advice columns, instance values, the caller's rng draws.  On a context with a communicator
+// (comm.hip) the same call runs one proof over several GPUs.
 // Everything here is host orchestration (no kernels): the point of having it in the library is that a proof of 2^17 rows is
 // ~9 ms of GPU work, and an interpreted host adds a millisecond of gaps between ~250 launches.
 // halo2-zkcert_amd/prover.py is the same schedule in Python over the small entry points (and the form the oracle backend runs).

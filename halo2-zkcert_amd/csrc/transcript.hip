@@ -3,7 +3,8 @@
 // BLAKE2b-512 personalised "Halo2-Transcript"; write_point absorbs prefix 1 and the canonical x, y (32 little-endian bytes each)
 // and appends the 32-byte compressed point to the proof; write_scalar absorbs prefix 2 and the canonical scalar and appends
 // its 32 bytes; a challenge absorbs prefix 0 and is the 64-byte digest of a copy of the state, reduced mod r (little-endian).
-// (The reference's own commands use snark-verifier's Poseidon / Keccak transcripts; a Rust caller passes its own callbacks.)
+// Further down: snark-verifier's Keccak EvmTranscript and its PoseidonTranscript — the two transcripts the reference's own commands use
+// (gen_evm_proof_shplonk / gen_snark_shplonk).  A Rust caller passes callbacks into its own transcript instead.
 #include <vector>
 
 #include "common.hpp"

@@ -19,9 +19,15 @@ and the evaluations of every queried polynomial at x * omega^rotation.
 The lookup argument's permuted columns are computed for real too (permute_expression_pair: a sort), which is why
 the synthetic lookup-advice columns draw their values from the table column: the lookup has to be satisfiable.
 
-What is NOT here ("next" rows): witness synthesis and the Poseidon / Keccak transcripts of snark-verifier.  The
-witness is replaced by synthetic columns of the right shape; the transcript is halo2's own Blake2bWrite (Blake2bTranscript below),
-so every Fiat-Shamir host round trip of the real prover is on the critical path.
+Transcript operations follow upstream's order (zkhip.h, zkhip_create_proof_ex): vk.transcript_repr and the instance values are
+absorbed first; the permuted lookup commitments go in per lookup (input, table); the evaluations are WRITTEN in upstream's order
+(advice, fixed, random, sigma, per permutation set, per lookup) while the multi-open consumes them in upstream's QUERY order.
+Transcripts: Blake2bTranscript below (halo2's Blake2bWrite over hashlib) or the library's Blake2b / Poseidon / Keccak transcripts
+driven from here (make_transcript): Poseidon is what the reference's gen_snark_shplonk commands use, Keccak what
+gen_evm_proof_shplonk uses.
+
+What is NOT here (out of scope): witness synthesis — the witness is a synthetic satisfiable instance of the circuit's shape
+(Prover._build_satisfiable / _build_satisfiable_sha), so the outputs are valid proofs.
 
 The schedule is written against a small backend interface so the same code drives the HIP library
 (GpuBackend, here) and, in tests/ and bench.py's cpu_baseline leg only, the CPU oracle.
@@ -159,8 +165,8 @@ class Blake2bTranscript:
     /root/reference/Cargo.lock:1320-1322]: a BLAKE2b-512 state personalised "Halo2-Transcript"; a point is absorbed as prefix 1
     and its canonical x and y (32 little-endian bytes each), a scalar as prefix 2 and its canonical 32 bytes; a challenge is
     prefix 0 followed by the 64-byte digest of a clone of the state, reduced into Fr as a little-endian integer.
-    (The reference's own commands use snark-verifier's Poseidon / Keccak transcripts, whose constants are not available here:
-    this is the transcript halo2 itself ships.)"""
+    (The reference's own commands use snark-verifier's Poseidon / Keccak transcripts: those live in the library, see
+    make_transcript; this class is the hashlib cross-check of the library's Blake2b one.)"""
 
     def __init__(self):
         self.state = hashlib.blake2b(digest_size=64, person=b"Halo2-Transcript")
