@@ -101,6 +101,24 @@ def test_multi_device_rccl_if_available(zk, tmp_path):
             assert o[key]["native"] == hexs
 
 
+@pytest.mark.parametrize("world,mode", [(8, "points"), (8, "columns"), (5, "points")])
+def test_eight_and_five_ranks(zk, tmp_path, world, mode):
+    """the rank count of the target node (8) and an odd one (5), all sharing device 0 through the host-staged transport: more ranks
+    than columns in a batch (padded all-gather rounds, ranks without a column), uneven point ranges, row ranges of 1/8 — every rank's
+    proof bytes equal the single-GPU proof's"""
+    ref = _single_gpu_proofs(zk)
+    os.environ["ZK_SHARD_MODE"] = mode
+    try:
+        outs = _run_workers(tmp_path, world, True, 0)
+    finally:
+        os.environ.pop("ZK_SHARD_MODE", None)
+    assert len(outs) == world
+    for o in outs:
+        assert o["shard_mode"] == mode
+        for key, hexs in ref.items():
+            assert o[key]["native"] == hexs and o[key]["python"] == hexs, key
+
+
 def test_column_round_robin_sharding(zk, tmp_path):
     """the other MSM split (for k <= 19): every rank holds the WHOLE window tables and commits columns r, r + N, ... of a
     batch completely; the 96-byte results are all-gathered (non-owners contribute the identity).  Same bytes as the single-GPU proof."""
