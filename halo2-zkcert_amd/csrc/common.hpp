@@ -7,6 +7,7 @@
 
 #include <deque>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -51,6 +52,7 @@ struct zkhip_options {
     int ntt_smax = 0, ntt_r8 = 1, ntt_group = 0;
     int permute_rank_sort = 1, eval_byval = 1, late_overlap = -1;
     int host_timing = 0;   // zkhip_create_proof prints its host-side phase times to stderr
+    int coset_quotient = 1;   // zkhip_create_proof evaluates the quotient on quotient_poly_degree cosets of size n (cosets.hip) when that is fewer rows
 };
 
 // Multi-GPU state of a context (comm.hip): rank / size, the RCCL communicator with its own stream (or the host-staged transport),
@@ -92,6 +94,7 @@ struct zkhip_ctx {
     void* h_pinned = nullptr;   // 64 KiB of pinned host memory for the small device->host reads on the critical path
     static constexpr size_t PINNED_BYTES = 64 * 1024;
     std::map<std::string, zk::Scratch> scratch;
+    std::map<std::string, std::shared_ptr<void>> host_objects;   // host-side companions of persistent buffers (cosets.hip's plans)
     std::map<std::string, void*> persistent;   // named device buffers that outlive a call (keygen-like derived data), freed with the context
     // Twiddle tables keyed by (log_n, omega).  w^e for any e < 2^log_n is lo[e & (2^h - 1)] * hi[e >> h]
     // (two tables of ~sqrt(n) entries: L2-resident, against a 16 * n-byte table that every strided NTT pass
@@ -166,5 +169,21 @@ int permute_expression_pair_async(zkhip_ctx* ctx, uint32_t k, uint32_t blinding_
                                   const void* d_sorted_table_keys);
 int permute_sorted_table_keys(zkhip_ctx* ctx, uint64_t key_id, uint32_t slot, uint32_t k, uint32_t blinding_factors, const void* d_table,
                               const void** d_keys);
+int ntt_tabled(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, size_t npolys, const uint64_t omega[4], uint32_t log_n,
+               const void* d_pre_tab, const void* d_post_tab, uint32_t tab_group, size_t tab_stride);
+int power_table(zkhip_ctx* ctx, const uint64_t base_abi[4], size_t count, void* d_out);
+// The quotient sweep over q cosets s_r H of the size-2^k domain H instead of the extended domain (cosets.hip): every column is q
+// blocks of n values (block r = the polynomial on s_r H, natural order), a rotation stays inside its block.
+struct SweepCosets { uint32_t q; const uint64_t* shifts_abi; /* q x 4: s_r */ const uint64_t* omega_abi; /* the size-n root */ };
+int evaluate_h_cosets(zkhip_ctx* ctx, const zk_evalh_args* A, const SweepCosets* cs, size_t first_row, size_t n_rows, void* d_out);
+// cosets.hip
+struct CosetPlan;
+int coset_plan(zkhip_ctx* ctx, const zkhip_domain* d, const CosetPlan** out);
+uint32_t coset_plan_q(const CosetPlan* p);
+int coeff_to_cosets(zkhip_ctx* ctx, const CosetPlan* p, const void* const* srcs, void* const* dsts, size_t npolys);
+int cosets_to_pieces(zkhip_ctx* ctx, const CosetPlan* p, void* d_vals, void* d_pieces);
+struct KeyCosets { std::vector<const void*> fixed, sigma; const void* l0; const void* l_last; const void* l_active; };
+int key_cosets(zkhip_ctx* ctx, const CosetPlan* p, const zk_proving_key* pk, const KeyCosets** out);
+void coset_sweep_view(const CosetPlan* p, SweepCosets* out);
 }
 static inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }

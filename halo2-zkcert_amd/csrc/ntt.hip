@@ -88,7 +88,16 @@ struct NttScale {
     fe pre[3];   // element i is multiplied by pre[i % 3] on the first load (if use_pre); R' form, < 2p
     fe post[3];  // output k is multiplied by post[k % 3] on the last store (if use_post)
     int use_pre, use_post;
+    // per-index tables (raw R' form), or null: element i is multiplied by pre_tab[i] on the first load, output k by post_tab[k] on
+    // the last store — the coset shifts s^i / s^-k of the quotient's coset-by-coset evaluation (cosets.hip)
+    const uint32_t* pre_tab;
+    const uint32_t* post_tab;
+    // polynomial p of the batch uses table (p / tab_group): tables are tab_stride elements apart (tab_p0: the launch's first polynomial)
+    uint32_t tab_group, tab_stride, tab_p0;
 };
+__device__ __forceinline__ const uint32_t* tab_of(const uint32_t* tab, const NttScale& sc, uint32_t p) {
+    return tab ? tab + (size_t)((sc.tab_p0 + p) / sc.tab_group) * sc.tab_stride * 8 : nullptr;
+}
 using tile_el = el<Fr, 40 * U>;   // anything held in a tile
 
 extern __shared__ uint32_t ntt_lds[];   // fe tile[NTT_TILE]
@@ -133,7 +142,7 @@ __device__ __forceinline__ void tile_ntt(fe* tile, uint32_t s, uint32_t logT, co
     __syncthreads();
 }
 
-__device__ __forceinline__ fe load_in(const uint32_t* src, uint32_t i, uint32_t n_in, const NttScale& sc) {
+__device__ __forceinline__ fe load_in(const uint32_t* src, uint32_t i, uint32_t n_in, const NttScale& sc, const uint32_t* pre_tab) {
     if (i >= n_in) return fe_zero();
     el1<Fr> v = load_raw<Fr>(src + (size_t)i * 8);
     if (sc.use_pre) {
@@ -141,6 +150,7 @@ __device__ __forceinline__ fe load_in(const uint32_t* src, uint32_t i, uint32_t 
         if (r == 1) return (v * el2<Fr>(sc.pre[1])).v;
         if (r == 2) return (v * el2<Fr>(sc.pre[2])).v;
     }
+    if (pre_tab) return (v * load_raw<Fr>(pre_tab + (size_t)i * 8)).v;
     return v.v;
 }
 
@@ -173,7 +183,7 @@ __global__ void __launch_bounds__(256) k_ntt_strided(const uint32_t* const* srcs
         for (uint32_t e = threadIdx.x; e < cnt; e += blockDim.x) {
             uint32_t tl = e & (T - 1), j = e >> logT;
             uint32_t pos = base | (j << lo_bits) | tl;
-            tile[bitrev(j, s) * T + tl] = load_in(src, pos, n_in, sc);
+            tile[bitrev(j, s) * T + tl] = load_in(src, pos, n_in, sc, tab_of(sc.pre_tab, sc, pi));
         }
         tile_ntt(tile, s, logT, tw);
 #pragma clang loop unroll(full)
@@ -209,7 +219,7 @@ __global__ void __launch_bounds__(256) k_ntt_final(const uint32_t* const* srcs, 
     for (uint32_t e = threadIdx.x; e < cnt; e += blockDim.x) {
         uint32_t j = e & (rows - 1), tl = e >> s;
         uint32_t row = ((k1_0 + tl) << rest_bits) | rest;
-        tile[bitrev(j, s) * T + tl] = load_in(src, (row << s) | j, n_in, sc);
+        tile[bitrev(j, s) * T + tl] = load_in(src, (row << s) | j, n_in, sc, tab_of(sc.pre_tab, sc, blockIdx.y));
     }
     tile_ntt(tile, s, logT, tw);
     // output index: k = k_1 + k_2 2^{s_1} + ... ; digits k_2..k_{p-1} come out of `rest` (slot order, msb first)
@@ -227,6 +237,7 @@ __global__ void __launch_bounds__(256) k_ntt_final(const uint32_t* const* srcs, 
         tile_el v(tile[r * T + tl]);
         void* out = dst + (size_t)k * 8;
         if (sc.use_post) store_raw<Fr>(out, v * el2<Fr>(sc.post[k % 3]));
+        else if (sc.post_tab) store_raw<Fr>(out, v * load_raw<Fr>(tab_of(sc.post_tab, sc, blockIdx.y) + (size_t)k * 8));
         else store_raw<Fr>(out, v);
     }
 }
@@ -352,6 +363,7 @@ __global__ void __launch_bounds__(256, 2) k_ntt_strided_r8(const NttPtrs PT, uin
     uint32_t base = (hi << (s + lo_bits)) | lo0;
     const uint32_t* src = PT.src[blockIdx.y];
     uint32_t* dst = PT.dst[blockIdx.y];
+    const uint32_t* pre_tab = tab_of(sc.pre_tab, sc, blockIdx.y);
     // ownership at the load: slot = row bits 0..2; row rho <-> digit j = bitrev(rho, s)
     const uint32_t tl0 = t & (T - 1), jrest = bitrev(t >> logT, s - 3);
     fe v[8];
@@ -359,7 +371,7 @@ __global__ void __launch_bounds__(256, 2) k_ntt_strided_r8(const NttPtrs PT, uin
     for (int q = 0; q < 8; ++q) {
         const uint32_t qr = ((q & 1) << 2) | (q & 2) | (q >> 2);   // bitrev3
         uint32_t j = (qr << (s - 3)) | jrest;
-        v[q] = load_in(src, base | (j << lo_bits) | tl0, n_in, sc);
+        v[q] = load_in(src, base | (j << lo_bits) | tl0, n_in, sc, pre_tab);
     }
     stages_first(v, tw);
     const uint32_t L_last = tile_rest(v, tile, s, logT, z, tw, t);
@@ -378,6 +390,8 @@ __global__ void __launch_bounds__(256, 2) k_ntt_final_r8(const NttPtrs PT, uint3
     fe* tile = reinterpret_cast<fe*>(ntt_lds);
     const uint32_t* src = PT.src[blockIdx.y];
     uint32_t* dst = PT.dst[blockIdx.y];
+    const uint32_t* pre_tab = tab_of(sc.pre_tab, sc, blockIdx.y);
+    const uint32_t* post_tab = tab_of(sc.post_tab, sc, blockIdx.y);
     const uint32_t T = 1u << logT, t = threadIdx.x;
     uint32_t hi_bits = m - s;
     uint32_t s1 = dg.np > 1 ? dg.sw[0] : 0;
@@ -392,7 +406,7 @@ __global__ void __launch_bounds__(256, 2) k_ntt_final_r8(const NttPtrs PT, uint3
 #pragma clang loop unroll(full)
     for (int q = 0; q < 8; ++q) {
         const uint32_t qr = ((q & 1) << 2) | (q & 2) | (q >> 2);
-        v[q] = load_in(src, (row0 << s) | (qr << (s - 3)) | jl, n_in, sc);
+        v[q] = load_in(src, (row0 << s) | (qr << (s - 3)) | jl, n_in, sc, pre_tab);
     }
     stages_first(v, tw);
     // group 0's ownership in the common (tl, rest-of-row) thread numbering
@@ -413,6 +427,7 @@ __global__ void __launch_bounds__(256, 2) k_ntt_final_r8(const NttPtrs PT, uint3
         uint32_t k = (r << hi_bits) | kbase | (k1_0 + tl);
         void* out = dst + (size_t)k * 8;
         if (sc.use_post) store_raw<Fr>(out, tile_el(v[q]) * el2<Fr>(sc.post[k % 3]));
+        else if (post_tab) store_raw<Fr>(out, tile_el(v[q]) * load_raw<Fr>(post_tab + (size_t)k * 8));
         else store_raw<Fr>(out, tile_el(v[q]));
     }
 }
@@ -513,8 +528,9 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
         lo_bits -= s;
         uint32_t logT = std::min<uint32_t>(ilog2(NTT_TILE) - s, lo_bits);
         NttScale scq = sc;
-        if (q != 0) scq.use_pre = 0;
+        if (q != 0) { scq.use_pre = 0; scq.pre_tab = nullptr; }
         scq.use_post = 0;
+        scq.post_tab = nullptr;
         uint32_t** out = (q + 2 == np) ? d_tmp : d_dst;
         unsigned blocks = (unsigned)(n >> (s + logT));
         // polynomials per workgroup: as many as keep >= 512 workgroups in the launch (two per CU; measured crossover)
@@ -533,6 +549,7 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
                 NttPtrs PT;
                 const size_t cnt = std::min<size_t>(NTT_MAXP, npolys - p0);
                 for (size_t i = 0; i < cnt; ++i) { PT.src[i] = (const uint32_t*)hs[p0 + i]; PT.dst[i] = (uint32_t*)hd[p0 + i]; }
+                scq.tab_p0 = (uint32_t)p0;
                 hipLaunchKernelGGL(k_ntt_strided_r8, dim3(blocks, (unsigned)cnt), dim3(256), NTT_TILE * sizeof(fe), st, PT, m, s, lo_bits, logT,
                                    q == 0 ? n_in : (uint32_t)n, tw, scq, z, (const uint32_t*)ptab);
             }
@@ -547,7 +564,7 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
         uint32_t s1 = np > 1 ? sw[0] : 0;
         uint32_t logT = np > 1 ? std::min<uint32_t>(ilog2(NTT_TILE) - s, s1) : 0;
         NttScale scq = sc;
-        if (np > 1) scq.use_pre = 0;
+        if (np > 1) { scq.use_pre = 0; scq.pre_tab = nullptr; }
         NttDigits dg;
         dg.np = np;
         for (int i = 0; i < 6; ++i) dg.sw[i] = sw[i];
@@ -560,6 +577,7 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
                 NttPtrs PT;
                 const size_t cnt = std::min<size_t>(NTT_MAXP, npolys - p0);
                 for (size_t i = 0; i < cnt; ++i) { PT.src[i] = (const uint32_t*)hs[p0 + i]; PT.dst[i] = (uint32_t*)all[npolys + p0 + i]; }
+                scq.tab_p0 = (uint32_t)p0;
                 hipLaunchKernelGGL(k_ntt_final_r8, dim3(blocks, (unsigned)cnt), dim3(256), NTT_TILE * sizeof(fe), st, PT, m, s, logT, (uint32_t)n, tw,
                                    scq, dg, z);
             }
@@ -683,6 +701,28 @@ int lagrange_to_coeff_oop(zkhip_ctx* ctx, const zkhip_domain* d, const void* con
     sc.use_post = 1;
     sc.post[0] = sc.post[1] = sc.post[2] = d->ifft_divisor.v;
     return ntt_run(ctx, srcs, dsts, npolys, d->omega_inv_abi, d->k, 1u << d->k, sc);
+}
+// a size-2^log_n transform with per-index scaling tables (raw R' powers from power_table), either of which may be null
+// (polynomial p uses table p / tab_group of a run of tables tab_stride elements apart)
+int ntt_tabled(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, size_t npolys, const uint64_t omega[4], uint32_t log_n,
+               const void* d_pre_tab, const void* d_post_tab, uint32_t tab_group, size_t tab_stride) {
+    if (!ctx || !srcs || !dsts || !omega || !tab_group) { set_error("ntt_tabled: null argument"); return ZKHIP_EINVAL; }
+    NttScale sc = no_scale();
+    sc.pre_tab = (const uint32_t*)d_pre_tab;
+    sc.post_tab = (const uint32_t*)d_post_tab;
+    sc.tab_group = tab_group;
+    sc.tab_stride = (uint32_t)tab_stride;
+    return ntt_run(ctx, srcs, dsts, npolys, omega, log_n, 1u << log_n, sc);
+}
+// d_out[i] = base^i for i < count, in the kernels' raw R' form (32 B each), on the context's stream
+int power_table(zkhip_ctx* ctx, const uint64_t base_abi[4], size_t count, void* d_out) {
+    if (!ctx || !base_abi || !d_out) { set_error("power_table: null argument"); return ZKHIP_EINVAL; }
+    fe32 base;   // the caller's array may be 8-byte aligned only
+    memcpy(base.w, base_abi, 32);
+    el2<Fr> b = from_abi<Fr>(base);
+    hipLaunchKernelGGL(k_powers, dim3(div_up(div_up(count, 16), 64)), dim3(64), 0, ctx->stream, (uint32_t*)d_out, count, b.v);
+    ZK_LAUNCH_CHECK();
+    return ZKHIP_OK;
 }
 }  // namespace zk
 extern "C" {

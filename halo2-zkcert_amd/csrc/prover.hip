@@ -121,8 +121,22 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
     auto pad = [&](size_t cnt) { return dist ? (cnt + NR - 1) / NR * NR : cnt; };   // all-gather rounds of NR columns: pad the column blocks
 
     // ---- workspace (library-owned, reused across proofs)
-    char *w_coeff, *w_ext, *w_rand, *w_comp, *w_blind, *w_perm_l, *w_perm_c, *w_ext_perm, *w_z, *w_ext_z, *w_h, *w_hpoly, *w_evals, *w_com;
-    const size_t NB = n * 32, EB = en * 32;
+    // ---- the quotient's evaluation points: the extended domain, or — when that is fewer rows and the key is known to the context
+    // (key_id) — quotient_poly_degree cosets of the size-n domain (cosets.hip); the same h either way
+    const zk::CosetPlan* cplan = nullptr;
+    const zk::KeyCosets* kcos = nullptr;
+    const bool coset_mode = ctx->opt.coset_quotient != 0 && pk->key_id != 0 && qd >= 2 && qd < (1u << (ek - k)) && (!F || pk->fixed_coeff) &&
+                            (!P || pk->sigma_coeff);
+    if (coset_mode) {
+        ZK_TRY(zk::coset_plan(ctx, pk->domain, &cplan));
+        ZK_TRY(zk::key_cosets(ctx, cplan, pk, &kcos));
+    } else if ((F && !pk->fixed_cosets) || (P && !pk->sigma_cosets) || ((P || L) && (!pk->l0 || !pk->l_last || !pk->l_active_row))) {
+        set_error("zkhip_create_proof: the proving key's extended cosets are missing (they are optional only with key_id and coefficient forms)");
+        return ZKHIP_EINVAL;
+    }
+    const size_t ext_rows = coset_mode ? (size_t)qd * n : en;
+    char *w_coeff, *w_ext, *w_rand, *w_comp, *w_blind, *w_perm_l, *w_perm_c, *w_ext_perm, *w_z, *w_ext_z, *w_h, *w_hvals = nullptr, *w_hpoly, *w_evals, *w_com;
+    const size_t NB = n * 32, EB = ext_rows * 32;
     auto ws = [&](const char* name, size_t bytes, char** p) { void* q; int rc = ctx->get_scratch(name, bytes ? bytes : 32, &q); *p = (char*)q; return rc; };
     ZK_TRY(ws("cp_coeff", (A + I) * NB, &w_coeff));
     ZK_TRY(ws("cp_ext", pad(A + I) * EB, &w_ext));
@@ -188,6 +202,7 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
     ZK_TRY(ws("cp_z", (Zp + L) * NB, &w_z));
     ZK_TRY(ws("cp_ext_z", pad(Zp + L) * EB, &w_ext_z));
     ZK_TRY(ws("cp_h", EB, &w_h));
+    if (coset_mode) ZK_TRY(ws("cp_hvals", EB, &w_hvals));
     ZK_TRY(ws("cp_hpoly", NB, &w_hpoly));
     const size_t max_q = (size_t)pk->n_advice_queries + pk->n_fixed_queries + 3 * Zp + 5 * L + P + 2;
     ZK_TRY(ws("cp_evals", max_q * 32, &w_evals));
@@ -198,7 +213,10 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
 
     // coeff_to_extended of `count` polynomials whose outputs are consecutive EB-sized slices of one padded workspace block
     auto to_extended = [&](const void* const* srcs, void* const* dsts, size_t count) -> int {
-        if (!dist) return zkhip_coeff_to_extended_device(ctx, pk->domain, srcs, n, dsts, count);
+        auto transform = [&](const void* const* s_, void* const* d_, size_t c_) -> int {
+            return coset_mode ? zk::coeff_to_cosets(ctx, cplan, s_, d_, c_) : zkhip_coeff_to_extended_device(ctx, pk->domain, s_, n, d_, c_);
+        };
+        if (!dist) return transform(srcs, dsts, count);
         // by polynomial, pipelined: rank RK transforms column t NR + RK of round t, then the round's NR columns are all-gathered in
         // place on the communicator's stream while this stream already transforms the rank's column of round t + 1
         for (size_t t = 0; t * NR < count; ++t) {
@@ -206,7 +224,7 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
             if (j < count) {
                 const void* s1[1] = {srcs[j]};
                 void* d1[1] = {dsts[j]};
-                ZK_TRY(zkhip_coeff_to_extended_device(ctx, pk->domain, s1, n, d1, 1));
+                ZK_TRY(transform(s1, d1, 1));
             }
             char* block = (char*)dsts[t * NR];
             ZK_TRY(zk::comm_allgather_begin(ctx, block + RK * EB, block, EB));
@@ -413,30 +431,42 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
         memcpy(a.extended_omega, ext_omega_abi, 32); memcpy(a.g_coset, g_coset_abi, 32); memcpy(a.delta, pk->delta, 32);
         memcpy(a.beta, beta, 32); memcpy(a.gamma, gamma, 32); memcpy(a.theta, theta, 32); memcpy(a.y, y, 32);
         a.n_fixed = F; a.n_advice = A; a.n_instance = I;
-        a.fixed_cosets = (const uint64_t* const*)pk->fixed_cosets;
+        a.fixed_cosets = (const uint64_t* const*)(coset_mode ? kcos->fixed.data() : pk->fixed_cosets);
         a.advice_cosets = (const uint64_t* const*)ext_ptrs.data();
         a.instance_cosets = (const uint64_t* const*)(ext_ptrs.data() + A);
-        a.l0 = (const uint64_t*)pk->l0; a.l_last = (const uint64_t*)pk->l_last; a.l_active_row = (const uint64_t*)pk->l_active_row;
+        a.l0 = (const uint64_t*)(coset_mode ? kcos->l0 : pk->l0);
+        a.l_last = (const uint64_t*)(coset_mode ? kcos->l_last : pk->l_last);
+        a.l_active_row = (const uint64_t*)(coset_mode ? kcos->l_active : pk->l_active_row);
         a.custom_gates = pk->custom_gates;
         a.n_perm_columns = P; a.n_perm_sets = Zp;
         a.perm_column_type = pk->perm_column_type; a.perm_column_index = pk->perm_column_index;
-        a.perm_sigma_cosets = (const uint64_t* const*)pk->sigma_cosets;
+        a.perm_sigma_cosets = (const uint64_t* const*)(coset_mode ? kcos->sigma.data() : pk->sigma_cosets);
         a.perm_product_cosets = (const uint64_t* const*)(ext_z.data() + L);
         a.n_lookups = L;
         a.lookup_graphs = pk->lookup_graphs;
         a.lookup_product_cosets = (const uint64_t* const*)ext_z.data();
         a.lookup_input_cosets = (const uint64_t* const*)ext_perm.data();
         a.lookup_table_cosets = (const uint64_t* const*)(ext_perm.data() + L);
-        if (dist && en % (64 * NR) == 0) {
-            const size_t rows = en / NR;
-            ZK_TRY(zkhip_evaluate_h_rows_device(ctx, &a, RK * rows, rows, w_h + RK * rows * 32));
-            ZK_TRY(zk::comm_allgather(ctx, w_h + RK * rows * 32, w_h, rows * 32));
+        zk::SweepCosets sc;
+        if (coset_mode) zk::coset_sweep_view(cplan, &sc);
+        char* vals = coset_mode ? w_hvals : w_h;
+        auto sweep = [&](size_t first, size_t rows, char* dst) -> int {
+            return coset_mode ? zk::evaluate_h_cosets(ctx, &a, &sc, first, rows, dst) : zkhip_evaluate_h_rows_device(ctx, &a, first, rows, dst);
+        };
+        if (dist && ext_rows % (64 * NR) == 0) {
+            const size_t rows = ext_rows / NR;
+            ZK_TRY(sweep(RK * rows, rows, vals + RK * rows * 32));
+            ZK_TRY(zk::comm_allgather(ctx, vals + RK * rows * 32, vals, rows * 32));
         } else {
-            ZK_TRY(zkhip_evaluate_h_device(ctx, &a, w_h));
+            ZK_TRY(sweep(0, ext_rows, vals));
         }
     }
-    ZK_TRY(zkhip_divide_by_vanishing_device(ctx, pk->domain, w_h));
-    {
+    if (coset_mode) {
+        // per coset: inverse transform and s_r^-t; then the q x q combination that also carries 1 / (n (s_r^n - 1)): the division by the
+        // vanishing polynomial, which is constant on a coset
+        ZK_TRY(zk::cosets_to_pieces(ctx, cplan, w_hvals, w_h));
+    } else {
+        ZK_TRY(zkhip_divide_by_vanishing_device(ctx, pk->domain, w_h));
         void* hp[1] = {w_h};
         ZK_TRY(zkhip_extended_to_coeff_device(ctx, pk->domain, hp, 1));
     }

@@ -273,6 +273,10 @@ struct SweepParams {
     const uint32_t* const* cols;   // fixed ++ advice ++ instance (ABI form)
     uint32_t* out;
     uint32_t isize_mask, rot_scale, nslots, final_reduce;
+    // Row addressing: index(row, d) = (row & hi_mask) | ((row + d) & isize_mask).  Extended domain: hi_mask = 0, isize_mask =
+    // 2^extended_k - 1, rot_scale = 2^(extended_k - k).  Coset blocks (SweepCosets): hi_mask = ~(n - 1) keeps the block, isize_mask =
+    // n - 1, rot_scale = 1; block r = row >> coset_shift selects the coset's constants (coset_shift = 31 otherwise: always 0).
+    uint32_t hi_mask, coset_shift;
     uint32_t row0;                 // first row of this launch (row-range entry point: out[0] is row0's value)
     Section gates;
     // permutation
@@ -308,7 +312,7 @@ __device__ __forceinline__ fe fetch(const SweepParams& P, uint32_t o, uint32_t r
     uint32_t kind = o >> 28, a = (o >> 14) & 0x3fff, b = o & 0x3fff;
     if (kind == K_SLOT) return slot_read(a);
     if (kind == K_CONST) return fe_split<0>(mem_load(P.consts + (size_t)a * 8));
-    uint32_t r = (uint32_t)((int32_t)row + P.rots[b] * (int32_t)P.rot_scale) & P.isize_mask;
+    uint32_t r = (row & P.hi_mask) | ((uint32_t)((int32_t)row + P.rots[b] * (int32_t)P.rot_scale) & P.isize_mask);
     return fe_split<5>(mem_load(P.cols[a] + (size_t)r * 8));
 }
 __device__ __forceinline__ fe raw_add(const fe& a, const fe& b) {
@@ -367,11 +371,11 @@ __global__ void __launch_bounds__(128) k_sweep(SweepParams P) {
     run_section(P, P.gates, row, value.v, y.v);
     if (P.gates.result != 0xffffffffu) value = elv(fetch(P, P.gates.result, row));  // 0xffffffff: `value` already holds it
 
-    const uint32_t mask = P.isize_mask;
+    const uint32_t mask = P.isize_mask, hi = row & P.hi_mask;
     if (P.n_perm_sets) {
         const el1<Fr> beta = ldk(P, P.c_beta), gamma = ldk(P, P.c_gamma), k_one = ldk(P, P.c_one);
-        uint32_t r_next = (row + P.rot_scale) & mask;
-        uint32_t r_last = (uint32_t)((int32_t)row + P.last_rot * (int32_t)P.rot_scale) & mask;
+        uint32_t r_next = hi | ((row + P.rot_scale) & mask);
+        uint32_t r_last = hi | ((uint32_t)((int32_t)row + P.last_rot * (int32_t)P.rot_scale) & mask);
         elc l0 = ldc(P.l0, row), ll = ldc(P.l_last, row), la = ldc(P.l_active, row);
         elc zf = ldc(P.perm_z[0], row);
         value = value * y + (k_one - zf) * l0;
@@ -381,9 +385,10 @@ __global__ void __launch_bounds__(128) k_sweep(SweepParams P) {
             elc zi = ldc(P.perm_z[s], row), zp = ldc(P.perm_z[s - 1], r_last);
             value = value * y + (zi - zp) * l0;
         }
-        // current_delta = beta * g_coset * extended_omega^row
-        el2<Fr> xw = load_raw<Fr>(P.xt_lo + (size_t)(row & ((1u << P.xt_h) - 1)) * 8) * load_raw<Fr>(P.xt_hi + (size_t)(row >> P.xt_h) * 8);
-        el2<Fr> cur = ldk(P, P.c_delta_start) * xw;
+        // current_delta = beta * g_coset * extended_omega^row   (coset blocks: beta * s_r * omega^(row mod n), s_r from the table)
+        const uint32_t xi = row & mask;
+        el2<Fr> xw = load_raw<Fr>(P.xt_lo + (size_t)(xi & ((1u << P.xt_h) - 1)) * 8) * load_raw<Fr>(P.xt_hi + (size_t)(xi >> P.xt_h) * 8);
+        el2<Fr> cur = ldk(P, P.c_delta_start + (row >> P.coset_shift)) * xw;
         const el1<Fr> delta = ldk(P, P.c_delta);
         for (uint32_t s = 0; s < P.n_perm_sets; ++s) {
             uint32_t c0 = s * P.chunk_len, c1 = min(c0 + P.chunk_len, P.n_perm_cols);
@@ -401,7 +406,7 @@ __global__ void __launch_bounds__(128) k_sweep(SweepParams P) {
     if (P.n_lookups) {
         const el1<Fr> beta = ldk(P, P.c_beta), gamma = ldk(P, P.c_gamma), k_one = ldk(P, P.c_one);
         elc l0 = ldc(P.l0, row), ll = ldc(P.l_last, row), la = ldc(P.l_active, row);
-        uint32_t r_next = (row + P.rot_scale) & mask, r_prev = (row - P.rot_scale) & mask;
+        uint32_t r_next = hi | ((row + P.rot_scale) & mask), r_prev = hi | ((row - P.rot_scale) & mask);
         for (uint32_t n = 0; n < P.n_lookups; ++n) {
             Section sec = P.lookup_secs[n];
             fe dummy = fe_zero();
@@ -425,7 +430,11 @@ __global__ void __launch_bounds__(128) k_sweep(SweepParams P) {
 }
 
 // ------------------------------------------------------------------ entry point
-static int evaluate_h_rows(zkhip_ctx* ctx, const zk_evalh_args* A, size_t first_row, size_t n_rows, void* d_out);
+static int evaluate_h_rows(zkhip_ctx* ctx, const zk_evalh_args* A, size_t first_row, size_t n_rows, void* d_out, const zk::SweepCosets* cs = nullptr);
+int zk::evaluate_h_cosets(zkhip_ctx* ctx, const zk_evalh_args* A, const SweepCosets* cs, size_t first_row, size_t n_rows, void* d_out) {
+    if (!cs || !cs->q || !cs->shifts_abi || !cs->omega_abi) { set_error("evaluate_h_cosets: null argument"); return ZKHIP_EINVAL; }
+    return evaluate_h_rows(ctx, A, first_row, n_rows, d_out, cs);
+}
 extern "C" int zkhip_evaluate_h_device(zkhip_ctx* ctx, const zk_evalh_args* A, void* d_out) {
     if (!A) { set_error("zkhip_evaluate_h_device: null argument"); return ZKHIP_EINVAL; }
     return evaluate_h_rows(ctx, A, 0, (size_t)1 << (A->extended_k <= 26 ? A->extended_k : 0), d_out);
@@ -433,7 +442,7 @@ extern "C" int zkhip_evaluate_h_device(zkhip_ctx* ctx, const zk_evalh_args* A, v
 extern "C" int zkhip_evaluate_h_rows_device(zkhip_ctx* ctx, const zk_evalh_args* A, size_t first_row, size_t n_rows, void* d_out) {
     return evaluate_h_rows(ctx, A, first_row, n_rows, d_out);
 }
-static int evaluate_h_rows(zkhip_ctx* ctx, const zk_evalh_args* A, size_t first_row, size_t n_rows, void* d_out) {
+static int evaluate_h_rows(zkhip_ctx* ctx, const zk_evalh_args* A, size_t first_row, size_t n_rows, void* d_out, const zk::SweepCosets* cs) {
     if (!ctx || !A || !d_out) { set_error("zkhip_evaluate_h_device: null argument"); return ZKHIP_EINVAL; }
     if (A->extended_k < A->k || A->extended_k > 26 || A->extended_k < 2) { set_error("zkhip_evaluate_h_device: extended_k = %u unsupported (2..26)", A->extended_k); return ZKHIP_EINVAL; }
     if (A->n_perm_sets && A->cs_degree < 3) { set_error("zkhip_evaluate_h_device: cs_degree < 3 with a permutation argument"); return ZKHIP_EINVAL; }
@@ -448,7 +457,15 @@ static int evaluate_h_rows(zkhip_ctx* ctx, const zk_evalh_args* A, size_t first_
     L.c_one = L.add_const(fe_pack(fe_canonical<Fr>(one<Fr>().v)));
     L.c_beta = cst(A->beta); L.c_gamma = cst(A->gamma); L.c_theta = cst(A->theta); L.c_y = cst(A->y);
     uint32_t c_delta = cst(A->delta);
-    uint32_t c_delta_start = L.add_const(fe_pack(fe_canonical<Fr>((from_abi<Fr>(mem_load(A->beta)) * from_abi<Fr>(mem_load(A->g_coset))).v)));
+    // beta * (the coset generator): one entry, or one per coset block (consecutive)
+    uint32_t c_delta_start = 0;
+    for (uint32_t r = 0; r < (cs ? cs->q : 1u); ++r) {
+        const uint64_t* shift = cs ? cs->shifts_abi + 4 * r : A->g_coset;
+        fe32 sh;   // the coset table may be 8-byte aligned only
+        memcpy(sh.w, shift, 32);
+        uint32_t idx = L.add_const(fe_pack(fe_canonical<Fr>((from_abi<Fr>(mem_load(A->beta)) * from_abi<Fr>(sh)).v)));
+        if (r == 0) c_delta_start = idx;
+    }
     L.c_chal0 = (uint32_t)L.consts.size();
     for (uint32_t i = 0; i < A->n_challenges; ++i) cst(A->challenges + 4 * i);
 
@@ -460,7 +477,8 @@ static int evaluate_h_rows(zkhip_ctx* ctx, const zk_evalh_args* A, size_t first_
 
     // pack everything into one upload
     hipStream_t st = ctx->stream;
-    const size_t isize = (size_t)1 << A->extended_k;
+    // rows of the sweep: the extended domain, or q blocks of n
+    const size_t isize = cs ? (size_t)cs->q << A->k : (size_t)1 << A->extended_k;
     std::vector<uint32_t> perm_slot(A->n_perm_columns);
     for (uint32_t c = 0; c < A->n_perm_columns; ++c) {
         uint32_t ty = A->perm_column_type[c], ix = A->perm_column_index[c];
@@ -500,9 +518,11 @@ static int evaluate_h_rows(zkhip_ctx* ctx, const zk_evalh_args* A, size_t first_
     P.rots = (const int32_t*)(b + o_rots);
     P.cols = (const uint32_t* const*)(b + o_cols);
     P.out = (uint32_t*)d_out;
-    P.isize_mask = (uint32_t)isize - 1;
+    P.isize_mask = cs ? (1u << A->k) - 1 : (uint32_t)isize - 1;
+    P.hi_mask = cs ? ~P.isize_mask : 0u;
+    P.coset_shift = cs ? A->k : 31u;
     P.row0 = (uint32_t)first_row;
-    P.rot_scale = 1u << (A->extended_k - A->k);
+    P.rot_scale = cs ? 1u : 1u << (A->extended_k - A->k);
     P.nslots = L.max_slots;
     P.gates = gates;
     P.n_perm_sets = A->n_perm_sets; P.n_perm_cols = A->n_perm_columns;
@@ -521,15 +541,16 @@ static int evaluate_h_rows(zkhip_ctx* ctx, const zk_evalh_args* A, size_t first_
     if (A->n_perm_sets) {
         if (!A->l0 || !A->l_last || !A->l_active_row) { set_error("zkhip_evaluate_h_device: l0/l_last/l_active_row missing"); return ZKHIP_EINVAL; }
         const zkhip_ctx::Twiddle* xt;
-        ZK_TRY(ctx->get_twiddles(A->extended_omega, A->extended_k, &xt));
+        ZK_TRY(cs ? ctx->get_twiddles(cs->omega_abi, A->k, &xt) : ctx->get_twiddles(A->extended_omega, A->extended_k, &xt));
         P.xt_lo = (const uint32_t*)xt->d_lo;
         P.xt_hi = (const uint32_t*)xt->d_hi;
         P.xt_h = xt->h;
     }
     // one thread per row; domains below 64 rows (k = 4, 5 circuits: the lookup compression runs on 2^k rows) take one partial wave
-    const unsigned block = n_rows % 128 == 0 ? 128 : (n_rows % 64 == 0 ? 64 : (unsigned)n_rows);
-    if (first_row + n_rows > isize || n_rows == 0 || (n_rows % 64 && n_rows > 64)) {
-        set_error("zkhip_evaluate_h_rows_device: rows [%zu, %zu) out of the extended domain or not a multiple of 64", first_row, first_row + n_rows);
+    // (q blocks of 16 or 32 rows — 48, 96, 80 ... — go in half or quarter waves)
+    const unsigned block = n_rows % 128 == 0 ? 128 : n_rows % 64 == 0 ? 64 : n_rows < 64 ? (unsigned)n_rows : n_rows % 32 == 0 ? 32 : 16;
+    if (first_row + n_rows > isize || n_rows == 0 || (n_rows % 16 && n_rows > 64)) {
+        set_error("zkhip_evaluate_h_rows_device: rows [%zu, %zu) out of the domain or not a multiple of 16", first_row, first_row + n_rows);
         return ZKHIP_EINVAL;
     }
     size_t lds = (size_t)std::max<uint32_t>(L.max_slots, 1) * 9 * 4 * block;

@@ -65,6 +65,7 @@ SYMBOLS = [
     "zkhip_domain_new", "zkhip_domain_free", "zkhip_domain_k", "zkhip_domain_extended_k", "zkhip_domain_quotient_poly_degree",
     "zkhip_domain_constants", "zkhip_lagrange_to_coeff_device", "zkhip_coeff_to_lagrange_device",
     "zkhip_coeff_to_extended_device", "zkhip_extended_to_coeff_device", "zkhip_divide_by_vanishing_device",
+    "zkhip_domain_cosets", "zkhip_coeff_to_cosets_device", "zkhip_cosets_to_pieces_device", "zkhip_evaluate_h_cosets_device",
     "zkhip_lagrange_to_coeff", "zkhip_coeff_to_extended", "zkhip_extended_to_coeff",
     "zkhip_evaluate_h_device", "zkhip_evaluate_h_rows_device", "zkhip_synth_fill_device", "zkhip_synth_small_device",
     "zkhip_batch_invert_device", "zkhip_eval_polynomial_device", "zkhip_eval_polynomials_at_device", "zkhip_permutation_products_device",
@@ -881,6 +882,36 @@ class EvaluationDomain:
 
     def divide_by_vanishing_poly_device(self, a):
         _check(lib().zkhip_divide_by_vanishing_device(self.ctx.h, self.h, C.c_void_p(a.data_ptr())))
+
+    # the coset layout of the quotient (cosets.hip): q = quotient_poly_degree blocks of n, block r = extended rows r + E i
+    def cosets(self):
+        """-> (q, shifts): the coset generators s_r = g w_ext^r as a host (q, 4) ABI array; raises when q >= 2^(extended_k - k)"""
+        q = C.c_uint32()
+        _check(lib().zkhip_domain_cosets(self.ctx.h, self.h, C.byref(q), None))
+        shifts = np.zeros((q.value, 4), dtype=np.uint64)
+        _check(lib().zkhip_domain_cosets(self.ctx.h, self.h, C.byref(q), _p(shifts)))
+        return q.value, shifts
+
+    def coeff_to_cosets_device(self, polys):
+        if not polys:
+            return []
+        outs = [self.ctx.empty(self.n * self.quotient_poly_degree) for _ in polys]
+        _check(lib().zkhip_coeff_to_cosets_device(self.ctx.h, self.h, _ptr_array(polys), _ptr_array(outs), C.c_size_t(len(polys))))
+        return outs
+
+    def cosets_to_pieces_device(self, vals):
+        """vals: q n numerator values in the coset layout (overwritten) -> q n coefficients of numerator / (X^n - 1)"""
+        out = self.ctx.empty(self.n * self.quotient_poly_degree)
+        _check(lib().zkhip_cosets_to_pieces_device(self.ctx.h, self.h, C.c_void_p(vals.data_ptr()), C.c_void_p(out.data_ptr())))
+        return out
+
+    def evaluate_h_cosets(self, pack, first_row=0, n_rows=None):
+        """the sweep over coset-layout columns (zkhip_evaluate_h_cosets_device) -> (n_rows, 4) device tensor"""
+        n_rows = self.n * self.quotient_poly_degree - first_row if n_rows is None else n_rows
+        out = self.ctx.empty(n_rows)
+        _check(lib().zkhip_evaluate_h_cosets_device(self.ctx.h, self.h, C.byref(pack.args), C.c_size_t(first_row), C.c_size_t(n_rows),
+                                                    C.c_void_p(out.data_ptr())))
+        return out
 
 
 class EvalhPack:

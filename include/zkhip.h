@@ -178,6 +178,20 @@ int  zkhip_coeff_to_extended_device(zkhip_ctx* ctx, const zkhip_domain* dom, con
 int  zkhip_extended_to_coeff_device(zkhip_ctx* ctx, const zkhip_domain* dom, void* const* d_polys, size_t npolys);
 /* divide_by_vanishing_poly: a[i] *= t_evaluations[i mod 2^(extended_k-k)], in place. */
 int  zkhip_divide_by_vanishing_device(zkhip_ctx* ctx, const zkhip_domain* dom, void* d_a);
+/* ---- the same quotient on quotient_poly_degree cosets of the size-n domain (cosets.hip) ----
+ * The extended domain g<w_ext> is the union of E = 2^(extended_k - k) cosets s_r<w>, s_r = g w_ext^r; h has fewer than q n coefficients
+ * (q = quotient_poly_degree), so q of them determine it.  When q < E (cs.degree() = 4: 3 of 4; 6: 5 of 8) zkhip_create_proof_ex works
+ * on the first q cosets: fewer transform and sweep rows, the same h, pieces, commitments and proof bytes as EvaluationDomain's
+ * coeff_to_extended / divide_by_vanishing_poly / extended_to_coeff whenever the numerator is a multiple of X^n - 1, i.e. for every
+ * witness that satisfies the circuit (for one that does not, neither result is a quotient and the two differ; zkhip_set_option(ctx,
+ * "coset_quotient", 0) keeps the extended domain).  A column in this layout is q blocks of n values, block r = the polynomial on
+ * s_r<w> in natural order = extended index r + E i.  These entry points expose the pieces for tests and for callers with their own
+ * schedule; all return ZKHIP_EINVAL when q >= E. */
+int  zkhip_domain_cosets(zkhip_ctx* ctx, const zkhip_domain* dom, uint32_t* q, uint64_t* shifts /* q x 4 (ABI form) or NULL */);
+/* d_in[i]: n coefficients; d_out[i]: q n values */
+int  zkhip_coeff_to_cosets_device(zkhip_ctx* ctx, const zkhip_domain* dom, const void* const* d_in, void* const* d_out, size_t npolys);
+/* d_vals: q n numerator values (overwritten); d_pieces: q n coefficients of numerator / (X^n - 1), piece j at element j n */
+int  zkhip_cosets_to_pieces_device(zkhip_ctx* ctx, const zkhip_domain* dom, void* d_vals, void* d_pieces);
 /* Host-pointer forms (upload, transform, download). */
 int  zkhip_lagrange_to_coeff(zkhip_ctx* ctx, const zkhip_domain* dom, uint64_t* a);
 int  zkhip_coeff_to_extended(zkhip_ctx* ctx, const zkhip_domain* dom, const uint64_t* coeffs, size_t n_in, uint64_t* out);
@@ -229,6 +243,11 @@ int  zkhip_evaluate_h_device(zkhip_ctx* ctx, const zk_evalh_args* args, void* d_
 /* the same for the extended rows [first_row, first_row + n_rows) only (n_rows a multiple of 64; d_out holds n_rows elements): the
  * row-sharded sweep of a proof spread over several GPUs — the columns are complete on every GPU, rotations wrap as usual */
 int  zkhip_evaluate_h_rows_device(zkhip_ctx* ctx, const zk_evalh_args* args, size_t first_row, size_t n_rows, void* d_out);
+/* The sweep over the coset layout above: every *_cosets pointer of `args` (and l0, l_last, l_active_row) is a q-block column, rows
+ * [first_row, first_row + n_rows) of the q n; row r n + i is the natural sweep's extended row r + E i.  args->extended_omega / g_coset
+ * are not used. */
+int  zkhip_evaluate_h_cosets_device(zkhip_ctx* ctx, const zkhip_domain* dom, const zk_evalh_args* args, size_t first_row, size_t n_rows,
+                                    void* d_out);
 
 /* ---- grand products and evaluations: the O(n) field work of create_proof between the commitments ----
  * All columns are DEVICE arrays of n = 2^k ABI field elements; pointer lists are HOST arrays.  Asynchronous.
