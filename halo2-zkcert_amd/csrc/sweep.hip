@@ -378,12 +378,12 @@ __global__ void __launch_bounds__(128) k_sweep(SweepParams P) {
         uint32_t r_last = hi | ((uint32_t)((int32_t)row + P.last_rot * (int32_t)P.rot_scale) & mask);
         elc l0 = ldc(P.l0, row), ll = ldc(P.l_last, row), la = ldc(P.l_active, row);
         elc zf = ldc(P.perm_z[0], row);
-        value = value * y + (k_one - zf) * l0;
+        value = muladd2(value, y, k_one - zf, l0);   // value y + (1 - z) l0: two products, one reduction
         elc zl = ldc(P.perm_z[P.n_perm_sets - 1], row);
-        value = value * y + (sqr(zl) - zl) * ll;
+        value = muladd2(value, y, sqr(zl) - zl, ll);
         for (uint32_t s = 1; s < P.n_perm_sets; ++s) {
             elc zi = ldc(P.perm_z[s], row), zp = ldc(P.perm_z[s - 1], r_last);
-            value = value * y + (zi - zp) * l0;
+            value = muladd2(value, y, zi - zp, l0);
         }
         // current_delta = beta * g_coset * extended_omega^row   (coset blocks: beta * s_r * omega^(row mod n), s_r from the table)
         const uint32_t xi = row & mask;
@@ -400,7 +400,7 @@ __global__ void __launch_bounds__(128) k_sweep(SweepParams P) {
                 right = right * (v + cur + gamma);
                 cur = cur * delta;
             }
-            value = value * y + (left - right) * la;
+            value = muladd2(value, y, left - right, la);
         }
     }
     if (P.n_lookups) {
@@ -416,12 +416,12 @@ __global__ void __launch_bounds__(128) k_sweep(SweepParams P) {
             elc a = ldc(P.lookup_a[n], row), ap = ldc(P.lookup_a[n], r_prev);
             elc sv = ldc(P.lookup_s[n], row);
             auto a_minus_s = a - sv;
-            value = value * y + (k_one - z) * l0;
-            value = value * y + (sqr(z) - z) * ll;
+            value = muladd2(value, y, k_one - z, l0);
+            value = muladd2(value, y, sqr(z) - z, ll);
             auto t = (a + beta) * (sv + gamma) * zn - z * table_value;
-            value = value * y + t * la;
-            value = value * y + a_minus_s * l0;
-            value = value * y + a_minus_s * (a - ap) * la;
+            value = muladd2(value, y, t, la);
+            value = muladd2(value, y, a_minus_s, l0);
+            value = muladd2(value, y, a_minus_s * (a - ap), la);
         }
     }
     // back to the ABI form; the host sets final_reduce when the gate program alone could leave > 88 p
