@@ -56,7 +56,7 @@ def host_threads():
     return n
 
 
-KERNEL_SOURCES = ("bn254.hpp", "common.hpp", "msm.hip", "ntt.hip", "sweep.hip")
+KERNEL_SOURCES = ("bn254.hpp", "common.hpp", "msm.hip", "ntt.hip", "sweep.hip", "cosets.hip")
 
 
 def build_hash():
@@ -222,6 +222,11 @@ def main():
         n = 1 << shape.k
         counts = shape.counts(prover.dom.extended_k)
         en = 1 << prover.dom.extended_k
+        # zkhip_create_proof_ex evaluates the quotient on quotient_poly_degree cosets of the size-n domain when that is fewer rows than the
+        # extended domain (degree 4: 3 of 4); the Python schedule always uses the extended domain
+        qd = prover.dom.quotient_poly_degree
+        coset_q = qd if (not args.python_schedule and qd < (en >> shape.k) and os.environ.get("ZKHIP_COSET_QUOTIENT", "1") != "0") else 0
+        q_rows = coset_q * n if coset_q else en
         prove = (lambda: prover.prove(wit, transcript=kind)) if args.python_schedule else (lambda: prover.prove_native(wit, transcript=kind))
         for _ in range(warmup):
             prove()
@@ -260,14 +265,16 @@ def main():
         if not shard:
             dom = prover.dom
             batch = [ctx.synth_fill(n, 9000 + j) for j in range(8)]
-            dom.coeff_to_extended_device(batch)
+            # the transform the proof issues: onto q cosets of the size-n domain when that is fewer rows (csrc/cosets.hip), else onto the extended domain
+            to_quotient_domain = dom.coeff_to_cosets_device if coset_q else dom.coeff_to_extended_device
+            to_quotient_domain(batch)
             ctx.profile_enable(True)
             reps = 3
             for _ in range(reps):
-                outs = dom.coeff_to_extended_device(batch)
+                outs = to_quotient_domain(batch)
             ms_s, l_s = ctx.profile_read("ntt_strided")
             ms_f, l_f = ctx.profile_read("ntt_final")
-            iso["ntt"] = dict(ms=(ms_s + ms_f) / reps, launches=(l_s + l_f) / reps, elems=8 * en, per_kernel=dict(ntt_strided=(ms_s / reps, l_s / reps), ntt_final=(ms_f / reps, l_f / reps)))
+            iso["ntt"] = dict(ms=(ms_s + ms_f) / reps, launches=(l_s + l_f) / reps, elems=8 * q_rows, per_kernel=dict(ntt_strided=(ms_s / reps, l_s / reps), ntt_final=(ms_f / reps, l_f / reps)))
             ctx.profile_enable(False)
             del batch, outs
         ctx.profile_enable(False)
@@ -323,15 +330,17 @@ def main():
             roof["ntt"] = {"kernel": "k_ntt_strided_r8 + k_ntt_final_r8", "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": round(tr_l) if tr_l else None,
                            "algorithmic_bytes_per_launch": round(64.0 * i_["elems"] / max(i_["launches"], 1)), "avg_launch_ms": round(i_["ms"] / max(i_["launches"], 1), 4),
-                           "timing": "HIP events, 3 isolated batches of 8 coset NTTs (2^%d -> 2^%d) after a warm-up" % (shape.k, prover.dom.extended_k),
-                           "in_proof_ms_per_step": round(ntt_ms, 3), "transforms_per_step": counts["intt_n"] + counts["ntt_ext"] + counts["intt_ext"],
+                           "timing": ("HIP events, 3 isolated batches of 8 columns onto %d cosets (8 x %d transforms of 2^%d) after a warm-up" % (coset_q, coset_q, shape.k)) if coset_q
+                                     else "HIP events, 3 isolated batches of 8 coset NTTs (2^%d -> 2^%d) after a warm-up" % (shape.k, prover.dom.extended_k),
+                           "in_proof_ms_per_step": round(ntt_ms, 3),
+                           "transforms_per_step": counts["intt_n"] + counts["ntt_ext"] * (coset_q or 1) + counts["intt_ext"] * (coset_q or 1),
                            "note": "algorithmic = 64 B per element per transform; a transform of 2^m elements is ceil(m / 9) launches; VALU-issue bound "
                                    "(valu_busy 0.80-0.86 at k >= 19, profiles/r02_*_valu_*.csv), not HBM bound; in-proof spans overlap the MSM phases"}
         # sweep: 32 B x (distinct (column, rotation) reads + 1 write) per extended row
         sw = kernels["sweep"]
         if sw["ms_per_step"] > 0 and not shard:
             reads = len(shape.queries()) + len(shape.perm_columns) + 2 * shape.n_perm_sets + 5 * len(shape.lookups) + 3
-            alg = 32.0 * (reads + 1) * en
+            alg = 32.0 * (reads + 1) * q_rows
             main_ms = per_launch("sweep")
             # the lookup compressions run through the same kernel on 2^k rows; the quotient sweep is the one long launch
             ach = alg / (sw["ms_per_step"] / 1000.0) / 1e9
@@ -339,8 +348,11 @@ def main():
                              "traffic": round(traffic["sweep"]) if traffic and traffic["sweep"] else None, "algorithmic_bytes_per_launch": round(alg / max(sw["launches_per_step"], 1)),
                              "avg_launch_ms": round(main_ms, 4), "distinct_reads_per_row": reads, "timing": f"HIP events, {breakdown_passes} untimed passes"}
         res = {"value": round(ms_per_step / 1000.0, 6), "unit": "s", "steps": steps, "warmup": warmup, "ms_per_step": round(ms_per_step, 3),
-               "workload": f"{shape.name}: {counts['msm']} MSM_2^{shape.k} + {counts['intt_n']} iNTT_2^{shape.k} + {counts['ntt_ext']} NTT_2^{prover.dom.extended_k} + "
-                           f"1 iNTT_2^{prover.dom.extended_k} + sweep over 2^{prover.dom.extended_k} rows + lookup permute, {shape.n_perm_sets}+{len(shape.lookups)} grand products, "
+               "workload": f"{shape.name}: {counts['msm']} MSM_2^{shape.k} + {counts['intt_n']} iNTT_2^{shape.k} + " + (
+                               f"{counts['ntt_ext']} x {coset_q} coset NTT_2^{shape.k} + {coset_q} iNTT_2^{shape.k} + sweep over {coset_q} x 2^{shape.k} rows (the quotient on {coset_q} of the "
+                               f"{1 << (prover.dom.extended_k - shape.k)} cosets of the 2^{prover.dom.extended_k} extended domain)" if coset_q else
+                               f"{counts['ntt_ext']} NTT_2^{prover.dom.extended_k} + 1 iNTT_2^{prover.dom.extended_k} + sweep over 2^{prover.dom.extended_k} rows") +
+                           f" + lookup permute, {shape.n_perm_sets}+{len(shape.lookups)} grand products, "
                            f"evaluations, SHPLONK; satisfiable synthetic instance (valid proof), free witness cells "
                            + ("uniform field elements (the worst case for the commitments)" if witness == "uniform" or shape.layout == "sha" else
                               "drawn from SURVEY.md 8(d)'s value mix (limbs / bits / uniform)")

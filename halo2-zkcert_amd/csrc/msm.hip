@@ -412,11 +412,11 @@ __global__ void __launch_bounds__(256) k_sort_lo_staged(const uint32_t* part_off
 
 // The same pass for the default 4096-pair tile with ONE LDS atomic per pair: the counting atomic's return value is the pair's
 // rank inside its bin, kept in registers (16 pairs per thread) until the bins' starts are known.
-template <int PER_T>
-__global__ void __launch_bounds__(256) k_sort_lo_staged16(const uint32_t* part_off_all, const uint32_t* tile_start_all, SortGeom g,
+template <int PER_T, int NT>
+__global__ void __launch_bounds__(NT) k_sort_lo_staged16(const uint32_t* part_off_all, const uint32_t* tile_start_all, SortGeom g,
                                                           const uint32_t* tmp_entry_all, const uint16_t* tmp_key_all, size_t items,
                                                           const uint32_t* off_all, uint32_t* cursor_all, uint32_t* entries_all) {
-    __shared__ uint32_t w_tot[4];
+    __shared__ uint32_t w_tot[NT / 64];
     const uint32_t tid = threadIdx.x, col = blockIdx.y, blk = blockIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t* po = part_off_all + (size_t)col * SORT_PSTRIDE;
     const uint32_t* ts = tile_start_all + (size_t)col * SORT_PSTRIDE;
@@ -427,20 +427,20 @@ __global__ void __launch_bounds__(256) k_sort_lo_staged16(const uint32_t* part_o
         if (ts[mid] <= blk) lo_p = mid; else hi_p = mid;
     }
     const uint32_t p = lo_p;
-    const uint32_t beg = po[p] + (blk - ts[p]) * (PER_T * 256u), end = min(beg + (PER_T * 256u), po[p + 1]), cnt = end - beg;
+    const uint32_t beg = po[p] + (blk - ts[p]) * (PER_T * (uint32_t)NT), end = min(beg + (PER_T * (uint32_t)NT), po[p + 1]), cnt = end - beg;
     const uint32_t nbins = 1u << g.LB;
     uint32_t* hist = sort_lds;                 // [nbins] counts
     uint32_t* base = hist + nbins;             // [nbins] global position of the bin's run
     uint32_t* lst = base + nbins;              // [nbins] start of the bin inside the staged tile
     uint32_t* st_e = lst + nbins;              // [tile] staged entries
-    uint16_t* st_k = reinterpret_cast<uint16_t*>(st_e + (PER_T * 256u));   // [tile] their bins
-    for (uint32_t j = tid; j < nbins; j += 256) hist[j] = 0;
+    uint16_t* st_k = reinterpret_cast<uint16_t*>(st_e + (PER_T * (uint32_t)NT));   // [tile] their bins
+    for (uint32_t j = tid; j < nbins; j += NT) hist[j] = 0;
     __syncthreads();
     const uint16_t* tmp_key = tmp_key_all + (size_t)col * items;
     uint32_t keys[PER_T], ranks[PER_T];
 #pragma unroll
     for (int q = 0; q < PER_T; ++q) {
-        uint32_t j = beg + tid + q * 256;
+        uint32_t j = beg + tid + q * NT;
         keys[q] = j < end ? tmp_key[j] : 0xFFFFFFFFu;
     }
 #pragma unroll
@@ -449,7 +449,7 @@ __global__ void __launch_bounds__(256) k_sort_lo_staged16(const uint32_t* part_o
     const uint32_t bucket0 = p << g.LB;
     const uint32_t* off = off_all + (size_t)col * (g.B + 4);
     uint32_t* cursor = cursor_all + (size_t)col * g.B;
-    const uint32_t per = (nbins + 255) / 256;
+    const uint32_t per = (nbins + NT - 1) / NT;
     uint32_t my = 0;
     for (uint32_t q = 0; q < per; ++q) { uint32_t j = tid * per + q; if (j < nbins) my += hist[j]; }
     uint32_t inc = my;
@@ -474,13 +474,13 @@ __global__ void __launch_bounds__(256) k_sort_lo_staged16(const uint32_t* part_o
     for (int q = 0; q < PER_T; ++q) {
         if (keys[q] != 0xFFFFFFFFu) {
             uint32_t slot = lst[keys[q]] + ranks[q];
-            st_e[slot] = tmp_entry[beg + tid + q * 256];
+            st_e[slot] = tmp_entry[beg + tid + q * NT];
             st_k[slot] = (uint16_t)keys[q];
         }
     }
     __syncthreads();
     uint32_t* entries = entries_all + (size_t)col * items;
-    for (uint32_t i = tid; i < cnt; i += 256) {
+    for (uint32_t i = tid; i < cnt; i += NT) {
         uint32_t key = st_k[i];
         entries[base[key] + (i - lst[key])] = st_e[i];
     }
@@ -1083,15 +1083,31 @@ static int msm_local(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const 
         hipError_t attr_err = hipSuccess;
         std::call_once(attr_once, [&] {
             attr_err = hipFuncSetAttribute((const void*)k_sort_lo_staged, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)k_sort_lo_staged16<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)k_sort_lo_staged16<32, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)k_sort_lo_staged16<8, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)k_sort_lo_staged16<16, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)k_sort_lo_staged16<16, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)k_sort_lo_staged16<4, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         });
         ZK_HIP(attr_err);
         const bool one_atomic = ctx->opt.sort_one_atomic != 0;
-        if (g.tile == 8192 && one_atomic)
-            hipLaunchKernelGGL(k_sort_lo_staged16<32>, gt, dim3(256), lds, st, (const uint32_t*)d_part_off, (const uint32_t*)d_tile_start, g,
+        if (g.tile == 8192 && one_atomic && (ctx->opt.sort_wide == 1 || ctx->opt.sort_wide < 0))
+            hipLaunchKernelGGL((k_sort_lo_staged16<8, 1024>), gt, dim3(1024), lds, st, (const uint32_t*)d_part_off, (const uint32_t*)d_tile_start, g,
+                               (const uint32_t*)d_tmp_entry, (const uint16_t*)d_tmp_key, items, (const uint32_t*)d_off, d_cursor, (uint32_t*)d_entries);
+        else if (g.tile == 16384 && one_atomic && ctx->opt.sort_wide == 2)
+            hipLaunchKernelGGL((k_sort_lo_staged16<16, 1024>), gt, dim3(1024), lds, st, (const uint32_t*)d_part_off, (const uint32_t*)d_tile_start, g,
+                               (const uint32_t*)d_tmp_entry, (const uint16_t*)d_tmp_key, items, (const uint32_t*)d_off, d_cursor, (uint32_t*)d_entries);
+        else if (g.tile == 8192 && one_atomic && ctx->opt.sort_wide == 3)
+            hipLaunchKernelGGL((k_sort_lo_staged16<16, 512>), gt, dim3(512), lds, st, (const uint32_t*)d_part_off, (const uint32_t*)d_tile_start, g,
+                               (const uint32_t*)d_tmp_entry, (const uint16_t*)d_tmp_key, items, (const uint32_t*)d_off, d_cursor, (uint32_t*)d_entries);
+        else if (g.tile == 4096 && one_atomic && ctx->opt.sort_wide == 4)
+            hipLaunchKernelGGL((k_sort_lo_staged16<4, 1024>), gt, dim3(1024), lds, st, (const uint32_t*)d_part_off, (const uint32_t*)d_tile_start, g,
+                               (const uint32_t*)d_tmp_entry, (const uint16_t*)d_tmp_key, items, (const uint32_t*)d_off, d_cursor, (uint32_t*)d_entries);
+        else if (g.tile == 8192 && one_atomic)
+            hipLaunchKernelGGL((k_sort_lo_staged16<32, 256>), gt, dim3(256), lds, st, (const uint32_t*)d_part_off, (const uint32_t*)d_tile_start, g,
                                (const uint32_t*)d_tmp_entry, (const uint16_t*)d_tmp_key, items, (const uint32_t*)d_off, d_cursor, (uint32_t*)d_entries);
         else if (g.tile == SORT_TILE && one_atomic)
-            hipLaunchKernelGGL(k_sort_lo_staged16<16>, gt, dim3(256), lds, st, (const uint32_t*)d_part_off, (const uint32_t*)d_tile_start, g,
+            hipLaunchKernelGGL((k_sort_lo_staged16<16, 256>), gt, dim3(256), lds, st, (const uint32_t*)d_part_off, (const uint32_t*)d_tile_start, g,
                                (const uint32_t*)d_tmp_entry, (const uint16_t*)d_tmp_key, items, (const uint32_t*)d_off, d_cursor, (uint32_t*)d_entries);
         else
         hipLaunchKernelGGL(k_sort_lo_staged, gt, dim3(256), lds, st, (const uint32_t*)d_part_off, (const uint32_t*)d_tile_start, g,
