@@ -140,6 +140,8 @@ def main():
     ap.add_argument("--sha-advice", type=int, default=32)
     ap.add_argument("--sha-fixed", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the with_h2d passes (profiling runs: they split the advice commitment into two launches, "
+                    "which changes the per-launch averages a kernel trace reports)")
     ap.add_argument("--no-other-configs", action="store_true", help="time the headline configuration only")
     ap.add_argument("--other-steps", type=int, default=10)
     ap.add_argument("--shard", default="auto", choices=["auto", "points", "columns"],
@@ -279,7 +281,7 @@ def main():
             del batch, outs
         ctx.profile_enable(False)
         h2d = None
-        if with_h2d and world == 1 and not args.python_schedule:
+        if with_h2d and world == 1 and not args.python_schedule and not args.no_h2d:
             # the same step with the advice columns handed over as pinned HOST arrays (a Rust caller's Vec<Fr> columns) and the
             # instance columns built from the instance values: the uploads are inside the timed region
             prover.prove_native(wit, transcript=kind, host_inputs=True)
@@ -307,9 +309,10 @@ def main():
         alg = 96.0 * pairs / a_l
         avg_s = live["ms_per_step"] / a_l / 1000.0
         ach = alg / avg_s / 1e9 if avg_s > 0 else 0.0
-        # one XYZZ mixed addition (8 products + 2 squarings) per (non-zero digit, point) pair: zero digits are skipped, so the count is
+        # one XYZZ mixed addition (8 products + 2 squarings, 9 reductions) per (non-zero digit, point) pair: zero digits are skipped, so the count is
         # the one the library reports from its sort (dense = n x windows per column; bit / small-valued columns have far fewer)
-        mads = real_pairs * (8 * 171 + 2 * 126)
+        # v_mad_u64_u32 per addition: 8 products x 81 + 2 squarings x 45 + 9 Montgomery reductions x 90 (r (Q - X3) - Y1 PPP shares one)
+        mads = real_pairs * (8 * 81 + 2 * 45 + 9 * 90)
         int_ach = mads / (live["ms_per_step"] / 1000.0) / 1e12 if live["ms_per_step"] > 0 else 0.0
         roof["msm_accum_affine"] = {"kernel": "k_accum_affine", "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": round(traffic["msm_accum_affine"]) if traffic and traffic["msm_accum_affine"] else None,

@@ -44,7 +44,7 @@ def main():
             ctx.to_host(params.commit_batch_device(cols))
             prof = {nm: round(ctx.profile_read(nm)[0], 3) for nm in ("msm_digits", "msm_plan", "msm_accum_affine", "msm_accum_jac", "msm_tail")}
             ctx.profile_enable(False)
-            mads = ncols * n * W * (8 * 171 + 2 * 126)   # XYZZ mixed add: 8M + 2S
+            mads = ncols * n * W * (8 * 81 + 2 * 45 + 9 * 90)   # XYZZ mixed add: 8M + 2S, 9 reductions
             print(f"MSM k={k} c={c} W={W} ncols={ncols}: {ms:.3f} ms total ({ms / ncols:.3f} ms/col)  {prof}  "
                   f"accum {mads / prof['msm_accum_affine'] / 1e9:.2f} Tmad/s", flush=True)
         params.free()

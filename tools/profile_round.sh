@@ -13,7 +13,7 @@ export TMPDIR=/tmp
 python3 tools/kernel_bench.py > "$out/kernel_bench.txt" 2> "$out/bench.err"
 cd /tmp
 for cfg in rsa17 sha19 agg22; do
-    args="--config $cfg --no-other-configs --no-cpu-baseline --steps 3 --warmup 1"
+    args="--config $cfg --no-other-configs --no-cpu-baseline --no-h2d --steps 3 --warmup 1"
     rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_$cfg" -- python3 "$root/bench.py" $args > "$out/stats_$cfg.json" 2> "$out/stats_$cfg.err"
     for c in FETCH_SIZE WRITE_SIZE SQ_LDS_BANK_CONFLICT; do
         rocprofv3 --pmc $c --output-format csv -d "$out/pmc_${cfg}_$c" -- python3 "$root/bench.py" $args > "$out/pmc_${cfg}_$c.json" 2> "$out/pmc_${cfg}_$c.err"
