@@ -122,6 +122,20 @@ def test_create_proof_same_bytes_on_either_domain(zk, oracle, k):
     cp = pv.Prover(OracleBackend(8), sh, satisfiable=True)
     w = gp.witness(3)
     on = gp.prove_native(w, transcript="poseidon")
+    # on the coset path the key's extended cosets are not read: a caller may leave them out ...
+    pk = gp._native_key()
+    saved = {f: getattr(pk, f) for f in ("fixed_cosets", "sigma_cosets", "l0", "l_last", "l_active_row")}
+    for f in saved:
+        setattr(pk, f, None)
+    try:
+        assert gp.prove_native(w, transcript="poseidon")["proof"] == on["proof"]
+        ctx.set_option("coset_quotient", 0)      # ... but the extended-domain path needs them and says so
+        with pytest.raises(ffi.ZkhipError, match="extended cosets are missing"):
+            gp.prove_native(w, transcript="poseidon")
+    finally:
+        ctx.set_option("coset_quotient", 1)
+        for f, v in saved.items():
+            setattr(pk, f, v)
     ctx.set_option("coset_quotient", 0)
     try:
         off = gp.prove_native(w, transcript="poseidon")
