@@ -152,7 +152,9 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
     const bool split_upload = in->advice_on_host && A && (size_t)A * NB >= ((size_t)64 << 20);
     // many columns (the SHA-256 circuit's 32): uploaded and committed in up to 4 groups of >= 8 columns, so that the commitment of group
     // g runs while group g + 1 is still on the wire; few big columns (the aggregation circuit's 4): one group behind the random polynomial
-    const uint32_t n_groups = split_upload ? std::max<uint32_t>(1, std::min<uint32_t>(4, A / 8)) : 1;
+    // few columns of >= 64 MiB each (k >= 21: a column's upload, 2.5 ms, is shorter than its commitment): groups of two columns, up to 4
+    // groups — every extra batch costs a host round trip and a latency-bound tail, so no finer
+    const uint32_t n_groups = !split_upload ? 1 : NB >= ((size_t)64 << 20) ? std::min<uint32_t>(4, (A + 1) / 2) : std::max<uint32_t>(1, std::min<uint32_t>(4, A / 8));
     auto group_begin = [&](uint32_t g_) { return (uint32_t)((uint64_t)A * g_ / n_groups); };
     if (split_upload) {
         if (!ctx->copy_stream) {
