@@ -164,6 +164,39 @@ ZK_HD __forceinline__ fe fe_mul2_raw(const fe& a, const fe& b, const fe& c, cons
     return r;
 }
 
+// sum_{k < N} a_k * b_k / 2^261 mod p with ONE reduction (N <= 4: columns stay below (N + 1) * 9 * 2^58 < 2^64).
+// Normalised inputs; output < (sum A_k B_k / 128 + 1) p.
+template <class P, int N>
+ZK_HD __forceinline__ fe fe_dot_raw(const fe* a, const fe* b) {
+    static_assert(N >= 1 && N <= 4, "fe_dot_raw: at most four products per reduction");
+    uint64_t acc[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) acc[j] = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+#pragma unroll
+            for (int j = 0; j < 9; ++j) acc[j] += (uint64_t)a[k].l[j] * b[k].l[i];
+        uint32_t q = ((uint32_t)acc[0] * P::INV) & LMASK;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) acc[j] += (uint64_t)q * P::M[j];
+        uint64_t carry = acc[0] >> LB;
+        acc[0] = acc[1] + carry;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) acc[j] = acc[j + 1];
+        acc[8] = 0;
+    }
+    fe r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        r.l[j] = (uint32_t)acc[j] & LMASK;
+        acc[j + 1] += acc[j] >> LB;
+    }
+    r.l[8] = (uint32_t)acc[8];
+    return r;
+}
+
 // a * a / 2^261 mod p: the 36 cross products once (doubled), 9 squares, then the 81 reduction products:
 // 126 multiplier instructions instead of 171.  Columns stay below 2 * 4 * 2^58 + 2^58 + 9 * 2^58 < 2^63.
 template <class P>
@@ -315,6 +348,14 @@ struct el {
 template <class P, int A, int B>
 ZK_HD __forceinline__ el<P, mul_bound(A, B)> operator*(const el<P, A>& a, const el<P, B>& b) {
     return el<P, mul_bound(A, B)>(fe_mul_raw<P>(a.v, b.v));
+}
+// a0 b0 + a1 b1 + a2 b2 + a3 b3 with one reduction (all eight operands < 2p)
+template <class P>
+ZK_HD __forceinline__ el<P, mul_bound(4 * U, 4 * U) + 0> dot4(const el<P, 2 * U>& a0, const el<P, 2 * U>& b0, const el<P, 2 * U>& a1, const el<P, 2 * U>& b1,
+                                                            const el<P, 2 * U>& a2, const el<P, 2 * U>& b2, const el<P, 2 * U>& a3, const el<P, 2 * U>& b3) {
+    // 4 * (2p * 2p) / 128 + 1 p = (16 p^2 / 128 p) + p < 2p: the bound of a product of two 4p values
+    fe a[4] = {a0.v, a1.v, a2.v, a3.v}, b[4] = {b0.v, b1.v, b2.v, b3.v};
+    return el<P, mul_bound(4 * U, 4 * U)>(fe_dot_raw<P, 4>(a, b));
 }
 // a * b + c * d with one reduction
 constexpr int mul2_bound(int a, int b, int c, int d) { return (a * b + c * d + 128 * U - 1) / (128 * U) + U; }

@@ -109,7 +109,8 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
         ZK_HIP(hipEventCreateWithFlags(&ctx->side_event, hipEventDisableTiming));
     }
     const bool late = ctx->opt.late_overlap >= 0 ? ctx->opt.late_overlap != 0 : k <= 18;
-    Overlap ov{ctx, ctx->stream, ctx->side_stream, ctx->side_event, late};
+    const bool serial = ctx->opt.late_overlap == 2;   // analysis only: everything on the main stream, so a kernel trace shows isolated durations
+    Overlap ov{ctx, ctx->stream, serial ? ctx->stream : ctx->side_stream, ctx->side_event, late};
     StreamGuard guard{ctx, ctx->stream};
     hipStream_t st = ctx->stream;
 

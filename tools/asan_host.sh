@@ -9,7 +9,7 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/build/asan
 mkdir -p "$out"
 rt=$(find /opt/rocm*/lib/llvm/lib/clang -name 'libclang_rt.asan-x86_64.so' | head -1)
-for f in ctx comm msm ntt sweep srs_gen polyops permute shplonk prover transcript selftest; do
+for f in ctx comm msm ntt sweep cosets srs_gen polyops permute shplonk prover transcript selftest; do
     /opt/rocm/bin/hipcc -O1 -g -std=c++17 -fPIC --offload-arch=gfx950 -Xarch_host -fsanitize=address,undefined -Xarch_host -fno-omit-frame-pointer \
         -Wno-unused-function -c "$root/halo2-zkcert_amd/csrc/$f.hip" -o "$out/$f.o" &
 done
