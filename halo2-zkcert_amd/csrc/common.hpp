@@ -185,5 +185,6 @@ int cosets_to_pieces(zkhip_ctx* ctx, const CosetPlan* p, void* d_vals, void* d_p
 struct KeyCosets { std::vector<const void*> fixed, sigma; const void* l0; const void* l_last; const void* l_active; };
 int key_cosets(zkhip_ctx* ctx, const CosetPlan* p, const zk_proving_key* pk, const KeyCosets** out);
 void coset_sweep_view(const CosetPlan* p, SweepCosets* out);
+void coset_forget_key(zkhip_ctx* ctx, uint64_t key_id);   // the plans' host-side entries of a released key (the device buffers are the caller's to free)
 }
 static inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }

@@ -191,6 +191,11 @@ int zk::key_cosets(zkhip_ctx* ctx, const CosetPlan* cp, const zk_proving_key* pk
     return ZKHIP_OK;
 }
 
+void zk::coset_forget_key(zkhip_ctx* ctx, uint64_t key_id) {
+    for (auto& kv : ctx->host_objects)
+        if (kv.first.compare(0, 11, "coset_plan:") == 0) static_cast<CosetPlan*>(kv.second.get())->keys.erase(key_id);
+}
+
 // ------------------------------------------------------------------ C ABI
 extern "C" {
 int zkhip_domain_cosets(zkhip_ctx* ctx, const zkhip_domain* dom, uint32_t* q, uint64_t* shifts) {

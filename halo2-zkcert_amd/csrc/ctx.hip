@@ -220,6 +220,22 @@ int zkhip_trim(zkhip_ctx* c) {
     }
     return ZKHIP_OK;
 }
+int zkhip_key_release(zkhip_ctx* c, uint64_t key_id) {
+    if (!c) { set_error("null ctx"); return ZKHIP_EINVAL; }
+    ZK_HIP(hipDeviceSynchronize());
+    char a[48], b[48];
+    snprintf(a, sizeof a, "pe_table_keys:%llx:", (unsigned long long)key_id);
+    snprintf(b, sizeof b, "key_cosets:%llx:", (unsigned long long)key_id);
+    for (auto it = c->persistent.begin(); it != c->persistent.end();) {
+        const std::string& k = it->first;
+        if (k.compare(0, strlen(a), a) == 0 || k.compare(0, strlen(b), b) == 0) {
+            if (it->second) (void)hipFree(it->second);
+            it = c->persistent.erase(it);
+        } else ++it;
+    }
+    zk::coset_forget_key(c, key_id);
+    return ZKHIP_OK;
+}
 int zkhip_synchronize(zkhip_ctx* c) {
     if (!c) { set_error("null ctx"); return ZKHIP_EINVAL; }
     ZK_HIP(hipStreamSynchronize(c->stream));

@@ -53,7 +53,7 @@ class ZkEvalhArgs(C.Structure):
 
 # every symbol include/zkhip.h declares (checked by tests/test_abi.py without a GPU)
 SYMBOLS = [
-    "zkhip_init", "zkhip_destroy", "zkhip_last_error", "zkhip_set_stream", "zkhip_synchronize", "zkhip_set_option", "zkhip_trim",
+    "zkhip_init", "zkhip_destroy", "zkhip_last_error", "zkhip_set_stream", "zkhip_synchronize", "zkhip_set_option", "zkhip_trim", "zkhip_key_release",
     "zkhip_comm_unique_id", "zkhip_comm_init", "zkhip_comm_init_host", "zkhip_comm_destroy", "zkhip_comm_info", "zkhip_comm_allgather_device", "zkhip_comm_shard_columns",
     "zkhip_kzg_setup_range", "zkhip_srs_load_range", "zkhip_srs_range", "zkhip_malloc", "zkhip_free",
     "zkhip_memcpy_h2d", "zkhip_memcpy_d2h", "zkhip_timer_start", "zkhip_timer_stop_ms",
@@ -180,6 +180,10 @@ class Context:
 
     def trim(self):
         _check(lib().zkhip_trim(self.h))
+
+    def key_release(self, key_id):
+        """frees what the context caches per proving key (sorted lookup tables, the key's columns in the coset layout)"""
+        _check(lib().zkhip_key_release(self.h, C.c_uint64(int(key_id))))
 
     # ---- one proof over several GPUs (zkhip_comm_*): one process per GPU
     world, rank = 1, 0

@@ -874,6 +874,11 @@ class Prover:
             w += [(("lookup_z", i_), 0), (("lookup_z", i_), 1), (("lookup_a", i_), 0), (("lookup_a", i_), -1), (("lookup_s", i_), 0)]
         return w
 
+    def release(self):
+        """drops what the library's context caches for this proving key (zkhip_key_release): call when the Prover is done"""
+        if getattr(self, "_npk", None) is not None and hasattr(self.b, "ctx") and hasattr(self.b.ctx, "key_release"):
+            self.b.ctx.key_release(self._npk.key_id)
+
     def _native_key(self):
         """zk_proving_key for zkhip_create_proof (built once; the arrays it points to are kept alive on self)"""
         if getattr(self, "_npk", None) is not None:

@@ -58,6 +58,9 @@ int  zkhip_synchronize(zkhip_ctx* ctx);
 int  zkhip_set_option(zkhip_ctx* ctx, const char* name, int value);
 /* Frees the scratch buffers of streams the context no longer uses (scratch is per stream).  Synchronises the device. */
 int  zkhip_trim(zkhip_ctx* ctx);
+/* Drops what the context keeps per proving key (zk_proving_key.key_id): the sorted lookup tables and the key's columns in the coset
+ * layout.  Call it when a ProvingKey is dropped; a later proof with the same key_id rebuilds them.  Synchronises the device. */
+int  zkhip_key_release(zkhip_ctx* ctx, uint64_t key_id);
 int  zkhip_malloc(zkhip_ctx* ctx, size_t bytes, void** dptr);
 int  zkhip_free(zkhip_ctx* ctx, void* dptr);
 int  zkhip_memcpy_h2d(zkhip_ctx* ctx, void* dst, const void* src, size_t bytes);

@@ -154,3 +154,24 @@ def test_create_proof_same_bytes_on_either_domain(zk, oracle, k):
         assert on_bad["commitments"][:nq] == off_bad["commitments"][:nq]
     finally:
         ctx.set_option("coset_quotient", 1)
+
+
+def test_key_release_frees_the_cached_columns(zk, oracle):
+    """zkhip_key_release: the per-key caches (coset-layout fixed / sigma / l columns, sorted lookup table) go back to the allocator
+    and a later proof with the same key rebuilds them — same bytes"""
+    import torch
+
+    ffi, ctx = zk
+    k = 14
+    gp = pv.Prover(pv.GpuBackend(ctx, ffi), pv.CircuitShape.small(k), satisfiable=True)
+    w = gp.witness(1)
+    first = gp.prove_native(w, transcript="poseidon")["proof"]
+    torch.cuda.synchronize()
+    held = torch.cuda.mem_get_info()[0]
+    gp.release()
+    freed = torch.cuda.mem_get_info()[0] - held
+    sh = gp.shape
+    cached = (len(gp.fixed_lagrange) + len(sh.perm_columns) + 3) * 3 * (32 << k)      # the key's columns on 3 cosets
+    assert freed >= cached, (freed, cached)
+    assert gp.prove_native(w, transcript="poseidon")["proof"] == first
+    gp.release()
