@@ -493,7 +493,10 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
     // Up to 9 bits per pass (T = 4..8 elements per contiguous run).  Measured on MI355X: 6-bit passes with
     // 1 KiB runs are 7 % SLOWER at 2^24 than 8/9-bit passes — the kernels are bound by per-element work
     // (butterfly products, the inter-pass twiddle, canonical stores), not by the run length.
-    uint32_t smax = 9;
+    // Round 2, isolated batches of 8 (tools/ntt_plan_bench.py): two passes of up to 11 bits beat three of 6-7 bits up to 2^21 (2^19 -10 %,
+    // 2^20 -14 %, 2^21 -6 %: a polynomial is <= 64 MiB and the 32-64 byte runs of the second pass still hit the last-level cache);
+    // at 2^22 11 + 11 is 1.4 % slower than 8 + 7 + 7, from 2^23 both plans are three passes.
+    uint32_t smax = m >= 22 ? 10 : 11;
     { int v = ctx->opt.ntt_smax; if (v >= 4 && v <= 11) smax = (uint32_t)v; }
     uint32_t np = m <= 11 ? 1 : (m + smax - 1) / smax;
     if (np > 6) { set_error("ntt: too many passes"); return ZKHIP_EINVAL; }
