@@ -263,10 +263,19 @@ __global__ void __launch_bounds__(256) k_sort_hi(const ColPtrs scalar_cols, size
     uint32_t* st_e = sort_lds;                                                // [256 W]
     uint16_t* st_k = reinterpret_cast<uint16_t*>(st_e + 256 * g.W);           // [256 W]
     uint8_t* st_p = reinterpret_cast<uint8_t*>(st_k + 256 * g.W);             // [256 W]
-    if (tid == 0) {   // <= 256 partitions: a serial scan is cheaper than a barrier tree
-        uint32_t run = 0;
-        for (uint32_t p = 0; p < g.P; ++p) { lst[p] = run; run += cnt_of[p]; }
-        lst[g.P] = run;
+    {   // exclusive scan of the <= 256 partition counts: wave shuffles + the four wave totals (a serial loop on one thread cost ~2 us per block)
+        __shared__ uint32_t wtot[4];
+        const uint32_t lane = tid & 63, wave = tid >> 6;
+        const uint32_t mine = tid < g.P ? cnt_of[tid] : 0u;
+        uint32_t inc = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { uint32_t u = __shfl_up(inc, d); if ((int)lane >= d) inc += u; }
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        uint32_t before = 0;
+        for (uint32_t w_ = 0; w_ < wave; ++w_) before += wtot[w_];
+        if (tid < g.P) lst[tid] = before + inc - mine;
+        if (tid == 255) lst[g.P] = before + inc;   // g.P <= 256: thread 255's inclusive total is the block's (counts beyond P are 0)
     }
     __syncthreads();
     if (tid < g.P) hist[tid] = lst[tid];
