@@ -48,7 +48,7 @@ struct Scratch {
 // zkhip_set_option — never looked up on the hot path.  0 / -1 = "use the measured default".
 struct zkhip_options {
     int msm_c = 0, msm_seg = 0, msm_tailparts = 0, msm_ch = 0, msm_widetail = -1, msm_adaptive_l = 1, msm_debug = 0;
-    int sort_hb = 0, sort_tile = 0, sort_one_atomic = 1, sort_wide = -1;   // sort_wide: low-pass block shape (-1: 1024 threads x 8 pairs for 8192-pair tiles)
+    int sort_hb = 0, sort_tile = 0, sort_one_atomic = 1, sort_copies = 0, sort_wide = -1;   // sort_wide: low-pass block shape (-1: 1024 threads x 8 pairs for 8192-pair tiles)
     int ntt_smax = 0, ntt_r8 = 1, ntt_group = 0;
     int permute_rank_sort = 1, eval_byval = 1, late_overlap = -1;
     int host_timing = 0;   // zkhip_create_proof prints its host-side phase times to stderr

@@ -122,7 +122,7 @@ const OptName OPTIONS[] = {
     {"ZKHIP_MSM_TAILPARTS", "msm_tailparts", &zkhip_options::msm_tailparts}, {"ZKHIP_MSM_CH", "msm_ch", &zkhip_options::msm_ch},
     {"ZKHIP_MSM_WIDETAIL", "msm_widetail", &zkhip_options::msm_widetail}, {"ZKHIP_MSM_ADAPTIVE_L", "msm_adaptive_l", &zkhip_options::msm_adaptive_l},
     {"ZKHIP_MSM_DEBUG", "msm_debug", &zkhip_options::msm_debug}, {"ZKHIP_SORT_HB", "sort_hb", &zkhip_options::sort_hb},
-    {"ZKHIP_SORT_TILE", "sort_tile", &zkhip_options::sort_tile}, {"ZKHIP_SORT_ONE_ATOMIC", "sort_one_atomic", &zkhip_options::sort_one_atomic}, {"ZKHIP_SORT_WIDE", "sort_wide", &zkhip_options::sort_wide},
+    {"ZKHIP_SORT_TILE", "sort_tile", &zkhip_options::sort_tile}, {"ZKHIP_SORT_ONE_ATOMIC", "sort_one_atomic", &zkhip_options::sort_one_atomic}, {"ZKHIP_SORT_WIDE", "sort_wide", &zkhip_options::sort_wide}, {"ZKHIP_SORT_COPIES", "sort_copies", &zkhip_options::sort_copies},
     {"ZKHIP_NTT_SMAX", "ntt_smax", &zkhip_options::ntt_smax}, {"ZKHIP_NTT_R8", "ntt_r8", &zkhip_options::ntt_r8},
     {"ZKHIP_NTT_GROUP", "ntt_group", &zkhip_options::ntt_group}, {"ZKHIP_PERMUTE_RANK_SORT", "permute_rank_sort", &zkhip_options::permute_rank_sort},
     {"ZKHIP_EVAL_BYVAL", "eval_byval", &zkhip_options::eval_byval}, {"ZKHIP_LATE_OVERLAP", "late_overlap", &zkhip_options::late_overlap},

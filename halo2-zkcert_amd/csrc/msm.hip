@@ -162,9 +162,13 @@ int srs_build_raw(zkhip_ctx* ctx, const void* d_bases_raw, size_t n, zkhip_srs**
 // device table
 struct ColPtrs { const uint32_t* const* dev; const uint32_t* val[16]; };
 __device__ __forceinline__ const uint32_t* col_ptr(const ColPtrs& c, uint32_t col) { return c.dev ? c.dev[col] : c.val[col]; }
-struct SortGeom { uint32_t c, W, B, HB, LB, P, tile; };   // tile: pairs of one partition handled by one workgroup of the low pass
+struct SortGeom { uint32_t c, W, B, HB, LB, P, tile, R; };   // R: copies of the partition counters (power of two <= SORT_COPIES)   // tile: pairs of one partition handled by one workgroup of the low pass
 #define SORT_TILE 4096u
 #define SORT_MAXP 256u     // partitions of the high radix pass (HB <= 8)
+// The high pass's 2 x P global counters per column (partition sizes, then scatter cursors) are hit by every workgroup: 16384 returning
+// atomics per address at 2^22, all of them in eight 128-byte lines — measured 0.2 ms per column, half of the pass.  They are kept in
+// R copies (workgroup b uses copy b mod R; k_part_scan turns the counts into per-copy bases inside each partition's range).
+#define SORT_COPIES 64u
 #define SORT_PSTRIDE 260u  // part_off / tile_start: P + 1 entries per column, padded
 
 extern __shared__ uint32_t sort_lds[];   // staging area of the two scatter kernels
@@ -229,14 +233,17 @@ __global__ void __launch_bounds__(256) k_sort_hi(const ColPtrs scalar_cols, size
         }
     }
     __syncthreads();
-    uint32_t* part_cnt = part_cnt_all + (size_t)col * SORT_MAXP;
+    const uint32_t copy = blockIdx.x & (g.R - 1);
+    uint32_t* part_cnt = part_cnt_all + (size_t)col * SORT_MAXP * SORT_COPIES;   // [copy][partition]: counts, after k_part_scan the copy's base
     if (!SCATTER) {
-        if (tid < g.P && hist[tid]) atomicAdd(&part_cnt[tid], hist[tid]);
+        if (tid < g.P && hist[tid]) atomicAdd(&part_cnt[copy * SORT_MAXP + tid], hist[tid]);
         return;
     }
     if (tid < g.P) {
         uint32_t h = hist[tid];
-        base[tid] = h ? part_off_all[(size_t)col * SORT_PSTRIDE + tid] + atomicAdd(&part_cursor_all[(size_t)col * SORT_MAXP + tid], h) : 0u;
+        base[tid] = h ? part_off_all[(size_t)col * SORT_PSTRIDE + tid] + part_cnt[copy * SORT_MAXP + tid] +
+                            atomicAdd(&part_cursor_all[((size_t)col * SORT_COPIES + copy) * SORT_MAXP + tid], h)
+                      : 0u;
         cnt_of[tid] = h;
         hist[tid] = 0;
     }
@@ -304,10 +311,15 @@ __global__ void __launch_bounds__(256) k_sort_hi(const ColPtrs scalar_cols, size
 }
 
 // part_off = exclusive scan of part_cnt (P + 1 entries); tile_start = exclusive scan of ceil(part_cnt / tile).
-__global__ void __launch_bounds__(SORT_MAXP) k_part_scan(const uint32_t* part_cnt_all, uint32_t P, uint32_t tile, uint32_t* part_off_all, uint32_t* tile_start_all) {
+// (the R copies of a partition's count are replaced by their exclusive prefix: the copy's base inside the partition's range)
+__global__ void __launch_bounds__(SORT_MAXP) k_part_scan(uint32_t* part_cnt_all, uint32_t P, uint32_t R, uint32_t tile, uint32_t* part_off_all, uint32_t* tile_start_all) {
     __shared__ uint32_t a[SORT_MAXP], b[SORT_MAXP];
     uint32_t col = blockIdx.x, t = threadIdx.x;
-    uint32_t v = t < P ? part_cnt_all[(size_t)col * SORT_MAXP + t] : 0u;
+    uint32_t v = 0;
+    if (t < P) {
+        uint32_t* pc = part_cnt_all + (size_t)col * SORT_MAXP * SORT_COPIES + t;
+        for (uint32_t r = 0; r < R; ++r) { uint32_t c = pc[r * SORT_MAXP]; pc[r * SORT_MAXP] = v; v += c; }
+    }
     uint32_t tl = (v + tile - 1) / tile;
     a[t] = v; b[t] = tl;
     __syncthreads();
@@ -987,6 +999,9 @@ static int msm_local(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const 
     const size_t pstride0 = items / seg0_min + B + 1;
     SortGeom g;
     g.c = c; g.W = W; g.B = B;
+    g.R = 1;
+    while (g.R < SORT_COPIES && (size_t)g.R * 512 <= div_up(n, 256)) g.R *= 2;   // ~256+ workgroups per copy
+    { int v = ctx->opt.sort_copies; if (v >= 1 && v <= (int)SORT_COPIES && (v & (v - 1)) == 0) g.R = (uint32_t)v; }
     const uint32_t KB = c - 1;
     g.HB = KB >= 18 ? 8 : (KB > 8 ? 7 : KB / 2);   // 256 partitions from c = 19 (measured: digits -14 % at 2^20, -8 % at 2^21)
     { int v = ctx->opt.sort_hb; if (v >= 1 && v <= 8 && v < (int)KB && (int)KB - v <= 11) g.HB = (uint32_t)v; }
@@ -999,11 +1014,11 @@ static int msm_local(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const 
     if (g.LB > 11) { set_error("zkhip_msm: window c = %u unsupported by the sort (max 20)", c); return ZKHIP_EINVAL; }
     ZK_TRY(ctx->get_scratch("msm_colptrs", 2 * ncols * sizeof(void*), &d_colptrs));
     // zeroed every call: part_cnt[SORT_MAXP] + part_cursor[SORT_MAXP] + cnt[B] + cursor[B] per column
-    const size_t zero_words = ncols * (2 * (size_t)SORT_MAXP + 2 * (size_t)B);
+    const size_t zero_words = ncols * (2 * (size_t)SORT_MAXP * SORT_COPIES + 2 * (size_t)B);
     ZK_TRY(ctx->get_scratch("msm_zero", zero_words * 4, &d_zero));
     uint32_t* d_part_cnt = (uint32_t*)d_zero;
-    uint32_t* d_part_cursor = d_part_cnt + ncols * SORT_MAXP;
-    uint32_t* d_cnt = d_part_cursor + ncols * SORT_MAXP;
+    uint32_t* d_part_cursor = d_part_cnt + ncols * SORT_MAXP * SORT_COPIES;
+    uint32_t* d_cnt = d_part_cursor + ncols * SORT_MAXP * SORT_COPIES;
     uint32_t* d_cursor = d_cnt + ncols * (size_t)B;
     void* d_part;
     ZK_TRY(ctx->get_scratch("msm_part", ncols * 2 * SORT_PSTRIDE * 4, &d_part));   // part_off + tile_start, SORT_PSTRIDE each per column
@@ -1068,7 +1083,7 @@ static int msm_local(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const 
     { ProfScope ps(ctx, "msm_digits");
     hipLaunchKernelGGL(k_sort_hi<false>, gn, dim3(256), 0, st, cp_scalars, n, first, srs->n, g, d_part_cnt, d_part_cursor,
                        (const uint32_t*)d_part_off, (uint32_t*)d_tmp_entry, (uint16_t*)d_tmp_key, items);
-    hipLaunchKernelGGL(k_part_scan, dim3((unsigned)ncols), dim3(SORT_MAXP), 0, st, (const uint32_t*)d_part_cnt, g.P, g.tile, d_part_off, d_tile_start);
+    hipLaunchKernelGGL(k_part_scan, dim3((unsigned)ncols), dim3(SORT_MAXP), 0, st, d_part_cnt, g.P, g.R, g.tile, d_part_off, d_tile_start);
     hipLaunchKernelGGL(k_sort_hi<true>, gn, dim3(256), g.W <= 24 ? (size_t)256 * g.W * 7 + 16 : 0, st, cp_scalars, n, first, srs->n, g, d_part_cnt, d_part_cursor,
                        (const uint32_t*)d_part_off, (uint32_t*)d_tmp_entry, (uint16_t*)d_tmp_key, items);
     hipLaunchKernelGGL(k_sort_lo_count, gt, dim3(256), 0, st, (const uint32_t*)d_part_off, (const uint32_t*)d_tile_start, g,
