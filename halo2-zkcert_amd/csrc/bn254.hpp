@@ -452,6 +452,13 @@ template <class P>
 ZK_HD __forceinline__ el<P, 32 * U> load_x32(const void* p) { return el<P, 32 * U>(fe_split<5>(mem_load(p))); }
 template <class P, int A>
 ZK_HD __forceinline__ void store_raw(void* p, const el<P, A>& a) { mem_store(p, fe_pack(fe_canonical<P>(a.v))); }
+// a value < 4p (< 2^256) packed as it is, NOT reduced below p: for intermediate buffers whose readers take lazy inputs (the NTT's
+// pass-to-pass buffers: the next pass loads "< 2p" operands anyway) — saves fe_canonical's three conditional subtractions
+template <class P, int A>
+ZK_HD __forceinline__ void store_packed(void* p, const el<P, A>& a) {
+    static_assert(A <= 4 * U, "store_packed: the value must fit 256 bits");
+    mem_store(p, fe_pack(a.v));
+}
 template <class P, int A>
 ZK_HD __forceinline__ fe32 to_abi(const el<P, A>& a) {
     static_assert(A <= 88 * U, "to_abi input bound");

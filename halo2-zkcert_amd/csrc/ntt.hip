@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(256) k_ntt_strided(const uint32_t* const* srcs
             if (e < cnt) {
                 uint32_t tl = e & (T - 1), r = e >> logT;
                 tile_el v(tile[r * T + tl]);
-                store_raw<Fr>(dst + (size_t)(base | (r << lo_bits) | tl) * 8, v * el2<Fr>(twr[it]));
+                store_packed<Fr>(dst + (size_t)(base | (r << lo_bits) | tl) * 8, v * el2<Fr>(twr[it]));   // < 2p, read by the next pass only
             }
         }
         __syncthreads();   // the tile is reloaded for the next polynomial
@@ -381,7 +381,7 @@ __global__ void __launch_bounds__(256, 2) k_ntt_strided_r8(const NttPtrs PT, uin
         uint32_t L = L_last | ((uint32_t)q << p_last);
         uint32_t tl = L & (T - 1), r = L >> logT;
         uint32_t rel = (r << lo_bits) | lo0 | tl;
-        store_raw<Fr>(dst + ((size_t)(hi << (s + lo_bits)) | rel) * 8, tile_el(v[q]) * load_raw<Fr>(ptab + (size_t)rel * 8));
+        store_packed<Fr>(dst + ((size_t)(hi << (s + lo_bits)) | rel) * 8, tile_el(v[q]) * load_raw<Fr>(ptab + (size_t)rel * 8));   // < 2p, read by the next pass only
     }
 }
 
