@@ -1035,7 +1035,7 @@ static int msm_local(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const 
     ZK_TRY(ctx->get_scratch("msm_offB", ncols * (B + 4) * 4, &d_offB));
     ZK_TRY(ctx->get_scratch("msm_pA", ncols * pstride0 * PART_WORDS * 4, &d_pA));
     ZK_TRY(ctx->get_scratch("msm_pB", ncols * pstride0 * PART_WORDS * 4, &d_pB));
-    uint32_t CH = B > 8192 ? B / 8192 : 1;
+    uint32_t CH = B > 8192 ? std::min<uint32_t>(B / 8192, 32) : 1;   // 2^19 buckets (c = 20): 32 beats 64 by 0.4 ms per k = 22 proof, 16 equals 32
     { int v = ctx->opt.msm_ch; if (v >= 1 && v <= 256) CH = (uint32_t)v; }
     uint32_t nchunks = (B + CH - 1) / CH;
     // a wide batch has enough chunks to fill the chip with one lane each; otherwise four lanes share every point operation
