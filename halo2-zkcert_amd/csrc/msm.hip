@@ -54,6 +54,17 @@ __global__ void k_import_bases(const uint32_t* in_xy_abi, uint32_t* out_xy_raw, 
     g1a_store_raw(out_xy_raw + i * 16, a);
     g1j_store_raw(out_xyz_raw + i * 24, g1j_from_affine(a));
 }
+// Window layout: W = ceil(255 / c) windows over the 254 bits a recoded scalar (<= (r - 1) / 2 < 2^253, plus room for the last carry)
+// can occupy.  Windows 0 .. W-3 are c bits wide; the LAST TWO share the remaining R = 254 - (W - 2) c bits evenly (c = 20: 17 + 17
+// instead of 20 + 14).  With a 14-bit top window every one of its n digits fell into the first 2^13 buckets — 512 entries per bucket
+// at 2^22 against 96 elsewhere, i.e. 10 partial sums in those buckets and a reduction round (k_accum_jac) for every MSM; two 17-bit
+// windows put 2 x 64 extra entries into the first 2^16 buckets (3.4 partial sums: none).
+ZK_HD __forceinline__ void window_at(uint32_t w, uint32_t c, uint32_t W, uint32_t& off, uint32_t& bits) {
+    const uint32_t base = (W - 2) * c, R = 254 - base, ca = (R + 1) / 2;
+    if (w + 2 < W) { off = w * c; bits = c; }
+    else if (w + 2 == W) { off = base; bits = ca; }
+    else { off = base + ca; bits = R - ca; }
+}
 __global__ void k_pow2c(const uint32_t* in_xyz, uint32_t* out_xyz, size_t n, uint32_t c) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -133,7 +144,9 @@ static int srs_build(zkhip_ctx* ctx, const void* d_bases, size_t n, zkhip_srs** 
     constexpr int G = 8;
     unsigned gt = div_up(div_up(n, G), 256);
     for (uint32_t w = 1; w < s->W; ++w) {
-        hipLaunchKernelGGL(k_pow2c, dim3(g), dim3(256), 0, st, (const uint32_t*)ja, (uint32_t*)jb, n, s->c);
+        uint32_t off_prev, bits_prev;
+        window_at(w - 1, s->c, s->W, off_prev, bits_prev);   // window w's multiple is 2^(bits of window w - 1) times the previous one
+        hipLaunchKernelGGL(k_pow2c, dim3(g), dim3(256), 0, st, (const uint32_t*)ja, (uint32_t*)jb, n, bits_prev);
         hipLaunchKernelGGL(k_batch_to_affine<G>, dim3(gt), dim3(256), 0, st, (const uint32_t*)jb,
                            (uint32_t*)((char*)s->d_table + (size_t)w * n * 64), n);
         std::swap(ja, jb);
@@ -149,7 +162,7 @@ int srs_build_raw(zkhip_ctx* ctx, const void* d_bases_raw, size_t n, zkhip_srs**
 }  // namespace zk
 
 // ------------------------------------------------------------------ digit recoding + sort by bucket
-// Signed digits d_w in [-(2^(c-1)-1), 2^(c-1)], sum d_w 2^(c w) = scalar.  W*c >= 255 so the last carry is
+// Signed digits d_w in [-(2^(c_w-1)-1), 2^(c_w-1)], sum d_w 2^(off_w) = scalar (window_at: offsets and widths).  The windows cover 254 bits so the last carry is
 // zero for every canonical scalar < r < 2^254.  The n*W (digit, point) pairs are grouped by bucket |d| - 1
 // with a two-level most-significant-digit radix partition whose histograms live in LDS:
 //   hi pass: 256 scalars (256 W pairs) per block, P = 2^HB partitions by the top bits of the bucket;
@@ -173,13 +186,15 @@ struct SortGeom { uint32_t c, W, B, HB, LB, P, tile, R; };   // R: copies of the
 
 extern __shared__ uint32_t sort_lds[];   // staging area of the two scatter kernels
 
-__device__ __forceinline__ void digit_at(const uint32_t* sl, uint32_t w, uint32_t c, uint32_t half, uint32_t mask, uint32_t& carry,
-                                         uint32_t& mag, uint32_t& neg) {
-    uint32_t bit = w * c, limb = bit >> 5, sh = bit & 31;
+__device__ __forceinline__ void digit_at(const uint32_t* sl, uint32_t w, uint32_t c, uint32_t W, uint32_t& carry, uint32_t& mag, uint32_t& neg) {
+    uint32_t bit, cw;
+    window_at(w, c, W, bit, cw);
+    const uint32_t half = 1u << (cw - 1), mask = (1u << cw) - 1;
+    uint32_t limb = bit >> 5, sh = bit & 31;
     uint64_t v = 0;
     if (limb < 8) v = sl[limb] | ((uint64_t)sl[limb + 1] << 32);
     uint32_t raw = ((uint32_t)(v >> sh) & mask) + carry;
-    if (raw > half) { mag = (1u << c) - raw; neg = 1; carry = 1; } else { mag = raw; neg = 0; carry = 0; }
+    if (raw > half) { mag = (1u << cw) - raw; neg = 1; carry = 1; } else { mag = raw; neg = 0; carry = 0; }
 }
 
 // SCATTER = false: part_cnt[p] += pairs of this block in partition p.
@@ -224,11 +239,11 @@ __global__ void __launch_bounds__(256) k_sort_hi(const ColPtrs scalar_cols, size
         sl[tid][8] = 0;
     }
     __syncthreads();
-    const uint32_t half = 1u << (g.c - 1), mask = (1u << g.c) - 1, lomask = (1u << g.LB) - 1;
+    const uint32_t lomask = (1u << g.LB) - 1;
     if (live) {
         uint32_t carry = 0, mag, neg;
         for (uint32_t w = 0; w < g.W; ++w) {
-            digit_at(sl[tid], w, g.c, half, mask, carry, mag, neg);
+            digit_at(sl[tid], w, g.c, g.W, carry, mag, neg);
             if (mag) atomicAdd(&hist[(mag - 1) >> g.LB], 1u);
         }
     }
@@ -254,7 +269,7 @@ __global__ void __launch_bounds__(256) k_sort_hi(const ColPtrs scalar_cols, size
         if (live) {
             uint32_t carry = 0, mag, neg;
             for (uint32_t w = 0; w < g.W; ++w) {
-                digit_at(sl[tid], w, g.c, half, mask, carry, mag, neg);
+                digit_at(sl[tid], w, g.c, g.W, carry, mag, neg);
                 if (mag) {
                     uint32_t b = mag - 1, p = b >> g.LB;
                     uint32_t pos = base[p] + atomicAdd(&hist[p], 1u);
@@ -290,7 +305,7 @@ __global__ void __launch_bounds__(256) k_sort_hi(const ColPtrs scalar_cols, size
     if (live) {
         uint32_t carry = 0, mag, neg;
         for (uint32_t w = 0; w < g.W; ++w) {
-            digit_at(sl[tid], w, g.c, half, mask, carry, mag, neg);
+            digit_at(sl[tid], w, g.c, g.W, carry, mag, neg);
             if (mag) {
                 uint32_t b = mag - 1, p = b >> g.LB;
                 uint32_t slot = atomicAdd(&hist[p], 1u);
@@ -1183,7 +1198,10 @@ static int msm_local(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const 
     size_t bound = items / L + B + 1;
     if (bound > pstride0) bound = pstride0;
     // the tail folds up to tail_parts partial sums per bucket itself; heavier buckets (skewed scalars) go through reduction rounds
-    uint32_t tail_parts = 8;
+    // From 2^20 points a reduction round pays whenever a bucket holds more than 4 partial sums (k_accum_jac folds them with every
+    // lane busy; the tail's quads would do it inside their dependent chains: 11.5 against 3.0 + 5.3 ms per k = 22 proof); below, where
+    // the round is a latency chain of its own, only skewed columns get one.
+    uint32_t tail_parts = n >= ((size_t)1 << 20) ? 4 : 8;
     { int v = ctx->opt.msm_tailparts; if (v >= 1 && v <= 64) tail_parts = (uint32_t)v; }
     while (maxcnt > tail_parts) {
         seg = maxcnt <= 16 ? maxcnt : 8;
