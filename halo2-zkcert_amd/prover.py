@@ -616,11 +616,12 @@ class Prover:
             self._build_satisfiable(seed)
         self.fixed_coeff = b.clone(self.fixed_lagrange)
         b.lagrange_to_coeff(self.fixed_coeff)
-        self.fixed_cosets = b.coeff_to_extended(self.fixed_coeff)
         self.sigma_coeff = b.clone(self.sigma_lagrange)
         b.lagrange_to_coeff(self.sigma_coeff)
-        self.sigma_cosets = b.coeff_to_extended(self.sigma_coeff)
-        self.l0, self.l_last, self.l_active = b.l_cosets(sh.blinding_factors)
+        # The extended-domain forms of the key (fixed / sigma cosets, l_0 / l_last / l_active) are built on first use: the Python
+        # schedule needs them, zkhip_create_proof_ex does not when it evaluates the quotient on cosets of the size-n domain
+        # (cs_degree - 1 < extension factor: csrc/cosets.hip derives the key's columns in its own layout from the coefficient forms).
+        self._ext = None
         self.gates_graph = ev.build_custom_gates(sh.gates)
         self.lookup_graphs = [ev.build_lookup(i, t) for i, t in sh.lookups]
         self.compress_graphs = []
@@ -635,6 +636,25 @@ class Prover:
         self.omega = pow(ROOT_OF_UNITY, 1 << (28 - sh.k), R)
         # vk.transcript_repr stand-in (upstream: a Blake2b hash of the verifying key's Debug form, absorbed first by vk.hash_into)
         self.vk_repr = fr_from_int_host(int.from_bytes(hashlib.blake2b(sh.name.encode(), digest_size=64).digest(), "little") % R)
+
+    def _extended_key(self):
+        if self._ext is None:
+            b = self.b
+            l0, l_last, l_active = b.l_cosets(self.shape.blinding_factors)
+            self._ext = dict(fixed=b.coeff_to_extended(self.fixed_coeff), sigma=b.coeff_to_extended(self.sigma_coeff), l0=l0, l_last=l_last,
+                             l_active=l_active)
+        return self._ext
+
+    fixed_cosets = property(lambda self: self._extended_key()["fixed"])
+    sigma_cosets = property(lambda self: self._extended_key()["sigma"])
+    l0 = property(lambda self: self._extended_key()["l0"])
+    l_last = property(lambda self: self._extended_key()["l_last"])
+    l_active = property(lambda self: self._extended_key()["l_active"])
+
+    @property
+    def coset_quotient_applies(self):
+        """cs_degree - 1 cosets of the size-n domain are fewer rows than the extended domain (the library's default path then)"""
+        return self.dom.quotient_poly_degree < (1 << (self.dom.extended_k - self.shape.k))
 
     @property
     def n_instance_values(self):
@@ -879,9 +899,9 @@ class Prover:
         if getattr(self, "_npk", None) is not None and hasattr(self.b, "ctx") and hasattr(self.b.ctx, "key_release"):
             self.b.ctx.key_release(self._npk.key_id)
 
-    def _native_key(self):
+    def _native_key(self, with_extended=False):
         """zk_proving_key for zkhip_create_proof (built once; the arrays it points to are kept alive on self)"""
-        if getattr(self, "_npk", None) is not None:
+        if getattr(self, "_npk", None) is not None and not (with_extended and not self._npk.fixed_cosets and not self._npk.l0):
             return self._npk
         import ctypes as C
 
@@ -911,9 +931,12 @@ class Prover:
         pk.n_fixed, pk.n_advice, pk.n_instance = len(self.fixed_lagrange), sh.n_advice, sh.n_instance
         pk.n_lookups, pk.n_perm_columns = len(sh.lookups), len(sh.perm_columns)
         pk.g, pk.g_lagrange, pk.domain = b.params.g, b.params.g_lagrange, b.domain.h
-        pk.fixed_lagrange, pk.fixed_coeff, pk.fixed_cosets = ptrs(self.fixed_lagrange), ptrs(self.fixed_coeff), ptrs(self.fixed_cosets)
-        pk.sigma_lagrange, pk.sigma_coeff, pk.sigma_cosets = ptrs(self.sigma_lagrange), ptrs(self.sigma_coeff), ptrs(self.sigma_cosets)
-        pk.l0, pk.l_last, pk.l_active_row = self.l0.data_ptr(), self.l_last.data_ptr(), self.l_active.data_ptr()
+        pk.fixed_lagrange, pk.fixed_coeff = ptrs(self.fixed_lagrange), ptrs(self.fixed_coeff)
+        pk.sigma_lagrange, pk.sigma_coeff = ptrs(self.sigma_lagrange), ptrs(self.sigma_coeff)
+        if self._ext is not None or not self.coset_quotient_applies or with_extended:
+            pk.fixed_cosets, pk.sigma_cosets = ptrs(self.fixed_cosets), ptrs(self.sigma_cosets)
+            pk.l0, pk.l_last, pk.l_active_row = self.l0.data_ptr(), self.l_last.data_ptr(), self.l_active.data_ptr()
+        # else: NULL — the coset path derives them; prove_native retries with them if the library asks
         pk.custom_gates = pack.graph(self.gates_graph, b.fr_many)
         pk.lookup_graphs = graphs(self.lookup_graphs)
         pk.lookup_input_compress = graphs([p_[0] for p_ in self.compress_graphs])
@@ -936,7 +959,8 @@ class Prover:
         self._npk, self._npk_keep = pk, keep
         return pk
 
-    def prove_native(self, wit, fetch_h=False, python_transcript=False, evm=False, transcript=None, host_inputs=False, blinding=None):
+    def prove_native(self, wit, fetch_h=False, python_transcript=False, evm=False, transcript=None, host_inputs=False, blinding=None,
+                     auto_extended=True):
         """The same pass through zkhip_create_proof_ex (the schedule and all host arithmetic in the library).
         transcript: "blake2b" (halo2's Blake2bWrite, the default), "poseidon" (snark-verifier's native transcript: what the
         reference's prove-* commands and the aggregation snark use), "evm" (Keccak-256: gen-x509-agg-evm-proof; points are 64
@@ -1028,6 +1052,11 @@ class Prover:
             inp.blinding = C.cast(C.pointer(bl), C.c_void_p)
         ctx.use_torch_stream()
         rc = ffi.lib().zkhip_create_proof_ex(ctx.h, C.byref(pk), C.byref(inp), t_ref, C.byref(out))
+        if rc != 0 and auto_extended and b"extended cosets are missing" in ffi.lib().zkhip_last_error():
+            # the context runs the extended-domain path (coset_quotient = 0): hand over the key's extended forms (nothing has entered the
+            # transcript yet: the library checks its inputs first)
+            pk = self._native_key(with_extended=True)
+            rc = ffi.lib().zkhip_create_proof_ex(ctx.h, C.byref(pk), C.byref(inp), t_ref, C.byref(out))
         if rc == ffi.ECONSTRAINT:
             raise ffi.ConstraintSystemFailure(ffi.lib().zkhip_last_error().decode())
         if rc != 0:

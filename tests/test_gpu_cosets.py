@@ -131,7 +131,7 @@ def test_create_proof_same_bytes_on_either_domain(zk, oracle, k):
         assert gp.prove_native(w, transcript="poseidon")["proof"] == on["proof"]
         ctx.set_option("coset_quotient", 0)      # ... but the extended-domain path needs them and says so
         with pytest.raises(ffi.ZkhipError, match="extended cosets are missing"):
-            gp.prove_native(w, transcript="poseidon")
+            gp.prove_native(w, transcript="poseidon", auto_extended=False)
     finally:
         ctx.set_option("coset_quotient", 1)
         for f, v in saved.items():
