@@ -18,7 +18,7 @@ use crate::plonk::evaluation::{Calculation, GraphEvaluator, ValueSource};
 use crate::plonk::{Any, Error, ProvingKey};
 use crate::poly::commitment::{CommitmentScheme, Params, Prover as _};
 use crate::poly::kzg::commitment::{KZGCommitmentScheme, ParamsKZG};
-use crate::poly::{LagrangeCoeff, Polynomial};
+use crate::poly::{ExtendedLagrangeCoeff, LagrangeCoeff, Polynomial};
 use crate::transcript::{EncodedChallenge, TranscriptWrite};
 
 fn check(rc: i32, what: &str) -> Result<(), Error> {
@@ -171,9 +171,16 @@ fn device_key(ctx: *mut sys::zkhip_ctx, params: &ParamsKZG<Bn256>, pk: &ProvingK
     unsafe {
         assert_eq!(sys::zkhip_domain_new(ctx, cs.degree() as u32, domain.k(), &g_coset as *const Fr as *const u64, &mut dom), sys::ZKHIP_OK, "{}", sys::last_error());
     }
-    let fixed = [DevCols::upload(ctx, &pk.fixed_values), DevCols::upload(ctx, &pk.fixed_polys), DevCols::upload(ctx, &pk.fixed_cosets)];
-    let sigma = [DevCols::upload(ctx, &pk.permutation.permutations), DevCols::upload(ctx, &pk.permutation.polys), DevCols::upload(ctx, &pk.permutation.cosets)];
-    let l = DevCols::upload(ctx, &[pk.l0.clone(), pk.l_last.clone(), pk.l_active_row.clone()]);
+    // cs.degree() - 1 cosets of the size-n domain are fewer rows than the extended domain (halo2-lib's degree 4: 3 < 4): the library
+    // evaluates the quotient there and derives the key's columns in that layout from the coefficient forms (include/zkhip.h, "the same
+    // quotient on quotient_poly_degree cosets"), so the pk's extended cosets — most of its bytes — are not uploaded at all
+    let coset_path = (cs.degree() as u32 - 1) < (1u32 << (domain.extended_k() - domain.k()));
+    let ext = |cols: &[Polynomial<Fr, ExtendedLagrangeCoeff>]| if coset_path { DevCols { ptrs: Vec::new() } } else { DevCols::upload(ctx, cols) };
+    let fixed = [DevCols::upload(ctx, &pk.fixed_values), DevCols::upload(ctx, &pk.fixed_polys), ext(&pk.fixed_cosets)];
+    let sigma = [DevCols::upload(ctx, &pk.permutation.permutations), DevCols::upload(ctx, &pk.permutation.polys), ext(&pk.permutation.cosets)];
+    let l = ext(&[pk.l0.clone(), pk.l_last.clone(), pk.l_active_row.clone()]);
+    let or_null = |d: &DevCols| if d.ptrs.is_empty() { std::ptr::null() } else { d.ptrs.as_ptr() };
+    let l_ptr = |i: usize| if l.ptrs.is_empty() { std::ptr::null() } else { l.ptrs[i] };
     let gates = FlatGraph::new(&pk.ev.custom_gates);
     let lookup_graphs: Vec<FlatGraph> = pk.ev.lookups.iter().map(FlatGraph::new).collect();
     let compress_in: Vec<FlatGraph> = cs.lookups().iter().map(|a| compress_graph(a.input_expressions())).collect();
@@ -208,13 +215,13 @@ fn device_key(ctx: *mut sys::zkhip_ctx, params: &ParamsKZG<Bn256>, pk: &ProvingK
         domain: dom,
         fixed_lagrange: fixed[0].ptrs.as_ptr(),
         fixed_coeff: fixed[1].ptrs.as_ptr(),
-        fixed_cosets: fixed[2].ptrs.as_ptr(),
+        fixed_cosets: or_null(&fixed[2]),
         sigma_lagrange: sigma[0].ptrs.as_ptr(),
         sigma_coeff: sigma[1].ptrs.as_ptr(),
-        sigma_cosets: sigma[2].ptrs.as_ptr(),
-        l0: l.ptrs[0],
-        l_last: l.ptrs[1],
-        l_active_row: l.ptrs[2],
+        sigma_cosets: or_null(&sigma[2]),
+        l0: l_ptr(0),
+        l_last: l_ptr(1),
+        l_active_row: l_ptr(2),
         custom_gates: gates.ffi(),
         lookup_graphs: lookup_ffi.as_ptr(),
         lookup_input_compress: compress_in_ffi.as_ptr(),
