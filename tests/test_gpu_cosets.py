@@ -175,3 +175,22 @@ def test_key_release_frees_the_cached_columns(zk, oracle):
     assert freed >= cached, (freed, cached)
     assert gp.prove_native(w, transcript="poseidon")["proof"] == first
     gp.release()
+
+
+@pytest.mark.parametrize("k", [17, 20])
+def test_full_size_proofs_agree_on_either_domain(zk, oracle, k):
+    """BASELINE sizes: the RSA-shaped k = 17 circuit (two-pass size-n transforms) and the aggregation shape at k = 20 (2^20: two 10-bit
+    passes; 3 x 2^20 sweep rows) through zkhip_create_proof_ex on 3 cosets and on the extended domain: identical proof bytes"""
+    ffi, ctx = zk
+    sh = pv.CircuitShape.rsa(k)
+    gp = pv.Prover(pv.GpuBackend(ctx, ffi), sh, satisfiable=True)
+    w = gp.witness(2)
+    on = gp.prove_native(w, transcript="poseidon")["proof"]
+    ctx.set_option("coset_quotient", 0)
+    try:
+        off = gp.prove_native(w, transcript="poseidon")["proof"]
+    finally:
+        ctx.set_option("coset_quotient", 1)
+    assert on == off
+    gp.release()
+    del gp, w
