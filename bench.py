@@ -365,6 +365,7 @@ def main():
                "perm_columns": len(shape.perm_columns), "degree": shape.degree, "transcript": kind, "proof_bytes": len(trace.get("proof", b"")),
                "setup_s": round(setup_s, 3), "resident_bytes": int(resident), "rooflines": roof, "kernels_ms_per_step": kernels,
                "traffic_source": traffic_file, "with_h2d": h2d, "msm_shard": shard_mode}
+        prover.release()          # the context's per-key caches (coset-layout key columns, sorted lookup table)
         backend.params.free()
         del prover, wit, trace, backend
         return res, shape
