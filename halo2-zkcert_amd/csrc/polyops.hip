@@ -30,8 +30,14 @@ __device__ __forceinline__ void inv_store(uint32_t* p, const el2<Fr>& v) {
     if (FORM == 0) store_raw<Fr>(p, v); else store_div32<Fr>(p, v);
 }
 
-template <int FORM>
-__global__ void __launch_bounds__(PO_BLOCK) k_batch_invert(uint32_t* a, size_t n) {
+// LEVEL 0: the tile's root is inverted here (one binary-Euclid inversion per 2048 elements: ~30 k instructions on one wave, as much VALU
+//          work as everything else in the tile).
+// LEVEL 1: the tile's root product is only STORED (roots[tile], raw R' form); nothing is written to `a`.
+// LEVEL 2: the root's inverse is READ from roots[tile] (a second-level batch inversion of all roots ran in between).
+// Two-level use (launch_batch_invert, n >= 2^16): level 1, k_batch_invert<0, 0> over the roots, level 2 — one inversion per 2^22
+// elements instead of 2048 of them, for one extra pass over the data.
+template <int FORM, int LEVEL = 0>
+__global__ void __launch_bounds__(PO_BLOCK) k_batch_invert(uint32_t* a, size_t n, uint32_t* roots = nullptr) {
     __shared__ fe tree[2 * PO_BLOCK];   // tree[256 + t] = leaf t, tree[i] = tree[2i] * tree[2i+1]
     const uint32_t t = threadIdx.x;
     const size_t base = (size_t)blockIdx.x * PO_TILE;
@@ -55,9 +61,16 @@ __global__ void __launch_bounds__(PO_BLOCK) k_batch_invert(uint32_t* a, size_t n
         if (t < w) tree[w + t] = (el2<Fr>(tree[2 * (w + t)]) * el2<Fr>(tree[2 * (w + t) + 1])).v;
         __syncthreads();
     }
+    if (LEVEL == 1) {
+        // an all-zero tile has root 1 (zeros are skipped in the products), never 0: the second level needs no special case
+        if (t == 0) store_raw<Fr>(roots + (size_t)blockIdx.x * 8, el2<Fr>(tree[1]));
+        return;
+    }
     // every lane of wave 0 inverts the root (same cost as one lane; avoids a broadcast)
     __shared__ fe root_inv;
-    if (t < 64) {
+    if (LEVEL == 2) {
+        if (t == 0) root_inv = load_raw<Fr>(roots + (size_t)blockIdx.x * 8).v;
+    } else if (t < 64) {
         el2<Fr> r = inv_euclid<Fr>(el2<Fr>(tree[1]));   // one value, the same in all 64 lanes: binary Euclid beats the 380-product Fermat chain
         if (t == 0) root_inv = r.v;
     }
@@ -84,6 +97,23 @@ __global__ void __launch_bounds__(PO_BLOCK) k_batch_invert(uint32_t* a, size_t n
             if (i < n) inv_store<FORM>(a + i * 8, r);
         }
     }
+}
+
+// in place over n elements of form FORM on the context's stream
+template <int FORM>
+static int launch_batch_invert(zkhip_ctx* ctx, void* d_a, size_t n) {
+    const unsigned tiles = div_up(n, PO_TILE);
+    if (n < ((size_t)1 << 16)) {
+        hipLaunchKernelGGL((k_batch_invert<FORM, 0>), dim3(tiles), dim3(PO_BLOCK), 0, ctx->stream, (uint32_t*)d_a, n, (uint32_t*)nullptr);
+    } else {
+        void* d_roots;
+        ZK_TRY(ctx->get_scratch("po_inv_roots", (size_t)tiles * 32, &d_roots));
+        hipLaunchKernelGGL((k_batch_invert<FORM, 1>), dim3(tiles), dim3(PO_BLOCK), 0, ctx->stream, (uint32_t*)d_a, n, (uint32_t*)d_roots);
+        hipLaunchKernelGGL((k_batch_invert<0, 0>), dim3(div_up(tiles, PO_TILE)), dim3(PO_BLOCK), 0, ctx->stream, (uint32_t*)d_roots, (size_t)tiles, (uint32_t*)nullptr);
+        hipLaunchKernelGGL((k_batch_invert<FORM, 2>), dim3(tiles), dim3(PO_BLOCK), 0, ctx->stream, (uint32_t*)d_a, n, (uint32_t*)d_roots);
+    }
+    ZK_LAUNCH_CHECK();
+    return ZKHIP_OK;
 }
 
 // ------------------------------------------------------------------ running products
@@ -314,9 +344,7 @@ int zkhip_batch_invert_device(zkhip_ctx* ctx, void* d_a, size_t n) {
     if (!ctx || !d_a) { set_error("zkhip_batch_invert_device: null argument"); return ZKHIP_EINVAL; }
     if (n == 0) return ZKHIP_OK;
     ProfScope ps(ctx, "batch_invert");
-    hipLaunchKernelGGL(k_batch_invert<1>, dim3(div_up(n, PO_TILE)), dim3(PO_BLOCK), 0, ctx->stream, (uint32_t*)d_a, n);
-    ZK_LAUNCH_CHECK();
-    return ZKHIP_OK;
+    return launch_batch_invert<1>(ctx, d_a, n);
 }
 
 // xs_host: npolys ABI points (one per polynomial)
@@ -400,7 +428,7 @@ int zkhip_permutation_products_device(zkhip_ctx* ctx, uint32_t k, const void* co
     ProfScope ps(ctx, "grand_product");
     dim3 grid(div_up(n, 256), nsets);
     hipLaunchKernelGGL(k_perm_terms<1>, grid, dim3(256), 0, st, P, n, (uint32_t*)d_terms);
-    hipLaunchKernelGGL(k_batch_invert<0>, dim3(div_up((size_t)nsets * n, PO_TILE)), dim3(PO_BLOCK), 0, st, (uint32_t*)d_terms, (size_t)nsets * n);
+    ZK_TRY(launch_batch_invert<0>(ctx, d_terms, (size_t)nsets * n));
     hipLaunchKernelGGL(k_perm_terms<0>, grid, dim3(256), 0, st, P, n, (uint32_t*)d_terms);
     return running_products(ctx, d_terms, nsets, n, n - blinding_factors, nsets, n - blinding_factors - 1, d_blinding, d_z);
 }
@@ -420,7 +448,7 @@ int zkhip_lookup_product_device(zkhip_ctx* ctx, uint32_t k, const void* d_compre
     ProfScope ps(ctx, "grand_product");
     hipLaunchKernelGGL(k_lookup_terms<1>, dim3(div_up(n, 256)), dim3(256), 0, st, (const uint32_t*)d_permuted_input, (const uint32_t*)d_permuted_table,
                        bv, gv, n, (uint32_t*)d_terms);
-    hipLaunchKernelGGL(k_batch_invert<0>, dim3(div_up(n, PO_TILE)), dim3(PO_BLOCK), 0, st, (uint32_t*)d_terms, n);
+    ZK_TRY(launch_batch_invert<0>(ctx, d_terms, n));
     hipLaunchKernelGGL(k_lookup_terms<0>, dim3(div_up(n, 256)), dim3(256), 0, st, (const uint32_t*)d_compressed_input,
                        (const uint32_t*)d_compressed_table, bv, gv, n, (uint32_t*)d_terms);
     void* zs[1] = {d_z};
@@ -484,7 +512,7 @@ int zkhip_grand_products_device(zkhip_ctx* ctx, uint32_t k, const uint64_t beta[
     for (size_t l = 0; l < n_lookups; ++l)
         hipLaunchKernelGGL(k_lookup_terms<1>, dim3(div_up(n, 256)), dim3(256), 0, st, (const uint32_t*)d_permuted_input[l],
                            (const uint32_t*)d_permuted_table[l], bv, gv, n, (uint32_t*)d_terms + ((size_t)nsets + l) * n * 8);
-    hipLaunchKernelGGL(k_batch_invert<0>, dim3(div_up((size_t)nseg * n, PO_TILE)), dim3(PO_BLOCK), 0, st, (uint32_t*)d_terms, (size_t)nseg * n);
+    ZK_TRY(launch_batch_invert<0>(ctx, d_terms, (size_t)nseg * n));
     if (nsets) hipLaunchKernelGGL(k_perm_terms<0>, dim3(div_up(n, 256), nsets), dim3(256), 0, st, P, n, (uint32_t*)d_terms);
     for (size_t l = 0; l < n_lookups; ++l)
         hipLaunchKernelGGL(k_lookup_terms<0>, dim3(div_up(n, 256)), dim3(256), 0, st, (const uint32_t*)d_compressed_input[l],
