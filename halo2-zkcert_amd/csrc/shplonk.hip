@@ -66,15 +66,23 @@ struct KdEntry {
 };
 struct KdArgs { KdEntry e[KD_MAX]; };
 
-// suffix scan over the 256 per-thread values in LDS: S_t = sum_{q >= t} m^(q - t) A_q, m = the slope of one thread's span
-__device__ __forceinline__ void suffix_scan_256(fe* sc, uint32_t t, el2<Fr> m) {
-    for (uint32_t d = 1; d < SP_BLOCK; d <<= 1) {
+// suffix scan over the 256 per-thread values in LDS: S_t = sum_{q >= t} m^(q - t) A_q, m = the slope of one thread's span.
+// The eight slopes m^(2^level) are the same for every thread: thread 0 squares them once into LDS (mp) instead of 256 threads
+// squaring along (8 of the ~16 products a thread spends on the scan).  Callers synchronise after sc[] is written; the first barrier
+// below also publishes mp.
+__device__ __forceinline__ void suffix_scan_256(fe* sc, fe* mp, uint32_t t, el2<Fr> m) {
+    if (t == 0) {
+#pragma unroll
+        for (int l = 0; l < 8; ++l) { mp[l] = m.v; m = sqr(m); }
+    }
+    __syncthreads();
+    int l = 0;
+    for (uint32_t d = 1; d < SP_BLOCK; d <<= 1, ++l) {
         bool on = t + d < SP_BLOCK;
         fe mine = sc[t];
         fe other = on ? sc[t + d] : fe_zero();
         __syncthreads();
-        if (on) sc[t] = canonical(el1<Fr>(mine) + el1<Fr>(other) * m).v;
-        m = sqr(m);
+        if (on) sc[t] = canonical(el1<Fr>(mine) + el1<Fr>(other) * el2<Fr>(mp[l])).v;
         __syncthreads();
     }
 }
@@ -95,10 +103,12 @@ __global__ void __launch_bounds__(SP_BLOCK) k_kd_totals(const KdArgs K, size_t n
     }
     sc[t] = canonical(s).v;
     el2<Fr> m = r;
+    if (t == 0) {   // only the thread that fills the slope table needs r^SP_PER
 #pragma unroll
-    for (int q = 0; q < SP_PER_LOG; ++q) m = sqr(m);   // r^SP_PER
-    __syncthreads();
-    suffix_scan_256(sc, t, m);
+        for (int q = 0; q < SP_PER_LOG; ++q) m = sqr(m);
+    }
+    __shared__ fe mp[8];
+    suffix_scan_256(sc, mp, t, m);
     if (t == 0) mem_store(tot_all + ((size_t)e * nblk + blockIdx.x) * 8, fe_pack(sc[0]));
 }
 // pass 2 (one block per entry): carry[entry][blk] = s at the first index of tile blk + 1 (exclusive suffix scan, slope r^2048)
@@ -114,8 +124,8 @@ __global__ void __launch_bounds__(SP_BLOCK) k_kd_carries(const KdArgs K, uint32_
     el<Fr, 4 * U> s = zero<Fr>();
     for (uint32_t q = hi; q > lo; --q) s = s * M + load_raw<Fr>(tot + (size_t)(q - 1) * 8);
     sc[t] = canonical(s).v;
-    __syncthreads();
-    suffix_scan_256(sc, t, pow_u64<Fr>(M, c));
+    __shared__ fe mp[8];
+    suffix_scan_256(sc, mp, t, pow_u64<Fr>(M, c));
     s = zero<Fr>();
     if (t + 1 < SP_BLOCK) s = el1<Fr>(sc[t + 1]);
     for (uint32_t q = hi; q > lo; --q) {
@@ -140,14 +150,16 @@ __global__ void __launch_bounds__(SP_BLOCK) k_kd_apply(const KdArgs K, size_t n,
         s = s * r + v[j];
     }
     el2<Fr> m = r;
+    if (t == 0 || t == SP_BLOCK - 1) {   // r^SP_PER: the slope table's seed (thread 0) and the carry's weight (last thread)
 #pragma unroll
-    for (int q = 0; q < SP_PER_LOG; ++q) m = sqr(m);   // r^SP_PER
+        for (int q = 0; q < SP_PER_LOG; ++q) m = sqr(m);
+    }
     const el1<Fr> cb = load_raw<Fr>(carry_all + ((size_t)e * nblk + blockIdx.x) * 8);
     el1<Fr> agg = canonical(s);
     if (t == SP_BLOCK - 1) agg = canonical(agg + cb * m);   // the tile's carry enters above its last thread
     sc[t] = agg.v;
-    __syncthreads();
-    suffix_scan_256(sc, t, m);
+    __shared__ fe mp[8];
+    suffix_scan_256(sc, mp, t, m);
     s = (t + 1 < SP_BLOCK) ? el1<Fr>(sc[t + 1]) : cb;
 #pragma clang loop unroll(full)
     for (int j = SP_PER - 1; j >= 0; --j) {
