@@ -32,6 +32,8 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;       // optional: what RCCL itself says the communicator spans
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 Rccl g_rccl;
@@ -47,6 +49,8 @@ int load_rccl() {
     g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(h, "ncclAllGather");
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
+    g_rccl.CommCount = (decltype(g_rccl.CommCount))dlsym(h, "ncclCommCount");
+    g_rccl.CommUserRank = (decltype(g_rccl.CommUserRank))dlsym(h, "ncclCommUserRank");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy) {
         set_error("zkhip_comm: librccl lacks a required symbol");
         return ZKHIP_EINVAL;
@@ -102,6 +106,7 @@ int comm_allgather_begin(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_
         ZK_HIP(hipMemcpyAsync(d_recv, cm.stage, total, hipMemcpyHostToDevice, ctx->stream));
         ZK_HIP(hipStreamSynchronize(ctx->stream));   // the staging buffer is reused by the next call
         cm.bytes_gathered += bytes * (size_t)(cm.nranks - 1);
+        cm.collectives += 1;
         return ZKHIP_OK;
     }
     ncclComm_t c = (ncclComm_t)cm.nccl;
@@ -109,6 +114,7 @@ int comm_allgather_begin(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_
     ZK_HIP(hipStreamWaitEvent(cm.stream, cm.ev_in, 0));
     ZK_NCCL(g_rccl.AllGather(d_send, d_recv, bytes, ncclInt8, c, cm.stream));
     cm.bytes_gathered += bytes * (size_t)(cm.nranks - 1);
+    cm.collectives += 1;
     return ZKHIP_OK;
 }
 int comm_allgather_end(zkhip_ctx* ctx) {
@@ -149,7 +155,7 @@ int zkhip_comm_unique_id(uint8_t id[128]) {
 
 int zkhip_comm_init(zkhip_ctx* ctx, const uint8_t id[128], int rank, int nranks) {
     if (!ctx || !id || nranks < 1 || rank < 0 || rank >= nranks) { set_error("zkhip_comm_init: bad argument"); return ZKHIP_EINVAL; }
-    if (ctx->comm.nranks > 1) { set_error("zkhip_comm_init: the context already has a communicator"); return ZKHIP_EINVAL; }
+    if (ctx->comm.nccl || ctx->comm.host_allgather) { set_error("zkhip_comm_init: the context already has a communicator (zkhip_comm_destroy first)"); return ZKHIP_EINVAL; }
     ZK_TRY(load_rccl());
     ZK_HIP(hipSetDevice(ctx->device));
     ncclUniqueId a;
@@ -172,7 +178,7 @@ int zkhip_comm_init(zkhip_ctx* ctx, const uint8_t id[128], int rank, int nranks)
 
 int zkhip_comm_init_host(zkhip_ctx* ctx, int rank, int nranks, zkhip_host_allgather_fn fn, void* user) {
     if (!ctx || !fn || nranks < 1 || rank < 0 || rank >= nranks) { set_error("zkhip_comm_init_host: bad argument"); return ZKHIP_EINVAL; }
-    if (ctx->comm.nranks > 1) { set_error("zkhip_comm_init_host: the context already has a communicator"); return ZKHIP_EINVAL; }
+    if (ctx->comm.nccl || ctx->comm.host_allgather) { set_error("zkhip_comm_init_host: the context already has a communicator (zkhip_comm_destroy first)"); return ZKHIP_EINVAL; }
     ctx->comm.host_allgather = fn;
     ctx->comm.host_user = user;
     ctx->comm.rank = rank;
@@ -204,6 +210,22 @@ int zkhip_comm_info(const zkhip_ctx* ctx, int* rank, int* nranks, uint64_t* byte
     if (rank) *rank = ctx->comm.rank;
     if (nranks) *nranks = ctx->comm.nranks;
     if (bytes_gathered) *bytes_gathered = ctx->comm.bytes_gathered;
+    return ZKHIP_OK;
+}
+
+// transport: "rccl" / "host" / "none"; transport_ranks: the rank count the transport ITSELF reports (ncclCommCount for RCCL — evidence
+// that RCCL really joined N processes — the caller's nranks for the host transport, 1 without a communicator)
+int zkhip_comm_describe(const zkhip_ctx* ctx, char* transport, size_t cap, int* transport_ranks, uint64_t* collectives) {
+    if (!ctx) { set_error("null ctx"); return ZKHIP_EINVAL; }
+    const zkhip_comm& cm = ctx->comm;
+    const char* t = cm.nccl ? "rccl" : (cm.host_allgather ? "host" : "none");
+    if (transport && cap) { strncpy(transport, t, cap - 1); transport[cap - 1] = 0; }
+    if (transport_ranks) {
+        int cnt = cm.nccl ? -1 : cm.nranks;
+        if (cm.nccl && g_rccl.CommCount) ZK_NCCL(g_rccl.CommCount((ncclComm_t)cm.nccl, &cnt));
+        *transport_ranks = cnt;
+    }
+    if (collectives) *collectives = cm.collectives;
     return ZKHIP_OK;
 }
 

@@ -67,6 +67,7 @@ struct zkhip_comm {
     void* stage = nullptr;        // pinned staging buffer of the host transport
     size_t stage_bytes = 0;
     uint64_t bytes_gathered = 0;  // bytes this rank received through RCCL all-gathers
+    uint64_t collectives = 0;     // exchanges issued so far
     int shard_columns = 0;        // MSMs over whole-SRS handles: 1 = split the batch by column over the ranks, 0 = replicate
 };
 

@@ -39,12 +39,25 @@ void zk::coset_sweep_view(const CosetPlan* p, SweepCosets* out) {
 
 static inline void put_abi(uint64_t* out, const HF& a) { memcpy(out, a.w, 32); }   // HF is the ABI form; no alignment assumed
 
-static int dev_alloc(zkhip_ctx* ctx, const std::string& name, size_t bytes, void** out) {
-    hipError_t e = hipMalloc(out, bytes);
-    if (e != hipSuccess) { (void)hipGetLastError(); set_error("hipMalloc(%zu) for %s failed: %s", bytes, name.c_str(), hipGetErrorString(e)); return ZKHIP_ENOMEM; }
-    ctx->persistent[name] = *out;   // freed with the context
-    return ZKHIP_OK;
-}
+// A device buffer that becomes one of the context's persistent (named) buffers only when its owner says the object it belongs to is
+// complete: until keep() the destructor frees it, so a plan / key that fails half-way leaves nothing behind, and a retry cannot
+// overwrite (leak) an earlier allocation of the same name.
+struct PendingBuffer {
+    zkhip_ctx* ctx;
+    std::string name;
+    void* ptr = nullptr;
+    PendingBuffer(zkhip_ctx* c, std::string nm) : ctx(c), name(std::move(nm)) {}
+    PendingBuffer(const PendingBuffer&) = delete;
+    int alloc(size_t bytes) {
+        auto old = ctx->persistent.find(name);   // a stale entry (no host-side object refers to it, or we would not be here)
+        if (old != ctx->persistent.end()) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(old->second); ctx->persistent.erase(old); }
+        hipError_t e = hipMalloc(&ptr, bytes);
+        if (e != hipSuccess) { (void)hipGetLastError(); ptr = nullptr; set_error("hipMalloc(%zu) for %s failed: %s", bytes, name.c_str(), hipGetErrorString(e)); return ZKHIP_ENOMEM; }
+        return ZKHIP_OK;
+    }
+    void keep() { if (ptr) ctx->persistent[name] = ptr; ptr = nullptr; }   // freed with the context (or by zkhip_key_release)
+    ~PendingBuffer() { if (ptr) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ptr); } }
+};
 
 int zk::coset_plan(zkhip_ctx* ctx, const zkhip_domain* d, const CosetPlan** out) {
     if (!ctx || !d || !out) { set_error("coset_plan: null argument"); return ZKHIP_EINVAL; }
@@ -65,8 +78,11 @@ int zk::coset_plan(zkhip_ctx* ctx, const zkhip_domain* d, const CosetPlan** out)
     put_abi(plan->omega_inv_abi, hf_invert(w));
     plan->shifts_abi.resize(4 * q);
     plan->minv_abi.resize(4 * (size_t)q * q);
-    ZK_TRY(dev_alloc(ctx, std::string(name) + ":pre", (size_t)q * n * 32, &plan->d_pre));
-    ZK_TRY(dev_alloc(ctx, std::string(name) + ":post", (size_t)q * n * 32, &plan->d_post));
+    PendingBuffer b_pre(ctx, std::string(name) + ":pre"), b_post(ctx, std::string(name) + ":post");
+    ZK_TRY(b_pre.alloc((size_t)q * n * 32));
+    ZK_TRY(b_post.alloc((size_t)q * n * 32));
+    plan->d_pre = b_pre.ptr;
+    plan->d_post = b_post.ptr;
     std::vector<HF> c(q), tinv(q);
     HF s = hg;
     HF ninv = hf_invert(hf_from_fe32(to_abi(from_u64<Fr>((uint64_t)n))));
@@ -105,6 +121,8 @@ int zk::coset_plan(zkhip_ctx* ctx, const zkhip_domain* d, const CosetPlan** out)
     for (uint32_t j = 0; j < q; ++j)
         for (uint32_t r = 0; r < q; ++r) put_abi(plan->minv_abi.data() + 4 * ((size_t)j * q + r), hmul(at(j, q + r), tinv[r]));
     ZK_HIP(hipStreamSynchronize(ctx->stream));   // one-time: other streams of the context read the tables too
+    b_pre.keep();
+    b_post.keep();
     ctx->host_objects[name] = plan;
     *out = plan.get();
     return ZKHIP_OK;
@@ -155,8 +173,9 @@ int zk::key_cosets(zkhip_ctx* ctx, const CosetPlan* cp, const zk_proving_key* pk
     const size_t n = (size_t)1 << p->k, NB = n * 32, CB = p->q * NB;
     char name[96];
     snprintf(name, sizeof name, "key_cosets:%llx:%u:%u", (unsigned long long)pk->key_id, p->k, p->q);
-    void* base;
-    ZK_TRY(dev_alloc(ctx, name, (size_t)(F + P + 3) * CB, &base));
+    PendingBuffer b_key(ctx, name);
+    ZK_TRY(b_key.alloc((size_t)(F + P + 3) * CB));
+    void* base = b_key.ptr;
     KeyCosets kc;
     std::vector<const void*> src;
     std::vector<void*> dst;
@@ -186,6 +205,7 @@ int zk::key_cosets(zkhip_ctx* ctx, const CosetPlan* cp, const zk_proving_key* pk
     ZK_TRY(coeff_to_cosets(ctx, p, (const void* const*)lag, l_dst, 3));
     kc.l0 = l_dst[0]; kc.l_last = l_dst[1]; kc.l_active = l_dst[2];
     ZK_HIP(hipStreamSynchronize(ctx->stream));   // one-time; later proofs may read these from any stream of the context
+    b_key.keep();
     auto ins = p->keys.emplace(pk->key_id, std::move(kc));
     *out = &ins.first->second;
     return ZKHIP_OK;
@@ -198,6 +218,15 @@ void zk::coset_forget_key(zkhip_ctx* ctx, uint64_t key_id) {
 
 // ------------------------------------------------------------------ C ABI
 extern "C" {
+// 1 if zkhip_create_proof_ex will evaluate this key's quotient on cosets of the size-n domain (so the key's extended-domain forms —
+// fixed_cosets, sigma_cosets, l0, l_last, l_active_row — may be NULL), 0 if it will use the extended domain and needs them.  The same
+// predicate the prover evaluates: a binding asks instead of guessing (the Rust shim decided on its own).
+int zkhip_coset_quotient_applies(const zkhip_ctx* ctx, const zk_proving_key* pk) {
+    if (!ctx || !pk || !pk->domain) return 0;
+    const uint32_t k = zkhip_domain_k(pk->domain), ek = zkhip_domain_extended_k(pk->domain), qd = zkhip_domain_quotient_poly_degree(pk->domain);
+    return ctx->opt.coset_quotient != 0 && pk->key_id != 0 && qd >= 2 && qd < (1u << (ek - k)) && (!pk->n_fixed || pk->fixed_coeff) &&
+           (!pk->n_perm_columns || pk->sigma_coeff);
+}
 int zkhip_domain_cosets(zkhip_ctx* ctx, const zkhip_domain* dom, uint32_t* q, uint64_t* shifts) {
     const CosetPlan* p;
     ZK_TRY(coset_plan(ctx, dom, &p));

@@ -56,7 +56,16 @@ struct Overlap {
 struct StreamGuard {   // whatever happens, the context leaves on its main stream
     zkhip_ctx* ctx;
     hipStream_t main;
-    ~StreamGuard() { ctx->stream = main; }
+    bool host_uploads = false, done = false;
+    // an error exit after asynchronous copies FROM THE CALLER'S host buffers were enqueued: wait for them, or a caller that drops its
+    // Vec<Fr> / pinned buffers on the error races the DMA still in flight
+    ~StreamGuard() {
+        ctx->stream = main;
+        if (host_uploads && !done) {
+            if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+            (void)hipStreamSynchronize(main);
+        }
+    }
 };
 inline void abi_of(const HF& a, uint64_t out[4]) { fe32 m = hf_abi(a); memcpy(out, m.w, 32); }
 }  // namespace
@@ -100,6 +109,21 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
         set_error("zkhip_create_proof: SRS / domain do not match k = %u", k);
         return ZKHIP_EINVAL;
     }
+    // every input check comes BEFORE the first asynchronous copy from the caller's memory
+    if (!in->d_instance)
+        for (uint32_t j = 0; j < I; ++j)
+            if (in->instance_len[j] > n || (in->instance_len[j] && !in->instance_values[j])) {
+                set_error("zkhip_create_proof: instance column %u has %zu values (n = %zu) or a null pointer", j, (size_t)in->instance_len[j], n);
+                return ZKHIP_EINVAL;
+            }
+    for (uint32_t j = 0; j < A; ++j)
+        if (!in->advice[j]) { set_error("zkhip_create_proof: advice column %u is null", j); return ZKHIP_EINVAL; }
+    if (bl && ((L && !bl->lookup_permuted) || (Zp && bf && !bl->perm_z) || (L && bf && !bl->lookup_z) || !bl->random_poly)) {
+        // a caller that supplies its rng draws supplies ALL of them: silently falling back to the seeded generator for a missing member
+        // would make those blinding rows predictable (zero knowledge lost without an error)
+        set_error("zkhip_create_proof: zk_blinding given but a member with a non-zero row count is NULL (lookup_permuted / perm_z / lookup_z / random_poly)");
+        return ZKHIP_EINVAL;
+    }
     uint64_t omega_abi[4], ext_omega_abi[4], g_coset_abi[4];
     zkhip_domain_constants(pk->domain, omega_abi, ext_omega_abi, g_coset_abi);
 
@@ -112,6 +136,7 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
     const bool serial = ctx->opt.late_overlap == 2;   // analysis only: everything on the main stream, so a kernel trace shows isolated durations
     Overlap ov{ctx, ctx->stream, serial ? ctx->stream : ctx->side_stream, ctx->side_event, late};
     StreamGuard guard{ctx, ctx->stream};
+    guard.host_uploads = in->advice_on_host || (bl && bl->on_host);
     hipStream_t st = ctx->stream;
 
     // ---- one proof over several GPUs (comm.hip): MSMs are collective by themselves (sharded SRS handles); here the coset NTTs go by
@@ -126,8 +151,7 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
     // (key_id) — quotient_poly_degree cosets of the size-n domain (cosets.hip); the same h either way
     const zk::CosetPlan* cplan = nullptr;
     const zk::KeyCosets* kcos = nullptr;
-    const bool coset_mode = ctx->opt.coset_quotient != 0 && pk->key_id != 0 && qd >= 2 && qd < (1u << (ek - k)) && (!F || pk->fixed_coeff) &&
-                            (!P || pk->sigma_coeff);
+    const bool coset_mode = zkhip_coset_quotient_applies(ctx, pk) != 0;
     if (coset_mode) {
         ZK_TRY(zk::coset_plan(ctx, pk->domain, &cplan));
         ZK_TRY(zk::key_cosets(ctx, cplan, pk, &kcos));
@@ -179,7 +203,6 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
     for (uint32_t j = 0; j < I; ++j) {
         if (in->d_instance) { ins_cols[j] = in->d_instance[j]; continue; }
         const size_t len = in->instance_len[j];
-        if (len > n) { set_error("zkhip_create_proof: instance column %u has %zu values > n", j, len); return ZKHIP_EINVAL; }
         ZK_HIP(hipMemsetAsync(w_ins_in + j * NB, 0, NB, st));
         if (len) ZK_TRY(ctx->upload(w_ins_in + j * NB, in->instance_values[j], len * 32));
         ins_cols[j] = w_ins_in + j * NB;
@@ -582,5 +605,6 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
             fprintf(stderr, "  %8.1f us  (+%7.1f)  %s\n", std::chrono::duration<double, std::micro>(marks[i].t - marks[0].t).count(),
                     std::chrono::duration<double, std::micro>(marks[i].t - marks[i - 1].t).count(), marks[i].what);
     }
+    guard.done = true;
     return ZKHIP_OK;
 }

@@ -30,7 +30,9 @@ using namespace zk;
 struct LcArgs {
     const uint32_t* p[LC_MAX];
     fe32 c[LC_MAX];        // R' form, canonical
-    fe32 low[LC_LOW_MAX];  // ABI scale
+    fe32 low[LC_LOW_MAX];  // ABI scale; a correction of more than LC_LOW_MAX coefficients (a rotation set of more than 8 points:
+                           // the zkevm SHA-256 bit circuit queries its bit columns at many rotations) comes from low_dev instead
+    const uint32_t* low_dev;
 };
 // out[i] = (accumulate ? out[i] : 0) + sum_j c_j polys[j][i] - (i < nlow ? low[i] : 0)
 __global__ void __launch_bounds__(256) k_lincomb(const LcArgs A, uint32_t npolys, size_t n, uint32_t nlow, int accumulate, uint32_t* out) {
@@ -53,7 +55,7 @@ __global__ void __launch_bounds__(256) k_lincomb(const LcArgs A, uint32_t npolys
     for (; j + 2 <= npolys; j += 2)
         acc = canonical(acc + muladd2(load_raw<Fr>(A.p[j] + i * 8), el1<Fr>(sc[j]), load_raw<Fr>(A.p[j + 1] + i * 8), el1<Fr>(sc[j + 1])));
     for (; j < npolys; ++j) acc = canonical(acc + load_raw<Fr>(A.p[j] + i * 8) * el1<Fr>(sc[j]));
-    if (i < nlow) acc = canonical(acc - el1<Fr>(fe_split<0>(A.low[i])));
+    if (i < nlow) acc = canonical(acc - el1<Fr>(fe_split<0>(A.low_dev ? mem_load(A.low_dev + i * 8) : A.low[i])));
     store_raw<Fr>(out + i * 8, acc);
 }
 
@@ -193,6 +195,11 @@ static int divide_round(zkhip_ctx* ctx, size_t n, const std::vector<KdEntry>& en
 // out = sum_j c_j polys[j] - low with the scalars already in R' form (raw) and low in ABI scale
 static int lincomb_raw(zkhip_ctx* ctx, size_t n, const void* const* d_polys, size_t npolys, const fe32* coeffs_raw, const fe32* low_abi,
                        size_t nlow, void* d_out) {
+    void* d_low = nullptr;
+    if (nlow > LC_LOW_MAX) {   // stream-ordered upload through the pinned ring: the previous launch that read this scratch is ahead of it
+        ZK_TRY(ctx->get_scratch("lc_low", nlow * 32, &d_low));
+        ZK_TRY(ctx->upload(d_low, low_abi, nlow * 32));
+    }
     ProfScope ps(ctx, "linear_combination");
     size_t done = 0;
     do {
@@ -204,7 +211,8 @@ static int lincomb_raw(zkhip_ctx* ctx, size_t n, const void* const* d_polys, siz
             A.p[j] = (const uint32_t*)d_polys[done + j];
             A.c[j] = coeffs_raw[done + j];
         }
-        if (last) for (size_t j = 0; j < nlow; ++j) A.low[j] = low_abi[j];
+        if (last && !d_low) for (size_t j = 0; j < nlow; ++j) A.low[j] = low_abi[j];
+        if (last) A.low_dev = (const uint32_t*)d_low;
         hipLaunchKernelGGL(k_lincomb, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, A, cnt, n, last ? (uint32_t)nlow : 0u, done ? 1 : 0,
                            (uint32_t*)d_out);
         done += cnt;
@@ -248,7 +256,6 @@ int zkhip_shplonk_open(zkhip_ctx* ctx, const zkhip_srs* srs, size_t n, const voi
         q_pt[i] = j;
     }
     const uint32_t np = (uint32_t)upts.size();
-    if (np > LC_LOW_MAX) { set_error("zkhip_shplonk_open: %u distinct points (max %d)", np, LC_LOW_MAX); return ZKHIP_EINVAL; }
     std::vector<uint32_t> order(np);            // point indices ascending by value = the super point set
     for (uint32_t i = 0; i < np; ++i) order[i] = i;
     std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return words_less(uwords[a], uwords[b]); });
@@ -424,7 +431,7 @@ int zkhip_shplonk_open(zkhip_ctx* ctx, const zkhip_srs* srs, size_t n, const voi
 int zkhip_linear_combination_device(zkhip_ctx* ctx, size_t n, const void* const* d_polys, size_t npolys, const uint64_t* coeffs,
                                     const uint64_t* low, size_t nlow, void* d_out) {
     if (!ctx || !d_out || (npolys && (!d_polys || !coeffs)) || (nlow && !low)) { set_error("zkhip_linear_combination_device: null argument"); return ZKHIP_EINVAL; }
-    if (nlow > n || nlow > LC_LOW_MAX) { set_error("zkhip_linear_combination_device: nlow = %zu unsupported (<= min(n, %d))", nlow, LC_LOW_MAX); return ZKHIP_EINVAL; }
+    if (nlow > n) { set_error("zkhip_linear_combination_device: nlow = %zu exceeds n = %zu", nlow, n); return ZKHIP_EINVAL; }
     if (n == 0) return ZKHIP_OK;
     std::vector<fe32> cf(npolys ? npolys : 1), lw(nlow ? nlow : 1);
     for (size_t j = 0; j < npolys; ++j) cf[j] = abi_to_raw(coeffs + 4 * j);

@@ -54,7 +54,7 @@ class ZkEvalhArgs(C.Structure):
 # every symbol include/zkhip.h declares (checked by tests/test_abi.py without a GPU)
 SYMBOLS = [
     "zkhip_init", "zkhip_destroy", "zkhip_last_error", "zkhip_set_stream", "zkhip_synchronize", "zkhip_set_option", "zkhip_trim", "zkhip_key_release",
-    "zkhip_comm_unique_id", "zkhip_comm_init", "zkhip_comm_init_host", "zkhip_comm_destroy", "zkhip_comm_info", "zkhip_comm_allgather_device", "zkhip_comm_shard_columns",
+    "zkhip_comm_unique_id", "zkhip_comm_init", "zkhip_comm_init_host", "zkhip_comm_destroy", "zkhip_comm_info", "zkhip_comm_describe", "zkhip_comm_allgather_device", "zkhip_comm_shard_columns",
     "zkhip_kzg_setup_range", "zkhip_srs_load_range", "zkhip_srs_range", "zkhip_malloc", "zkhip_free",
     "zkhip_memcpy_h2d", "zkhip_memcpy_d2h", "zkhip_timer_start", "zkhip_timer_stop_ms",
     "zkhip_profile_enable", "zkhip_profile_select", "zkhip_profile_read", "zkhip_profile_counter",
@@ -71,7 +71,7 @@ SYMBOLS = [
     "zkhip_batch_invert_device", "zkhip_eval_polynomial_device", "zkhip_eval_polynomials_at_device", "zkhip_permutation_products_device",
     "zkhip_permute_expression_pair_device", "zkhip_lookup_product_device", "zkhip_grand_products_device",
     "zkhip_linear_combination_device", "zkhip_divide_by_linear_device", "zkhip_kate_division_device", "zkhip_shplonk_open",
-    "zkhip_create_proof", "zkhip_create_proof_ex",
+    "zkhip_create_proof", "zkhip_create_proof_ex", "zkhip_coset_quotient_applies",
     "zkhip_blake2b_transcript_new", "zkhip_blake2b_transcript_free", "zkhip_blake2b_transcript_callbacks", "zkhip_blake2b_transcript_proof",
     "zkhip_blake2b_transcript_points", "zkhip_blake2b_transcript_challenges",
     "zkhip_evm_transcript_new", "zkhip_evm_transcript_free", "zkhip_evm_transcript_callbacks", "zkhip_evm_transcript_proof",
@@ -247,6 +247,16 @@ class Context:
         v = C.c_uint64()
         _check(lib().zkhip_comm_info(self.h, None, None, C.byref(v)))
         return v.value
+
+    def comm_describe(self):
+        """-> dict(transport, nranks, transport_ranks, bytes_gathered, collectives): what the library's communicator itself reports
+        (transport_ranks is ncclCommCount for RCCL: evidence that RCCL joined that many processes)"""
+        buf = C.create_string_buffer(16)
+        tr, co, by, rk, nr = C.c_int(), C.c_uint64(), C.c_uint64(), C.c_int(), C.c_int()
+        _check(lib().zkhip_comm_describe(self.h, buf, C.c_size_t(16), C.byref(tr), C.byref(co)))
+        _check(lib().zkhip_comm_info(self.h, C.byref(rk), C.byref(nr), C.byref(by)))
+        return dict(transport=buf.value.decode(), rank=rk.value, nranks=nr.value, transport_ranks=tr.value, bytes_gathered=by.value,
+                    collectives=co.value)
 
     def comm_allgather(self, send, recv):
         """all-gather of device tensors through the context's communicator (recv: world x send)"""

@@ -103,6 +103,9 @@ int  zkhip_comm_destroy(zkhip_ctx* ctx);
  * every rank computes every column.  Point-range handles (zkhip_kzg_setup_range) are always split by point range. */
 int  zkhip_comm_shard_columns(zkhip_ctx* ctx, int on);
 int  zkhip_comm_info(const zkhip_ctx* ctx, int* rank, int* nranks, uint64_t* bytes_gathered);
+/* transport <- "rccl" / "host" / "none"; transport_ranks <- the rank count the transport itself reports (ncclCommCount for RCCL, -1 if that
+ * symbol is missing); collectives <- exchanges issued so far.  What a launcher prints to show that RCCL really spans N processes. */
+int  zkhip_comm_describe(const zkhip_ctx* ctx, char* transport, size_t cap, int* transport_ranks, uint64_t* collectives);
 int  zkhip_comm_allgather_device(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_rank);
 
 /* ---- SRS: ParamsKZG::{g, g_lagrange} (halo2_proofs src/poly/kzg/commitment.rs) ----
@@ -295,7 +298,7 @@ int  zkhip_grand_products_device(zkhip_ctx* ctx, uint32_t k, const uint64_t beta
  * gen_snark_shplonk at /root/reference/src/helpers.rs:233,299) ----
  * d_out[i] = sum_j coeffs[j] * d_polys[j][i] - (i < nlow ? low[i] : 0): the y- / v-power combinations of the rotation sets'
  * polynomials minus the low-degree interpolant.  d_polys is a HOST array of device polynomials of n coefficients; coeffs
- * (npolys x 4) and low (nlow x 4, nlow <= 8) are host arrays; d_out must not alias an input. */
+ * (npolys x 4) and low (nlow x 4, nlow <= n) are host arrays; d_out must not alias an input. */
 int  zkhip_linear_combination_device(zkhip_ctx* ctx, size_t n, const void* const* d_polys, size_t npolys, const uint64_t* coeffs,
                                      const uint64_t* low, size_t nlow, void* d_out);
 /* d_dst[j] = d_src[j] / (X - roots[j]) (remainder dropped, top coefficient zero) for npolys polynomials of n coefficients in
@@ -312,7 +315,7 @@ int  zkhip_kate_division_device(zkhip_ctx* ctx, size_t n, void* const* d_polys, 
  * d_polys[query_poly[i]] (n coefficients, device) at query_points[i] with value query_evals[i] (host arrays, nq x 4 u64, ABI form;
  * the caller has computed the evaluations, e.g. with zkhip_eval_polynomials_at_device).  Rotation sets are formed as in
  * construct_intermediate_sets (commitments in query order, points ascending).  Scalars cross the callbacks in ABI form, points
- * as 32 compressed bytes and as affine (x, y).  At most 8 distinct points. */
+ * as 32 compressed bytes and as affine (x, y).  Any number of distinct points / rotation-set sizes (upstream has no limit). */
 typedef struct zk_transcript {
     void* user;
     void (*write_point)(void* user, const uint8_t bytes32[32], const uint64_t xy[8]);
@@ -398,8 +401,22 @@ typedef struct zk_proof_inputs {
                                                  (zkhip_synth_fill_device seeds +300.., +320.., +340, +360, +380) */
     uint64_t blinding_seed;
 } zk_proof_inputs;
+/* A zk_blinding that is given must be complete: every member whose row count is non-zero for this key (lookup_permuted / lookup_z with
+ * lookups, perm_z with permutation sets, random_poly always) must be non-NULL, else ZKHIP_EINVAL — never a silent fall-back to the
+ * seeded generator.  All argument checks happen before the first asynchronous copy from the caller's memory; on an error after that
+ * point the call waits for its copies before it returns, so the caller may drop its buffers.
+ * PHASES [UPSTREAM-RECALL: axiom's create_proof commits the advice columns phase by phase and squeezes the user challenges of a phase
+ * after its commitments]: this call implements ONE advice phase (FirstPhase) and no user challenges — zk_evalh_args.challenges is not
+ * fed by it.  The three circuits of the reference (RSA, zkevm SHA-256, the aggregation circuit; /root/reference/src/bin/cli.rs:296-527)
+ * use phase 0 only, so nothing on the path needs more; a multi-phase circuit (halo2-lib's RLC chips) must be proved through the
+ * step-wise entry points, committing each phase's columns and squeezing its challenges in the caller. */
 int  zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, const zk_proof_inputs* in, const zk_transcript* transcript,
                            zk_proof_out* out);
+/* 1 if zkhip_create_proof_ex will evaluate this key's quotient on quotient_poly_degree cosets of the size-n domain — the key's
+ * extended-domain forms (fixed_cosets, sigma_cosets, l0, l_last, l_active_row) may then be NULL — 0 if it will work on the extended
+ * domain and needs them (option "coset_quotient" off, key_id 0, degree too high, coefficient forms missing).  The predicate the prover
+ * itself evaluates: a binding asks it instead of re-deriving the rule. */
+int  zkhip_coset_quotient_applies(const zkhip_ctx* ctx, const zk_proving_key* pk);
 /* The resident-pipeline short form: device columns, seeded blinding, no instance absorption. */
 int  zkhip_create_proof(zkhip_ctx* ctx, const zk_proving_key* pk, const void* const* d_advice, const void* const* d_instance,
                         uint64_t blinding_seed, const zk_transcript* transcript, zk_proof_out* out);

@@ -6,7 +6,7 @@
 //! calculations, num_intermediates }`, `Calculation`, `ValueSource`): the module lives inside the crate, so private fields are reachable.
 use std::collections::HashMap;
 use std::ffi::c_void;
-use std::sync::{Mutex, OnceLock};
+use std::sync::{Arc, Mutex, OnceLock};
 
 use ff::{Field, PrimeField, WithSmallOrderMulGroup};
 use halo2curves::bn256::{Bn256, Fr, G1Affine};
@@ -104,9 +104,20 @@ fn compress_graph(exprs: &[crate::plonk::Expression<Fr>]) -> FlatGraph {
 
 // ---------------------------------------------------------------------------------------------------------------- device proving key
 struct DevCols {
+    ctx: *mut sys::zkhip_ctx,
     ptrs: Vec<*const c_void>,
 }
+impl Drop for DevCols {
+    fn drop(&mut self) {
+        for p in self.ptrs.drain(..) {
+            unsafe { sys::zkhip_free(self.ctx, p as *mut c_void) };
+        }
+    }
+}
 impl DevCols {
+    fn none(ctx: *mut sys::zkhip_ctx) -> Self {
+        DevCols { ctx, ptrs: Vec::new() }
+    }
     fn upload<B>(ctx: *mut sys::zkhip_ctx, polys: &[Polynomial<Fr, B>]) -> Self {
         let mut ptrs = Vec::with_capacity(polys.len());
         for p in polys {
@@ -118,13 +129,19 @@ impl DevCols {
             }
             ptrs.push(d as *const c_void);
         }
-        DevCols { ptrs }
+        DevCols { ctx, ptrs }
     }
 }
 
-/// Everything `zk_proving_key` points to, kept alive for the life of the process (one per `ProvingKey`, cached by its address).
+/// Everything `zk_proving_key` points to.  One per DISTINCT proving key, cached by the key's CONTENT (the verifying key's
+/// `transcript_repr`, a hash over the constraint system and the fixed / permutation commitments, plus k) — never by the address of the
+/// `ProvingKey`, which the allocator reuses: `let pk = keygen_pk(..)` in a loop would silently meet a stale entry.  Dropping the entry
+/// (`evict_device_key`, or process exit) releases what the library caches under `key_id` (`zkhip_key_release`: the key's columns in the
+/// coset layout, sorted lookup tables), the uploaded fixed / sigma columns and the domain.
 struct DeviceKey {
+    ctx: *mut sys::zkhip_ctx,
     ffi: sys::zk_proving_key,
+    ext_uploaded: bool,
     _fixed: [DevCols; 3],
     _sigma: [DevCols; 3],
     _l: DevCols,
@@ -143,6 +160,34 @@ struct DeviceKey {
     _fix_q: (Vec<u32>, Vec<i32>),
 }
 unsafe impl Send for DeviceKey {}
+impl Drop for DeviceKey {
+    fn drop(&mut self) {
+        unsafe {
+            sys::zkhip_key_release(self.ctx, self.ffi.key_id);
+            sys::zkhip_domain_free(self.ctx, self.ffi.domain as *mut sys::zkhip_domain);
+        }
+        // the DevCols members free their columns in their own Drop; the SRS handles belong to halo2curves::zkhip's cache (evict_srs)
+    }
+}
+
+type KeyFingerprint = ([u8; 32], u32);
+fn fingerprint(pk: &ProvingKey<G1Affine>) -> KeyFingerprint {
+    // VerifyingKey { transcript_repr, .. }: private field, reachable inside the crate [UPSTREAM-RECALL]
+    (pk.vk.transcript_repr.to_repr(), pk.vk.get_domain().k())
+}
+fn key_cache() -> &'static Mutex<HashMap<KeyFingerprint, Arc<Mutex<DeviceKey>>>> {
+    static KEYS: OnceLock<Mutex<HashMap<KeyFingerprint, Arc<Mutex<DeviceKey>>>>> = OnceLock::new();
+    KEYS.get_or_init(|| Mutex::new(HashMap::new()))
+}
+/// Drops the device-side copy of `pk` (call when a proving key is retired: a long-lived service that rotates circuits).  The entry is
+/// freed when the last proof using it has returned.
+pub fn evict_device_key(pk: &ProvingKey<G1Affine>) -> bool {
+    key_cache().lock().unwrap().remove(&fingerprint(pk)).is_some()
+}
+/// Drops every cached key (before `zkhip_destroy` of the process-wide context).
+pub fn evict_all_device_keys() {
+    key_cache().lock().unwrap().clear();
+}
 
 fn single_column(exprs: &[crate::plonk::Expression<Fr>], want_advice: bool) -> i32 {
     use crate::plonk::Expression;
@@ -156,12 +201,12 @@ fn single_column(exprs: &[crate::plonk::Expression<Fr>], want_advice: bool) -> i
     }
 }
 
-fn device_key(ctx: *mut sys::zkhip_ctx, params: &ParamsKZG<Bn256>, pk: &ProvingKey<G1Affine>) -> &'static Mutex<DeviceKey> {
-    static KEYS: OnceLock<Mutex<HashMap<usize, &'static Mutex<DeviceKey>>>> = OnceLock::new();
+fn device_key(ctx: *mut sys::zkhip_ctx, params: &ParamsKZG<Bn256>, pk: &ProvingKey<G1Affine>) -> Arc<Mutex<DeviceKey>> {
     static NEXT_ID: std::sync::atomic::AtomicU64 = std::sync::atomic::AtomicU64::new(1);
-    let mut keys = KEYS.get_or_init(|| Mutex::new(HashMap::new())).lock().unwrap();
-    if let Some(k) = keys.get(&(pk as *const _ as usize)) {
-        return k;
+    let fp = fingerprint(pk);
+    let mut keys = key_cache().lock().unwrap();
+    if let Some(k) = keys.get(&fp) {
+        return k.clone();
     }
     let cs = pk.vk.cs();
     let domain = pk.vk.get_domain();
@@ -174,13 +219,12 @@ fn device_key(ctx: *mut sys::zkhip_ctx, params: &ParamsKZG<Bn256>, pk: &ProvingK
     // cs.degree() - 1 cosets of the size-n domain are fewer rows than the extended domain (halo2-lib's degree 4: 3 < 4): the library
     // evaluates the quotient there and derives the key's columns in that layout from the coefficient forms (include/zkhip.h, "the same
     // quotient on quotient_poly_degree cosets"), so the pk's extended cosets — most of its bytes — are not uploaded at all
-    let coset_path = (cs.degree() as u32 - 1) < (1u32 << (domain.extended_k() - domain.k()));
-    let ext = |cols: &[Polynomial<Fr, ExtendedLagrangeCoeff>]| if coset_path { DevCols { ptrs: Vec::new() } } else { DevCols::upload(ctx, cols) };
-    let fixed = [DevCols::upload(ctx, &pk.fixed_values), DevCols::upload(ctx, &pk.fixed_polys), ext(&pk.fixed_cosets)];
-    let sigma = [DevCols::upload(ctx, &pk.permutation.permutations), DevCols::upload(ctx, &pk.permutation.polys), ext(&pk.permutation.cosets)];
-    let l = ext(&[pk.l0.clone(), pk.l_last.clone(), pk.l_active_row.clone()]);
-    let or_null = |d: &DevCols| if d.ptrs.is_empty() { std::ptr::null() } else { d.ptrs.as_ptr() };
-    let l_ptr = |i: usize| if l.ptrs.is_empty() { std::ptr::null() } else { l.ptrs[i] };
+    // Whether that path applies is the LIBRARY's decision (option "coset_quotient" / ZKHIP_COSET_QUOTIENT, degree, key_id): the key is
+    // first assembled without the extended forms, the library is asked (zkhip_coset_quotient_applies), and the extended forms are
+    // uploaded only if it answers no (`ensure_extended` below) — the shim never guesses.
+    let fixed = [DevCols::upload(ctx, &pk.fixed_values), DevCols::upload(ctx, &pk.fixed_polys), DevCols::none(ctx)];
+    let sigma = [DevCols::upload(ctx, &pk.permutation.permutations), DevCols::upload(ctx, &pk.permutation.polys), DevCols::none(ctx)];
+    let l = DevCols::none(ctx);
     let gates = FlatGraph::new(&pk.ev.custom_gates);
     let lookup_graphs: Vec<FlatGraph> = pk.ev.lookups.iter().map(FlatGraph::new).collect();
     let compress_in: Vec<FlatGraph> = cs.lookups().iter().map(|a| compress_graph(a.input_expressions())).collect();
@@ -215,13 +259,13 @@ fn device_key(ctx: *mut sys::zkhip_ctx, params: &ParamsKZG<Bn256>, pk: &ProvingK
         domain: dom,
         fixed_lagrange: fixed[0].ptrs.as_ptr(),
         fixed_coeff: fixed[1].ptrs.as_ptr(),
-        fixed_cosets: or_null(&fixed[2]),
+        fixed_cosets: std::ptr::null(),
         sigma_lagrange: sigma[0].ptrs.as_ptr(),
         sigma_coeff: sigma[1].ptrs.as_ptr(),
-        sigma_cosets: or_null(&sigma[2]),
-        l0: l_ptr(0),
-        l_last: l_ptr(1),
-        l_active_row: l_ptr(2),
+        sigma_cosets: std::ptr::null(),
+        l0: std::ptr::null(),
+        l_last: std::ptr::null(),
+        l_active_row: std::ptr::null(),
         custom_gates: gates.ffi(),
         lookup_graphs: lookup_ffi.as_ptr(),
         lookup_input_compress: compress_in_ffi.as_ptr(),
@@ -240,8 +284,10 @@ fn device_key(ctx: *mut sys::zkhip_ctx, params: &ParamsKZG<Bn256>, pk: &ProvingK
         delta: delta_w,
         vk_transcript_repr: std::ptr::null(), // absorbed by upstream's code before the hand-over
     };
-    let key: &'static Mutex<DeviceKey> = Box::leak(Box::new(Mutex::new(DeviceKey {
+    let key = Arc::new(Mutex::new(DeviceKey {
+        ctx,
         ffi,
+        ext_uploaded: false,
         _fixed: fixed,
         _sigma: sigma,
         _l: l,
@@ -258,9 +304,28 @@ fn device_key(ctx: *mut sys::zkhip_ctx, params: &ParamsKZG<Bn256>, pk: &ProvingK
         _perm_index: perm_index,
         _adv_q: adv_q,
         _fix_q: fix_q,
-    })));
-    keys.insert(pk as *const _ as usize, key);
+    }));
+    keys.insert(fp, key.clone());
     key
+}
+
+/// The extended-domain forms of the key (fixed / sigma cosets, l_0, l_last, l_active_row), uploaded the first time the library says
+/// it will work on the extended domain for this key (coset quotient switched off for byte parity on unsatisfied witnesses, or a
+/// degree for which the cosets save nothing).
+fn ensure_extended(key: &mut DeviceKey, pk: &ProvingKey<G1Affine>) {
+    if key.ext_uploaded || unsafe { sys::zkhip_coset_quotient_applies(key.ctx, &key.ffi) } != 0 {
+        return;
+    }
+    let ctx = key.ctx;
+    key._fixed[2] = DevCols::upload(ctx, &pk.fixed_cosets);
+    key._sigma[2] = DevCols::upload(ctx, &pk.permutation.cosets);
+    key._l = DevCols::upload(ctx, &[pk.l0.clone(), pk.l_last.clone(), pk.l_active_row.clone()]);
+    key.ffi.fixed_cosets = key._fixed[2].ptrs.as_ptr();
+    key.ffi.sigma_cosets = key._sigma[2].ptrs.as_ptr();
+    key.ffi.l0 = key._l.ptrs[0];
+    key.ffi.l_last = key._l.ptrs[1];
+    key.ffi.l_active_row = key._l.ptrs[2];
+    key.ext_uploaded = true;
 }
 
 // ---------------------------------------------------------------------------------------------------------------- transcript callbacks
@@ -306,7 +371,9 @@ pub fn create_proof_after_synthesis<E: EncodedChallenge<G1Affine>, R: RngCore, T
     transcript: &mut T,
 ) -> Result<(), Error> {
     let ctx = curves_zkhip::context().expect("zkhip context");
-    let key = device_key(ctx, params, pk).lock().unwrap();
+    let key_entry = device_key(ctx, params, pk);
+    let mut key = key_entry.lock().unwrap();
+    ensure_extended(&mut key, pk);
     let cs = pk.vk.cs();
     let n = params.n() as usize;
     let bf = cs.blinding_factors();

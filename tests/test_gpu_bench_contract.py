@@ -38,7 +38,7 @@ def test_bench_prints_one_contract_line():
     assert d["config"]["headline"] == "agg22" and d["config"]["k"] == 22 and d["config"]["transcript"] == "evm"
     assert abs(d["value"] * 1000.0 - d["ms_per_step"]) < 1e-3 and 0.05 < d["value"] < 1.0
     rf = d["roofline"]
-    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s") and rf["peak"] == 8000.0
+    assert rf["bound"] in ("hbm", "mfma", "valu") and abs(rf["hbm_frac"] - rf["frac"]) < 1e-9 and rf["unit"] in ("GB/s", "TFLOP/s") and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and rf["avg_launch_ms"] > 0
     assert rf["traffic"] is None or rf["traffic"] > 0          # quoted only when profiles/ holds a PMC pass of exactly this build
     cfg = d["configs"]["agg22"]
@@ -49,17 +49,35 @@ def test_bench_prints_one_contract_line():
     assert cfg["setup_s"] > 0 and cfg["resident_bytes"] > (6 << 30) and cfg["proof_bytes"] > 1000
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > d["value"] and cb["unit"] == "s" and cb["sample"]
-    assert cb["scale"] == 16.0 and abs(cb["value"] - cb["measured_s"] * 16.0) < 1e-2
+    # measured at k = 20 (one full pass) and carried to k = 22 by the MEASURED k = 18 -> 20 growth: scale <= 4 x 4 rows, stated in the line
+    assert cb["measured_k"] == 20 and 1.0 < cb["scale"] <= 20.0 and 3.0 < cb["growth_per_4x_rows"] < 5.0
+    assert abs(cb["value"] - cb["measured_s"] * cb["scale"]) < 0.05 and cb["k18_s"] < cb["measured_s"]
+    assert d["comm"] is None and d["first_proof_s"] > d["setup_s"]
 
 
 def test_bench_two_ranks_on_one_device():
     """the N > 1 control flow of bench.py (one k = 18 proof sharded over 2 ranks through the library's communicator, host-staged
     transport because both ranks share device 0): a strong-scaling line from rank 0"""
     env = dict(os.environ, ZKHIP_BENCH_ONE_DEVICE="1", ZKHIP_BENCH_DIST_BACKEND="gloo")
-    d = _run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-              os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--agg-k", "18"], env=env)
+    env.pop("WORLD_SIZE", None)
+    # `python bench.py --gpus 2` on its own: bench.py starts its two ranks itself (torch.distributed.run as a child process)
+    d = _run([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--agg-k", "18"], env=env)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["proofs_per_step"] == 1 and "sharded x2" in d["config"]["parallelism"]
     assert d["cpu_baseline"] is None and d["value"] > 0
+    cm = d["comm"]
+    assert cm["transport"] == "host" and cm["nranks"] == 2 and cm["transport_ranks"] == 2 and cm["shard_mode"] == "columns"
+    assert cm["bytes_gathered_per_step"] > 0 and cm["collectives_total"] > 0
+
+
+def test_bench_fails_without_a_communicator():
+    """N > 1 and no communicator: the run fails (no weak-scaling line under a strong-scaling n_gpus) unless --allow-replicas"""
+    env = dict(os.environ, ZKHIP_BENCH_ONE_DEVICE="1", ZKHIP_BENCH_DIST_BACKEND="gloo", ZKHIP_BENCH_FAIL_COMM="1")
+    env.pop("WORLD_SIZE", None)
+    args = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--agg-k", "16"]
+    r = subprocess.run(args, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    d = _run(args[1:] + ["--allow-replicas"], env=env)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["proofs_per_step"] == 2 and "comm_note" in d and d["comm"] is None
 
 
 def test_bench_chain_four_ranks_on_one_device():
@@ -69,3 +87,4 @@ def test_bench_chain_four_ranks_on_one_device():
     d = _run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
               os.path.join(ROOT, "bench.py"), "--gpus", "4", "--chain", "--steps", "1", "--warmup", "1", "--agg-k", "18"], env=env)
     assert d["n_gpus"] == 4 and d["proofs_per_step"] == 5 and "chain" in d["config"]["workload"] and d["value"] > 0
+    assert d["comm"]["nranks"] == 4 and d["comm"]["bytes_gathered_per_step"] > 0 and len(d["proof_bytes"]) == 2

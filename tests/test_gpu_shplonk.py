@@ -130,3 +130,53 @@ def test_native_multiopen_golden(zk, oracle):
     assert order == ["shplonk_y", "shplonk_v", "shplonk_h1", "shplonk_u", "shplonk_h2"]
     for got, exp in ((pr["h1"], g["h1"]), (pr["h2"], g["h2"])):
         assert zo.affine_to_ints(np.asarray(got[0]).reshape(1, 8))[0] == (H(exp[0]), H(exp[1]))
+
+
+def test_native_multiopen_many_rotations(zk, oracle):
+    """Rotation sets of 12 and 13 points (> 8: the zkevm SHA-256 bit circuit queries its bit columns at many rotations,
+    /root/reference/src/sha256_bit_circuit.rs:51-56; upstream's SHPLONK has no limit): zkhip_shplonk_open == the Python SHPLONK on the
+    oracle backend (commitments h1, h2), and the verifier's equation under the SRS trapdoor holds."""
+    import halo2_zkcert_amd.prover as pv
+    import halo2_zkcert_amd.shplonk as sp
+    import pyref
+    from oracle_backend import OracleBackend
+
+    ffi, ctx = zk
+    zo = oracle
+    k, n, s = 9, 1 << 9, 0x5EED1234
+    omega = pow(pv.ROOT_OF_UNITY, 1 << (28 - k), R)
+    x = 0x1234567890ABCDEF1234567890ABCDEF % R
+    rots_a = list(range(-5, 7))                  # 12 points
+    rots_b = list(range(-6, 7))                  # 13 points, a different set
+    polys_h = [zo.synth_raw253(7800 + j, n) for j in range(4)]
+    pt = lambda r_: x * pow(omega, r_ % (1 << k), R) % R
+    queries = []
+    for pid, rots in ((0, rots_a), (1, [0, 1]), (2, rots_a), (3, rots_b)):
+        for r_ in rots:
+            e = zo.fr_to_int(zo.eval_polynomial(polys_h[pid], zo.fr_from_int(pt(r_))))
+            queries.append((pid, pt(r_), e))
+    ch = {"shplonk_y": 0x1111111122222222 % R, "shplonk_v": 0x3333333344444444555555 % R, "shplonk_u": 0x66666666777777778888888899 % R}
+    ob = OracleBackend(4)
+    ob.setup(k, 3, s)
+    ref = sp.ProverSHPLONK(ob).create_proof({i: q.copy() for i, q in enumerate(polys_h)}, queries, lambda t: ch[t], lambda t, c: None)
+    b = pv.GpuBackend(ctx, ffi)
+    b.setup(k, 3, s)
+    polys = {i: ctx.to_device(q) for i, q in enumerate(polys_h)}
+    flat = zo.fr_arr_from_ints([e for _, _, e in queries])
+    pr = b.multiopen(polys, [(i, p_) for i, p_, _ in queries], flat, lambda t: ch[t], lambda t, pts: None)
+    aff = lambda g_: zo.affine_to_ints(np.asarray(g_[0]).reshape(1, 8))[0]
+    assert aff(pr["h1"]) == aff(ref["h1"]) and aff(pr["h2"]) == aff(ref["h2"])
+    # the verifier's side, sharing no code with either prover: commitments by the oracle's MSM, equation under the trapdoor
+    commits = {i: zo.affine_to_ints(zo.g1_to_affine(zo.best_multiexp(q, ob.g, 4)).reshape(1, 8))[0] for i, q in enumerate(polys_h)}
+    sets, supers = [], sorted({p_ for _, p_, _ in queries})
+    for pid in range(4):
+        pts = sorted(p_ for i, p_, _ in queries if i == pid)
+        ev = {p_: e for i, p_, e in queries if i == pid}
+        for rs in sets:
+            if rs["points"] == pts:
+                rs["commitments"].append((pid, [ev[p_] for p_ in pts]))
+                break
+        else:
+            sets.append({"points": pts, "commitments": [(pid, [ev[p_] for p_ in pts])]})
+    assert len(sets) == 3 and max(len(rs["points"]) for rs in sets) == 13
+    assert pyref.shplonk_verify(commits, sets, supers, ch["shplonk_y"], ch["shplonk_v"], ch["shplonk_u"], aff(pr["h1"]), aff(pr["h2"]), s)
