@@ -254,7 +254,7 @@ def test_quad_cooperative_point_ops(zk, oracle):
     def xyzz(k, z):   # k*G in XYZZ coordinates with Z = z, raw R' (2^261) form limbs
         if k == 0:
             return [0, R261, 0, 0]
-        x, y = zo.affine_to_ints(zo.g1_to_affine(zo.g1_mul_gen(zo.fr_from_int(k))).reshape(1, 8))[0]
+        x, y = zo.affine_to_ints(zo.g1_mul_gen(zo.fr_from_int(k)).reshape(1, 8))[0]
         zz, zzz = z * z % P_MOD, z * z * z % P_MOD
         return [v * R261 % P_MOD for v in (x * zz % P_MOD, y * zzz % P_MOD, zz, zzz)]
 

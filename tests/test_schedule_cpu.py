@@ -83,7 +83,7 @@ def test_blake2b_transcript_layout(oracle):
     import hashlib
 
     zo = oracle
-    g = zo.g1_to_affine(zo.g1_mul_gen(zo.fr_from_int(5)))                    # 5 G, Montgomery limbs
+    g = zo.g1_mul_gen(zo.fr_from_int(5))                    # 5 G, Montgomery limbs
     gx, gy = zo.affine_to_ints(g.reshape(1, 8))[0]
     s = 0x1234567890ABCDEF1234567890ABCDEF
     t = pv.Blake2bTranscript()
@@ -112,7 +112,7 @@ def test_native_blake2b_transcript_matches_python(oracle):
     expect_proof = b""
     got, exp = [], []
     for i in range(1, 30):
-        pt = zo.g1_to_affine(zo.g1_mul_gen(zo.fr_from_int(i * 7 + 1)))
+        pt = zo.g1_mul_gen(zo.fr_from_int(i * 7 + 1))
         byts = zo.g1_to_bytes(pt)
         cb.write_point(cb.user, (C.c_uint8 * 32)(*byts), pt.ctypes.data_as(C.POINTER(C.c_uint64)))
         py.write_point(pt)
@@ -159,7 +159,7 @@ def test_keccak_and_evm_transcript(oracle):
 
     got = []
     for i in range(1, 9):
-        pt = zo.g1_to_affine(zo.g1_mul_gen(zo.fr_from_int(i * 13 + 2)))
+        pt = zo.g1_mul_gen(zo.fr_from_int(i * 13 + 2))
         x, y = zo.affine_to_ints(pt.reshape(1, 8))[0]
         cb.write_point(cb.user, (C.c_uint8 * 32)(), pt.ctypes.data_as(C.POINTER(C.c_uint64)))
         enc = x.to_bytes(32, "big") + y.to_bytes(32, "big")
@@ -278,7 +278,7 @@ def test_poseidon_golden_and_library_transcript(oracle):
     expect_proof = b""
     got, exp = [], []
     for i in range(1, 14):
-        pt = zo.g1_to_affine(zo.g1_mul_gen(zo.fr_from_int(i * 11 + 3)))
+        pt = zo.g1_mul_gen(zo.fr_from_int(i * 11 + 3))
         x, y = zo.affine_to_ints(pt.reshape(1, 8))[0]
         t.write_point(pt)
         sp.update([x % P.R, y % P.R])

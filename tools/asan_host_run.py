@@ -13,7 +13,7 @@ L = ffi.lib()
 for kind in ("blake2b", "poseidon", "evm"):
     t = ffi.LibTranscript(kind)
     for i in range(1, 40):
-        pt = zo.g1_to_affine(zo.g1_mul_gen(zo.fr_from_int(i * 7 + 1)))
+        pt = zo.g1_mul_gen(zo.fr_from_int(i * 7 + 1))
         t.write_point(pt)
         t.common_scalar(zo.fr_from_int(i))
         if i % 3 == 0: t.write_scalar(zo.fr_from_int(pow(i, 33, P.R)))
