@@ -42,6 +42,27 @@ __global__ void __launch_bounds__(256) k_fixed_base_mul(const uint32_t* scalars,
     }
     g1j_store_raw(out_xyz + i * 24, acc);
 }
+// The setup's scalars on the device (the host loop — 2^22 x ~7 products in the limb layer compiled for the host — was 5 of the 6.3 s
+// that bench.py reported as setup_s at k = 22): 16 consecutive indices per thread, the first power by square-and-multiply.
+//   mono:     out[i] = s^(first + i)
+//   lagrange: pass 1  out[i] = s - w^(first + i)            (then one batch inversion over the array)
+//             pass 2  out[i] = num * w^(first + i) * out[i]  with num = (s^n - 1) / n:   l_i(s)
+// All in the ABI form (Montgomery, R = 2^256), as the fixed-base multiplication below reads them.
+__global__ void k_setup_scalars(uint32_t* out, size_t count, size_t first, fe base_v, fe s_v, fe num_v, int mode) {
+    const size_t CHK = 16;
+    const size_t lo = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) * CHK;
+    if (lo >= count) return;
+    const el2<Fr> base(base_v), sv(s_v), num(num_v);
+    el2<Fr> w = pow_u64<Fr>(base, (uint64_t)(first + lo));
+    const size_t hi = lo + CHK < count ? lo + CHK : count;
+    for (size_t i = lo; i < hi; ++i) {
+        if (mode == 0) store_div32<Fr>(out + i * 8, w);
+        else if (mode == 1) store_div32<Fr>(out + i * 8, reduce(sv - w));
+        else store_div32<Fr>(out + i * 8, (num * w) * load_x32<Fr>(out + i * 8));
+        w = w * base;
+    }
+}
+
 namespace zk {  // msm.hip
 int launch_batch_to_affine(zkhip_ctx* ctx, const void* d_in_xyz, void* d_out_xy, size_t n);
 int srs_build_raw(zkhip_ctx* ctx, const void* d_bases_raw, size_t n, zkhip_srs** out);
@@ -77,43 +98,30 @@ extern "C" int zkhip_kzg_setup_range(zkhip_ctx* ctx, uint32_t k, const uint64_t 
     const size_t n = (size_t)1 << k;
     if (count == 0 || first + count > n) { set_error("zkhip_kzg_setup_range: [%zu, %zu) is not inside [0, 2^%u)", first, first + count, k); return ZKHIP_EINVAL; }
     el2<Fr> s = from_abi<Fr>(mem_load(s_u));
-    std::vector<fe32> sc(count);
     void *d_sc, *d_pts;
     ZK_TRY(ctx->get_scratch("kzg_scalars", count * 32, &d_sc));
     ZK_TRY(ctx->get_scratch("kzg_points", count * 64, &d_pts));
     const el2<Fr> sn = pow_u64<Fr>(s, (uint64_t)n);
+    const dim3 grid(div_up(div_up(count, 16), 64)), block(64);
     if (g) {
-        el2<Fr> cur = pow_u64<Fr>(s, (uint64_t)first);
-        for (size_t i = 0; i < count; ++i) { sc[i] = to_abi(cur); cur = cur * s; }
-        ZK_HIP(hipMemcpyAsync(d_sc, sc.data(), count * 32, hipMemcpyHostToDevice, ctx->stream));
-        ZK_HIP(hipStreamSynchronize(ctx->stream));
+        hipLaunchKernelGGL(k_setup_scalars, grid, block, 0, ctx->stream, (uint32_t*)d_sc, count, first, s.v, s.v, s.v, 0);
+        ZK_LAUNCH_CHECK();
         ZK_TRY(zkhip_fixed_base_mul_device(ctx, d_sc, count, d_pts));
         ZK_TRY(srs_build_raw(ctx, d_pts, count, g));
         srs_set_range(*g, first, n);
     }
     if (g_lagrange) {
-        // l_i(s) = (s^n - 1)/n * w^i / (s - w^i), batch-inverted
+        // l_i(s) = (s^n - 1)/n * w^i / (s - w^i), batch-inverted on the device; s - w^i = 0 for some i iff s^n = 1
         el2<Fr> omega = from_canonical_words<Fr>(FR_ROOT_OF_UNITY);
         for (uint32_t i = k; i < FR_S; ++i) omega = sqr(omega);
-        el2<Fr> num = reduce(sn - one<Fr>()) * inv<Fr>(from_u64<Fr>((uint64_t)n));
-        std::vector<el2<Fr>> den(count), pre(count), val(count);
-        el2<Fr> w = pow_u64<Fr>(omega, (uint64_t)first), acc = one<Fr>();
-        for (size_t i = 0; i < count; ++i) {
-            den[i] = reduce(s - w);
-            if (is_zero(den[i])) { set_error("zkhip_kzg_setup: s is an n-th root of unity"); return ZKHIP_EINVAL; }
-            pre[i] = acc;
-            acc = acc * den[i];
-            val[i] = num * w;
-            w = w * omega;
-        }
-        el2<Fr> iv = inv<Fr>(acc);
-        for (size_t i = count; i-- > 0;) {
-            el2<Fr> di = iv * pre[i];
-            iv = iv * den[i];
-            sc[i] = to_abi(val[i] * di);
-        }
-        ZK_HIP(hipMemcpyAsync(d_sc, sc.data(), count * 32, hipMemcpyHostToDevice, ctx->stream));
-        ZK_HIP(hipStreamSynchronize(ctx->stream));
+        const el2<Fr> vanish = reduce(sn - one<Fr>());
+        if (is_zero(vanish)) { set_error("zkhip_kzg_setup: s is an n-th root of unity"); return ZKHIP_EINVAL; }
+        const el2<Fr> num = vanish * inv<Fr>(from_u64<Fr>((uint64_t)n));
+        hipLaunchKernelGGL(k_setup_scalars, grid, block, 0, ctx->stream, (uint32_t*)d_sc, count, first, omega.v, s.v, num.v, 1);
+        ZK_LAUNCH_CHECK();
+        ZK_TRY(zkhip_batch_invert_device(ctx, d_sc, count));
+        hipLaunchKernelGGL(k_setup_scalars, grid, block, 0, ctx->stream, (uint32_t*)d_sc, count, first, omega.v, s.v, num.v, 2);
+        ZK_LAUNCH_CHECK();
         ZK_TRY(zkhip_fixed_base_mul_device(ctx, d_sc, count, d_pts));
         ZK_TRY(srs_build_raw(ctx, d_pts, count, g_lagrange));
         srs_set_range(*g_lagrange, first, n);

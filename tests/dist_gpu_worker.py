@@ -28,22 +28,35 @@ ctx.comm_init(rank, world, dist)
 mode = os.environ.get("ZK_SHARD_MODE", "points")
 ctx.comm_shard(mode)
 out = {"transport": ctx.transport, "shard_mode": mode}
+native_only = os.environ.get("ZK_NATIVE_ONLY") == "1"       # full-size cases: the Python schedule (extended domain, no workspace reuse) is not run
 for spec in json.loads(os.environ["ZK_SHAPES"]):
     if spec[0] == "small":
         sh = pv.CircuitShape.small(spec[1])
     elif spec[0] == "sha":
         sh = pv.CircuitShape.sha256(spec[1], n_advice=12, n_fixed=5)
+    elif spec[0] == "shafull":                               # bench.py's SHA-256-shaped configuration (BASELINE configs[2])
+        sh = pv.CircuitShape.sha256(spec[1], n_advice=32, n_fixed=12)
+    elif spec[0] == "agg":                                   # bench.py's aggregation-shaped configuration (BASELINE configs[3])
+        sh = pv.CircuitShape.agg(spec[1], 3, 1)
     else:
         sh = pv.CircuitShape.rsa(spec[1])
     p = pv.Prover(pv.GpuBackend(ctx, ffi), sh, satisfiable=True)
     first, count, total = p.b.params.range()
     assert total == 1 << sh.k and (first, count) == (ctx.shard_range(total) if mode == "points" else (0, total)), (first, count, total)
     w = p.witness(1)
+    g0 = ctx.comm_bytes_gathered()
     tr = p.prove_native(w, transcript=spec[2])
-    tp = p.prove(w, transcript=spec[2])           # the Python schedule over the small entry points: MSMs collective, the rest replicated
-    out[f"{spec[0]}{spec[1]}{spec[2]}"] = dict(native=tr["proof"].hex(), python=tp["proof"].hex())
+    gathered = ctx.comm_bytes_gathered() - g0
+    # the Python schedule over the small entry points: MSMs collective, the rest replicated
+    tp = tr if native_only else p.prove(w, transcript=spec[2])
+    out[f"{spec[0]}{spec[1]}{spec[2]}"] = dict(native=tr["proof"].hex(), python=tp["proof"].hex(), bytes_gathered=gathered)
+    p.release()
     p.b.params.free()
+    del p, w, tr, tp
+    ctx.trim()
+    torch.cuda.empty_cache()
 out["bytes_gathered"] = ctx.comm_bytes_gathered()
+out["comm"] = ctx.comm_describe()
 with open(os.path.join(os.environ["ZK_OUT"], f"rank{rank}.json"), "w") as f:
     json.dump(out, f)
 dist.barrier()
