@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_DIR, "libzkhip.so")
+LIB_PATH = os.environ.get("ZKHIP_LIB") or os.path.join(_DIR, "libzkhip.so")   # ZKHIP_LIB: A/B runs of another build of the same library
 _LIB = None
 
 
