@@ -17,6 +17,9 @@
 // one-GPU box (RCCL refuses two ranks per device), or a launcher without RCCL.
 #include <dlfcn.h>
 
+#include <algorithm>
+#include <vector>
+
 #include "common.hpp"
 using namespace zk;
 
@@ -32,6 +35,10 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;    // optional: the all-to-all of row ranges
+    ncclResult_t (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;       // optional: what RCCL itself says the communicator spans
     ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -49,6 +56,10 @@ int load_rccl() {
     g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(h, "ncclAllGather");
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
+    g_rccl.Send = (decltype(g_rccl.Send))dlsym(h, "ncclSend");
+    g_rccl.Recv = (decltype(g_rccl.Recv))dlsym(h, "ncclRecv");
+    g_rccl.GroupStart = (decltype(g_rccl.GroupStart))dlsym(h, "ncclGroupStart");
+    g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))dlsym(h, "ncclGroupEnd");
     g_rccl.CommCount = (decltype(g_rccl.CommCount))dlsym(h, "ncclCommCount");
     g_rccl.CommUserRank = (decltype(g_rccl.CommUserRank))dlsym(h, "ncclCommUserRank");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy) {
@@ -66,6 +77,20 @@ int load_rccl() {
             return ZKHIP_EHIP;                                                                                  \
         }                                                                                                       \
     } while (0)
+
+// a batch of row copies with wrap-around: dst[(dst_row0 + i) & dst_mask] = src[(src_row0 + i) & src_mask], i < count, 32-byte rows.
+// Packs the row windows (own range + halo, modulo the block) of coset blocks into an all-to-all buffer and unpacks them on the other side.
+struct RowCopyArgs { zk::RowCopy e[ZK_ROWCOPY_MAX]; };
+__global__ void __launch_bounds__(256) k_row_copies(const RowCopyArgs A) {
+    const zk::RowCopy c = A.e[blockIdx.y];
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= c.count) return;
+    const uint4* s = reinterpret_cast<const uint4*>(c.src + (size_t)((c.src_row0 + i) & c.src_mask) * 8);
+    uint4* d = reinterpret_cast<uint4*>(c.dst + (size_t)((c.dst_row0 + i) & c.dst_mask) * 8);
+    const uint4 a = s[0], b = s[1];
+    d[0] = a;
+    d[1] = b;
+}
 
 // out[col] = sum over ranks of parts[rank][col] (Jacobian, ABI form as the MSM's last kernel writes it)
 __global__ void k_fold_partials(const uint32_t* parts, uint32_t nranks, uint32_t ncols, uint32_t* out) {
@@ -129,6 +154,75 @@ int comm_allgather(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t byte
     return comm_allgather_end(ctx);
 }
 
+int comm_row_copies(zkhip_ctx* ctx, const std::vector<RowCopy>& list) {
+    for (size_t done = 0; done < list.size(); done += ZK_ROWCOPY_MAX) {
+        const size_t cnt = std::min<size_t>(ZK_ROWCOPY_MAX, list.size() - done);
+        RowCopyArgs A;
+        memset(&A, 0, sizeof A);
+        uint32_t longest = 0;
+        for (size_t j = 0; j < cnt; ++j) { A.e[j] = list[done + j]; longest = std::max(longest, A.e[j].count); }
+        if (!longest) continue;
+        hipLaunchKernelGGL(k_row_copies, dim3(div_up(longest, 256), (uint32_t)cnt), dim3(256), 0, ctx->stream, A);
+    }
+    ZK_LAUNCH_CHECK();
+    return ZKHIP_OK;
+}
+
+// All-to-all of equal blocks: d_send holds nranks blocks of `bytes` (block r goes to rank r), d_recv receives nranks blocks (block r came
+// from rank r); the rank's own block is not moved (callers leave it out of their packing).  Ordered like the all-gathers: enqueued
+// behind everything issued on the calling stream, and the calling stream waits for it before it returns (begin + end in one).
+//   RCCL: one group of ncclSend / ncclRecv pairs on the communicator's stream — point-to-point over xGMI, every link busy at once;
+//   host transport: the caller's all-to-all callback if one was given (zkhip_comm_set_host_alltoall), else the exchange is emulated
+//   through the all-gather callback (every rank gathers every send buffer and keeps its column: correct, N times the volume — the
+//   counter still reports the bytes an all-to-all moves, and comm_describe says "emulated").
+int comm_alltoall(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t bytes) {
+    zkhip_comm& cm = ctx->comm;
+    if (cm.nranks <= 1 || bytes == 0) return ZKHIP_OK;
+    const size_t N = (size_t)cm.nranks, total = bytes * N;
+    if (cm.host_allgather) {
+        const size_t need = cm.host_alltoall ? 2 * total : total * N + total;
+        if (cm.stage_bytes < need) {
+            if (cm.stage) (void)hipHostFree(cm.stage);
+            cm.stage = nullptr;
+            cm.stage_bytes = 0;
+            ZK_HIP(hipHostMalloc(&cm.stage, need, hipHostMallocDefault));
+            cm.stage_bytes = need;
+        }
+        char* h_recv = (char*)cm.stage;
+        char* h_send = (char*)cm.stage + (cm.host_alltoall ? total : total * N);
+        ZK_HIP(hipMemcpyAsync(h_send, d_send, total, hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP(hipStreamSynchronize(ctx->stream));
+        if (cm.host_alltoall) {
+            int rc = cm.host_alltoall(cm.host_alltoall_user, h_send, h_recv, bytes);
+            if (rc != 0) { set_error("zkhip_comm: the host all-to-all callback returned %d", rc); return ZKHIP_EHIP; }
+            ZK_HIP(hipMemcpyAsync(d_recv, h_recv, total, hipMemcpyHostToDevice, ctx->stream));
+        } else {
+            int rc = cm.host_allgather(cm.host_user, h_send, h_recv, total);   // h_recv[r] = rank r's whole send buffer
+            if (rc != 0) { set_error("zkhip_comm: the host all-gather callback returned %d", rc); return ZKHIP_EHIP; }
+            for (size_t r = 0; r < N; ++r)
+                ZK_HIP(hipMemcpyAsync((char*)d_recv + r * bytes, h_recv + r * total + (size_t)cm.rank * bytes, bytes, hipMemcpyHostToDevice, ctx->stream));
+        }
+        ZK_HIP(hipStreamSynchronize(ctx->stream));
+        cm.bytes_gathered += bytes * (N - 1);
+        cm.collectives += 1;
+        return ZKHIP_OK;
+    }
+    if (!g_rccl.Send || !g_rccl.Recv || !g_rccl.GroupStart || !g_rccl.GroupEnd) { set_error("zkhip_comm: librccl lacks ncclSend / ncclRecv / ncclGroup*"); return ZKHIP_EINVAL; }
+    ncclComm_t c = (ncclComm_t)cm.nccl;
+    ZK_HIP(hipEventRecord(cm.ev_in, ctx->stream));
+    ZK_HIP(hipStreamWaitEvent(cm.stream, cm.ev_in, 0));
+    ZK_NCCL(g_rccl.GroupStart());
+    for (size_t r = 0; r < N; ++r) {
+        if ((int)r == cm.rank) continue;
+        ZK_NCCL(g_rccl.Send((const char*)d_send + r * bytes, bytes, ncclInt8, (int)r, c, cm.stream));
+        ZK_NCCL(g_rccl.Recv((char*)d_recv + r * bytes, bytes, ncclInt8, (int)r, c, cm.stream));
+    }
+    ZK_NCCL(g_rccl.GroupEnd());
+    cm.bytes_gathered += bytes * (N - 1);
+    cm.collectives += 1;
+    return comm_allgather_end(ctx);
+}
+
 // the partial sums of a point-range-sharded batch of MSMs -> the sums, on every rank (d_out may be pinned host memory)
 int comm_fold_partials(zkhip_ctx* ctx, const void* d_part, size_t ncols, void* d_out) {
     zkhip_comm& cm = ctx->comm;
@@ -183,6 +277,14 @@ int zkhip_comm_init_host(zkhip_ctx* ctx, int rank, int nranks, zkhip_host_allgat
     ctx->comm.host_user = user;
     ctx->comm.rank = rank;
     ctx->comm.nranks = nranks;
+    return ZKHIP_OK;
+}
+
+int zkhip_comm_set_host_alltoall(zkhip_ctx* ctx, zkhip_host_alltoall_fn fn, void* user) {
+    if (!ctx) { set_error("null ctx"); return ZKHIP_EINVAL; }
+    if (!ctx->comm.host_allgather) { set_error("zkhip_comm_set_host_alltoall: the context has no host-staged communicator"); return ZKHIP_EINVAL; }
+    ctx->comm.host_alltoall = fn;
+    ctx->comm.host_alltoall_user = user;
     return ZKHIP_OK;
 }
 

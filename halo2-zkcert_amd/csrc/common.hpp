@@ -52,6 +52,7 @@ struct zkhip_options {
     int ntt_smax = 0, ntt_r8 = 1, ntt_group = 0;
     int permute_rank_sort = 1, eval_byval = 1, late_overlap = -1;
     int host_timing = 0;   // zkhip_create_proof prints its host-side phase times to stderr
+    int row_sharded = 1;      // multi-rank proofs on the coset path: all-to-all of row windows (1) / all-gather of complete columns (0)
     int coset_quotient = 1;   // zkhip_create_proof evaluates the quotient on quotient_poly_degree cosets of size n (cosets.hip) when that is fewer rows
 };
 
@@ -64,6 +65,8 @@ struct zkhip_comm {
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     zkhip_host_allgather_fn host_allgather = nullptr;
     void* host_user = nullptr;
+    zkhip_host_alltoall_fn host_alltoall = nullptr;   // optional companion of the host transport (else emulated through the all-gather)
+    void* host_alltoall_user = nullptr;
     void* stage = nullptr;        // pinned staging buffer of the host transport
     size_t stage_bytes = 0;
     uint64_t bytes_gathered = 0;  // bytes this rank received through RCCL all-gathers
@@ -163,6 +166,10 @@ namespace zk {
 int comm_allgather(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t bytes);
 int comm_allgather_begin(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t bytes);
 int comm_allgather_end(zkhip_ctx* ctx);
+int comm_alltoall(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_pair);
+struct RowCopy { const uint32_t* src; uint32_t* dst; uint32_t src_row0, dst_row0, count, src_mask, dst_mask; };
+#define ZK_ROWCOPY_MAX 48
+int comm_row_copies(zkhip_ctx* ctx, const std::vector<RowCopy>& list);
 int comm_fold_partials(zkhip_ctx* ctx, const void* d_part, size_t ncols, void* d_out);
 int lagrange_to_coeff_oop(zkhip_ctx* ctx, const zkhip_domain* d, const void* const* srcs, void* const* dsts, size_t npolys);
 int permute_expression_pair_async(zkhip_ctx* ctx, uint32_t k, uint32_t blinding_factors, const void* d_input, const void* d_table,

@@ -127,7 +127,7 @@ const OptName OPTIONS[] = {
     {"ZKHIP_NTT_GROUP", "ntt_group", &zkhip_options::ntt_group}, {"ZKHIP_PERMUTE_RANK_SORT", "permute_rank_sort", &zkhip_options::permute_rank_sort},
     {"ZKHIP_EVAL_BYVAL", "eval_byval", &zkhip_options::eval_byval}, {"ZKHIP_LATE_OVERLAP", "late_overlap", &zkhip_options::late_overlap},
     {"ZKHIP_HOST_TIMING", "host_timing", &zkhip_options::host_timing},
-    {"ZKHIP_COSET_QUOTIENT", "coset_quotient", &zkhip_options::coset_quotient},
+    {"ZKHIP_COSET_QUOTIENT", "coset_quotient", &zkhip_options::coset_quotient}, {"ZKHIP_ROW_SHARDED", "row_sharded", &zkhip_options::row_sharded},
 };
 }  // namespace
 

@@ -410,9 +410,9 @@ __global__ void __launch_bounds__(256) k_sort_lo_staged(const uint32_t* part_off
     const uint32_t bucket0 = p << g.LB;
     const uint32_t* off = off_all + (size_t)col * (g.B + 4);
     uint32_t* cursor = cursor_all + (size_t)col * g.B;
-    const uint32_t per = (nbins + 255) / 256;
+    const uint32_t per = (nbins + 255) / 256;   // thread t owns bins t, t + 256, ...: see k_sort_lo_staged16
     uint32_t my = 0;
-    for (uint32_t q = 0; q < per; ++q) { uint32_t j = tid * per + q; if (j < nbins) my += hist[j]; }
+    for (uint32_t q = 0; q < per; ++q) { uint32_t j = q * 256 + tid; if (j < nbins) my += hist[j]; }
     uint32_t inc = my;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { uint32_t u = __shfl_up(inc, d); if ((int)lane >= d) inc += u; }
@@ -421,7 +421,7 @@ __global__ void __launch_bounds__(256) k_sort_lo_staged(const uint32_t* part_off
     uint32_t run = inc - my;
     for (uint32_t w = 0; w < wave; ++w) run += w_tot[w];
     for (uint32_t q = 0; q < per; ++q) {
-        uint32_t j = tid * per + q;
+        uint32_t j = q * 256 + tid;
         if (j < nbins) {
             uint32_t h = hist[j];
             base[j] = h ? off[bucket0 + j] + atomicAdd(&cursor[bucket0 + j], h) : 0u;
@@ -485,9 +485,13 @@ __global__ void __launch_bounds__(NT) k_sort_lo_staged16(const uint32_t* part_of
     const uint32_t bucket0 = p << g.LB;
     const uint32_t* off = off_all + (size_t)col * (g.B + 4);
     uint32_t* cursor = cursor_all + (size_t)col * g.B;
+    // Thread t owns bins t, t + NT, ... (NOT a contiguous range): the order of the bins' runs inside the staged tile is irrelevant — the
+    // write-out addresses every pair through base[] / lst[] of its own bin — and with this ownership the lanes of a wave read
+    // consecutive LDS words (a contiguous range per thread is an 8-way / 2-way bank conflict on three arrays) and issue their returning
+    // global atomics on consecutive cursor words, i.e. one cache line per wave instead of one per lane.
     const uint32_t per = (nbins + NT - 1) / NT;
     uint32_t my = 0;
-    for (uint32_t q = 0; q < per; ++q) { uint32_t j = tid * per + q; if (j < nbins) my += hist[j]; }
+    for (uint32_t q = 0; q < per; ++q) { uint32_t j = q * NT + tid; if (j < nbins) my += hist[j]; }
     uint32_t inc = my;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { uint32_t u = __shfl_up(inc, d); if ((int)lane >= d) inc += u; }
@@ -496,7 +500,7 @@ __global__ void __launch_bounds__(NT) k_sort_lo_staged16(const uint32_t* part_of
     uint32_t run = inc - my;
     for (uint32_t w = 0; w < wave; ++w) run += w_tot[w];
     for (uint32_t q = 0; q < per; ++q) {
-        uint32_t j = tid * per + q;
+        uint32_t j = q * NT + tid;
         if (j < nbins) {
             uint32_t h = hist[j];
             base[j] = h ? off[bucket0 + j] + atomicAdd(&cursor[bucket0 + j], h) : 0u;

@@ -255,17 +255,29 @@ __device__ __forceinline__ uint32_t swz(uint32_t L, const Swz& z) { return L ^ (
 // thread index -> logical index with a zero 3-bit slot field at bit p
 __device__ __forceinline__ uint32_t place(uint32_t t, uint32_t p) { return (t & ((1u << p) - 1)) | ((t >> p) << (p + 3)); }
 
-__device__ __forceinline__ void bfly(fe& a, fe& b, const el2<Fr>& bw) {   // (a, b) <- (a + bw, a - bw + 3p)
+// (a, b) <- (a + bw, a - bw + 3p) WITHOUT carry propagation: bw is normalised (limbs < 2^29); a's limbs may be lazy.  Per stage a limb
+// grows by < 2^29 (sum) or < 2^30 (difference: the borrow-spread constant), so from normalised inputs three stages leave every limb below
+// 7 * 2^29 < 2^32, and a lazy multiplicand of the third stage (limbs < 5 * 2^29) keeps the product's 64-bit columns below
+// 9 * 5 * 2^58 + 9 * 2^58 < 2^64.  A register group (<= 3 stages) therefore normalises ONCE, when it hands its values on (norm8) — a third
+// of the carry passes of the stage-by-stage form, 9 % of the kernels' instructions.  The value bound (+3p per stage) is unchanged.
+__device__ __forceinline__ void bfly(fe& a, fe& b, const el2<Fr>& bw) {
     fe sum, dif;
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
         sum.l[q] = a.l[q] + bw.v.l[q];
         dif.l[q] = a.l[q] + kp_spread<Fr>(3, q) - bw.v.l[q];
     }
-    fe_normalize(sum);
-    fe_normalize(dif);
     a = sum;
     b = dif;
+}
+__device__ __forceinline__ void norm8(fe (&v)[8]) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) fe_normalize(v[q]);
+}
+// a unit twiddle after the first stage: contract the (lazy) operand by conditional subtractions instead of a product by one
+__device__ __forceinline__ el1<Fr> unit_operand(fe x) {
+    fe_normalize(x);
+    return canonical(tile_el(x));
 }
 
 // stages 0..2 on freshly loaded values (< 2p); slot = row bits 0..2, so the twiddle exponents are compile-time:
@@ -276,13 +288,14 @@ __device__ __forceinline__ void stages_first(fe (&v)[8], const TwDev& tw) {
     el2<Fr> w4 = load_raw<Fr>(tw.bf + ((size_t)1 << (tw.bf_shift - 1)) * 8);
 #pragma unroll
     for (int h = 0; h < 8; h += 4) {
-        bfly(v[h], v[h + 2], canonical(tile_el(v[h + 2])));
+        bfly(v[h], v[h + 2], unit_operand(v[h + 2]));
         bfly(v[h + 1], v[h + 3], tile_el(v[h + 3]) * w4);
     }
-    bfly(v[0], v[4], canonical(tile_el(v[4])));
+    bfly(v[0], v[4], unit_operand(v[4]));
     bfly(v[1], v[5], tile_el(v[5]) * load_raw<Fr>(tw.bf + ((size_t)1 << (tw.bf_shift - 2)) * 8));
     bfly(v[2], v[6], tile_el(v[6]) * w4);
     bfly(v[3], v[7], tile_el(v[7]) * load_raw<Fr>(tw.bf + ((size_t)3 << (tw.bf_shift - 2)) * 8));
+    norm8(v);
 }
 
 // stages [e - G_, e) with the slot at row bits [e-3, e); rho0 = this thread's row index with a zero slot field.
@@ -308,6 +321,7 @@ __device__ __forceinline__ void stages_general(fe (&v)[8], uint32_t rho0, uint32
     stage_general<G_, 0>(v, rho0, e, tw);
     if constexpr (G_ > 1) stage_general<G_, 1>(v, rho0, e, tw);
     if constexpr (G_ > 2) stage_general<G_, 2>(v, rho0, e, tw);
+    norm8(v);
 }
 
 // groups 1.. of a tile whose group 0 is already done in v (slot at logical bit logT, held by the thread that place() would

@@ -14,6 +14,7 @@
 // ~9 ms of GPU work, and an interpreted host adds a millisecond of gaps between ~250 launches.
 // halo2-zkcert_amd/prover.py is the same schedule in Python over the small entry points (and the form the oracle backend runs).
 #include <chrono>
+#include <cstdlib>
 #include <vector>
 
 #include "common.hpp"
@@ -237,12 +238,56 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
     // (4 KiB in, past the small read-back slots) when they fit
     if ((A + 2 * L + Zp + L + qd + 2) * 96 + 4096 + 64 <= zkhip_ctx::PINNED_BYTES) w_com = (char*)ctx->h_pinned + 4096;
 
+    // ---- row-sharded cosets: with the quotient on q cosets of the size-n domain, rank R sweeps rows [R m, (R+1) m),
+    // m = n / N, of EVERY coset block, and a rotation stays inside its block — so of every column it needs those rows plus a halo of
+    // H = max |rotation| rows on either side (modulo n), and nothing else.  The coset NTTs stay by polynomial (the rank that transforms a
+    // column holds all of it); instead of all-gathering complete columns, each owner sends every peer ITS row windows: an all-to-all of
+    // q (m + 2 H) rows per (column, peer) = 1 / N of the all-gather's volume.  The column buffers keep their full q n size (the sweep
+    // addresses them as before; the memory is there), a rank just never fills — or reads — the rows outside its windows.
+    uint32_t halo = std::max<uint32_t>(1, bf + 1);
+    auto scan_rots = [&](const zk_graph& g_) { for (uint32_t i = 0; i < g_.n_rotations; ++i) halo = std::max<uint32_t>(halo, (uint32_t)std::abs(g_.rotations[i])); };
+    scan_rots(pk->custom_gates);
+    for (uint32_t i = 0; i < L; ++i) scan_rots(pk->lookup_graphs[i]);
+    const size_t m_rows = n / NR;
+    const bool row_mode = dist && coset_mode && ctx->opt.row_sharded != 0 && n % (NR * 64) == 0 && 2 * (size_t)halo < m_rows;
     // coeff_to_extended of `count` polynomials whose outputs are consecutive EB-sized slices of one padded workspace block
     auto to_extended = [&](const void* const* srcs, void* const* dsts, size_t count) -> int {
         auto transform = [&](const void* const* s_, void* const* d_, size_t c_) -> int {
             return coset_mode ? zk::coeff_to_cosets(ctx, cplan, s_, d_, c_) : zkhip_coeff_to_extended_device(ctx, pk->domain, s_, n, d_, c_);
         };
         if (!dist) return transform(srcs, dsts, count);
+        if (row_mode) {
+            // my columns (j = t NR + RK) in one batch, then the windows of every peer packed, exchanged and unpacked
+            std::vector<const void*> ms;
+            std::vector<void*> md;
+            for (size_t j = RK; j < count; j += NR) { ms.push_back(srcs[j]); md.push_back(dsts[j]); }
+            if (!ms.empty()) ZK_TRY(transform(ms.data(), md.data(), ms.size()));
+            const size_t maxcols = (count + NR - 1) / NR, W = m_rows + 2 * halo, blk = maxcols * qd * W * 32;
+            char *w_send, *w_recv;
+            ZK_TRY(ws("cp_a2a_send", NR * blk, &w_send));
+            ZK_TRY(ws("cp_a2a_recv", NR * blk, &w_recv));
+            const uint32_t nmask = (uint32_t)n - 1;
+            std::vector<zk::RowCopy> list;
+            for (size_t r = 0; r < NR; ++r) {
+                if (r == RK) continue;
+                for (size_t t = 0; t < md.size(); ++t)
+                    for (uint32_t b_ = 0; b_ < qd; ++b_)
+                        list.push_back(zk::RowCopy{(const uint32_t*)((char*)md[t] + (size_t)b_ * NB), (uint32_t*)(w_send + r * blk + (t * qd + b_) * W * 32),
+                                                   (uint32_t)((r * m_rows + n - halo) & nmask), 0u, (uint32_t)W, nmask, 0xffffffffu});
+            }
+            ZK_TRY(zk::comm_row_copies(ctx, list));
+            ZK_TRY(zk::comm_alltoall(ctx, w_send, w_recv, blk));
+            list.clear();
+            for (size_t r = 0; r < NR; ++r) {
+                if (r == RK) continue;
+                size_t t = 0;
+                for (size_t j = r; j < count; j += NR, ++t)
+                    for (uint32_t b_ = 0; b_ < qd; ++b_)
+                        list.push_back(zk::RowCopy{(const uint32_t*)(w_recv + r * blk + (t * qd + b_) * W * 32), (uint32_t*)((char*)dsts[j] + (size_t)b_ * NB), 0u,
+                                                   (uint32_t)((RK * m_rows + n - halo) & nmask), (uint32_t)W, 0xffffffffu, nmask});
+            }
+            return zk::comm_row_copies(ctx, list);
+        }
         // by polynomial, pipelined: rank RK transforms column t NR + RK of round t, then the round's NR columns are all-gathered in
         // place on the communicator's stream while this stream already transforms the rank's column of round t + 1
         for (size_t t = 0; t * NR < count; ++t) {
@@ -479,7 +524,13 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
         auto sweep = [&](size_t first, size_t rows, char* dst) -> int {
             return coset_mode ? zk::evaluate_h_cosets(ctx, &a, &sc, first, rows, dst) : zkhip_evaluate_h_rows_device(ctx, &a, first, rows, dst);
         };
-        if (dist && ext_rows % (64 * NR) == 0) {
+        if (row_mode) {
+            // this rank's row range of every coset block; the numerator's blocks are completed by one all-gather per block (the inverse
+            // transforms below run on whole blocks)
+            for (uint32_t b_ = 0; b_ < qd; ++b_) ZK_TRY(sweep(b_ * n + RK * m_rows, m_rows, vals + (b_ * n + RK * m_rows) * 32));
+            for (uint32_t b_ = 0; b_ < qd; ++b_) ZK_TRY(zk::comm_allgather_begin(ctx, vals + (b_ * n + RK * m_rows) * 32, vals + (size_t)b_ * NB, m_rows * 32));
+            ZK_TRY(zk::comm_allgather_end(ctx));
+        } else if (dist && ext_rows % (64 * NR) == 0) {
             const size_t rows = ext_rows / NR;
             ZK_TRY(sweep(RK * rows, rows, vals + RK * rows * 32));
             ZK_TRY(zk::comm_allgather(ctx, vals + RK * rows * 32, vals, rows * 32));

@@ -54,7 +54,7 @@ class ZkEvalhArgs(C.Structure):
 # every symbol include/zkhip.h declares (checked by tests/test_abi.py without a GPU)
 SYMBOLS = [
     "zkhip_init", "zkhip_destroy", "zkhip_last_error", "zkhip_set_stream", "zkhip_synchronize", "zkhip_set_option", "zkhip_trim", "zkhip_key_release",
-    "zkhip_comm_unique_id", "zkhip_comm_init", "zkhip_comm_init_host", "zkhip_comm_destroy", "zkhip_comm_info", "zkhip_comm_describe", "zkhip_comm_allgather_device", "zkhip_comm_shard_columns",
+    "zkhip_comm_unique_id", "zkhip_comm_init", "zkhip_comm_init_host", "zkhip_comm_set_host_alltoall", "zkhip_comm_destroy", "zkhip_comm_info", "zkhip_comm_describe", "zkhip_comm_allgather_device", "zkhip_comm_shard_columns",
     "zkhip_kzg_setup_range", "zkhip_srs_load_range", "zkhip_srs_range", "zkhip_malloc", "zkhip_free",
     "zkhip_memcpy_h2d", "zkhip_memcpy_d2h", "zkhip_timer_start", "zkhip_timer_stop_ms",
     "zkhip_profile_enable", "zkhip_profile_select", "zkhip_profile_read", "zkhip_profile_counter",
@@ -225,6 +225,25 @@ class Context:
                     return 1
             self._host_ag = HOST_ALLGATHER_FN(_ag)
             _check(lib().zkhip_comm_init_host(self.h, C.c_int(rank), C.c_int(world), self._host_ag, None))
+
+            def _a2a(user, send, recv, nbytes):     # block r of send -> rank r; block r of recv <- rank r
+                try:
+                    mine = torch.frombuffer((C.c_uint8 * (nbytes * world)).from_address(send), dtype=torch.uint8).clone()
+                    out = torch.empty(nbytes * world, dtype=torch.uint8)
+                    if dist.get_backend() == "nccl":
+                        o = out.to(self.device)
+                        dist.all_to_all_single(o, mine.to(self.device))
+                        out = o.cpu()
+                    else:
+                        dist.all_to_all_single(out, mine)
+                    C.memmove(recv, out.numpy().ctypes.data, nbytes * world)
+                    return 0
+                except Exception as e:   # noqa: BLE001
+                    print(f"zkhip host all-to-all failed: {e}", flush=True)
+                    return 1
+            if os.environ.get("ZKHIP_HOST_A2A", "1") != "0":      # 0: let the library emulate it through the all-gather callback
+                self._host_a2a = HOST_ALLGATHER_FN(_a2a)
+                _check(lib().zkhip_comm_set_host_alltoall(self.h, self._host_a2a, None))
         else:
             raise ValueError(transport)
         self.rank, self.world, self.transport = rank, world, transport

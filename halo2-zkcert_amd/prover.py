@@ -599,29 +599,45 @@ class Prover:
     """Keygen-shaped setup once, then prove() = one create_proof-shaped pass (the benchmark step)."""
     _key_counter = 0
 
-    def __init__(self, backend, shape, srs_trapdoor=0x1D5C0FFEE, satisfiable=False):
+    def __init__(self, backend, shape, srs_trapdoor=0x1D5C0FFEE, satisfiable=False, key_file=None):
         """satisfiable=True (halo2-lib shaped circuits only): selectors, copy constraints and witness are built so that every
         gate, the permutation and the lookup hold, i.e. prove() returns a proof the verifier accepts.  The arithmetic is the
-        same either way; with False the fixed / sigma columns are uniform synthetic values."""
+        same either way; with False the fixed / sigma columns are uniform synthetic values.
+        key_file: a formats.ProvingKeyFile (what `read_pk` returns in the reference, /root/reference/src/bin/cli.rs:312,335,362,455,509):
+        the key's fixed / sigma columns in all their forms and the l-polynomials come from the FILE — nothing of the key is generated —
+        and the witness is the caller's (load_witness)."""
         self.b, self.shape = backend, shape
         self.satisfiable = satisfiable
         self.dom = backend.setup(shape.k, shape.degree, srs_trapdoor)
         self.n = 1 << shape.k
         sh, b, n = shape, backend, self.n
         seed = sh.seed * 1000
-        # pk: fixed columns and sigma polynomials in Lagrange form, coefficient form and as extended cosets; l cosets
-        self.fixed_lagrange = [b.synth(n, seed + 100 + i) for i in range(sh.n_fixed)]
-        self.sigma_lagrange = [b.synth(n, seed + 200 + i) for i in range(len(sh.perm_columns))]
-        if satisfiable:
-            self._build_satisfiable(seed)
-        self.fixed_coeff = b.clone(self.fixed_lagrange)
-        b.lagrange_to_coeff(self.fixed_coeff)
-        self.sigma_coeff = b.clone(self.sigma_lagrange)
-        b.lagrange_to_coeff(self.sigma_coeff)
+        self._ext = None
+        if key_file is not None:
+            if key_file.k != sh.k or len(key_file.fixed_values) != sh.n_fixed or len(key_file.permutations) != len(sh.perm_columns):
+                raise ValueError(f"proving key file (k = {key_file.k}, {len(key_file.fixed_values)} fixed, {len(key_file.permutations)} permutation "
+                                 f"columns) does not match the circuit shape {sh.name} (k = {sh.k}, {sh.n_fixed}, {len(sh.perm_columns)})")
+            up = lambda cols: [b.from_host(np.array(c, dtype=np.uint64)) for c in cols]      # a copy: the file is a read-only mapping
+            self.fixed_lagrange, self.fixed_coeff = up(key_file.fixed_values), up(key_file.fixed_polys)
+            self.sigma_lagrange, self.sigma_coeff = up(key_file.permutations), up(key_file.permutation_polys)
+            if key_file.extended_k == self.dom.extended_k:
+                # the file's extended forms are used as they are (uploaded on first use: the coset-quotient path never touches them)
+                self._ext_file = key_file
+            self.key_source = "file"
+        else:
+            # pk: fixed columns and sigma polynomials in Lagrange form, coefficient form and as extended cosets; l cosets
+            self.fixed_lagrange = [b.synth(n, seed + 100 + i) for i in range(sh.n_fixed)]
+            self.sigma_lagrange = [b.synth(n, seed + 200 + i) for i in range(len(sh.perm_columns))]
+            if satisfiable:
+                self._build_satisfiable(seed)
+            self.fixed_coeff = b.clone(self.fixed_lagrange)
+            b.lagrange_to_coeff(self.fixed_coeff)
+            self.sigma_coeff = b.clone(self.sigma_lagrange)
+            b.lagrange_to_coeff(self.sigma_coeff)
+            self.key_source = "generated"
         # The extended-domain forms of the key (fixed / sigma cosets, l_0 / l_last / l_active) are built on first use: the Python
         # schedule needs them, zkhip_create_proof_ex does not when it evaluates the quotient on cosets of the size-n domain
         # (cs_degree - 1 < extension factor: csrc/cosets.hip derives the key's columns in its own layout from the coefficient forms).
-        self._ext = None
         self.gates_graph = ev.build_custom_gates(sh.gates)
         self.lookup_graphs = [ev.build_lookup(i, t) for i, t in sh.lookups]
         self.compress_graphs = []
@@ -638,6 +654,11 @@ class Prover:
         self.vk_repr = fr_from_int_host(int.from_bytes(hashlib.blake2b(sh.name.encode(), digest_size=64).digest(), "little") % R)
 
     def _extended_key(self):
+        if self._ext is None and getattr(self, "_ext_file", None) is not None:
+            kf, b = self._ext_file, self.b
+            up = lambda cols: [b.from_host(np.array(c, dtype=np.uint64)) for c in cols]
+            self._ext = dict(fixed=up(kf.fixed_cosets), sigma=up(kf.permutation_cosets), l0=up([kf.l0])[0], l_last=up([kf.l_last])[0],
+                             l_active=up([kf.l_active_row])[0])
         if self._ext is None:
             b = self.b
             l0, l_last, l_active = b.l_cosets(self.shape.blinding_factors)
@@ -893,6 +914,28 @@ class Prover:
         for i_ in range(L):
             w += [(("lookup_z", i_), 0), (("lookup_z", i_), 1), (("lookup_a", i_), 0), (("lookup_a", i_), -1), (("lookup_s", i_), 0)]
         return w
+
+    def save_witness(self, wit, path):
+        """the advice columns and instance values of a witness as one .npz (host arrays, ABI form): what a circuit's witness generation
+        hands to create_proof — the synthetic stand-in for `circuit` + `instances` of gen_snark_shplonk (/root/reference/src/helpers.rs:233)"""
+        h = self.b.to_host
+        np.savez(path, base=np.int64(wit["base"]), n_advice=len(wit["advice"]), n_instance=len(wit["instance_values"]),
+                 **{f"advice_{i}": h(c) for i, c in enumerate(wit["advice"])},
+                 **{f"instance_values_{i}": np.asarray(v, dtype=np.uint64) for i, v in enumerate(wit["instance_values"])})
+
+    def load_witness(self, path):
+        z = np.load(path)
+        b, n = self.b, self.n
+        advice = [b.from_host(z[f"advice_{i}"]) for i in range(int(z["n_advice"]))]
+        inst_vals = [np.array(z[f"instance_values_{i}"], dtype=np.uint64).reshape(-1, 4) for i in range(int(z["n_instance"]))]
+        if len(advice) != self.shape.n_advice or any(len(b.to_host(c)) != n for c in advice[:1]):
+            raise ValueError(f"{path}: {len(advice)} advice columns for a circuit with {self.shape.n_advice}")
+        instance = []
+        for v in inst_vals:
+            col = np.zeros((n, 4), dtype=np.uint64)
+            col[:len(v)] = v
+            instance.append(b.from_host(col))
+        return dict(advice=advice, instance=instance, instance_values=inst_vals, base=int(z["base"]))
 
     def release(self):
         """drops what the library's context caches for this proving key (zkhip_key_release): call when the Prover is done"""

@@ -93,9 +93,13 @@ int  zkhip_profile_counter(zkhip_ctx* ctx, const char* name, uint64_t* value);
  * zkhip_comm_init_host is the same with the all-gathers staged through host memory and a caller-supplied function (bring-up on a
  * one-GPU box, launchers without RCCL): fn(user, send, recv, bytes) must fill recv[r * bytes ..] with rank r's send block. */
 typedef int (*zkhip_host_allgather_fn)(void* user, const void* send, void* recv, size_t bytes_per_rank);
+/* the host transport's all-to-all (optional): send / recv hold nranks blocks of bytes_per_pair; block r of send goes to rank r, block r of
+ * recv comes from rank r.  Without it the library emulates the exchange through the all-gather callback (N times the volume). */
+typedef int (*zkhip_host_alltoall_fn)(void* user, const void* send, void* recv, size_t bytes_per_pair);
 int  zkhip_comm_unique_id(uint8_t id[128]);
 int  zkhip_comm_init(zkhip_ctx* ctx, const uint8_t id[128], int rank, int nranks);
 int  zkhip_comm_init_host(zkhip_ctx* ctx, int rank, int nranks, zkhip_host_allgather_fn fn, void* user);
+int  zkhip_comm_set_host_alltoall(zkhip_ctx* ctx, zkhip_host_alltoall_fn fn, void* user);
 int  zkhip_comm_destroy(zkhip_ctx* ctx);
 /* MSMs over WHOLE-SRS handles (every rank holds the full window tables) on a context with a communicator: on = 1 splits every batch by
  * column — rank r commits columns r, r + N, ... completely, results all-gathered — the split of choice while one MSM cannot fill

@@ -80,3 +80,25 @@ def test_snark_file_round_trip(oracle, tmp_path):
         assert got.protocol == protocol and got.instances == inst and got.proof == proof
     with pytest.raises(ValueError):
         fm.SnarkFile.read(path, protocol_len=len(protocol) + 1)
+
+
+def test_prover_from_proving_key_file(oracle, tmp_path):
+    """read_pk -> create_proof (/root/reference/src/bin/cli.rs:312,320): a Prover built from a ProvingKeyFile generates nothing of the key
+    and, with the witness that was saved beside it, reproduces the proof bytes of the prover that wrote the file — on the extended-domain
+    path, which reads the file's fixed_cosets / permutation cosets / l-polynomials."""
+    sh = pv.CircuitShape.small(6)
+    p1 = pv.Prover(OracleBackend(2), sh, satisfiable=True)
+    w1 = p1.witness(2)
+    ref = p1.prove(w1, transcript="poseidon")["proof"]
+    fixed_c = [c[0] for c in p1.b.commit(p1.fixed_coeff, lagrange=False)]
+    sigma_c = [c[0] for c in p1.b.commit(p1.sigma_coeff, lagrange=False)]
+    fm.ProvingKeyFile.from_prover(p1, fixed_c, sigma_c).write(tmp_path / "k.pk")
+    p1.save_witness(w1, tmp_path / "w.npz")
+    kf = fm.ProvingKeyFile.read(tmp_path / "k.pk", n_perm_columns=len(sh.perm_columns), n_selectors=0)
+    p2 = pv.Prover(OracleBackend(2), sh, key_file=kf)
+    assert p2.key_source == "file" and not hasattr(p2, "_value_src")
+    w2 = p2.load_witness(tmp_path / "w.npz")
+    assert p2.prove(w2, transcript="poseidon")["proof"] == ref
+    assert p2._ext is not None and (p2.l0 == kf.l0).all()                       # the extended forms came from the file
+    with pytest.raises(ValueError):
+        pv.Prover(OracleBackend(2), pv.CircuitShape.small(7), key_file=kf)

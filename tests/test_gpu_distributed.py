@@ -23,12 +23,19 @@ def _free_port():
         sk.bind(("127.0.0.1", 0))
         return sk.getsockname()[1]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SHAPES = [["small", 8, "poseidon"], ["sha", 9, "poseidon"], ["small", 7, "evm"]]
+# small 8 / 10: the coset-quotient path with row-sharded cosets (all-to-all of row windows) whenever 64 N divides n — N = 2 at k = 8, N = 8 at
+# k = 10; N = 3 / 5 and the SHA shape (extended domain) take the all-gather path
+SHAPES = [["small", 8, "poseidon"], ["sha", 9, "poseidon"], ["small", 7, "evm"], ["small", 10, "evm"]]
+
+
+_REF = {}
 
 
 def _single_gpu_proofs(zk):
+    if _REF:
+        return _REF
     ffi, ctx = zk
-    out = {}
+    out = _REF
     for spec in SHAPES:
         sh = pv.CircuitShape.small(spec[1]) if spec[0] == "small" else pv.CircuitShape.sha256(spec[1], n_advice=12, n_fixed=5)
         p = pv.Prover(pv.GpuBackend(ctx, ffi), sh, satisfiable=True)
@@ -119,6 +126,21 @@ def test_eight_and_five_ranks(zk, tmp_path, world, mode):
             assert o[key]["native"] == hexs and o[key]["python"] == hexs, key
 
 
+def test_all_gather_path_and_emulated_all_to_all(zk, tmp_path):
+    """the two fall-backs of the row-sharded exchange give the same bytes: complete columns all-gathered (option row_sharded = 0, what
+    N = 3 / 5 and the extended-domain circuits use anyway), and the all-to-all emulated through the host transport's all-gather callback"""
+    ref = _single_gpu_proofs(zk)
+    for extra in ({"ZKHIP_ROW_SHARDED": "0"}, {"ZKHIP_HOST_A2A": "0"}):
+        outs = _run_workers(tmp_path, 2, True, 0, extra_env=extra)
+        for o in outs:
+            for key, hexs in ref.items():
+                assert o[key]["native"] == hexs and o[key]["python"] == hexs, (extra, key)
+    # and the volumes differ as designed: the row-sharded exchange of the k = 10 circuit moves less than the all-gathers
+    a = _run_workers(tmp_path, 2, True, 0, extra_env={"ZKHIP_ROW_SHARDED": "0"})[0]["small10evm"]["bytes_gathered"]
+    b = _run_workers(tmp_path, 2, True, 0)[0]["small10evm"]["bytes_gathered"]
+    assert b < a, (a, b)
+
+
 def test_column_round_robin_sharding(zk, tmp_path):
     """the other MSM split (for k <= 19): every rank holds the WHOLE window tables and commits columns r, r + N, ... of a
     batch completely; the 96-byte results are all-gathered (non-owners contribute the identity).  Same bytes as the single-GPU proof."""
@@ -167,9 +189,11 @@ def test_agg_k22_proof_over_two_ranks_by_point_range(zk, tmp_path):
     assert len(ref) > 1000
     n = 1 << 22
     for o in outs:
-        # what one rank receives per proof: today every complete coset column (5 advice / instance + 2 permuted + 5 products) and the numerator
-        # are all-gathered — 13 x 384 MiB, half of it received at N = 2 — plus the latency-sized partial sums
-        assert 0 < o["agg22evm"]["bytes_gathered"] <= 13 * 3 * n * 32 // 2 + (16 << 20), o["agg22evm"]["bytes_gathered"]
+        # What one rank receives per proof.  Round 2 all-gathered every complete coset column (5 advice / instance + 2 permuted + 5 products) and
+        # the numerator: 13 x 384 MiB, half of it received at N = 2 = 2.6 GB.  Row-sharded: per phase an all-to-all of row windows (own range
+        # + halo) of the columns the peer transformed — ceil(5/2) + ceil(2/2) + ceil(5/2) = 7 column-windows of 3 x n/2 rows — plus the
+        # numerator's row ranges (3 x n/2 rows) and the latency-sized partial sums: 8 x 3 x n/2 x 32 B = 1.6 GB.
+        assert 0 < o["agg22evm"]["bytes_gathered"] <= 8 * 3 * (n // 2) * 32 + (32 << 20), o["agg22evm"]["bytes_gathered"]
 
 
 def test_sha_k19_proof_over_two_ranks_by_column(zk, tmp_path):

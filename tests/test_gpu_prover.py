@@ -274,31 +274,91 @@ def test_native_create_proof_evm_transcript(zk, oracle):
     assert P.plonk_verify(vk, instance, coms, _pts(te["points"]["quotient"]), evals, te["query_list"], te["challenges"], h1, h2, s)
 
 
-def test_cli_shaped_driver_and_srs_file_round_trip(zk, tmp_path, capsys):
-    """tools/zkcert_cli.py (the reference CLI's command / argument names, /root/reference/src/bin/cli.rs:95-211): the first run
-    generates the SRS and leaves kzg_bn254_<k>.srs under --params-path, the second reads it back — same proof bytes; the EVM
-    command's proof has the 64-byte point layout."""
+def _cli():
     import importlib.util
-    import json
     import os
 
     spec = importlib.util.spec_from_file_location("zkcert_cli", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "zkcert_cli.py"))
     cli = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(cli)
+    return cli
+
+
+def test_cli_shaped_driver_and_srs_file_round_trip(zk, tmp_path, capsys):
+    """tools/zkcert_cli.py (the reference CLI's command / argument names, /root/reference/src/bin/cli.rs:95-211): the first run
+    generates the SRS and leaves kzg_bn254_<k>.synthetic.srs under --params-path and writes the proving key (`gen_pk(.., Some(path))`)
+    and the witness; the second run READS the SRS, the proving key file (`read_pk`) and the witness back — same proof bytes, as a bincode
+    Snark (`gen_snark_shplonk(.., Some(path))`); the aggregation command reads the leaf snarks (`read_snark`) and takes its advice column
+    count from the break points file; the EVM command's proof has the 64-byte point layout."""
+    import json
+    import os
+
+    import halo2_zkcert_amd.formats as fm
+
+    cli = _cli()
     params = str(tmp_path / "params")
+    pk, wit = str(tmp_path / "rsa_1.pk"), str(tmp_path / "rsa_1.witness.npz")
     outs = []
     for name in ("a.proof", "b.proof"):
-        cli.main(["prove-rsa", "--k", "9", "--params-path", params, "--proof-path", str(tmp_path / name)])
+        cli.main(["prove-rsa", "--k", "9", "--params-path", params, "--pk-path", pk, "--witness-path", wit, "--proof-path", str(tmp_path / name)])
         outs.append(json.loads(capsys.readouterr().out.strip().splitlines()[-1]))
     assert not os.path.exists(os.path.join(params, "kzg_bn254_9.srs"))      # the reference's file name is never written with a synthetic SRS
     srs = os.path.join(params, "kzg_bn254_9.synthetic.srs")
     assert os.path.getsize(srs) == 4 + 2 * 512 * 64 + 256 and outs[0]["params"] == srs and outs[0]["transcript"] == "poseidon"
     assert open(srs, "rb").read()[-256:] != bytes(256)                      # real g2 / [s] g2, not identity points
-    a, b = (tmp_path / "a.proof").read_bytes(), (tmp_path / "b.proof").read_bytes()
-    assert a == b and len(a) == outs[0]["proof_bytes"] and len(a) % 32 == 0
-    cli.main(["gen-x509-agg-evm-proof", "--agg-k", "9", "--params-path", params, "--agg-proof-path", str(tmp_path / "e.proof")])
+    assert outs[0]["proving_key"]["source"] == "generated" and outs[1]["proving_key"]["source"] == "file" and os.path.getsize(pk) > 512 * 32 * 10
+    a, b = fm.SnarkFile.read(tmp_path / "a.proof", protocol_len=0), fm.SnarkFile.read(tmp_path / "b.proof", protocol_len=0)
+    assert a.proof == b.proof and a.instances == b.instances and len(a.proof) == outs[0]["proof_bytes"] and len(a.proof) % 32 == 0
+    assert [len(c) for c in a.instances] == [32]
+    fm.write_break_points(tmp_path / "bp.json", [[500, 501, 502, 503], []])          # 4 break points = 5 advice columns
+    cli.main(["gen-x509-agg-evm-proof", "--agg-k", "9", "--params-path", params, "--no-pk-file", "--agg-proof-path", str(tmp_path / "e.proof"),
+              "--snark-paths", str(tmp_path / "a.proof"), str(tmp_path / "b.proof"), "--break-points-path", str(tmp_path / "bp.json")])
     e = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
-    assert e["transcript"] == "evm-keccak" and e["proof_bytes"] > len(a)
+    assert e["transcript"] == "evm-keccak" and e["proof_bytes"] > len(a.proof) and e["break_points"]["advice_columns"] == 5
+    assert [s_["proof_bytes"] for s_ in e["snarks"]] == [len(a.proof)] * 2 and "a5+1" in e["circuit"]
+    assert (tmp_path / "e.proof").stat().st_size == e["proof_bytes"]
+
+
+def test_proof_from_an_oracle_written_proving_key_file(zk, oracle, tmp_path, capsys):
+    """the artefact readers have a consumer.  The ORACLE backend runs the keygen-shaped setup, writes the proving key
+    (formats.ProvingKeyFile: ProvingKey::write layout) and the witness, and proves on the CPU; the GPU side builds NOTHING of the key —
+    `read_pk` -> zk_proving_key (fixed / sigma columns in three forms, l-polynomials from the file) — and must produce the oracle's
+    proof bytes: through Prover(key_file=...) on both quotient paths, and through the CLI driver."""
+    import json
+
+    import halo2_zkcert_amd.formats as fm
+
+    ffi, ctx = zk
+    zo = oracle
+    sh = pv.CircuitShape.rsa(9)
+    cp = pv.Prover(OracleBackend(8), sh, satisfiable=True)
+    w = cp.witness(5)
+    ref = cp.prove(w, transcript="poseidon")["proof"]
+    fixed_c = [c[0] for c in cp.b.commit(cp.fixed_coeff, lagrange=False)]
+    sigma_c = [c[0] for c in cp.b.commit(cp.sigma_coeff, lagrange=False)]
+    pk_path, wit_path = tmp_path / "rsa_1.pk", tmp_path / "rsa_1.witness.npz"
+    fm.ProvingKeyFile.from_prover(cp, fixed_c, sigma_c).write(pk_path)
+    cp.save_witness(w, wit_path)
+    kf = fm.ProvingKeyFile.read(pk_path, n_perm_columns=len(sh.perm_columns), n_selectors=0)
+    gp = pv.Prover(pv.GpuBackend(ctx, ffi), sh, key_file=kf)
+    assert gp.key_source == "file" and not hasattr(gp, "_value_src")          # no keygen ran on this side
+    gw = gp.load_witness(wit_path)
+    assert gp.prove_native(gw, transcript="poseidon")["proof"] == ref           # quotient on cosets (key columns derived from fixed_polys / permutation polys)
+    ctx.set_option("coset_quotient", 0)
+    try:
+        assert gp.prove_native(gw, transcript="poseidon")["proof"] == ref       # extended domain: the file's fixed_cosets / permutation cosets / l0 ...
+    finally:
+        ctx.set_option("coset_quotient", 1)
+    # the vk's commitments in the file (made by the oracle's MSM) are what the GPU commits to for the same polynomials
+    g_fixed = [np.asarray(c[0], dtype=np.uint64) for c in gp.b.commit(gp.fixed_coeff, lagrange=False)]
+    assert (np.stack(g_fixed) == kf.fixed_commitments).all()
+    gp.release()
+    cli = _cli()
+    cli.main(["prove-rsa", "--k", "9", "--params-path", str(tmp_path / "params"), "--pk-path", str(pk_path), "--witness-path", str(wit_path),
+              "--proof-path", str(tmp_path / "cli.proof")])
+    out = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert out["proving_key"]["source"] == "file"
+    assert fm.SnarkFile.read(tmp_path / "cli.proof", protocol_len=0).proof == ref
 
 
 # ------------------------------------------------------------------ round 2
