@@ -175,7 +175,10 @@ int comm_row_copies(zkhip_ctx* ctx, const std::vector<RowCopy>& list) {
 //   host transport: the caller's all-to-all callback if one was given (zkhip_comm_set_host_alltoall), else the exchange is emulated
 //   through the all-gather callback (every rank gathers every send buffer and keeps its column: correct, N times the volume — the
 //   counter still reports the bytes an all-to-all moves, and comm_describe says "emulated").
-int comm_alltoall(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t bytes) {
+// send_to[r] = 0: this rank has nothing for rank r; recv_from[r] = 0: rank r has nothing for this rank (null = all ones).  The two patterns
+// must be consistent across the ranks (they follow from column / block ownership, which every rank knows).  RCCL skips the silent pairs;
+// the host transport moves the padded buffers (a test transport: its counter says so).
+int comm_alltoall(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t bytes, const uint8_t* send_to, const uint8_t* recv_from) {
     zkhip_comm& cm = ctx->comm;
     if (cm.nranks <= 1 || bytes == 0) return ZKHIP_OK;
     const size_t N = (size_t)cm.nranks, total = bytes * N;
@@ -211,14 +214,15 @@ int comm_alltoall(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t bytes
     ncclComm_t c = (ncclComm_t)cm.nccl;
     ZK_HIP(hipEventRecord(cm.ev_in, ctx->stream));
     ZK_HIP(hipStreamWaitEvent(cm.stream, cm.ev_in, 0));
+    size_t received = 0;
     ZK_NCCL(g_rccl.GroupStart());
     for (size_t r = 0; r < N; ++r) {
         if ((int)r == cm.rank) continue;
-        ZK_NCCL(g_rccl.Send((const char*)d_send + r * bytes, bytes, ncclInt8, (int)r, c, cm.stream));
-        ZK_NCCL(g_rccl.Recv((char*)d_recv + r * bytes, bytes, ncclInt8, (int)r, c, cm.stream));
+        if (!send_to || send_to[r]) ZK_NCCL(g_rccl.Send((const char*)d_send + r * bytes, bytes, ncclInt8, (int)r, c, cm.stream));
+        if (!recv_from || recv_from[r]) { ZK_NCCL(g_rccl.Recv((char*)d_recv + r * bytes, bytes, ncclInt8, (int)r, c, cm.stream)); received += bytes; }
     }
     ZK_NCCL(g_rccl.GroupEnd());
-    cm.bytes_gathered += bytes * (N - 1);
+    cm.bytes_gathered += received;
     cm.collectives += 1;
     return comm_allgather_end(ctx);
 }

@@ -166,7 +166,7 @@ namespace zk {
 int comm_allgather(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t bytes);
 int comm_allgather_begin(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t bytes);
 int comm_allgather_end(zkhip_ctx* ctx);
-int comm_alltoall(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_pair);
+int comm_alltoall(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_pair, const uint8_t* send_to = nullptr, const uint8_t* recv_from = nullptr);
 struct RowCopy { const uint32_t* src; uint32_t* dst; uint32_t src_row0, dst_row0, count, src_mask, dst_mask; };
 #define ZK_ROWCOPY_MAX 48
 int comm_row_copies(zkhip_ctx* ctx, const std::vector<RowCopy>& list);
@@ -190,6 +190,8 @@ int coset_plan(zkhip_ctx* ctx, const zkhip_domain* d, const CosetPlan** out);
 uint32_t coset_plan_q(const CosetPlan* p);
 int coeff_to_cosets(zkhip_ctx* ctx, const CosetPlan* p, const void* const* srcs, void* const* dsts, size_t npolys);
 int cosets_to_pieces(zkhip_ctx* ctx, const CosetPlan* p, void* d_vals, void* d_pieces);
+int cosets_inverse_blocks(zkhip_ctx* ctx, const CosetPlan* p, void* d_vals, const uint32_t* blocks, size_t nblocks);
+int cosets_combine_range(zkhip_ctx* ctx, const CosetPlan* p, const void* d_vals, void* d_pieces, size_t first_row, size_t count);
 struct KeyCosets { std::vector<const void*> fixed, sigma; const void* l0; const void* l_last; const void* l_active; };
 int key_cosets(zkhip_ctx* ctx, const CosetPlan* p, const zk_proving_key* pk, const KeyCosets** out);
 void coset_sweep_view(const CosetPlan* p, SweepCosets* out);

@@ -153,6 +153,30 @@ int zk::cosets_to_pieces(zkhip_ctx* ctx, const CosetPlan* p, void* d_vals, void*
     return ZKHIP_OK;
 }
 
+// The same in two steps for the row-sharded form (prover.hip): the inverse transform of SOME blocks (their owner's), and the combination
+// restricted to a row range (pointwise in the rows).
+int zk::cosets_inverse_blocks(zkhip_ctx* ctx, const CosetPlan* p, void* d_vals, const uint32_t* blocks, size_t nblocks) {
+    if (!ctx || !p || !d_vals || (nblocks && !blocks)) { set_error("cosets_inverse_blocks: null argument"); return ZKHIP_EINVAL; }
+    const size_t n = (size_t)1 << p->k, NB = n * 32;
+    for (size_t i = 0; i < nblocks; ++i) {
+        if (blocks[i] >= p->q) { set_error("cosets_inverse_blocks: block %u of %u", blocks[i], p->q); return ZKHIP_EINVAL; }
+        void* u[1] = {(char*)d_vals + blocks[i] * NB};
+        ZK_TRY(ntt_tabled(ctx, (const void* const*)u, u, 1, p->omega_inv_abi, p->k, nullptr, (const char*)p->d_post + blocks[i] * NB, 1, n));
+    }
+    return ZKHIP_OK;
+}
+int zk::cosets_combine_range(zkhip_ctx* ctx, const CosetPlan* p, const void* d_vals, void* d_pieces, size_t first_row, size_t count) {
+    if (!ctx || !p || !d_vals || !d_pieces) { set_error("cosets_combine_range: null argument"); return ZKHIP_EINVAL; }
+    const size_t n = (size_t)1 << p->k, NB = n * 32;
+    if (first_row + count > n) { set_error("cosets_combine_range: rows [%zu, %zu) of %zu", first_row, first_row + count, n); return ZKHIP_EINVAL; }
+    std::vector<const void*> u(p->q);
+    for (uint32_t r = 0; r < p->q; ++r) u[r] = (const char*)d_vals + r * NB + first_row * 32;
+    for (uint32_t j = 0; j < p->q; ++j)
+        ZK_TRY(zkhip_linear_combination_device(ctx, count, u.data(), p->q, p->minv_abi.data() + 4 * (size_t)j * p->q, nullptr, 0,
+                                               (char*)d_pieces + j * NB + first_row * 32));
+    return ZKHIP_OK;
+}
+
 // out[i] = (lo <= i < hi) ? 1 : 0 in the ABI form: the Lagrange-basis vectors of l_0, l_last and l_active_row
 __global__ void k_indicator(uint32_t* out, size_t n, size_t lo, size_t hi, fe32 one_abi) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;

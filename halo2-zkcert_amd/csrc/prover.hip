@@ -250,6 +250,15 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
     for (uint32_t i = 0; i < L; ++i) scan_rots(pk->lookup_graphs[i]);
     const size_t m_rows = n / NR;
     const bool row_mode = dist && coset_mode && ctx->opt.row_sharded != 0 && n % (NR * 64) == 0 && 2 * (size_t)halo < m_rows;
+    // With MSMs by point range a commitment reads only this rank's rows of a column: the quotient's pieces, h(X) and SHPLONK's polynomials
+    // then never need to be complete anywhere (shplonk.hip makes the same test on the SRS handle).
+    bool pieces_sharded = false;
+    if (row_mode && !ctx->comm.shard_columns) {
+        size_t s_first, s_count, s_total;
+        zkhip_srs_range(pk->g, &s_first, &s_count, &s_total);
+        pieces_sharded = s_total == n && s_count == m_rows && s_first == RK * m_rows && m_rows >= 64;
+    }
+    const size_t my_lo = pieces_sharded ? RK * m_rows : 0, my_n = pieces_sharded ? m_rows : n, my_lo_b = my_lo * 32;
     // coeff_to_extended of `count` polynomials whose outputs are consecutive EB-sized slices of one padded workspace block
     auto to_extended = [&](const void* const* srcs, void* const* dsts, size_t count) -> int {
         auto transform = [&](const void* const* s_, void* const* d_, size_t c_) -> int {
@@ -276,7 +285,9 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
                                                    (uint32_t)((r * m_rows + n - halo) & nmask), 0u, (uint32_t)W, nmask, 0xffffffffu});
             }
             ZK_TRY(zk::comm_row_copies(ctx, list));
-            ZK_TRY(zk::comm_alltoall(ctx, w_send, w_recv, blk));
+            std::vector<uint8_t> has_cols(NR), to_all(NR, md.empty() ? 0 : 1);
+            for (size_t r = 0; r < NR; ++r) has_cols[r] = r < count;      // rank r transforms columns r, r + NR, ...: none if r >= count
+            ZK_TRY(zk::comm_alltoall(ctx, w_send, w_recv, blk, to_all.data(), has_cols.data()));
             list.clear();
             for (size_t r = 0; r < NR; ++r) {
                 if (r == RK) continue;
@@ -525,11 +536,13 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
             return coset_mode ? zk::evaluate_h_cosets(ctx, &a, &sc, first, rows, dst) : zkhip_evaluate_h_rows_device(ctx, &a, first, rows, dst);
         };
         if (row_mode) {
-            // this rank's row range of every coset block; the numerator's blocks are completed by one all-gather per block (the inverse
-            // transforms below run on whole blocks)
+            // this rank's row range of every coset block
             for (uint32_t b_ = 0; b_ < qd; ++b_) ZK_TRY(sweep(b_ * n + RK * m_rows, m_rows, vals + (b_ * n + RK * m_rows) * 32));
-            for (uint32_t b_ = 0; b_ < qd; ++b_) ZK_TRY(zk::comm_allgather_begin(ctx, vals + (b_ * n + RK * m_rows) * 32, vals + (size_t)b_ * NB, m_rows * 32));
-            ZK_TRY(zk::comm_allgather_end(ctx));
+            if (!pieces_sharded) {
+                // the numerator's blocks are completed by one all-gather per block (the inverse transforms below run on whole blocks)
+                for (uint32_t b_ = 0; b_ < qd; ++b_) ZK_TRY(zk::comm_allgather_begin(ctx, vals + (b_ * n + RK * m_rows) * 32, vals + (size_t)b_ * NB, m_rows * 32));
+                ZK_TRY(zk::comm_allgather_end(ctx));
+            }
         } else if (dist && ext_rows % (64 * NR) == 0) {
             const size_t rows = ext_rows / NR;
             ZK_TRY(sweep(RK * rows, rows, vals + RK * rows * 32));
@@ -538,7 +551,59 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
             ZK_TRY(sweep(0, ext_rows, vals));
         }
     }
-    if (coset_mode) {
+    if (pieces_sharded) {
+        // Block b's inverse transform belongs to rank b mod N: (1) every rank sends its rows of block b to that owner (an all-to-all in
+        // which only the owners receive), (2) the owner transforms its complete blocks, (3) sends every rank ITS row range of them, and
+        // (4) each rank forms its rows of the q pieces (the q x q combination is pointwise).  2 q n / N rows cross instead of the all-gather's
+        // q n, and no rank ever holds a complete piece: the commitments below read only this rank's rows.
+        const size_t nb_max = (qd + NR - 1) / NR, blk = nb_max * m_rows * 32;
+        char *w_send, *w_recv;
+        ZK_TRY(ws("cp_a2a_send", NR * blk, &w_send));
+        ZK_TRY(ws("cp_a2a_recv", NR * blk, &w_recv));
+        std::vector<uint32_t> mine_blocks;
+        for (uint32_t b_ = (uint32_t)RK; b_ < qd; b_ += (uint32_t)NR) mine_blocks.push_back(b_);
+        std::vector<uint8_t> owner(NR), everyone(NR, 1), nobody(NR, 0);
+        for (size_t r = 0; r < NR; ++r) owner[r] = r < qd;
+        std::vector<zk::RowCopy> list;
+        const uint32_t full = 0xffffffffu;
+        for (size_t r = 0; r < NR; ++r) {
+            if (r == RK) continue;
+            size_t t = 0;
+            for (uint32_t b_ = (uint32_t)r; b_ < qd; b_ += (uint32_t)NR, ++t)
+                list.push_back(zk::RowCopy{(const uint32_t*)(w_hvals + ((size_t)b_ * n + RK * m_rows) * 32), (uint32_t*)(w_send + r * blk + t * m_rows * 32), 0u, 0u,
+                                           (uint32_t)m_rows, full, full});
+        }
+        ZK_TRY(zk::comm_row_copies(ctx, list));
+        ZK_TRY(zk::comm_alltoall(ctx, w_send, w_recv, blk, owner.data(), mine_blocks.empty() ? nobody.data() : everyone.data()));
+        list.clear();
+        for (size_t r = 0; r < NR && !mine_blocks.empty(); ++r) {
+            if (r == RK) continue;
+            for (size_t t = 0; t < mine_blocks.size(); ++t)
+                list.push_back(zk::RowCopy{(const uint32_t*)(w_recv + r * blk + t * m_rows * 32), (uint32_t*)(w_hvals + ((size_t)mine_blocks[t] * n + r * m_rows) * 32), 0u,
+                                           0u, (uint32_t)m_rows, full, full});
+        }
+        ZK_TRY(zk::comm_row_copies(ctx, list));
+        ZK_TRY(zk::cosets_inverse_blocks(ctx, cplan, w_hvals, mine_blocks.data(), mine_blocks.size()));
+        list.clear();
+        for (size_t r = 0; r < NR && !mine_blocks.empty(); ++r) {
+            if (r == RK) continue;
+            for (size_t t = 0; t < mine_blocks.size(); ++t)
+                list.push_back(zk::RowCopy{(const uint32_t*)(w_hvals + ((size_t)mine_blocks[t] * n + r * m_rows) * 32), (uint32_t*)(w_send + r * blk + t * m_rows * 32), 0u,
+                                           0u, (uint32_t)m_rows, full, full});
+        }
+        ZK_TRY(zk::comm_row_copies(ctx, list));
+        ZK_TRY(zk::comm_alltoall(ctx, w_send, w_recv, blk, mine_blocks.empty() ? nobody.data() : everyone.data(), owner.data()));
+        list.clear();
+        for (size_t r = 0; r < NR; ++r) {
+            if (r == RK) continue;
+            size_t t = 0;
+            for (uint32_t b_ = (uint32_t)r; b_ < qd; b_ += (uint32_t)NR, ++t)
+                list.push_back(zk::RowCopy{(const uint32_t*)(w_recv + r * blk + t * m_rows * 32), (uint32_t*)(w_hvals + ((size_t)b_ * n + RK * m_rows) * 32), 0u, 0u,
+                                           (uint32_t)m_rows, full, full});
+        }
+        ZK_TRY(zk::comm_row_copies(ctx, list));
+        ZK_TRY(zk::cosets_combine_range(ctx, cplan, w_hvals, w_h, RK * m_rows, m_rows));
+    } else if (coset_mode) {
         // per coset: inverse transform and s_r^-t; then the q x q combination that also carries 1 / (n (s_r^n - 1)): the division by the
         // vanishing polynomial, which is constant on a coset
         ZK_TRY(zk::cosets_to_pieces(ctx, cplan, w_hvals, w_h));
@@ -564,7 +629,9 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
         std::vector<uint64_t> cf(4 * qd);
         HF acc = hone();
         for (uint32_t i = 0; i < qd; ++i) { abi_of(acc, cf.data() + 4 * i); acc = hmul(acc, xn); }
-        ZK_TRY(zkhip_linear_combination_device(ctx, n, pieces.data(), qd, cf.data(), nullptr, 0, w_hpoly));
+        std::vector<const void*> pl(qd);
+        for (uint32_t i = 0; i < qd; ++i) pl[i] = (const char*)pieces[i] + my_lo_b;
+        ZK_TRY(zkhip_linear_combination_device(ctx, my_n, pl.data(), qd, cf.data(), nullptr, 0, w_hpoly + my_lo_b));
     }
     // polynomial table for the multi-open: advice, fixed, sigma, perm_z, lookup (z, a, s) per lookup, random, h
     std::vector<const void*> polys;
@@ -628,12 +695,51 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
         char* ev_out = w_evals;
         const bool ev_pinned = nq * 32 + 32768 + 64 <= zkhip_ctx::PINNED_BYTES;
         if (ev_pinned) ev_out = (char*)ctx->h_pinned + 32768;
+        if (dist && ctx->opt.row_sharded != 0 && nq >= 2 * NR) {
+            // the evaluations are independent: rank r evaluates queries r, r + NR, ... (the 32-byte results are all-gathered, padded to the
+            // same count per rank, and put back in query order).  h(X) exists only as row ranges when the pieces are sharded: every rank
+            // evaluates ITS rows as a polynomial of degree < m (one more slot per rank) and h(x) = sum_R x^(R m) P_R(x) is put together here.
+            const size_t ih = nq - 2;                       // q(o_h, 0) above: the last query but one
+            const size_t per = (nq + NR - 1) / NR + 1;
+            std::vector<const void*> mq;
+            std::vector<uint64_t> mp;
+            for (size_t i = RK; i < nq; i += NR) {
+                if (pieces_sharded && i == ih) continue;
+                mq.push_back(qp[i]);
+                mp.insert(mp.end(), q_points.begin() + 4 * i, q_points.begin() + 4 * i + 4);
+            }
+            char* w_evg;
+            ZK_TRY(ws("cp_evals_gather", NR * per * 32, &w_evg));
+            char* mine = w_evg + RK * per * 32;
+            ZK_HIP(hipMemsetAsync(mine, 0, per * 32, ctx->stream));
+            if (!mq.empty()) ZK_TRY(zkhip_eval_polynomials_at_device(ctx, mq.data(), mq.size(), n, mp.data(), mine));
+            if (pieces_sharded) {
+                const void* hp[1] = {w_hpoly + my_lo_b};
+                ZK_TRY(zkhip_eval_polynomials_at_device(ctx, hp, 1, my_n, q_points.data() + 4 * ih, mine + (per - 1) * 32));
+            }
+            ZK_TRY(zk::comm_allgather(ctx, mine, w_evg, per * 32));
+            std::vector<uint64_t> all(NR * per * 4);
+            ZK_TRY(zkhip_memcpy_d2h(ctx, all.data(), w_evg, NR * per * 32));
+            std::vector<size_t> taken(NR, 0);
+            for (size_t i = 0; i < nq; ++i) {
+                if (pieces_sharded && i == ih) continue;
+                const size_t r = i % NR;
+                memcpy(q_evals.data() + 4 * i, all.data() + 4 * (r * per + taken[r]++), 32);
+            }
+            if (pieces_sharded) {
+                const HF xm = hpow(x, m_rows);
+                HF acc = hzero();
+                for (size_t r = NR; r-- > 0;) acc = hadd(hmul(acc, xm), hf_from_abi(all.data() + 4 * (r * per + per - 1)));
+                abi_of(acc, q_evals.data() + 4 * ih);
+            }
+        } else {
         ZK_TRY(zkhip_eval_polynomials_at_device(ctx, qp.data(), nq, n, q_points.data(), ev_out));
         if (ev_pinned) {
             ZK_HIP(stream_wait(ctx->stream));
             memcpy(q_evals.data(), ev_out, nq * 32);
         } else {
             ZK_TRY(zkhip_memcpy_d2h(ctx, q_evals.data(), w_evals, nq * 32));
+        }
         }
     }
     mark("evaluations read back");

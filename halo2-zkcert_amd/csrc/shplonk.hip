@@ -114,7 +114,9 @@ __global__ void __launch_bounds__(SP_BLOCK) k_kd_totals(const KdArgs K, size_t n
     if (t == 0) mem_store(tot_all + ((size_t)e * nblk + blockIdx.x) * 8, fe_pack(sc[0]));
 }
 // pass 2 (one block per entry): carry[entry][blk] = s at the first index of tile blk + 1 (exclusive suffix scan, slope r^2048)
-__global__ void __launch_bounds__(SP_BLOCK) k_kd_carries(const KdArgs K, uint32_t nblk, const uint32_t* tot_all, uint32_t* carry_all) {
+// If total_all is given, entry e's Horner total over ALL tiles (the value of the suffix recurrence at the array's first index with zero
+// carry-in: sum_j a_j r^j) is stored there — what a rank of a row-sharded division hands to the ranks below it.
+__global__ void __launch_bounds__(SP_BLOCK) k_kd_carries(const KdArgs K, uint32_t nblk, const uint32_t* tot_all, uint32_t* carry_all, uint32_t* total_all) {
     __shared__ fe sc[SP_BLOCK];
     const uint32_t t = threadIdx.x, e = blockIdx.x;
     const uint32_t* tot = tot_all + (size_t)e * nblk * 8;
@@ -128,6 +130,7 @@ __global__ void __launch_bounds__(SP_BLOCK) k_kd_carries(const KdArgs K, uint32_
     sc[t] = canonical(s).v;
     __shared__ fe mp[8];
     suffix_scan_256(sc, mp, t, pow_u64<Fr>(M, c));
+    if (total_all && t == 0) store_raw<Fr>(total_all + (size_t)e * 8, el1<Fr>(sc[0]));
     s = zero<Fr>();
     if (t + 1 < SP_BLOCK) s = el1<Fr>(sc[t + 1]);
     for (uint32_t q = hi; q > lo; --q) {
@@ -170,23 +173,76 @@ __global__ void __launch_bounds__(SP_BLOCK) k_kd_apply(const KdArgs K, size_t n,
     }
 }
 
+// Row-sharded division: the local array is rows [lo, lo + m) of the polynomial and the recurrence continues above it: with the carry-in
+// c = s[lo + m] the true quotient is q[j] = q0[j] + c r^(m - 1 - j), q0 the zero-carry result of the three passes above.  Each thread fixes
+// 16 consecutive coefficients: one power by square-and-multiply, then a running product downwards.
+struct KdFix { uint32_t* dst; fe32 r; fe32 c; };   // r, c in R' form canonical
+struct KdFixArgs { KdFix e[KD_MAX]; };
+__global__ void __launch_bounds__(256) k_kd_fix(const KdFixArgs F, size_t m) {
+    const uint32_t e = blockIdx.y;
+    const size_t j0 = (blockIdx.x * (size_t)256 + threadIdx.x) * 16;
+    if (j0 >= m) return;
+    const size_t j1 = j0 + 16 < m ? j0 + 16 : m;
+    const el1<Fr> r(fe_split<0>(F.e[e].r)), c(fe_split<0>(F.e[e].c));
+    el2<Fr> w = c * pow_u64<Fr>(el2<Fr>(r), (uint64_t)(m - j1));      // c r^(m - 1 - (j1 - 1))
+    uint32_t* dst = F.e[e].dst;
+    for (size_t j = j1; j-- > j0;) {
+        store_raw<Fr>(dst + j * 8, load_raw<Fr>(dst + j * 8) + w);
+        w = w * r;
+    }
+}
+
 static fe32 abi_to_raw(const uint64_t* p) { return fe_pack(fe_canonical<Fr>(from_abi<Fr>(mem_load(p)).v)); }
 
-// dst_j = src_j / (X - root_j) for `count` polynomials, KD_MAX per launch triple
-static int divide_round(zkhip_ctx* ctx, size_t n, const std::vector<KdEntry>& ents) {
+// dst_j = src_j / (X - root_j) for `count` polynomials, KD_MAX per launch triple.
+// sharded = true (a context with a communicator, the arrays are this rank's rows [RK m, (RK + 1) m) of n = N m coefficients): the suffix
+// recurrence runs across the ranks — every rank publishes its range totals (32 B per division, one all-gather), derives its carry-in
+// from the ranks above it on the host (Horner in r^m) and adds the geometric correction (k_kd_fix).
+static int divide_round(zkhip_ctx* ctx, size_t n, const std::vector<KdEntry>& ents, bool sharded = false) {
     hipStream_t st = ctx->stream;
     uint32_t nblk = div_up(n, SP_TILE);
-    void *d_tot, *d_carry;
+    void *d_tot, *d_carry, *d_total = nullptr;
     ZK_TRY(ctx->get_scratch("kd_tot", (size_t)KD_MAX * nblk * 32, &d_tot));
     ZK_TRY(ctx->get_scratch("kd_carry", (size_t)KD_MAX * nblk * 32, &d_carry));
+    const size_t NR = (size_t)ctx->comm.nranks, RK = (size_t)ctx->comm.rank;
+    if (sharded) ZK_TRY(ctx->get_scratch("kd_total", (NR + 1) * KD_MAX * 32, &d_total));
     for (size_t done = 0; done < ents.size(); done += KD_MAX) {
         uint32_t cnt = (uint32_t)std::min<size_t>(KD_MAX, ents.size() - done);
         KdArgs K;
         memset(&K, 0, sizeof K);
         for (uint32_t j = 0; j < cnt; ++j) K.e[j] = ents[done + j];
+        uint32_t* mine = sharded ? (uint32_t*)((char*)d_total + RK * KD_MAX * 32) : nullptr;
         hipLaunchKernelGGL(k_kd_totals, dim3(nblk, cnt), dim3(SP_BLOCK), 0, st, K, n, nblk, (uint32_t*)d_tot);
-        hipLaunchKernelGGL(k_kd_carries, dim3(cnt), dim3(SP_BLOCK), 0, st, K, nblk, (const uint32_t*)d_tot, (uint32_t*)d_carry);
+        hipLaunchKernelGGL(k_kd_carries, dim3(cnt), dim3(SP_BLOCK), 0, st, K, nblk, (const uint32_t*)d_tot, (uint32_t*)d_carry, mine);
         hipLaunchKernelGGL(k_kd_apply, dim3(nblk, cnt), dim3(SP_BLOCK), 0, st, K, n, nblk, (const uint32_t*)d_carry);
+        ZK_LAUNCH_CHECK();
+        if (sharded) {
+            ZK_TRY(zk::comm_allgather(ctx, mine, d_total, KD_MAX * 32));
+            std::vector<uint32_t> tot(NR * KD_MAX * 8);
+            ZK_TRY(zkhip_memcpy_d2h(ctx, tot.data(), d_total, NR * KD_MAX * 32));
+            if (RK + 1 < NR) {
+                KdFixArgs F;
+                memset(&F, 0, sizeof F);
+                for (uint32_t j = 0; j < cnt; ++j) {
+                    // the totals are in the coefficients' scale (the ABI form, which is HF's form); the root travels in the R' form:
+                    // c = T_(R+1) + r^m (T_(R+2) + r^m (...)) with r^m in the ABI form
+                    fe32 rr = K.e[j].r;                          // r in R' form, canonical
+                    HF r_abi = hf_from_fe32(to_abi(el1<Fr>(fe_split<0>(rr))));
+                    const HF rm = hpow(r_abi, (uint64_t)n);
+                    HF acc = hzero();
+                    for (size_t q = NR; q-- > RK + 1;) {
+                        fe32 t;
+                        memcpy(t.w, tot.data() + (q * KD_MAX + j) * 8, 32);
+                        acc = hadd(hmul(acc, rm), hf_from_fe32(t));
+                    }
+                    F.e[j].dst = K.e[j].dst;
+                    F.e[j].r = rr;
+                    F.e[j].c = hf_words(acc);
+                }
+                hipLaunchKernelGGL(k_kd_fix, dim3(div_up(div_up(n, 16), 256), cnt), dim3(256), 0, st, F, n);
+                ZK_LAUNCH_CHECK();
+            }
+        }
     }
     ZK_LAUNCH_CHECK();
     return ZKHIP_OK;
@@ -242,6 +298,24 @@ int zkhip_shplonk_open(zkhip_ctx* ctx, const zkhip_srs* srs, size_t n, const voi
         return ZKHIP_EINVAL;
     }
     if (nq == 0 || n == 0 || n > zkhip_srs_len(srs)) { set_error("zkhip_shplonk_open: bad sizes (n = %zu, queries = %zu)", n, nq); return ZKHIP_EINVAL; }
+    // Row-sharded (a communicator, MSMs by point range): every polynomial arithmetic below is pointwise or a suffix recurrence, and a
+    // point-range commitment reads only this rank's rows — so each rank works on rows [lo, lo + nl) of every polynomial: linear
+    // combinations on the range, divisions with the carries exchanged as 32-byte range totals (divide_round), the low-degree correction on
+    // rank 0 only.  The scratch polynomials keep their full size; only the rank's range of them is ever written or read.
+    size_t lo = 0, nl = n;
+    bool sharded = false;
+    {
+        size_t s_first, s_count, s_total;
+        zkhip_srs_range(srs, &s_first, &s_count, &s_total);
+        const size_t NR = (size_t)ctx->comm.nranks, RK = (size_t)ctx->comm.rank;
+        if (NR > 1 && ctx->opt.row_sharded != 0 && !ctx->comm.shard_columns && n % NR == 0 && s_total == n && s_count == n / NR && s_first == RK * (n / NR) &&
+            n / NR >= 64) {
+            sharded = true;
+            nl = n / NR;
+            lo = RK * nl;
+        }
+    }
+    const size_t lo_b = lo * 32;
     // ---- construct_intermediate_sets: unique points (by value), the point set of every commitment, sets in first-appearance order
     std::vector<HF> upts;
     std::vector<Words> uwords;
@@ -344,7 +418,9 @@ int zkhip_shplonk_open(zkhip_ctx* ctx, const zkhip_srs* srs, size_t n, const voi
         }
         std::vector<fe32> low_abi(m);
         for (size_t d = 0; d < m; ++d) low_abi[d] = hf_abi(low[d]);
-        ZK_TRY(lincomb_raw(ctx, n, ptrs.data(), ptrs.size(), coeffs.data(), low_abi.data(), m, (char*)d_num + si * n * 32));
+        if (sharded && m > nl) { set_error("zkhip_shplonk_open: a rotation set of %zu points exceeds the rank's %zu rows", m, nl); return ZKHIP_EINVAL; }
+        for (auto& q_ : ptrs) q_ = (const char*)q_ + lo_b;
+        ZK_TRY(lincomb_raw(ctx, nl, ptrs.data(), ptrs.size(), coeffs.data(), low_abi.data(), lo == 0 ? m : 0, (char*)d_num + si * n * 32 + lo_b));
     }
     // ---- all divisions in one pass (partial fractions), then h(X) = sum_i v^i sum_r Q_ir / prod_{s != r} (r - s)
     std::vector<HF> vpow(nsets);
@@ -360,15 +436,15 @@ int zkhip_shplonk_open(zkhip_ctx* ctx, const zkhip_srs* srs, size_t n, const voi
         for (size_t si = 0; si < nsets; ++si)
             for (size_t i = 0; i < sets[si].points.size(); ++i, ++o) {
                 KdEntry e;
-                e.src = (const uint32_t*)((char*)d_num + si * n * 32);
-                e.dst = (uint32_t*)((char*)d_quot + o * n * 32);
+                e.src = (const uint32_t*)((char*)d_num + si * n * 32 + lo_b);
+                e.dst = (uint32_t*)((char*)d_quot + o * n * 32 + lo_b);
                 e.r = hf_raw(upts[sets[si].points[i]]);
                 ents.push_back(e);
                 weights.push_back(hf_raw(hmul(vpow[si], sets[si].inv_den[i])));
                 ptrs.push_back(e.dst);
             }
-        { ProfScope ps(ctx, "kate_division"); ZK_TRY(divide_round(ctx, n, ents)); }
-        ZK_TRY(lincomb_raw(ctx, n, ptrs.data(), ptrs.size(), weights.data(), nullptr, 0, d_hx));
+        { ProfScope ps(ctx, "kate_division"); ZK_TRY(divide_round(ctx, nl, ents, sharded)); }
+        ZK_TRY(lincomb_raw(ctx, nl, ptrs.data(), ptrs.size(), weights.data(), nullptr, 0, (char*)d_hx + lo_b));
     }
     uint8_t bytes[32];
     {
@@ -409,17 +485,17 @@ int zkhip_shplonk_open(zkhip_ctx* ctx, const zkhip_srs* srs, size_t n, const voi
                 for (size_t d = sets[si].interp[ci].size(); d-- > 0;) ru = hadd(hmul(ru, u), sets[si].interp[ci][d]);
                 konst = hadd(konst, hmul(c, ru));
                 coeffs.push_back(hf_raw(c));
-                ptrs.push_back(d_polys[sets[si].commits[ci]]);
+                ptrs.push_back((const char*)d_polys[sets[si].commits[ci]] + lo_b);
                 yp = hmul(yp, y);
             }
         }
         coeffs.push_back(hf_raw(hsub(hzero(), hmul(zt, inv0))));
-        ptrs.push_back(d_hx);
+        ptrs.push_back((const char*)d_hx + lo_b);
         fe32 low_abi = hf_abi(konst);
-        ZK_TRY(lincomb_raw(ctx, n, ptrs.data(), ptrs.size(), coeffs.data(), &low_abi, 1, d_lx));
+        ZK_TRY(lincomb_raw(ctx, nl, ptrs.data(), ptrs.size(), coeffs.data(), &low_abi, lo == 0 ? 1 : 0, (char*)d_lx + lo_b));
         std::vector<KdEntry> ents(1);
-        ents[0].src = (const uint32_t*)d_lx; ents[0].dst = (uint32_t*)d_lx; ents[0].r = hf_raw(u);
-        { ProfScope ps(ctx, "kate_division"); ZK_TRY(divide_round(ctx, n, ents)); }
+        ents[0].src = (const uint32_t*)((char*)d_lx + lo_b); ents[0].dst = (uint32_t*)((char*)d_lx + lo_b); ents[0].r = hf_raw(u);
+        { ProfScope ps(ctx, "kate_division"); ZK_TRY(divide_round(ctx, nl, ents, sharded)); }
         const void* col[1] = {d_lx};
         ZK_TRY(zkhip_msm_g1_batch_device(ctx, srs, col, 1, n, d_com));
         ZK_TRY(zkhip_commitments_read(ctx, d_com, 1, h2_xy, bytes));

@@ -127,6 +127,13 @@ def test_long_mixed_sum_keeps_invariants(zt, oracle):
     negs = np.random.default_rng(1).integers(0, 2, n).astype(np.uint8)
     negs[4] = negs[5] = 0
     negs[8], negs[9] = 0, 1
+    # the XYZZ sum alternates between two accumulators (even / odd index): make the exceptional cases of g1x_add_mixed happen INSIDE one
+    # accumulator — acc == q exactly (index 0 then 2: the doubling branch of the fix-up), acc == -q (index 1 then 3: the sum becomes the
+    # identity, and index 5 then meets an identity accumulator) — the formula-first / unlikely-fix-up form of round 3 must take them
+    pts[2] = pts[0]
+    negs[0] = negs[2] = 0
+    pts[3] = pts[1]
+    negs[1], negs[3] = 0, 1
     o = zo.new(12)
     zt.zkt_g1_sum_mixed(zo.p(pts), negs.ctypes.data_as(C.c_void_p), C.c_size_t(n), zo.p(o))
     sc = zo.fr_arr_from_ints([(R - 1) if s else 1 for s in negs])

@@ -388,14 +388,20 @@ def test_native_proof_bytes_verify(zk, oracle, k, kind):
 
 def test_rsa_k17_poseidon_proof_bytes_verify(zk, oracle):
     """BASELINE configs[1] under the transcript the reference's prove-rsa really uses (gen_snark_shplonk = Poseidon,
-    /root/reference/src/bin/cli.rs:320): the k = 17 proof's bytes verify."""
-    from verify_util import verify_proof
+    /root/reference/src/bin/cli.rs:320): the k = 17 proof's bytes verify — against a verifying key whose fixed / sigma commitments were
+    made by the CPU ORACLE (its own SRS from the trapdoor, its own best_multiexp), so nothing the verifier is given comes from the GPU
+    except the proof; the GPU-side commitments of the same polynomials are the same points."""
+    from verify_util import verify_proof, vk_commitments
 
     ffi, ctx = zk
     gp = pv.Prover(pv.GpuBackend(ctx, ffi), pv.CircuitShape.rsa(17), satisfiable=True)
     w = gp.witness(0)
     t = gp.prove_native(w, transcript="poseidon")
-    assert t["n_commitments"] == 16 and verify_proof(gp, w, t["proof"], "poseidon")
+    assert t["n_commitments"] == 16 and verify_proof(gp, w, t["proof"], "poseidon", oracle_vk=True)
+    assert vk_commitments(gp, oracle_side=True) == vk_commitments(gp)
+    bad = bytearray(t["proof"])
+    bad[-70] ^= 4
+    assert not verify_proof(gp, w, bytes(bad), "poseidon", oracle_vk=True)
 
 
 def test_sha_satisfiable_matches_oracle_k11(zk, oracle):

@@ -20,17 +20,27 @@ def _queries(sh):
     return aq, fq
 
 
-def vk_commitments(prover):
-    """the verifying key's fixed / sigma commitments, committed with the prover's own backend as keygen would (cached)"""
-    if getattr(prover, "_vk_coms", None) is None:
+def vk_commitments(prover, oracle_side=False, srs_trapdoor=0x1D5C0FFEE, threads=8):
+    """the verifying key's fixed / sigma commitments (cached).  Default: committed with the prover's own backend, as keygen would.
+    oracle_side=True: committed by the CPU ORACLE (its own SRS from the trapdoor, its own MSM) from host copies of the key's polynomials —
+    the verifier's inputs then owe nothing to the GPU (at k = 17 the verifier was checking GPU commitments with GPU-made
+    vk points)."""
+    key = "_vk_coms_oracle" if oracle_side else "_vk_coms"
+    if getattr(prover, key, None) is None:
         b = prover.b
-        fixed = [_pts([c[0]])[0] for c in b.commit(prover.fixed_coeff, lagrange=False)]
-        sigma = [_pts([c[0]])[0] for c in b.commit(prover.sigma_coeff, lagrange=False)]
-        prover._vk_coms = (fixed, sigma)
-    return prover._vk_coms
+        if oracle_side:
+            mono, _ = zo.kzg_setup_scalars(prover.shape.k, zo.fr_from_int(srs_trapdoor))
+            g = zo.fixed_base_mul(mono, threads)
+            com = lambda col: zo.affine_to_ints(zo.g1_to_affine(zo.best_multiexp(np.asarray(b.to_host(col), dtype=np.uint64), g, threads)).reshape(1, 8))[0]
+            fixed, sigma = [com(c) for c in prover.fixed_coeff], [com(c) for c in prover.sigma_coeff]
+        else:
+            fixed = [_pts([c[0]])[0] for c in b.commit(prover.fixed_coeff, lagrange=False)]
+            sigma = [_pts([c[0]])[0] for c in b.commit(prover.sigma_coeff, lagrange=False)]
+        setattr(prover, key, (fixed, sigma))
+    return getattr(prover, key)
 
 
-def verify_proof(prover, wit, proof, kind, srs_trapdoor=0x1D5C0FFEE):
+def verify_proof(prover, wit, proof, kind, srs_trapdoor=0x1D5C0FFEE, oracle_vk=False):
     """True iff the proof BYTES verify: pyref.verify_proof_bytes reads them in upstream's verifier order with the named transcript
     ("blake2b", "evm", "poseidon"), re-derives every challenge, and checks the gate / permutation / lookup identities and the
     SHPLONK opening.  Nothing of the prover's trace is consulted."""
@@ -38,7 +48,7 @@ def verify_proof(prover, wit, proof, kind, srs_trapdoor=0x1D5C0FFEE):
 
     sh = prover.shape
     aq, fq = _queries(sh)
-    fixed, sigma = vk_commitments(prover)
+    fixed, sigma = vk_commitments(prover, oracle_side=oracle_vk, srs_trapdoor=srs_trapdoor)
     inst_vals = [zo.fr_arr_to_ints(np.asarray(v, dtype=np.uint64)) for v in wit["instance_values"]]
     inst_cols = [v + [0] * ((1 << sh.k) - len(v)) for v in inst_vals]
     return P.verify_proof_bytes(_vk(sh), kind, proof, pv.from_mont_host(prover.vk_repr), inst_vals, inst_cols, fixed, sigma, aq, fq, srs_trapdoor)
