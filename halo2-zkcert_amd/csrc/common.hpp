@@ -119,6 +119,7 @@ struct zkhip_ctx {
     std::string prof_only;   // if non-empty, only spans of this name are recorded (keeps the event traffic off the timed path)
     struct ProfSpan { const char* name; hipEvent_t e0, e1; };
     std::vector<ProfSpan> prof_spans;
+    uint64_t n_row_sharded = 0, n_pieces_sharded = 0, n_shplonk_sharded = 0;   // multi-rank proofs by exchange mode (zkhip_profile_counter)
     uint64_t prof_msm_pairs = 0, prof_msm_dense_pairs = 0;   // (digit, point) pairs accumulated / n W per column, while profiling all kernels
     std::vector<hipEvent_t> prof_pool;
     hipEvent_t prof_event();

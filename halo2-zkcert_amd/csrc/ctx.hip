@@ -90,6 +90,9 @@ int zkhip_profile_counter(zkhip_ctx* c, const char* name, uint64_t* value) {
     if (!c || !name || !value) { set_error("zkhip_profile_counter: null argument"); return ZKHIP_EINVAL; }
     if (strcmp(name, "msm_pairs") == 0) *value = c->prof_msm_pairs;
     else if (strcmp(name, "msm_dense_pairs") == 0) *value = c->prof_msm_dense_pairs;
+    else if (strcmp(name, "proofs_row_sharded") == 0) *value = c->n_row_sharded;         // always counted (not only while profiling)
+    else if (strcmp(name, "proofs_pieces_sharded") == 0) *value = c->n_pieces_sharded;
+    else if (strcmp(name, "shplonk_row_sharded") == 0) *value = c->n_shplonk_sharded;
     else { set_error("zkhip_profile_counter: unknown counter '%s'", name); return ZKHIP_EINVAL; }
     return ZKHIP_OK;
 }

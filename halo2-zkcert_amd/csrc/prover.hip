@@ -258,6 +258,8 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
         zkhip_srs_range(pk->g, &s_first, &s_count, &s_total);
         pieces_sharded = s_total == n && s_count == m_rows && s_first == RK * m_rows && m_rows >= 64;
     }
+    if (row_mode) ctx->n_row_sharded += 1;
+    if (pieces_sharded) ctx->n_pieces_sharded += 1;
     const size_t my_lo = pieces_sharded ? RK * m_rows : 0, my_n = pieces_sharded ? m_rows : n, my_lo_b = my_lo * 32;
     // coeff_to_extended of `count` polynomials whose outputs are consecutive EB-sized slices of one padded workspace block
     auto to_extended = [&](const void* const* srcs, void* const* dsts, size_t count) -> int {

@@ -311,6 +311,7 @@ int zkhip_shplonk_open(zkhip_ctx* ctx, const zkhip_srs* srs, size_t n, const voi
         if (NR > 1 && ctx->opt.row_sharded != 0 && !ctx->comm.shard_columns && n % NR == 0 && s_total == n && s_count == n / NR && s_first == RK * (n / NR) &&
             n / NR >= 64) {
             sharded = true;
+            ctx->n_shplonk_sharded += 1;
             nl = n / NR;
             lo = RK * nl;
         }

@@ -79,7 +79,9 @@ int  zkhip_profile_enable(zkhip_ctx* ctx, int on);
 int  zkhip_profile_select(zkhip_ctx* ctx, const char* kernel);
 int  zkhip_profile_read(zkhip_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches);
 /* Work counters accumulated while profiling ALL kernels (no selection): "msm_pairs" = (non-zero digit, point) pairs the MSM
- * accumulations really processed (zero digits are skipped), "msm_dense_pairs" = n * windows per column. */
+ * accumulations really processed (zero digits are skipped), "msm_dense_pairs" = n * windows per column.  Counted always, on a context with
+ * a communicator: "proofs_row_sharded" (zkhip_create_proof_ex calls that exchanged row windows instead of complete columns),
+ * "proofs_pieces_sharded" (... whose quotient pieces stayed row ranges), "shplonk_row_sharded" (zkhip_shplonk_open calls on row ranges). */
 int  zkhip_profile_counter(zkhip_ctx* ctx, const char* name, uint64_t* value);
 
 /* ---- one proof over several GPUs: one process per GPU, RCCL over xGMI ----

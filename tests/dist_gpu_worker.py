@@ -57,6 +57,7 @@ for spec in json.loads(os.environ["ZK_SHAPES"]):
     torch.cuda.empty_cache()
 out["bytes_gathered"] = ctx.comm_bytes_gathered()
 out["comm"] = ctx.comm_describe()
+out["modes"] = {k_: ctx.profile_counter(k_) for k_ in ("proofs_row_sharded", "proofs_pieces_sharded", "shplonk_row_sharded")}
 with open(os.path.join(os.environ["ZK_OUT"], f"rank{rank}.json"), "w") as f:
     json.dump(out, f)
 dist.barrier()

@@ -67,6 +67,10 @@ def test_sharded_proof_equals_single_gpu_proof(zk, tmp_path, world):
         for key, hexs in ref.items():
             assert o[key]["native"] == hexs, (key, "native")
             assert o[key]["python"] == hexs, (key, "python")
+        if world == 2:      # 64 N divides n for the k = 8 and k = 10 circuits: row windows, row-range pieces and SHPLONK on row ranges were taken
+            assert o["modes"]["proofs_row_sharded"] >= 2 and o["modes"]["proofs_pieces_sharded"] >= 2 and o["modes"]["shplonk_row_sharded"] >= 2, o["modes"]
+        else:               # N = 3: nothing divides — the all-gather path
+            assert o["modes"]["proofs_row_sharded"] == 0, o["modes"]
 
 
 def test_rccl_communicator_single_rank(zk):
@@ -121,6 +125,8 @@ def test_eight_and_five_ranks(zk, tmp_path, world, mode):
         os.environ.pop("ZK_SHARD_MODE", None)
     assert len(outs) == world
     for o in outs:
+        if world == 8:      # k = 10: 64 x 8 divides 2^10; by column the windows are still exchanged, the pieces stay complete
+            assert o["modes"]["proofs_row_sharded"] >= 1 and (o["modes"]["proofs_pieces_sharded"] >= 1) == (mode == "points"), o["modes"]
         assert o["shard_mode"] == mode
         for key, hexs in ref.items():
             assert o[key]["native"] == hexs and o[key]["python"] == hexs, key
@@ -193,7 +199,10 @@ def test_agg_k22_proof_over_two_ranks_by_point_range(zk, tmp_path):
         # the numerator: 13 x 384 MiB, half of it received at N = 2 = 2.6 GB.  Row-sharded: per phase an all-to-all of row windows (own range
         # + halo) of the columns the peer transformed — ceil(5/2) + ceil(2/2) + ceil(5/2) = 7 column-windows of 3 x n/2 rows — plus the
         # numerator's row ranges (3 x n/2 rows) and the latency-sized partial sums: 8 x 3 x n/2 x 32 B = 1.6 GB.
-        assert 0 < o["agg22evm"]["bytes_gathered"] <= 8 * 3 * (n // 2) * 32 + (32 << 20), o["agg22evm"]["bytes_gathered"]
+        # (round 3, later) the quotient's pieces stay row ranges: the numerator's all-gather (3 x n/2 rows) is replaced by two all-to-alls of
+        # the blocks' row ranges to / from their owners (2 blocks of n/2 rows each way at N = 2, padded): 7 x 3 + 2 x 2 windows of n/2 rows
+        assert 0 < o["agg22evm"]["bytes_gathered"] <= (7 * 3 + 4) * (n // 2) * 32 + (32 << 20), o["agg22evm"]["bytes_gathered"]
+        assert o["modes"] == {"proofs_row_sharded": 1, "proofs_pieces_sharded": 1, "shplonk_row_sharded": 1}, o["modes"]
 
 
 def test_sha_k19_proof_over_two_ranks_by_column(zk, tmp_path):
