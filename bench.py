@@ -480,6 +480,7 @@ def main():
         d = ctx.comm_describe()
         return {"transport": d["transport"], "nranks": d["nranks"], "transport_ranks": d["transport_ranks"], "collectives_total": d["collectives"],
                 "bytes_gathered_per_step": int(per_step_bytes), "shard_mode": shard_mode,
+                "exchange_modes": {k_: ctx.profile_counter(k_) for k_ in ("proofs_row_sharded", "proofs_pieces_sharded", "shplonk_row_sharded")},
                 "note": "nranks / transport_ranks / bytes: what the library's own communicator reports on rank 0 (zkhip_comm_info / zkhip_comm_describe; "
                         "transport_ranks = ncclCommCount); bytes = received by this rank through all-gathers in one step"}
 
@@ -534,7 +535,7 @@ def main():
             "config": {"workload": head["workload"], "headline": args.config, "k": head["k"], "advice": head["advice"], "fixed": head["fixed"],
                        "lookups": head["lookups"], "perm_columns": head["perm_columns"], "degree": head["degree"], "transcript": head["transcript"],
                        "host": "prover.py (Python schedule over the C ABI)" if args.python_schedule else "zkhip_create_proof_ex (schedule and transcript in the library)",
-                       "parallelism": "1 GPU" if world == 1 else (f"one proof sharded x{world}: MSMs by {'point range (window tables 1/' + str(world) + ' per rank)' if head.get('msm_shard') == 'points' else 'column (whole tables on every rank)'}, coset NTTs by polynomial, then an all-to-all of row windows (own row range + halo of every coset block: 1/N of an all-gather of complete columns), sweep by row range per coset block, all-gather of the numerator's row ranges and of the 96-byte partial sums — all inside the library (ncclSend/ncclRecv groups, ncclAllGather)" if shard
+                       "parallelism": "1 GPU" if world == 1 else (f"one proof sharded x{world}: MSMs by {'point range (window tables 1/' + str(world) + ' per rank)' if head.get('msm_shard') == 'points' else 'column (whole tables on every rank)'}, coset NTTs by polynomial, then an all-to-all of row windows (own row range + halo of every coset block: 1/N of an all-gather of complete columns), sweep by row range per coset block, the quotient's pieces / h(X) / SHPLONK on row ranges (numerator blocks to their owners and back, Kate division with carries across ranks), evaluations by query, all-gather of the 96-byte partial sums — all inside the library (ncclSend/ncclRecv groups, ncclAllGather)" if shard
                                                                    else f"{world} independent proofs, one per GPU, no collective")},
             "roofline": {k_: dom[k_] for k_ in ("kernel", "bound", "hbm_frac", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms", "note")},
             "int_roofline": dict(kernel="k_accum_affine", **dom["int_roofline"]),

@@ -90,8 +90,13 @@ int  zkhip_profile_counter(zkhip_ctx* ctx, const char* name, uint64_t* value);
  *   - zkhip_kzg_setup_range / zkhip_srs_load_range give each rank the window tables of its point range only (1/N of the table);
  *   - every MSM entry point over such an SRS is COLLECTIVE: each rank sums its slice, the ncols x 96-byte partial sums are
  *     all-gathered and folded on the device, every rank receives the complete sums;
- *   - zkhip_create_proof_ex additionally distributes the coset NTTs by polynomial and the quotient sweep by row range (all-gather
- *     of the extended columns and of h in place); every rank must call it with identical inputs and obtains the identical proof.
+ *   - zkhip_create_proof_ex additionally distributes the coset NTTs by polynomial, keeps the cosets ROW-SHARDED (an all-to-all of row
+ *     windows — own row range + halo of every coset block — instead of all-gathers of complete columns, whenever the quotient runs on
+ *     cosets and 64 N divides n), sweeps by row range, shards the evaluations by query, and — with MSMs by point range — keeps the
+ *     quotient's pieces, h(X) and SHPLONK's polynomials as row ranges (zkhip_shplonk_open does the same on its own when its SRS handle
+ *     is this rank's point range: linear combinations on the range, divisions by X - r with the carries exchanged as 32-byte range
+ *     totals).  Every rank must call it with identical inputs and obtains the identical proof; zk_proof_out.d_h then holds this
+ *     rank's rows of the pieces only.  Option "row_sharded" = 0 restores the all-gather form.
  * zkhip_comm_init_host is the same with the all-gathers staged through host memory and a caller-supplied function (bring-up on a
  * one-GPU box, launchers without RCCL): fn(user, send, recv, bytes) must fill recv[r * bytes ..] with rank r's send block. */
 typedef int (*zkhip_host_allgather_fn)(void* user, const void* send, void* recv, size_t bytes_per_rank);
