@@ -191,6 +191,11 @@ int coset_plan(zkhip_ctx* ctx, const zkhip_domain* d, const CosetPlan** out);
 uint32_t coset_plan_q(const CosetPlan* p);
 int coeff_to_cosets(zkhip_ctx* ctx, const CosetPlan* p, const void* const* srcs, void* const* dsts, size_t npolys);
 int cosets_to_pieces(zkhip_ctx* ctx, const CosetPlan* p, void* d_vals, void* d_pieces);
+int grand_products_range(zkhip_ctx* ctx, uint32_t k, const uint64_t beta[4], const uint64_t gamma[4], uint32_t blinding_factors,
+                         const void* const* d_values, const void* const* d_sigmas, size_t ncols, uint32_t chunk_len, const void* d_perm_blinding,
+                         void* const* d_perm_z, size_t n_lookups, const void* const* d_compressed_input, const void* const* d_compressed_table,
+                         const void* const* d_permuted_input, const void* const* d_permuted_table, const void* d_lookup_blinding,
+                         void* const* d_lookup_z, size_t row0, size_t count);   // polyops.hip: rows [row0, row0 + count) of every z (collective when count < n)
 int cosets_inverse_blocks(zkhip_ctx* ctx, const CosetPlan* p, void* d_vals, const uint32_t* blocks, size_t nblocks);
 int cosets_combine_range(zkhip_ctx* ctx, const CosetPlan* p, const void* d_vals, void* d_pieces, size_t first_row, size_t count);
 struct KeyCosets { std::vector<const void*> fixed, sigma; const void* l0; const void* l_last; const void* l_active; };

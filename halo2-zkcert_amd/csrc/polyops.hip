@@ -152,7 +152,8 @@ __global__ void __launch_bounds__(PO_BLOCK) k_rp_local(const uint32_t* in_all, s
         if (lo + j < n) store_raw<Fr>(local + (lo + j) * 8, before * pre[j]);
     if (t == PO_BLOCK - 1) store_raw<Fr>(block_tot_all + ((size_t)seg * nblk + blockIdx.x) * 8, el2<Fr>(sc[t]));
 }
-__global__ void __launch_bounds__(1024) k_rp_blocks(const uint32_t* block_tot_all, uint32_t* block_pre_all, uint32_t nblk) {
+// seg_total (optional): the product of ALL of the segment's tiles — a row-range shard's contribution to the ranks above it
+__global__ void __launch_bounds__(1024) k_rp_blocks(const uint32_t* block_tot_all, uint32_t* block_pre_all, uint32_t nblk, uint32_t* seg_total = nullptr) {
     __shared__ fe sc[1024];
     const uint32_t t = threadIdx.x, seg = blockIdx.x;
     const uint32_t* tot = block_tot_all + (size_t)seg * nblk * 8;
@@ -174,6 +175,38 @@ __global__ void __launch_bounds__(1024) k_rp_blocks(const uint32_t* block_tot_al
         if (b < nblk) store_raw<Fr>(pre + (size_t)b * 8, carry * excl);
         carry = carry * el2<Fr>(sc[1023]);
         __syncthreads();
+    }
+    if (seg_total && t == 0) store_raw<Fr>(seg_total + (size_t)seg * 8, carry);
+}
+// Row-range shards (one proof over several GPUs, prover.hip): rank R holds rows [R m, (R + 1) m) of every segment.  Each rank publishes,
+// per segment, the product of its rows' terms (k_rp_blocks' seg_total) and — the rank that holds the chain row — its local unchained
+// prefix there (k_rp_pick); after the all-gather k_rp_shard_first turns them into this rank's multiplier of the whole segment:
+// (product of the lower ranks' totals) x (the chain: product over the earlier chained segments of their FULL prefix at the chain row).
+__global__ void k_rp_pick(const uint32_t* local_all, const uint32_t* block_pre_all, size_t n, uint32_t nblk, uint32_t nseg, size_t row, int have,
+                          uint32_t* out) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nseg) return;
+    el2<Fr> v = one<Fr>();
+    if (have) v = load_raw<Fr>(local_all + ((size_t)s * n + row) * 8) * load_raw<Fr>(block_pre_all + ((size_t)s * nblk + row / PO_TILE) * 8);
+    store_raw<Fr>(out + (size_t)s * 8, v);
+}
+// xchg[rank][0..nseg) = totals, xchg[rank][nseg..2 nseg) = picks
+__global__ void k_rp_shard_first(const uint32_t* xchg, uint32_t nranks, uint32_t rank, uint32_t nseg, uint32_t nchain, uint32_t chain_rank,
+                                 uint32_t* seg_first) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    el2<Fr> f = one<Fr>();
+    for (uint32_t s = 0; s < nseg; ++s) {
+        el2<Fr> below = one<Fr>();
+        for (uint32_t r = 0; r < rank; ++r) below = below * load_raw<Fr>(xchg + ((size_t)r * 2 * nseg + s) * 8);
+        const bool chained = s < nchain && nchain > 1;
+        el2<Fr> first = below;
+        if (chained) first = below * f;
+        store_raw<Fr>(seg_first + (size_t)s * 8, first);
+        if (chained) {   // the segment's full unchained prefix at the chain row
+            el2<Fr> last = load_raw<Fr>(xchg + ((size_t)chain_rank * 2 * nseg + nseg + s) * 8);
+            for (uint32_t r = 0; r < chain_rank; ++r) last = last * load_raw<Fr>(xchg + ((size_t)r * 2 * nseg + s) * 8);
+            f = f * last;
+        }
     }
 }
 // seg_first[seg]: raw R'-form multiplier of the whole segment (chains the permutation sets); may be null (= 1)
@@ -320,9 +353,11 @@ __global__ void __launch_bounds__(PO_BLOCK) k_eval_final(const EvArgs A, const u
 static fe32 abi_to_raw(const uint64_t* p) { return fe_pack(fe_canonical<Fr>(from_abi<Fr>(mem_load(p)).v)); }
 static fe abi_to_fe(const uint64_t* p) { return fe_canonical<Fr>(from_abi<Fr>(mem_load(p)).v); }
 
-// z_out[seg] (ABI) = running products of nseg raw arrays `d_terms` ([seg][n]); chain: multiply segment s by the last kept row of s-1
+// z_out[seg] (ABI) = running products of nseg raw arrays `d_terms` ([seg][n]); chain: multiply segment s by the last kept row of s-1.
+// shard != nullptr: the arrays are rows [row0, row0 + n) of n_total (this rank's range; n_keep and chain_row are GLOBAL rows then).
+struct RpShard { size_t row0, n_total; };
 static int running_products(zkhip_ctx* ctx, const void* d_terms, uint32_t nseg, size_t n, size_t n_keep, uint32_t nchain, size_t chain_row,
-                            const void* d_blinding, void* const* z_out_host) {
+                            const void* d_blinding, void* const* z_out_host, const RpShard* shard = nullptr) {
     const bool chain = nchain > 1;
     hipStream_t st = ctx->stream;
     uint32_t nblk = div_up(n, PO_TILE);
@@ -334,7 +369,26 @@ static int running_products(zkhip_ctx* ctx, const void* d_terms, uint32_t nseg, 
     ZK_TRY(ctx->get_scratch("po_zptr", (size_t)nseg * sizeof(void*), &d_zptr));
     ZK_TRY(ctx->upload(d_zptr, z_out_host, nseg * sizeof(void*)));
     hipLaunchKernelGGL(k_rp_local, dim3(nblk, nseg), dim3(PO_BLOCK), 0, st, (const uint32_t*)d_terms, n, (uint32_t*)d_local, (uint32_t*)d_tot, nblk);
-    hipLaunchKernelGGL(k_rp_blocks, dim3(nseg), dim3(1024), 0, st, (const uint32_t*)d_tot, (uint32_t*)d_pre, nblk);
+    if (shard) {
+        const uint32_t NR = (uint32_t)ctx->comm.nranks, RK = (uint32_t)ctx->comm.rank;
+        void* d_x;
+        ZK_TRY(ctx->get_scratch("po_xchg", (size_t)NR * 2 * nseg * 32, &d_x));
+        uint32_t* mine = (uint32_t*)d_x + (size_t)RK * 2 * nseg * 8;
+        hipLaunchKernelGGL(k_rp_blocks, dim3(nseg), dim3(1024), 0, st, (const uint32_t*)d_tot, (uint32_t*)d_pre, nblk, mine);
+        const uint32_t chain_rank = (uint32_t)(chain_row / n);
+        const bool have = chain_row >= shard->row0 && chain_row < shard->row0 + n;
+        hipLaunchKernelGGL(k_rp_pick, dim3(div_up(nseg, 64)), dim3(64), 0, st, (const uint32_t*)d_local, (const uint32_t*)d_pre, n, nblk, nseg,
+                           have ? chain_row - shard->row0 : (size_t)0, have ? 1 : 0, mine + (size_t)nseg * 8);
+        ZK_LAUNCH_CHECK();
+        ZK_TRY(zk::comm_allgather(ctx, mine, d_x, (size_t)2 * nseg * 32));
+        hipLaunchKernelGGL(k_rp_shard_first, dim3(1), dim3(64), 0, st, (const uint32_t*)d_x, NR, RK, nseg, nchain, chain_rank, (uint32_t*)d_first);
+        const size_t keep_local = n_keep <= shard->row0 ? 0 : std::min(n, n_keep - shard->row0);
+        hipLaunchKernelGGL(k_rp_apply, dim3(div_up(n, PO_BLOCK), nseg), dim3(PO_BLOCK), 0, st, (const uint32_t*)d_local, (const uint32_t*)d_pre,
+                           (const uint32_t*)d_first, n, nblk, (uint32_t* const*)d_zptr, keep_local, (const uint32_t*)d_blinding);
+        ZK_LAUNCH_CHECK();
+        return ZKHIP_OK;
+    }
+    hipLaunchKernelGGL(k_rp_blocks, dim3(nseg), dim3(1024), 0, st, (const uint32_t*)d_tot, (uint32_t*)d_pre, nblk, (uint32_t*)nullptr);
     if (chain) hipLaunchKernelGGL(k_rp_chain, dim3(1), dim3(64), 0, st, (const uint32_t*)d_local, (const uint32_t*)d_pre, n, nblk, nseg, nchain,
                                   chain_row, (uint32_t*)d_first);
     hipLaunchKernelGGL(k_rp_apply, dim3(div_up(n, PO_BLOCK), nseg), dim3(PO_BLOCK), 0, st, (const uint32_t*)d_local, (const uint32_t*)d_pre,
@@ -463,17 +517,22 @@ int zkhip_lookup_product_device(zkhip_ctx* ctx, uint32_t k, const void* d_compre
 
 // permutation::commit and every lookup's commit_product behind ONE batch inversion (each inversion pass has a
 // ~0.3 ms latency floor: 380 dependent products on one wave).  Segments: the permutation sets, then the lookups.
-int zkhip_grand_products_device(zkhip_ctx* ctx, uint32_t k, const uint64_t beta[4], const uint64_t gamma[4], uint32_t blinding_factors,
-                                const void* const* d_values, const void* const* d_sigmas, size_t ncols, uint32_t chunk_len,
-                                const void* d_perm_blinding, void* const* d_perm_z,
-                                size_t n_lookups, const void* const* d_compressed_input, const void* const* d_compressed_table,
-                                const void* const* d_permuted_input, const void* const* d_permuted_table, const void* d_lookup_blinding,
-                                void* const* d_lookup_z) {
+// Rows [row0, row0 + count) only (count < n: a context with a communicator, every rank its own range — the terms are pointwise in the
+// rows, the running products are completed across the ranks by running_products' exchange); z columns are written in that range.
+static int grand_products_rows(zkhip_ctx* ctx, uint32_t k, const uint64_t beta[4], const uint64_t gamma[4], uint32_t blinding_factors,
+                               const void* const* d_values, const void* const* d_sigmas, size_t ncols, uint32_t chunk_len,
+                               const void* d_perm_blinding, void* const* d_perm_z,
+                               size_t n_lookups, const void* const* d_compressed_input, const void* const* d_compressed_table,
+                               const void* const* d_permuted_input, const void* const* d_permuted_table, const void* d_lookup_blinding,
+                               void* const* d_lookup_z, size_t row0, size_t count) {
     if (!ctx || !beta || !gamma) { set_error("zkhip_grand_products_device: null argument"); return ZKHIP_EINVAL; }
     if (ncols && (!d_values || !d_sigmas || !d_perm_z || chunk_len == 0)) { set_error("zkhip_grand_products_device: bad permutation arguments"); return ZKHIP_EINVAL; }
     if (n_lookups && (!d_compressed_input || !d_compressed_table || !d_permuted_input || !d_permuted_table || !d_lookup_z)) { set_error("zkhip_grand_products_device: bad lookup arguments"); return ZKHIP_EINVAL; }
     if (k == 0 || k > 26) { set_error("zkhip_grand_products_device: bad k"); return ZKHIP_EINVAL; }
-    size_t n = (size_t)1 << k;
+    const size_t n_total = (size_t)1 << k;
+    const bool ranged = count != n_total;
+    if (row0 + count > n_total || count == 0) { set_error("zkhip_grand_products_device: rows [%zu, %zu) of %zu", row0, row0 + count, n_total); return ZKHIP_EINVAL; }
+    const size_t n = count, off = row0 * 32;
     const uint32_t bf = blinding_factors;
     if (bf + 1 >= n) { set_error("zkhip_grand_products_device: too many blinding factors"); return ZKHIP_EINVAL; }
     uint32_t nsets = ncols ? (uint32_t)((ncols + chunk_len - 1) / chunk_len) : 0;
@@ -497,14 +556,15 @@ int zkhip_grand_products_device(zkhip_ctx* ctx, uint32_t k, const uint64_t beta[
         mem_store(w_abi, to_abi(w));
         const zkhip_ctx::Twiddle* tw;
         ZK_TRY(ctx->get_twiddles(w_abi, k, &tw));
-        el2<Fr> b = from_abi<Fr>(mem_load(beta)), delta = from_canonical_words<Fr>(FR_DELTA), dj = one<Fr>();
+        // the identity permutation's value at GLOBAL row row0 + i is delta^j w^row0 w^i: the range's offset goes into the per-column constant
+        el2<Fr> b = from_abi<Fr>(mem_load(beta)) * pow_u64<Fr>(w, (uint64_t)row0), delta = from_canonical_words<Fr>(FR_DELTA), dj = one<Fr>();
         std::vector<fe32> dbeta(ncols);
         for (size_t j = 0; j < ncols; ++j) { dbeta[j] = fe_pack(fe_canonical<Fr>((dj * b).v)); dj = dj * delta; }
         void *d_ptrs, *d_dbeta;
         ZK_TRY(ctx->get_scratch("po_perm_ptrs", 2 * ncols * sizeof(void*), &d_ptrs));
         ZK_TRY(ctx->get_scratch("po_perm_dbeta", ncols * 32, &d_dbeta));
         std::vector<const void*> ptrs(2 * ncols);
-        for (size_t j = 0; j < ncols; ++j) { ptrs[j] = d_values[j]; ptrs[ncols + j] = d_sigmas[j]; }
+        for (size_t j = 0; j < ncols; ++j) { ptrs[j] = (const char*)d_values[j] + off; ptrs[ncols + j] = (const char*)d_sigmas[j] + off; }
         ZK_TRY(ctx->upload(d_ptrs, ptrs.data(), 2 * ncols * sizeof(void*)));
         ZK_TRY(ctx->upload(d_dbeta, dbeta.data(), ncols * 32));
         P.values = (const uint32_t* const*)d_ptrs;
@@ -515,18 +575,42 @@ int zkhip_grand_products_device(zkhip_ctx* ctx, uint32_t k, const uint64_t beta[
         P.w_lo = (const uint32_t*)tw->d_lo; P.w_hi = (const uint32_t*)tw->d_hi; P.w_h = tw->h;
         hipLaunchKernelGGL(k_perm_terms<1>, dim3(div_up(n, 256), nsets), dim3(256), 0, st, P, n, (uint32_t*)d_terms);
     }
+    auto at = [&](const void* p_) { return (const uint32_t*)((const char*)p_ + off); };
     for (size_t l = 0; l < n_lookups; ++l)
-        hipLaunchKernelGGL(k_lookup_terms<1>, dim3(div_up(n, 256)), dim3(256), 0, st, (const uint32_t*)d_permuted_input[l],
-                           (const uint32_t*)d_permuted_table[l], bv, gv, n, (uint32_t*)d_terms + ((size_t)nsets + l) * n * 8);
+        hipLaunchKernelGGL(k_lookup_terms<1>, dim3(div_up(n, 256)), dim3(256), 0, st, at(d_permuted_input[l]), at(d_permuted_table[l]), bv, gv, n,
+                           (uint32_t*)d_terms + ((size_t)nsets + l) * n * 8);
     ZK_TRY(launch_batch_invert<0>(ctx, d_terms, (size_t)nseg * n));
     if (nsets) hipLaunchKernelGGL(k_perm_terms<0>, dim3(div_up(n, 256), nsets), dim3(256), 0, st, P, n, (uint32_t*)d_terms);
     for (size_t l = 0; l < n_lookups; ++l)
-        hipLaunchKernelGGL(k_lookup_terms<0>, dim3(div_up(n, 256)), dim3(256), 0, st, (const uint32_t*)d_compressed_input[l],
-                           (const uint32_t*)d_compressed_table[l], bv, gv, n, (uint32_t*)d_terms + ((size_t)nsets + l) * n * 8);
+        hipLaunchKernelGGL(k_lookup_terms<0>, dim3(div_up(n, 256)), dim3(256), 0, st, at(d_compressed_input[l]), at(d_compressed_table[l]), bv, gv, n,
+                           (uint32_t*)d_terms + ((size_t)nsets + l) * n * 8);
     std::vector<void*> zs(nseg);
-    for (uint32_t i = 0; i < nsets; ++i) zs[i] = d_perm_z[i];
-    for (size_t l = 0; l < n_lookups; ++l) zs[nsets + l] = d_lookup_z[l];
-    return running_products(ctx, d_terms, nseg, n, n - bf, nsets, n - bf - 1, d_blind, zs.data());
+    for (uint32_t i = 0; i < nsets; ++i) zs[i] = (char*)d_perm_z[i] + off;
+    for (size_t l = 0; l < n_lookups; ++l) zs[nsets + l] = (char*)d_lookup_z[l] + off;
+    RpShard sh{row0, n_total};
+    return running_products(ctx, d_terms, nseg, n, n_total - bf, nsets, n_total - bf - 1, d_blind, zs.data(), ranged ? &sh : nullptr);
+}
+int zkhip_grand_products_device(zkhip_ctx* ctx, uint32_t k, const uint64_t beta[4], const uint64_t gamma[4], uint32_t blinding_factors,
+                                const void* const* d_values, const void* const* d_sigmas, size_t ncols, uint32_t chunk_len,
+                                const void* d_perm_blinding, void* const* d_perm_z,
+                                size_t n_lookups, const void* const* d_compressed_input, const void* const* d_compressed_table,
+                                const void* const* d_permuted_input, const void* const* d_permuted_table, const void* d_lookup_blinding,
+                                void* const* d_lookup_z) {
+    if (k == 0 || k > 26) { set_error("zkhip_grand_products_device: bad k"); return ZKHIP_EINVAL; }
+    return grand_products_rows(ctx, k, beta, gamma, blinding_factors, d_values, d_sigmas, ncols, chunk_len, d_perm_blinding, d_perm_z, n_lookups,
+                               d_compressed_input, d_compressed_table, d_permuted_input, d_permuted_table, d_lookup_blinding, d_lookup_z, 0,
+                               (size_t)1 << k);
 }
 
 }  // extern "C"
+
+namespace zk {
+int grand_products_range(zkhip_ctx* ctx, uint32_t k, const uint64_t beta[4], const uint64_t gamma[4], uint32_t blinding_factors,
+                         const void* const* d_values, const void* const* d_sigmas, size_t ncols, uint32_t chunk_len, const void* d_perm_blinding,
+                         void* const* d_perm_z, size_t n_lookups, const void* const* d_compressed_input, const void* const* d_compressed_table,
+                         const void* const* d_permuted_input, const void* const* d_permuted_table, const void* d_lookup_blinding,
+                         void* const* d_lookup_z, size_t row0, size_t count) {
+    return grand_products_rows(ctx, k, beta, gamma, blinding_factors, d_values, d_sigmas, ncols, chunk_len, d_perm_blinding, d_perm_z, n_lookups,
+                               d_compressed_input, d_compressed_table, d_permuted_input, d_permuted_table, d_lookup_blinding, d_lookup_z, row0, count);
+}
+}  // namespace zk

@@ -317,6 +317,51 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
         return ZKHIP_OK;
     };
 
+    // ---- owner / row-range layout of the NEW columns (pieces_sharded only).  Column j of a batch has the owner j mod N — the rank that runs
+    // its inverse transform, its coset NTT and its evaluations and therefore holds it COMPLETE — and every rank holds ITS ROW RANGE of the
+    // coefficient form, which is all a point-range commitment and SHPLONK on row ranges read.  exchange_ranges moves row ranges between
+    // the ranks and the owners: dir 0 = every rank's rows of column j to owner(j) (who ends up with the whole column), dir 1 = the owner's
+    // rows [r m, (r + 1) m) of column j to rank r.
+    auto exchange_ranges = [&](int dir, const void* const* src, void* const* dst, size_t count) -> int {
+        const size_t maxcols = (count + NR - 1) / NR, blk = maxcols * m_rows * 32;
+        char *w_send, *w_recv;
+        ZK_TRY(ws("cp_a2a_send", NR * blk, &w_send));
+        ZK_TRY(ws("cp_a2a_recv", NR * blk, &w_recv));
+        const uint32_t full = 0xffffffffu, M = (uint32_t)m_rows;
+        std::vector<uint8_t> is_owner(NR), all1(NR, 1), all0(NR, 0);
+        for (size_t r = 0; r < NR; ++r) is_owner[r] = r < count;
+        const bool i_own = RK < count;
+        std::vector<zk::RowCopy> list;
+        auto rows = [&](const void* base, size_t row) { return (const uint32_t*)((const char*)base + row * 32); };
+        for (size_t r = 0; r < NR; ++r) {
+            if (r == RK) continue;
+            if (dir == 0) { size_t t = 0; for (size_t j = r; j < count; j += NR, ++t) list.push_back(zk::RowCopy{rows(src[j], RK * m_rows), (uint32_t*)(w_send + r * blk + t * m_rows * 32), 0u, 0u, M, full, full}); }
+            else { size_t t = 0; for (size_t j = RK; j < count; j += NR, ++t) list.push_back(zk::RowCopy{rows(src[j], r * m_rows), (uint32_t*)(w_send + r * blk + t * m_rows * 32), 0u, 0u, M, full, full}); }
+        }
+        ZK_TRY(zk::comm_row_copies(ctx, list));
+        if (dir == 0) ZK_TRY(zk::comm_alltoall(ctx, w_send, w_recv, blk, is_owner.data(), i_own ? all1.data() : all0.data()));
+        else ZK_TRY(zk::comm_alltoall(ctx, w_send, w_recv, blk, i_own ? all1.data() : all0.data(), is_owner.data()));
+        list.clear();
+        for (size_t r = 0; r < NR; ++r) {
+            if (r == RK) continue;
+            if (dir == 0) { size_t t = 0; for (size_t j = RK; j < count; j += NR, ++t) list.push_back(zk::RowCopy{(const uint32_t*)(w_recv + r * blk + t * m_rows * 32), (uint32_t*)rows(dst[j], r * m_rows), 0u, 0u, M, full, full}); }
+            else { size_t t = 0; for (size_t j = r; j < count; j += NR, ++t) list.push_back(zk::RowCopy{(const uint32_t*)(w_recv + r * blk + t * m_rows * 32), (uint32_t*)rows(dst[j], RK * m_rows), 0u, 0u, M, full, full}); }
+        }
+        for (size_t j = RK; j < count; j += NR)      // the owner's own rows when the exchange is not in place
+            if (src[j] != dst[j]) list.push_back(zk::RowCopy{rows(src[j], RK * m_rows), (uint32_t*)rows(dst[j], RK * m_rows), 0u, 0u, M, full, full});
+        return zk::comm_row_copies(ctx, list);
+    };
+    // lagrange_to_coeff of a batch by owner: lag[j] complete on every rank (lag_sharded = false) or present as row ranges only (true);
+    // afterwards coeff[j] is complete on owner(j) and every rank holds its row range of it
+    auto owner_intt = [&](const void* const* lag, void* const* coeff, size_t count, bool lag_sharded) -> int {
+        if (lag_sharded) ZK_TRY(exchange_ranges(0, lag, coeff, count));
+        std::vector<const void*> ms;
+        std::vector<void*> md;
+        for (size_t j = RK; j < count; j += NR) { ms.push_back(lag_sharded ? (const void*)coeff[j] : lag[j]); md.push_back(coeff[j]); }
+        if (!ms.empty()) ZK_TRY(zk::lagrange_to_coeff_oop(ctx, pk->domain, ms.data(), md.data(), ms.size()));
+        return exchange_ranges(1, (const void* const*)coeff, coeff, count);
+    };
+
     uint64_t ch[4];
     std::vector<uint64_t> xy;
     std::vector<uint8_t> by;
@@ -377,7 +422,8 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
         if (A + I) {
             std::vector<const void*> lag(A + I);   // out of place: the witness columns stay in Lagrange form, no copy
             for (uint32_t j = 0; j < A + I; ++j) lag[j] = j < A ? d_advice[j] : d_instance[j - A];
-            ZK_TRY(zk::lagrange_to_coeff_oop(ctx, pk->domain, lag.data(), coeff_ptrs.data(), A + I));
+            if (pieces_sharded) ZK_TRY(owner_intt(lag.data(), coeff_ptrs.data(), A + I, false));
+            else ZK_TRY(zk::lagrange_to_coeff_oop(ctx, pk->domain, lag.data(), coeff_ptrs.data(), A + I));
             ZK_TRY(to_extended((const void* const*)coeff_ptrs.data(), ext_ptrs.data(), A + I));
         }
         ov.end();
@@ -438,7 +484,8 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
         {
             std::vector<const void*> lag(2 * L);
             for (uint32_t j = 0; j < 2 * L; ++j) lag[j] = w_perm_l + j * NB;
-            ZK_TRY(zk::lagrange_to_coeff_oop(ctx, pk->domain, lag.data(), perm_c.data(), 2 * L));
+            if (pieces_sharded) ZK_TRY(owner_intt(lag.data(), perm_c.data(), 2 * L, false));
+            else ZK_TRY(zk::lagrange_to_coeff_oop(ctx, pk->domain, lag.data(), perm_c.data(), 2 * L));
         }
         // transcript order (lookup::Argument::commit_permuted per lookup): permuted input, then permuted table, lookup by lookup
         std::vector<const void*> cols(2 * L);
@@ -481,15 +528,25 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
         char* lb = pb + (size_t)Zp * bf * 32;
         if (Zp) ZK_TRY(blind_rows(bl ? bl->perm_z : nullptr, 0, (size_t)Zp * bf, pb, blinding_seed + 340));
         if (L) ZK_TRY(blind_rows(bl ? bl->lookup_z : nullptr, 0, (size_t)L * bf, lb, blinding_seed + 360));
+        if (pieces_sharded)   // this rank's rows of every z; the running products are completed across the ranks (32 bytes per set and rank)
+            ZK_TRY(zk::grand_products_range(ctx, k, beta, gamma, bf, values.data(), pk->sigma_lagrange, P, chunk, pb, z_ptrs.data(), L, ci.data(), ct.data(),
+                                            pi.data(), pt.data(), lb, z_ptrs.data() + Zp, RK * m_rows, m_rows));
+        else
         ZK_TRY(zkhip_grand_products_device(ctx, k, beta, gamma, bf, values.data(), pk->sigma_lagrange, P, chunk, pb, z_ptrs.data(), L, ci.data(),
                                            ct.data(), pi.data(), pt.data(), lb, z_ptrs.data() + Zp));
     }
     if (Zp + L) {
-        ZK_TRY(zkhip_lagrange_to_coeff_device(ctx, pk->domain, z_ptrs.data(), Zp + L));
         // extended forms in the order the sweep wants them: lookups first, then permutation sets (as the Python schedule)
         std::vector<const void*> src(Zp + L);
         for (uint32_t i = 0; i < L; ++i) { src[i] = z_ptrs[Zp + i]; ext_z[i] = w_ext_z + i * EB; }
         for (uint32_t s_ = 0; s_ < Zp; ++s_) { src[L + s_] = z_ptrs[s_]; ext_z[L + s_] = w_ext_z + (L + s_) * EB; }
+        if (pieces_sharded) {   // row ranges -> the owners (batch order = the order of the coset transforms), inverse transform there, ranges back
+            std::vector<void*> zb(Zp + L);
+            for (uint32_t i = 0; i < Zp + L; ++i) zb[i] = const_cast<void*>(src[i]);
+            ZK_TRY(owner_intt(src.data(), zb.data(), Zp + L, true));
+        } else {
+            ZK_TRY(zkhip_lagrange_to_coeff_device(ctx, pk->domain, z_ptrs.data(), Zp + L));
+        }
         std::vector<const void*> cols(z_ptrs.begin(), z_ptrs.end());
         std::vector<const zkhip_srs*> bases(Zp + L, pk->g);
         ov.arm();
@@ -702,11 +759,27 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
             // same count per rank, and put back in query order).  h(X) exists only as row ranges when the pieces are sharded: every rank
             // evaluates ITS rows as a polynomial of degree < m (one more slot per rank) and h(x) = sum_R x^(R m) P_R(x) is put together here.
             const size_t ih = nq - 2;                       // q(o_h, 0) above: the last query but one
-            const size_t per = (nq + NR - 1) / NR + 1;
+            // who evaluates query i: the owner of its polynomial when that polynomial is complete on one rank only (the new columns in the
+            // owner / row-range layout), else round robin
+            std::vector<int> q_rank(nq);
+            std::vector<size_t> n_of(NR, 0);
+            for (size_t i = 0; i < nq; ++i) {
+                int o = -1;
+                const uint32_t pi_ = q_poly[i];
+                if (pieces_sharded) {
+                    if (pi_ < A) o = (int)(pi_ % NR);
+                    else if (pi_ >= o_pz && pi_ < o_lk) o = (int)((L + (pi_ - o_pz)) % NR);
+                    else if (pi_ >= o_lk && pi_ < o_rand) { const uint32_t li = (pi_ - o_lk) / 3, wh = (pi_ - o_lk) % 3; o = (int)((wh == 2 ? L + li : li) % NR); }
+                }
+                q_rank[i] = (pieces_sharded && i == ih) ? -1 : (o >= 0 ? o : (int)(i % NR));
+                if (q_rank[i] >= 0) n_of[q_rank[i]] += 1;
+            }
+            size_t per = 1;
+            for (size_t r = 0; r < NR; ++r) per = std::max(per, n_of[r] + 1);
             std::vector<const void*> mq;
             std::vector<uint64_t> mp;
-            for (size_t i = RK; i < nq; i += NR) {
-                if (pieces_sharded && i == ih) continue;
+            for (size_t i = 0; i < nq; ++i) {
+                if (q_rank[i] != (int)RK) continue;
                 mq.push_back(qp[i]);
                 mp.insert(mp.end(), q_points.begin() + 4 * i, q_points.begin() + 4 * i + 4);
             }
@@ -724,8 +797,8 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
             ZK_TRY(zkhip_memcpy_d2h(ctx, all.data(), w_evg, NR * per * 32));
             std::vector<size_t> taken(NR, 0);
             for (size_t i = 0; i < nq; ++i) {
-                if (pieces_sharded && i == ih) continue;
-                const size_t r = i % NR;
+                if (q_rank[i] < 0) continue;
+                const size_t r = (size_t)q_rank[i];
                 memcpy(q_evals.data() + 4 * i, all.data() + 4 * (r * per + taken[r]++), 32);
             }
             if (pieces_sharded) {
