@@ -25,7 +25,7 @@ def _free_port():
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # small 8 / 10: the coset-quotient path with row-sharded cosets (all-to-all of row windows) whenever 64 N divides n — N = 2 at k = 8, N = 8 at
 # k = 10; N = 3 / 5 and the SHA shape (extended domain) take the all-gather path
-SHAPES = [["small", 8, "poseidon"], ["sha", 9, "poseidon"], ["small", 7, "evm"], ["small", 10, "evm"]]
+SHAPES = [["small", 8, "poseidon"], ["sha", 9, "poseidon"], ["small", 7, "evm"], ["small", 10, "evm"], ["two", 9, "poseidon"]]
 
 
 _REF = {}
@@ -37,7 +37,8 @@ def _single_gpu_proofs(zk):
     ffi, ctx = zk
     out = _REF
     for spec in SHAPES:
-        sh = pv.CircuitShape.small(spec[1]) if spec[0] == "small" else pv.CircuitShape.sha256(spec[1], n_advice=12, n_fixed=5)
+        sh = (pv.CircuitShape.small(spec[1]) if spec[0] == "small" else pv.CircuitShape.sha256(spec[1], n_advice=12, n_fixed=5) if spec[0] == "sha" else
+              pv.CircuitShape(f"two_lookups_k{spec[1]}", spec[1], 2, 2, 1, 4, 6, 0x2100C0 + spec[1]))
         p = pv.Prover(pv.GpuBackend(ctx, ffi), sh, satisfiable=True)
         out[f"{spec[0]}{spec[1]}{spec[2]}"] = p.prove_native(p.witness(1), transcript=spec[2])["proof"].hex()
         p.b.params.free()
@@ -112,7 +113,7 @@ def test_multi_device_rccl_if_available(zk, tmp_path):
             assert o[key]["native"] == hexs
 
 
-@pytest.mark.parametrize("world,mode", [(8, "points"), (8, "columns"), (5, "points")])
+@pytest.mark.parametrize("world,mode", [(8, "points"), (8, "columns"), (5, "points"), (4, "points")])
 def test_eight_and_five_ranks(zk, tmp_path, world, mode):
     """the rank count of the target node (8) and an odd one (5), all sharing device 0 through the host-staged transport: more ranks
     than columns in a batch (padded all-gather rounds, ranks without a column), uneven point ranges, row ranges of 1/8 — every rank's
@@ -125,7 +126,7 @@ def test_eight_and_five_ranks(zk, tmp_path, world, mode):
         os.environ.pop("ZK_SHARD_MODE", None)
     assert len(outs) == world
     for o in outs:
-        if world == 8:      # k = 10: 64 x 8 divides 2^10; by column the windows are still exchanged, the pieces stay complete
+        if world in (4, 8):      # k = 10 (and for N = 4 also k = 8, 9): 64 N divides n; by column the windows are still exchanged, the pieces stay complete
             assert o["modes"]["proofs_row_sharded"] >= 1 and (o["modes"]["proofs_pieces_sharded"] >= 1) == (mode == "points"), o["modes"]
         assert o["shard_mode"] == mode
         for key, hexs in ref.items():
