@@ -366,7 +366,7 @@ def main():
                                     "int_roofline": {"bound": "v_mad_u64_u32 issue", "achieved": round(int_ach, 2), "peak": MAD_PEAK_T, "unit": "Tmad/s",
                                                      "frac": round(int_ach / MAD_PEAK_T, 4), "window_bits": c_bits, "windows": windows,
                                                      "digit_pairs_per_step": round(real_pairs), "dense_digit_pairs_per_step": round(dense_pairs)},
-                                    "note": "integer-multiply bound (VALU busy 0.92-1.03 in profiles/r02_*_valu_*.csv), window tables trade HBM bytes for doublings: see DESIGN.md"}
+                                    "note": "VALU-issue (integer multiply) bound: valu_busy 0.89-0.99 in profiles/r03_*_valu_*.csv; the window tables trade HBM bytes for doublings (counted traffic 6-18x the algorithmic bytes): see DESIGN.md 5"}
         # NTT: 64 B per element per transform (one read + one write), whatever the number of passes.  Isolated batch of 8 coset NTTs
         # (coeff_to_extended: n -> extended_n) — the shape the proof issues
         ntt_ms = kernels["ntt_strided"]["ms_per_step"] + kernels["ntt_final"]["ms_per_step"]
@@ -384,7 +384,7 @@ def main():
                            "in_proof_ms_per_step": round(ntt_ms, 3),
                            "transforms_per_step": counts["intt_n"] + counts["ntt_ext"] * (coset_q or 1) + counts["intt_ext"] * (coset_q or 1),
                            "note": "algorithmic = 64 B per element per transform; a transform of 2^m elements is ceil(m / 9) launches; VALU-issue bound "
-                                   "(valu_busy 0.80-0.86 at k >= 19, profiles/r02_*_valu_*.csv), not HBM bound; in-proof spans overlap the MSM phases"}
+                                   "(valu_busy 0.78-0.79 at k >= 19 with two waves per SIMD, profiles/r03_*_valu_*.csv), not HBM bound; in-proof spans overlap the MSM phases"}
         # sweep: 32 B x (distinct (column, rotation) reads + 1 write) per extended row
         sw = kernels["sweep"]
         if sw["ms_per_step"] > 0 and not shard:
