@@ -754,7 +754,7 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
         char* ev_out = w_evals;
         const bool ev_pinned = nq * 32 + 32768 + 64 <= zkhip_ctx::PINNED_BYTES;
         if (ev_pinned) ev_out = (char*)ctx->h_pinned + 32768;
-        if (dist && ctx->opt.row_sharded != 0 && nq >= 2 * NR) {
+        if (dist && ((ctx->opt.row_sharded != 0 && nq >= 2 * NR) || pieces_sharded)) {   // (with sharded pieces h(X) exists as row ranges only: always this form)
             // the evaluations are independent: rank r evaluates queries r, r + NR, ... (the 32-byte results are all-gathered, padded to the
             // same count per rank, and put back in query order).  h(X) exists only as row ranges when the pieces are sharded: every rank
             // evaluates ITS rows as a polynomial of degree < m (one more slot per rank) and h(x) = sum_R x^(R m) P_R(x) is put together here.
