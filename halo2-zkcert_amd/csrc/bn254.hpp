@@ -363,6 +363,31 @@ template <class P, int A, int B, int C, int D>
 ZK_HD __forceinline__ el<P, mul2_bound(A, B, C, D)> muladd2(const el<P, A>& a, const el<P, B>& b, const el<P, C>& c, const el<P, D>& d) {
     return el<P, mul2_bound(A, B, C, D)>(fe_mul2_raw<P>(a.v, b.v, c.v, d.v));
 }
+// A difference / negation that is ONLY a multiplicand of the two-product accumulation needs no carry pass: ell<P, B> is a value
+// < (B / 16) p whose limbs are NOT normalised (each < 1.5 * 2^30: a normalised limb plus a borrow-spread constant).  Columns of
+// fe_mul2_raw with a normalised x lazy and a lazy x normalised product: 9 (1.5 * 2^59 + 2^59) + 9 * 2^58 = 27 * 2^59 < 2^64.
+// Not accepted by anything else (a squaring's or a subtraction's operand must be normalised).
+template <class P, int B>
+struct ell { fe v; };
+template <class P, int A, int B>
+ZK_HD __forceinline__ ell<P, A + (ceil_p(B) + 1) * U> sub_lazy(const el<P, A>& a, const el<P, B>& b) {
+    ell<P, A + (ceil_p(B) + 1) * U> r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.v.l[i] = a.v.l[i] + kp_spread<P>(ceil_p(B) + 1, i) - b.v.l[i];
+    return r;
+}
+template <class P, int B>
+ZK_HD __forceinline__ ell<P, (ceil_p(B) + 1) * U> neg_lazy(const el<P, B>& b) {
+    ell<P, (ceil_p(B) + 1) * U> r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.v.l[i] = kp_spread<P>(ceil_p(B) + 1, i) - b.v.l[i];
+    return r;
+}
+template <class P, int A, int B, int C, int D>
+ZK_HD __forceinline__ el<P, mul2_bound(A, B, C, D)> muladd2(const el<P, A>& a, const ell<P, B>& b, const ell<P, C>& c, const el<P, D>& d) {
+    static_assert(mul2_bound(A, B, C, D) <= BMAX, "lazy bound out of range");
+    return el<P, mul2_bound(A, B, C, D)>(fe_mul2_raw<P>(a.v, b.v, c.v, d.v));
+}
 template <class P, int A>
 ZK_HD __forceinline__ el<P, mul_bound(A, A)> sqr(const el<P, A>& a) {
     return el<P, mul_bound(A, A)>(fe_sqr_raw<P>(a.v));
@@ -401,6 +426,16 @@ ZK_HD __forceinline__ el<P, K * A> mul_small(const el<P, A>& a) {
     for (int i = 0; i < 9; ++i) r.l[i] = a.v.l[i] * (uint32_t)K;
     fe_normalize(r);
     return el<P, K * A>(r);
+}
+// a + K b with ONE carry pass (K <= 4: limbs stay below (1 + K) 2^29 < 2^32)
+template <int K, class P, int A, int B>
+ZK_HD __forceinline__ el<P, A + K * B> add_mul_small(const el<P, A>& a, const el<P, B>& b) {
+    static_assert(K >= 1 && K <= 4, "small multiple");
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = a.v.l[i] + b.v.l[i] * (uint32_t)K;
+    fe_normalize(r);
+    return el<P, A + K * B>(r);
 }
 // a == 0 mod p?  If a = k p with k < A/16 then k = a_0 * p_0^-1 mod 2^29: three instructions reject every
 // other value; the exact test runs only when the filter fires (probability ~ k_max / 2^29 per lane).
@@ -838,8 +873,8 @@ ZK_HD inline g1x g1x_add_mixed(const g1x& p, const g1a& q) {
     auto ppp = pp_ * pp;
     auto q_ = p.x * pp;
     g1x o;
-    auto x3 = sqr(r) - (ppp + mul_small<2>(q_));
-    o.y = muladd2(r, q_ - x3, neg(p.y), ppp);   // r (Q - X3) - Y1 PPP: two products, one reduction
+    auto x3 = sqr(r) - add_mul_small<2>(ppp, q_);
+    o.y = muladd2(r, sub_lazy(q_, x3), neg_lazy(p.y), ppp);   // r (Q - X3) - Y1 PPP: two products, one reduction, no carry pass on the two differences
     o.zz = p.zz * pp;
     o.zzz = p.zzz * ppp;
     o.x = x3;
@@ -866,8 +901,8 @@ ZK_HD inline g1x g1x_add(const g1x& p, const g1x& q) {
     auto ppp = pp_ * pp;
     auto q_ = u1 * pp;
     g1x o;
-    auto x3 = sqr(r) - (ppp + mul_small<2>(q_));
-    o.y = muladd2(r, q_ - x3, neg(s1), ppp);
+    auto x3 = sqr(r) - add_mul_small<2>(ppp, q_);
+    o.y = muladd2(r, sub_lazy(q_, x3), neg_lazy(s1), ppp);
     o.zz = p.zz * q.zz * pp;
     o.zzz = p.zzz * q.zzz * ppp;
     o.x = x3;
