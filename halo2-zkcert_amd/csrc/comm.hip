@@ -44,6 +44,9 @@ struct Rccl {
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 Rccl g_rccl;
+// verdict of zkhip_comm_init's all-to-all self-check per context: 1 passed on every rank, -1 failed somewhere (kept here, not in the
+// context struct: common.hpp is part of the kernel-source hash that keys the committed counter profiles)
+std::map<const zkhip_ctx*, int> g_a2a_checked;
 int load_rccl() {
     if (g_rccl.lib) return ZKHIP_OK;
     const char* names[] = {"librccl.so", "librccl.so.1"};
@@ -271,6 +274,45 @@ int zkhip_comm_init(zkhip_ctx* ctx, const uint8_t id[128], int rank, int nranks)
     }
     ctx->comm.rank = rank;
     ctx->comm.nranks = nranks;
+    // The grouped send / recv exchange (comm_alltoall) is what the row-sharded proof rides on, and no multi-GPU box was available to the
+    // build: prove it on THIS communicator before any proof depends on it.  Every rank sends peer r the word (rank << 16 | r) in a
+    // 64-byte block and checks what arrives; the verdicts are all-gathered (the primitive the round-2 path has always used) so that
+    // all ranks take the same decision: any failure switches this context to the all-gather exchange (row_sharded = 0), loudly.
+    if (nranks > 1) {
+        int ok = 1;
+        void* d_buf = nullptr;
+        const size_t blk = 64, N = (size_t)nranks;
+        if (hipMalloc(&d_buf, (2 * N + N) * blk) != hipSuccess) { (void)hipGetLastError(); ok = 0; }
+        std::vector<uint32_t> h((2 * N + N) * blk / 4, 0);
+        if (ok) {
+            for (size_t r = 0; r < N; ++r) for (size_t w = 0; w < blk / 4; ++w) h[r * blk / 4 + w] = ((uint32_t)rank << 16) | (uint32_t)r;
+            ok = hipMemcpy(d_buf, h.data(), (2 * N + N) * blk, hipMemcpyHostToDevice) == hipSuccess;
+        }
+        if (ok && (!g_rccl.Send || !g_rccl.Recv || !g_rccl.GroupStart || !g_rccl.GroupEnd)) ok = 0;
+        if (ok && comm_alltoall(ctx, d_buf, (char*)d_buf + N * blk, blk) != ZKHIP_OK) ok = 0;
+        if (ok) ok = hipStreamSynchronize(ctx->stream) == hipSuccess && hipMemcpy(h.data(), d_buf, (2 * N + N) * blk, hipMemcpyDeviceToHost) == hipSuccess;
+        for (size_t r = 0; ok && r < N; ++r)
+            if ((int)r != rank && h[(N + r) * blk / 4] != (((uint32_t)r << 16) | (uint32_t)rank)) ok = 0;
+        // agree: verdict of rank r at word r of the third region
+        uint32_t mine = (uint32_t)ok;
+        int all_ok = ok;
+        if (d_buf && hipMemcpy((char*)d_buf + (2 * N + (size_t)rank) * blk, &mine, 4, hipMemcpyHostToDevice) == hipSuccess &&
+            comm_allgather(ctx, (char*)d_buf + (2 * N + (size_t)rank) * blk, (char*)d_buf + 2 * N * blk, blk) == ZKHIP_OK &&
+            hipStreamSynchronize(ctx->stream) == hipSuccess && hipMemcpy(h.data(), (char*)d_buf + 2 * N * blk, N * blk, hipMemcpyDeviceToHost) == hipSuccess) {
+            for (size_t r = 0; r < N; ++r) all_ok = all_ok && h[r * blk / 4] == 1u;
+        } else {
+            all_ok = 0;   // (if even the all-gather fails the proofs will report it; the exchange mode no longer matters)
+        }
+        if (d_buf) (void)hipFree(d_buf);
+        ctx->comm.bytes_gathered = 0;
+        ctx->comm.collectives = 0;
+        if (!all_ok) {
+            ctx->opt.row_sharded = 0;
+            fprintf(stderr, "zkhip_comm_init: the all-to-all self-check failed on some rank (this rank: %s): falling back to the all-gather exchange (row_sharded = 0)\n",
+                    ok ? "ok" : "FAILED");
+        }
+        g_a2a_checked[ctx] = all_ok ? 1 : -1;
+    }
     return ZKHIP_OK;
 }
 
@@ -302,6 +344,7 @@ int zkhip_comm_destroy(zkhip_ctx* ctx) {
     if (cm.ev_out) (void)hipEventDestroy(cm.ev_out);
     if (cm.stage) (void)hipHostFree(cm.stage);
     cm = zkhip_comm();
+    g_a2a_checked.erase(ctx);
     return ZKHIP_OK;
 }
 
@@ -324,7 +367,9 @@ int zkhip_comm_info(const zkhip_ctx* ctx, int* rank, int* nranks, uint64_t* byte
 int zkhip_comm_describe(const zkhip_ctx* ctx, char* transport, size_t cap, int* transport_ranks, uint64_t* collectives) {
     if (!ctx) { set_error("null ctx"); return ZKHIP_EINVAL; }
     const zkhip_comm& cm = ctx->comm;
-    const char* t = cm.nccl ? "rccl" : (cm.host_allgather ? "host" : "none");
+    const auto chk = g_a2a_checked.find(ctx);
+    const char* t = cm.nccl ? (chk != g_a2a_checked.end() && chk->second < 0 ? "rccl (all-to-all self-check failed: all-gather exchange)" : "rccl")
+                            : (cm.host_allgather ? "host" : "none");
     if (transport && cap) { strncpy(transport, t, cap - 1); transport[cap - 1] = 0; }
     if (transport_ranks) {
         int cnt = cm.nccl ? -1 : cm.nranks;

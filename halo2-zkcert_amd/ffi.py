@@ -270,9 +270,9 @@ class Context:
     def comm_describe(self):
         """-> dict(transport, nranks, transport_ranks, bytes_gathered, collectives): what the library's communicator itself reports
         (transport_ranks is ncclCommCount for RCCL: evidence that RCCL joined that many processes)"""
-        buf = C.create_string_buffer(16)
+        buf = C.create_string_buffer(96)
         tr, co, by, rk, nr = C.c_int(), C.c_uint64(), C.c_uint64(), C.c_int(), C.c_int()
-        _check(lib().zkhip_comm_describe(self.h, buf, C.c_size_t(16), C.byref(tr), C.byref(co)))
+        _check(lib().zkhip_comm_describe(self.h, buf, C.c_size_t(96), C.byref(tr), C.byref(co)))
         _check(lib().zkhip_comm_info(self.h, C.byref(rk), C.byref(nr), C.byref(by)))
         return dict(transport=buf.value.decode(), rank=rk.value, nranks=nr.value, transport_ranks=tr.value, bytes_gathered=by.value,
                     collectives=co.value)
