@@ -88,3 +88,15 @@ def test_bench_chain_four_ranks_on_one_device():
               os.path.join(ROOT, "bench.py"), "--gpus", "4", "--chain", "--steps", "1", "--warmup", "1", "--agg-k", "18"], env=env)
     assert d["n_gpus"] == 4 and d["proofs_per_step"] == 5 and "chain" in d["config"]["workload"] and d["value"] > 0
     assert d["comm"]["nranks"] == 4 and d["comm"]["bytes_gathered_per_step"] > 0 and len(d["proof_bytes"]) == 2
+
+
+def test_full_size_chain_on_one_gpu():
+    """BASELINE configs[4] at FULL size on one GPU (`--chain`): 2 x RSA k = 17 + 2 x SHA-shaped k = 19 leaf proofs (Poseidon), then the k = 22
+    aggregation-shaped proof (Keccak) — five proofs per step, each of the size its single-configuration run produces, in about the sum
+    of their times."""
+    d = _run([os.path.join(ROOT, "bench.py"), "--chain", "--steps", "2", "--warmup", "1"])
+    assert d["n_gpus"] == 1 and d["proofs_per_step"] == 5 and "chain" in d["config"]["workload"] and d["comm"] is None
+    sizes = d["proof_bytes"]
+    assert len(sizes) == 5 and sizes[0] == sizes[2] and sizes[1] == sizes[3] and all(s > 1000 for s in sizes)
+    assert sizes[4] > sizes[0]                      # 64-byte points under the EVM transcript
+    assert 0.12 < d["value"] < 0.5                  # 2 x 7 ms + 2 x 32 ms + 0.12 s
