@@ -236,7 +236,11 @@ class GpuBackend:
         # latency-bound MSM phases then get their CUs first and the NTTs fill what is idle
         if self.torch.cuda.current_stream(ctx.device) == self.torch.cuda.default_stream(ctx.device):
             self.torch.cuda.set_stream(self.torch.cuda.Stream(device=ctx.device, priority=-1))
-            ctx.use_torch_stream()
+        # ALWAYS bind the context to torch's current stream: the witness generators and the Python schedule mix torch ops (gathers,
+        # concatenations, the caching allocator's stream-ordered reuse) with library kernels, and a second backend created in the same
+        # process (another context on the same device) used to keep its context on the context's own stream — found by tools/stress_dist.py
+        # as a wrong witness column in the first proof of a process with two contexts
+        ctx.use_torch_stream()
         self.main = self.torch.cuda.current_stream(ctx.device)
         self.side = self.torch.cuda.Stream(device=ctx.device)
 
