@@ -285,8 +285,10 @@ def main():
         g0 = ctx.comm_bytes_gathered()
         barrier()
         t0 = time.perf_counter()
+        native_s = 0.0
         for _ in range(steps):
             trace = prove()
+            native_s += trace.get("native_call_s", 0.0)
         barrier()
         dt = time.perf_counter() - t0
         gathered = (ctx.comm_bytes_gathered() - g0) // max(steps, 1)
@@ -411,7 +413,8 @@ def main():
                "perm_columns": len(shape.perm_columns), "degree": shape.degree, "transcript": kind, "proof_bytes": len(trace.get("proof", b"")),
                "setup_s": round(setup_s, 3), "resident_bytes": int(resident), "rooflines": roof, "kernels_ms_per_step": kernels,
                "traffic_source": traffic_file, "with_h2d": h2d, "msm_shard": shard_mode,
-               "first_proof_s": round(setup_s + first_s, 3), "comm": comm_fields(gathered, shard_mode)}
+               "first_proof_s": round(setup_s + first_s, 3), "comm": comm_fields(gathered, shard_mode),
+               "native_call_ms_per_step": round(native_s * 1000.0 / steps, 3) if native_s else None}   # zkhip_create_proof_ex alone; ms_per_step also holds the ctypes wrapper around it
         prover.release()          # the context's per-key caches (coset-layout key columns, sorted lookup table)
         backend.params.free()
         del prover, wit, trace, backend

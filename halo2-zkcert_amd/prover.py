@@ -36,6 +36,8 @@ import contextlib
 import hashlib
 import os
 
+import time
+
 import numpy as np
 
 from . import evaluator as ev
@@ -1098,7 +1100,9 @@ class Prover:
             keep.append(bl)
             inp.blinding = C.cast(C.pointer(bl), C.c_void_p)
         ctx.use_torch_stream()
+        t_call = time.perf_counter()
         rc = ffi.lib().zkhip_create_proof_ex(ctx.h, C.byref(pk), C.byref(inp), t_ref, C.byref(out))
+        trace["native_call_s"] = time.perf_counter() - t_call      # the library call alone (the rest of this function is Python bookkeeping)
         if rc != 0 and auto_extended and b"extended cosets are missing" in ffi.lib().zkhip_last_error():
             # the context runs the extended-domain path (coset_quotient = 0): hand over the key's extended forms (nothing has entered the
             # transcript yet: the library checks its inputs first)
