@@ -51,6 +51,11 @@ int load_rccl() {
     if (g_rccl.lib) return ZKHIP_OK;
     const char* names[] = {"librccl.so", "librccl.so.1"};
     void* h = nullptr;
+    // ZKHIP_RCCL_LIB: another library with the same entry points (tests/fake_rccl: N ranks on one GPU through the RCCL transport's code path)
+    if (const char* over = getenv("ZKHIP_RCCL_LIB")) {
+        h = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+        if (!h) { set_error("zkhip_comm: ZKHIP_RCCL_LIB=%s cannot be loaded (%s)", over, dlerror()); return ZKHIP_EINVAL; }
+    }
     for (const char* nm : names) if (!h) h = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);   // the copy the process already uses (torch's)
     for (const char* nm : names) if (!h) h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
     if (!h) { set_error("zkhip_comm: librccl not found (%s)", dlerror()); return ZKHIP_EINVAL; }

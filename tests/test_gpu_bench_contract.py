@@ -100,3 +100,23 @@ def test_full_size_chain_on_one_gpu():
     assert len(sizes) == 5 and sizes[0] == sizes[2] and sizes[1] == sizes[3] and all(s > 1000 for s in sizes)
     assert sizes[4] > sizes[0]                      # 64-byte points under the EVM transcript
     assert 0.12 < d["value"] < 0.5                  # 2 x 7 ms + 2 x 32 ms + 0.12 s
+
+
+def test_bench_two_ranks_through_the_rccl_transport_path():
+    """`python bench.py --gpus 2` with the library's RCCL transport (comm.hip's RCCL branch: ncclCommInitRank, the all-to-all self-check,
+    event-fenced all-gathers, grouped send / recv) driven through tests/fake_rccl on one device: the line reports transport "rccl", the rank
+    count the (stand-in) library itself reports, and the row-sharded exchange modes."""
+    import subprocess as sp
+
+    src = os.path.join(ROOT, "tests", "fake_rccl", "fake_rccl.cpp")
+    lib = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
+    if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
+        sp.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-shared", "-fPIC", "-O1", src, "-o", lib])
+    env = dict(os.environ, ZKHIP_BENCH_ONE_DEVICE="1", ZKHIP_BENCH_DIST_BACKEND="gloo", ZKHIP_COMM_TRANSPORT="rccl", ZKHIP_RCCL_LIB=lib,
+               ZKFAKE_RCCL_SLOT_MB="64")
+    env.pop("WORLD_SIZE", None)
+    d = _run([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--agg-k", "18", "--shard", "points"], env=env)
+    cm = d["comm"]
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and cm["transport"] == "rccl" and cm["nranks"] == 2 and cm["transport_ranks"] == 2
+    assert cm["shard_mode"] == "points" and cm["bytes_gathered_per_step"] > 0
+    assert cm["exchange_modes"]["proofs_row_sharded"] >= 3 and cm["exchange_modes"]["proofs_pieces_sharded"] >= 3

@@ -214,3 +214,32 @@ def test_sha_k19_proof_over_two_ranks_by_column(zk, tmp_path):
     window tables on both ranks == the single-GPU proof bytes"""
     spec = ["shafull", 19, "poseidon"]
     _single_then_sharded(zk, tmp_path, spec, lambda: pv.CircuitShape.sha256(19, n_advice=32, n_fixed=12), "columns", 1800)
+
+
+# ---- the RCCL transport's own code path with more than one rank (a one-GPU box cannot run it against the real library: RCCL refuses two
+# ranks per device).  tests/fake_rccl is a stand-in with the same entry points that moves the bytes through shared memory and CHECKS that
+# every grouped send meets a receive of the same size on the peer (where the real library would hang).
+def _fake_rccl():
+    src = os.path.join(ROOT, "tests", "fake_rccl", "fake_rccl.cpp")
+    lib = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
+    if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
+        subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-shared", "-fPIC", "-O1", src, "-o", lib])
+    return lib
+
+
+@pytest.mark.parametrize("world,mode", [(2, "points"), (4, "points"), (8, "points"), (4, "columns")])
+def test_rccl_transport_path_with_emulated_rccl(zk, tmp_path, world, mode):
+    """zkhip_comm_init (dlopen, ncclCommInitRank, the all-to-all self-check), the event-fenced ncclAllGather and the grouped ncclSend / ncclRecv
+    exchanges with their silent pairs — comm.hip's RCCL branch — under 2, 4 and 8 ranks: same proof bytes as the single GPU, the
+    communicator reports transport "rccl" with ncclCommCount = N, the self-check passed (the row-sharded modes were taken), and no send
+    was left without its receive (the stand-in turns that into an error)."""
+    ref = _single_gpu_proofs(zk)
+    outs = _run_workers(tmp_path, world, True, 0, extra_env={"ZKHIP_RCCL_LIB": _fake_rccl(), "ZKHIP_COMM_TRANSPORT": "rccl", "ZK_SHARD_MODE": mode,
+                                                            "ZKFAKE_RCCL_SLOT_MB": "8"})
+    for o in outs:
+        assert o["transport"] == "rccl" and o["comm"]["transport"] == "rccl" and o["comm"]["transport_ranks"] == world and o["comm"]["nranks"] == world
+        assert o["bytes_gathered"] > 0 and o["modes"]["proofs_row_sharded"] >= 1, o["modes"]
+        if mode == "points":
+            assert o["modes"]["proofs_pieces_sharded"] >= 1 and o["modes"]["shplonk_row_sharded"] >= 1, o["modes"]
+        for key, hexs in ref.items():
+            assert o[key]["native"] == hexs and o[key]["python"] == hexs, key
