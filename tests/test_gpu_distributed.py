@@ -168,7 +168,7 @@ def test_column_round_robin_sharding(zk, tmp_path):
 # ---- the BASELINE configurations at FULL size over two ranks ("configs not exercised on the hardware they name" — the
 # sharded path had only ever run at k <= 9).  One device, host-staged transport: c = 17 shard tables of 2^21 points, 384 MiB gathers,
 # padded rounds at real size.  The single-GPU reference proof is made first and its memory given back before the ranks start.
-def _single_then_sharded(zk, tmp_path, spec, make_shape, mode, timeout):
+def _single_then_sharded(zk, tmp_path, spec, make_shape, mode, timeout, extra_env=None):
     import torch
 
     ffi, ctx = zk
@@ -180,10 +180,10 @@ def _single_then_sharded(zk, tmp_path, spec, make_shape, mode, timeout):
     del p, w
     ctx.trim()
     torch.cuda.empty_cache()
-    outs = _run_workers(tmp_path, 2, True, 0, shapes=[spec], extra_env={"ZK_SHARD_MODE": mode, "ZK_NATIVE_ONLY": "1"}, timeout=timeout)
+    outs = _run_workers(tmp_path, 2, True, 0, shapes=[spec], extra_env={"ZK_SHARD_MODE": mode, "ZK_NATIVE_ONLY": "1", **(extra_env or {})}, timeout=timeout)
     key = f"{spec[0]}{spec[1]}{spec[2]}"
     for o in outs:
-        assert o["shard_mode"] == mode and o["comm"]["nranks"] == 2 and o["comm"]["transport"] == "host"
+        assert o["shard_mode"] == mode and o["comm"]["nranks"] == 2 and o["comm"]["transport"] == (extra_env or {}).get("ZKHIP_COMM_TRANSPORT", "host")
         assert o[key]["native"] == ref.hex(), f"{key}: the sharded proof differs from the single-GPU proof"
     return ref, outs
 
@@ -243,3 +243,13 @@ def test_rccl_transport_path_with_emulated_rccl(zk, tmp_path, world, mode):
             assert o["modes"]["proofs_pieces_sharded"] >= 1 and o["modes"]["shplonk_row_sharded"] >= 1, o["modes"]
         for key, hexs in ref.items():
             assert o[key]["native"] == hexs and o[key]["python"] == hexs, key
+
+
+def test_agg_k22_proof_over_two_ranks_through_the_rccl_branch(zk, tmp_path):
+    """the full-size k = 22 proof over 2 ranks once more, through comm.hip's RCCL branch against the checking stand-in (600 MB all-to-all
+    blocks through 2.6 GB of shared memory): the single-GPU proof's bytes, every send paired with its receive"""
+    spec = ["agg", 22, "evm"]
+    _, outs = _single_then_sharded(zk, tmp_path, spec, lambda: pv.CircuitShape.agg(22, 3, 1), "points", 2400,
+                                   extra_env={"ZKHIP_RCCL_LIB": _fake_rccl(), "ZKHIP_COMM_TRANSPORT": "rccl", "ZKFAKE_RCCL_SLOT_MB": "700"})
+    for o in outs:
+        assert o["comm"]["transport_ranks"] == 2 and o["modes"] == {"proofs_row_sharded": 1, "proofs_pieces_sharded": 1, "shplonk_row_sharded": 1}
