@@ -168,7 +168,7 @@ def test_column_round_robin_sharding(zk, tmp_path):
 # ---- the BASELINE configurations at FULL size over two ranks ("configs not exercised on the hardware they name" — the
 # sharded path had only ever run at k <= 9).  One device, host-staged transport: c = 17 shard tables of 2^21 points, 384 MiB gathers,
 # padded rounds at real size.  The single-GPU reference proof is made first and its memory given back before the ranks start.
-def _single_then_sharded(zk, tmp_path, spec, make_shape, mode, timeout, extra_env=None):
+def _single_then_sharded(zk, tmp_path, spec, make_shape, mode, timeout, extra_env=None, world=2):
     import torch
 
     ffi, ctx = zk
@@ -180,10 +180,10 @@ def _single_then_sharded(zk, tmp_path, spec, make_shape, mode, timeout, extra_en
     del p, w
     ctx.trim()
     torch.cuda.empty_cache()
-    outs = _run_workers(tmp_path, 2, True, 0, shapes=[spec], extra_env={"ZK_SHARD_MODE": mode, "ZK_NATIVE_ONLY": "1", **(extra_env or {})}, timeout=timeout)
+    outs = _run_workers(tmp_path, world, True, 0, shapes=[spec], extra_env={"ZK_SHARD_MODE": mode, "ZK_NATIVE_ONLY": "1", **(extra_env or {})}, timeout=timeout)
     key = f"{spec[0]}{spec[1]}{spec[2]}"
     for o in outs:
-        assert o["shard_mode"] == mode and o["comm"]["nranks"] == 2 and o["comm"]["transport"] == (extra_env or {}).get("ZKHIP_COMM_TRANSPORT", "host")
+        assert o["shard_mode"] == mode and o["comm"]["nranks"] == world and o["comm"]["transport"] == (extra_env or {}).get("ZKHIP_COMM_TRANSPORT", "host")
         assert o[key]["native"] == ref.hex(), f"{key}: the sharded proof differs from the single-GPU proof"
     return ref, outs
 
@@ -253,3 +253,12 @@ def test_agg_k22_proof_over_two_ranks_through_the_rccl_branch(zk, tmp_path):
                                    extra_env={"ZKHIP_RCCL_LIB": _fake_rccl(), "ZKHIP_COMM_TRANSPORT": "rccl", "ZKFAKE_RCCL_SLOT_MB": "700"})
     for o in outs:
         assert o["comm"]["transport_ranks"] == 2 and o["modes"] == {"proofs_row_sharded": 1, "proofs_pieces_sharded": 1, "shplonk_row_sharded": 1}
+
+
+def test_agg_k20_proof_over_eight_ranks(zk, tmp_path):
+    """the target node's rank count at a size where it matters: the aggregation-shaped k = 20 proof over EIGHT ranks by point range (c = 17-sized
+    shard tables of 2^17 points, 4 MiB row windows; eight k = 22 ranks do not fit one device) == the single-GPU bytes, every exchange mode taken"""
+    spec = ["agg", 20, "evm"]
+    _, outs = _single_then_sharded(zk, tmp_path, spec, lambda: pv.CircuitShape.agg(20, 3, 1), "points", 1200, world=8)
+    for o in outs:
+        assert o["modes"] == {"proofs_row_sharded": 1, "proofs_pieces_sharded": 1, "shplonk_row_sharded": 1}
