@@ -49,7 +49,7 @@ struct Scratch {
 struct zkhip_options {
     int msm_c = 0, msm_seg = 0, msm_tailparts = 0, msm_ch = 0, msm_widetail = -1, msm_adaptive_l = 1, msm_debug = 0;
     int sort_hb = 0, sort_tile = 0, sort_one_atomic = 1, sort_copies = 0, sort_wide = -1;   // sort_wide: low-pass block shape (-1: 1024 threads x 8 pairs for 8192-pair tiles)
-    int ntt_smax = 0, ntt_r8 = 1, ntt_group = 0;
+    int ntt_smax = 0, ntt_r8 = 4, ntt_group = 0;   // ntt_r8: 0 stage-per-barrier, 1 8 per thread, 2 / 3 4 per thread on 2048 / 1024 tiles, 4 auto
     int permute_rank_sort = 1, eval_byval = 1, late_overlap = -1;
     int host_timing = 0;   // zkhip_create_proof prints its host-side phase times to stderr
     int row_sharded = 1;      // multi-rank proofs on the coset path: all-to-all of row windows (1) / all-gather of complete columns (0)

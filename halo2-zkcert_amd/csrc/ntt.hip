@@ -252,13 +252,16 @@ __global__ void __launch_bounds__(256) k_ntt_final(const uint32_t* const* srcs, 
 // slot field, land in 32 different banks (an element is 9 dwords, 9 is odd).
 struct Swz { uint32_t sh, mk, ts; };
 __device__ __forceinline__ uint32_t swz(uint32_t L, const Swz& z) { return L ^ (((L >> z.sh) & z.mk) << z.ts); }
-// thread index -> logical index with a zero 3-bit slot field at bit p
-__device__ __forceinline__ uint32_t place(uint32_t t, uint32_t p) { return (t & ((1u << p) - 1)) | ((t >> p) << (p + 3)); }
+// thread index -> logical index with a zero SB-bit slot field at bit p.  SB = 3: 8 elements per thread, 256 threads per tile, two waves per
+// SIMD (the tile's 72 KiB of LDS allow two workgroups per CU either way); SB = 2: 4 elements per thread, 512 threads, four waves per SIMD
+// at <= 128 registers, for two more exchanges per 11-stage tile.
+template <int SB>
+__device__ __forceinline__ uint32_t place(uint32_t t, uint32_t p) { return (t & ((1u << p) - 1)) | ((t >> p) << (p + SB)); }
 
 // (a, b) <- (a + bw, a - bw + 3p) WITHOUT carry propagation: bw is normalised (limbs < 2^29); a's limbs may be lazy.  Per stage a limb
 // grows by < 2^29 (sum) or < 2^30 (difference: the borrow-spread constant), so from normalised inputs three stages leave every limb below
 // 7 * 2^29 < 2^32, and a lazy multiplicand of the third stage (limbs < 5 * 2^29) keeps the product's 64-bit columns below
-// 9 * 5 * 2^58 + 9 * 2^58 < 2^64.  A register group (<= 3 stages) therefore normalises ONCE, when it hands its values on (norm8) — a third
+// 9 * 5 * 2^58 + 9 * 2^58 < 2^64.  A register group (<= 3 stages) therefore normalises ONCE, when it hands its values on (norm_all) — a third
 // of the carry passes of the stage-by-stage form, 9 % of the kernels' instructions.  The value bound (+3p per stage) is unchanged.
 __device__ __forceinline__ void bfly(fe& a, fe& b, const el2<Fr>& bw) {
     fe sum, dif;
@@ -270,9 +273,10 @@ __device__ __forceinline__ void bfly(fe& a, fe& b, const el2<Fr>& bw) {
     a = sum;
     b = dif;
 }
-__device__ __forceinline__ void norm8(fe (&v)[8]) {
+template <int E>
+__device__ __forceinline__ void norm_all(fe (&v)[E]) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) fe_normalize(v[q]);
+    for (int q = 0; q < E; ++q) fe_normalize(v[q]);
 }
 // a unit twiddle after the first stage: contract the (lazy) operand by conditional subtractions instead of a product by one
 __device__ __forceinline__ el1<Fr> unit_operand(fe x) {
@@ -280,75 +284,86 @@ __device__ __forceinline__ el1<Fr> unit_operand(fe x) {
     return canonical(tile_el(x));
 }
 
-// stages 0..2 on freshly loaded values (< 2p); slot = row bits 0..2, so the twiddle exponents are compile-time:
-// stage u pairs (q, q | 1 << u) with w_{2^(u+1)}^(q mod 2^u).  5 products for 12 butterflies.
-__device__ __forceinline__ void stages_first(fe (&v)[8], const TwDev& tw) {
+// stages 0..SB-1 on freshly loaded values (< 2p); slot = row bits 0..SB-1, so the twiddle exponents are compile-time:
+// stage u pairs (q, q | 1 << u) with w_{2^(u+1)}^(q mod 2^u).  SB = 3: 5 products for 12 butterflies; SB = 2: 1 for 4.
+template <int SB>
+__device__ __forceinline__ void stages_first(fe (&v)[1 << SB], const TwDev& tw) {
+    constexpr int E = 1 << SB;
 #pragma unroll
-    for (int q = 0; q < 8; q += 2) bfly(v[q], v[q + 1], el2<Fr>(v[q + 1]));
+    for (int q = 0; q < E; q += 2) bfly(v[q], v[q + 1], el2<Fr>(v[q + 1]));
     el2<Fr> w4 = load_raw<Fr>(tw.bf + ((size_t)1 << (tw.bf_shift - 1)) * 8);
 #pragma unroll
-    for (int h = 0; h < 8; h += 4) {
+    for (int h = 0; h < E; h += 4) {
         bfly(v[h], v[h + 2], unit_operand(v[h + 2]));
         bfly(v[h + 1], v[h + 3], tile_el(v[h + 3]) * w4);
     }
-    bfly(v[0], v[4], unit_operand(v[4]));
-    bfly(v[1], v[5], tile_el(v[5]) * load_raw<Fr>(tw.bf + ((size_t)1 << (tw.bf_shift - 2)) * 8));
-    bfly(v[2], v[6], tile_el(v[6]) * w4);
-    bfly(v[3], v[7], tile_el(v[7]) * load_raw<Fr>(tw.bf + ((size_t)3 << (tw.bf_shift - 2)) * 8));
-    norm8(v);
+    if constexpr (SB == 3) {
+        bfly(v[0], v[4], unit_operand(v[4]));
+        bfly(v[1], v[5], tile_el(v[5]) * load_raw<Fr>(tw.bf + ((size_t)1 << (tw.bf_shift - 2)) * 8));
+        bfly(v[2], v[6], tile_el(v[6]) * w4);
+        bfly(v[3], v[7], tile_el(v[7]) * load_raw<Fr>(tw.bf + ((size_t)3 << (tw.bf_shift - 2)) * 8));
+    }
+    norm_all(v);
 }
 
-// stages [e - G_, e) with the slot at row bits [e-3, e); rho0 = this thread's row index with a zero slot field.
-// The twiddle of a pair depends on the row bits below the partner bit only: 2^(3-G_+u) distinct ones in stage u.
-template <int G_, int U_>
-__device__ __forceinline__ void stage_general(fe (&v)[8], uint32_t rho0, uint32_t e, const TwDev& tw) {
-    constexpr int pb = 3 - G_ + U_;   // partner bit inside the slot
+// stages [e - G_, e) with the slot at row bits [e-SB, e); rho0 = this thread's row index with a zero slot field.
+// The twiddle of a pair depends on the row bits below the partner bit only: 2^(SB-G_+u) distinct ones in stage u.
+template <int SB, int G_, int U_>
+__device__ __forceinline__ void stage_general(fe (&v)[1 << SB], uint32_t rho0, uint32_t e, const TwDev& tw) {
+    constexpr int pb = SB - G_ + U_;   // partner bit inside the slot
     const uint32_t st = e - G_ + U_;
     const uint32_t msk = (1u << st) - 1;
 #pragma unroll
     for (int lb = 0; lb < (1 << pb); ++lb) {
-        uint32_t j = (rho0 | ((uint32_t)lb << (e - 3))) & msk;
+        uint32_t j = (rho0 | ((uint32_t)lb << (e - SB))) & msk;
         el2<Fr> w = load_raw<Fr>(tw.bf + ((size_t)j << (tw.bf_shift - st)) * 8);
 #pragma unroll
-        for (int hb = 0; hb < (4 >> pb); ++hb) {
+        for (int hb = 0; hb < ((1 << (SB - 1)) >> pb); ++hb) {
             const int q0 = lb | (hb << (pb + 1)), q1 = q0 | (1 << pb);
             bfly(v[q0], v[q1], tile_el(v[q1]) * w);
         }
     }
 }
-template <int G_>
-__device__ __forceinline__ void stages_general(fe (&v)[8], uint32_t rho0, uint32_t e, const TwDev& tw) {
-    stage_general<G_, 0>(v, rho0, e, tw);
-    if constexpr (G_ > 1) stage_general<G_, 1>(v, rho0, e, tw);
-    if constexpr (G_ > 2) stage_general<G_, 2>(v, rho0, e, tw);
-    norm8(v);
+template <int SB, int G_>
+__device__ __forceinline__ void stages_general(fe (&v)[1 << SB], uint32_t rho0, uint32_t e, const TwDev& tw) {
+    stage_general<SB, G_, 0>(v, rho0, e, tw);
+    if constexpr (G_ > 1) stage_general<SB, G_, 1>(v, rho0, e, tw);
+    if constexpr (G_ > 2) stage_general<SB, G_, 2>(v, rho0, e, tw);
+    norm_all(v);
 }
 
 // groups 1.. of a tile whose group 0 is already done in v (slot at logical bit logT, held by the thread that place() would
-// number t_first); leaves v in the last group's ownership (slot at logical bit logT + s - 3) and returns that thread's
+// number t_first); leaves v in the last group's ownership (slot at logical bit logT + s - SB) and returns that thread's
 // logical base index.
-__device__ __forceinline__ uint32_t tile_rest(fe (&v)[8], fe* tile, uint32_t s, uint32_t logT, const Swz& z, const TwDev& tw,
+template <int SB>
+__device__ __forceinline__ uint32_t tile_rest(fe (&v)[1 << SB], fe* tile, uint32_t s, uint32_t logT, const Swz& z, const TwDev& tw,
                                               uint32_t t_first) {
+    constexpr int E = 1 << SB;
     const uint32_t t = threadIdx.x;
     uint32_t p_prev = logT;
-    const uint32_t G = (s + 2) / 3;
+    const uint32_t G = (s + SB - 1) / SB;
 #pragma clang loop unroll(disable)
     for (uint32_t i = 1; i < G; ++i) {
-        uint32_t e = min(3 * i + 3, s), g = e - 3 * i, p = logT + e - 3;
-        uint32_t Lw = place(i == 1 ? t_first : t, p_prev);
+        uint32_t e = min(SB * i + SB, s), g = e - SB * i, p = logT + e - SB;
+        uint32_t Lw = place<SB>(i == 1 ? t_first : t, p_prev);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) tile[swz(Lw | ((uint32_t)q << p_prev), z)] = v[q];
+        for (int q = 0; q < E; ++q) tile[swz(Lw | ((uint32_t)q << p_prev), z)] = v[q];
         __syncthreads();
-        uint32_t Lr = place(t, p);
+        uint32_t Lr = place<SB>(t, p);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = tile[swz(Lr | ((uint32_t)q << p), z)];
+        for (int q = 0; q < E; ++q) v[q] = tile[swz(Lr | ((uint32_t)q << p), z)];
         uint32_t rho0 = Lr >> logT;
-        if (g == 3) stages_general<3>(v, rho0, e, tw);
-        else if (g == 2) stages_general<2>(v, rho0, e, tw);
-        else stages_general<1>(v, rho0, e, tw);
+        if constexpr (SB == 3) {
+            if (g == 3) stages_general<3, 3>(v, rho0, e, tw);
+            else if (g == 2) stages_general<3, 2>(v, rho0, e, tw);
+            else stages_general<3, 1>(v, rho0, e, tw);
+        } else {
+            if (g == 2) stages_general<2, 2>(v, rho0, e, tw);
+            else stages_general<2, 1>(v, rho0, e, tw);
+        }
         p_prev = p;
     }
-    return place(G == 1 ? t_first : t, p_prev);
+    return place<SB>(G == 1 ? t_first : t, p_prev);
 }
 
 // table[pos] = w^((lo * r) << hi_bits) for pos = (r << lo_bits) | lo: the Cooley-Tukey twiddle of a non-final pass's output at
@@ -366,9 +381,10 @@ __global__ void k_pass_twiddles(uint32_t* table, uint32_t count, uint32_t lo_bit
 // stream, ~7 us of it per call); longer batches go in launches of NTT_MAXP
 #define NTT_MAXP 16
 struct NttPtrs { const uint32_t* src[NTT_MAXP]; uint32_t* dst[NTT_MAXP]; };
-__global__ void __launch_bounds__(256, 2) k_ntt_strided_r8(const NttPtrs PT, uint32_t m, uint32_t s,
-                                                            uint32_t lo_bits, uint32_t logT, uint32_t n_in, TwDev tw, NttScale sc, Swz z,
-                                                            const uint32_t* __restrict__ ptab) {
+template <int SB>
+__device__ __forceinline__ void ntt_strided_rt(const NttPtrs& PT, uint32_t m, uint32_t s, uint32_t lo_bits, uint32_t logT, uint32_t n_in,
+                                               const TwDev& tw, const NttScale& sc, const Swz& z, const uint32_t* __restrict__ ptab) {
+    constexpr int E = 1 << SB;
     fe* tile = reinterpret_cast<fe*>(ntt_lds);
     const uint32_t T = 1u << logT, t = threadIdx.x;
     uint32_t tiles_lo = 1u << (lo_bits - logT);
@@ -378,29 +394,47 @@ __global__ void __launch_bounds__(256, 2) k_ntt_strided_r8(const NttPtrs PT, uin
     const uint32_t* src = PT.src[blockIdx.y];
     uint32_t* dst = PT.dst[blockIdx.y];
     const uint32_t* pre_tab = tab_of(sc.pre_tab, sc, blockIdx.y);
-    // ownership at the load: slot = row bits 0..2; row rho <-> digit j = bitrev(rho, s)
-    const uint32_t tl0 = t & (T - 1), jrest = bitrev(t >> logT, s - 3);
-    fe v[8];
+    // ownership at the load: slot = row bits 0..SB-1; row rho <-> digit j = bitrev(rho, s)
+    const uint32_t tl0 = t & (T - 1), jrest = bitrev(t >> logT, s - SB);
+    fe v[E];
 #pragma clang loop unroll(full)
-    for (int q = 0; q < 8; ++q) {
-        const uint32_t qr = ((q & 1) << 2) | (q & 2) | (q >> 2);   // bitrev3
-        uint32_t j = (qr << (s - 3)) | jrest;
+    for (int q = 0; q < E; ++q) {
+        const uint32_t qr = SB == 3 ? ((q & 1) << 2) | (q & 2) | (q >> 2) : ((q & 1) << 1) | (q >> 1);   // bitrev of the slot
+        uint32_t j = (qr << (s - SB)) | jrest;
         v[q] = load_in(src, base | (j << lo_bits) | tl0, n_in, sc, pre_tab);
     }
-    stages_first(v, tw);
-    const uint32_t L_last = tile_rest(v, tile, s, logT, z, tw, t);
-    const uint32_t p_last = logT + s - 3;
+    stages_first<SB>(v, tw);
+    const uint32_t L_last = tile_rest<SB>(v, tile, s, logT, z, tw, t);
+    const uint32_t p_last = logT + s - SB;
 #pragma clang loop unroll(full)
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < E; ++q) {
         uint32_t L = L_last | ((uint32_t)q << p_last);
         uint32_t tl = L & (T - 1), r = L >> logT;
         uint32_t rel = (r << lo_bits) | lo0 | tl;
         store_packed<Fr>(dst + ((size_t)(hi << (s + lo_bits)) | rel) * 8, tile_el(v[q]) * load_raw<Fr>(ptab + (size_t)rel * 8));   // < 2p, read by the next pass only
     }
 }
+__global__ void __launch_bounds__(256, 2) k_ntt_strided_r8(const NttPtrs PT, uint32_t m, uint32_t s,
+                                                            uint32_t lo_bits, uint32_t logT, uint32_t n_in, TwDev tw, NttScale sc, Swz z,
+                                                            const uint32_t* __restrict__ ptab) {
+    ntt_strided_rt<3>(PT, m, s, lo_bits, logT, n_in, tw, sc, z, ptab);
+}
+__global__ void __launch_bounds__(512, 4) k_ntt_strided_r4(const NttPtrs PT, uint32_t m, uint32_t s,
+                                                            uint32_t lo_bits, uint32_t logT, uint32_t n_in, TwDev tw, NttScale sc, Swz z,
+                                                            const uint32_t* __restrict__ ptab) {
+    ntt_strided_rt<2>(PT, m, s, lo_bits, logT, n_in, tw, sc, z, ptab);
+}
 
-__global__ void __launch_bounds__(256, 2) k_ntt_final_r8(const NttPtrs PT, uint32_t m, uint32_t s,
-                                                       uint32_t logT, uint32_t n_in, TwDev tw, NttScale sc, NttDigits dg, Swz z) {
+__global__ void __launch_bounds__(256, 4) k_ntt_strided_r4s(const NttPtrs PT, uint32_t m, uint32_t s,
+                                                             uint32_t lo_bits, uint32_t logT, uint32_t n_in, TwDev tw, NttScale sc, Swz z,
+                                                             const uint32_t* __restrict__ ptab) {
+    ntt_strided_rt<2>(PT, m, s, lo_bits, logT, n_in, tw, sc, z, ptab);
+}
+
+template <int SB>
+__device__ __forceinline__ void ntt_final_rt(const NttPtrs& PT, uint32_t m, uint32_t s, uint32_t logT, uint32_t n_in, const TwDev& tw,
+                                             const NttScale& sc, const NttDigits& dg, const Swz& z) {
+    constexpr int E = 1 << SB;
     fe* tile = reinterpret_cast<fe*>(ntt_lds);
     const uint32_t* src = PT.src[blockIdx.y];
     uint32_t* dst = PT.dst[blockIdx.y];
@@ -412,19 +446,19 @@ __global__ void __launch_bounds__(256, 2) k_ntt_final_r8(const NttPtrs PT, uint3
     uint32_t rest_bits = hi_bits - s1;
     uint32_t rest = blockIdx.x & ((1u << rest_bits) - 1);
     uint32_t k1_0 = (blockIdx.x >> rest_bits) << logT;
-    // load: lanes run along j (contiguous in memory); thread = (jl, tl), its 8 values j = jl | qq << (s-3) are the rows
-    // rho = bitrev(jl, s-3) * 8 + bitrev3(qq)
-    fe v[8];
-    const uint32_t jl = t & ((1u << (s - 3)) - 1), tl0 = t >> (s - 3);
+    // load: lanes run along j (contiguous in memory); thread = (jl, tl), its E values j = jl | qq << (s-SB) are the rows
+    // rho = bitrev(jl, s-SB) * E + bitrev(qq, SB)
+    fe v[E];
+    const uint32_t jl = t & ((1u << (s - SB)) - 1), tl0 = t >> (s - SB);
     const uint32_t row0 = ((k1_0 + tl0) << rest_bits) | rest;
 #pragma clang loop unroll(full)
-    for (int q = 0; q < 8; ++q) {
-        const uint32_t qr = ((q & 1) << 2) | (q & 2) | (q >> 2);
-        v[q] = load_in(src, (row0 << s) | (qr << (s - 3)) | jl, n_in, sc, pre_tab);
+    for (int q = 0; q < E; ++q) {
+        const uint32_t qr = SB == 3 ? ((q & 1) << 2) | (q & 2) | (q >> 2) : ((q & 1) << 1) | (q >> 1);
+        v[q] = load_in(src, (row0 << s) | (qr << (s - SB)) | jl, n_in, sc, pre_tab);
     }
-    stages_first(v, tw);
+    stages_first<SB>(v, tw);
     // group 0's ownership in the common (tl, rest-of-row) thread numbering
-    const uint32_t L_last = tile_rest(v, tile, s, logT, z, tw, tl0 | (bitrev(jl, s - 3) << logT));
+    const uint32_t L_last = tile_rest<SB>(v, tile, s, logT, z, tw, tl0 | (bitrev(jl, s - SB) << logT));
     uint32_t kbase = 0, shift_out = s1, rb = rest_bits;
     for (uint32_t q = 1; q + 1 < dg.np; ++q) {
         uint32_t w = dg.sw[q];
@@ -433,9 +467,9 @@ __global__ void __launch_bounds__(256, 2) k_ntt_final_r8(const NttPtrs PT, uint3
         kbase |= d << shift_out;
         shift_out += w;
     }
-    const uint32_t p_last = logT + s - 3;
+    const uint32_t p_last = logT + s - SB;
 #pragma clang loop unroll(full)
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < E; ++q) {
         uint32_t L = L_last | ((uint32_t)q << p_last);
         uint32_t tl = L & (T - 1), r = L >> logT;
         uint32_t k = (r << hi_bits) | kbase | (k1_0 + tl);
@@ -444,6 +478,19 @@ __global__ void __launch_bounds__(256, 2) k_ntt_final_r8(const NttPtrs PT, uint3
         else if (post_tab) store_raw<Fr>(out, tile_el(v[q]) * load_raw<Fr>(post_tab + (size_t)k * 8));
         else store_raw<Fr>(out, tile_el(v[q]));
     }
+}
+__global__ void __launch_bounds__(256, 2) k_ntt_final_r8(const NttPtrs PT, uint32_t m, uint32_t s,
+                                                       uint32_t logT, uint32_t n_in, TwDev tw, NttScale sc, NttDigits dg, Swz z) {
+    ntt_final_rt<3>(PT, m, s, logT, n_in, tw, sc, dg, z);
+}
+__global__ void __launch_bounds__(512, 4) k_ntt_final_r4(const NttPtrs PT, uint32_t m, uint32_t s,
+                                                       uint32_t logT, uint32_t n_in, TwDev tw, NttScale sc, NttDigits dg, Swz z) {
+    ntt_final_rt<2>(PT, m, s, logT, n_in, tw, sc, dg, z);
+}
+
+__global__ void __launch_bounds__(256, 4) k_ntt_final_r4s(const NttPtrs PT, uint32_t m, uint32_t s,
+                                                        uint32_t logT, uint32_t n_in, TwDev tw, NttScale sc, NttDigits dg, Swz z) {
+    ntt_final_rt<2>(PT, m, s, logT, n_in, tw, sc, dg, z);
 }
 
 __global__ void k_mul_periodic(uint32_t* a, size_t n, const uint32_t* tev, uint32_t period_mask) {
@@ -499,7 +546,7 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
     hipError_t attr_err = hipSuccess;
     std::call_once(lds_attr_once, [&] {
         attr_err = hipFuncSetAttribute((const void*)k_ntt_strided, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NTT_TILE * sizeof(fe)));
-        for (const void* f : {(const void*)k_ntt_final, (const void*)k_ntt_strided_r8, (const void*)k_ntt_final_r8})
+        for (const void* f : {(const void*)k_ntt_final, (const void*)k_ntt_strided_r8, (const void*)k_ntt_final_r8, (const void*)k_ntt_strided_r4, (const void*)k_ntt_final_r4})
             if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NTT_TILE * sizeof(fe)));
     });
     ZK_HIP(attr_err);
@@ -510,23 +557,39 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
     // Round 2, isolated batches of 8 (tools/ntt_plan_bench.py): two passes of up to 11 bits beat three of 6-7 bits up to 2^21 (2^19 -10 %,
     // 2^20 -14 %, 2^21 -6 %: a polynomial is <= 64 MiB and the 32-64 byte runs of the second pass still hit the last-level cache);
     // at 2^22 11 + 11 is 1.4 % slower than 8 + 7 + 7, from 2^23 both plans are three passes.
-    uint32_t smax = m >= 22 ? 10 : 11;
-    { int v = ctx->opt.ntt_smax; if (v >= 4 && v <= 11) smax = (uint32_t)v; }
-    uint32_t np = m <= 11 ? 1 : (m + smax - 1) / smax;
-    if (np > 6) { set_error("ntt: too many passes"); return ZKHIP_EINVAL; }
-    uint32_t sw[6] = {0, 0, 0, 0, 0, 0};
-    for (uint32_t q = 0; q < np; ++q) sw[q] = m / np + (q < m % np ? 1 : 0);
-    // register-tiled kernels: every pass on full 2048-element tiles (true whenever np > 1 with the default plan)
-    bool r8 = np > 1 && twh->bf_bits >= 2;
-    {
+    // register-tiled kernels (every pass on full tiles; true whenever np > 1 with the default plans).  ntt_r8: 1 = 8 elements per thread on
+    // 2048-element tiles; 2 = 4 per thread, same tiles (512 threads); 3 = 4 per thread on 1024-element tiles (256 threads, 36 KiB of LDS: four
+    // independent tiles per CU instead of two)
+    uint32_t np = 1, sw[6] = {0, 0, 0, 0, 0, 0};
+    auto plan = [&](uint32_t tlog, uint32_t sb) -> bool {
+        uint32_t smax = m >= 22 ? 10 : 11;
+        { int v = ctx->opt.ntt_smax; if (v >= 4 && v <= 11) smax = (uint32_t)v; }
+        smax = std::min(smax, tlog);
+        np = m <= 11 ? 1 : (m + smax - 1) / smax;
+        for (uint32_t q = 0; q < 6; ++q) sw[q] = q < np ? m / np + (q < m % np ? 1 : 0) : 0;
+        if (np > 6) return false;
+        bool ok = np > 1 && twh->bf_bits >= 2;
         uint32_t lb = m;
-        for (uint32_t q = 0; q < np && r8; ++q) {
+        for (uint32_t q = 0; q < np && ok; ++q) {
             lb -= sw[q];
             uint32_t avail = q + 1 < np ? lb : sw[0];
-            if (sw[q] < 3 || sw[q] > ilog2(NTT_TILE) || avail < ilog2(NTT_TILE) - sw[q]) r8 = false;
+            if (sw[q] < sb || sw[q] > tlog || avail < tlog - sw[q]) ok = false;
         }
-    }
-    r8 = r8 && ctx->opt.ntt_r8 != 0;
+        return ok;
+    };
+    // auto (4): 4 per thread everywhere — on 2048-element tiles from 2^21 (two passes of <= 11 bits), on 1024-element tiles below.  Measured in
+    // the proofs (r03, A/B on one box): k = 22 -1.5 % with the 2048 tiles, k = 19 -1.0 % and k = 17 -0.6 % with the 1024 ones, against 8 per thread
+    int want = ctx->opt.ntt_r8;
+    if (want == 4) want = m >= 21 ? 2 : 3;
+    bool r8 = false;
+    uint32_t tlog = ilog2(NTT_TILE), SBh = 3;
+    if (want == 3 && plan(10, 2)) { r8 = true; tlog = 10; SBh = 2; }
+    else if (want == 2 && plan(tlog, 2)) { r8 = true; SBh = 2; }
+    else { r8 = plan(tlog, 3) && want != 0; }
+    if (np > 6) { set_error("ntt: too many passes"); return ZKHIP_EINVAL; }
+    const bool r4 = r8 && SBh == 2;
+    const unsigned rthreads = (1u << tlog) >> SBh;
+    const size_t rlds = ((size_t)1 << tlog) * sizeof(fe);
     std::vector<void*> tmp_host(npolys);
     if (np > 1) {
         void* d_tmpbuf;
@@ -543,7 +606,7 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
     for (uint32_t q = 0; q + 1 < np; ++q) {
         uint32_t s = sw[q];
         lo_bits -= s;
-        uint32_t logT = std::min<uint32_t>(ilog2(NTT_TILE) - s, lo_bits);
+        uint32_t logT = std::min<uint32_t>(tlog - s, lo_bits);
         NttScale scq = sc;
         if (q != 0) { scq.use_pre = 0; scq.pre_tab = nullptr; }
         scq.use_post = 0;
@@ -556,7 +619,7 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
         { int v = ctx->opt.ntt_group; if (v >= 1 && v <= 64) group = (uint32_t)v; }
         ProfScope ps(ctx, "ntt_strided");
         if (r8) {
-            Swz z{logT + 3, logT < 5 ? (1u << (5 - logT)) - 1 : 0u, logT};
+            Swz z{logT + SBh, logT < 5 ? (1u << (5 - logT)) - 1 : 0u, logT};
             const void* ptab;
             ZK_TRY(pass_twiddles(ctx, twh, tw, q, s, lo_bits, &ptab));
             // host views of this pass's sources / destinations (the same choice as cur_src / out below)
@@ -567,8 +630,12 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
                 const size_t cnt = std::min<size_t>(NTT_MAXP, npolys - p0);
                 for (size_t i = 0; i < cnt; ++i) { PT.src[i] = (const uint32_t*)hs[p0 + i]; PT.dst[i] = (uint32_t*)hd[p0 + i]; }
                 scq.tab_p0 = (uint32_t)p0;
-                hipLaunchKernelGGL(k_ntt_strided_r8, dim3(blocks, (unsigned)cnt), dim3(256), NTT_TILE * sizeof(fe), st, PT, m, s, lo_bits, logT,
-                                   q == 0 ? n_in : (uint32_t)n, tw, scq, z, (const uint32_t*)ptab);
+                if (r4)
+                    hipLaunchKernelGGL(tlog == 10 ? k_ntt_strided_r4s : k_ntt_strided_r4, dim3(blocks, (unsigned)cnt), dim3(rthreads), rlds, st, PT, m, s, lo_bits, logT,
+                                       q == 0 ? n_in : (uint32_t)n, tw, scq, z, (const uint32_t*)ptab);
+                else
+                    hipLaunchKernelGGL(k_ntt_strided_r8, dim3(blocks, (unsigned)cnt), dim3(256), NTT_TILE * sizeof(fe), st, PT, m, s, lo_bits, logT,
+                                       q == 0 ? n_in : (uint32_t)n, tw, scq, z, (const uint32_t*)ptab);
             }
         } else
         hipLaunchKernelGGL(k_ntt_strided, dim3(blocks, (unsigned)((npolys + group - 1) / group)), dim3(256), NTT_TILE * sizeof(fe), st,
@@ -579,7 +646,7 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
     {
         uint32_t s = sw[np - 1];
         uint32_t s1 = np > 1 ? sw[0] : 0;
-        uint32_t logT = np > 1 ? std::min<uint32_t>(ilog2(NTT_TILE) - s, s1) : 0;
+        uint32_t logT = np > 1 ? std::min<uint32_t>(tlog - s, s1) : 0;
         NttScale scq = sc;
         if (np > 1) { scq.use_pre = 0; scq.pre_tab = nullptr; }
         NttDigits dg;
@@ -588,15 +655,19 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
         unsigned blocks = (unsigned)(n >> (s + logT));
         ProfScope ps(ctx, "ntt_final");
         if (r8) {
-            Swz z{6, 31, 0};
+            Swz z{tlog - 5, 31, 0};
             const void* const* hs = all.data() + 2 * npolys;   // np > 1: the last non-final pass wrote tmp
             for (size_t p0 = 0; p0 < npolys; p0 += NTT_MAXP) {
                 NttPtrs PT;
                 const size_t cnt = std::min<size_t>(NTT_MAXP, npolys - p0);
                 for (size_t i = 0; i < cnt; ++i) { PT.src[i] = (const uint32_t*)hs[p0 + i]; PT.dst[i] = (uint32_t*)all[npolys + p0 + i]; }
                 scq.tab_p0 = (uint32_t)p0;
-                hipLaunchKernelGGL(k_ntt_final_r8, dim3(blocks, (unsigned)cnt), dim3(256), NTT_TILE * sizeof(fe), st, PT, m, s, logT, (uint32_t)n, tw,
-                                   scq, dg, z);
+                if (r4)
+                    hipLaunchKernelGGL(tlog == 10 ? k_ntt_final_r4s : k_ntt_final_r4, dim3(blocks, (unsigned)cnt), dim3(rthreads), rlds, st, PT, m, s, logT, (uint32_t)n, tw,
+                                       scq, dg, z);
+                else
+                    hipLaunchKernelGGL(k_ntt_final_r8, dim3(blocks, (unsigned)cnt), dim3(256), NTT_TILE * sizeof(fe), st, PT, m, s, logT, (uint32_t)n, tw,
+                                       scq, dg, z);
             }
         } else
         hipLaunchKernelGGL(k_ntt_final, dim3(blocks, (unsigned)npolys), dim3(256), NTT_TILE * sizeof(fe), st, (const uint32_t* const*)cur_src,

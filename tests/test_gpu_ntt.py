@@ -47,11 +47,15 @@ def test_fft_vs_oracle(zk, oracle, log_n):
 
 
 @pytest.mark.parametrize("log_n,smax,r8", [(13, "9", "0"), (16, "9", "0"), (18, "6", "1"), (12, "4", "1"), (15, "5", "1"),
-                                            (14, "7", "1"), (20, "11", "1"), (21, "11", "1"), (19, "10", "1")])
+                                            (14, "7", "1"), (20, "11", "1"), (21, "11", "1"), (19, "10", "1"),
+                                            (12, "4", "2"), (15, "5", "2"), (14, "7", "2"), (20, "11", "2"), (21, "11", "2"), (22, "11", "2"), (18, "6", "2"),
+                                            (12, "4", "3"), (15, "5", "3"), (14, "7", "3"), (20, "10", "3"), (21, "7", "3"), (19, "10", "3"), (17, "9", "3"),
+                                            (22, "0", "4"), (19, "0", "4"), (17, "0", "4")])
 def test_fft_tile_plans(zk, oracle, log_n, smax, r8):
-    """every shape of the tile transform: the stage-per-barrier kernels (ntt_r8 = 0) and the register-tiled ones with stage
-    groups 3+1, 3+2, 3+3, 3+3+1 ... 3+3+3+2 (ntt_smax changes the digits of the pass plan; zkhip_set_option, the knobs are
-    no longer read from the environment per call)"""
+    """every shape of the tile transform: the stage-per-barrier kernels (ntt_r8 = 0) and the register-tiled ones — 8 elements per thread
+    (1: stage groups 3+1, 3+2, 3+3, 3+3+1 ... 3+3+3+2), 4 per thread on 2048-element tiles (2: groups of 2, the last of 1 or 2) and on
+    1024-element tiles (3), and the default choice between them (4).  ntt_smax changes the digits of the pass plan (zkhip_set_option, the
+    knobs are no longer read from the environment per call)"""
     ffi, ctx = zk
     zo = oracle
     ctx.set_option("ntt_smax", int(smax))
@@ -62,7 +66,7 @@ def test_fft_tile_plans(zk, oracle, log_n, smax, r8):
         assert (ctx.best_fft(a, w, log_n) == zo.best_fft(a, w, log_n, 8)).all()
     finally:
         ctx.set_option("ntt_smax", 0)
-        ctx.set_option("ntt_r8", 1)
+        ctx.set_option("ntt_r8", 4)
 
 
 def test_fft_batch_device(zk, oracle):
