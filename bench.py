@@ -100,14 +100,20 @@ def pmc_traffic(config, bh):
         best = (f, rows)
     if best is None:
         return None, None
-    per = {}
+    per, calls = {}, {}
     for r in best[1]:
         per[(r["counter"], r["kernel"])] = float(r["avg_per_dispatch"]) * 1024.0
+        calls[r["kernel"]] = max(calls.get(r["kernel"], 0), int(float(r["dispatches"])))
     def tr(kernel, fetch_scale):
         f, w = per.get(("FETCH_SIZE", kernel)), per.get(("WRITE_SIZE", kernel))
         return None if f is None or w is None else f * fetch_scale + w
-    out = {"msm_accum_affine": tr("k_accum_affine", 1.0), "ntt_strided": tr("k_ntt_strided_r8", 2.0), "ntt_final": tr("k_ntt_final_r8", 2.0),
-           "sweep": tr("k_sweep", 2.0)}
+    def ntt_kernel(stem):
+        """the register-tiled variant this configuration's transforms ran on (8 or 4 elements per thread, 2048 / 1024 tiles: ntt.hip picks by size)"""
+        have = [k for k in calls if k.startswith(stem + "_r")]
+        return max(have, key=lambda k: calls[k]) if have else stem + "_r4"
+    ks, kf = ntt_kernel("k_ntt_strided"), ntt_kernel("k_ntt_final")
+    out = {"msm_accum_affine": tr("k_accum_affine", 1.0), "ntt_strided": tr(ks, 2.0), "ntt_final": tr(kf, 2.0),
+           "sweep": tr("k_sweep", 2.0), "ntt_kernels": f"{ks} + {kf}"}
     return out, os.path.relpath(best[0], ROOT)
 
 
@@ -378,7 +384,7 @@ def main():
             tr_l = None
             if traffic and traffic["ntt_strided"] and traffic["ntt_final"]:
                 tr_l = (traffic["ntt_strided"] * i_["per_kernel"]["ntt_strided"][1] + traffic["ntt_final"] * i_["per_kernel"]["ntt_final"][1]) / max(i_["launches"], 1)
-            roof["ntt"] = {"kernel": "k_ntt_strided_r8 + k_ntt_final_r8", "bound": "valu", "hbm_frac": round(ach / HBM_PEAK_GBS, 5), "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            roof["ntt"] = {"kernel": (traffic or {}).get("ntt_kernels") or ("k_ntt_strided_r4 + k_ntt_final_r4" if shape.k >= 21 else "k_ntt_strided_r4s + k_ntt_final_r4s"), "bound": "valu", "hbm_frac": round(ach / HBM_PEAK_GBS, 5), "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": round(tr_l) if tr_l else None,
                            "algorithmic_bytes_per_launch": round(64.0 * i_["elems"] / max(i_["launches"], 1)), "avg_launch_ms": round(i_["ms"] / max(i_["launches"], 1), 4),
                            "timing": ("HIP events, 3 isolated batches of 8 columns onto %d cosets (8 x %d transforms of 2^%d) after a warm-up" % (coset_q, coset_q, shape.k)) if coset_q
@@ -386,7 +392,7 @@ def main():
                            "in_proof_ms_per_step": round(ntt_ms, 3),
                            "transforms_per_step": counts["intt_n"] + counts["ntt_ext"] * (coset_q or 1) + counts["intt_ext"] * (coset_q or 1),
                            "note": "algorithmic = 64 B per element per transform; a transform of 2^m elements is ceil(m / 9) launches; VALU-issue bound "
-                                   "(valu_busy 0.78-0.79 at k >= 19 with two waves per SIMD, profiles/r03_*_valu_*.csv), not HBM bound; in-proof spans overlap the MSM phases"}
+                                   "(4 elements per thread, four waves per SIMD; valu_busy in profiles/r03_*_valu_*.csv; the memory side alone is 0.6 of the time and the two overlap imperfectly: profiles/r03_ntt_experiments.md), not HBM bound; in-proof spans overlap the MSM phases"}
         # sweep: 32 B x (distinct (column, rotation) reads + 1 write) per extended row
         sw = kernels["sweep"]
         if sw["ms_per_step"] > 0 and not shard:

@@ -39,7 +39,7 @@ for cfg in ("agg22", "rsa17", "sha19"):
         if "k_accum_affine" in r_["Name"]:
             print(cfg, "k_accum_affine rocprof", r_["Calls"], "calls avg", round(float(r_["AverageNs"]) / 1e6, 4), "ms; live", live)
     for r_ in csv.DictReader(l for l in open(os.path.join(src, f"valu_{cfg}.csv")) if not l.startswith("#")):
-        if r_["kernel"] in ("k_accum_affine", "k_ntt_strided_r8", "k_sweep", "k_sort_hi", "k_sort_lo_staged16"):
+        if r_["kernel"] in ("k_accum_affine", "k_ntt_strided_r8", "k_ntt_strided_r4", "k_ntt_strided_r4s", "k_ntt_final_r4", "k_ntt_final_r4s", "k_sweep", "k_sort_hi", "k_sort_lo_staged16"):
             print("   ", r_["kernel"], "valu_busy", r_["valu_busy"], "lanes", r_["lanes_active"], "valu/wave", r_["valu_insts_per_wave"])
 for k, v in j["configs"]["agg22"]["kernels_ms_per_step"].items():
     print("   ", k, v["ms_per_step"])
