@@ -36,6 +36,40 @@ def test_coeff_to_cosets_is_the_extended_subset(zk, oracle, k, degree):
     dom.free()
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("k,degree", [(13, 4), (14, 6)])
+def test_coset_transforms_on_every_tile_kernel(zk, oracle, k, degree, mode):
+    """the per-index pre- / post-scaling tables of the coset transforms (NttScale::pre_tab / post_tab) through each family of tile kernels:
+    stage-per-barrier (ntt_r8 = 0), 8 elements per thread (1), 4 per thread on 2048- (2) and 1024-element tiles (3) — forwards against the
+    extended-domain transform (itself held against the oracle in test_gpu_ntt.py), backwards by recovering random pieces exactly"""
+    ffi, ctx = zk
+    n = 1 << k
+    dom = ffi.EvaluationDomain(ctx, degree, k)
+    q, shifts = dom.cosets()
+    polys = [ctx.synth_fill(n, 7500 + 10 * k + i) for i in range(3)]
+    ctx.set_option("ntt_r8", 4)
+    ext = [ctx.to_host(e_) for e_ in dom.coeff_to_extended_device(polys)]
+    ctx.set_option("ntt_r8", mode)
+    try:
+        cos = dom.coeff_to_cosets_device(polys)
+        for e_, c_ in zip(ext, cos):
+            assert (ctx.to_host(c_) == _blocks(e_, n, q)).all()
+        pieces = [ctx.synth_fill(n, 7600 + 10 * k + j) for j in range(q)]
+        pc = dom.coeff_to_cosets_device(pieces)
+        blocks = []
+        for r in range(q):
+            c = pow(pv.from_mont_host(shifts[r]), n, pv.R)
+            coeffs = np.stack([pv.fr_from_int_host((c - 1) * pow(c, j, pv.R)) for j in range(q)])
+            blocks.append(ffi.linear_combination_device(ctx, [p_[r * n:(r + 1) * n] for p_ in pc], coeffs))
+        import torch
+
+        got = ctx.to_host(dom.cosets_to_pieces_device(torch.cat(blocks, dim=0).contiguous()))
+        assert (got == np.concatenate([ctx.to_host(p_) for p_ in pieces])).all()
+    finally:
+        ctx.set_option("ntt_r8", 4)
+        dom.free()
+
+
 def test_cosets_refused_when_they_save_nothing(zk):
     ffi, ctx = zk
     for degree in (3, 5, 9):     # q = 2, 4, 8 = the extension factor
