@@ -250,8 +250,27 @@ __global__ void __launch_bounds__(256) k_ntt_final(const uint32_t* const* srcs, 
 // short last group simply carries 3 - g passive bits.  Logical tile index L = row * T + tl as above; the LDS element index is
 // L with a few high bits XORed into low ones (Swz) so that the 32 lanes of an access, which differ in bits on both sides of the
 // slot field, land in 32 different banks (an element is 9 dwords, 9 is odd).
+// Three rules, chosen per launch (compile-time in the kernel: an index costs three instructions and there are 2 E of them per exchange).
+//   SWZ_FIELD : the field L[sh ...] & mk XORed in at bit ts — the strided passes (slot of group 0 at logT: sh = logT + SB) and the final
+//               pass's tiles with logT + SB >= 5 (its first write runs the lanes along the bit-REVERSED top row bits: sh = log tile - 5).
+//   SWZ_FIELD2: the final pass's tiles with logT + SB <= 4, where the slot of the second group still lies inside the five bank bits and the
+//               one field folds two lane bits onto one bank bit (2- / 4-way conflicts; measured on the first 4-per-thread build: 6.6 M /
+//               23.6 M conflict cycles per dispatch at 2^19 / 2^21): a second field, L[5 ...] of slot width, under the top of the bank bits.
+//   SWZ_REV   : SB = 2 at logT = 0, where no two fields do: bank bit j takes the row bits in reversed order (L8, L7, L6, L5 ^ L10, L6 ^ L9).
+// tests/test_ntt_swizzle.py replays every access of every tile shape against these rules (32 lanes, 32 banks, 9-dword elements).
 struct Swz { uint32_t sh, mk, ts; };
-__device__ __forceinline__ uint32_t swz(uint32_t L, const Swz& z) { return L ^ (((L >> z.sh) & z.mk) << z.ts); }
+enum { SWZ_FIELD = 0, SWZ_FIELD2 = 1, SWZ_REV = 2 };
+template <int SB, int RULE>
+__device__ __forceinline__ uint32_t swz(uint32_t L, const Swz& z) {
+    if constexpr (RULE == SWZ_REV) {
+        const uint32_t x = L >> 5;
+        return L ^ (__brev(x & 15u) >> 28) ^ (((x >> 5) & 1u) << 3) ^ ((((x >> 1) ^ (x >> 4)) & 1u) << 4);
+    } else {
+        uint32_t a = L ^ (((L >> z.sh) & z.mk) << z.ts);
+        if constexpr (RULE == SWZ_FIELD2) a ^= ((L >> 5) & ((1u << SB) - 1)) << (5 - SB);
+        return a;
+    }
+}
 // thread index -> logical index with a zero SB-bit slot field at bit p.  SB = 3: 8 elements per thread, 256 threads per tile, two waves per
 // SIMD (the tile's 72 KiB of LDS allow two workgroups per CU either way); SB = 2: 4 elements per thread, 512 threads, four waves per SIMD
 // at <= 128 registers, for two more exchanges per 11-stage tile.
@@ -335,7 +354,7 @@ __device__ __forceinline__ void stages_general(fe (&v)[1 << SB], uint32_t rho0, 
 // groups 1.. of a tile whose group 0 is already done in v (slot at logical bit logT, held by the thread that place() would
 // number t_first); leaves v in the last group's ownership (slot at logical bit logT + s - SB) and returns that thread's
 // logical base index.
-template <int SB>
+template <int SB, int RULE>
 __device__ __forceinline__ uint32_t tile_rest(fe (&v)[1 << SB], fe* tile, uint32_t s, uint32_t logT, const Swz& z, const TwDev& tw,
                                               uint32_t t_first) {
     constexpr int E = 1 << SB;
@@ -347,11 +366,11 @@ __device__ __forceinline__ uint32_t tile_rest(fe (&v)[1 << SB], fe* tile, uint32
         uint32_t e = min(SB * i + SB, s), g = e - SB * i, p = logT + e - SB;
         uint32_t Lw = place<SB>(i == 1 ? t_first : t, p_prev);
 #pragma unroll
-        for (int q = 0; q < E; ++q) tile[swz(Lw | ((uint32_t)q << p_prev), z)] = v[q];
+        for (int q = 0; q < E; ++q) tile[swz<SB, RULE>(Lw | ((uint32_t)q << p_prev), z)] = v[q];
         __syncthreads();
         uint32_t Lr = place<SB>(t, p);
 #pragma unroll
-        for (int q = 0; q < E; ++q) v[q] = tile[swz(Lr | ((uint32_t)q << p), z)];
+        for (int q = 0; q < E; ++q) v[q] = tile[swz<SB, RULE>(Lr | ((uint32_t)q << p), z)];
         uint32_t rho0 = Lr >> logT;
         if constexpr (SB == 3) {
             if (g == 3) stages_general<3, 3>(v, rho0, e, tw);
@@ -404,7 +423,7 @@ __device__ __forceinline__ void ntt_strided_rt(const NttPtrs& PT, uint32_t m, ui
         v[q] = load_in(src, base | (j << lo_bits) | tl0, n_in, sc, pre_tab);
     }
     stages_first<SB>(v, tw);
-    const uint32_t L_last = tile_rest<SB>(v, tile, s, logT, z, tw, t);
+    const uint32_t L_last = tile_rest<SB, SWZ_FIELD>(v, tile, s, logT, z, tw, t);
     const uint32_t p_last = logT + s - SB;
 #pragma clang loop unroll(full)
     for (int q = 0; q < E; ++q) {
@@ -431,7 +450,7 @@ __global__ void __launch_bounds__(256, 4) k_ntt_strided_r4s(const NttPtrs PT, ui
     ntt_strided_rt<2>(PT, m, s, lo_bits, logT, n_in, tw, sc, z, ptab);
 }
 
-template <int SB>
+template <int SB, int RULE>
 __device__ __forceinline__ void ntt_final_rt(const NttPtrs& PT, uint32_t m, uint32_t s, uint32_t logT, uint32_t n_in, const TwDev& tw,
                                              const NttScale& sc, const NttDigits& dg, const Swz& z) {
     constexpr int E = 1 << SB;
@@ -458,7 +477,7 @@ __device__ __forceinline__ void ntt_final_rt(const NttPtrs& PT, uint32_t m, uint
     }
     stages_first<SB>(v, tw);
     // group 0's ownership in the common (tl, rest-of-row) thread numbering
-    const uint32_t L_last = tile_rest<SB>(v, tile, s, logT, z, tw, tl0 | (bitrev(jl, s - SB) << logT));
+    const uint32_t L_last = tile_rest<SB, RULE>(v, tile, s, logT, z, tw, tl0 | (bitrev(jl, s - SB) << logT));
     uint32_t kbase = 0, shift_out = s1, rb = rest_bits;
     for (uint32_t q = 1; q + 1 < dg.np; ++q) {
         uint32_t w = dg.sw[q];
@@ -479,18 +498,21 @@ __device__ __forceinline__ void ntt_final_rt(const NttPtrs& PT, uint32_t m, uint
         else store_raw<Fr>(out, tile_el(v[q]));
     }
 }
+template <int RULE>
 __global__ void __launch_bounds__(256, 2) k_ntt_final_r8(const NttPtrs PT, uint32_t m, uint32_t s,
                                                        uint32_t logT, uint32_t n_in, TwDev tw, NttScale sc, NttDigits dg, Swz z) {
-    ntt_final_rt<3>(PT, m, s, logT, n_in, tw, sc, dg, z);
+    ntt_final_rt<3, RULE>(PT, m, s, logT, n_in, tw, sc, dg, z);
 }
+template <int RULE>
 __global__ void __launch_bounds__(512, 4) k_ntt_final_r4(const NttPtrs PT, uint32_t m, uint32_t s,
                                                        uint32_t logT, uint32_t n_in, TwDev tw, NttScale sc, NttDigits dg, Swz z) {
-    ntt_final_rt<2>(PT, m, s, logT, n_in, tw, sc, dg, z);
+    ntt_final_rt<2, RULE>(PT, m, s, logT, n_in, tw, sc, dg, z);
 }
 
+template <int RULE>
 __global__ void __launch_bounds__(256, 4) k_ntt_final_r4s(const NttPtrs PT, uint32_t m, uint32_t s,
                                                         uint32_t logT, uint32_t n_in, TwDev tw, NttScale sc, NttDigits dg, Swz z) {
-    ntt_final_rt<2>(PT, m, s, logT, n_in, tw, sc, dg, z);
+    ntt_final_rt<2, RULE>(PT, m, s, logT, n_in, tw, sc, dg, z);
 }
 
 __global__ void k_mul_periodic(uint32_t* a, size_t n, const uint32_t* tev, uint32_t period_mask) {
@@ -546,7 +568,8 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
     hipError_t attr_err = hipSuccess;
     std::call_once(lds_attr_once, [&] {
         attr_err = hipFuncSetAttribute((const void*)k_ntt_strided, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NTT_TILE * sizeof(fe)));
-        for (const void* f : {(const void*)k_ntt_final, (const void*)k_ntt_strided_r8, (const void*)k_ntt_final_r8, (const void*)k_ntt_strided_r4, (const void*)k_ntt_final_r4})
+        for (const void* f : {(const void*)k_ntt_final, (const void*)k_ntt_strided_r8, (const void*)k_ntt_strided_r4, (const void*)k_ntt_final_r8<SWZ_FIELD>, (const void*)k_ntt_final_r8<SWZ_FIELD2>,
+                              (const void*)k_ntt_final_r4<SWZ_FIELD>, (const void*)k_ntt_final_r4<SWZ_FIELD2>, (const void*)k_ntt_final_r4<SWZ_REV>})
             if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NTT_TILE * sizeof(fe)));
     });
     ZK_HIP(attr_err);
@@ -656,18 +679,19 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
         ProfScope ps(ctx, "ntt_final");
         if (r8) {
             Swz z{tlog - 5, 31, 0};
+            const int rule = logT + SBh >= 5 ? SWZ_FIELD : (SBh == 2 && logT == 0 ? SWZ_REV : SWZ_FIELD2);
+            typedef void (*FinalK)(const NttPtrs, uint32_t, uint32_t, uint32_t, uint32_t, TwDev, NttScale, NttDigits, Swz);
+            FinalK fk;
+            if (!r4) fk = rule == SWZ_FIELD ? k_ntt_final_r8<SWZ_FIELD> : k_ntt_final_r8<SWZ_FIELD2>;
+            else if (tlog == 10) fk = rule == SWZ_FIELD ? k_ntt_final_r4s<SWZ_FIELD> : rule == SWZ_FIELD2 ? k_ntt_final_r4s<SWZ_FIELD2> : k_ntt_final_r4s<SWZ_REV>;
+            else fk = rule == SWZ_FIELD ? k_ntt_final_r4<SWZ_FIELD> : rule == SWZ_FIELD2 ? k_ntt_final_r4<SWZ_FIELD2> : k_ntt_final_r4<SWZ_REV>;
             const void* const* hs = all.data() + 2 * npolys;   // np > 1: the last non-final pass wrote tmp
             for (size_t p0 = 0; p0 < npolys; p0 += NTT_MAXP) {
                 NttPtrs PT;
                 const size_t cnt = std::min<size_t>(NTT_MAXP, npolys - p0);
                 for (size_t i = 0; i < cnt; ++i) { PT.src[i] = (const uint32_t*)hs[p0 + i]; PT.dst[i] = (uint32_t*)all[npolys + p0 + i]; }
                 scq.tab_p0 = (uint32_t)p0;
-                if (r4)
-                    hipLaunchKernelGGL(tlog == 10 ? k_ntt_final_r4s : k_ntt_final_r4, dim3(blocks, (unsigned)cnt), dim3(rthreads), rlds, st, PT, m, s, logT, (uint32_t)n, tw,
-                                       scq, dg, z);
-                else
-                    hipLaunchKernelGGL(k_ntt_final_r8, dim3(blocks, (unsigned)cnt), dim3(256), NTT_TILE * sizeof(fe), st, PT, m, s, logT, (uint32_t)n, tw,
-                                       scq, dg, z);
+                hipLaunchKernelGGL(fk, dim3(blocks, (unsigned)cnt), dim3(rthreads), rlds, st, PT, m, s, logT, (uint32_t)n, tw, scq, dg, z);
             }
         } else
         hipLaunchKernelGGL(k_ntt_final, dim3(blocks, (unsigned)npolys), dim3(256), NTT_TILE * sizeof(fe), st, (const uint32_t* const*)cur_src,
