@@ -364,13 +364,25 @@ ZK_HD __forceinline__ el<P, mul2_bound(A, B, C, D)> muladd2(const el<P, A>& a, c
     return el<P, mul2_bound(A, B, C, D)>(fe_mul2_raw<P>(a.v, b.v, c.v, d.v));
 }
 // A difference / negation that is ONLY a multiplicand of the two-product accumulation needs no carry pass: ell<P, B> is a value
-// < (B / 16) p whose limbs are NOT normalised (each < 1.5 * 2^30: a normalised limb plus a borrow-spread constant).  Columns of
-// fe_mul2_raw with a normalised x lazy and a lazy x normalised product: 9 (1.5 * 2^59 + 2^59) + 9 * 2^58 = 27 * 2^59 < 2^64.
+// < (B / 16) p whose limbs are NOT normalised (each < 3 * 2^29: a normalised limb < 2^29 plus a borrow-spread constant <= 2^30).
+// Columns of fe_mul2_raw with a normalised x lazy and a lazy x normalised product: each of the 9 steps of a column adds at most
+// 2^29 * 3 * 2^29 (a x lazy b) + 3 * 2^29 * 2^29 (lazy c x d) + 2^29 * 2^29 (m x p) = 7 * 2^58, so a column stays below 63 * 2^58 =
+// 0.984 * 2^64 — under 2 % of headroom, which is why the limb bound of the spread constant is a static_assert and not a comment.
 // Not accepted by anything else (a squaring's or a subtraction's operand must be normalised).
+template <class P>
+ZK_HD constexpr bool kp_spread_fits(uint32_t k) {   // every limb of spread(k p) <= 2^30 (top limb: < 2^29, it carries no borrow constant)
+    for (int i = 0; i < 8; ++i)
+        if (kp_spread<P>(k, i) > (1u << 30)) return false;
+    return kp_spread<P>(k, 8) < (1u << LB);
+}
 template <class P, int B>
-struct ell { fe v; };
+struct ell {
+    static_assert(B >= 1 && B <= BMAX, "lazy bound out of range (value must stay below 2^261)");
+    fe v;
+};
 template <class P, int A, int B>
 ZK_HD __forceinline__ ell<P, A + (ceil_p(B) + 1) * U> sub_lazy(const el<P, A>& a, const el<P, B>& b) {
+    static_assert(kp_spread_fits<P>(ceil_p(B) + 1), "a limb of spread(k p) exceeds 2^30: the 63 * 2^58 column bound of the lazy muladd2 no longer holds");
     ell<P, A + (ceil_p(B) + 1) * U> r;
 #pragma unroll
     for (int i = 0; i < 9; ++i) r.v.l[i] = a.v.l[i] + kp_spread<P>(ceil_p(B) + 1, i) - b.v.l[i];
@@ -378,6 +390,7 @@ ZK_HD __forceinline__ ell<P, A + (ceil_p(B) + 1) * U> sub_lazy(const el<P, A>& a
 }
 template <class P, int B>
 ZK_HD __forceinline__ ell<P, (ceil_p(B) + 1) * U> neg_lazy(const el<P, B>& b) {
+    static_assert(kp_spread_fits<P>(ceil_p(B) + 1), "a limb of spread(k p) exceeds 2^30: the 63 * 2^58 column bound of the lazy muladd2 no longer holds");
     ell<P, (ceil_p(B) + 1) * U> r;
 #pragma unroll
     for (int i = 0; i < 9; ++i) r.v.l[i] = kp_spread<P>(ceil_p(B) + 1, i) - b.v.l[i];

@@ -44,9 +44,6 @@ struct Rccl {
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 Rccl g_rccl;
-// verdict of zkhip_comm_init's all-to-all self-check per context: 1 passed on every rank, -1 failed somewhere (kept here, not in the
-// context struct: common.hpp is part of the kernel-source hash that keys the committed counter profiles)
-std::map<const zkhip_ctx*, int> g_a2a_checked;
 int load_rccl() {
     if (g_rccl.lib) return ZKHIP_OK;
     const char* names[] = {"librccl.so", "librccl.so.1"};
@@ -224,12 +221,22 @@ int comm_alltoall(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t bytes
     ZK_HIP(hipStreamWaitEvent(cm.stream, cm.ev_in, 0));
     size_t received = 0;
     ZK_NCCL(g_rccl.GroupStart());
-    for (size_t r = 0; r < N; ++r) {
+    // an error inside the group must not leave it open (every later call on this thread would be deferred into it and never launched):
+    // remember the first one, close the group whatever happened, then report
+    ncclResult_t first = 0;
+    const char* what = "";
+    for (size_t r = 0; r < N && !first; ++r) {
         if ((int)r == cm.rank) continue;
-        if (!send_to || send_to[r]) ZK_NCCL(g_rccl.Send((const char*)d_send + r * bytes, bytes, ncclInt8, (int)r, c, cm.stream));
-        if (!recv_from || recv_from[r]) { ZK_NCCL(g_rccl.Recv((char*)d_recv + r * bytes, bytes, ncclInt8, (int)r, c, cm.stream)); received += bytes; }
+        if (!send_to || send_to[r]) { first = g_rccl.Send((const char*)d_send + r * bytes, bytes, ncclInt8, (int)r, c, cm.stream); what = "ncclSend"; }
+        if (!first && (!recv_from || recv_from[r])) { first = g_rccl.Recv((char*)d_recv + r * bytes, bytes, ncclInt8, (int)r, c, cm.stream); what = "ncclRecv"; received += bytes; }
     }
-    ZK_NCCL(g_rccl.GroupEnd());
+    const ncclResult_t closed = g_rccl.GroupEnd();
+    if (first || closed) {
+        const ncclResult_t rr = first ? first : closed;
+        set_error("zkhip_comm: %s failed inside the all-to-all group (collective #%llu): %s", first ? what : "ncclGroupEnd",
+                  (unsigned long long)cm.collectives + 1, g_rccl.GetErrorString ? g_rccl.GetErrorString(rr) : "rccl error");
+        return ZKHIP_EHIP;
+    }
     cm.bytes_gathered += received;
     cm.collectives += 1;
     return comm_allgather_end(ctx);
@@ -279,6 +286,7 @@ int zkhip_comm_init(zkhip_ctx* ctx, const uint8_t id[128], int rank, int nranks)
     }
     ctx->comm.rank = rank;
     ctx->comm.nranks = nranks;
+    if (nranks > 1) zk::g_watch.ctx = ctx;   // host waits of this context now have a deadline (common.hpp)
     // The grouped send / recv exchange (comm_alltoall) is what the row-sharded proof rides on, and no multi-GPU box was available to the
     // build: prove it on THIS communicator before any proof depends on it.  Every rank sends peer r the word (rank << 16 | r) in a
     // 64-byte block and checks what arrives; the verdicts are all-gathered (the primitive the round-2 path has always used) so that
@@ -287,36 +295,54 @@ int zkhip_comm_init(zkhip_ctx* ctx, const uint8_t id[128], int rank, int nranks)
         int ok = 1;
         void* d_buf = nullptr;
         const size_t blk = 64, N = (size_t)nranks;
-        if (hipMalloc(&d_buf, (2 * N + N) * blk) != hipSuccess) { (void)hipGetLastError(); ok = 0; }
+        if (zk::dev_malloc((void**)&d_buf, (2 * N + N) * blk) != hipSuccess) { (void)hipGetLastError(); ok = 0; }
         std::vector<uint32_t> h((2 * N + N) * blk / 4, 0);
         if (ok) {
             for (size_t r = 0; r < N; ++r) for (size_t w = 0; w < blk / 4; ++w) h[r * blk / 4 + w] = ((uint32_t)rank << 16) | (uint32_t)r;
             ok = hipMemcpy(d_buf, h.data(), (2 * N + N) * blk, hipMemcpyHostToDevice) == hipSuccess;
         }
         if (ok && (!g_rccl.Send || !g_rccl.Recv || !g_rccl.GroupStart || !g_rccl.GroupEnd)) ok = 0;
-        if (ok && comm_alltoall(ctx, d_buf, (char*)d_buf + N * blk, blk) != ZKHIP_OK) ok = 0;
-        if (ok) ok = hipStreamSynchronize(ctx->stream) == hipSuccess && hipMemcpy(h.data(), d_buf, (2 * N + N) * blk, hipMemcpyDeviceToHost) == hipSuccess;
+        if (ok && comm_alltoall(ctx, d_buf, (char*)d_buf + N * blk, blk) != ZKHIP_OK) {
+            // a send / recv / group call FAILED on this communicator (not: wrong bytes arrived).  Its state is unknown, so no verdict
+            // all-gather is issued on it: init fails here, with the RCCL error, and the peers run into their wait deadline.
+            std::string why = zkhip_last_error();
+            (void)hipFree(d_buf);
+            (void)zkhip_comm_destroy(ctx);
+            set_error("zkhip_comm_init: the all-to-all self-check could not be issued: %s", why.c_str());
+            return ZKHIP_EHIP;
+        }
+        if (ok) {
+            const hipError_t we = stream_wait(ctx->stream);
+            if (we == hipErrorLaunchTimeOut) {   // a peer never arrived: the communicator is unusable and the device is busy waiting on it — no destroy (it would block), just fail
+                set_error("zkhip_comm_init: the all-to-all self-check did not complete");
+                return ZKHIP_EHIP;
+            }
+            ok = we == hipSuccess && hipMemcpy(h.data(), d_buf, (2 * N + N) * blk, hipMemcpyDeviceToHost) == hipSuccess;
+        }
         for (size_t r = 0; ok && r < N; ++r)
             if ((int)r != rank && h[(N + r) * blk / 4] != (((uint32_t)r << 16) | (uint32_t)rank)) ok = 0;
         // agree: verdict of rank r at word r of the third region
         uint32_t mine = (uint32_t)ok;
         int all_ok = ok;
+        hipError_t we = hipSuccess;
         if (d_buf && hipMemcpy((char*)d_buf + (2 * N + (size_t)rank) * blk, &mine, 4, hipMemcpyHostToDevice) == hipSuccess &&
             comm_allgather(ctx, (char*)d_buf + (2 * N + (size_t)rank) * blk, (char*)d_buf + 2 * N * blk, blk) == ZKHIP_OK &&
-            hipStreamSynchronize(ctx->stream) == hipSuccess && hipMemcpy(h.data(), (char*)d_buf + 2 * N * blk, N * blk, hipMemcpyDeviceToHost) == hipSuccess) {
+            (we = stream_wait(ctx->stream)) == hipSuccess && hipMemcpy(h.data(), (char*)d_buf + 2 * N * blk, N * blk, hipMemcpyDeviceToHost) == hipSuccess) {
             for (size_t r = 0; r < N; ++r) all_ok = all_ok && h[r * blk / 4] == 1u;
         } else {
             all_ok = 0;   // (if even the all-gather fails the proofs will report it; the exchange mode no longer matters)
         }
+        if (we == hipErrorLaunchTimeOut) {   // a peer failed its init (see above) or died: this rank follows, loudly
+            set_error("zkhip_comm_init: the verdict all-gather of the self-check did not complete (a peer failed or left)");
+            return ZKHIP_EHIP;
+        }
         if (d_buf) (void)hipFree(d_buf);
         ctx->comm.bytes_gathered = 0;
         ctx->comm.collectives = 0;
-        if (!all_ok) {
-            ctx->opt.row_sharded = 0;
-            fprintf(stderr, "zkhip_comm_init: the all-to-all self-check failed on some rank (this rank: %s): falling back to the all-gather exchange (row_sharded = 0)\n",
+        if (!all_ok)
+            fprintf(stderr, "zkhip_comm_init: the all-to-all self-check failed on some rank (this rank: %s): this communicator uses the all-gather exchange\n",
                     ok ? "ok" : "FAILED");
-        }
-        g_a2a_checked[ctx] = all_ok ? 1 : -1;
+        ctx->comm.a2a_ok = all_ok ? 1 : -1;   // lives and dies with the communicator; the user's row_sharded option is left alone
     }
     return ZKHIP_OK;
 }
@@ -328,6 +354,7 @@ int zkhip_comm_init_host(zkhip_ctx* ctx, int rank, int nranks, zkhip_host_allgat
     ctx->comm.host_user = user;
     ctx->comm.rank = rank;
     ctx->comm.nranks = nranks;
+    if (nranks > 1) zk::g_watch.ctx = ctx;
     return ZKHIP_OK;
 }
 
@@ -349,7 +376,7 @@ int zkhip_comm_destroy(zkhip_ctx* ctx) {
     if (cm.ev_out) (void)hipEventDestroy(cm.ev_out);
     if (cm.stage) (void)hipHostFree(cm.stage);
     cm = zkhip_comm();
-    g_a2a_checked.erase(ctx);
+    if (zk::g_watch.ctx == ctx) zk::g_watch.ctx = nullptr;
     return ZKHIP_OK;
 }
 
@@ -372,8 +399,7 @@ int zkhip_comm_info(const zkhip_ctx* ctx, int* rank, int* nranks, uint64_t* byte
 int zkhip_comm_describe(const zkhip_ctx* ctx, char* transport, size_t cap, int* transport_ranks, uint64_t* collectives) {
     if (!ctx) { set_error("null ctx"); return ZKHIP_EINVAL; }
     const zkhip_comm& cm = ctx->comm;
-    const auto chk = g_a2a_checked.find(ctx);
-    const char* t = cm.nccl ? (chk != g_a2a_checked.end() && chk->second < 0 ? "rccl (all-to-all self-check failed: all-gather exchange)" : "rccl")
+    const char* t = cm.nccl ? (cm.a2a_ok < 0 ? "rccl (all-to-all self-check failed: all-gather exchange)" : "rccl")
                             : (cm.host_allgather ? "host" : "none");
     if (transport && cap) { strncpy(transport, t, cap - 1); transport[cap - 1] = 0; }
     if (transport_ranks) {

@@ -35,6 +35,12 @@ void set_error(const char* fmt, ...);
 
 #define ZK_LAUNCH_CHECK() ZK_HIP(hipGetLastError())
 
+// every device allocation of the library goes through here: the time spent inside hipMalloc is what a cold process pays before its
+// first proof (58 GB at k = 22), and zkhip_profile_counter("alloc_us" / "alloc_bytes" / "alloc_calls") reports it
+struct AllocStats { uint64_t ns = 0, bytes = 0, calls = 0; };
+extern AllocStats g_alloc;   // ctx.hip
+hipError_t dev_malloc(void** p, size_t bytes);
+
 // Named scratch buffers owned by the context, grown on demand and reused across calls so the hot
 // path never calls hipMalloc (MI355X has 288 GB: scratch is sized for the largest call seen).
 struct Scratch {
@@ -53,6 +59,7 @@ struct zkhip_options {
     int permute_rank_sort = 1, eval_byval = 1, late_overlap = -1;
     int host_timing = 0;   // zkhip_create_proof prints its host-side phase times to stderr
     int row_sharded = 1;      // multi-rank proofs on the coset path: all-to-all of row windows (1) / all-gather of complete columns (0)
+    int comm_timeout_ms = 120000;   // host waits of a multi-rank context give up after this long (0: wait for ever): see zk::CommWatch
     int coset_quotient = 1;   // zkhip_create_proof evaluates the quotient on quotient_poly_degree cosets of size n (cosets.hip) when that is fewer rows
 };
 
@@ -72,6 +79,11 @@ struct zkhip_comm {
     uint64_t bytes_gathered = 0;  // bytes this rank received through RCCL all-gathers
     uint64_t collectives = 0;     // exchanges issued so far
     int shard_columns = 0;        // MSMs over whole-SRS handles: 1 = split the batch by column over the ranks, 0 = replicate
+    int a2a_ok = 0;               // verdict of zkhip_comm_init's all-to-all self-check: 1 passed on every rank, -1 failed somewhere, 0 not run
+    const char* phase = "";       // which part of the proof the host is issuing (what a timed-out wait reports)
+    // the exchange a multi-rank proof uses: row windows by grouped send / recv only where the user asked for it AND this communicator
+    // has shown it can do it (the user's option itself is never overwritten)
+    bool row_sharded(const zkhip_options& o) const { return o.row_sharded != 0 && a2a_ok >= 0; }
 };
 
 struct zkhip_ctx {
@@ -140,15 +152,25 @@ struct ProfScope {
     ~ProfScope() { if (active) c->prof_end(); }
 };
 
+// A context with a communicator waits for its peers whenever it waits for its own stream: a collective whose partner never arrives
+// (a rank that died, an RCCL that cannot connect two GPUs) would leave the host in hipStreamSynchronize for ever.  While a communicator
+// exists the slow path of the two waits below is therefore a poll with a deadline (zkhip_options::comm_timeout_ms); on expiry the wait
+// fails with hipErrorLaunchTimeOut and the error text names the rank, the number of collectives issued so far and the phase of the proof.
+namespace zk {
+struct CommWatch { const zkhip_ctx* ctx = nullptr; };
+extern CommWatch g_watch;                                  // ctx.hip; set by zkhip_comm_init*, cleared by zkhip_comm_destroy
+hipError_t wait_slow(hipStream_t st, hipEvent_t ev);       // ctx.hip: the blocking wait, or the deadline poll when g_watch.ctx is set
+}
+
 // Waits for a stream by polling: hipStreamSynchronize sleeps on an interrupt and wakes tens of microseconds late, and the prover
-// has a dozen Fiat-Shamir round trips per proof on its critical path.  Bounded spin, then the blocking wait.
+// has a dozen Fiat-Shamir round trips per proof on its critical path.  Bounded spin, then the slow wait.
 static inline hipError_t stream_wait(hipStream_t st) {
     for (int i = 0; i < 2000000; ++i) {
         hipError_t e = hipStreamQuery(st);
         if (e != hipErrorNotReady) return e;
     }
     (void)hipGetLastError();
-    return hipStreamSynchronize(st);
+    return zk::wait_slow(st, nullptr);
 }
 
 // Waits (polling) for an event recorded right after a small read-back, not for the whole stream: the kernels issued after the
@@ -159,7 +181,7 @@ static inline hipError_t event_wait(hipEvent_t ev) {
         if (e != hipErrorNotReady) return e;
     }
     (void)hipGetLastError();
-    return hipEventSynchronize(ev);
+    return zk::wait_slow(nullptr, ev);
 }
 
 struct zkhip_domain;
@@ -201,6 +223,9 @@ int cosets_combine_range(zkhip_ctx* ctx, const CosetPlan* p, const void* d_vals,
 struct KeyCosets { std::vector<const void*> fixed, sigma; const void* l0; const void* l_last; const void* l_active; };
 int key_cosets(zkhip_ctx* ctx, const CosetPlan* p, const zk_proving_key* pk, const KeyCosets** out);
 void coset_sweep_view(const CosetPlan* p, SweepCosets* out);
+int shplonk_open(zkhip_ctx* ctx, const zkhip_srs* srs, size_t n, const void* const* d_polys, size_t npolys, const uint32_t* query_poly,
+                 const uint64_t* query_points, const uint64_t* query_evals, size_t nq, const zk_transcript* tr, uint64_t h1_xy[8], uint64_t h2_xy[8],
+                 bool rows_only);   // shplonk.hip: zkhip_shplonk_open; rows_only = the polynomials exist as this rank's row range only
 void coset_forget_key(zkhip_ctx* ctx, uint64_t key_id);   // the plans' host-side entries of a released key (the device buffers are the caller's to free)
 }
 static inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }

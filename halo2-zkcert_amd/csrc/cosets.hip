@@ -51,7 +51,7 @@ struct PendingBuffer {
     int alloc(size_t bytes) {
         auto old = ctx->persistent.find(name);   // a stale entry (no host-side object refers to it, or we would not be here)
         if (old != ctx->persistent.end()) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(old->second); ctx->persistent.erase(old); }
-        hipError_t e = hipMalloc(&ptr, bytes);
+        hipError_t e = zk::dev_malloc((void**)&ptr, bytes);
         if (e != hipSuccess) { (void)hipGetLastError(); ptr = nullptr; set_error("hipMalloc(%zu) for %s failed: %s", bytes, name.c_str(), hipGetErrorString(e)); return ZKHIP_ENOMEM; }
         return ZKHIP_OK;
     }

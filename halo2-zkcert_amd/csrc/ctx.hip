@@ -4,13 +4,54 @@
 #include "common.hpp"
 #include "hostfield.hpp"
 
+#include <chrono>
+#include <thread>
+
 namespace zk {
-static thread_local char g_err[512] = "";
+static thread_local char g_err[768] = "";
+static thread_local char g_stuck[256] = "";   // what a timed-out wait found (appended to the error the failing call reports)
 void set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
-    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    int len = vsnprintf(g_err, sizeof g_err, fmt, ap);
     va_end(ap);
+    if (g_stuck[0] && len >= 0 && (size_t)len < sizeof g_err) {
+        snprintf(g_err + len, sizeof g_err - (size_t)len, " [%s]", g_stuck);
+        g_stuck[0] = 0;
+    }
+}
+
+AllocStats g_alloc;
+hipError_t dev_malloc(void** p, size_t bytes) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const hipError_t e = hipMalloc(p, bytes);
+    g_alloc.ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    g_alloc.bytes += bytes;
+    g_alloc.calls += 1;
+    return e;
+}
+
+CommWatch g_watch;
+hipError_t wait_slow(hipStream_t st, hipEvent_t ev) {
+    const zkhip_ctx* c = g_watch.ctx;
+    const int limit_ms = c ? c->opt.comm_timeout_ms : 0;
+    if (limit_ms <= 0) return st ? hipStreamSynchronize(st) : hipEventSynchronize(ev);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        for (int i = 0; i < 64; ++i) {
+            hipError_t e = st ? hipStreamQuery(st) : hipEventQuery(ev);
+            if (e != hipErrorNotReady) return e;
+        }
+        (void)hipGetLastError();
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (ms > (double)limit_ms) {
+            snprintf(g_stuck, sizeof g_stuck, "rank %d of %d stuck after collective #%llu, phase '%s': no progress on the device for %d ms (comm_timeout_ms)",
+                     c->comm.rank, c->comm.nranks, (unsigned long long)c->comm.collectives, c->comm.phase ? c->comm.phase : "", limit_ms);
+            fprintf(stderr, "zkhip: %s\n", g_stuck);
+            return hipErrorLaunchTimeOut;
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
 }
 }  // namespace zk
 using namespace zk;
@@ -28,7 +69,7 @@ int zkhip_ctx::get_scratch(const char* name, size_t bytes, void** out) {
             s.bytes = 0;
         }
         size_t want = bytes + bytes / 8;
-        hipError_t e = hipMalloc(&s.ptr, want);
+        hipError_t e = zk::dev_malloc((void**)&s.ptr, want);
         if (e != hipSuccess) {
             (void)hipGetLastError();
             s.ptr = nullptr;
@@ -90,6 +131,9 @@ int zkhip_profile_counter(zkhip_ctx* c, const char* name, uint64_t* value) {
     if (!c || !name || !value) { set_error("zkhip_profile_counter: null argument"); return ZKHIP_EINVAL; }
     if (strcmp(name, "msm_pairs") == 0) *value = c->prof_msm_pairs;
     else if (strcmp(name, "msm_dense_pairs") == 0) *value = c->prof_msm_dense_pairs;
+    else if (strcmp(name, "alloc_us") == 0) *value = zk::g_alloc.ns / 1000;              // process-wide: time inside hipMalloc, bytes, calls
+    else if (strcmp(name, "alloc_bytes") == 0) *value = zk::g_alloc.bytes;
+    else if (strcmp(name, "alloc_calls") == 0) *value = zk::g_alloc.calls;
     else if (strcmp(name, "proofs_row_sharded") == 0) *value = c->n_row_sharded;         // always counted (not only while profiling)
     else if (strcmp(name, "proofs_pieces_sharded") == 0) *value = c->n_pieces_sharded;
     else if (strcmp(name, "shplonk_row_sharded") == 0) *value = c->n_shplonk_sharded;
@@ -131,6 +175,7 @@ const OptName OPTIONS[] = {
     {"ZKHIP_EVAL_BYVAL", "eval_byval", &zkhip_options::eval_byval}, {"ZKHIP_LATE_OVERLAP", "late_overlap", &zkhip_options::late_overlap},
     {"ZKHIP_HOST_TIMING", "host_timing", &zkhip_options::host_timing},
     {"ZKHIP_COSET_QUOTIENT", "coset_quotient", &zkhip_options::coset_quotient}, {"ZKHIP_ROW_SHARDED", "row_sharded", &zkhip_options::row_sharded},
+    {"ZKHIP_COMM_TIMEOUT_MS", "comm_timeout_ms", &zkhip_options::comm_timeout_ms},
 };
 }  // namespace
 
@@ -246,7 +291,7 @@ int zkhip_synchronize(zkhip_ctx* c) {
 }
 int zkhip_malloc(zkhip_ctx* c, size_t bytes, void** dptr) {
     if (!c || !dptr) { set_error("zkhip_malloc: bad argument"); return ZKHIP_EINVAL; }
-    hipError_t e = hipMalloc(dptr, bytes ? bytes : 16);
+    hipError_t e = zk::dev_malloc((void**)dptr, bytes ? bytes : 16);
     if (e != hipSuccess) { (void)hipGetLastError(); set_error("hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); return ZKHIP_ENOMEM; }
     return ZKHIP_OK;
 }

@@ -131,7 +131,7 @@ static int srs_build(zkhip_ctx* ctx, const void* d_bases, size_t n, zkhip_srs** 
     s->W = (255 + s->c - 1) / s->c;
     s->B = 1u << (s->c - 1);
     if ((size_t)s->W * n >= ((size_t)1 << 31)) { delete s; set_error("zkhip_srs_load: W*n overflows the 31-bit pair index"); return ZKHIP_EINVAL; }
-    hipError_t e = hipMalloc(&s->d_table, (size_t)s->W * n * 64);
+    hipError_t e = zk::dev_malloc((void**)&s->d_table, (size_t)s->W * n * 64);
     if (e != hipSuccess) { (void)hipGetLastError(); delete s; set_error("hipMalloc SRS table (%zu B): %s", (size_t)s->W * n * 64, hipGetErrorString(e)); return ZKHIP_ENOMEM; }
     void *ja, *jb;
     int rc = ctx->get_scratch("srs_jac_a", n * 96, &ja);

@@ -57,7 +57,7 @@ int zkhip_ctx::get_twiddles(const uint64_t omega[4], uint32_t log_n, const Twidd
     t.bf_bits = log_n >= 1 ? std::min<uint32_t>(10, log_n - 1) : 0;
     size_t n_lo = (size_t)1 << t.h, n_hi = (size_t)1 << (log_n - t.h), n_bf = (size_t)1 << t.bf_bits;
     void* base;
-    hipError_t e = hipMalloc(&base, (n_lo + n_hi + n_bf) * 32);
+    hipError_t e = zk::dev_malloc((void**)&base, (n_lo + n_hi + n_bf) * 32);
     if (e != hipSuccess) { (void)hipGetLastError(); set_error("hipMalloc twiddles: %s", hipGetErrorString(e)); return ZKHIP_ENOMEM; }
     t.d_lo = base;
     t.d_hi = (char*)base + n_lo * 32;
@@ -534,7 +534,7 @@ static int pass_twiddles(zkhip_ctx* ctx, const zkhip_ctx::Twiddle* twh, const Tw
     if (it != ctx->persistent.end()) { *out = it->second; return ZKHIP_OK; }
     uint32_t count = 1u << (s + lo_bits), hi_bits = twh->log_n - s - lo_bits;
     void* d;
-    hipError_t e = hipMalloc(&d, (size_t)count * 32);
+    hipError_t e = zk::dev_malloc((void**)&d, (size_t)count * 32);
     if (e != hipSuccess) { (void)hipGetLastError(); set_error("hipMalloc pass twiddles: %s", hipGetErrorString(e)); return ZKHIP_ENOMEM; }
     hipLaunchKernelGGL(k_pass_twiddles, dim3(div_up((size_t)count, 256)), dim3(256), 0, ctx->stream, (uint32_t*)d, count, lo_bits, hi_bits, tw);
     ZK_LAUNCH_CHECK();
@@ -771,7 +771,7 @@ int zkhip_domain_new(zkhip_ctx* ctx, uint32_t j, uint32_t k, const uint64_t g_co
         tev[i] = fe_pack(fe_canonical<Fr>(inv<Fr>(reduce(cur - one<Fr>())).v));
         cur = cur * step;
     }
-    hipError_t e = hipMalloc(&d->d_t_evaluations, d->n_t * 32);
+    hipError_t e = zk::dev_malloc((void**)&d->d_t_evaluations, d->n_t * 32);
     if (e != hipSuccess) { (void)hipGetLastError(); delete d; set_error("hipMalloc t_evaluations: %s", hipGetErrorString(e)); return ZKHIP_ENOMEM; }
     ZK_HIP(hipMemcpyAsync(d->d_t_evaluations, tev.data(), d->n_t * 32, hipMemcpyHostToDevice, ctx->stream));
     ZK_HIP(hipStreamSynchronize(ctx->stream));

@@ -295,7 +295,7 @@ int zk::permute_sorted_table_keys(zkhip_ctx* ctx, uint64_t key_id, uint32_t slot
     if (it != ctx->persistent.end()) { *d_keys = it->second; return ZKHIP_OK; }
     size_t n = (size_t)1 << k, np = std::max(n, (size_t)BT_TILE), usable = n - (blinding_factors + 1);
     void* d = nullptr;
-    hipError_t e = hipMalloc(&d, np * 32);
+    hipError_t e = zk::dev_malloc((void**)&d, np * 32);
     if (e != hipSuccess) { (void)hipGetLastError(); set_error("hipMalloc(%zu) for the sorted table keys failed: %s", np * 32, hipGetErrorString(e)); return ZKHIP_ENOMEM; }
     hipLaunchKernelGGL(k_pe_keys, dim3(div_up(np, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)d_table, np, usable, (uint32_t*)d);
     int rc = bitonic_sort(ctx, d, np, 1);

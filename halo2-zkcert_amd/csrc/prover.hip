@@ -97,6 +97,7 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
     const bool timing = ctx->opt.host_timing != 0;
     auto mark = [&](const char* what) { if (timing) marks.push_back({what, std::chrono::steady_clock::now()}); };
     mark("start");
+    ctx->comm.phase = "advice";
     if (!pk->g || !pk->g_lagrange || !pk->domain) { set_error("zkhip_create_proof: proving key without SRS / domain"); return ZKHIP_EINVAL; }
     const uint32_t k = pk->k, bf = pk->blinding_factors;
     const size_t n = (size_t)1 << k;
@@ -249,7 +250,7 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
     scan_rots(pk->custom_gates);
     for (uint32_t i = 0; i < L; ++i) scan_rots(pk->lookup_graphs[i]);
     const size_t m_rows = n / NR;
-    const bool row_mode = dist && coset_mode && ctx->opt.row_sharded != 0 && n % (NR * 64) == 0 && 2 * (size_t)halo < m_rows;
+    const bool row_mode = dist && coset_mode && ctx->comm.row_sharded(ctx->opt) && n % (NR * 64) == 0 && 2 * (size_t)halo < m_rows;
     // With MSMs by point range a commitment reads only this rank's rows of a column: the quotient's pieces, h(X) and SHPLONK's polynomials
     // then never need to be complete anywhere (shplonk.hip makes the same test on the SRS handle).
     bool pieces_sharded = false;
@@ -442,6 +443,7 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
     mark("advice committed + absorbed");
     tr->squeeze_challenge(tr->user, ch);
     mark("theta");
+    ctx->comm.phase = "lookup permute";
     uint64_t theta[4];
     memcpy(theta, ch, 32);
 
@@ -510,6 +512,7 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
     tr->squeeze_challenge(tr->user, beta);
     tr->squeeze_challenge(tr->user, gamma);
     mark("beta gamma");
+    ctx->comm.phase = "grand products";
 
     // ---- 3. grand products: permutation sets, then lookups; commitments in coefficient form
     std::vector<void*> z_ptrs(Zp + L), ext_z(Zp + L);   // [perm sets..., lookups...]
@@ -562,6 +565,7 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
     uint64_t y[4];
     tr->squeeze_challenge(tr->user, y);
     mark("y");
+    ctx->comm.phase = "quotient";
 
     // ---- 5. quotient: sweep over the extended coset, division by the vanishing polynomial, back to coefficients, pieces
     ZK_TRY(ov.join());
@@ -680,6 +684,7 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
     mark("quotient committed + absorbed");
     tr->squeeze_challenge(tr->user, ch);
     mark("x");
+    ctx->comm.phase = "evaluations";
     const HF x = hf_from_abi(ch);
 
     // ---- 5b. evaluations at x * omega^rotation in upstream's query order; h(X) = sum_i x^(n i) h_i(X)
@@ -754,7 +759,7 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
         char* ev_out = w_evals;
         const bool ev_pinned = nq * 32 + 32768 + 64 <= zkhip_ctx::PINNED_BYTES;
         if (ev_pinned) ev_out = (char*)ctx->h_pinned + 32768;
-        if (dist && ((ctx->opt.row_sharded != 0 && nq >= 2 * NR) || pieces_sharded)) {   // (with sharded pieces h(X) exists as row ranges only: always this form)
+        if (dist && ((ctx->comm.row_sharded(ctx->opt) && nq >= 2 * NR) || pieces_sharded)) {   // (with sharded pieces h(X) exists as row ranges only: always this form)
             // the evaluations are independent: rank r evaluates queries r, r + NR, ... (the 32-byte results are all-gathered, padded to the
             // same count per rank, and put back in query order).  h(X) exists only as row ranges when the pieces are sharded: every rank
             // evaluates ITS rows as a polynomial of degree < m (one more slot per rank) and h(x) = sum_R x^(R m) P_R(x) is put together here.
@@ -820,6 +825,7 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
     mark("evaluations read back");
     for (uint32_t i : w_order) tr->write_scalar(tr->user, q_evals.data() + 4 * (size_t)i);   // h(x) is not written: the verifier recomputes it
     mark("evaluations absorbed");
+    ctx->comm.phase = "shplonk";
     if (out) {
         out->d_h = w_h;
         out->n_evals = nq;
@@ -830,13 +836,14 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
     }
     // ---- 6. SHPLONK multi-open of all of them
     uint64_t h1[8], h2[8];
-    ZK_TRY(zkhip_shplonk_open(ctx, pk->g, n, polys.data(), polys.size(), q_poly.data(), q_points.data(), q_evals.data(), nq, tr, h1, h2));
+    ZK_TRY(zk::shplonk_open(ctx, pk->g, n, polys.data(), polys.size(), q_poly.data(), q_points.data(), q_evals.data(), nq, tr, h1, h2, pieces_sharded));
     mark("shplonk done");
     if (timing) {
         for (size_t i = 1; i < marks.size(); ++i)
             fprintf(stderr, "  %8.1f us  (+%7.1f)  %s\n", std::chrono::duration<double, std::micro>(marks[i].t - marks[0].t).count(),
                     std::chrono::duration<double, std::micro>(marks[i].t - marks[i - 1].t).count(), marks[i].what);
     }
+    ctx->comm.phase = "";
     guard.done = true;
     return ZKHIP_OK;
 }

@@ -288,11 +288,11 @@ struct RotSet {
 };
 }  // namespace
 
-extern "C" {
-
-int zkhip_shplonk_open(zkhip_ctx* ctx, const zkhip_srs* srs, size_t n, const void* const* d_polys, size_t npolys, const uint32_t* query_poly,
-                       const uint64_t* query_points, const uint64_t* query_evals, size_t nq, const zk_transcript* tr, uint64_t h1_xy[8],
-                       uint64_t h2_xy[8]) {
+// rows_only: the caller's polynomials exist as THIS RANK'S ROW RANGE only (zkhip_create_proof_ex with sharded pieces): the row-sharded
+// form below is then not a choice but a precondition, and the call fails instead of reading rows nobody filled.
+int zk::shplonk_open(zkhip_ctx* ctx, const zkhip_srs* srs, size_t n, const void* const* d_polys, size_t npolys, const uint32_t* query_poly,
+                     const uint64_t* query_points, const uint64_t* query_evals, size_t nq, const zk_transcript* tr, uint64_t h1_xy[8],
+                     uint64_t h2_xy[8], bool rows_only) {
     if (!ctx || !srs || !d_polys || !query_poly || !query_points || !query_evals || !tr || !tr->write_point || !tr->squeeze_challenge || !h1_xy || !h2_xy) {
         set_error("zkhip_shplonk_open: null argument");
         return ZKHIP_EINVAL;
@@ -308,12 +308,18 @@ int zkhip_shplonk_open(zkhip_ctx* ctx, const zkhip_srs* srs, size_t n, const voi
         size_t s_first, s_count, s_total;
         zkhip_srs_range(srs, &s_first, &s_count, &s_total);
         const size_t NR = (size_t)ctx->comm.nranks, RK = (size_t)ctx->comm.rank;
-        if (NR > 1 && ctx->opt.row_sharded != 0 && !ctx->comm.shard_columns && n % NR == 0 && s_total == n && s_count == n / NR && s_first == RK * (n / NR) &&
+        if (NR > 1 && ctx->comm.row_sharded(ctx->opt) && !ctx->comm.shard_columns && n % NR == 0 && s_total == n && s_count == n / NR && s_first == RK * (n / NR) &&
             n / NR >= 64) {
             sharded = true;
             ctx->n_shplonk_sharded += 1;
             nl = n / NR;
             lo = RK * nl;
+        }
+        if (rows_only && !sharded) {
+            set_error("zkhip_shplonk_open: the polynomials exist as row ranges only, but this context / SRS handle does not select the row-sharded multi-open "
+                      "(ranks %zu, row_sharded %d, shard_columns %d, SRS range [%zu, +%zu) of %zu, n %zu)", NR, (int)ctx->comm.row_sharded(ctx->opt),
+                      ctx->comm.shard_columns, s_first, s_count, s_total, n);
+            return ZKHIP_EINVAL;
         }
     }
     const size_t lo_b = lo * 32;
@@ -503,6 +509,14 @@ int zkhip_shplonk_open(zkhip_ctx* ctx, const zkhip_srs* srs, size_t n, const voi
         tr->write_point(tr->user, bytes, h2_xy);
     }
     return ZKHIP_OK;
+}
+
+extern "C" {
+
+int zkhip_shplonk_open(zkhip_ctx* ctx, const zkhip_srs* srs, size_t n, const void* const* d_polys, size_t npolys, const uint32_t* query_poly,
+                       const uint64_t* query_points, const uint64_t* query_evals, size_t nq, const zk_transcript* tr, uint64_t h1_xy[8],
+                       uint64_t h2_xy[8]) {
+    return zk::shplonk_open(ctx, srs, n, d_polys, npolys, query_poly, query_points, query_evals, nq, tr, h1_xy, h2_xy, false);
 }
 
 int zkhip_linear_combination_device(zkhip_ctx* ctx, size_t n, const void* const* d_polys, size_t npolys, const uint64_t* coeffs,
