@@ -14,7 +14,12 @@ north-star target is stated on; /root/reference/src/bin/cli.rs:464-527).  `confi
 each timed with its own steps / warm-ups and its own rooflines: RSA k = 17 and zkevm-SHA256-shaped k = 19 under the Poseidon
 transcript (what gen_snark_shplonk uses, cli.rs:320,369), aggregation k = 22 under Keccak.  --config picks another headline.
 
-N > 1 (one process per GPU, RCCL): ONE k = 22 proof sharded over the ranks — every MSM by point range (window tables sharded 1/N),
+N > 1: the N processes torch.distributed.run starts (the driver's launch line, or `python bench.py --gpus N` on its own) are GPU-free
+SUPERVISORS: each runs the real rank as a child process with a wall-clock budget, and together they walk a ladder of fresh worker sets
+(row-sharded -> all-gather exchange -> MSMs by column -> independent proofs) until one rung completes on every rank; the line says which
+rung it is (`ladder`, `comm_note`) and the run fails only if every rung does.  Inside the library every host wait of a multi-rank context
+has a deadline (comm_timeout_ms), so a rank stuck in a collective dies loudly instead of spinning.
+The workers (one process per GPU, RCCL): ONE k = 22 proof sharded over the ranks — every MSM by point range (window tables sharded 1/N),
 coset NTTs by polynomial, the quotient sweep by row range; partial sums / columns / h exchanged with ncclAllGather inside the library
 (zkhip_comm_*), everything else replicated -> "scaling": "strong".  --replicas runs N independent proofs instead ("weak");
 --chain runs BASELINE configs[4] (2 x RSA + 2 x SHA leaf proofs on 4 ranks, barrier, then the sharded aggregation proof).
@@ -134,22 +139,258 @@ def cpu_pass_seconds(pv, shape, transcript, threads, repeats=3, warm=True):
     return statistics.median(ts), ts
 
 
-def self_launch(n):
-    """python -m torch.distributed.run --nnodes=1 --nproc-per-node n --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>
-    as a child process; -> its exit code (a rank that fails makes torchrun, and therefore this run, fail)."""
+def recorded_cpu_k22():
+    """profiles/r04_cpu_k22.json: ONE process on the GPU box's host cores that timed the CPU oracle on the headline shape at k = 18, 20 and 22
+    (bench.py --cpu-baseline-k 22) -> dict or None"""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r04_cpu_k22.json")))["cpu_baseline"]
+        return d if d.get("measured_k") == 22 else None
+    except Exception:   # noqa: BLE001
+        return None
+
+
+def cpu_baseline(pv, args, config, head_k, transcript):
+    """The CPU leg of the line: the same schedule on oracle/zkoracle.c (OpenMP, all usable host cores), SRS / keygen excluded.  GPU-free.
+    The headline is k = 22: one CPU pass at that size takes two minutes, so the default run MEASURES the same circuit shape and transcript at
+    k = 20 (one full pass) and k = 18 (median of 3 after a warm-up) — a bounded sample — and carries the k = 20 figure to k = 22 with the
+    k = 20 -> 22 time ratio of the recorded real pass (profiles/r04_cpu_k22.json, same box kind, quoted beside it as measured_at_k22); without
+    a record, with the measured k = 18 -> 20 growth.  --cpu-baseline-k 22 times real passes at all three sizes (scale 1).
+    -> (dict for the line, dict for configs.rsa17 or None)"""
+    threads = host_threads()
+
+    def shape_at(k_):
+        return make_shape(pv, config, argparse.Namespace(**{**vars(args), "agg_k": k_}))
+    if config == "agg22" and head_k > 18:
+        k_m = max(19, min(head_k, args.cpu_baseline_k))
+        med18, ts18 = cpu_pass_seconds(pv, shape_at(18), transcript, threads)
+        t20 = None
+        if k_m > 20:
+            t20, _ = cpu_pass_seconds(pv, shape_at(20), transcript, threads, repeats=1, warm=False)
+        t_m, _ = cpu_pass_seconds(pv, shape_at(k_m), transcript, threads, repeats=1, warm=False)
+        per4 = (t_m / med18) ** (2.0 / (k_m - 18))          # measured growth per 4x rows
+        rec = recorded_cpu_k22() if head_k == 22 else None
+        if k_m == head_k:
+            scale, how = 1.0, "a real pass at the headline size"
+        elif rec and k_m == 20 and rec.get("k20_s") and rec.get("cores") == threads:
+            scale = rec["value"] / rec["k20_s"]
+            how = f"x{scale:.3f} = the k = 22 / k = 20 time ratio of the recorded real passes (profiles/r04_cpu_k22.json: {rec['value']:.1f} s / {rec['k20_s']:.1f} s on {rec['cores']} cores)"
+        else:
+            scale = per4 ** ((head_k - k_m) / 2.0)
+            how = f"x{scale:.3f} = the measured k = 18 -> {k_m} growth carried to k = {head_k}"
+        out = dict(value=round(t_m * scale, 4), unit="s", cores=threads, kind="port", measured_s=round(t_m, 4), scale=round(scale, 4),
+                   sample=f"{shape_at(k_m).name}: ONE full pass at k = {k_m} = {t_m:.3f} s; the same shape at k = 18: median of 3 after a warm-up = "
+                          f"{med18:.3f} s ({', '.join(f'{t:.3f}' for t in ts18)}); measured growth per 4x rows = {per4:.3f}; {how}"
+                          "; oracle/zkoracle.c with OpenMP, SRS / keygen excluded",
+                   measured_k=k_m, k18_s=round(med18, 4), growth_per_4x_rows=round(per4, 4))
+        if t20 is not None:
+            out["k20_s"] = round(t20, 4)
+        if rec and k_m != head_k:
+            out["measured_at_k22"] = dict(value=rec["value"], unit="s", cores=rec["cores"], k20_s=rec.get("k20_s"), k18_s=rec.get("k18_s"),
+                                          source="profiles/r04_cpu_k22.json (one real pass of this shape at k = 22 on the GPU box's host cores, round 4)")
+    else:
+        sh = shape_at(head_k) if config == "agg22" else make_shape(pv, config, args)
+        med, ts = cpu_pass_seconds(pv, sh, transcript, threads)
+        out = dict(value=round(med, 4), unit="s", cores=threads, kind="port", measured_s=round(med, 4), scale=1.0,
+                   sample=f"{sh.name}: median of 3 full passes after a warm-up ({', '.join(f'{t:.3f}' for t in ts)}); "
+                          "oracle/zkoracle.c with OpenMP, SRS / keygen excluded")
+    rsa = None
+    if config != "rsa17" and not args.no_other_configs and args.gpus == 1 and not args.chain:
+        med17, ts17 = cpu_pass_seconds(pv, pv.CircuitShape.rsa(17), "poseidon", threads)
+        rsa = dict(value=round(med17, 4), unit="s", cores=threads, kind="port",
+                   sample=f"rsa_k17: median of 3 full passes after a warm-up ({', '.join(f'{t:.3f}' for t in ts17)})")
+    return out, rsa
+
+
+def chain_cpu_baseline(pv, args):
+    """BASELINE configs[4] on the CPU oracle: the five proofs one after the other.  Bounded sample: the RSA k = 17 proof (median of 3), ONE
+    pass of the SHA-shaped k = 19 proof, and the aggregation proof as cpu_baseline() samples it; value = 2 x rsa + 2 x sha + agg."""
+    threads = host_threads()
+    agg, _ = cpu_baseline(pv, args, "agg22", args.agg_k, "evm")
+    med17, _ = cpu_pass_seconds(pv, pv.CircuitShape.rsa(17), "poseidon", threads)
+    t19, _ = cpu_pass_seconds(pv, make_shape(pv, "sha19", args), "poseidon", threads, repeats=1, warm=False)
+    return dict(value=round(2 * med17 + 2 * t19 + agg["value"], 4), unit="s", cores=threads, kind="port",
+                sample=f"2 x rsa_k17 ({med17:.3f} s, median of 3) + 2 x sha256_k19 ({t19:.3f} s, one pass) + the aggregation proof ({agg['value']:.3f} s: {agg['sample']})",
+                parts=dict(rsa17_s=round(med17, 4), sha19_s=round(t19, 4), agg=agg))
+
+
+LADDER = {
+    # one sharded proof: each rung is a FRESH set of worker processes (a rank that touched the GPU is never reused or exec'ed over)
+    "shard": [("row-sharded (all-to-all of row windows, torch control plane on RCCL)", [], {}),
+              ("all-gather exchange (row_sharded = 0), torch control plane on gloo", [], {"ZKHIP_ROW_SHARDED": "0", "ZKHIP_BENCH_DIST_BACKEND": "gloo"}),
+              ("MSMs by column, whole tables on every rank", ["--shard", "columns"], {"ZKHIP_ROW_SHARDED": "0", "ZKHIP_BENCH_DIST_BACKEND": "gloo"}),
+              ("independent proofs, one per GPU (no collective on the data path)", ["--replicas"], {"ZKHIP_BENCH_DIST_BACKEND": "gloo"})],
+    "replicas": [("independent proofs, one per GPU", [], {}),
+                 ("independent proofs, one per GPU, torch control plane on gloo", [], {"ZKHIP_BENCH_DIST_BACKEND": "gloo"})],
+    "chain": [("leaf proofs on ranks 0-3, aggregation proof row-sharded over all ranks", [], {}),
+              ("aggregation proof with the all-gather exchange, torch control plane on gloo", [], {"ZKHIP_ROW_SHARDED": "0", "ZKHIP_BENCH_DIST_BACKEND": "gloo"}),
+              ("aggregation proof with MSMs by column", ["--shard", "columns"], {"ZKHIP_ROW_SHARDED": "0", "ZKHIP_BENCH_DIST_BACKEND": "gloo"}),
+              ("aggregation proof on rank 0 alone (no collective on the data path)", ["--agg-unsharded"], {"ZKHIP_BENCH_DIST_BACKEND": "gloo"})],
+}
+
+
+def _free_port():
     import socket
-    import subprocess
 
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+        return sk.getsockname()[1]
+
+
+def _kill_group(child, grace=5.0):
+    """SIGTERM, then SIGKILL, to the process GROUP the child leads (start_new_session=True): exactly what this process started"""
+    import signal
+
+    if child.poll() is not None:
+        return
+    for sig, wait in ((signal.SIGTERM, grace), (signal.SIGKILL, 10.0)):
+        try:
+            os.killpg(child.pid, sig)
+        except ProcessLookupError:
+            return
+        t_end = time.monotonic() + wait
+        while time.monotonic() < t_end:
+            if child.poll() is not None:
+                return
+            time.sleep(0.1)
+
+
+def self_launch(n, budget_s):
+    """python -m torch.distributed.run --nnodes=1 --nproc-per-node n --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>
+    as a child process in its own process group; -> its exit code.  The n processes it starts are SUPERVISORS (supervise() below): they never
+    touch the GPU and run the fallback ladder of fresh worker processes.  This parent only holds the outermost deadline."""
+    import subprocess
+
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
     env.setdefault("OMP_NUM_THREADS", str(max(1, host_threads() // n)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     print("bench.py: launching " + " ".join(cmd), file=sys.stderr, flush=True)
-    return subprocess.call(cmd, env=env)
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return child.wait(timeout=budget_s)
+    except subprocess.TimeoutExpired:
+        print(f"bench.py: the {n}-rank run did not finish within {budget_s:.0f} s: killing it", file=sys.stderr, flush=True)
+        _kill_group(child)
+        return 124
+    except BaseException:
+        _kill_group(child)
+        raise
+
+
+def supervise(args):
+    """One of the N processes torch.distributed.run started (by the driver, or by self_launch).  It NEVER touches the GPU: it runs the actual
+    bench rank as a child process (ZKHIP_BENCH_ROLE=worker, own process group), with a wall-clock budget, and coordinates with the
+    other supervisors through a TCP store.  A rung fails when any rank's worker exits non-zero or overruns its budget; every supervisor
+    then kills its worker's process group and all of them start a FRESH worker on the next rung of LADDER (row-sharded -> all-gather
+    exchange -> MSMs by column -> independent proofs).  Rank 0 relays the JSON line of the first rung that completes on every rank, adds
+    the ladder's history and — workers gone, GPU idle — times the CPU baseline.  -> exit code (non-zero only if every rung failed)."""
+    import datetime
+    import signal
+    import subprocess
+    import tempfile
+
+    from torch.distributed import TCPStore   # CPU only: no HIP call is made in this process
+
+    rank, world, local_rank = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+    addr, port = os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ["MASTER_PORT"])
+    agent_store = os.environ.get("TORCHELASTIC_USE_AGENT_STORE") == "True"     # torch.distributed.run hosts the store at MASTER_PORT itself
+    store = TCPStore(addr, port, world, is_master=(rank == 0 and not agent_store), timeout=datetime.timedelta(seconds=300), wait_for_workers=False)
+    kind = "chain" if args.chain else ("replicas" if args.replicas else "shard")
+    rungs = LADDER[kind] if not args.no_ladder else LADDER[kind][:1]
+    t_begin = time.monotonic()
+    history, current = [], {"child": None}
+
+    def on_term(signum, frame):   # the launcher is tearing the job down: take the worker along
+        if current["child"] is not None:
+            _kill_group(current["child"], grace=2.0)
+        os._exit(143)
+    signal.signal(signal.SIGTERM, on_term)
+
+    def count(key):
+        return store.add(key, 0)
+
+    for i, (label, extra_args, extra_env) in enumerate(rungs):
+        key = f"zkbench/rung{i}"
+        if rank == 0:
+            store.set(key + "/port", str(_free_port()))
+        wport = int(store.get(key + "/port"))
+        later = len(rungs) - 1 - i
+        budget = max(min(60.0, args.rung_budget), min(args.rung_budget, args.ladder_budget - (time.monotonic() - t_begin) - 150.0 * later))
+        env = dict(os.environ, ZKHIP_BENCH_ROLE="worker", ZKHIP_BENCH_RUNG=label, MASTER_PORT=str(wport), **extra_env)
+        env.setdefault("ZKHIP_COMM_TIMEOUT_MS", str(args.comm_timeout_ms))
+        for k_ in ("TORCHELASTIC_USE_AGENT_STORE",):     # the workers rendezvous among themselves on their own port
+            env.pop(k_, None)
+        out_f = tempfile.NamedTemporaryFile(prefix=f"zkbench_r{rank}_", suffix=".out", delete=False)
+        # (ZKHIP_BENCH_WORKER_SCRIPT: tests/fake_bench_worker.py stands in for the GPU rank in the CPU-only tests of this ladder)
+        cmd = [sys.executable, os.environ.get("ZKHIP_BENCH_WORKER_SCRIPT") or os.path.abspath(__file__)] + sys.argv[1:] + extra_args
+        if rank == 0:
+            print(f"bench.py: rung {i + 1}/{len(rungs)} [{label}] budget {budget:.0f} s", file=sys.stderr, flush=True)
+        child = subprocess.Popen(cmd, env=env, stdout=out_f, start_new_session=True)
+        current["child"] = child
+        t0, why = time.monotonic(), ""
+        while True:
+            rc = child.poll()
+            if rc is not None:
+                if rc != 0:
+                    why = f"rank {rank}: worker exited with code {rc}"
+                break
+            if time.monotonic() - t0 > budget:
+                why = f"rank {rank}: worker overran its {budget:.0f} s budget (killed)"
+                _kill_group(child)
+                break
+            if count(key + "/fail") > 0:      # a peer's worker failed: mine cannot complete a collective run either
+                time.sleep(3.0)               # (let it report its own error first)
+                if child.poll() is None:
+                    _kill_group(child)
+                why = why or f"rank {rank}: stopped because a peer's worker failed"
+                break
+            time.sleep(0.25)
+        current["child"] = None
+        if why and child.returncode != 0:
+            store.add(key + "/fail", 1)
+            store.set(key + f"/why{rank}", why)
+        store.add(key + "/done", 1)
+        t_w = time.monotonic()
+        while count(key + "/done") < world and time.monotonic() - t_w < budget + 60.0:
+            time.sleep(0.1)
+        failed = count(key + "/fail") > 0 or count(key + "/done") < world
+        out_f.close()
+        text = open(out_f.name, "r", errors="replace").read()
+        os.unlink(out_f.name)
+        if not failed:
+            if rank == 0:
+                lines = [ln for ln in text.splitlines() if ln.strip().startswith("{")]
+                if not lines:
+                    print("bench.py: the workers finished without a JSON line", file=sys.stderr, flush=True)
+                    return 1
+                out = json.loads(lines[-1])
+                out["ladder"] = {"rung": i + 1, "of": len(rungs), "label": label, "failed_rungs": history,
+                                 "note": "GPU-free supervisors (one per rank) run each rung in fresh worker processes with a wall-clock budget"}
+                if history:
+                    out["comm_note"] = "; ".join(f"rung {h['rung']} [{h['label']}] failed: {h['why']}" for h in history) + f"; this line is rung {i + 1} [{label}]"
+                if out.get("cpu_baseline") is None and not args.no_cpu_baseline:
+                    try:
+                        import halo2_zkcert_amd.prover as pv
+                        out["cpu_baseline"] = chain_cpu_baseline(pv, args) if args.chain else cpu_baseline(pv, args, args.config, out["config"].get("k", args.agg_k), out["config"].get("transcript", TRANSCRIPT[args.config]))[0]
+                    except Exception as e:   # noqa: BLE001 — the GPU measurement stands on its own
+                        out["cpu_baseline"] = dict(error=str(e)[:300])
+                print(json.dumps(out), flush=True)
+            return 0
+        whys = []
+        if rank == 0:
+            for r in range(world):
+                try:
+                    if store.check([key + f"/why{r}"]):
+                        whys.append(store.get(key + f"/why{r}").decode())
+                except Exception:   # noqa: BLE001
+                    pass
+            print(f"bench.py: rung {i + 1} [{label}] FAILED: {'; '.join(whys) or 'no rank reported why'}", file=sys.stderr, flush=True)
+        history.append({"rung": i + 1, "label": label, "why": "; ".join(whys)[:400] if whys else "see stderr"})
+        time.sleep(1.0)     # let the killed workers' GPU queues be torn down before the next rung starts
+    if rank == 0:
+        print("bench.py: every rung of the ladder failed", file=sys.stderr, flush=True)
+    return 1
 
 
 def main():
@@ -175,18 +416,40 @@ def main():
     ap.add_argument("--replicas", action="store_true", help="N > 1: N independent proofs, one per GPU (weak scaling) instead of one sharded proof")
     ap.add_argument("--chain", action="store_true", help="N >= 4: BASELINE configs[4] — 2 x RSA + 2 x SHA leaf proofs on 4 ranks, then the sharded aggregation proof")
     ap.add_argument("--python-schedule", action="store_true", help="drive the proof from prover.py over the small entry points (same proof bytes)")
-    ap.add_argument("--allow-replicas", action="store_true", help="N > 1: if the library's communicator cannot be created, run N independent proofs "
-                    "(weak scaling, said so in the line) instead of failing")
     ap.add_argument("--no-chain", action="store_true", help="skip the configs.chain entry (BASELINE configs[4] on this GPU) of the default line")
     ap.add_argument("--cpu-baseline-k", type=int, default=20, help="rows (2^k) of the CPU oracle's timed pass for the k = 22 headline; the k = 18 pass "
                     "is timed beside it and the measured k-2 -> k ratio is what extrapolates (22 = one real pass, no extrapolation: minutes)")
+    ap.add_argument("--rung-budget", type=float, default=420.0, help="N > 1: wall-clock seconds one rung of the fallback ladder may take before its workers are killed")
+    ap.add_argument("--ladder-budget", type=float, default=1500.0, help="N > 1: wall-clock seconds for the whole ladder (the driver's own limit is 1800 s)")
+    ap.add_argument("--no-ladder", action="store_true", help="N > 1: first rung only (a failure is the run's failure)")
+    ap.add_argument("--comm-timeout-ms", type=int, default=60000, help="N > 1: the library's deadline for a host wait on a multi-rank context (zkhip_set_option comm_timeout_ms)")
+    ap.add_argument("--agg-unsharded", action="store_true", help="--chain, N >= 4: the aggregation proof on rank 0 alone (last rung of the ladder: no collective)")
     args = ap.parse_args()
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # `python bench.py --gpus N` on its own: start the N ranks ourselves (one process per GPU under torch.distributed.run) BEFORE this
-        # process has touched torch or the GPU, relay their output, leave with their exit code.  A child process, never an exec.
-        sys.exit(self_launch(args.gpus))
+    if args.gpus > 1 and os.environ.get("ZKHIP_BENCH_ROLE") != "worker":
+        # Neither of these two processes ever touches the GPU (no HIP call, no torch.cuda): children, never an exec.
+        if "WORLD_SIZE" not in os.environ:
+            # `python bench.py --gpus N` on its own: start N supervisors under torch.distributed.run and hold the outermost deadline
+            sys.exit(self_launch(args.gpus, args.ladder_budget + 240.0))
+        # one of the N processes torch.distributed.run started (the driver's launch line, or self_launch): the GPU-free supervisor of this rank
+        sys.exit(supervise(args))
+    if args.gpus > 1:
+        # a worker: any failure ends the process at once, without the teardown of a communicator that may be stuck (the supervisor starts the next rung)
+        try:
+            worker(args)
+            sys.stdout.flush()
+            sys.stderr.flush()
+        except BaseException as e:   # noqa: BLE001
+            import traceback
 
+            traceback.print_exc()
+            print(f"bench.py worker rank {os.environ.get('RANK')}: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+            os._exit(e.code if isinstance(e, SystemExit) and isinstance(e.code, int) else 1)
+        os._exit(0)
+    worker(args)
+
+
+def worker(args):
     import torch
 
     import halo2_zkcert_amd.ffi as ffi
@@ -215,41 +478,41 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}")
 
     ctx = ffi.Context(local_rank)
-    shard = world > 1 and not args.replicas
-    comm_note = None
+    shard = world > 1 and not args.replicas and not (args.chain and args.agg_unsharded)
+    if world > 1:
+        ctx.set_option("comm_timeout_ms", args.comm_timeout_ms)
     if shard:
         # RCCL communicator inside the library (unique id broadcast through torch.distributed).  If it cannot be created on some rank
-        # (no librccl, an RCCL error) every rank learns it and the run FAILS: a line that says n_gpus N must come from N cooperating
-        # ranks.  --allow-replicas degrades instead — loudly, in the JSON line — to N independent proofs ("scaling": "weak").
-        err = ""
-        try:
-            if os.environ.get("ZKHIP_BENCH_FAIL_COMM") == "1":     # test hook: what a missing librccl / an RCCL error looks like
-                raise RuntimeError("ZKHIP_BENCH_FAIL_COMM")
-            ctx.comm_init(rank, world, dist)
-        except Exception as e:   # noqa: BLE001
-            err = str(e)[:200]
-        flag = torch.tensor([1 if err else 0], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        if int(flag.item()):
-            if not err:
-                ctx.comm_destroy()
-            shard = False
-            comm_note = f"zkhip_comm_init failed on some rank ({err or 'another rank'}): fell back to {world} independent proofs (--replicas)"
-            if rank == 0:
-                print("bench.py: " + comm_note, file=sys.stderr)
-            if not args.allow_replicas:
-                dist.destroy_process_group()
-                raise SystemExit("bench.py: no communicator and --allow-replicas not given: " + comm_note)
-        else:
-            info = ctx.comm_describe()
-            if info["nranks"] != world or info["transport_ranks"] not in (world, -1):
-                raise SystemExit(f"bench.py: the library's communicator reports {info} for WORLD_SIZE {world}")
+        # (no librccl, an RCCL error) this worker FAILS — a line that says n_gpus N must come from N cooperating ranks — and the
+        # supervisors move every rank to the next rung of the ladder in fresh processes (supervise()).
+        hook = os.environ.get("ZKHIP_BENCH_FAIL_COMM", "")     # test hook: what a missing librccl / an RCCL error looks like ("1": always, "row": on the row-sharded rung only)
+        if hook == "1" or (hook == "row" and os.environ.get("ZKHIP_ROW_SHARDED", "1") != "0"):
+            raise SystemExit(f"bench.py rank {rank}: ZKHIP_BENCH_FAIL_COMM={hook} (injected communicator failure)")
+        ctx.comm_init(rank, world, dist)
+        info = ctx.comm_describe()
+        if info["nranks"] != world or info["transport_ranks"] not in (world, -1):
+            raise SystemExit(f"bench.py: the library's communicator reports {info} for WORLD_SIZE {world}")
     bh = build_hash()
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def teardown():
+        """the line is out: leave.  Destroying communicators is collective-ish and has no deadline of its own, so a timer ends the process
+        (exit code 0: the measurement is complete) if it has not returned in 30 s."""
+        if world == 1:
+            return
+        import threading
+
+        t_ = threading.Timer(30.0, lambda: os._exit(0))
+        t_.daemon = True
+        t_.start()
+        dist.barrier()
+        if shard:
+            ctx.comm_destroy()
+        dist.destroy_process_group()
 
     def run_config(name, steps, warmup, breakdown_passes=2, with_h2d=True, witness="uniform"):
         """-> result dict for one configuration (collective: every rank calls it with the same arguments)"""
@@ -417,6 +680,7 @@ def main():
                "witness": "bits / words (SHA-256 bit circuit layout)" if shape.layout == "sha" else witness,
                "k": shape.k, "advice": shape.n_advice, "fixed": shape.n_fixed, "instance_values": prover.n_instance_values, "lookups": len(shape.lookups),
                "perm_columns": len(shape.perm_columns), "degree": shape.degree, "transcript": kind, "proof_bytes": len(trace.get("proof", b"")),
+               "proof_sha256": hashlib.sha256(bytes(trace.get("proof", b""))).hexdigest(),
                "setup_s": round(setup_s, 3), "resident_bytes": int(resident), "rooflines": roof, "kernels_ms_per_step": kernels,
                "traffic_source": traffic_file, "with_h2d": h2d, "msm_shard": shard_mode,
                "first_proof_s": round(setup_s + first_s, 3), "comm": comm_fields(gathered, shard_mode),
@@ -431,32 +695,47 @@ def main():
         barrier, then the aggregation proof.  N >= 4: one leaf proof per rank 0..3 on an unsharded context, then the k = 22 proof
         sharded over all N ranks; N = 1: the five proofs one after the other.  (The aggregation circuit's witness generation — the
         in-circuit verification of the four snarks on the CPU, src/lib.rs:43-49 — is outside the path and not timed.)  Collective."""
-        if world > 1 and (not shard or world < 4):
-            raise SystemExit("--chain needs --gpus 1 or >= 4 (sharded)")
+        if world > 1 and world < 4:
+            raise SystemExit("--chain needs --gpus 1 or >= 4")
+        agg_here = shard or world == 1 or rank == 0        # --agg-unsharded (last rung of the ladder): the aggregation proof on rank 0 alone
         leaf_ctx = ffi.Context(local_rank) if shard else ctx
         leaf_names = ["rsa17", "sha19", "rsa17", "sha19"]
         mine = leaf_names if world == 1 else ([leaf_names[rank]] if rank < 4 else [])
-        leaves = []
+        leaves, pairs = [], 0.0
         for j, nm in enumerate(mine):
             sh_ = make_shape(pv, nm, args)
             pr_ = pv.Prover(pv.GpuBackend(leaf_ctx, ffi), sh_, satisfiable=True)
             leaves.append((pr_, pr_.witness(j if world == 1 else rank), TRANSCRIPT[nm]))
+            pairs += sh_.counts(pr_.dom.extended_k)["msm"] * float(1 << sh_.k)
         if shard:
             ctx.comm_shard("points" if args.shard == "auto" else args.shard)
-        agg = pv.Prover(pv.GpuBackend(ctx, ffi), make_shape(pv, "agg22", args), satisfiable=True)
-        agg_w = agg.witness(0)
-        sizes = []
+        agg = agg_w = None
+        if agg_here:
+            agg_shape = make_shape(pv, "agg22", args)
+            agg = pv.Prover(pv.GpuBackend(ctx, ffi), agg_shape, satisfiable=True)
+            agg_w = agg.witness(0)
+            pairs += agg_shape.counts(agg.dom.extended_k)["msm"] * float(1 << agg_shape.k) / (world if shard else 1)
+        sizes, digests = [], []
 
         def chain_step():
-            del sizes[:]
+            del sizes[:], digests[:]
             for pr_, w_, kind_ in leaves:
-                sizes.append(len(pr_.prove_native(w_, transcript=kind_)["proof"]))
+                pf_ = bytes(pr_.prove_native(w_, transcript=kind_)["proof"])
+                sizes.append(len(pf_))
+                digests.append(hashlib.sha256(pf_).hexdigest())
             barrier()
-            t_ = agg.prove_native(agg_w, transcript="evm")
-            sizes.append(len(t_["proof"]))
+            if agg_here:
+                pf_ = bytes(agg.prove_native(agg_w, transcript="evm")["proof"])
+                sizes.append(len(pf_))
+                digests.append(hashlib.sha256(pf_).hexdigest())
 
         for _ in range(warmup):
             chain_step()
+        DOMINANT = "msm_accum_affine"
+        ctxs = [ctx] + ([leaf_ctx] if leaf_ctx is not ctx else [])
+        for c_ in ctxs:
+            c_.profile_select(DOMINANT)
+            c_.profile_enable(True)
         g0 = ctx.comm_bytes_gathered()
         barrier()
         t0 = time.perf_counter()
@@ -468,17 +747,39 @@ def main():
             t = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
+        acc_ms, acc_l = 0.0, 0
+        for c_ in ctxs:
+            ms_, l_ = c_.profile_read(DOMINANT)
+            acc_ms, acc_l = acc_ms + ms_, acc_l + l_
+            c_.profile_select(None)
+            c_.profile_enable(False)
+        roof = None
+        if acc_l and acc_ms > 0:
+            alg = 96.0 * pairs * steps / acc_l
+            avg_s = acc_ms / acc_l / 1000.0
+            ach = alg / avg_s / 1e9
+            roof = {"kernel": "k_accum_affine", "bound": "valu", "hbm_frac": round(ach / HBM_PEAK_GBS, 5), "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": round(alg), "avg_launch_ms": round(avg_s * 1000.0, 4),
+                    "launches_per_step": acc_l / steps, "timing": "HIP events inside the timed region, all proofs of the chain this rank ran",
+                    "note": "rank 0's share: 96 B per (scalar, point) pair over every commitment of its leaf proof(s) and its 1/N of the aggregation proof's; "
+                            "VALU-issue bound like the single proofs (DESIGN.md 5); traffic: see the per-configuration PMC passes of the N = 1 line"}
+        if world == 1:
+            par = "5 proofs in sequence on 1 GPU"
+        elif shard:
+            par = f"leaf proofs on ranks 0-3 (one each), then one proof sharded x{world}"
+        else:
+            par = "leaf proofs on ranks 0-3 (one each), then the aggregation proof on rank 0 alone (no collective on the data path)"
         res = {"value": round(dt / steps, 6), "unit": "s", "steps": steps, "warmup": warmup, "ms_per_step": round(dt * 1000.0 / steps, 3), "proofs_per_step": 5,
                "workload": "chain (BASELINE configs[4]): 2 x RSA k=17 + 2 x SHA256-shaped k=19 leaf proofs (Poseidon), barrier, aggregation-shaped "
                            f"k={args.agg_k} proof (Keccak)",
-               "parallelism": "5 proofs in sequence on 1 GPU" if world == 1 else f"leaf proofs on ranks 0-3 (one each), then one proof sharded x{world}",
-               "proof_bytes": list(sizes),
+               "parallelism": par, "proof_bytes": list(sizes), "proof_sha256": list(digests), "roofline": roof,
                "bytes_gathered_per_step": (ctx.comm_bytes_gathered() - g0) // steps if shard else 0}
         for pr_, _, _ in leaves:
             pr_.release()
             pr_.b.params.free()
-        agg.release()
-        agg.b.params.free()
+        if agg is not None:
+            agg.release()
+            agg.b.params.free()
         if leaf_ctx is not ctx:
             leaf_ctx.close()
         return res
@@ -496,16 +797,16 @@ def main():
     if args.chain:
         res = run_chain(args.steps, args.warmup)
         if rank == 0:
+            cb = None
+            if world == 1 and not args.no_cpu_baseline:      # N > 1: rank 0's GPU-free supervisor times it once the workers are gone
+                cb = chain_cpu_baseline(pv, args)
             print(json.dumps({"metric": "create_proof wall-time (s): RSA k=17 / SHA256 k=19 / agg k=22 at 1/2/4/8 GPU", "value": res["value"], "unit": "s",
                               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": False,
                               "scaling": "strong", "vs_baseline": None, "dtype": "u256 (BN254 Fr/Fq, Montgomery)", "data": "synthetic", "proofs_per_step": 5,
-                              "config": {"workload": res["workload"], "parallelism": res["parallelism"]}, "proof_bytes": res["proof_bytes"],
+                              "config": {"workload": res["workload"], "parallelism": res["parallelism"], "k": args.agg_k, "transcript": "evm"}, "proof_bytes": res["proof_bytes"], "proof_sha256": res["proof_sha256"],
                               "comm": comm_fields(res["bytes_gathered_per_step"], "points" if args.shard == "auto" else args.shard),
-                              "roofline": None, "cpu_baseline": None}))
-        if world > 1:
-            dist.barrier()
-            ctx.comm_destroy()
-            dist.destroy_process_group()
+                              "roofline": res["roofline"], "cpu_baseline": cb, "build": bh}), flush=True)
+        teardown()
         return
 
     out_configs = {}
@@ -548,46 +849,18 @@ def main():
                                                                    else f"{world} independent proofs, one per GPU, no collective")},
             "roofline": {k_: dom[k_] for k_ in ("kernel", "bound", "hbm_frac", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms", "note")},
             "int_roofline": dict(kernel="k_accum_affine", **dom["int_roofline"]),
-            "configs": out_configs, "build": bh, **({"comm_note": comm_note} if comm_note else {}),
+            "configs": out_configs, "build": bh,
             "comm": head["comm"],
             "setup_s": head["setup_s"], "first_proof_s": head["first_proof_s"], "resident_bytes": head["resident_bytes"], "with_h2d": head["with_h2d"],
         }
         if not args.no_cpu_baseline and world == 1:
-            threads = host_threads()
-            # The headline is k = 22: one CPU pass at that size and its SRS take the oracle minutes.  The baseline is therefore the SAME
-            # circuit shape and transcript MEASURED at k = --cpu-baseline-k (default 20: one full pass) and at k = 18 (median of 3 after a
-            # warm-up); the measured time ratio of those two (4x the rows) is printed and is what carries the k = 20 figure to k = 22 — not
-            # the row count.  --cpu-baseline-k 22 times one real pass (scale 1).
-            def shape_at(k_):
-                return make_shape(pv, args.config, argparse.Namespace(**{**vars(args), "agg_k": k_})) if args.config == "agg22" else head_shape
-            if args.config == "agg22" and head["k"] > 18:
-                k_m = max(19, min(head["k"], args.cpu_baseline_k))
-                med18, ts18 = cpu_pass_seconds(pv, shape_at(18), head["transcript"], threads)
-                t_m, _ = cpu_pass_seconds(pv, shape_at(k_m), head["transcript"], threads, repeats=1, warm=False)
-                per4 = (t_m / med18) ** (2.0 / (k_m - 18))          # measured growth per 4x rows
-                scale = per4 ** ((head["k"] - k_m) / 2.0)
-                out["cpu_baseline"] = dict(value=round(t_m * scale, 4), unit="s", cores=threads, kind="port", measured_s=round(t_m, 4), scale=round(scale, 4),
-                                           sample=f"{shape_at(k_m).name}: ONE full pass at k = {k_m} = {t_m:.3f} s; the same shape at k = 18: median of 3 after a warm-up = "
-                                                  f"{med18:.3f} s ({', '.join(f'{t:.3f}' for t in ts18)}); measured growth per 4x rows = {per4:.3f} -> x{scale:.3f} to k = {head['k']}"
-                                                  "; oracle/zkoracle.c with OpenMP, SRS / keygen excluded",
-                                           measured_k=k_m, k18_s=round(med18, 4), growth_per_4x_rows=round(per4, 4))
-            else:
-                med, ts = cpu_pass_seconds(pv, head_shape, head["transcript"], threads)
-                out["cpu_baseline"] = dict(value=round(med, 4), unit="s", cores=threads, kind="port", measured_s=round(med, 4), scale=1.0,
-                                           sample=f"{head_shape.name}: median of 3 full passes after a warm-up ({', '.join(f'{t:.3f}' for t in ts)}); "
-                                                  "oracle/zkoracle.c with OpenMP, SRS / keygen excluded")
-            if "rsa17" in out_configs and "error" not in out_configs["rsa17"] and args.config != "rsa17":
-                med17, ts17 = cpu_pass_seconds(pv, pv.CircuitShape.rsa(17), "poseidon", threads)
-                out_configs["rsa17"]["cpu_baseline"] = dict(value=round(med17, 4), unit="s", cores=threads, kind="port",
-                                                            sample=f"rsa_k17: median of 3 full passes after a warm-up ({', '.join(f'{t:.3f}' for t in ts17)})")
+            out["cpu_baseline"], rsa_cb = cpu_baseline(pv, args, args.config, head["k"], head["transcript"])
+            if rsa_cb and "rsa17" in out_configs and "error" not in out_configs["rsa17"]:
+                out_configs["rsa17"]["cpu_baseline"] = rsa_cb
         else:
-            out["cpu_baseline"] = None
-        print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        if shard:
-            ctx.comm_destroy()
-        dist.destroy_process_group()
+            out["cpu_baseline"] = None     # N > 1: the GPU-free supervisor of rank 0 times it once the workers are gone (supervise())
+        print(json.dumps(out), flush=True)
+    teardown()
 
 
 if __name__ == "__main__":

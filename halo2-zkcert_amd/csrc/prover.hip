@@ -13,6 +13,7 @@
 // Everything here is host orchestration (no kernels): the point of having it in the library is that a proof of 2^17 rows is
 // ~9 ms of GPU work, and an interpreted host adds a millisecond of gaps between ~250 launches.
 // halo2-zkcert_amd/prover.py is the same schedule in Python over the small entry points (and the form the oracle backend runs).
+#include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <vector>
@@ -838,6 +839,17 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
     uint64_t h1[8], h2[8];
     ZK_TRY(zk::shplonk_open(ctx, pk->g, n, polys.data(), polys.size(), q_poly.data(), q_points.data(), q_evals.data(), nq, tr, h1, h2, pieces_sharded));
     mark("shplonk done");
+    if (ctx->opt.host_timing >= 2) {   // what the context holds after this proof: scratch by name (bytes), largest first
+        std::vector<std::pair<size_t, std::string>> rows;
+        size_t total = 0;
+        for (auto& kv : ctx->scratch) { rows.push_back({kv.second.bytes, kv.first}); total += kv.second.bytes; }
+        std::sort(rows.begin(), rows.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+        fprintf(stderr, "  scratch: %zu buffers, %.2f GiB\n", rows.size(), total / 1073741824.0);
+        for (auto& r : rows) if (r.first >= (64u << 20)) fprintf(stderr, "    %9.1f MiB  %s\n", r.first / 1048576.0, r.second.c_str());
+        size_t ptotal = 0;
+        for (auto& kv : ctx->persistent) (void)kv, ptotal += 1;
+        fprintf(stderr, "  persistent buffers: %zu\n", ptotal);
+    }
     if (timing) {
         for (size_t i = 1; i < marks.size(); ++i)
             fprintf(stderr, "  %8.1f us  (+%7.1f)  %s\n", std::chrono::duration<double, std::micro>(marks[i].t - marks[0].t).count(),

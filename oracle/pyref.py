@@ -557,10 +557,12 @@ def shplonk_linearisation(polys, rotation_sets, super_points, y, v, u, h, n):
     return [c * inv0 % R for c in q]
 
 
-def shplonk_verify(commitments, rotation_sets, super_points, y, v, u, h1, h2, s):
-    """The verifier's pairing check e(h2, [s]_2) = e(L, [1]_2) restated with the trapdoor s: s * h2 == L in G1, where
+def shplonk_verify(commitments, rotation_sets, super_points, y, v, u, h1, h2, s=None, srs_g2=None):
+    """The verifier's final check e(h2, [s]_2) = e(L, [1]_2), where
     L = sum_i v^i z_i (sum_j y^j C_ij) - [sum_i v^i z_i sum_j y^j R_ij(u)] G - z_0 h1 + u h2, z_i = Z_{T\\S_i}(u) / Z_{T\\S_0}(u),
-    z_0 = Z_T(u) / Z_{T\\S_0}(u).  commitments: id -> affine point; h1, h2 affine."""
+    z_0 = Z_T(u) / Z_{T\\S_0}(u).  commitments: id -> affine point; h1, h2 affine.
+    srs_g2 = (g2, s_g2), the two G2 points of the params file: the PAIRING check itself, e(L, g2) e(-h2, s_g2) = 1 — no trapdoor needed
+    (the reference's own acceptance test, /root/reference/src/bin/cli.rs:524); else the same equation under a known trapdoor s: s h2 == L in G1."""
     G = (1, 2)
     inv0 = None
     acc = INF
@@ -582,7 +584,213 @@ def shplonk_verify(commitments, rotation_sets, super_points, y, v, u, h1, h2, s)
     acc = jac_add(acc, scalar_mul((-r_acc) % R, from_affine(G)))
     acc = jac_add(acc, scalar_mul((-z_0) % R, from_affine(h1)))
     acc = jac_add(acc, scalar_mul(u, from_affine(h2)))
+    if srs_g2 is not None:
+        g2, s_g2 = srs_g2
+        neg_h2 = (0, 0) if h2 == (0, 0) else (h2[0], (-h2[1]) % P)
+        return pairing_check([(to_affine(acc), g2), (neg_h2, s_g2)])
+    if s is None:
+        raise ValueError("shplonk_verify needs the params' G2 points (srs_g2) or the trapdoor (s)")
     return to_affine(acc) == to_affine(scalar_mul(s % R, from_affine(h2)))
+
+
+# ----------------------------------------------------------------------------- BN254 optimal ate pairing (the verifier's real check)
+# The reference's acceptance criterion is a pairing check (evm_verify, /root/reference/src/bin/cli.rs:524, src/tests/x509_aggregation.rs:110;
+# halo2_proofs' VerifierSHPLONK ends in e(L, [1]_2) = e(h2, [s]_2)).  Restated from the curve's published definition (EIP-196 / EIP-197:
+# the alt_bn128 precompiles): tower Fp2 = Fp[u] / (u^2 + 1), Fp6 = Fp2[v] / (v^3 - xi), Fp12 = Fp6[w] / (w^2 - v), xi = 9 + u;
+# G2 on the twist y^2 = x^3 + 3 / xi with EIP-197's generator; optimal ate pairing with loop parameter 6 x + 2, x = 4965661367192848881,
+# two Frobenius line steps, and the plain final exponentiation f^((p^12 - 1) / r) (no cyclotomic shortcuts: every step is the textbook one).
+# Anchors (tests/test_pairing_cpu.py): the generator is on the twist and has order r, e is bilinear and non-degenerate, e(G1, G2)^r = 1,
+# and the precompile's product form e(a G1, G2) e(-G1, a G2) = 1 holds — no pairing value is taken from memory.
+BN_X = 4965661367192848881
+ATE_LOOP = 6 * BN_X + 2
+G2_GEN = ((10857046999023057135944570762232829481370756359578518086990519993285655852781,
+           11559732032986387107991004021392285783925812861821192530917403151452391805634),
+          (8495653923123431417604973247489272438418190587263600148770280649306958101930,
+           4082367875863433681332203403145435568316851327593401208105741076214120093531))    # ((x.c0, x.c1), (y.c0, y.c1)), c0 + c1 u
+
+
+def f2_add(a, b): return ((a[0] + b[0]) % P, (a[1] + b[1]) % P)
+def f2_sub(a, b): return ((a[0] - b[0]) % P, (a[1] - b[1]) % P)
+def f2_neg(a): return ((-a[0]) % P, (-a[1]) % P)
+def f2_mul(a, b): return ((a[0] * b[0] - a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
+def f2_scale(a, k): return (a[0] * k % P, a[1] * k % P)
+def f2_conj(a): return (a[0], (-a[1]) % P)
+
+
+def f2_inv(a):
+    d = pow((a[0] * a[0] + a[1] * a[1]) % P, P - 2, P)
+    return (a[0] * d % P, (-a[1]) * d % P)
+
+
+def f2_pow(a, e):
+    r = (1, 0)
+    while e:
+        if e & 1:
+            r = f2_mul(r, a)
+        a = f2_mul(a, a)
+        e >>= 1
+    return r
+
+
+XI = (9, 1)
+F2_ZERO, F2_ONE = (0, 0), (1, 0)
+TWIST_B = f2_mul((3, 0), f2_inv(XI))
+
+
+def f2_mul_xi(a):      # (a0 + a1 u)(9 + u)
+    return ((9 * a[0] - a[1]) % P, (a[0] + 9 * a[1]) % P)
+
+
+# Fp6: (c0, c1, c2) = c0 + c1 v + c2 v^2, v^3 = xi
+def f6_add(a, b): return (f2_add(a[0], b[0]), f2_add(a[1], b[1]), f2_add(a[2], b[2]))
+def f6_sub(a, b): return (f2_sub(a[0], b[0]), f2_sub(a[1], b[1]), f2_sub(a[2], b[2]))
+
+
+def f6_mul(a, b):
+    t00, t11, t22 = f2_mul(a[0], b[0]), f2_mul(a[1], b[1]), f2_mul(a[2], b[2])
+    t01 = f2_add(f2_mul(a[0], b[1]), f2_mul(a[1], b[0]))
+    t02 = f2_add(f2_mul(a[0], b[2]), f2_mul(a[2], b[0]))
+    t12 = f2_add(f2_mul(a[1], b[2]), f2_mul(a[2], b[1]))
+    return (f2_add(t00, f2_mul_xi(t12)), f2_add(t01, f2_mul_xi(t22)), f2_add(t02, t11))
+
+
+def f6_mul_v(a):       # a v
+    return (f2_mul_xi(a[2]), a[0], a[1])
+
+
+F6_ZERO, F6_ONE = (F2_ZERO, F2_ZERO, F2_ZERO), (F2_ONE, F2_ZERO, F2_ZERO)
+F12_ONE = (F6_ONE, F6_ZERO)
+
+
+# Fp12: (c0, c1) = c0 + c1 w, w^2 = v
+def f12_mul(a, b):
+    t0, t1 = f6_mul(a[0], b[0]), f6_mul(a[1], b[1])
+    cross = f6_sub(f6_sub(f6_mul(f6_add(a[0], a[1]), f6_add(b[0], b[1])), t0), t1)
+    return (f6_add(t0, f6_mul_v(t1)), cross)
+
+
+def f12_pow(a, e):
+    r = F12_ONE
+    while e:
+        if e & 1:
+            r = f12_mul(r, a)
+        a = f12_mul(a, a)
+        e >>= 1
+    return r
+
+
+# G2 on the twist, affine, None = identity
+def g2_on_curve(q):
+    return q is None or f2_mul(q[1], q[1]) == f2_add(f2_mul(f2_mul(q[0], q[0]), q[0]), TWIST_B)
+
+
+def g2_neg(q):
+    return None if q is None else (q[0], f2_neg(q[1]))
+
+
+def g2_add(p1, p2):
+    if p1 is None:
+        return p2
+    if p2 is None:
+        return p1
+    if p1[0] == p2[0]:
+        if f2_add(p1[1], p2[1]) == F2_ZERO:
+            return None
+        lam = f2_mul(f2_scale(f2_mul(p1[0], p1[0]), 3), f2_inv(f2_scale(p1[1], 2)))
+    else:
+        lam = f2_mul(f2_sub(p2[1], p1[1]), f2_inv(f2_sub(p2[0], p1[0])))
+    x3 = f2_sub(f2_sub(f2_mul(lam, lam), p1[0]), p2[0])
+    return (x3, f2_sub(f2_mul(lam, f2_sub(p1[0], x3)), p1[1]))
+
+
+def g2_mul(k, q):
+    acc = None
+    while k:
+        if k & 1:
+            acc = g2_add(acc, q)
+        q = g2_add(q, q)
+        k >>= 1
+    return acc
+
+
+def g2_from_raw_bytes(b):
+    """128 bytes of halo2curves' RawBytes form (x.c0, x.c1, y.c0, y.c1: 32 little-endian bytes each, Montgomery) -> twist point.
+    What ParamsKZG::write puts after the G1 bases: g2, then s_g2 [UPSTREAM-RECALL; layout as halo2-zkcert_amd/ffi.py writes it]."""
+    c = [from_mont(int.from_bytes(b[32 * i:32 * i + 32], "little"), P) for i in range(4)]
+    if any(v >= P for v in c):
+        raise ValueError("G2 coordinate not canonical")
+    q = ((c[0], c[1]), (c[2], c[3]))
+    if q == (F2_ZERO, F2_ZERO):
+        return None
+    if not g2_on_curve(q):
+        raise ValueError("G2 point not on the twist")
+    return q
+
+
+_GAMMA = None
+
+
+def _frobenius_constants():
+    """xi^((p - 1) / 3), xi^((p - 1) / 2) (pi on the twist: conjugate, then scale) and the same for p^2 (in Fp)"""
+    global _GAMMA
+    if _GAMMA is None:
+        _GAMMA = (f2_pow(XI, (P - 1) // 3), f2_pow(XI, (P - 1) // 2), f2_pow(XI, (P * P - 1) // 3), f2_pow(XI, (P * P - 1) // 2))
+    return _GAMMA
+
+
+def _line(t, q, px, py):
+    """The line through the untwisted images of t and q (the tangent if t = q), evaluated at the G1 point (px, py), and t + q.
+    Untwist psi(x', y') = (x' w^2, y' w^3): a slope lam on the twist is lam w on E(Fp12), so
+    l(P) = yP - lam xP w + (lam xT - yT) w^3, i.e. Fp12 coefficients 1: yP, w: -lam xP, w^3 = v w: lam xT - yT."""
+    if t[0] == q[0] and t[1] == q[1]:
+        lam = f2_mul(f2_scale(f2_mul(t[0], t[0]), 3), f2_inv(f2_scale(t[1], 2)))
+    elif t[0] == q[0]:
+        # vertical line x - xT: lies in a proper subfield after untwisting only up to w^2; its value is killed by the final exponentiation
+        return F12_ONE, None
+    else:
+        lam = f2_mul(f2_sub(q[1], t[1]), f2_inv(f2_sub(q[0], t[0])))
+    x3 = f2_sub(f2_sub(f2_mul(lam, lam), t[0]), q[0])
+    y3 = f2_sub(f2_mul(lam, f2_sub(t[0], x3)), t[1])
+    ell = (((py % P, 0), F2_ZERO, F2_ZERO), (f2_scale(f2_neg(lam), px), f2_sub(f2_mul(lam, t[0]), t[1]), F2_ZERO))
+    return ell, (x3, y3)
+
+
+def miller_loop(p1, q2):
+    """f_{6x+2, Q}(P) l_{[6x+2]Q, pi(Q)}(P) l_{[6x+2]Q + pi(Q), -pi^2(Q)}(P); p1 affine G1 (x, y), q2 affine twist point; identity -> 1"""
+    if q2 is None or p1 is None or p1 == (0, 0):
+        return F12_ONE
+    px, py = p1
+    f, t = F12_ONE, q2
+    for bit in bin(ATE_LOOP)[3:]:
+        ell, t2 = _line(t, t, px, py)
+        f = f12_mul(f12_mul(f, f), ell)
+        t = t2
+        if bit == "1":
+            ell, t2 = _line(t, q2, px, py)
+            f = f12_mul(f, ell)
+            t = t2
+    g12, g13, g22, g23 = _frobenius_constants()
+    q1 = (f2_mul(f2_conj(q2[0]), g12), f2_mul(f2_conj(q2[1]), g13))
+    nq2 = (f2_mul(q2[0], g22), f2_neg(f2_mul(q2[1], g23)))
+    ell, t2 = _line(t, q1, px, py)
+    f = f12_mul(f, ell)
+    ell, _ = _line(t2, nq2, px, py)
+    return f12_mul(f, ell)
+
+
+FINAL_EXP = (P ** 12 - 1) // R
+
+
+def pairing(p1, q2):
+    return f12_pow(miller_loop(p1, q2), FINAL_EXP)
+
+
+def pairing_check(pairs):
+    """EIP-197's form: True iff prod e(P_i, Q_i) = 1 (one final exponentiation for the product of the Miller loops)"""
+    f = F12_ONE
+    for p1, q2 in pairs:
+        f = f12_mul(f, miller_loop(p1, q2))
+    return f12_pow(f, FINAL_EXP) == F12_ONE
 
 
 # ----------------------------------------------------------------------------- PLONK verifier (algebraic)
@@ -680,7 +888,7 @@ def plonk_expected_h(vk, instance_cols, evals, ch):
     return acc * pow((pow(x, n, R) - 1) % R, R - 2, R) % R
 
 
-def plonk_verify(vk, instance_cols, commitments, h_pieces, evals, query_list, ch, h1, h2, s):
+def plonk_verify(vk, instance_cols, commitments, h_pieces, evals, query_list, ch, h1, h2, s=None, srs_g2=None):
     """commitments: key -> affine point for every queried polynomial except h; h_pieces: the quotient's piece commitments;
     query_list: [(key, rotation)] in the prover's query order (h included); True iff the multi-open verifies with h's
     evaluation REPLACED by the value the constraint system dictates."""
@@ -700,7 +908,7 @@ def plonk_verify(vk, instance_cols, commitments, h_pieces, evals, query_list, ch
         ev = expected_h if key == ("h", 0) else evals[(key, rot)]
         queries.append((key, x * pow(w, rot % n, R) % R, ev))
     rs, sp = construct_intermediate_sets(queries)
-    return shplonk_verify(coms, rs, sp, ch["shplonk_y"], ch["shplonk_v"], ch["shplonk_u"], h1, h2, s)
+    return shplonk_verify(coms, rs, sp, ch["shplonk_y"], ch["shplonk_v"], ch["shplonk_u"], h1, h2, s, srs_g2)
 
 
 # ----------------------------------------------------------------------------- point decompression (transcript readers)
@@ -1039,9 +1247,10 @@ def multiopen_query_list(vk, advice_queries, fixed_queries):
 
 
 def verify_proof_bytes(vk, kind, proof, vk_repr, instance_values, instance_cols, fixed_commitments, sigma_commitments, advice_queries,
-                       fixed_queries, s):
+                       fixed_queries, s=None, srs_g2=None):
     """The whole verifier over PROOF BYTES: read in upstream's order with the named transcript, challenges re-derived, then the
-    algebraic checks of plonk_verify (the pairing replaced by the SRS trapdoor s).  fixed / sigma commitments: the vk's points."""
+    algebraic checks of plonk_verify, closed by the pairing e(L, g2) = e(h2, s_g2) over the params' G2 points (srs_g2 = (g2, s_g2)) or,
+    for an SRS whose trapdoor s is known, by the same equation in G1.  fixed / sigma commitments: the vk's points."""
     try:
         pr = read_plonk_proof(vk, kind, proof, vk_repr, instance_values, advice_queries, fixed_queries)
     except ValueError:
@@ -1052,4 +1261,4 @@ def verify_proof_bytes(vk, kind, proof, vk_repr, instance_values, instance_cols,
     for i, c in enumerate(sigma_commitments):
         coms[("sigma", i)] = c
     return plonk_verify(vk, instance_cols, coms, pr["h_pieces"], pr["evals"], multiopen_query_list(vk, advice_queries, fixed_queries),
-                        pr["challenges"], pr["h1"], pr["h2"], s)
+                        pr["challenges"], pr["h1"], pr["h2"], s, srs_g2)

@@ -8,7 +8,7 @@
 // collected between ncclGroupStart / ncclGroupEnd and executed at the end of the group; before any byte moves, every rank publishes the
 // size of each (peer) send and receive it posted and the tables are cross-checked — a send without its matching receive (or with another
 // size) is reported as an ERROR by both sides instead of the hang the real library would produce.
-//   hipcc -shared -fPIC -O1 tests/fake_rccl/fake_rccl.cpp -o tests/fake_rccl/libfake_rccl.so
+//   hipcc --offload-arch=gfx950 -shared -fPIC -O1 tests/fake_rccl/fake_rccl.cpp -o tests/fake_rccl/libfake_rccl.so
 #include <fcntl.h>
 #include <hip/hip_runtime.h>
 #include <pthread.h>
@@ -21,6 +21,39 @@
 #include <cstring>
 #include <ctime>
 #include <vector>
+
+// Fault injection (tests of bench.py's fallback ladder and of the library's wait deadline), ZKFAKE_RCCL_STALL="<mode>:<rank>:<nth>": on rank
+// <rank>, at the <nth> collective call after ncclCommInitRank (all-gathers and send / recv groups both count; the library's init-time
+// self-check is calls 1 and 2; mode suffix "-row": only while ZKHIP_ROW_SHARDED is not 0, i.e. on the first rung of bench.py's ladder),
+//   device — the exchange completes, then a kernel that spins for ZKFAKE_RCCL_STALL_S seconds (default 30) is enqueued on the collective's
+//            stream: what a collective whose peer never arrives looks like to the host (a stream that makes no progress);
+//   host   — the call never returns: what a blocked RCCL host call looks like (only an outer watchdog can end it).
+__global__ void k_fake_spin(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(127);
+}
+static int g_calls = 0;
+static void maybe_stall(int rank, hipStream_t st, bool before) {
+    const char* e = getenv("ZKFAKE_RCCL_STALL");
+    if (!e) return;
+    char mode[16] = "";
+    int r = -1, nth = -1;
+    if (sscanf(e, "%15[^:]:%d:%d", mode, &r, &nth) != 3 || r != rank) return;
+    if (char* suffix = strstr(mode, "-row")) {      // "device-row" / "host-row": only while the library is on its row-sharded exchange
+        const char* rs = getenv("ZKHIP_ROW_SHARDED");
+        if (rs && strcmp(rs, "0") == 0) return;
+        *suffix = 0;
+    }
+    if (before) { ++g_calls; if (g_calls == nth && strcmp(mode, "host") == 0) for (;;) sleep(1000); return; }
+    if (g_calls == nth && strcmp(mode, "device") == 0) {
+        const char* s_ = getenv("ZKFAKE_RCCL_STALL_S");
+        const double secs = s_ ? atof(s_) : 30.0;
+        int khz = 100000;
+        (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, 0);
+        hipLaunchKernelGGL(k_fake_spin, dim3(1), dim3(1), 0, st, (unsigned long long)(secs * 1000.0 * khz));
+        fprintf(stderr, "fake rccl: rank %d stalls its stream for %.0f s after collective call %d (ZKFAKE_RCCL_STALL)\n", rank, secs, nth);
+    }
+}
 
 extern "C" {
 typedef struct { char internal[128]; } ncclUniqueId;
@@ -104,6 +137,7 @@ static char* box(ncclComm_t c, int src, int dst) { return c->data + ((size_t)src
 
 ncclResult_t ncclAllGather(const void* send, void* recv, size_t count, int /*dtype: bytes*/, ncclComm_t c, hipStream_t st) {
     if (count > c->h->slot) { g_err = "fake rccl: all-gather block larger than ZKFAKE_RCCL_SLOT_MB"; return 5; }
+    maybe_stall(c->rank, st, true);
     ncclResult_t rc = 0;      // (every path reaches both barriers: an error on one rank must not strand the others)
     if (hipStreamSynchronize(st) != hipSuccess) { g_err = "fake rccl: hipStreamSynchronize"; rc = 1; }
     if (!rc && hipMemcpy(box(c, c->rank, c->rank), send, count, hipMemcpyDeviceToHost) != hipSuccess) { g_err = "fake rccl: D2H"; rc = 1; }
@@ -111,6 +145,7 @@ ncclResult_t ncclAllGather(const void* send, void* recv, size_t count, int /*dty
     for (int r = 0; r < c->nranks && !rc; ++r)
         if (hipMemcpy((char*)recv + (size_t)r * count, box(c, r, r), count, hipMemcpyHostToDevice) != hipSuccess) { g_err = "fake rccl: H2D"; rc = 1; }
     pthread_barrier_wait(&c->h->barrier);
+    maybe_stall(c->rank, st, false);
     return rc;
 }
 
@@ -121,6 +156,8 @@ static ncclResult_t run_group() {
     if (g_ops.empty()) return 0;
     ncclComm_t c = g_ops[0].c;
     const int me = c->rank, N = c->nranks;
+    hipStream_t st0 = g_ops[0].st;
+    maybe_stall(me, st0, true);
     for (int r = 0; r < N; ++r) { c->h->send_size[me][r] = 0; c->h->recv_size[me][r] = 0; }
     ncclResult_t rc = 0;
     for (auto& o : g_ops) {
@@ -141,6 +178,7 @@ static ncclResult_t run_group() {
         if (!rc && !o.send && hipMemcpy(o.rbuf, box(c, o.peer, me), o.bytes, hipMemcpyHostToDevice) != hipSuccess) { g_err = "fake rccl: H2D"; rc = 1; }
     pthread_barrier_wait(&c->h->barrier);
     g_ops.clear();
+    maybe_stall(me, st0, false);
     return rc;
 }
 ncclResult_t ncclGroupStart() { ++g_depth; return 0; }

@@ -49,73 +49,58 @@ def test_bench_prints_one_contract_line():
     assert cfg["setup_s"] > 0 and cfg["resident_bytes"] > (6 << 30) and cfg["proof_bytes"] > 1000
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > d["value"] and cb["unit"] == "s" and cb["sample"]
-    # measured at k = 20 (one full pass) and carried to k = 22 by the MEASURED k = 18 -> 20 growth: scale <= 4 x 4 rows, stated in the line
-    assert cb["measured_k"] == 20 and 1.0 < cb["scale"] <= 8.0 and 3.0 < cb["growth_per_4x_rows"] < 8.0
+    # measured at k = 20 (one full pass) and carried to k = 22 by the k = 22 / k = 20 ratio of the RECORDED real passes (profiles/r04_cpu_k22.json),
+    # which the line quotes beside it (measured_at_k22: scale 1 on record)
+    assert cb["measured_k"] == 20 and 3.0 < cb["scale"] <= 5.0 and 3.0 < cb["growth_per_4x_rows"] < 8.0
     assert abs(cb["value"] - cb["measured_s"] * cb["scale"]) < 0.05 and cb["k18_s"] < cb["measured_s"]
+    m22 = cb["measured_at_k22"]
+    assert m22["value"] > 3.0 * m22["k20_s"] > 9.0 * m22["k18_s"] and m22["cores"] == cb["cores"] and "profiles/r04_cpu_k22.json" in m22["source"]
+    assert abs(cb["scale"] - m22["value"] / m22["k20_s"]) < 1e-3
     assert d["comm"] is None and d["first_proof_s"] > d["setup_s"]
 
 
 def test_bench_two_ranks_on_one_device():
     """the N > 1 control flow of bench.py (one k = 18 proof sharded over 2 ranks through the library's communicator, host-staged
-    transport because both ranks share device 0): a strong-scaling line from rank 0"""
+    transport because both ranks share device 0): a strong-scaling line from rank 0, relayed by its GPU-free supervisor — first rung of the
+    ladder — with the roofline of rank 0's share and the CPU baseline the supervisor times once the workers are gone"""
     env = dict(os.environ, ZKHIP_BENCH_ONE_DEVICE="1", ZKHIP_BENCH_DIST_BACKEND="gloo")
     env.pop("WORLD_SIZE", None)
-    # `python bench.py --gpus 2` on its own: bench.py starts its two ranks itself (torch.distributed.run as a child process)
-    d = _run([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--agg-k", "18"], env=env)
+    # `python bench.py --gpus 2` on its own: bench.py starts torch.distributed.run -> 2 supervisors -> 2 workers (children, never an exec)
+    d = _run([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--agg-k", "16"], env=env)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["proofs_per_step"] == 1 and "sharded x2" in d["config"]["parallelism"]
-    assert d["cpu_baseline"] is None and d["value"] > 0
+    assert d["value"] > 0 and d["ladder"]["rung"] == 1 and d["ladder"]["failed_rungs"] == [] and "comm_note" not in d
     cm = d["comm"]
     assert cm["transport"] == "host" and cm["nranks"] == 2 and cm["transport_ranks"] == 2 and cm["shard_mode"] == "columns"
     assert cm["bytes_gathered_per_step"] > 0 and cm["collectives_total"] > 0
+    assert d["roofline"]["avg_launch_ms"] > 0 and 0 < d["roofline"]["frac"] < 1
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > d["value"] and cb["scale"] == 1.0 and "agg_k16" in cb["sample"]
 
 
-def test_bench_fails_without_a_communicator():
-    """N > 1 and no communicator: the run fails (no weak-scaling line under a strong-scaling n_gpus) unless --allow-replicas"""
+def test_ladder_falls_back_when_the_communicator_fails():
+    """N > 1 and the library's communicator cannot be created (injected): every sharded rung fails in fresh processes, the last rung — N
+    independent proofs — completes, and the line says so ("scaling": "weak", comm_note, ladder.failed_rungs); with --no-ladder the run fails."""
     env = dict(os.environ, ZKHIP_BENCH_ONE_DEVICE="1", ZKHIP_BENCH_DIST_BACKEND="gloo", ZKHIP_BENCH_FAIL_COMM="1")
     env.pop("WORLD_SIZE", None)
-    args = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--agg-k", "16"]
-    r = subprocess.run(args, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    args = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--agg-k", "16", "--no-cpu-baseline"]
+    r = subprocess.run(args + ["--no-ladder"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
-    d = _run(args[1:] + ["--allow-replicas"], env=env)
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["proofs_per_step"] == 2 and "comm_note" in d and d["comm"] is None
+    d = _run(args[1:], env=env)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["proofs_per_step"] == 2 and d["comm"] is None
+    assert d["ladder"]["rung"] == 4 and len(d["ladder"]["failed_rungs"]) == 3
+    assert "rung 1" in d["comm_note"] and "rung 4" in d["comm_note"] and "exited with code" in d["comm_note"]
+    # only the row-sharded exchange fails: the second rung (all-gather exchange) carries the run, still one sharded proof
+    env["ZKHIP_BENCH_FAIL_COMM"] = "row"
+    d = _run(args[1:], env=env)
+    assert d["scaling"] == "strong" and d["ladder"]["rung"] == 2 and d["comm"]["exchange_modes"]["proofs_row_sharded"] == 0 and d["comm"]["nranks"] == 2
 
 
-def test_bench_chain_four_ranks_on_one_device():
-    """BASELINE configs[4] (`--chain`): leaf proofs on ranks 0-3 (2 x RSA k = 17, 2 x SHA-shaped k = 19, unsharded contexts), barrier,
-    then the aggregation-shaped proof (k = 18 here) sharded over the four ranks — control flow on one device (host-staged transport)."""
-    env = dict(os.environ, ZKHIP_BENCH_ONE_DEVICE="1", ZKHIP_BENCH_DIST_BACKEND="gloo")
-    d = _run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-              os.path.join(ROOT, "bench.py"), "--gpus", "4", "--chain", "--steps", "1", "--warmup", "1", "--agg-k", "18"], env=env)
-    assert d["n_gpus"] == 4 and d["proofs_per_step"] == 5 and "chain" in d["config"]["workload"] and d["value"] > 0
-    assert d["comm"]["nranks"] == 4 and d["comm"]["bytes_gathered_per_step"] > 0 and len(d["proof_bytes"]) == 2
-
-
-def test_full_size_chain_on_one_gpu():
-    """BASELINE configs[4] at FULL size on one GPU (`--chain`): 2 x RSA k = 17 + 2 x SHA-shaped k = 19 leaf proofs (Poseidon), then the k = 22
-    aggregation-shaped proof (Keccak) — five proofs per step, each of the size its single-configuration run produces, in about the sum
-    of their times."""
-    d = _run([os.path.join(ROOT, "bench.py"), "--chain", "--steps", "2", "--warmup", "1"])
-    assert d["n_gpus"] == 1 and d["proofs_per_step"] == 5 and "chain" in d["config"]["workload"] and d["comm"] is None
-    sizes = d["proof_bytes"]
-    assert len(sizes) == 5 and sizes[0] == sizes[2] and sizes[1] == sizes[3] and all(s > 1000 for s in sizes)
-    assert sizes[4] > sizes[0]                      # 64-byte points under the EVM transcript
-    assert 0.12 < d["value"] < 0.5                  # 2 x 7 ms + 2 x 32 ms + 0.12 s
-
-
-def test_bench_two_ranks_through_the_rccl_transport_path():
-    """`python bench.py --gpus 2` with the library's RCCL transport (comm.hip's RCCL branch: ncclCommInitRank, the all-to-all self-check,
-    event-fenced all-gathers, grouped send / recv) driven through tests/fake_rccl on one device: the line reports transport "rccl", the rank
-    count the (stand-in) library itself reports, and the row-sharded exchange modes."""
-    import subprocess as sp
-
-    src = os.path.join(ROOT, "tests", "fake_rccl", "fake_rccl.cpp")
-    lib = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
-    if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
-        sp.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-shared", "-fPIC", "-O1", src, "-o", lib])
+def _fake_rccl():
+    lib = _fake_rccl()
     env = dict(os.environ, ZKHIP_BENCH_ONE_DEVICE="1", ZKHIP_BENCH_DIST_BACKEND="gloo", ZKHIP_COMM_TRANSPORT="rccl", ZKHIP_RCCL_LIB=lib,
                ZKFAKE_RCCL_SLOT_MB="64")
     env.pop("WORLD_SIZE", None)
-    d = _run([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--agg-k", "18", "--shard", "points"], env=env)
+    d = _run([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--agg-k", "18", "--shard", "points", "--no-cpu-baseline"], env=env)
     cm = d["comm"]
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and cm["transport"] == "rccl" and cm["nranks"] == 2 and cm["transport_ranks"] == 2
     assert cm["shard_mode"] == "points" and cm["bytes_gathered_per_step"] > 0

@@ -223,7 +223,7 @@ def _fake_rccl():
     src = os.path.join(ROOT, "tests", "fake_rccl", "fake_rccl.cpp")
     lib = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
     if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
-        subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-shared", "-fPIC", "-O1", src, "-o", lib])
+        subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-shared", "-fPIC", "-O1", src, "-o", lib])
     return lib
 
 

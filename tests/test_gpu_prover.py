@@ -592,3 +592,43 @@ def test_survey_witness_mix_is_satisfiable(zk, oracle):
     t = gp.prove_native(w, transcript="evm")
     assert t["proof"] == cp.prove(cp.witness(0, dist="survey"), transcript="evm")["proof"]
     assert verify_proof(gp, w, t["proof"], "evm")
+
+
+@pytest.mark.parametrize("k", [9, 13])
+def test_proof_on_a_params_file_of_unknown_trapdoor_passes_the_pairing_check(zk, oracle, tmp_path, k):
+    """The reference's acceptance criterion is the pairing (evm_verify, /root/reference/src/bin/cli.rs:524; src/tests/x509_aggregation.rs:110),
+    and its SRS comes from a file (gen_srs, cli.rs:222,306).  A CHILD PROCESS draws a trapdoor from os.urandom, writes kzg_bn254_<k>.srs and exits
+    without telling anyone; this process reads the file, proves on it, and the byte-driven verifier closes SHPLONK with
+    e(L, g2) = e(h2, s_g2) over the file's two G2 points.  The synthetic SRS's trapdoor equation must fail on the same bytes."""
+    import os
+    import subprocess
+    import sys
+
+    from verify_util import srs_g2_from_params_file, verify_proof
+
+    ffi, ctx = zk
+    path = str(tmp_path / f"kzg_bn254_{k}.srs")
+    code = ("import os, sys; sys.path.insert(0, %r)\n"
+            "import halo2_zkcert_amd.ffi as ffi, halo2_zkcert_amd.prover as pv\n"
+            "R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001\n"
+            "ctx = ffi.Context(0); s = int.from_bytes(os.urandom(48), 'little') %% R\n"
+            "ffi.ParamsKZG.setup(ctx, %d, pv.fr_from_int_host(s)).write(%r)\n" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), k, path))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip() == "", out.stderr[-2000:]
+    g2 = srs_g2_from_params_file(path)
+    assert g2[0] == __import__("pyref").G2_GEN and g2[1] is not None and g2[1] != g2[0]
+    backend = pv.GpuBackend(ctx, ffi)
+    backend.params_file = path
+    sh = pv.CircuitShape.small(k)
+    gp = pv.Prover(backend, sh, satisfiable=True)
+    assert backend.params_source == path
+    wit = gp.witness(0)
+    for kind in ("poseidon", "evm"):
+        proof = gp.prove_native(wit, transcript=kind)["proof"]
+        assert verify_proof(gp, wit, proof, kind, srs_g2=g2)
+        assert not verify_proof(gp, wit, proof, kind)                       # the public synthetic trapdoor is not this file's
+        bad = bytearray(proof)
+        bad[len(bad) // 2] ^= 1
+        assert not verify_proof(gp, wit, bytes(bad), kind, srs_g2=g2)
+    gp.release()
+    backend.params.free()

@@ -40,10 +40,18 @@ def vk_commitments(prover, oracle_side=False, srs_trapdoor=0x1D5C0FFEE, threads=
     return getattr(prover, key)
 
 
-def verify_proof(prover, wit, proof, kind, srs_trapdoor=0x1D5C0FFEE, oracle_vk=False):
+def srs_g2_from_params_file(path):
+    """(g2, s_g2) of a ParamsKZG file: its last 256 bytes (poly/kzg/commitment.rs ParamsKZG::write order: k, g, g_lagrange, g2, s_g2)"""
+    raw = open(path, "rb").read()[-256:]
+    return P.g2_from_raw_bytes(raw[:128]), P.g2_from_raw_bytes(raw[128:])
+
+
+def verify_proof(prover, wit, proof, kind, srs_trapdoor=0x1D5C0FFEE, oracle_vk=False, srs_g2=None):
     """True iff the proof BYTES verify: pyref.verify_proof_bytes reads them in upstream's verifier order with the named transcript
     ("blake2b", "evm", "poseidon"), re-derives every challenge, and checks the gate / permutation / lookup identities and the
-    SHPLONK opening.  Nothing of the prover's trace is consulted."""
+    SHPLONK opening.  Nothing of the prover's trace is consulted.  srs_g2 = (g2, s_g2) from the params file: the opening is closed by the
+    PAIRING e(L, g2) = e(h2, s_g2) — the reference's own acceptance check (evm_verify, /root/reference/src/bin/cli.rs:524) — and the
+    trapdoor is not used at all; else by the same equation in G1 under the known trapdoor of a synthetic SRS."""
     import halo2_zkcert_amd.prover as pv
 
     sh = prover.shape
@@ -51,7 +59,8 @@ def verify_proof(prover, wit, proof, kind, srs_trapdoor=0x1D5C0FFEE, oracle_vk=F
     fixed, sigma = vk_commitments(prover, oracle_side=oracle_vk, srs_trapdoor=srs_trapdoor)
     inst_vals = [zo.fr_arr_to_ints(np.asarray(v, dtype=np.uint64)) for v in wit["instance_values"]]
     inst_cols = [v + [0] * ((1 << sh.k) - len(v)) for v in inst_vals]
-    return P.verify_proof_bytes(_vk(sh), kind, proof, pv.from_mont_host(prover.vk_repr), inst_vals, inst_cols, fixed, sigma, aq, fq, srs_trapdoor)
+    return P.verify_proof_bytes(_vk(sh), kind, proof, pv.from_mont_host(prover.vk_repr), inst_vals, inst_cols, fixed, sigma, aq, fq,
+                                None if srs_g2 is not None else srs_trapdoor, srs_g2)
 
 
 def verify_trace(prover, wit, trace, srs_trapdoor=0x1D5C0FFEE, tamper=None):

@@ -81,7 +81,7 @@ if tiny_first:
 t_setup0 = time.perf_counter()
 prover = clock("Prover: ParamsKZG.setup + keygen-shaped fixture", lambda: pv.Prover(be, shape, satisfiable=True))
 wit = clock("witness fixture", lambda: prover.witness(0))
-ctx.set_option("host_timing", 1)
+ctx.set_option("host_timing", int(os.environ.get("COLD_TIMING", "1")))
 clock("first proof", lambda: prover.prove_native(wit, transcript=kind))
 first_proof_s = time.perf_counter() - t_setup0
 ctx.set_option("host_timing", 0)
