@@ -722,19 +722,21 @@ class Prover:
         m = len(src_rows)
         dst_rows = rng.permutation(gate_rows)[:m] + 2                      # `c` inputs when the partner is a basic column
         other_rows = rng.permutation(u)[:m]
-        pairs = []
-        inst_used = [0] * sh.n_instance
-        for t in range(m):
-            pcol = partner_cols[t % len(partner_cols)]
-            kind, idx = sh.perm_columns[pcol]
-            prow = dst_rows[t] if (kind == "advice" and idx < sh.n_basic) else other_rows[t]
-            if kind == "instance":      # only the first rows of an instance column carry values: one copy per public input, then constants
-                if inst_used[idx] < self.n_instance_values:
-                    prow = inst_used[idx]
-                    inst_used[idx] += 1
-                else:
-                    pcol = col_of[("fixed", sh.n_basic)]
-            pairs.append((col_of[("advice", t % sh.n_basic)] * n + int(src_rows[t]), pcol * n + int(prow)))
+        # pair t ties the `b` input of a gate in basic column t mod n_basic to a cell of partner column partner_cols[t mod len]: a `c` input
+        # if the partner is a basic column, any usable row otherwise; an instance partner takes the column's public inputs in turn (one copy
+        # per public input) and falls back to the constants column once they are used up.  (numpy throughout: m = usable / 8 pairs.)
+        t_ = np.arange(m)
+        pc = np.asarray(partner_cols, dtype=np.int64)[t_ % len(partner_cols)]
+        is_basic = np.array([kind == "advice" and idx < sh.n_basic for kind, idx in sh.perm_columns])
+        prow = np.where(is_basic[pc], dst_rows, other_rows).astype(np.int64)
+        for i in range(sh.n_instance):
+            hit = pc == col_of[("instance", i)]
+            turn = np.cumsum(hit) - 1
+            take = hit & (turn < self.n_instance_values)
+            prow[take] = turn[take]
+            pc[hit & ~take] = col_of[("fixed", sh.n_basic)]
+        adv_col = np.asarray([col_of[("advice", c)] for c in range(sh.n_basic)], dtype=np.int64)
+        pairs = np.stack([adv_col[t_ % sh.n_basic] * n + src_rows.astype(np.int64), pc * n + prow], axis=1)
         self._set_copy_constraints(pairs)
         # out = mask * (a(-3) + a(-2) a(-1)) + (1 - mask) * a(0), per basic column; the mask is appended to the fixed columns
         self._fill_graphs = []
@@ -757,12 +759,12 @@ class Prover:
         sh, b, n = self.shape, self.b, self.n
         P = len(sh.perm_columns)
         one = fr_from_int_host(1)
+        pairs = np.asarray(pairs, dtype=np.int64).reshape(-1, 2)
+        assert len(np.unique(pairs)) == pairs.size, "copy pairs must be disjoint"
         perm = np.arange(P * n, dtype=np.int64)
         value_src = np.arange(P * n, dtype=np.int64)
-        for p_, q_ in pairs:
-            assert perm[p_] == p_ and perm[q_] == q_, "copy pairs must be disjoint"
-            perm[p_], perm[q_] = q_, p_
-            value_src[p_] = q_
+        perm[pairs[:, 0]], perm[pairs[:, 1]] = pairs[:, 1], pairs[:, 0]
+        value_src[pairs[:, 0]] = pairs[:, 1]
         self._value_src = value_src
         self.copy_pairs = pairs
         # identity permutation values delta^j * w^i, then the swaps

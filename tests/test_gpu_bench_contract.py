@@ -96,6 +96,97 @@ def test_ladder_falls_back_when_the_communicator_fails():
 
 
 def _fake_rccl():
+    import subprocess as sp
+
+    src = os.path.join(ROOT, "tests", "fake_rccl", "fake_rccl.cpp")
+    lib = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
+    if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
+        sp.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-shared", "-fPIC", "-O1", src, "-o", lib])
+    return lib
+
+
+def test_a_stuck_collective_ends_the_rank_at_the_librarys_deadline():
+    """A collective whose stream never makes progress (tests/fake_rccl, ZKFAKE_RCCL_STALL=device-row:1:6 — rank 1, sixth collective call, row-sharded
+    rung only): the library's wait deadline (comm_timeout_ms) ends rank 1 with "stuck after collective #n, phase ...", the supervisors
+    stop rank 0's worker, and the next rung — fresh processes, all-gather exchange — completes."""
+    env = dict(os.environ, ZKHIP_BENCH_ONE_DEVICE="1", ZKHIP_BENCH_DIST_BACKEND="gloo", ZKHIP_COMM_TRANSPORT="rccl", ZKHIP_RCCL_LIB=_fake_rccl(),
+               ZKFAKE_RCCL_SLOT_MB="64", ZKFAKE_RCCL_STALL="device-row:1:6", ZKFAKE_RCCL_STALL_S="20")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--agg-k", "16", "--shard", "points",
+                        "--no-cpu-baseline", "--comm-timeout-ms", "4000", "--rung-budget", "120"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][-1])
+    assert d["ladder"]["rung"] == 2 and d["scaling"] == "strong" and d["comm"]["transport"] == "rccl"
+    assert "stuck after collective #" in r.stderr and "phase '" in r.stderr and "rank 1 of 2" in r.stderr
+
+
+def test_a_blocked_collective_call_is_ended_by_the_rung_budget():
+    """The same with a collective call that never returns on the host (ZKFAKE_RCCL_STALL=host-row:0:6): nothing inside the process can end it; the
+    supervisors kill the workers' process groups at the rung budget and the next rung completes."""
+    env = dict(os.environ, ZKHIP_BENCH_ONE_DEVICE="1", ZKHIP_BENCH_DIST_BACKEND="gloo", ZKHIP_COMM_TRANSPORT="rccl", ZKHIP_RCCL_LIB=_fake_rccl(),
+               ZKFAKE_RCCL_SLOT_MB="64", ZKFAKE_RCCL_STALL="host-row:0:6")
+    env.pop("WORLD_SIZE", None)
+    d = _run([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--agg-k", "16", "--shard", "points", "--no-cpu-baseline",
+              "--rung-budget", "45"], env=env)
+    assert d["ladder"]["rung"] == 2 and "overran" in d["ladder"]["failed_rungs"][0]["why"] and d["scaling"] == "strong"
+
+
+def test_one_rank_under_the_launcher_matches_the_plain_run():
+    """python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1 (the driver's launch shape at N = 1) = the plain run within 2 %"""
+    common = ["--gpus", "1", "--steps", "8", "--warmup", "2", "--no-other-configs", "--no-cpu-baseline", "--no-h2d"]
+    plain = _run([os.path.join(ROOT, "bench.py")] + common)
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    launched = _run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                     os.path.join(ROOT, "bench.py")] + common, env=env)
+    assert launched["n_gpus"] == 1 and abs(launched["value"] / plain["value"] - 1.0) < 0.02, (plain["value"], launched["value"])
+    assert launched["configs"]["agg22"]["proof_sha256"] == plain["configs"]["agg22"]["proof_sha256"]
+
+
+def test_bench_chain_four_ranks_on_one_device():
+    """BASELINE configs[4] (`--chain`): leaf proofs on ranks 0-3 (2 x RSA k = 17, 2 x SHA-shaped k = 19, unsharded contexts), barrier,
+    then the aggregation-shaped proof (k = 18 here) sharded over the four ranks — control flow on one device (host-staged transport)."""
+    env = dict(os.environ, ZKHIP_BENCH_ONE_DEVICE="1", ZKHIP_BENCH_DIST_BACKEND="gloo")
+    d = _run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+              os.path.join(ROOT, "bench.py"), "--gpus", "4", "--chain", "--steps", "1", "--warmup", "1", "--agg-k", "18", "--no-cpu-baseline"], env=env)
+    assert d["n_gpus"] == 4 and d["proofs_per_step"] == 5 and "chain" in d["config"]["workload"] and d["value"] > 0
+    assert d["comm"]["nranks"] == 4 and d["comm"]["bytes_gathered_per_step"] > 0 and len(d["proof_bytes"]) == 2
+    assert d["ladder"]["rung"] == 1 and d["roofline"]["kernel"] == "k_accum_affine" and d["roofline"]["avg_launch_ms"] > 0 and 0 < d["roofline"]["frac"] < 1
+
+
+def test_full_size_chain_over_four_ranks_equals_the_single_gpu_bytes():
+    """BASELINE configs[4] at FULL size with the k = 22 aggregation proof sharded over four ranks (`--chain --gpus 4 --agg-k 22`; one device,
+    host-staged transport): the aggregation proof's bytes are the single-GPU proof's, the leaf proofs' are the single-GPU chain's
+    (/root/reference/src/tests/x509_aggregation.rs:20-110, src/bin/cli.rs:464-527)."""
+    one = _run([os.path.join(ROOT, "bench.py"), "--chain", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"])
+    env = dict(os.environ, ZKHIP_BENCH_ONE_DEVICE="1", ZKHIP_BENCH_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    four = _run([os.path.join(ROOT, "bench.py"), "--gpus", "4", "--chain", "--steps", "1", "--warmup", "1", "--agg-k", "22", "--no-cpu-baseline",
+                 "--rung-budget", "800"], env=env, timeout=1500)
+    assert four["n_gpus"] == 4 and four["ladder"]["rung"] == 1 and four["comm"]["nranks"] == 4 and four["comm"]["shard_mode"] == "points"
+    assert four["comm"]["exchange_modes"]["proofs_pieces_sharded"] >= 2
+    assert len(one["proof_sha256"]) == 5 and len(four["proof_sha256"]) == 2            # rank 0: its RSA leaf proof + the aggregation proof
+    assert four["proof_sha256"][1] == one["proof_sha256"][4] and four["proof_bytes"][1] == one["proof_bytes"][4] > 2000
+    assert four["proof_sha256"][0] == one["proof_sha256"][0]
+
+
+def test_full_size_chain_on_one_gpu():
+    """BASELINE configs[4] at FULL size on one GPU (`--chain`): 2 x RSA k = 17 + 2 x SHA-shaped k = 19 leaf proofs (Poseidon), then the k = 22
+    aggregation-shaped proof (Keccak) — five proofs per step, each of the size its single-configuration run produces, in about the sum
+    of their times."""
+    d = _run([os.path.join(ROOT, "bench.py"), "--chain", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    assert d["roofline"]["kernel"] == "k_accum_affine" and d["roofline"]["launches_per_step"] >= 10 and 0 < d["roofline"]["frac"] < 1
+    assert d["n_gpus"] == 1 and d["proofs_per_step"] == 5 and "chain" in d["config"]["workload"] and d["comm"] is None
+    sizes = d["proof_bytes"]
+    assert len(sizes) == 5 and sizes[0] == sizes[2] and sizes[1] == sizes[3] and all(s > 1000 for s in sizes)
+    assert sizes[4] > sizes[0]                      # 64-byte points under the EVM transcript
+    assert 0.12 < d["value"] < 0.5                  # 2 x 7 ms + 2 x 32 ms + 0.12 s
+
+
+def test_bench_two_ranks_through_the_rccl_transport_path():
+    """`python bench.py --gpus 2` with the library's RCCL transport (comm.hip's RCCL branch: ncclCommInitRank, the all-to-all self-check,
+    event-fenced all-gathers, grouped send / recv) driven through tests/fake_rccl on one device: the line reports transport "rccl", the rank
+    count the (stand-in) library itself reports, and the row-sharded exchange modes."""
     lib = _fake_rccl()
     env = dict(os.environ, ZKHIP_BENCH_ONE_DEVICE="1", ZKHIP_BENCH_DIST_BACKEND="gloo", ZKHIP_COMM_TRANSPORT="rccl", ZKHIP_RCCL_LIB=lib,
                ZKFAKE_RCCL_SLOT_MB="64")

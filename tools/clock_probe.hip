@@ -85,10 +85,16 @@ int main() {
                 std::sort(mhz.begin(), mhz.end());
                 std::sort(cyc.begin(), cyc.end());
                 double waves_per_simd = wpc / 4.0;
-                // a SIMD interleaves waves_per_simd waves; each executes iters * per_iter instructions in cyc cycles
-                double cpi = cyc[blocks / 2] / ((double)iters * per_iter[kind] * waves_per_simd);
-                printf("%-15s waves/CU=%2d iters=%8d: %8.3f ms  shader clock median %.0f MHz (min %.0f max %.0f)  %.2f shader cycles per wave instruction per SIMD\n",
-                       names[kind], wpc, iters, ms, mhz[blocks / 2], mhz[0], mhz[blocks - 1], cpi);
+                // A SIMD interleaves waves_per_simd waves, each executing iters * per_iter instructions.  The figure to quote is the one
+                // from the kernel's WALL time (HIP events) at the measured shader clock: it is what a whole launch pays.  The per-block
+                // cycle count (median over blocks of clock64 deltas) only covers the span in which THAT block was resident; with more
+                // blocks than fit at once (4 and 8 waves per SIMD here) blocks run in turns and the median block sees fewer competitors
+                // than the launch average — that column under-reports (3.07 printed where the wall time gives 4.65).
+                double cpi_block = cyc[blocks / 2] / ((double)iters * per_iter[kind] * waves_per_simd);
+                double cpi_wall = (double)ms * 1e-3 * mhz[blocks / 2] * 1e6 / ((double)iters * per_iter[kind] * waves_per_simd);
+                printf("%-15s waves/CU=%2d iters=%8d: %8.3f ms  shader clock median %.0f MHz (min %.0f max %.0f)  %.2f shader cycles per wave instruction per SIMD "
+                       "from the launch's wall time (per-block median span: %.2f)\n",
+                       names[kind], wpc, iters, ms, mhz[blocks / 2], mhz[0], mhz[blocks - 1], cpi_wall, cpi_block);
             }
         }
     }
