@@ -162,24 +162,31 @@ def cpu_baseline(pv, args, config, head_k, transcript):
         return make_shape(pv, config, argparse.Namespace(**{**vars(args), "agg_k": k_}))
     if config == "agg22" and head_k > 18:
         k_m = max(19, min(head_k, args.cpu_baseline_k))
-        med18, ts18 = cpu_pass_seconds(pv, shape_at(18), transcript, threads)
-        t20 = None
-        if k_m > 20:
-            t20, _ = cpu_pass_seconds(pv, shape_at(20), transcript, threads, repeats=1, warm=False)
-        t_m, _ = cpu_pass_seconds(pv, shape_at(k_m), transcript, threads, repeats=1, warm=False)
-        per4 = (t_m / med18) ** (2.0 / (k_m - 18))          # measured growth per 4x rows
         rec = recorded_cpu_k22() if head_k == 22 else None
+        use_rec = bool(rec and k_m == 20 and rec.get("k20_s") and rec.get("k18_s") and rec.get("cores") == threads)
+        t20 = None
+        if use_rec:
+            # bounded sample (10-30 s of CPU work): ONE pass at k = 20; the k = 18 figure and the growth are the record's
+            med18, ts18 = rec["k18_s"], []
+        else:
+            med18, ts18 = cpu_pass_seconds(pv, shape_at(18), transcript, threads)
+            if k_m > 20:
+                t20, _ = cpu_pass_seconds(pv, shape_at(20), transcript, threads, repeats=1, warm=False)
+        t_m, _ = cpu_pass_seconds(pv, shape_at(k_m), transcript, threads, repeats=1, warm=False)
+        per4 = (t_m / med18) ** (2.0 / (k_m - 18))          # growth per 4x rows, k = 18 -> k_m
         if k_m == head_k:
             scale, how = 1.0, "a real pass at the headline size"
-        elif rec and k_m == 20 and rec.get("k20_s") and rec.get("cores") == threads:
+        elif use_rec:
             scale = rec["value"] / rec["k20_s"]
-            how = f"x{scale:.3f} = the k = 22 / k = 20 time ratio of the recorded real passes (profiles/r04_cpu_k22.json: {rec['value']:.1f} s / {rec['k20_s']:.1f} s on {rec['cores']} cores)"
+            how = (f"x{scale:.3f} = the k = 22 / k = 20 time ratio of the recorded real passes (profiles/r04_cpu_k22.json: {rec['value']:.1f} s / {rec['k20_s']:.1f} s / "
+                   f"{rec['k18_s']:.2f} s at k = 22 / 20 / 18 on {rec['cores']} cores, one process)")
         else:
             scale = per4 ** ((head_k - k_m) / 2.0)
             how = f"x{scale:.3f} = the measured k = 18 -> {k_m} growth carried to k = {head_k}"
+        k18_txt = (f"k = 18 in the record: {med18:.3f} s" if use_rec else
+                   f"the same shape at k = 18: median of 3 after a warm-up = {med18:.3f} s ({', '.join(f'{t:.3f}' for t in ts18)})")
         out = dict(value=round(t_m * scale, 4), unit="s", cores=threads, kind="port", measured_s=round(t_m, 4), scale=round(scale, 4),
-                   sample=f"{shape_at(k_m).name}: ONE full pass at k = {k_m} = {t_m:.3f} s; the same shape at k = 18: median of 3 after a warm-up = "
-                          f"{med18:.3f} s ({', '.join(f'{t:.3f}' for t in ts18)}); measured growth per 4x rows = {per4:.3f}; {how}"
+                   sample=f"{shape_at(k_m).name}: ONE full pass at k = {k_m} = {t_m:.3f} s; {k18_txt}; growth per 4x rows k = 18 -> {k_m} = {per4:.3f}; {how}"
                           "; oracle/zkoracle.c with OpenMP, SRS / keygen excluded",
                    measured_k=k_m, k18_s=round(med18, 4), growth_per_4x_rows=round(per4, 4))
         if t20 is not None:
@@ -552,6 +559,7 @@ def worker(args):
         ctx.profile_select(DOMINANT)
         ctx.profile_enable(True)
         g0 = ctx.comm_bytes_gathered()
+        c0 = ctx.comm_describe()["collectives"] if shard else 0
         barrier()
         t0 = time.perf_counter()
         native_s = 0.0
@@ -561,6 +569,7 @@ def worker(args):
         barrier()
         dt = time.perf_counter() - t0
         gathered = (ctx.comm_bytes_gathered() - g0) // max(steps, 1)
+        coll_per_proof = (ctx.comm_describe()["collectives"] - c0) / max(steps, 1) if shard else 0
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -683,7 +692,7 @@ def worker(args):
                "proof_sha256": hashlib.sha256(bytes(trace.get("proof", b""))).hexdigest(),
                "setup_s": round(setup_s, 3), "resident_bytes": int(resident), "rooflines": roof, "kernels_ms_per_step": kernels,
                "traffic_source": traffic_file, "with_h2d": h2d, "msm_shard": shard_mode,
-               "first_proof_s": round(setup_s + first_s, 3), "comm": comm_fields(gathered, shard_mode),
+               "first_proof_s": round(setup_s + first_s, 3), "comm": comm_fields(gathered, shard_mode, coll_per_proof),
                "native_call_ms_per_step": round(native_s * 1000.0 / steps, 3) if native_s else None}   # zkhip_create_proof_ex alone; ms_per_step also holds the ctypes wrapper around it
         prover.release()          # the context's per-key caches (coset-layout key columns, sorted lookup table)
         backend.params.free()
@@ -737,6 +746,7 @@ def worker(args):
             c_.profile_select(DOMINANT)
             c_.profile_enable(True)
         g0 = ctx.comm_bytes_gathered()
+        c0 = ctx.comm_describe()["collectives"] if shard else 0
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -773,7 +783,8 @@ def worker(args):
                "workload": "chain (BASELINE configs[4]): 2 x RSA k=17 + 2 x SHA256-shaped k=19 leaf proofs (Poseidon), barrier, aggregation-shaped "
                            f"k={args.agg_k} proof (Keccak)",
                "parallelism": par, "proof_bytes": list(sizes), "proof_sha256": list(digests), "roofline": roof,
-               "bytes_gathered_per_step": (ctx.comm_bytes_gathered() - g0) // steps if shard else 0}
+               "bytes_gathered_per_step": (ctx.comm_bytes_gathered() - g0) // steps if shard else 0,
+               "collectives_per_step": (ctx.comm_describe()["collectives"] - c0) / steps if shard else 0}
         for pr_, _, _ in leaves:
             pr_.release()
             pr_.b.params.free()
@@ -784,11 +795,12 @@ def worker(args):
             leaf_ctx.close()
         return res
 
-    def comm_fields(per_step_bytes, shard_mode):
+    def comm_fields(per_step_bytes, shard_mode, collectives_per_step=None):
         if not shard:
             return None
         d = ctx.comm_describe()
         return {"transport": d["transport"], "nranks": d["nranks"], "transport_ranks": d["transport_ranks"], "collectives_total": d["collectives"],
+                "collectives_per_step": collectives_per_step,     # exchanges (all-gathers + all-to-alls) the library issued per timed step on this rank
                 "bytes_gathered_per_step": int(per_step_bytes), "shard_mode": shard_mode,
                 "exchange_modes": {k_: ctx.profile_counter(k_) for k_ in ("proofs_row_sharded", "proofs_pieces_sharded", "shplonk_row_sharded")},
                 "note": "nranks / transport_ranks / bytes: what the library's own communicator reports on rank 0 (zkhip_comm_info / zkhip_comm_describe; "
@@ -804,7 +816,7 @@ def worker(args):
                               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": False,
                               "scaling": "strong", "vs_baseline": None, "dtype": "u256 (BN254 Fr/Fq, Montgomery)", "data": "synthetic", "proofs_per_step": 5,
                               "config": {"workload": res["workload"], "parallelism": res["parallelism"], "k": args.agg_k, "transcript": "evm"}, "proof_bytes": res["proof_bytes"], "proof_sha256": res["proof_sha256"],
-                              "comm": comm_fields(res["bytes_gathered_per_step"], "points" if args.shard == "auto" else args.shard),
+                              "comm": comm_fields(res["bytes_gathered_per_step"], "points" if args.shard == "auto" else args.shard, res["collectives_per_step"]),
                               "roofline": res["roofline"], "cpu_baseline": cb, "build": bh}), flush=True)
         teardown()
         return

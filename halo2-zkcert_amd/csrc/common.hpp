@@ -55,6 +55,7 @@ struct Scratch {
 struct zkhip_options {
     int msm_c = 0, msm_seg = 0, msm_tailparts = 0, msm_ch = 0, msm_widetail = -1, msm_adaptive_l = 1, msm_debug = 0;
     int sort_hb = 0, sort_tile = 0, sort_one_atomic = 1, sort_copies = 0, sort_wide = -1;   // sort_wide: low-pass block shape (-1: 1024 threads x 8 pairs for 8192-pair tiles)
+    int ntt_lds_pad = 0;   // analysis only: KiB of unused dynamic LDS added to every register-tiled NTT workgroup (fewer tiles per CU: the occupancy-vs-time curve)
     int ntt_smax = 0, ntt_r8 = 4, ntt_group = 0;   // ntt_r8: 0 stage-per-barrier, 1 8 per thread, 2 / 3 4 per thread on 2048 / 1024 tiles, 4 auto
     int permute_rank_sort = 1, eval_byval = 1, late_overlap = -1;
     int host_timing = 0;   // zkhip_create_proof prints its host-side phase times to stderr
@@ -152,37 +153,21 @@ struct ProfScope {
     ~ProfScope() { if (active) c->prof_end(); }
 };
 
-// A context with a communicator waits for its peers whenever it waits for its own stream: a collective whose partner never arrives
-// (a rank that died, an RCCL that cannot connect two GPUs) would leave the host in hipStreamSynchronize for ever.  While a communicator
-// exists the slow path of the two waits below is therefore a poll with a deadline (zkhip_options::comm_timeout_ms); on expiry the wait
-// fails with hipErrorLaunchTimeOut and the error text names the rank, the number of collectives issued so far and the phase of the proof.
+// Host waits.  hipStreamSynchronize sleeps on an interrupt and wakes tens of microseconds late, and the prover has a dozen Fiat-Shamir
+// round trips per proof on its critical path: the two waits below POLL (hipStreamQuery / hipEventQuery), reading the clock every 64 polls.
+// A context with a communicator waits for its peers whenever it waits for its own stream — a collective whose partner never arrives (a
+// rank that died, an RCCL that cannot connect two GPUs) would leave the host polling for ever — so while a communicator exists the poll
+// has a deadline (zkhip_options::comm_timeout_ms): on expiry the wait fails with hipErrorLaunchTimeOut and the error text names the rank,
+// the number of collectives issued so far and the phase of the proof.  Without a communicator: poll for 10 s, then the blocking wait.
 namespace zk {
 struct CommWatch { const zkhip_ctx* ctx = nullptr; };
 extern CommWatch g_watch;                                  // ctx.hip; set by zkhip_comm_init*, cleared by zkhip_comm_destroy
-hipError_t wait_slow(hipStream_t st, hipEvent_t ev);       // ctx.hip: the blocking wait, or the deadline poll when g_watch.ctx is set
+hipError_t wait_poll(hipStream_t st, hipEvent_t ev);       // ctx.hip
 }
-
-// Waits for a stream by polling: hipStreamSynchronize sleeps on an interrupt and wakes tens of microseconds late, and the prover
-// has a dozen Fiat-Shamir round trips per proof on its critical path.  Bounded spin, then the slow wait.
-static inline hipError_t stream_wait(hipStream_t st) {
-    for (int i = 0; i < 2000000; ++i) {
-        hipError_t e = hipStreamQuery(st);
-        if (e != hipErrorNotReady) return e;
-    }
-    (void)hipGetLastError();
-    return zk::wait_slow(st, nullptr);
-}
-
-// Waits (polling) for an event recorded right after a small read-back, not for the whole stream: the kernels issued after the
-// event keep running while the host acts on the value, so the next launches queue up behind them without a bubble.
-static inline hipError_t event_wait(hipEvent_t ev) {
-    for (int i = 0; i < 2000000; ++i) {
-        hipError_t e = hipEventQuery(ev);
-        if (e != hipErrorNotReady) return e;
-    }
-    (void)hipGetLastError();
-    return zk::wait_slow(nullptr, ev);
-}
+static inline hipError_t stream_wait(hipStream_t st) { return zk::wait_poll(st, nullptr); }
+// Waits for an event recorded right after a small read-back, not for the whole stream: the kernels issued after the event keep running
+// while the host acts on the value, so the next launches queue up behind them without a bubble.
+static inline hipError_t event_wait(hipEvent_t ev) { return zk::wait_poll(nullptr, ev); }
 
 struct zkhip_domain;
 namespace zk {

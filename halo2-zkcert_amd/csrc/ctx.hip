@@ -32,10 +32,9 @@ hipError_t dev_malloc(void** p, size_t bytes) {
 }
 
 CommWatch g_watch;
-hipError_t wait_slow(hipStream_t st, hipEvent_t ev) {
+hipError_t wait_poll(hipStream_t st, hipEvent_t ev) {
     const zkhip_ctx* c = g_watch.ctx;
-    const int limit_ms = c ? c->opt.comm_timeout_ms : 0;
-    if (limit_ms <= 0) return st ? hipStreamSynchronize(st) : hipEventSynchronize(ev);
+    const double limit_ms = c && c->opt.comm_timeout_ms > 0 ? (double)c->opt.comm_timeout_ms : 0.0;
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
         for (int i = 0; i < 64; ++i) {
@@ -44,13 +43,17 @@ hipError_t wait_slow(hipStream_t st, hipEvent_t ev) {
         }
         (void)hipGetLastError();
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        if (ms > (double)limit_ms) {
-            snprintf(g_stuck, sizeof g_stuck, "rank %d of %d stuck after collective #%llu, phase '%s': no progress on the device for %d ms (comm_timeout_ms)",
-                     c->comm.rank, c->comm.nranks, (unsigned long long)c->comm.collectives, c->comm.phase ? c->comm.phase : "", limit_ms);
-            fprintf(stderr, "zkhip: %s\n", g_stuck);
-            return hipErrorLaunchTimeOut;
+        if (limit_ms > 0.0) {
+            if (ms > limit_ms) {
+                snprintf(g_stuck, sizeof g_stuck, "rank %d of %d stuck after collective #%llu, phase '%s': no progress on the device for %d ms (comm_timeout_ms)",
+                         c->comm.rank, c->comm.nranks, (unsigned long long)c->comm.collectives, c->comm.phase ? c->comm.phase : "", c->opt.comm_timeout_ms);
+                fprintf(stderr, "zkhip: %s\n", g_stuck);
+                return hipErrorLaunchTimeOut;
+            }
+            if (ms > 200.0) std::this_thread::sleep_for(std::chrono::microseconds(100));   // a wait this long is not a Fiat-Shamir round trip: stop burning the core
+        } else if (ms > 10000.0) {
+            return st ? hipStreamSynchronize(st) : hipEventSynchronize(ev);
         }
-        std::this_thread::sleep_for(std::chrono::microseconds(200));
     }
 }
 }  // namespace zk
@@ -171,7 +174,7 @@ const OptName OPTIONS[] = {
     {"ZKHIP_MSM_DEBUG", "msm_debug", &zkhip_options::msm_debug}, {"ZKHIP_SORT_HB", "sort_hb", &zkhip_options::sort_hb},
     {"ZKHIP_SORT_TILE", "sort_tile", &zkhip_options::sort_tile}, {"ZKHIP_SORT_ONE_ATOMIC", "sort_one_atomic", &zkhip_options::sort_one_atomic}, {"ZKHIP_SORT_WIDE", "sort_wide", &zkhip_options::sort_wide}, {"ZKHIP_SORT_COPIES", "sort_copies", &zkhip_options::sort_copies},
     {"ZKHIP_NTT_SMAX", "ntt_smax", &zkhip_options::ntt_smax}, {"ZKHIP_NTT_R8", "ntt_r8", &zkhip_options::ntt_r8},
-    {"ZKHIP_NTT_GROUP", "ntt_group", &zkhip_options::ntt_group}, {"ZKHIP_PERMUTE_RANK_SORT", "permute_rank_sort", &zkhip_options::permute_rank_sort},
+    {"ZKHIP_NTT_GROUP", "ntt_group", &zkhip_options::ntt_group}, {"ZKHIP_NTT_LDS_PAD", "ntt_lds_pad", &zkhip_options::ntt_lds_pad}, {"ZKHIP_PERMUTE_RANK_SORT", "permute_rank_sort", &zkhip_options::permute_rank_sort},
     {"ZKHIP_EVAL_BYVAL", "eval_byval", &zkhip_options::eval_byval}, {"ZKHIP_LATE_OVERLAP", "late_overlap", &zkhip_options::late_overlap},
     {"ZKHIP_HOST_TIMING", "host_timing", &zkhip_options::host_timing},
     {"ZKHIP_COSET_QUOTIENT", "coset_quotient", &zkhip_options::coset_quotient}, {"ZKHIP_ROW_SHARDED", "row_sharded", &zkhip_options::row_sharded},
@@ -286,7 +289,7 @@ int zkhip_key_release(zkhip_ctx* c, uint64_t key_id) {
 }
 int zkhip_synchronize(zkhip_ctx* c) {
     if (!c) { set_error("null ctx"); return ZKHIP_EINVAL; }
-    ZK_HIP(hipStreamSynchronize(c->stream));
+    ZK_HIP(stream_wait(c->stream));      // (polling, with the communicator's deadline if there is one)
     return ZKHIP_OK;
 }
 int zkhip_malloc(zkhip_ctx* c, size_t bytes, void** dptr) {
@@ -303,7 +306,7 @@ int zkhip_free(zkhip_ctx* c, void* dptr) {
 int zkhip_memcpy_h2d(zkhip_ctx* c, void* dst, const void* src, size_t bytes) {
     if (!c) { set_error("null ctx"); return ZKHIP_EINVAL; }
     ZK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
-    ZK_HIP(hipStreamSynchronize(c->stream));
+    ZK_HIP(stream_wait(c->stream));
     return ZKHIP_OK;
 }
 int zkhip_memcpy_d2h(zkhip_ctx* c, void* dst, const void* src, size_t bytes) {

@@ -571,6 +571,10 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
         for (const void* f : {(const void*)k_ntt_final, (const void*)k_ntt_strided_r8, (const void*)k_ntt_strided_r4, (const void*)k_ntt_final_r8<SWZ_FIELD>, (const void*)k_ntt_final_r8<SWZ_FIELD2>,
                               (const void*)k_ntt_final_r4<SWZ_FIELD>, (const void*)k_ntt_final_r4<SWZ_FIELD2>, (const void*)k_ntt_final_r4<SWZ_REV>})
             if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NTT_TILE * sizeof(fe)));
+        // the occupancy experiment (ntt_lds_pad) asks for up to a whole CU's LDS per workgroup of the 4-per-thread kernels
+        for (const void* f : {(const void*)k_ntt_strided_r4, (const void*)k_ntt_strided_r4s, (const void*)k_ntt_final_r4<SWZ_FIELD>, (const void*)k_ntt_final_r4<SWZ_FIELD2>, (const void*)k_ntt_final_r4<SWZ_REV>,
+                              (const void*)k_ntt_final_r4s<SWZ_FIELD>, (const void*)k_ntt_final_r4s<SWZ_FIELD2>, (const void*)k_ntt_final_r4s<SWZ_REV>})
+            if (attr_err == hipSuccess && ctx->opt.ntt_lds_pad > 0) attr_err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     ZK_HIP(attr_err);
     // pass plan
@@ -612,7 +616,7 @@ static int ntt_run(zkhip_ctx* ctx, const void* const* srcs, void* const* dsts, s
     if (np > 6) { set_error("ntt: too many passes"); return ZKHIP_EINVAL; }
     const bool r4 = r8 && SBh == 2;
     const unsigned rthreads = (1u << tlog) >> SBh;
-    const size_t rlds = ((size_t)1 << tlog) * sizeof(fe);
+    const size_t rlds = std::min<size_t>(((size_t)1 << tlog) * sizeof(fe) + (r4 && ctx->opt.ntt_lds_pad > 0 ? (size_t)ctx->opt.ntt_lds_pad * 1024 : 0), 160 * 1024);
     std::vector<void*> tmp_host(npolys);
     if (np > 1) {
         void* d_tmpbuf;

@@ -25,6 +25,24 @@ else:
     dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
 ctx = ffi.Context(dev)
 ctx.comm_init(rank, world, dist)
+if os.environ.get("ZK_STALL_TEST") == "1":
+    # the library's wait deadline (common.hpp wait_poll): one all-gather through the communicator, then a host wait on the context's stream.
+    # The stand-in library stalls ONE rank's collective stream (ZKFAKE_RCCL_STALL=device:<rank>:3): that rank's wait must fail with the
+    # deadline's message, the other rank's must succeed.  No teardown: a communicator with a stuck stream is not destroyed, the process leaves.
+    send = torch.full((64,), rank + 1, dtype=torch.uint8, device="cuda")
+    recv = torch.zeros((64 * world,), dtype=torch.uint8, device="cuda")
+    res = {"rank": rank, "error": None}
+    torch.cuda.synchronize()
+    try:
+        ctx.comm_allgather(send, recv)
+        ctx.synchronize()
+        res["recv"] = recv.cpu().tolist()[::64]
+    except Exception as e:   # noqa: BLE001
+        res["error"] = str(e)
+    with open(os.path.join(os.environ["ZK_OUT"], f"rank{rank}.json"), "w") as f:
+        json.dump(res, f)
+    sys.stdout.flush()
+    os._exit(0)
 mode = os.environ.get("ZK_SHARD_MODE", "points")
 ctx.comm_shard(mode)
 out = {"transport": ctx.transport, "shard_mode": mode}

@@ -245,6 +245,19 @@ def test_rccl_transport_path_with_emulated_rccl(zk, tmp_path, world, mode):
             assert o[key]["native"] == hexs and o[key]["python"] == hexs, key
 
 
+def test_a_stuck_collective_fails_the_host_wait_at_the_deadline(zk, tmp_path):
+    """comm_timeout_ms (common.hpp wait_poll): the stand-in library leaves rank 0's collective stream spinning after the first all-gather that
+    follows the init-time self-check (ZKFAKE_RCCL_STALL=device:0:3) — a collective whose peer never arrives, as the host sees it.  Rank 0's next
+    wait on its context fails after 2 s with the rank, the collective count and the phase in the message instead of polling for ever;
+    rank 1, whose all-gather completed, is not affected."""
+    outs = _run_workers(tmp_path, 2, True, 0, extra_env={"ZKHIP_RCCL_LIB": _fake_rccl(), "ZKHIP_COMM_TRANSPORT": "rccl", "ZKFAKE_RCCL_SLOT_MB": "8",
+                                                         "ZK_STALL_TEST": "1", "ZKFAKE_RCCL_STALL": "device:0:3", "ZKFAKE_RCCL_STALL_S": "40",
+                                                         "ZKHIP_COMM_TIMEOUT_MS": "2000"}, timeout=300)
+    assert outs[1]["error"] is None and outs[1]["recv"] == [1, 2]
+    err = outs[0]["error"]
+    assert err and "rank 0 of 2 stuck after collective #1" in err and "no progress on the device for 2000 ms" in err, err
+
+
 def test_agg_k22_proof_over_two_ranks_through_the_rccl_branch(zk, tmp_path):
     """the full-size k = 22 proof over 2 ranks once more, through comm.hip's RCCL branch against the checking stand-in (600 MB all-to-all
     blocks through 2.6 GB of shared memory): the single-GPU proof's bytes, every send paired with its receive"""
