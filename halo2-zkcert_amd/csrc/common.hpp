@@ -162,12 +162,12 @@ struct ProfScope {
 namespace zk {
 struct CommWatch { const zkhip_ctx* ctx = nullptr; };
 extern CommWatch g_watch;                                  // ctx.hip; set by zkhip_comm_init*, cleared by zkhip_comm_destroy
-hipError_t wait_poll(hipStream_t st, hipEvent_t ev);       // ctx.hip
+hipError_t wait_poll(hipStream_t st, hipEvent_t ev);       // ctx.hip: ev != null: wait for the event; else for the stream (null = the legacy default stream)
 }
 static inline hipError_t stream_wait(hipStream_t st) { return zk::wait_poll(st, nullptr); }
 // Waits for an event recorded right after a small read-back, not for the whole stream: the kernels issued after the event keep running
 // while the host acts on the value, so the next launches queue up behind them without a bubble.
-static inline hipError_t event_wait(hipEvent_t ev) { return zk::wait_poll(nullptr, ev); }
+static inline hipError_t event_wait(hipEvent_t ev) { return ev ? zk::wait_poll(nullptr, ev) : hipErrorInvalidResourceHandle; }
 
 struct zkhip_domain;
 namespace zk {

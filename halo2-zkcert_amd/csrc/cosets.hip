@@ -209,7 +209,10 @@ int zk::key_cosets(zkhip_ctx* ctx, const CosetPlan* cp, const zk_proving_key* pk
         src.push_back(i < F ? pk->fixed_coeff[i] : pk->sigma_coeff[i - F]);
         dst.push_back(d);
     }
-    ZK_TRY(coeff_to_cosets(ctx, p, src.data(), dst.data(), F + P));
+    // in batches of four polynomials: the transform's pass buffer is sized by the batch, and one batch of all F + P columns (4.7 GiB at
+    // k = 22) would stay in the context for good as the largest scratch buffer it ever needed — first-touched once, never used again
+    for (size_t i0 = 0; i0 < src.size(); i0 += 4)
+        ZK_TRY(coeff_to_cosets(ctx, p, src.data() + i0, dst.data() + i0, std::min<size_t>(4, src.size() - i0)));
     // l_0, l_last (row n - blinding_factors - 1), l_active_row = 1 - l_last - sum of the blinding rows' basis polynomials:
     // Lagrange indicator vectors -> coefficients -> cosets
     void* d_lag;

@@ -38,7 +38,7 @@ hipError_t wait_poll(hipStream_t st, hipEvent_t ev) {
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
         for (int i = 0; i < 64; ++i) {
-            hipError_t e = st ? hipStreamQuery(st) : hipEventQuery(ev);
+            hipError_t e = ev ? hipEventQuery(ev) : hipStreamQuery(st);      // (st may be the null stream: a context bound to the caller's default stream)
             if (e != hipErrorNotReady) return e;
         }
         (void)hipGetLastError();
@@ -52,7 +52,7 @@ hipError_t wait_poll(hipStream_t st, hipEvent_t ev) {
             }
             if (ms > 200.0) std::this_thread::sleep_for(std::chrono::microseconds(100));   // a wait this long is not a Fiat-Shamir round trip: stop burning the core
         } else if (ms > 10000.0) {
-            return st ? hipStreamSynchronize(st) : hipEventSynchronize(ev);
+            return ev ? hipEventSynchronize(ev) : hipStreamSynchronize(st);
         }
     }
 }
@@ -71,7 +71,9 @@ int zkhip_ctx::get_scratch(const char* name, size_t bytes, void** out) {
             s.ptr = nullptr;
             s.bytes = 0;
         }
-        size_t want = bytes + bytes / 8;
+        // a little slack on small buffers (sizes that creep up call after call); none on large ones: every GiB a context holds is
+        // first-touched once — 4 ms on a warm box, ~27 ms on a freshly leased one (profiles/r04_cold_start.md)
+        size_t want = bytes < ((size_t)64 << 20) ? bytes + bytes / 8 : bytes;
         hipError_t e = zk::dev_malloc((void**)&s.ptr, want);
         if (e != hipSuccess) {
             (void)hipGetLastError();

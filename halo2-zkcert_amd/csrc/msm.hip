@@ -1013,9 +1013,28 @@ static int msm_local(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const 
     const uint32_t c = srs->c, W = srs->W, B = srs->B;
     const size_t items = n * W;
     const uint32_t seg0_min = 8;
+    // Round-0 segment length depends on the problem size only: aim for ~2 waves per SIMD over the chip.
+    uint32_t seg = seg0_min;
+    {
+        // about four waves per SIMD over the launch, as a power of two (L = 24 / 40 cost 2-3 % of a 2^17 proof against 16 / 32: the
+        // lane index arithmetic divides by L) and at least 16 (at 8 a single column's buckets collect more than 8 partial sums each
+        // and every MSM pays reduction rounds)
+        size_t target_threads = (size_t)256 * 4 * 64 * 4;
+        size_t sgl = (ncols * items) / target_threads;
+        if (sgl >= 8) {   // smaller launches are latency chains: keep the lanes short (8)
+            seg = 16;
+            const uint32_t cap = n >= ((size_t)1 << 20) ? 64 : 32;   // measured: 2^18-2^19 prefer 16-32 (-3 %), 2^20-2^22 64
+            while (seg < cap && (size_t)seg * 2 <= sgl) seg *= 2;
+        }
+        { int v = ctx->opt.msm_seg; if (v >= (int)seg0_min && v <= 256) seg = (uint32_t)v; }
+    }
     // scratch
     void *d_colptrs, *d_zero, *d_off, *d_tmp_entry, *d_tmp_key, *d_entries, *d_max, *d_cntA, *d_cntB, *d_offA, *d_offB, *d_pA, *d_pB, *d_chunks;
-    const size_t pstride0 = items / seg0_min + B + 1;
+    // Partial sums per column: one per (round-0 lane, bucket it touches).  A lane covers l consecutive sorted entries, l = lane_len(total, items,
+    // seg, ncols) >= total * seg / items (and >= 2), so there are at most total / l + B <= items / seg + B of them whatever the column's density;
+    // the reduction rounds only shrink that.  (Until round 4 the two buffers were sized for seg = 8: 11.3 GiB for a five-column batch at k = 22,
+    // of which 2.1 GiB could ever be written.)
+    const size_t pstride0 = items / seg + B + 64;
     SortGeom g;
     g.c = c; g.W = W; g.B = B;
     g.R = 1;
@@ -1075,21 +1094,6 @@ static int msm_local(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const 
         cp_tables.dev = (const uint32_t* const*)((const void**)d_colptrs + ncols);
     }
     ZK_HIP(hipMemsetAsync(d_zero, 0, zero_words * 4, st));
-    // Round-0 segment length depends on the problem size only: aim for ~2 waves per SIMD over the chip.
-    uint32_t seg = seg0_min;
-    {
-        // about four waves per SIMD over the launch, as a power of two (L = 24 / 40 cost 2-3 % of a 2^17 proof against 16 / 32: the
-        // lane index arithmetic divides by L) and at least 16 (at 8 a single column's buckets collect more than 8 partial sums each
-        // and every MSM pays reduction rounds)
-        size_t target_threads = (size_t)256 * 4 * 64 * 4;
-        size_t sgl = (ncols * items) / target_threads;
-        if (sgl >= 8) {   // smaller launches are latency chains: keep the lanes short (8)
-            seg = 16;
-            const uint32_t cap = n >= ((size_t)1 << 20) ? 64 : 32;   // measured: 2^18-2^19 prefer 16-32 (-3 %), 2^20-2^22 64
-            while (seg < cap && (size_t)seg * 2 <= sgl) seg *= 2;
-        }
-        { int v = ctx->opt.msm_seg; if (v >= (int)seg0_min && v <= 256) seg = (uint32_t)v; }
-    }
     dim3 gn(div_up(n, 256), (unsigned)ncols);
     dim3 gt(div_up(items, g.tile) + g.P, (unsigned)ncols);
     // the "heaviest bucket" read-back: the plan kernel stores it straight into pinned host memory (slot at 1 KiB) when it fits
