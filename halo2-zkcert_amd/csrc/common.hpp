@@ -111,6 +111,9 @@ struct zkhip_ctx {
     void* h_pinned = nullptr;   // 64 KiB of pinned host memory for the small device->host reads on the critical path
     static constexpr size_t PINNED_BYTES = 64 * 1024;
     std::map<std::string, zk::Scratch> scratch;
+    // name -> a buffer of ANOTHER phase that is dead while this name is in use (zkhip_create_proof_ex lends the advice cosets' block to
+    // SHPLONK's quotient scratch): get_scratch hands it out instead of allocating, if it is large enough.  Set and cleared by the lender.
+    std::map<std::string, zk::Scratch> lent;
     std::map<std::string, std::shared_ptr<void>> host_objects;   // host-side companions of persistent buffers (cosets.hip's plans)
     std::map<std::string, void*> persistent;   // named device buffers that outlive a call (keygen-like derived data), freed with the context
     // Twiddle tables keyed by (log_n, omega).  w^e for any e < 2^log_n is lo[e & (2^h - 1)] * hi[e >> h]

@@ -835,7 +835,14 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
         if (out->eval_rotation && out->evals_cap >= nq) memcpy(out->eval_rotation, q_rot.data(), nq * 4);
         if (out->eval_write_order && out->evals_cap >= nq) memcpy(out->eval_write_order, w_order.data(), w_order.size() * 4);
     }
-    // ---- 6. SHPLONK multi-open of all of them
+    // ---- 6. SHPLONK multi-open of all of them.  The cosets of the advice / product columns are dead since the sweep: their blocks serve as
+    // the multi-open's quotient / numerator scratch (2.4 GiB at k = 22 that are then never allocated)
+    struct Lend {
+        zkhip_ctx* c;
+        ~Lend() { c->lent.clear(); }
+    } lend{ctx};
+    ctx->lent["sp_quot"] = zk::Scratch{w_ext, pad(A + I) * EB};
+    ctx->lent["sp_num"] = zk::Scratch{w_ext_z, pad(Zp + L) * EB};
     uint64_t h1[8], h2[8];
     ZK_TRY(zk::shplonk_open(ctx, pk->g, n, polys.data(), polys.size(), q_poly.data(), q_points.data(), q_evals.data(), nq, tr, h1, h2, pieces_sharded));
     mark("shplonk done");
