@@ -26,12 +26,14 @@ import halo2_zkcert_amd.prover as pv
 ffi.lib()
 t_lib = time.perf_counter() - t0
 
-args = [a for a in sys.argv[1:] if not a.startswith("--")]
+then = sys.argv[sys.argv.index("--then") + 1] if "--then" in sys.argv else None      # a second configuration in the same process (what bench.py's other configs see)
+args = [a for a in sys.argv[1:] if not a.startswith("--") and a != then]
 name = args[0] if args else "agg22"
 tiny_first = "--tiny-first" in sys.argv
-shape = {"agg22": lambda: pv.CircuitShape.agg(22, 3, 1), "rsa17": lambda: pv.CircuitShape.rsa(17),
-         "sha19": lambda: pv.CircuitShape.sha256(19, n_advice=32, n_fixed=12)}[name]()
-kind = {"agg22": "evm", "rsa17": "poseidon", "sha19": "poseidon"}[name]
+SHAPES = {"agg22": lambda: pv.CircuitShape.agg(22, 3, 1), "rsa17": lambda: pv.CircuitShape.rsa(17),
+          "sha19": lambda: pv.CircuitShape.sha256(19, n_advice=32, n_fixed=12)}
+KINDS = {"agg22": "evm", "rsa17": "poseidon", "sha19": "poseidon"}
+shape, kind = SHAPES[name](), KINDS[name]
 print(f"  {'import torch':46s} {t_torch:8.3f} s\n  {'import ffi + dlopen libzkhip.so':46s} {t_lib:8.3f} s", flush=True)
 
 ctx = None
@@ -88,3 +90,16 @@ ctx.set_option("host_timing", 0)
 clock("second proof", lambda: prover.prove_native(wit, transcript=kind), count=False)
 clock("third proof", lambda: prover.prove_native(wit, transcript=kind), count=False)
 print(f"  first_proof_s as bench.py defines it (Prover + witness + first proof): {first_proof_s:.3f} s; process so far {time.perf_counter() - t_proc:.3f} s")
+
+if then:
+    print(f"  -- then {then} in the same process (release, empty_cache, new Prover): what bench.py's configs.{then}.first_proof_s is made of")
+    clock("release the first key, free its params", lambda: (prover.release(), be.params.free()), count=False)
+    del prover, wit
+    clock("torch.cuda.empty_cache()", lambda: torch.cuda.empty_cache(), count=False)
+    t1 = time.perf_counter()
+    be2 = pv.GpuBackend(ctx, ffi)
+    p2 = clock(f"Prover({then})", lambda: pv.Prover(be2, SHAPES[then](), satisfiable=True), count=False)
+    w2 = clock("witness", lambda: p2.witness(0), count=False)
+    clock("first proof", lambda: p2.prove_native(w2, transcript=KINDS[then]), count=False)
+    print(f"  first_proof_s of {then} after {name}: {time.perf_counter() - t1:.3f} s")
+    clock("second proof", lambda: p2.prove_native(w2, transcript=KINDS[then]), count=False)
