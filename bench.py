@@ -697,6 +697,12 @@ def worker(args):
         prover.release()          # the context's per-key caches (coset-layout key columns, sorted lookup table)
         backend.params.free()
         del prover, wit, trace, backend
+        # the prover object sits in reference cycles: collect it NOW — left to the cyclic collector, the hipFree / hipHostFree of its 5.5 GiB of
+        # columns and 512 MiB of pinned upload buffers ran somewhere inside the NEXT configuration's timed set-up (0.6 s of rsa17's setup_s, r03)
+        import gc
+
+        gc.collect()
+        torch.cuda.empty_cache()
         return res, shape
 
     def run_chain(steps, warmup):
