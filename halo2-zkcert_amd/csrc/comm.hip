@@ -286,7 +286,6 @@ int zkhip_comm_init(zkhip_ctx* ctx, const uint8_t id[128], int rank, int nranks)
     }
     ctx->comm.rank = rank;
     ctx->comm.nranks = nranks;
-    if (nranks > 1) zk::g_watch.ctx = ctx;   // host waits of this context now have a deadline (common.hpp)
     // The grouped send / recv exchange (comm_alltoall) is what the row-sharded proof rides on, and no multi-GPU box was available to the
     // build: prove it on THIS communicator before any proof depends on it.  Every rank sends peer r the word (rank << 16 | r) in a
     // 64-byte block and checks what arrives; the verdicts are all-gathered (the primitive the round-2 path has always used) so that
@@ -312,7 +311,7 @@ int zkhip_comm_init(zkhip_ctx* ctx, const uint8_t id[128], int rank, int nranks)
             return ZKHIP_EHIP;
         }
         if (ok) {
-            const hipError_t we = stream_wait(ctx->stream);
+            const hipError_t we = stream_wait(ctx, ctx->stream);
             if (we == hipErrorLaunchTimeOut) {   // a peer never arrived: the communicator is unusable and the device is busy waiting on it — no destroy (it would block), just fail
                 set_error("zkhip_comm_init: the all-to-all self-check did not complete");
                 return ZKHIP_EHIP;
@@ -327,7 +326,7 @@ int zkhip_comm_init(zkhip_ctx* ctx, const uint8_t id[128], int rank, int nranks)
         hipError_t we = hipSuccess;
         if (d_buf && hipMemcpy((char*)d_buf + (2 * N + (size_t)rank) * blk, &mine, 4, hipMemcpyHostToDevice) == hipSuccess &&
             comm_allgather(ctx, (char*)d_buf + (2 * N + (size_t)rank) * blk, (char*)d_buf + 2 * N * blk, blk) == ZKHIP_OK &&
-            (we = stream_wait(ctx->stream)) == hipSuccess && hipMemcpy(h.data(), (char*)d_buf + 2 * N * blk, N * blk, hipMemcpyDeviceToHost) == hipSuccess) {
+            (we = stream_wait(ctx, ctx->stream)) == hipSuccess && hipMemcpy(h.data(), (char*)d_buf + 2 * N * blk, N * blk, hipMemcpyDeviceToHost) == hipSuccess) {
             for (size_t r = 0; r < N; ++r) all_ok = all_ok && h[r * blk / 4] == 1u;
         } else {
             all_ok = 0;   // (if even the all-gather fails the proofs will report it; the exchange mode no longer matters)
@@ -354,7 +353,6 @@ int zkhip_comm_init_host(zkhip_ctx* ctx, int rank, int nranks, zkhip_host_allgat
     ctx->comm.host_user = user;
     ctx->comm.rank = rank;
     ctx->comm.nranks = nranks;
-    if (nranks > 1) zk::g_watch.ctx = ctx;
     return ZKHIP_OK;
 }
 
@@ -376,7 +374,6 @@ int zkhip_comm_destroy(zkhip_ctx* ctx) {
     if (cm.ev_out) (void)hipEventDestroy(cm.ev_out);
     if (cm.stage) (void)hipHostFree(cm.stage);
     cm = zkhip_comm();
-    if (zk::g_watch.ctx == ctx) zk::g_watch.ctx = nullptr;
     return ZKHIP_OK;
 }
 

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <deque>
 #include <map>
 #include <memory>
@@ -37,7 +38,7 @@ void set_error(const char* fmt, ...);
 
 // every device allocation of the library goes through here: the time spent inside hipMalloc is what a cold process pays before its
 // first proof (58 GB at k = 22), and zkhip_profile_counter("alloc_us" / "alloc_bytes" / "alloc_calls") reports it
-struct AllocStats { uint64_t ns = 0, bytes = 0, calls = 0; };
+struct AllocStats { std::atomic<uint64_t> ns{0}, bytes{0}, calls{0}; };   // process-wide, any thread
 extern AllocStats g_alloc;   // ctx.hip
 hipError_t dev_malloc(void** p, size_t bytes);
 
@@ -159,18 +160,16 @@ struct ProfScope {
 // Host waits.  hipStreamSynchronize sleeps on an interrupt and wakes tens of microseconds late, and the prover has a dozen Fiat-Shamir
 // round trips per proof on its critical path: the two waits below POLL (hipStreamQuery / hipEventQuery), reading the clock every 64 polls.
 // A context with a communicator waits for its peers whenever it waits for its own stream — a collective whose partner never arrives (a
-// rank that died, an RCCL that cannot connect two GPUs) would leave the host polling for ever — so while a communicator exists the poll
-// has a deadline (zkhip_options::comm_timeout_ms): on expiry the wait fails with hipErrorLaunchTimeOut and the error text names the rank,
+// rank that died, an RCCL that cannot connect two GPUs) would leave the host polling for ever — so while the context has a communicator
+// (nranks > 1) the poll has a deadline (zkhip_options::comm_timeout_ms): on expiry the wait fails with hipErrorLaunchTimeOut and the error text names the rank,
 // the number of collectives issued so far and the phase of the proof.  Without a communicator: poll for 10 s, then the blocking wait.
 namespace zk {
-struct CommWatch { const zkhip_ctx* ctx = nullptr; };
-extern CommWatch g_watch;                                  // ctx.hip; set by zkhip_comm_init*, cleared by zkhip_comm_destroy
-hipError_t wait_poll(hipStream_t st, hipEvent_t ev);       // ctx.hip: ev != null: wait for the event; else for the stream (null = the legacy default stream)
+hipError_t wait_poll(const zkhip_ctx* c, hipStream_t st, hipEvent_t ev);   // ctx.hip: ev != null: wait for the event; else for the stream (null = the legacy default stream)
 }
-static inline hipError_t stream_wait(hipStream_t st) { return zk::wait_poll(st, nullptr); }
+static inline hipError_t stream_wait(const zkhip_ctx* c, hipStream_t st) { return zk::wait_poll(c, st, nullptr); }
 // Waits for an event recorded right after a small read-back, not for the whole stream: the kernels issued after the event keep running
 // while the host acts on the value, so the next launches queue up behind them without a bubble.
-static inline hipError_t event_wait(hipEvent_t ev) { return ev ? zk::wait_poll(nullptr, ev) : hipErrorInvalidResourceHandle; }
+static inline hipError_t event_wait(const zkhip_ctx* c, hipEvent_t ev) { return ev ? zk::wait_poll(c, nullptr, ev) : hipErrorInvalidResourceHandle; }
 
 struct zkhip_domain;
 namespace zk {

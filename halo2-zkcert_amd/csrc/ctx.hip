@@ -25,16 +25,14 @@ AllocStats g_alloc;
 hipError_t dev_malloc(void** p, size_t bytes) {
     const auto t0 = std::chrono::steady_clock::now();
     const hipError_t e = hipMalloc(p, bytes);
-    g_alloc.ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
-    g_alloc.bytes += bytes;
-    g_alloc.calls += 1;
+    g_alloc.ns.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed);
+    g_alloc.bytes.fetch_add(bytes, std::memory_order_relaxed);
+    g_alloc.calls.fetch_add(1, std::memory_order_relaxed);
     return e;
 }
 
-CommWatch g_watch;
-hipError_t wait_poll(hipStream_t st, hipEvent_t ev) {
-    const zkhip_ctx* c = g_watch.ctx;
-    const double limit_ms = c && c->opt.comm_timeout_ms > 0 ? (double)c->opt.comm_timeout_ms : 0.0;
+hipError_t wait_poll(const zkhip_ctx* c, hipStream_t st, hipEvent_t ev) {
+    const double limit_ms = c && c->comm.nranks > 1 && c->opt.comm_timeout_ms > 0 ? (double)c->opt.comm_timeout_ms : 0.0;
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
         for (int i = 0; i < 64; ++i) {
@@ -295,7 +293,7 @@ int zkhip_key_release(zkhip_ctx* c, uint64_t key_id) {
 }
 int zkhip_synchronize(zkhip_ctx* c) {
     if (!c) { set_error("null ctx"); return ZKHIP_EINVAL; }
-    ZK_HIP(stream_wait(c->stream));      // (polling, with the communicator's deadline if there is one)
+    ZK_HIP(stream_wait(c, c->stream));      // (polling, with the communicator's deadline if there is one)
     return ZKHIP_OK;
 }
 int zkhip_malloc(zkhip_ctx* c, size_t bytes, void** dptr) {
@@ -312,13 +310,13 @@ int zkhip_free(zkhip_ctx* c, void* dptr) {
 int zkhip_memcpy_h2d(zkhip_ctx* c, void* dst, const void* src, size_t bytes) {
     if (!c) { set_error("null ctx"); return ZKHIP_EINVAL; }
     ZK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
-    ZK_HIP(stream_wait(c->stream));
+    ZK_HIP(stream_wait(c, c->stream));
     return ZKHIP_OK;
 }
 int zkhip_memcpy_d2h(zkhip_ctx* c, void* dst, const void* src, size_t bytes) {
     if (!c) { set_error("null ctx"); return ZKHIP_EINVAL; }
     ZK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
-    ZK_HIP(stream_wait(c->stream));
+    ZK_HIP(stream_wait(c, c->stream));
     return ZKHIP_OK;
 }
 int zkhip_timer_start(zkhip_ctx* c) {
@@ -388,7 +386,7 @@ int zkhip_commitments_read(zkhip_ctx* c, const void* d_xyz, size_t n, uint64_t* 
         if (n * 96 > zkhip_ctx::PINNED_BYTES) { big.resize(12 * n); jac = big.data(); }
         ZK_HIP(hipMemcpyAsync(jac, d_xyz, n * 96, hipMemcpyDeviceToHost, c->stream));
     }
-    ZK_HIP(stream_wait(c->stream));
+    ZK_HIP(stream_wait(c, c->stream));
     zkhip_g1_batch_to_affine(jac, n, out_xy);
     if (out_bytes) for (size_t i = 0; i < n; ++i) zkhip_g1_to_bytes(out_xy + 8 * i, out_bytes + 32 * i);
     return ZKHIP_OK;

@@ -1187,8 +1187,8 @@ static int msm_local(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const 
             maxcnt = std::max(maxcnt, (uint32_t)v);
         }
     } else {
-        if (h_max_big.empty()) ZK_HIP(event_wait(ctx->ev_read));   // only the read-back: the scatter and round 0 are still running
-        else ZK_HIP(stream_wait(st));                               // pageable destination: wait for everything
+        if (h_max_big.empty()) ZK_HIP(event_wait(ctx, ctx->ev_read));   // only the read-back: the scatter and round 0 are still running
+        else ZK_HIP(stream_wait(ctx, st));                               // pageable destination: wait for everything
         for (size_t j = 0; j < ncols; ++j) maxcnt = std::max(maxcnt, h_max[j]);
     }
     if (maxcnt == 0) {

@@ -281,7 +281,7 @@ extern "C" int zkhip_permute_expression_pair_device(zkhip_ctx* ctx, uint32_t k, 
                                              (uint32_t*)d_err, nullptr));
     uint32_t* h_err = (uint32_t*)ctx->h_pinned;
     ZK_HIP(hipMemcpyAsync(h_err, d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(stream_wait(ctx->stream));
+    ZK_HIP(stream_wait(ctx, ctx->stream));
     if (*h_err) { set_error("permute_expression_pair: an input value is not in the table (ConstraintSystemFailure)"); return ZKHIP_ECONSTRAINT; }
     return ZKHIP_OK;
 }

@@ -816,7 +816,7 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
         } else {
         ZK_TRY(zkhip_eval_polynomials_at_device(ctx, qp.data(), nq, n, q_points.data(), ev_out));
         if (ev_pinned) {
-            ZK_HIP(stream_wait(ctx->stream));
+            ZK_HIP(stream_wait(ctx, ctx->stream));
             memcpy(q_evals.data(), ev_out, nq * 32);
         } else {
             ZK_TRY(zkhip_memcpy_d2h(ctx, q_evals.data(), w_evals, nq * 32));
