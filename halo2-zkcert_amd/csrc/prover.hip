@@ -119,8 +119,25 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
                 set_error("zkhip_create_proof: instance column %u has %zu values (n = %zu) or a null pointer", j, (size_t)in->instance_len[j], n);
                 return ZKHIP_EINVAL;
             }
+    // advice phases / user challenges (zk_proving_key.advice_column_phase, challenge_phase): phase 0 only unless the key says otherwise
+    const uint32_t NC = pk->n_challenges;
+    auto phase_of = [&](uint32_t j) -> uint32_t { return pk->advice_column_phase ? pk->advice_column_phase[j] : 0u; };
+    uint32_t max_phase = 0;
+    for (uint32_t j = 0; j < A; ++j) max_phase = std::max(max_phase, phase_of(j));
+    if (NC && !pk->challenge_phase) { set_error("zkhip_create_proof: n_challenges = %u but challenge_phase is NULL", NC); return ZKHIP_EINVAL; }
+    for (uint32_t c = 0; c < NC; ++c) max_phase = std::max<uint32_t>(max_phase, pk->challenge_phase[c]);
+    {
+        uint32_t max_adv = 0;
+        for (uint32_t j = 0; j < A; ++j) max_adv = std::max(max_adv, phase_of(j));
+        if (max_adv > 0 && !in->advice_phase) {
+            set_error("zkhip_create_proof: the key has advice columns of phase %u but zk_proof_inputs.advice_phase is NULL", max_adv);
+            return ZKHIP_EINVAL;
+        }
+    }
+    const bool multi_phase = max_phase > 0 || NC > 0;
     for (uint32_t j = 0; j < A; ++j)
-        if (!in->advice[j]) { set_error("zkhip_create_proof: advice column %u is null", j); return ZKHIP_EINVAL; }
+        if (phase_of(j) == 0 && !in->advice[j]) { set_error("zkhip_create_proof: advice column %u is null", j); return ZKHIP_EINVAL; }
+    std::vector<uint64_t> user_ch(4 * (size_t)std::max<uint32_t>(NC, 1), 0);   // the user challenges, ABI form, index = challenge index
     if (bl && ((L && !bl->lookup_permuted) || (Zp && bf && !bl->perm_z) || (L && bf && !bl->lookup_z) || !bl->random_poly)) {
         // a caller that supplies its rng draws supplies ALL of them: silently falling back to the seeded generator for a missing member
         // would make those blinding rows predictable (zero knowledge lost without an error)
@@ -177,7 +194,7 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
     // Large host columns (>= 64 MiB in all: 512 MiB at k = 22 = 10 ms over PCIe) are uploaded on a copy stream of their own while the
     // main stream already commits the vanishing argument's random polynomial, which needs none of them (phase 1 below); small ones
     // ride on the proof's stream.  From pinned memory the copies run at link rate; from pageable memory the runtime stages them.
-    const bool split_upload = in->advice_on_host && A && (size_t)A * NB >= ((size_t)64 << 20);
+    const bool split_upload = !multi_phase && in->advice_on_host && A && (size_t)A * NB >= ((size_t)64 << 20);
     // many columns (the SHA-256 circuit's 32): uploaded and committed in up to 4 groups of >= 8 columns, so that the commitment of group
     // g runs while group g + 1 is still on the wire; few big columns (the aggregation circuit's 4): one group behind the random polynomial
     // few columns of >= 64 MiB each (k >= 21: a column's upload, 2.5 ms, is shorter than its commitment): groups of two columns, up to 4
@@ -194,6 +211,7 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
     }
     for (uint32_t g_ = 0; g_ < n_groups; ++g_) {
         for (uint32_t j = group_begin(g_); j < group_begin(g_ + 1); ++j) {
+            if (phase_of(j) != 0) continue;     // bound after its phase's witness exists (bind_phase below)
             if (in->advice_on_host) {
                 ZK_HIP(hipMemcpyAsync(w_adv_in + j * NB, in->advice[j], NB, hipMemcpyHostToDevice, split_upload ? ctx->copy_stream : st));
                 adv_cols[j] = w_adv_in + j * NB;
@@ -399,7 +417,61 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
     for (uint32_t j = 0; j < A + I; ++j) { coeff_ptrs[j] = w_coeff + j * NB; ext_ptrs[j] = w_ext + j * EB; }
     std::vector<uint64_t> rand_xy;
     std::vector<uint8_t> rand_by;
-    {
+    auto absorb_vk_and_instances = [&]() {
+        // vk.hash_into(transcript), then every instance value (KZG: hashed, not committed) — upstream's first transcript operations.
+        // Nothing has entered the transcript yet, so they are absorbed while the GPU works on the first advice commitments (a sponge
+        // transcript such as Poseidon spends ~10 us per absorbed pair: 32 instance values would otherwise sit on the critical path).
+        if (!tr->common_scalar) return;
+        if (pk->vk_transcript_repr) tr->common_scalar(tr->user, pk->vk_transcript_repr);
+        if (in->instance_values)
+            for (uint32_t j = 0; j < I; ++j)
+                for (uint32_t i = 0; i < in->instance_len[j]; ++i) tr->common_scalar(tr->user, in->instance_values[j] + 4 * i);
+    };
+    if (multi_phase) {
+        // Upstream's loop over the phases (plonk/prover.rs [UPSTREAM-RECALL]): the witness of phase p (the caller's, through advice_phase:
+        // it depends on the challenges of the earlier phases), the commitments of phase p's columns — in column order, the random
+        // polynomial riding with phase 0 — written to the transcript, then the user challenges whose phase is p.  One commitment batch
+        // and one Fiat-Shamir round trip per phase; the columns' transforms follow the last phase (they overlap the lookup commitments).
+        const void** adv_in = const_cast<const void**>(in->advice);
+        for (uint32_t ph = 0; ph <= max_phase; ++ph) {
+            if (ph > 0) {
+                if (in->advice_phase(in->advice_phase_user, ph, user_ch.data(), adv_in) != 0) {
+                    set_error("zkhip_create_proof: the caller's advice_phase callback failed for phase %u", ph);
+                    return ZKHIP_EINVAL;
+                }
+                for (uint32_t j = 0; j < A; ++j) {
+                    if (phase_of(j) != ph) continue;
+                    if (!adv_in[j]) { set_error("zkhip_create_proof: advice column %u (phase %u) is null after advice_phase", j, ph); return ZKHIP_EINVAL; }
+                    if (in->advice_on_host) {
+                        ZK_HIP(hipMemcpyAsync(w_adv_in + j * NB, adv_in[j], NB, hipMemcpyHostToDevice, st));
+                        adv_cols[j] = w_adv_in + j * NB;
+                    } else {
+                        adv_cols[j] = adv_in[j];
+                    }
+                }
+            }
+            std::vector<const void*> cols;
+            std::vector<const zkhip_srs*> bases;
+            std::vector<uint32_t> which;
+            for (uint32_t j = 0; j < A; ++j)
+                if (phase_of(j) == ph) { cols.push_back(adv_cols[j]); bases.push_back(pk->g_lagrange); which.push_back(j); }
+            if (ph == 0) { cols.push_back(w_rand); bases.push_back(pk->g); }
+            ZK_TRY(commit_launch(cols, bases));
+            if (ph == 0) absorb_vk_and_instances();
+            ZK_TRY(commit_read(cols.size(), ph == 0 ? 1 : 0, &rand_xy, &rand_by));
+            for (uint32_t c = 0; c < NC; ++c)
+                if (pk->challenge_phase[c] == ph) tr->squeeze_challenge(tr->user, user_ch.data() + 4 * (size_t)c);
+        }
+        ZK_TRY(ov.begin());
+        if (A + I) {
+            std::vector<const void*> lag(A + I);
+            for (uint32_t j = 0; j < A + I; ++j) lag[j] = j < A ? d_advice[j] : d_instance[j - A];
+            if (pieces_sharded) ZK_TRY(owner_intt(lag.data(), coeff_ptrs.data(), A + I, false));
+            else ZK_TRY(zk::lagrange_to_coeff_oop(ctx, pk->domain, lag.data(), coeff_ptrs.data(), A + I));
+            ZK_TRY(to_extended((const void* const*)coeff_ptrs.data(), ext_ptrs.data(), A + I));
+        }
+        ov.end();
+    } else {
         std::vector<const void*> cols(d_advice, d_advice + A);
         std::vector<const zkhip_srs*> bases(A, pk->g_lagrange);
         cols.push_back(w_rand);
@@ -429,15 +501,7 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
             ZK_TRY(to_extended((const void* const*)coeff_ptrs.data(), ext_ptrs.data(), A + I));
         }
         ov.end();
-        // vk.hash_into(transcript), then every instance value (KZG: hashed, not committed) — upstream's first transcript operations.
-        // Nothing has entered the transcript yet, so they are absorbed HERE, while the GPU works on the advice commitments (a sponge
-        // transcript such as Poseidon spends ~10 us per absorbed pair: 32 instance values would otherwise sit on the critical path).
-        if (tr->common_scalar) {
-            if (pk->vk_transcript_repr) tr->common_scalar(tr->user, pk->vk_transcript_repr);
-            if (in->instance_values)
-                for (uint32_t j = 0; j < I; ++j)
-                    for (uint32_t i = 0; i < in->instance_len[j]; ++i) tr->common_scalar(tr->user, in->instance_values[j] + 4 * i);
-        }
+        absorb_vk_and_instances();
         mark("vk + instances absorbed (GPU busy)");
         ZK_TRY(commit_read(cols.size(), 1, &rand_xy, &rand_by));
     }
@@ -465,6 +529,7 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
             a.k = k; a.extended_k = k; a.cs_degree = 3; a.blinding_factors = 0;
             memcpy(a.theta, theta, 32);
             a.n_fixed = F; a.n_advice = A; a.n_instance = I;
+            a.n_challenges = NC; a.challenges = user_ch.data();
             a.fixed_cosets = (const uint64_t* const*)pk->fixed_lagrange;
             a.advice_cosets = (const uint64_t* const*)d_advice;
             a.instance_cosets = (const uint64_t* const*)d_instance;
@@ -577,6 +642,7 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
         memcpy(a.extended_omega, ext_omega_abi, 32); memcpy(a.g_coset, g_coset_abi, 32); memcpy(a.delta, pk->delta, 32);
         memcpy(a.beta, beta, 32); memcpy(a.gamma, gamma, 32); memcpy(a.theta, theta, 32); memcpy(a.y, y, 32);
         a.n_fixed = F; a.n_advice = A; a.n_instance = I;
+        a.n_challenges = NC; a.challenges = user_ch.data();
         a.fixed_cosets = (const uint64_t* const*)(coset_mode ? kcos->fixed.data() : pk->fixed_cosets);
         a.advice_cosets = (const uint64_t* const*)ext_ptrs.data();
         a.instance_cosets = (const uint64_t* const*)(ext_ptrs.data() + A);

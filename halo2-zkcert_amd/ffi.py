@@ -579,7 +579,8 @@ class ZkProvingKey(C.Structure):
                 ("n_advice_queries", C.c_uint32), ("n_fixed_queries", C.c_uint32),
                 ("advice_query_column", C.c_void_p), ("advice_query_rotation", C.c_void_p),
                 ("fixed_query_column", C.c_void_p), ("fixed_query_rotation", C.c_void_p),
-                ("delta", C.c_uint64 * 4), ("vk_transcript_repr", C.c_void_p)]
+                ("delta", C.c_uint64 * 4), ("vk_transcript_repr", C.c_void_p),
+                ("advice_column_phase", C.c_void_p), ("n_challenges", C.c_uint32), ("challenge_phase", C.c_void_p)]
 
 
 class ZkProofOut(C.Structure):
@@ -592,9 +593,13 @@ class ZkBlinding(C.Structure):
                 ("on_host", C.c_int)]
 
 
+ADVICE_PHASE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_void_p))
+
+
 class ZkProofInputs(C.Structure):
     _fields_ = [("advice", C.c_void_p), ("advice_on_host", C.c_int), ("d_instance", C.c_void_p), ("instance_values", C.c_void_p),
-                ("instance_len", C.c_void_p), ("blinding", C.c_void_p), ("blinding_seed", C.c_uint64)]
+                ("instance_len", C.c_void_p), ("blinding", C.c_void_p), ("blinding_seed", C.c_uint64),
+                ("advice_phase", ADVICE_PHASE_FN), ("advice_phase_user", C.c_void_p)]
 
 
 def shplonk_open(ctx, params, polys, query_poly, query_points, query_evals, write_point, squeeze_challenge):

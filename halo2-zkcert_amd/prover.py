@@ -35,6 +35,7 @@ The schedule is written against a small backend interface so the same code drive
 import contextlib
 import hashlib
 import os
+import sys
 
 import time
 
@@ -51,11 +52,18 @@ class CircuitShape:
     """Column / gate shape of one of the reference's circuits."""
 
     def __init__(self, name, k, n_basic_advice, n_lookup_advice, n_instance, degree, blinding_factors, seed, gates=None,
-                 n_fixed=None, perm_columns=None):
+                 n_fixed=None, perm_columns=None, n_phase1=0):
         self.name, self.k, self.seed = name, k, seed
         self.layout = "halo2-lib"
         self.n_basic, self.n_lookup = n_basic_advice, n_lookup_advice
-        self.n_advice = n_basic_advice + n_lookup_advice
+        # Advice PHASES (axiom's halo2 create_proof [UPSTREAM-RECALL]: the advice columns are committed phase by phase and the user
+        # challenges of a phase are squeezed after its commitments; halo2-lib's RLC chips put their running sums in phase 1).  The
+        # reference's three circuits are phase 0 only; n_phase1 appends columns of phase 1, each a(x) = challenge_0 * advice_0(x)
+        # (gate: selector_0 * (a - advice_0 * challenge_0)), with ONE user challenge squeezed after the phase-0 commitments.
+        self.n_phase1 = n_phase1
+        self.n_advice = n_basic_advice + n_lookup_advice + n_phase1
+        self.advice_phase = [0] * (n_basic_advice + n_lookup_advice) + [1] * n_phase1
+        self.challenge_phase = [0] if n_phase1 else []
         self.n_instance = n_instance
         # fixed: one selector per basic advice column, one constants column, one lookup table column
         self.n_fixed = n_basic_advice + 1 + (1 if n_lookup_advice else 0)
@@ -68,6 +76,9 @@ class CircuitShape:
         self.lookups = [([A(n_basic_advice + i, 0)], [("fixed", self.n_fixed - 1, 0)]) for i in range(n_lookup_advice)]
         self.perm_columns = ([("advice", c) for c in range(self.n_advice)] + [("fixed", n_basic_advice)]
                              + [("instance", i) for i in range(n_instance)])
+        for j in range(n_phase1):
+            c1 = n_basic_advice + n_lookup_advice + j
+            self.gates.append(("prod", ("fixed", 0, 0), ("sum", A(c1, 0), ("neg", ("prod", A(0, 0), ("challenge", 0))))))
         if gates is not None:
             self.gates = gates
         if n_fixed is not None:
@@ -124,6 +135,19 @@ class CircuitShape:
     @classmethod
     def small(cls, k=8):
         return cls(f"small_k{k}", k, 2, 1, 1, 4, 6, 0x5EED00 + k)
+
+    @classmethod
+    def two_phase(cls, k=8, n_phase1=1):
+        """the small circuit plus advice columns of the SECOND phase and one user challenge (see __init__)"""
+        return cls(f"two_phase_k{k}_p{n_phase1}", k, 2, 1, 1, 4, 6, 0x2F4A5E00 + k, n_phase1=n_phase1)
+
+    @property
+    def phases(self):
+        return sorted(set(self.advice_phase) | set(self.challenge_phase)) or [0]
+
+    def advice_commit_order(self):
+        """advice column indices in the order their commitments enter the transcript: by phase, by column inside a phase"""
+        return [i for ph in self.phases for i in range(self.n_advice) if self.advice_phase[i] == ph]
 
     def queries(self):
         """Distinct (kind, column, rotation) queries of the gates and lookups (what create_proof evaluates at x)."""
@@ -700,7 +724,7 @@ class Prover:
         sh, b, n = self.shape, self.b, self.n
         if sh.layout == "sha":
             return self._build_satisfiable_sha(seed)
-        assert sh.n_basic and sh.gates and len(sh.gates) == sh.n_basic, "satisfiable instances need the halo2-lib gate shape"
+        assert sh.n_basic and sh.gates and len(sh.gates) == sh.n_basic + sh.n_phase1, "satisfiable instances need the halo2-lib gate shape"
         u = n - (sh.blinding_factors + 1)
         one = fr_from_int_host(1)
         gate_rows = np.arange(0, u - 3, 4)
@@ -864,6 +888,8 @@ class Prover:
         for j in range(sh.n_lookup):
             idx = (splitmix64(np.arange(n, dtype=np.uint64) + np.uint64(((base + 20 + j) << 32) & 0xFFFFFFFFFFFFFFFF)) % np.uint64(n // 2)).astype(np.int64)
             advice.append(self.b.gather(self.fixed_lagrange[sh.n_fixed - 1], idx))
+        for _ in range(sh.n_phase1):      # columns of a later phase exist only once that phase's challenges do (advice_for_phase): zeros until then
+            advice.append(self.b.lincomb([advice[0]], [0], None))
         # instance columns: n_instance_values public inputs, zero-padded (upstream builds the instance polynomial the same way)
         nv = self.n_instance_values
         inst_vals = [self.b.to_host(self.b.synth(nv, base + 50 + i)) for i in range(sh.n_instance)]
@@ -885,6 +911,15 @@ class Prover:
             for c, g in self._fill_graphs:       # gate outputs
                 advice[c] = b.compress(g, self.fixed_lagrange + [self._out_mask], advice, instance, 0, sh.k)
         return dict(advice=advice, instance=instance, instance_values=inst_vals, base=base)
+
+    def advice_for_phase(self, wit, phase, user_challenges):
+        """Witness synthesis of a later phase (the circuit's job upstream: `synthesize` runs again with the challenges of the earlier
+        phases): fills wit["advice"][c] for the columns of `phase`.  user_challenges: canonical ints, index = challenge index."""
+        sh = self.shape
+        for c in range(sh.n_advice):
+            if sh.advice_phase[c] == phase and phase > 0:
+                wit["advice"][c] = self.b.lincomb([wit["advice"][0]], [user_challenges[0]], None)
+        wit.pop("advice_host", None)
 
     def _query_list(self):
         """[(key, rotation)] in upstream's query order (what create_proof evaluates at x and SHPLONK opens)"""
@@ -1007,6 +1042,10 @@ class Prover:
         pk.fixed_query_column, pk.fixed_query_rotation = arr((c for c, _ in fq), np.uint32), arr((r for _, r in fq), np.int32)
         pk.delta = (C.c_uint64 * 4)(*[int(v) for v in b.fr(DELTA)])
         pk.vk_transcript_repr = arr(self.vk_repr, np.uint64)
+        if any(sh.advice_phase) or sh.challenge_phase:
+            pk.advice_column_phase = arr(sh.advice_phase, np.uint8)
+            pk.n_challenges = len(sh.challenge_phase)
+            pk.challenge_phase = arr(sh.challenge_phase, np.uint8)
         self._npk, self._npk_keep = pk, keep
         return pk
 
@@ -1033,8 +1072,15 @@ class Prover:
         kind = transcript or ("evm" if evm else "blake2b")
         point_tags = ["advice"] * A + ["lookup_permuted"] * (2 * L) + ["products"] * (Zp + L) + ["random_poly"] + ["quotient"] * qd \
             + ["shplonk_h1", "shplonk_h2"]
-        squeeze_tags = ["theta", "beta", "gamma", "y", "x", "shplonk_y", "shplonk_v", "shplonk_u"]
-        trace = {"commitments": [], "challenges": {}, "points": {}, "transcript": kind}
+        user_order = [c_ for ph in sh.phases for c_, p_ in enumerate(sh.challenge_phase) if p_ == ph]      # squeeze order of the user challenges
+        squeeze_tags = [("user", c_) for c_ in user_order] + ["theta", "beta", "gamma", "y", "x", "shplonk_y", "shplonk_v", "shplonk_u"]
+        trace = {"commitments": [], "challenges": {"user": [None] * len(user_order)}, "points": {}, "transcript": kind}
+
+        def record_challenge(tag, value):
+            if isinstance(tag, tuple):
+                trace["challenges"]["user"][tag[1]] = value
+            else:
+                trace["challenges"][tag] = value
         nt = None
         keep = []
         if python_transcript:
@@ -1051,7 +1097,7 @@ class Prover:
                 tag = squeeze_tags[state["s"]]
                 state["s"] += 1
                 c = ts.squeeze()
-                trace["challenges"][tag] = c
+                record_challenge(tag, c)
                 return fr_from_int_host(c)
 
             t = ffi.make_transcript(write_point, squeeze, ts.write_scalar, ts.common_scalar)
@@ -1079,6 +1125,31 @@ class Prover:
             keep.append(ins)
             inp.d_instance = C.cast(ins, C.c_void_p)
         inp.advice = C.cast(adv, C.c_void_p)
+        if any(sh.advice_phase):
+            # later phases: the library calls back once the challenges of the earlier phases exist; the witness of that phase is synthesised
+            # here (advice_for_phase) and its columns' pointers stored into the advice array the library reads
+            def next_phase(_user, phase, ch_ptr, adv_ptr):
+                try:
+                    nch = len(sh.challenge_phase)
+                    user = [from_mont_host(np.array([ch_ptr[4 * c_ + q_] for q_ in range(4)], dtype=np.uint64)) for c_ in range(nch)]
+                    self.advice_for_phase(wit, phase, user)
+                    for c_ in range(A):
+                        if sh.advice_phase[c_] != phase:
+                            continue
+                        col = wit["advice"][c_]
+                        if host_inputs:
+                            col = col.cpu().pin_memory()
+                            keep.append(col)
+                        adv_ptr[c_] = col.data_ptr()
+                    ctx.use_torch_stream()
+                    self.b.torch.cuda.current_stream(ctx.device).synchronize()      # the columns are complete before the library reads them
+                    return 0
+                except Exception as e:   # noqa: BLE001 — an exception must not cross the C boundary
+                    print(f"advice_for_phase({phase}) failed: {e}", file=sys.stderr)
+                    return 1
+            cb = ffi.ADVICE_PHASE_FN(next_phase)
+            keep.append(cb)
+            inp.advice_phase = cb
         ivals = [np.ascontiguousarray(v, dtype=np.uint64) for v in wit["instance_values"]]
         ivp = (C.c_void_p * max(1, len(ivals)))(*[v.ctypes.data for v in ivals])
         ivl = np.array([len(v) for v in ivals] or [0], dtype=np.uint32)
@@ -1130,7 +1201,7 @@ class Prover:
                 trace["points"].setdefault(tag, []).append(pts[i_])
             assert off == len(proof)
             for tag, limbs in zip(squeeze_tags, chs):
-                trace["challenges"][tag] = from_mont_host(limbs)
+                record_challenge(tag, from_mont_host(limbs))
         else:
             assert state["p"] == len(point_tags) and state["s"] == len(squeeze_tags)
         assert out.n_evals == len(qlist)
@@ -1173,15 +1244,28 @@ class Prover:
         #    any challenge, so its commitment (step 4, monomial basis) rides in the same MSM pass; it enters the
         #    transcript at its usual place.  The coset NTTs of finished columns (step 5) are issued on a second
         #    stream as soon as their inputs exist, so they run beside the latency-bound MSM tails.
+        #    Phases (CircuitShape.advice_phase): the columns of phase p are committed and absorbed, then the user challenges of phase p are
+        #    squeezed, then the witness of phase p + 1 is synthesised with them (advice_for_phase) — upstream's loop over `phases`.
+        rand_poly = [b.synth(n, base + 380)]
+        user_ch, rand_commit = [], None
+        for ph in sh.phases:
+            if ph > 0:
+                self.advice_for_phase(wit, ph, user_ch)
+            cols_ph = [i for i in range(sh.n_advice) if sh.advice_phase[i] == ph]
+            batch = [wit["advice"][i] for i in cols_ph]
+            if rand_commit is None:
+                c1 = b.commit(batch + rand_poly, lagrange=[True] * len(batch) + [False])
+                rand_commit = c1[len(batch):]
+            else:
+                c1 = b.commit(batch, lagrange=True)
+            absorb("advice", c1[:len(batch)])
+            user_ch += [ts.squeeze() for p_ in sh.challenge_phase if p_ == ph]
         advice = b.clone(wit["advice"])
         instance = b.clone(wit["instance"])
-        rand_poly = [b.synth(n, base + 380)]
         with b.overlap():
             adv_coeff = b.clone(wit["advice"] + wit["instance"])
             b.lagrange_to_coeff(adv_coeff)
             ext_adv = b.coeff_to_extended(adv_coeff)
-        c1 = b.commit(advice + rand_poly, lagrange=[True] * len(advice) + [False])
-        t1 = absorb("advice", c1[:len(advice)])
         theta = ts.squeeze()
         # 2. lookups: theta-compress the input / table expressions, permute_expression_pair (sort; blinding rows are
         #    seeded stand-ins for the rng); commit the permuted pair in coefficient form
@@ -1210,7 +1294,7 @@ class Prover:
             ext_prod = b.coeff_to_extended(look_z + perm_z)
         t3 = absorb("products", b.commit(perm_z + look_z, lagrange=False))
         # 4. vanishing argument's random polynomial (committed in pass 1)
-        t4 = absorb("random_poly", c1[len(advice):])
+        t4 = absorb("random_poly", rand_commit)
         y = ts.squeeze()
         # 5. quotient: everything is on the extended coset by now; sweep, divide, back to coefficients
         b.join()
@@ -1219,7 +1303,7 @@ class Prover:
         lz_c, pz_c = ext_prod[:L], ext_prod[L:]
         kw = dict(k=sh.k, extended_k=dom.extended_k, cs_degree=sh.degree, blinding_factors=sh.blinding_factors,
                   extended_omega=dom.extended_omega, g_coset=dom.g_coset, delta=b.fr(DELTA), beta=b.fr(beta), gamma=b.fr(gamma),
-                  theta=b.fr(theta), y=b.fr(y), fixed=self.fixed_cosets, advice=adv_c, instance=ins_c, challenges=[],
+                  theta=b.fr(theta), y=b.fr(y), fixed=self.fixed_cosets, advice=adv_c, instance=ins_c, challenges=[b.fr(c_) for c_ in user_ch],
                   l0=self.l0, l_last=self.l_last, l_active=self.l_active, gates_graph=self.gates_graph,
                   perm_columns=sh.perm_columns, sigma=self.sigma_cosets, perm_z=pz_c, lookup_graphs=self.lookup_graphs,
                   lookup_z=lz_c, lookup_a=pin_c, lookup_s=ptab_c, to_mont=b.fr_many)
@@ -1265,7 +1349,7 @@ class Prover:
             queries = [(key, pt, evals[(key, rot)]) for (key, rot), pt in zip(qlist, points)]
             opening = ShplonkProver(b).create_proof(polys, queries, lambda tag: ts.squeeze(), absorb)
         trace["challenges"] = dict(theta=theta, beta=beta, gamma=gamma, y=y, x=x, shplonk_y=opening["y"], shplonk_v=opening["v"],
-                                   shplonk_u=opening["u"])
+                                   shplonk_u=opening["u"], user=list(user_ch))
         trace["opening"] = opening
         trace["h_pieces"] = pieces
         trace["n_commitments"] = len(trace["commitments"])

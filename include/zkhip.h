@@ -378,6 +378,12 @@ typedef struct zk_proving_key {
     const uint32_t* fixed_query_column; const int32_t* fixed_query_rotation;        /* HOST */
     uint64_t delta[4];                                                              /* Fr::DELTA, ABI form */
     const uint64_t* vk_transcript_repr;       /* HOST, 4 u64 (ABI) or NULL: pk.vk.transcript_repr, absorbed first (vk.hash_into) */
+    /* Advice phases and user challenges (cs.advice_column_phase / cs.challenge_phase [UPSTREAM-RECALL: axiom's create_proof loops over
+     * the phases: commit the advice columns of phase p, write them, squeeze the challenges whose phase is p]).  NULL / 0: every column
+     * in phase 0, no user challenge — the reference's three circuits. */
+    const uint8_t* advice_column_phase;       /* HOST, n_advice, or NULL */
+    uint32_t n_challenges;
+    const uint8_t* challenge_phase;           /* HOST, n_challenges (non-decreasing use is not required: challenge j is squeezed after phase challenge_phase[j]) */
 } zk_proving_key;
 typedef struct zk_proof_out {
     const void* d_h;          /* the quotient in coefficient form (quotient_poly_degree * n elements, library-owned, valid until the next proof) */
@@ -400,8 +406,14 @@ typedef struct zk_blinding {
     const void* random_poly;       /* the vanishing argument's random polynomial: n coefficients */
     int on_host;
 } zk_blinding;
+/* Witness synthesis of a later advice phase, in the caller's hands (upstream runs the circuit's `synthesize` again with the challenges
+ * of the earlier phases): called once per phase p > 0, after the challenges of phases < p are known.  challenges: HOST, n_challenges x 4
+ * u64 (ABI; entries of later phases are zero).  advice: the SAME array zk_proof_inputs.advice points to — the callee stores the pointers
+ * of phase p's columns into it (DEVICE or HOST as advice_on_host says; the buffers must stay valid until zkhip_create_proof_ex returns).
+ * Return 0, or non-zero to abort the proof (ZKHIP_EINVAL is returned). */
+typedef int (*zk_advice_phase_fn)(void* user, uint32_t phase, const uint64_t* challenges, const void** advice);
 typedef struct zk_proof_inputs {
-    const void* const* advice;                /* n_advice columns of n elements, Lagrange form */
+    const void* const* advice;                /* n_advice columns of n elements, Lagrange form (columns of later phases: see advice_phase) */
     int advice_on_host;                       /* 0: DEVICE columns (resident pipeline); 1: HOST columns (the Vec<Fr> a Rust caller holds;
                                                  uploaded by the library, fastest from pinned memory) */
     const void* const* d_instance;            /* n_instance DEVICE columns (zero-padded to n), or NULL: built from instance_values */
@@ -411,16 +423,18 @@ typedef struct zk_proof_inputs {
     const zk_blinding* blinding;              /* NULL: the library's counter generator seeded with blinding_seed
                                                  (zkhip_synth_fill_device seeds +300.., +320.., +340, +360, +380) */
     uint64_t blinding_seed;
+    zk_advice_phase_fn advice_phase;          /* required when the key has a column of phase > 0, else ignored (may be NULL) */
+    void* advice_phase_user;
 } zk_proof_inputs;
 /* A zk_blinding that is given must be complete: every member whose row count is non-zero for this key (lookup_permuted / lookup_z with
  * lookups, perm_z with permutation sets, random_poly always) must be non-NULL, else ZKHIP_EINVAL — never a silent fall-back to the
  * seeded generator.  All argument checks happen before the first asynchronous copy from the caller's memory; on an error after that
  * point the call waits for its copies before it returns, so the caller may drop its buffers.
  * PHASES [UPSTREAM-RECALL: axiom's create_proof commits the advice columns phase by phase and squeezes the user challenges of a phase
- * after its commitments]: this call implements ONE advice phase (FirstPhase) and no user challenges — zk_evalh_args.challenges is not
- * fed by it.  The three circuits of the reference (RSA, zkevm SHA-256, the aggregation circuit; /root/reference/src/bin/cli.rs:296-527)
- * use phase 0 only, so nothing on the path needs more; a multi-phase circuit (halo2-lib's RLC chips) must be proved through the
- * step-wise entry points, committing each phase's columns and squeezing its challenges in the caller. */
+ * after its commitments]: implemented since round 4 — zk_proving_key.advice_column_phase / challenge_phase say which column and which
+ * challenge belongs to which phase, zk_proof_inputs.advice_phase supplies the witness of the later phases, the challenges reach the gate
+ * and lookup expressions as ZK_VS_CHALLENGE.  The three circuits of the reference (RSA, zkevm SHA-256, the aggregation circuit;
+ * /root/reference/src/bin/cli.rs:296-527) use phase 0 only: for them nothing changes (all three fields NULL / 0). */
 int  zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, const zk_proof_inputs* in, const zk_transcript* transcript,
                            zk_proof_out* out);
 /* 1 if zkhip_create_proof_ex will evaluate this key's quotient on quotient_poly_degree cosets of the size-n domain — the key's

@@ -283,6 +283,12 @@ fn device_key(ctx: *mut sys::zkhip_ctx, params: &ParamsKZG<Bn256>, pk: &ProvingK
         fixed_query_rotation: fix_q.1.as_ptr(),
         delta: delta_w,
         vk_transcript_repr: std::ptr::null(), // absorbed by upstream's code before the hand-over
+        // phases: this shim hands over single-phase circuits only (the reference's three: /root/reference/src/helpers.rs:97-172,
+        // src/sha256_bit_circuit.rs:51-56); a multi-phase circuit fills these from cs.advice_column_phase() / cs.challenge_phase() and
+        // passes a zk_proof_inputs.advice_phase callback that re-runs its synthesize with the challenges
+        advice_column_phase: std::ptr::null(),
+        n_challenges: 0,
+        challenge_phase: std::ptr::null(),
     };
     let key = Arc::new(Mutex::new(DeviceKey {
         ctx,
@@ -403,6 +409,8 @@ pub fn create_proof_after_synthesis<E: EncodedChallenge<G1Affine>, R: RngCore, T
         instance_len: inst_len.as_ptr(),
         blinding: &blinding,
         blinding_seed: 0,
+        advice_phase: None,
+        advice_phase_user: std::ptr::null_mut(),
     };
     let callbacks = sys::zk_transcript {
         user: transcript as *mut T as *mut c_void,

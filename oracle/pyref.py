@@ -804,6 +804,8 @@ def eval_expr_at(e, get):
         return e[1] % R
     if k in ("fixed", "advice", "instance"):
         return get(k, e[1], e[2])
+    if k == "challenge":
+        return get("challenge", e[1], 0)
     if k == "neg":
         return (-eval_expr_at(e[1], get)) % R
     if k == "sum":
@@ -835,6 +837,8 @@ def plonk_expected_h(vk, instance_cols, evals, ch):
     inst_cache = {}
 
     def get(kind, col, rot):
+        if kind == "challenge":     # a user challenge (Expression::Challenge): squeezed after the commitments of its phase
+            return ch["user"][col]
         if kind == "instance":      # QUERY_INSTANCE = false for KZG: the verifier evaluates the instance polynomial itself
             if (col, rot) not in inst_cache:
                 pt = x * pow(w, rot % n, R) % R
@@ -1185,8 +1189,18 @@ def read_plonk_proof(vk, kind, proof, vk_repr, instance_values, advice_queries, 
     L = len(vk["lookups"])
     bf = vk["blinding_factors"]
     coms, evals, ch = {}, {}, {}
-    for i in range(n_adv):
-        coms[("advice", i)] = t.read_point()
+    # advice commitments phase by phase, the user challenges of a phase squeezed after its commitments (vk["advice_phase"] per column,
+    # vk["challenge_phase"] per challenge; absent = everything in phase 0, no user challenge)
+    adv_phase = list(vk.get("advice_phase") or [0] * n_adv) + [0] * n_adv
+    chal_phase = list(vk.get("challenge_phase") or [])
+    ch["user"] = [None] * len(chal_phase)
+    for ph in sorted(set(adv_phase[:n_adv]) | set(chal_phase)):
+        for i in range(n_adv):
+            if adv_phase[i] == ph:
+                coms[("advice", i)] = t.read_point()
+        for j, pj in enumerate(chal_phase):
+            if pj == ph:
+                ch["user"][j] = t.squeeze()
     ch["theta"] = t.squeeze()
     for i in range(L):
         coms[("lookup_a", i)] = t.read_point()

@@ -52,6 +52,8 @@ for spec in json.loads(os.environ["ZK_SHAPES"]):
         sh = pv.CircuitShape.small(spec[1])
     elif spec[0] == "sha":
         sh = pv.CircuitShape.sha256(spec[1], n_advice=12, n_fixed=5)
+    elif spec[0] == "phase":                                 # an advice column of the second phase + a user challenge
+        sh = pv.CircuitShape.two_phase(spec[1])
     elif spec[0] == "two":                                   # two lookups (agg-like with two lookup-advice columns): owner mapping of a', s', z per lookup
         sh = pv.CircuitShape(f"two_lookups_k{spec[1]}", spec[1], 2, 2, 1, 4, 6, 0x2100C0 + spec[1])
     elif spec[0] == "shafull":                               # bench.py's SHA-256-shaped configuration (BASELINE configs[2])

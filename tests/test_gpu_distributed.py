@@ -25,7 +25,8 @@ def _free_port():
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # small 8 / 10: the coset-quotient path with row-sharded cosets (all-to-all of row windows) whenever 64 N divides n — N = 2 at k = 8, N = 8 at
 # k = 10; N = 3 / 5 and the SHA shape (extended domain) take the all-gather path
-SHAPES = [["small", 8, "poseidon"], ["sha", 9, "poseidon"], ["small", 7, "evm"], ["small", 10, "evm"], ["two", 9, "poseidon"]]
+SHAPES = [["small", 8, "poseidon"], ["sha", 9, "poseidon"], ["small", 7, "evm"], ["small", 10, "evm"], ["two", 9, "poseidon"],
+          ["phase", 10, "poseidon"]]      # "phase": an advice column of the second phase and a user challenge (CircuitShape.two_phase)
 
 
 _REF = {}
@@ -38,6 +39,7 @@ def _single_gpu_proofs(zk):
     out = _REF
     for spec in SHAPES:
         sh = (pv.CircuitShape.small(spec[1]) if spec[0] == "small" else pv.CircuitShape.sha256(spec[1], n_advice=12, n_fixed=5) if spec[0] == "sha" else
+              pv.CircuitShape.two_phase(spec[1]) if spec[0] == "phase" else
               pv.CircuitShape(f"two_lookups_k{spec[1]}", spec[1], 2, 2, 1, 4, 6, 0x2100C0 + spec[1]))
         p = pv.Prover(pv.GpuBackend(ctx, ffi), sh, satisfiable=True)
         out[f"{spec[0]}{spec[1]}{spec[2]}"] = p.prove_native(p.witness(1), transcript=spec[2])["proof"].hex()

@@ -632,3 +632,41 @@ def test_proof_on_a_params_file_of_unknown_trapdoor_passes_the_pairing_check(zk,
         assert not verify_proof(gp, wit, bytes(bad), kind, srs_g2=g2)
     gp.release()
     backend.params.free()
+
+
+@pytest.mark.parametrize("k", [6, 9, 12])
+def test_two_phase_circuit_native_schedule_and_oracle_agree(zk, oracle, k):
+    """Advice phases and a user challenge (zk_proving_key.advice_column_phase / challenge_phase, zk_proof_inputs.advice_phase; upstream's
+    loop over `phases` in plonk/prover.rs [UPSTREAM-RECALL]): CircuitShape.two_phase — a column of phase 1 equal to challenge_0 * advice_0
+    under its gate.  zkhip_create_proof_ex (the witness of phase 1 synthesised in the callback, device and host columns), the Python
+    schedule on the GPU and the schedule on the oracle backend give the same proof BYTES under Poseidon and Keccak, and the byte-driven
+    verifier — which reads the commitments phase by phase and squeezes the challenge in between — accepts them."""
+    from verify_util import verify_proof
+
+    ffi, ctx = zk
+    sh = pv.CircuitShape.two_phase(k)
+    gp = pv.Prover(pv.GpuBackend(ctx, ffi), sh, satisfiable=True)
+    cp = pv.Prover(OracleBackend(8), sh, satisfiable=True)
+    for kind in ("poseidon", "evm"):
+        tc = cp.prove(cp.witness(0), transcript=kind)
+        tg = gp.prove(gp.witness(0), transcript=kind)
+        wn = gp.witness(0)
+        tn = gp.prove_native(wn, transcript=kind)
+        th = gp.prove_native(gp.witness(0), transcript=kind, host_inputs=True)
+        assert tc["challenges"]["user"] == tg["challenges"]["user"] == tn["challenges"]["user"] and len(tn["challenges"]["user"]) == 1
+        assert tn["proof"] == tc["proof"] and tg["proof"] == tc["proof"] and th["proof"] == tc["proof"]
+        assert verify_proof(gp, wn, tn["proof"], kind)
+    # the key says phase 1 but no callback is given: an argument error before anything enters the transcript
+    import ctypes as C
+
+    pk = gp._native_key()
+    inp = ffi.ZkProofInputs()
+    w = gp.witness(0)
+    adv = (C.c_void_p * sh.n_advice)(*[c_.data_ptr() for c_ in w["advice"]])
+    ins = (C.c_void_p * 1)(*[c_.data_ptr() for c_ in w["instance"]])
+    inp.advice, inp.d_instance = C.cast(adv, C.c_void_p), C.cast(ins, C.c_void_p)
+    nt = ffi.LibTranscript("poseidon")
+    rc = ffi.lib().zkhip_create_proof_ex(ctx.h, C.byref(pk), C.byref(inp), nt.callbacks, None)
+    assert rc == -1 and b"advice_phase is NULL" in ffi.lib().zkhip_last_error()
+    gp.release()
+    gp.b.params.free()

@@ -311,3 +311,30 @@ def test_k15_plumbing_on_cpu(oracle):
     tr = p.prove(wit, transcript="poseidon")
     assert tr["n_commitments"] == sh.counts(p.dom.extended_k)["msm"]
     assert verify_proof(p, wit, tr["proof"], "poseidon")
+
+
+@pytest.mark.parametrize("kind", ["poseidon", "evm"])
+def test_two_phase_circuit_with_a_user_challenge(oracle, kind):
+    """Advice PHASES (axiom's create_proof [UPSTREAM-RECALL]: the columns of phase p are committed and written, then the challenges of phase p
+    are squeezed, then the witness of phase p + 1 is synthesised with them): CircuitShape.two_phase adds a column of phase 1,
+    a(x) = challenge_0 * advice_0(x), under the gate selector_0 * (a - advice_0 * challenge_0).  The schedule on the oracle backend yields
+    proof bytes the byte-driven verifier accepts (it reads the advice commitments phase by phase and squeezes the user challenge in
+    between); a phase-1 witness synthesised with ANOTHER value of the challenge is rejected."""
+    from verify_util import verify_proof, verify_trace
+
+    sh = pv.CircuitShape.two_phase(5)
+    assert sh.advice_phase == [0, 0, 0, 1] and sh.challenge_phase == [0] and sh.advice_commit_order() == [0, 1, 2, 3]
+    p = pv.Prover(OracleBackend(2), sh, satisfiable=True)
+    wit = p.witness(0)
+    tr = p.prove(wit, transcript=kind)
+    assert len(tr["challenges"]["user"]) == 1 and 0 < tr["challenges"]["user"][0] < pv.R
+    assert verify_trace(p, wit, tr) and verify_proof(p, wit, tr["proof"], kind)
+    # the same circuit read as single-phase (the challenge squeezed nowhere) cannot verify: the transcripts diverge at the first squeeze
+    bad = bytearray(tr["proof"])
+    bad[3 * (64 if kind == "evm" else 32) + 7] ^= 1          # inside the phase-1 column's commitment
+    assert not verify_proof(p, wit, bytes(bad), kind)
+    honest = p.advice_for_phase
+    p.advice_for_phase = lambda w, ph, ch: honest(w, ph, [(ch[0] + 1) % pv.R])
+    wit2 = p.witness(0)
+    tr2 = p.prove(wit2, transcript=kind)
+    assert not verify_proof(p, wit2, tr2["proof"], kind)

@@ -11,7 +11,7 @@ def _pts(arrs):
 
 def _vk(sh):
     return dict(k=sh.k, degree=sh.degree, blinding_factors=sh.blinding_factors, gates=sh.gates, lookups=sh.lookups,
-                perm_columns=sh.perm_columns, n_advice=sh.n_advice)
+                perm_columns=sh.perm_columns, n_advice=sh.n_advice, advice_phase=list(sh.advice_phase), challenge_phase=list(sh.challenge_phase))
 
 
 def _queries(sh):
@@ -70,7 +70,7 @@ def verify_trace(prover, wit, trace, srs_trapdoor=0x1D5C0FFEE, tamper=None):
     vk = _vk(sh)
     pts = trace["points"]
     coms = {}
-    for i, p_ in enumerate(_pts(pts["advice"])):
+    for i, p_ in zip(sh.advice_commit_order(), _pts(pts["advice"])):      # transcript order: by phase, by column inside a phase
         coms[("advice", i)] = p_
     L = len(sh.lookups)
     lp = _pts(pts.get("lookup_permuted", []))
@@ -108,8 +108,13 @@ def verify_trace(prover, wit, trace, srs_trapdoor=0x1D5C0FFEE, tamper=None):
     for col in wit["instance_values"]:
         for v in col:
             ts.common_scalar(v)
-    for a in pts["advice"]:
-        ts.write_point(a)
+    order, user, at = sh.advice_commit_order(), [], 0
+    for ph in sh.phases:
+        for _ in [i for i in order if sh.advice_phase[i] == ph]:
+            ts.write_point(pts["advice"][at])
+            at += 1
+        user += [ts.squeeze() for p_ in sh.challenge_phase if p_ == ph]
+    assert user == list(ch.get("user", [])), (user, ch.get("user"))
     assert ts.squeeze() == ch["theta"]
     for a in pts.get("lookup_permuted", []):
         ts.write_point(a)
