@@ -61,16 +61,25 @@ def host_threads():
     return n
 
 
-KERNEL_SOURCES = ("bn254.hpp", "common.hpp", "msm.hip", "ntt.hip", "sweep.hip", "cosets.hip")
-
-
 def build_hash():
-    """identifies the source of the three measured kernels (field arithmetic, MSM, NTT, sweep): the PMC traffic figures under profiles/
-    are only quoted for the kernels they were measured on (host-only files — schedule, transcripts, communicator — do not enter)"""
-    h = hashlib.sha256()
-    for f in KERNEL_SOURCES:
-        h.update(open(os.path.join(ROOT, "halo2-zkcert_amd", "csrc", f), "rb").read())
-    return h.hexdigest()[:16]
+    """Identifies the DEVICE code of the library: sha256 of libzkhip.so's .hip_fatbin section (every kernel of every translation unit, as
+    compiled).  The PMC traffic figures under profiles/ are quoted only for the build they were measured on (`# build=<hash>` in their first
+    line).  Host-only edits — schedule, transcripts, communicator, waits — leave the section byte-identical (checked: round 4), so they
+    neither invalidate a counter pass nor have any reason to be shaped around one (until round 3 the key was a hash of six SOURCE files,
+    host code included)."""
+    import struct
+
+    b = open(os.path.join(ROOT, "halo2-zkcert_amd", "libzkhip.so"), "rb").read()
+    if b[:4] != b"\x7fELF" or b[4] != 2:
+        raise RuntimeError("libzkhip.so is not a 64-bit ELF file")
+    shoff = struct.unpack_from("<Q", b, 0x28)[0]
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", b, 0x3A)
+    secs = [struct.unpack_from("<IIQQQQIIQQ", b, shoff + i * shentsize) for i in range(shnum)]
+    names = secs[shstrndx][4]
+    for sec in secs:
+        if b[names + sec[0]: b.index(b"\0", names + sec[0])] == b".hip_fatbin":
+            return hashlib.sha256(b[sec[4]: sec[4] + sec[5]]).hexdigest()[:16]
+    raise RuntimeError("libzkhip.so has no .hip_fatbin section")
 
 
 def make_shape(pv, name, args):

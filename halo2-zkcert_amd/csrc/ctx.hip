@@ -210,7 +210,7 @@ int zkhip_init(zkhip_ctx** out, int device_id) {
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0) {
         (void)hipGetLastError();
-        set_error("zkhip_init: no HIP device visible (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+        set_error("zkhip_init: no HIP device is visible (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
         return ZKHIP_ENODEVICE;
     }
     if (device_id < 0 || device_id >= ndev) { set_error("zkhip_init: device %d out of range [0,%d)", device_id, ndev); return ZKHIP_EINVAL; }

@@ -999,7 +999,7 @@ static int msm_local(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const 
     const zkhip_srs* srs = srs_per_col[0];
     for (size_t j = 0; j < ncols; ++j) {
         const zkhip_srs* q = srs_per_col[j];
-        if (!q) { set_error("zkhip_msm: null SRS for column %zu", j); return ZKHIP_EINVAL; }
+        if (!q) { set_error("zkhip_msm: the SRS of column %zu is null", j); return ZKHIP_EINVAL; }
         if (q->n != srs->n || q->c != srs->c) { set_error("zkhip_msm: the SRS of column %zu has a different size", j); return ZKHIP_EINVAL; }
     }
     if (first + n > srs->n) { set_error("zkhip_msm: range [%zu, %zu) exceeds the %zu bases loaded", first, first + n, srs->n); return ZKHIP_EINVAL; }
@@ -1265,7 +1265,7 @@ static int msm_run(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const vo
     bool sharded = false;
     for (size_t j = 0; j < ncols; ++j) {
         const zkhip_srs* q = srs_per_col[j];
-        if (!q) { set_error("zkhip_msm: null SRS for column %zu", j); return ZKHIP_EINVAL; }
+        if (!q) { set_error("zkhip_msm: the SRS of column %zu is null", j); return ZKHIP_EINVAL; }
         if (q->first0 != srs->first0 || q->n != srs->n || q->n_total != srs->n_total) { set_error("zkhip_msm: the SRS of column %zu covers a different range", j); return ZKHIP_EINVAL; }
         sharded |= q->n_total != q->n;
     }
