@@ -1074,7 +1074,9 @@ class Prover:
             + ["shplonk_h1", "shplonk_h2"]
         user_order = [c_ for ph in sh.phases for c_, p_ in enumerate(sh.challenge_phase) if p_ == ph]      # squeeze order of the user challenges
         squeeze_tags = [("user", c_) for c_ in user_order] + ["theta", "beta", "gamma", "y", "x", "shplonk_y", "shplonk_v", "shplonk_u"]
-        trace = {"commitments": [], "challenges": {"user": [None] * len(user_order)}, "points": {}, "transcript": kind}
+        trace = {"commitments": [], "challenges": {}, "points": {}, "transcript": kind}
+        if user_order:
+            trace["challenges"]["user"] = [None] * len(user_order)
 
         def record_challenge(tag, value):
             if isinstance(tag, tuple):
@@ -1349,7 +1351,9 @@ class Prover:
             queries = [(key, pt, evals[(key, rot)]) for (key, rot), pt in zip(qlist, points)]
             opening = ShplonkProver(b).create_proof(polys, queries, lambda tag: ts.squeeze(), absorb)
         trace["challenges"] = dict(theta=theta, beta=beta, gamma=gamma, y=y, x=x, shplonk_y=opening["y"], shplonk_v=opening["v"],
-                                   shplonk_u=opening["u"], user=list(user_ch))
+                                   shplonk_u=opening["u"])
+        if user_ch:
+            trace["challenges"]["user"] = list(user_ch)      # the user challenges (multi-phase circuits only), index = challenge index
         trace["opening"] = opening
         trace["h_pieces"] = pieces
         trace["n_commitments"] = len(trace["commitments"])

@@ -838,7 +838,7 @@ def plonk_expected_h(vk, instance_cols, evals, ch):
 
     def get(kind, col, rot):
         if kind == "challenge":     # a user challenge (Expression::Challenge): squeezed after the commitments of its phase
-            return ch["user"][col]
+            return ch["user"][col]     # (KeyError: a challenge expression in a circuit whose reader squeezed none)
         if kind == "instance":      # QUERY_INSTANCE = false for KZG: the verifier evaluates the instance polynomial itself
             if (col, rot) not in inst_cache:
                 pt = x * pow(w, rot % n, R) % R
@@ -1193,7 +1193,8 @@ def read_plonk_proof(vk, kind, proof, vk_repr, instance_values, advice_queries, 
     # vk["challenge_phase"] per challenge; absent = everything in phase 0, no user challenge)
     adv_phase = list(vk.get("advice_phase") or [0] * n_adv) + [0] * n_adv
     chal_phase = list(vk.get("challenge_phase") or [])
-    ch["user"] = [None] * len(chal_phase)
+    if chal_phase:
+        ch["user"] = [None] * len(chal_phase)
     for ph in sorted(set(adv_phase[:n_adv]) | set(chal_phase)):
         for i in range(n_adv):
             if adv_phase[i] == ph:
