@@ -182,7 +182,7 @@ const OptName OPTIONS[] = {
     {"ZKHIP_EVAL_BYVAL", "eval_byval", &zkhip_options::eval_byval}, {"ZKHIP_LATE_OVERLAP", "late_overlap", &zkhip_options::late_overlap},
     {"ZKHIP_HOST_TIMING", "host_timing", &zkhip_options::host_timing},
     {"ZKHIP_COSET_QUOTIENT", "coset_quotient", &zkhip_options::coset_quotient}, {"ZKHIP_ROW_SHARDED", "row_sharded", &zkhip_options::row_sharded},
-    {"ZKHIP_COMM_TIMEOUT_MS", "comm_timeout_ms", &zkhip_options::comm_timeout_ms},
+    {"ZKHIP_COMM_TIMEOUT_MS", "comm_timeout_ms", &zkhip_options::comm_timeout_ms}, {"ZKHIP_RAND_OVERLAP", "rand_overlap", &zkhip_options::rand_overlap},
 };
 }  // namespace
 
@@ -246,6 +246,8 @@ void zkhip_destroy(zkhip_ctx* c) {
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->side_event) (void)hipEventDestroy(c->side_event);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
+    for (auto e : c->aux_event) if (e) (void)hipEventDestroy(e);
     for (auto e : c->copy_event) if (e) (void)hipEventDestroy(e);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->stage_ring) (void)hipHostFree(c->stage_ring);
@@ -263,10 +265,11 @@ int zkhip_set_stream(zkhip_ctx* c, void* s) {
 int zkhip_trim(zkhip_ctx* c) {
     if (!c) { set_error("null ctx"); return ZKHIP_EINVAL; }
     ZK_HIP(hipDeviceSynchronize());
-    char keep[3][32];
+    char keep[4][32];
     snprintf(keep[0], 32, "@%p", (void*)c->stream);
     snprintf(keep[1], 32, "@%p", (void*)c->own_stream);
     snprintf(keep[2], 32, "@%p", (void*)c->side_stream);
+    snprintf(keep[3], 32, "@%p", (void*)c->aux_stream);
     for (auto it = c->scratch.begin(); it != c->scratch.end();) {
         const std::string& k = it->first;
         bool live = false;

@@ -195,6 +195,16 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
     // main stream already commits the vanishing argument's random polynomial, which needs none of them (phase 1 below); small ones
     // ride on the proof's stream.  From pinned memory the copies run at link rate; from pageable memory the runtime stages them.
     const bool split_upload = !multi_phase && in->advice_on_host && A && (size_t)A * NB >= ((size_t)64 << 20);
+    // The vanishing argument's random polynomial depends on nothing: its commitment can leave the advice batch and run on a third stream
+    // beside the grand products and the z columns' inverse transforms (memory-bound kernels on the main stream).  Measured A/B (round 4,
+    // gpurun_out/r04p): k = 17 7.07 / 7.09 -> 6.94 / 6.99 ms (the MSM's latency chain hides behind the products phase), k = 19 neutral,
+    // k = 22 +0.25 ms (the side stream's NTTs already fill every idle multiplier slot: the proof is the sum of its instruction streams) —
+    // so by default only where proofs are latency-shaped (k <= 18).  Needs a products phase (Zp + L > 0).
+    const bool rand_late = !multi_phase && !split_upload && (Zp + L) > 0 && (ctx->opt.rand_overlap < 0 ? k <= 18 : ctx->opt.rand_overlap != 0);
+    if (rand_late && !ctx->aux_stream) {
+        ZK_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+        for (auto& e : ctx->aux_event) ZK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
     // many columns (the SHA-256 circuit's 32): uploaded and committed in up to 4 groups of >= 8 columns, so that the commitment of group
     // g runs while group g + 1 is still on the wire; few big columns (the aggregation circuit's 4): one group behind the random polynomial
     // few columns of >= 64 MiB each (k >= 21: a column's upload, 2.5 ms, is shorter than its commitment): groups of two columns, up to 4
@@ -413,6 +423,7 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
         ZK_TRY(zkhip_synth_fill_device(ctx, w_rand, n, blinding_seed + 380, 0));
     }
 
+    if (rand_late) ZK_HIP(hipEventRecord(ctx->aux_event[0], st));   // w_rand is complete on the main stream from here on
     std::vector<void*> coeff_ptrs(A + I), ext_ptrs(A + I);
     for (uint32_t j = 0; j < A + I; ++j) { coeff_ptrs[j] = w_coeff + j * NB; ext_ptrs[j] = w_ext + j * EB; }
     std::vector<uint64_t> rand_xy;
@@ -474,8 +485,10 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
     } else {
         std::vector<const void*> cols(d_advice, d_advice + A);
         std::vector<const zkhip_srs*> bases(A, pk->g_lagrange);
-        cols.push_back(w_rand);
-        bases.push_back(pk->g);
+        if (!rand_late) {
+            cols.push_back(w_rand);
+            bases.push_back(pk->g);
+        }
         if (split_upload) {
             // the random polynomial's commitment first (its slot is the last one of the batch), then — once the uploads have landed —
             // the advice columns'
@@ -503,7 +516,7 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
         ov.end();
         absorb_vk_and_instances();
         mark("vk + instances absorbed (GPU busy)");
-        ZK_TRY(commit_read(cols.size(), 1, &rand_xy, &rand_by));
+        ZK_TRY(commit_read(cols.size(), rand_late ? 0 : 1, &rand_xy, &rand_by));
     }
     mark("advice committed + absorbed");
     tr->squeeze_challenge(tr->user, ch);
@@ -616,6 +629,19 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
         } else {
             ZK_TRY(zkhip_lagrange_to_coeff_device(ctx, pk->domain, z_ptrs.data(), Zp + L));
         }
+        char* w_com_rand = w_com + (size_t)(A + 2 * L + Zp + L + qd + 1) * 96;   // the last slot of the commitment area: no batch reaches it
+        if (rand_late) {
+            // (the grand products and the inverse transforms above are queued on the main stream; the host blocks ~1 ms inside this MSM
+            // for its plan read-back and is back long before they finish)
+            ZK_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->aux_event[0], 0));
+            ctx->stream = ctx->aux_stream;
+            const void* rc[1] = {w_rand};
+            const zkhip_srs* rb[1] = {pk->g};
+            const int rc_ = zkhip_msm_g1_multi_device(ctx, rb, rc, 1, 0, n, w_com_rand);
+            ctx->stream = st;
+            ZK_TRY(rc_);
+            ZK_HIP(hipEventRecord(ctx->aux_event[1], ctx->aux_stream));
+        }
         std::vector<const void*> cols(z_ptrs.begin(), z_ptrs.end());
         std::vector<const zkhip_srs*> bases(Zp + L, pk->g);
         ov.arm();
@@ -627,6 +653,13 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
     }
     // ---- 4. the random polynomial enters the transcript here
     mark("products committed + absorbed");
+    if (rand_late) {
+        char* w_com_rand = w_com + (size_t)(A + 2 * L + Zp + L + qd + 1) * 96;
+        ZK_HIP(event_wait(ctx, ctx->aux_event[1]));
+        rand_xy.resize(8);
+        rand_by.resize(32);
+        ZK_TRY(zkhip_commitments_read(ctx, w_com_rand, 1, rand_xy.data(), rand_by.data()));
+    }
     tr->write_point(tr->user, rand_by.data(), rand_xy.data());
     uint64_t y[4];
     tr->squeeze_challenge(tr->user, y);
