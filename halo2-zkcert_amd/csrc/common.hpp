@@ -62,6 +62,7 @@ struct zkhip_options {
     int host_timing = 0;   // zkhip_create_proof prints its host-side phase times to stderr
     int row_sharded = 1;      // multi-rank proofs on the coset path: all-to-all of row windows (1) / all-gather of complete columns (0)
     int comm_timeout_ms = 120000;   // host waits of a multi-rank context give up after this long (0: wait for ever): see zk::CommWatch
+    int eval_chunks = -1;     // evaluations at x in this many launches, absorbed chunk by chunk while the next is computed (1: one launch; -1: by size)
     int rand_overlap = -1;    // the vanishing argument's random polynomial is committed on a third stream beside the grand products (0: with the advice batch; -1: by size)
     int coset_quotient = 1;   // zkhip_create_proof evaluates the quotient on quotient_poly_degree cosets of size n (cosets.hip) when that is fewer rows
 };
@@ -103,6 +104,7 @@ struct zkhip_ctx {
     hipEvent_t side_event = nullptr;
     hipStream_t aux_stream = nullptr;    // zkhip_create_proof's third stream: the random polynomial's commitment beside the (memory-bound) grand products
     hipEvent_t aux_event[2] = {nullptr, nullptr};
+    hipEvent_t eval_event[4] = {nullptr, nullptr, nullptr, nullptr};   // one per chunk of the pipelined evaluations (zkhip_create_proof_ex)
     hipStream_t copy_stream = nullptr;   // uploads of large host advice columns (zkhip_create_proof_ex, advice_on_host), created on first use
     hipEvent_t copy_event[4] = {nullptr, nullptr, nullptr, nullptr};   // one per upload group
     // Small host->device uploads of host temporaries (pointer tables, lowered programs): the bytes are copied into a pinned ring

@@ -183,6 +183,7 @@ const OptName OPTIONS[] = {
     {"ZKHIP_HOST_TIMING", "host_timing", &zkhip_options::host_timing},
     {"ZKHIP_COSET_QUOTIENT", "coset_quotient", &zkhip_options::coset_quotient}, {"ZKHIP_ROW_SHARDED", "row_sharded", &zkhip_options::row_sharded},
     {"ZKHIP_COMM_TIMEOUT_MS", "comm_timeout_ms", &zkhip_options::comm_timeout_ms}, {"ZKHIP_RAND_OVERLAP", "rand_overlap", &zkhip_options::rand_overlap},
+    {"ZKHIP_EVAL_CHUNKS", "eval_chunks", &zkhip_options::eval_chunks},
 };
 }  // namespace
 
@@ -246,6 +247,7 @@ void zkhip_destroy(zkhip_ctx* c) {
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->side_event) (void)hipEventDestroy(c->side_event);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    for (auto e : c->eval_event) if (e) (void)hipEventDestroy(e);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     for (auto e : c->aux_event) if (e) (void)hipEventDestroy(e);
     for (auto e : c->copy_event) if (e) (void)hipEventDestroy(e);

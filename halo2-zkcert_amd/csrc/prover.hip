@@ -840,6 +840,7 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
     const size_t nq = q_poly.size();
     if (nq > max_q) { set_error("zkhip_create_proof: query count"); return ZKHIP_EINVAL; }
     std::vector<uint64_t> q_points(4 * nq), q_evals(4 * nq);
+    bool evals_absorbed = false;
     {
         const HF omega = hf_from_abi(omega_abi);
         std::vector<std::pair<int32_t, HF>> cache;
@@ -913,6 +914,46 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
                 abi_of(acc, q_evals.data() + 4 * ih);
             }
         } else {
+        // A sponge transcript spends ~15 us of HOST time per absorbed pair (Poseidon: one permutation per two evaluations) — 0.8 ms for the
+        // SHA shape's 110 evaluations — with the GPU idle behind it.  With many evaluations they are therefore computed in four launches in
+        // the order the transcript WRITES them, and chunk c is absorbed while chunk c + 1 is still being computed.
+        uint32_t C = ctx->opt.eval_chunks > 0 ? (uint32_t)std::min(ctx->opt.eval_chunks, 4) : (ev_pinned && k <= 20 && nq >= 64 ? 4u : 1u);   // measured (gpurun_out/r04r, r04s): 110 evaluations at k = 19 in four launches -0.23 ms; 24 at k = 17 in two or three: nothing (noise); k = 22: +0.5 ms
+        if (!ev_pinned || nq < 2) C = 1;
+        if (C > 1) {
+            std::vector<uint32_t> order(w_order);
+            order.push_back((uint32_t)(nq - 2));      // h(x): evaluated, not written — last
+            for (uint32_t c = 0; c < C; ++c)
+                if (!ctx->eval_event[c]) ZK_HIP(hipEventCreateWithFlags(&ctx->eval_event[c], hipEventDisableTiming));
+            auto lo_of = [&](uint32_t c) { return (size_t)((uint64_t)nq * c / C); };   // chunk sizes differ by at most one
+            // the largest chunk first sizes the evaluation scratch once (a later, larger request would reallocate behind a stream sync)
+            std::vector<const void*> cq;
+            std::vector<uint64_t> cp;
+            for (uint32_t c = 0; c < C; ++c) {
+                const size_t b0 = lo_of(c), b1 = lo_of(c + 1);
+                cq.clear(); cp.clear();
+                for (size_t i = b0; i < b1; ++i) {
+                    cq.push_back(qp[order[i]]);
+                    cp.insert(cp.end(), q_points.begin() + 4 * (size_t)order[i], q_points.begin() + 4 * (size_t)order[i] + 4);
+                }
+                if (c == 0) {   // (size the scratch for the largest chunk up front)
+                    void* dummy;
+                    const uint32_t per_ = n >= ((size_t)1 << 16) ? 32 : 8;
+                    ZK_TRY(ctx->get_scratch("po_eval_part", ((nq + C - 1) / C + 1) * (size_t)div_up(n, (size_t)per_ * 256) * 32, &dummy));
+                    ZK_TRY(ctx->get_scratch("po_eval_ptrs", ((nq + C - 1) / C + 1) * sizeof(void*), &dummy));
+                    ZK_TRY(ctx->get_scratch("po_eval_xs", ((nq + C - 1) / C + 1) * 32, &dummy));
+                }
+                ZK_TRY(zkhip_eval_polynomials_at_device(ctx, cq.data(), cq.size(), n, cp.data(), ev_out + b0 * 32));
+                ZK_HIP(hipEventRecord(ctx->eval_event[c], ctx->stream));
+            }
+            for (uint32_t c = 0; c < C; ++c) {
+                ZK_HIP(event_wait(ctx, ctx->eval_event[c]));
+                for (size_t i = lo_of(c); i < lo_of(c + 1); ++i) {
+                    memcpy(q_evals.data() + 4 * (size_t)order[i], ev_out + i * 32, 32);
+                    if (i + 1 < nq) tr->write_scalar(tr->user, q_evals.data() + 4 * (size_t)order[i]);   // (the last entry is h(x): not written)
+                }
+            }
+            evals_absorbed = true;
+        } else {
         ZK_TRY(zkhip_eval_polynomials_at_device(ctx, qp.data(), nq, n, q_points.data(), ev_out));
         if (ev_pinned) {
             ZK_HIP(stream_wait(ctx, ctx->stream));
@@ -921,9 +962,11 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
             ZK_TRY(zkhip_memcpy_d2h(ctx, q_evals.data(), w_evals, nq * 32));
         }
         }
+        }
     }
     mark("evaluations read back");
-    for (uint32_t i : w_order) tr->write_scalar(tr->user, q_evals.data() + 4 * (size_t)i);   // h(x) is not written: the verifier recomputes it
+    if (!evals_absorbed)
+        for (uint32_t i : w_order) tr->write_scalar(tr->user, q_evals.data() + 4 * (size_t)i);   // h(x) is not written: the verifier recomputes it
     mark("evaluations absorbed");
     ctx->comm.phase = "shplonk";
     if (out) {
