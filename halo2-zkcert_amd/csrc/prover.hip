@@ -463,9 +463,8 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
             }
             std::vector<const void*> cols;
             std::vector<const zkhip_srs*> bases;
-            std::vector<uint32_t> which;
             for (uint32_t j = 0; j < A; ++j)
-                if (phase_of(j) == ph) { cols.push_back(adv_cols[j]); bases.push_back(pk->g_lagrange); which.push_back(j); }
+                if (phase_of(j) == ph) { cols.push_back(adv_cols[j]); bases.push_back(pk->g_lagrange); }
             if (ph == 0) { cols.push_back(w_rand); bases.push_back(pk->g); }
             ZK_TRY(commit_launch(cols, bases));
             if (ph == 0) absorb_vk_and_instances();
