@@ -25,7 +25,7 @@ torch.cuda.set_device(0)
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 shapes = {"small": pv.CircuitShape.small, "agg": pv.CircuitShape.agg, "two": lambda k: pv.CircuitShape(f"two_lookups_k{k}", k, 2, 2, 1, 4, 6, 0x2100C0 + k),
-          "sha": lambda k: pv.CircuitShape.sha256(k, n_advice=12, n_fixed=5)}
+          "sha": lambda k: pv.CircuitShape.sha256(k, n_advice=12, n_fixed=5), "phase": pv.CircuitShape.two_phase}
 solo = ffi.Context(0)
 done, seed, modes = 0, 0, {}
 t_end = time.time() + args.seconds
@@ -36,7 +36,7 @@ while True:
     if int(stop[0]):
         break
     k = args.kmin + seed % (args.kmax - args.kmin + 1)
-    name = ("small", "agg", "two", "sha")[(seed // 2) % 4]
+    name = ("small", "agg", "two", "sha", "phase")[(seed // 2) % 5]
     mode = ("points", "columns")[(seed // 5) % 2]
     kind = ("poseidon", "evm", "blake2b")[seed % 3]
     ctx = ffi.Context(0)

@@ -25,10 +25,11 @@ def main():
     done, seed = 0, 0
     provers = {}
     kinds = ("poseidon", "evm", "blake2b")
-    shapes = {"small": pv.CircuitShape.small, "sha": lambda k: pv.CircuitShape.sha256(k, n_advice=12, n_fixed=5), "agg": pv.CircuitShape.agg}
+    shapes = {"small": pv.CircuitShape.small, "sha": lambda k: pv.CircuitShape.sha256(k, n_advice=12, n_fixed=5), "agg": pv.CircuitShape.agg,
+              "phase": pv.CircuitShape.two_phase}      # an advice column of the second phase + a user challenge
     while time.time() < t_end:
         k = args.kmin + seed % (args.kmax - args.kmin + 1)
-        name = ("small", "sha", "agg")[(seed // 3) % 3]
+        name = ("small", "sha", "agg", "phase")[(seed // 3) % 4]
         if (name, k) not in provers:
             provers[(name, k)] = pv.Prover(pv.GpuBackend(ctx, ffi), shapes[name](k), satisfiable=True)
         p = provers[(name, k)]
