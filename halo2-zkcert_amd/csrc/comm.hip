@@ -44,14 +44,15 @@ struct Rccl {
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 Rccl g_rccl;
+std::string g_rccl_path;   // zkhip_comm_use_library
 int load_rccl() {
     if (g_rccl.lib) return ZKHIP_OK;
     const char* names[] = {"librccl.so", "librccl.so.1"};
     void* h = nullptr;
-    // ZKHIP_RCCL_LIB: another library with the same entry points (tests/fake_rccl: N ranks on one GPU through the RCCL transport's code path)
-    if (const char* over = getenv("ZKHIP_RCCL_LIB")) {
-        h = dlopen(over, RTLD_NOW | RTLD_LOCAL);
-        if (!h) { set_error("zkhip_comm: ZKHIP_RCCL_LIB=%s cannot be loaded (%s)", over, dlerror()); return ZKHIP_EINVAL; }
+    // zkhip_comm_use_library: the caller named the library (another RCCL build; tests/fake_rccl in the one-GPU tests)
+    if (!g_rccl_path.empty()) {
+        h = dlopen(g_rccl_path.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (!h) { set_error("zkhip_comm: %s cannot be loaded (%s)", g_rccl_path.c_str(), dlerror()); return ZKHIP_EINVAL; }
     }
     for (const char* nm : names) if (!h) h = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);   // the copy the process already uses (torch's)
     for (const char* nm : names) if (!h) h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
@@ -256,6 +257,12 @@ int comm_fold_partials(zkhip_ctx* ctx, const void* d_part, size_t ncols, void* d
 }  // namespace zk
 
 extern "C" {
+
+int zkhip_comm_use_library(const char* path) {
+    if (g_rccl.lib) { set_error("zkhip_comm_use_library: the collective library is already bound (call it before the first zkhip_comm_* call)"); return ZKHIP_EINVAL; }
+    g_rccl_path = path ? path : "";
+    return ZKHIP_OK;
+}
 
 int zkhip_comm_unique_id(uint8_t id[128]) {
     if (!id) { set_error("zkhip_comm_unique_id: null argument"); return ZKHIP_EINVAL; }

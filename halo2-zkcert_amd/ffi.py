@@ -12,6 +12,7 @@ import os
 import numpy as np
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
+_rccl_lib_named = False
 LIB_PATH = os.environ.get("ZKHIP_LIB") or os.path.join(_DIR, "libzkhip.so")   # ZKHIP_LIB: A/B runs of another build of the same library
 _LIB = None
 
@@ -54,7 +55,7 @@ class ZkEvalhArgs(C.Structure):
 # every symbol include/zkhip.h declares (checked by tests/test_abi.py without a GPU)
 SYMBOLS = [
     "zkhip_init", "zkhip_destroy", "zkhip_last_error", "zkhip_set_stream", "zkhip_synchronize", "zkhip_set_option", "zkhip_trim", "zkhip_key_release",
-    "zkhip_comm_unique_id", "zkhip_comm_init", "zkhip_comm_init_host", "zkhip_comm_set_host_alltoall", "zkhip_comm_destroy", "zkhip_comm_info", "zkhip_comm_describe", "zkhip_comm_allgather_device", "zkhip_comm_shard_columns",
+    "zkhip_comm_use_library", "zkhip_comm_unique_id", "zkhip_comm_init", "zkhip_comm_init_host", "zkhip_comm_set_host_alltoall", "zkhip_comm_destroy", "zkhip_comm_info", "zkhip_comm_describe", "zkhip_comm_allgather_device", "zkhip_comm_shard_columns",
     "zkhip_kzg_setup_range", "zkhip_srs_load_range", "zkhip_srs_range", "zkhip_malloc", "zkhip_free",
     "zkhip_memcpy_h2d", "zkhip_memcpy_d2h", "zkhip_timer_start", "zkhip_timer_stop_ms",
     "zkhip_profile_enable", "zkhip_profile_select", "zkhip_profile_read", "zkhip_profile_counter",
@@ -198,6 +199,12 @@ class Context:
         if transport is None:
             transport = os.environ.get("ZKHIP_COMM_TRANSPORT") or ("host" if dist is not None and dist.get_backend() == "gloo" else "rccl")
         if transport == "rccl":
+            # ZKHIP_RCCL_LIB (read HERE, by the Python binding — the library itself reads no such variable): the collective library the
+            # transport binds, through zkhip_comm_use_library; the one-GPU tests name tests/fake_rccl/libfake_rccl.so
+            global _rccl_lib_named
+            if os.environ.get("ZKHIP_RCCL_LIB") and not _rccl_lib_named:
+                _check(lib().zkhip_comm_use_library(os.environ["ZKHIP_RCCL_LIB"].encode()))
+                _rccl_lib_named = True
             ids = [None]
             if rank == 0:
                 buf = (C.c_uint8 * 128)()

@@ -103,6 +103,11 @@ typedef int (*zkhip_host_allgather_fn)(void* user, const void* send, void* recv,
 /* the host transport's all-to-all (optional): send / recv hold nranks blocks of bytes_per_pair; block r of send goes to rank r, block r of
  * recv comes from rank r.  Without it the library emulates the exchange through the all-gather callback (N times the volume). */
 typedef int (*zkhip_host_alltoall_fn)(void* user, const void* send, void* recv, size_t bytes_per_pair);
+/* Which collective library the RCCL transport binds (process-wide; before the first zkhip_comm_unique_id / zkhip_comm_init): a path for
+ * dlopen — another RCCL build than the one already in the process, or a stand-in with the same entry points (this repo's one-GPU tests
+ * drive the transport's code path through tests/fake_rccl).  NULL or never called: the librccl the process already uses (torch ships
+ * one), else the system's.  The library reads no environment variable for this. */
+int  zkhip_comm_use_library(const char* path);
 int  zkhip_comm_unique_id(uint8_t id[128]);
 int  zkhip_comm_init(zkhip_ctx* ctx, const uint8_t id[128], int rank, int nranks);
 int  zkhip_comm_init_host(zkhip_ctx* ctx, int rank, int nranks, zkhip_host_allgather_fn fn, void* user);
