@@ -331,6 +331,10 @@ class GpuBackend:
         """col[idx] (idx: host int64 array) — witness construction only"""
         return col[self.torch.from_numpy(idx).to(col.device)].contiguous()
 
+    def put_rows(self, col, idx, vals):
+        """col[idx] = vals in place (idx: host int64 array, distinct) — keygen-fixture construction only"""
+        col[self.torch.from_numpy(idx).to(col.device)] = vals
+
     def from_host(self, arr):
         return self.ctx.to_device(arr)
 
@@ -785,24 +789,35 @@ class Prover:
         one = fr_from_int_host(1)
         pairs = np.asarray(pairs, dtype=np.int64).reshape(-1, 2)
         assert len(np.unique(pairs)) == pairs.size, "copy pairs must be disjoint"
-        perm = np.arange(P * n, dtype=np.int64)
-        value_src = np.arange(P * n, dtype=np.int64)
-        perm[pairs[:, 0]], perm[pairs[:, 1]] = pairs[:, 1], pairs[:, 0]
-        value_src[pairs[:, 0]] = pairs[:, 1]
-        self._value_src = value_src
+        # witness(): the destination cells of permutation column j take their values from these source cells —
+        # _value_src[j] = [(source permutation column, destination rows, source rows)]
+        self._value_src = {}
+        for dc in range(P):
+            for sc in range(P):
+                m_ = (pairs[:, 0] // n == dc) & (pairs[:, 1] // n == sc)
+                if m_.any():
+                    self._value_src.setdefault(dc, []).append((sc, np.ascontiguousarray(pairs[m_, 0] % n), np.ascontiguousarray(pairs[m_, 1] % n)))
         self.copy_pairs = pairs
         # identity permutation values delta^j * w^i, then the swaps
         xpoly = np.zeros((n, 4), dtype=np.uint64)
         xpoly[1] = one
         omega_col = [b.from_host(xpoly)]
         b.coeff_to_lagrange(omega_col)
-        ident = b.concat([b.lincomb(omega_col, [pow(DELTA, j, R)], None) for j in range(P)])
-        sig = b.gather(ident, perm)
-        self.sigma_lagrange = [sig[j * n:(j + 1) * n] for j in range(P)]
-        if hasattr(self.sigma_lagrange[0], "contiguous"):
-            self.sigma_lagrange = [c.contiguous() for c in self.sigma_lagrange]
-        else:
-            self.sigma_lagrange = [np.ascontiguousarray(c) for c in self.sigma_lagrange]
+        # sigma = the identity columns with the cells of every pair swapped.  Sparse: the values of the ~n / 4 cells that move are gathered
+        # from the pristine identity columns first, then put in place (until round 4: one gather over all P n cells through a P n index
+        # array and a concatenated copy of the identity — 1.7 GiB of temporaries at k = 22 for a permutation that moves 4 % of the cells)
+        sigma = [b.lincomb(omega_col, [pow(DELTA, j, R)], None) for j in range(P)]
+        both = np.concatenate([pairs, pairs[:, ::-1]], axis=0) if len(pairs) else pairs      # (destination cell, source cell), both directions
+        dcol, drow, scol, srow = both[:, 0] // n, both[:, 0] % n, both[:, 1] // n, both[:, 1] % n
+        moves = []
+        for dc in range(P):
+            for sc in range(P):
+                m_ = (dcol == dc) & (scol == sc)
+                if m_.any():
+                    moves.append((dc, np.ascontiguousarray(drow[m_]), b.gather(sigma[sc], np.ascontiguousarray(srow[m_]))))
+        for dc, rows_, vals_ in moves:
+            b.put_rows(sigma[dc], rows_, vals_)
+        self.sigma_lagrange = sigma
 
     def _build_satisfiable_sha(self, seed):
         """The SHA-256-bit-circuit shape (CircuitShape.sha256) as a satisfiable instance:
@@ -906,8 +921,11 @@ class Prover:
             copy_cols = [(j, i) for j, (t, i) in enumerate(sh.perm_columns) if t == "advice" and i < sh.n_basic]
             for j, c in (reversed(copy_cols) if sh.layout == "sha" else copy_cols):       # copies: basic-advice cells take their partner's value
                 cols = {"advice": advice, "fixed": self.fixed_lagrange, "instance": instance}
-                stack = b.concat([cols[t][i] for t, i in sh.perm_columns])
-                advice[c] = b.gather(stack, self._value_src[j * n:(j + 1) * n])
+                # (sparse: only the destination cells are touched; source cells are never destinations, so gathering before putting reads
+                # what the full-column gather of earlier rounds read)
+                moves = [(rows_d, b.gather(cols[sh.perm_columns[sc][0]][sh.perm_columns[sc][1]], rows_s)) for sc, rows_d, rows_s in self._value_src.get(j, [])]
+                for rows_d, vals_ in moves:
+                    b.put_rows(advice[c], rows_d, vals_)
             for c, g in self._fill_graphs:       # gate outputs
                 advice[c] = b.compress(g, self.fixed_lagrange + [self._out_mask], advice, instance, 0, sh.k)
         return dict(advice=advice, instance=instance, instance_values=inst_vals, base=base)

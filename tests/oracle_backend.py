@@ -48,6 +48,9 @@ class OracleBackend:
     def gather(self, col, idx):
         return np.ascontiguousarray(col[idx])
 
+    def put_rows(self, col, idx, vals):
+        col[idx] = vals
+
     def permute(self, k, bf, cin, ctab, blind_in, blind_tab):
         return zo.permute_expression_pair(k, bf, cin, ctab, blind_in, blind_tab)
 
