@@ -791,12 +791,26 @@ class Prover:
         assert len(np.unique(pairs)) == pairs.size, "copy pairs must be disjoint"
         # witness(): the destination cells of permutation column j take their values from these source cells —
         # _value_src[j] = [(source permutation column, destination rows, source rows)]
+        def by_columns(cells):
+            """(destination cell, source cell) rows -> [(destination column, source column, destination rows, source rows)], one entry per
+            column pair that occurs: ONE stable radix sort of a small key instead of P^2 boolean masks over all pairs"""
+            if not len(cells):
+                return []
+            dst, src = np.ascontiguousarray(cells[:, 0]), np.ascontiguousarray(cells[:, 1])
+            dcol, drow, scol, srow = dst >> sh.k, dst & (n - 1), src >> sh.k, src & (n - 1)      # n = 2^k
+            key = (dcol * P + scol).astype(np.uint16)
+            order = np.argsort(key, kind="stable")
+            counts = np.bincount(key, minlength=P * P)
+            out, at = [], 0
+            for v in np.flatnonzero(counts):
+                idx = order[at:at + counts[v]]
+                at += counts[v]
+                out.append((int(v) // P, int(v) % P, np.ascontiguousarray(drow[idx]), np.ascontiguousarray(srow[idx])))
+            return out
+
         self._value_src = {}
-        for dc in range(P):
-            for sc in range(P):
-                m_ = (pairs[:, 0] // n == dc) & (pairs[:, 1] // n == sc)
-                if m_.any():
-                    self._value_src.setdefault(dc, []).append((sc, np.ascontiguousarray(pairs[m_, 0] % n), np.ascontiguousarray(pairs[m_, 1] % n)))
+        for dc, sc, rows_d, rows_s in by_columns(pairs):
+            self._value_src.setdefault(dc, []).append((sc, rows_d, rows_s))
         self.copy_pairs = pairs
         # identity permutation values delta^j * w^i, then the swaps
         xpoly = np.zeros((n, 4), dtype=np.uint64)
@@ -808,13 +822,7 @@ class Prover:
         # array and a concatenated copy of the identity — 1.7 GiB of temporaries at k = 22 for a permutation that moves 4 % of the cells)
         sigma = [b.lincomb(omega_col, [pow(DELTA, j, R)], None) for j in range(P)]
         both = np.concatenate([pairs, pairs[:, ::-1]], axis=0) if len(pairs) else pairs      # (destination cell, source cell), both directions
-        dcol, drow, scol, srow = both[:, 0] // n, both[:, 0] % n, both[:, 1] // n, both[:, 1] % n
-        moves = []
-        for dc in range(P):
-            for sc in range(P):
-                m_ = (dcol == dc) & (scol == sc)
-                if m_.any():
-                    moves.append((dc, np.ascontiguousarray(drow[m_]), b.gather(sigma[sc], np.ascontiguousarray(srow[m_]))))
+        moves = [(dc, rows_d, b.gather(sigma[sc], rows_s)) for dc, sc, rows_d, rows_s in by_columns(both)]
         for dc, rows_, vals_ in moves:
             b.put_rows(sigma[dc], rows_, vals_)
         self.sigma_lagrange = sigma
