@@ -733,9 +733,9 @@ class Prover:
         one = fr_from_int_host(1)
         gate_rows = np.arange(0, u - 3, 4)
         sel = np.zeros((n, 4), dtype=np.uint64)
-        sel[gate_rows] = one
+        sel[0:len(gate_rows) * 4:4] = one                # rows gate_rows = 0, 4, 8, ... (a slice, not an index array)
         out_mask = np.zeros((n, 4), dtype=np.uint64)
-        out_mask[gate_rows + 3] = one
+        out_mask[3:len(gate_rows) * 4:4] = one           # rows gate_rows + 3
         for c in range(sh.n_basic):
             self.fixed_lagrange[c] = b.from_host(sel)
         self._out_mask = b.from_host(out_mask)
