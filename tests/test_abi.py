@@ -100,3 +100,17 @@ def test_rust_bindings_are_generated_from_the_header(built):
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         names = re.findall(r"(\w+)\s*(?:\[\d*\])?\s*[;,]", body)
         assert names == [f[0] for f in cls._fields_], cname
+
+
+def test_bench_build_hash_is_the_device_code():
+    """bench.build_hash: sha256 of libzkhip.so's .hip_fatbin section (what keys the committed counter passes under profiles/); it must
+    parse the shipped library and match the `# build=` header of the newest pass, or roofline.traffic would silently become null"""
+    import glob
+    import importlib
+
+    bench = importlib.import_module("bench")
+    bh = bench.build_hash()
+    assert len(bh) == 16 and int(bh, 16) >= 0
+    heads = {open(f).readline().strip() for f in glob.glob(os.path.join(ROOT, "profiles", "r04_v3_pmc_*.csv"))}
+    assert heads == {"# build=" + bh}, (heads, bh)
+    assert bench.pmc_traffic("agg22", bh)[0]["msm_accum_affine"] > 1e9
