@@ -294,30 +294,33 @@ __device__ __forceinline__ el1<Fr> ev_x(const EvArgs& A, uint32_t i) { return A.
 template <int PER>
 __global__ void __launch_bounds__(PO_BLOCK) k_eval_tiles(const EvArgs A, size_t n, uint32_t* partial_all, uint32_t nblk) {
     __shared__ fe sc[PO_BLOCK];
+    __shared__ fe xpw[9];   // x^(2^l), l = 0 .. 8; xpw[8] = x^256
     const uint32_t t = threadIdx.x, poly = blockIdx.y;
     const uint32_t* c = ev_poly(A, poly);
     const el2<Fr> x = ev_x(A, poly);
-    const size_t lo = (size_t)blockIdx.x * (PER * PO_BLOCK) + (size_t)t * PER;
-    // Horner over this thread's PER coefficients
+    // The powers every thread needs are the same: thread 0 squares them once into LDS (instead of 256 threads squaring along).
+    if (t == 0) {
+        el2<Fr> xp = x;
+#pragma unroll
+        for (int l = 0; l < 9; ++l) { xpw[l] = xp.v; xp = sqr(xp); }
+    }
+    __syncthreads();
+    // Thread t owns coefficients t, t + 256, t + 512, ... of the tile (Horner in y = x^256): the 64 lanes of a wave read 2 KiB of
+    // consecutive bytes per step.  (Until round 4 a thread owned PER CONSECUTIVE coefficients — 1 KiB per lane, every load of a wave
+    // touching 64 different lines: 1.7 TB/s at 2^22; the tile's value is the same sum either way.)
+    const el2<Fr> y(xpw[8]);
+    const size_t base = (size_t)blockIdx.x * (PER * PO_BLOCK) + t;
     el<Fr, 4 * U> acc = zero<Fr>();
 #pragma unroll
     for (int j = PER - 1; j >= 0; --j) {
         el1<Fr> cj = zero<Fr>();
-        if (lo + j < n) cj = load_raw<Fr>(c + (lo + j) * 8);
-        acc = acc * x + cj;
+        const size_t i = base + (size_t)j * PO_BLOCK;
+        if (i < n) cj = load_raw<Fr>(c + i * 8);
+        acc = acc * y + cj;
     }
-    sc[t] = acc.v;
-    // x^PER, then pairwise: left + right * x^(PER * span).  The eight factors x^(PER 2^level) are the same for every thread: thread 0
-    // squares them once into LDS instead of 256 threads squaring along (13 of the ~50 products a thread spends on a tile).
-    __shared__ fe xpw[8];
-    if (t == 0) {
-        el2<Fr> xp = x;
-#pragma unroll
-        for (int q = 1; q < PER; q <<= 1) xp = sqr(xp);
-#pragma unroll
-        for (int l = 0; l < 8; ++l) { xpw[l] = xp.v; xp = sqr(xp); }
-    }
+    sc[t] = acc.v;   // P_t(y) = sum_j c[base + 256 j] y^j; the tile's value is sum_t x^t P_t(y)
     __syncthreads();
+    // pairwise: left + right * x^span
     int lvl = 0;
     for (uint32_t span = 1; span < PO_BLOCK; span <<= 1, ++lvl) {
         if ((t & (2 * span - 1)) == 0) sc[t] = (el<Fr, 4 * U>(sc[t]) + el<Fr, 4 * U>(sc[t + span]) * el2<Fr>(xpw[lvl])).v;   // < 4p + 2p: contract below
