@@ -283,7 +283,7 @@ struct RotSet {
     std::vector<uint32_t> points;                 // indices into the unique point list, ascending by field value
     std::vector<uint32_t> commits;                // polynomial indices, query order
     std::vector<std::vector<HF>> evals;           // [commit][point]
-    std::vector<std::vector<HF>> interp;          // [commit][degree]: the low-degree equivalent R_ij
+    std::vector<HF> low;                          // [degree]: R_i(X) = sum_j y^j R_ij(X), the set's combined low-degree equivalent
     std::vector<HF> inv_den;                      // 1 / prod_{s != r} (r - s) per point
 };
 }  // namespace
@@ -384,11 +384,9 @@ int zk::shplonk_open(zkhip_ctx* ctx, const zkhip_srs* srs, size_t n, const void*
         size_t o = 0;
         for (auto& rs : sets) { rs.inv_den.assign(dens.begin() + o, dens.begin() + o + rs.points.size()); o += rs.points.size(); }
     }
-    size_t total_roots = 0;
-    for (auto& rs : sets) total_roots += rs.points.size();
     void *d_num, *d_quot, *d_hx, *d_lx, *d_com;
     ZK_TRY(ctx->get_scratch("sp_num", nsets * n * 32, &d_num));
-    ZK_TRY(ctx->get_scratch("sp_quot", total_roots * n * 32, &d_quot));
+    ZK_TRY(ctx->get_scratch("sp_quot", (size_t)np * n * 32, &d_quot));
     ZK_TRY(ctx->get_scratch("sp_hx", n * 32, &d_hx));
     ZK_TRY(ctx->get_scratch("sp_lx", n * 32, &d_lx));
     ZK_TRY(ctx->get_scratch("sp_com", 96, &d_com));
@@ -418,7 +416,6 @@ int zk::shplonk_open(zkhip_ctx* ctx, const zkhip_srs* srs, size_t n, const void*
             for (size_t i = 0; i < m; ++i)
                 for (size_t d = 0; d < m; ++d) r[d] = hadd(r[d], hmul(rs.evals[ci][i], basis[i][d]));
             for (size_t d = 0; d < m; ++d) low[d] = hadd(low[d], hmul(yp, r[d]));
-            rs.interp.push_back(r);
             coeffs.push_back(hf_raw(yp));
             ptrs.push_back(d_polys[rs.commits[ci]]);
             yp = hmul(yp, y);
@@ -428,8 +425,14 @@ int zk::shplonk_open(zkhip_ctx* ctx, const zkhip_srs* srs, size_t n, const void*
         if (sharded && m > nl) { set_error("zkhip_shplonk_open: a rotation set of %zu points exceeds the rank's %zu rows", m, nl); return ZKHIP_EINVAL; }
         for (auto& q_ : ptrs) q_ = (const char*)q_ + lo_b;
         ZK_TRY(lincomb_raw(ctx, nl, ptrs.data(), ptrs.size(), coeffs.data(), low_abi.data(), lo == 0 ? m : 0, (char*)d_num + si * n * 32 + lo_b));
+        rs.low = low;
     }
-    // ---- all divisions in one pass (partial fractions), then h(X) = sum_i v^i sum_r Q_ir / prod_{s != r} (r - s)
+    // ---- h(X) = sum_i v^i g_i(X) / Z_i(X) by partial fractions, g_i = the set's numerator: sum_i v^i sum_{r in set i} w_ir g_i / (X - r).
+    // The division's quotient is LINEAR in its numerator, so the terms are grouped by ROOT (round 4; until then one division per (set, root)
+    // pair — 11 of them for the aggregation circuit's four sets over four points — and one 11-term combination):
+    //     h(X) = sum_r [ sum_{i : r in set i} v^i w_ir g_i(X) ] / (X - r)
+    // one division per DISTINCT point, all in one pass; a point of a single set divides that set's numerator directly and takes its
+    // weight in the final sum.
     std::vector<HF> vpow(nsets);
     {
         HF acc = hone();
@@ -438,20 +441,35 @@ int zk::shplonk_open(zkhip_ctx* ctx, const zkhip_srs* srs, size_t n, const void*
     {
         std::vector<KdEntry> ents;
         std::vector<fe32> weights;
-        std::vector<const void*> ptrs;
-        size_t o = 0;
-        for (size_t si = 0; si < nsets; ++si)
-            for (size_t i = 0; i < sets[si].points.size(); ++i, ++o) {
-                KdEntry e;
-                e.src = (const uint32_t*)((char*)d_num + si * n * 32 + lo_b);
-                e.dst = (uint32_t*)((char*)d_quot + o * n * 32 + lo_b);
-                e.r = hf_raw(upts[sets[si].points[i]]);
-                ents.push_back(e);
-                weights.push_back(hf_raw(hmul(vpow[si], sets[si].inv_den[i])));
-                ptrs.push_back(e.dst);
+        std::vector<const void*> quots;
+        for (uint32_t a = 0; a < np; ++a) {
+            std::vector<const void*> ptrs;
+            std::vector<fe32> cf;
+            HF w1 = hone();
+            for (size_t si = 0; si < nsets; ++si)
+                for (size_t i = 0; i < sets[si].points.size(); ++i)
+                    if (sets[si].points[i] == a) {
+                        ptrs.push_back((const char*)d_num + si * n * 32 + lo_b);
+                        w1 = hmul(vpow[si], sets[si].inv_den[i]);
+                        cf.push_back(hf_raw(w1));
+                    }
+            if (ptrs.empty()) continue;   // cannot happen: every unique point comes from a query
+            KdEntry e;
+            e.dst = (uint32_t*)((char*)d_quot + quots.size() * n * 32 + lo_b);
+            e.r = hf_raw(upts[a]);
+            if (ptrs.size() == 1) {
+                e.src = (const uint32_t*)ptrs[0];
+                weights.push_back(hf_raw(w1));
+            } else {
+                ZK_TRY(lincomb_raw(ctx, nl, ptrs.data(), ptrs.size(), cf.data(), nullptr, 0, e.dst));
+                e.src = e.dst;
+                weights.push_back(hf_raw(hone()));
             }
+            ents.push_back(e);
+            quots.push_back(e.dst);
+        }
         { ProfScope ps(ctx, "kate_division"); ZK_TRY(divide_round(ctx, nl, ents, sharded)); }
-        ZK_TRY(lincomb_raw(ctx, nl, ptrs.data(), ptrs.size(), weights.data(), nullptr, 0, (char*)d_hx + lo_b));
+        ZK_TRY(lincomb_raw(ctx, nl, quots.data(), quots.size(), weights.data(), nullptr, 0, (char*)d_hx + lo_b));
     }
     uint8_t bytes[32];
     {
@@ -480,26 +498,27 @@ int zk::shplonk_open(zkhip_ctx* ctx, const zkhip_srs* srs, size_t n, const void*
     hf_batch_invert(one_inv);
     const HF inv0 = one_inv[0];
     {
+        // sum_j y^j P_ij(X) = g_i(X) + R_i(X): the sets' numerators of the first round are still in d_num, so L(X) is a combination of
+        // nsets + 1 polynomials and a correction of max |set| low coefficients (until round 4: every queried polynomial read again)
         std::vector<fe32> coeffs;
         std::vector<const void*> ptrs;
-        HF konst = hzero();
+        size_t maxm = 1;
+        for (auto& rs : sets) maxm = std::max(maxm, rs.low.size());
+        std::vector<HF> lowv(maxm, hzero());   // out = sum c p - lowv: lowv[d] = sum_i scale_i ([d = 0] R_i(u) - R_i[d])
         for (size_t si = 0; si < nsets; ++si) {
-            HF yp = hone();
             const HF scale = hmul(hmul(vpow[si], zdiff[si]), inv0);
-            for (size_t ci = 0; ci < sets[si].commits.size(); ++ci) {
-                HF c = hmul(scale, yp);
-                HF ru = hzero();   // R_ij(u) by Horner
-                for (size_t d = sets[si].interp[ci].size(); d-- > 0;) ru = hadd(hmul(ru, u), sets[si].interp[ci][d]);
-                konst = hadd(konst, hmul(c, ru));
-                coeffs.push_back(hf_raw(c));
-                ptrs.push_back((const char*)d_polys[sets[si].commits[ci]] + lo_b);
-                yp = hmul(yp, y);
-            }
+            HF ru = hzero();   // R_i(u) by Horner
+            for (size_t d = sets[si].low.size(); d-- > 0;) ru = hadd(hmul(ru, u), sets[si].low[d]);
+            lowv[0] = hadd(lowv[0], hmul(scale, ru));
+            for (size_t d = 0; d < sets[si].low.size(); ++d) lowv[d] = hsub(lowv[d], hmul(scale, sets[si].low[d]));
+            coeffs.push_back(hf_raw(scale));
+            ptrs.push_back((const char*)d_num + si * n * 32 + lo_b);
         }
         coeffs.push_back(hf_raw(hsub(hzero(), hmul(zt, inv0))));
         ptrs.push_back((const char*)d_hx + lo_b);
-        fe32 low_abi = hf_abi(konst);
-        ZK_TRY(lincomb_raw(ctx, nl, ptrs.data(), ptrs.size(), coeffs.data(), &low_abi, lo == 0 ? 1 : 0, (char*)d_lx + lo_b));
+        std::vector<fe32> low_abi(maxm);
+        for (size_t d = 0; d < maxm; ++d) low_abi[d] = hf_abi(lowv[d]);
+        ZK_TRY(lincomb_raw(ctx, nl, ptrs.data(), ptrs.size(), coeffs.data(), low_abi.data(), lo == 0 ? maxm : 0, (char*)d_lx + lo_b));
         std::vector<KdEntry> ents(1);
         ents[0].src = (const uint32_t*)((char*)d_lx + lo_b); ents[0].dst = (uint32_t*)((char*)d_lx + lo_b); ents[0].r = hf_raw(u);
         { ProfScope ps(ctx, "kate_division"); ZK_TRY(divide_round(ctx, nl, ents, sharded)); }
