@@ -10,6 +10,8 @@
 //   * kate division by (X - r): q[j] = s[j+1], s[j] = a[j] + r s[j+1] is a suffix scan of affine maps with constant
 //     slope, done in three launches (tile totals, scan of the totals, rescan with carries); several polynomials, each
 //     with its own root, go through one launch (grid.y).
+//   * the multi-open divides once per DISTINCT opening point, not once per (rotation set, point): the quotient is linear in the
+//     numerator, so the sets' partial fractions are regrouped by root (zk::shplonk_open).
 #include <algorithm>
 #include <vector>
 
