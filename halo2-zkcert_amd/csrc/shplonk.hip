@@ -67,26 +67,27 @@ struct KdEntry {
     const uint32_t* src;
     uint32_t* dst;   // may equal src
     fe32 r;          // root, R' form canonical
+    fe32 r_per;      // r^SP_PER and r^SP_TILE, same form: filled in by divide_round on the host (16 host products) — on the device they
+    fe32 r_tile;     // were 4 / 12 dependent squarings at the head of every workgroup: pure latency at 2^17, where a pass is ~40 products deep
 };
 struct KdArgs { KdEntry e[KD_MAX]; };
 
-// suffix scan over the 256 per-thread values in LDS: S_t = sum_{q >= t} m^(q - t) A_q, m = the slope of one thread's span.
-// The eight slopes m^(2^level) are the same for every thread: thread 0 squares them once into LDS (mp) instead of 256 threads
-// squaring along (8 of the ~16 products a thread spends on the scan).  Callers synchronise after sc[] is written; the first barrier
-// below also publishes mp.
-__device__ __forceinline__ void suffix_scan_256(fe* sc, fe* mp, uint32_t t, el2<Fr> m) {
-    if (t == 0) {
-#pragma unroll
-        for (int l = 0; l < 8; ++l) { mp[l] = m.v; m = sqr(m); }
-    }
+// suffix scan over the 256 per-thread values in LDS: S_t = sum_{q >= t} m^(q - t) A_q, m = the slope of one thread's span (the same
+// in every thread).  Level l needs m^(2^l): the LAST thread, which has no partner in any level, squares the next level's slope while the
+// others do their product — one product per thread and level, none of them ahead of the scan (until round 4 thread 0 squared all eight
+// before the first level: 8 dependent products with 255 threads waiting).  The first barrier below orders the callers' sc[] writes too.
+__device__ __forceinline__ void suffix_scan_256(fe* sc, fe* mp, uint32_t t, const el2<Fr>& m) {
+    if (t == SP_BLOCK - 1) mp[0] = m.v;
     __syncthreads();
     int l = 0;
     for (uint32_t d = 1; d < SP_BLOCK; d <<= 1, ++l) {
         bool on = t + d < SP_BLOCK;
         fe mine = sc[t];
         fe other = on ? sc[t + d] : fe_zero();
+        fe slope = mp[l];
         __syncthreads();
-        if (on) sc[t] = canonical(el1<Fr>(mine) + el1<Fr>(other) * el2<Fr>(mp[l])).v;
+        if (on) sc[t] = canonical(el1<Fr>(mine) + el1<Fr>(other) * el2<Fr>(slope)).v;
+        else if (t == SP_BLOCK - 1 && l < 7) mp[l + 1] = sqr(el2<Fr>(slope)).v;
         __syncthreads();
     }
 }
@@ -106,13 +107,8 @@ __global__ void __launch_bounds__(SP_BLOCK) k_kd_totals(const KdArgs K, size_t n
         s = s * r + aj;
     }
     sc[t] = canonical(s).v;
-    el2<Fr> m = r;
-    if (t == 0) {   // only the thread that fills the slope table needs r^SP_PER
-#pragma unroll
-        for (int q = 0; q < SP_PER_LOG; ++q) m = sqr(m);
-    }
     __shared__ fe mp[8];
-    suffix_scan_256(sc, mp, t, m);
+    suffix_scan_256(sc, mp, t, el2<Fr>(fe_split<0>(K.e[e].r_per)));
     if (t == 0) mem_store(tot_all + ((size_t)e * nblk + blockIdx.x) * 8, fe_pack(sc[0]));
 }
 // pass 2 (one block per entry): carry[entry][blk] = s at the first index of tile blk + 1 (exclusive suffix scan, slope r^2048)
@@ -123,8 +119,7 @@ __global__ void __launch_bounds__(SP_BLOCK) k_kd_carries(const KdArgs K, uint32_
     const uint32_t t = threadIdx.x, e = blockIdx.x;
     const uint32_t* tot = tot_all + (size_t)e * nblk * 8;
     uint32_t* carry = carry_all + (size_t)e * nblk * 8;
-    el2<Fr> M = el1<Fr>(fe_split<0>(K.e[e].r));
-    for (int q = 0; q < SP_TILE_LOG; ++q) M = sqr(M);   // r^SP_TILE
+    const el2<Fr> M(fe_split<0>(K.e[e].r_tile));   // r^SP_TILE
     const uint32_t c = (nblk + SP_BLOCK - 1) / SP_BLOCK;
     const uint32_t lo = min(nblk, t * c), hi = min(nblk, lo + c);
     el<Fr, 4 * U> s = zero<Fr>();
@@ -156,11 +151,7 @@ __global__ void __launch_bounds__(SP_BLOCK) k_kd_apply(const KdArgs K, size_t n,
         if (lo + j < n) v[j] = load_raw<Fr>(a + (lo + j) * 8);
         s = s * r + v[j];
     }
-    el2<Fr> m = r;
-    if (t == 0 || t == SP_BLOCK - 1) {   // r^SP_PER: the slope table's seed (thread 0) and the carry's weight (last thread)
-#pragma unroll
-        for (int q = 0; q < SP_PER_LOG; ++q) m = sqr(m);
-    }
+    const el2<Fr> m(fe_split<0>(K.e[e].r_per));   // r^SP_PER: the scan's slope and the weight of the tile's carry
     const el1<Fr> cb = load_raw<Fr>(carry_all + ((size_t)e * nblk + blockIdx.x) * 8);
     el1<Fr> agg = canonical(s);
     if (t == SP_BLOCK - 1) agg = canonical(agg + cb * m);   // the tile's carry enters above its last thread
@@ -212,7 +203,14 @@ static int divide_round(zkhip_ctx* ctx, size_t n, const std::vector<KdEntry>& en
         uint32_t cnt = (uint32_t)std::min<size_t>(KD_MAX, ents.size() - done);
         KdArgs K;
         memset(&K, 0, sizeof K);
-        for (uint32_t j = 0; j < cnt; ++j) K.e[j] = ents[done + j];
+        for (uint32_t j = 0; j < cnt; ++j) {
+            K.e[j] = ents[done + j];
+            HF rp = hf_from_fe32(to_abi(el1<Fr>(fe_split<0>(K.e[j].r))));
+            for (int q = 0; q < SP_PER_LOG; ++q) rp = hmul(rp, rp);
+            K.e[j].r_per = hf_raw(rp);
+            for (int q = SP_PER_LOG; q < SP_TILE_LOG; ++q) rp = hmul(rp, rp);
+            K.e[j].r_tile = hf_raw(rp);
+        }
         uint32_t* mine = sharded ? (uint32_t*)((char*)d_total + RK * KD_MAX * 32) : nullptr;
         hipLaunchKernelGGL(k_kd_totals, dim3(nblk, cnt), dim3(SP_BLOCK), 0, st, K, n, nblk, (uint32_t*)d_tot);
         hipLaunchKernelGGL(k_kd_carries, dim3(cnt), dim3(SP_BLOCK), 0, st, K, nblk, (const uint32_t*)d_tot, (uint32_t*)d_carry, mine);
