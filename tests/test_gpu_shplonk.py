@@ -132,10 +132,16 @@ def test_native_multiopen_golden(zk, oracle):
         assert zo.affine_to_ints(np.asarray(got[0]).reshape(1, 8))[0] == (H(exp[0]), H(exp[1]))
 
 
-def test_native_multiopen_many_rotations(zk, oracle):
+@pytest.mark.parametrize("rots_a,rots_b,n_sets,max_set,n_points", [
+    (list(range(-5, 7)), list(range(-6, 7)), 3, 13, 13),
+    # 21 distinct points: more than one launch batch of the per-point divisions (KD_MAX = 16); points of one set only and of several
+    (list(range(-9, 10)), [0, 1, 20, 21], 3, 19, 21),
+])
+def test_native_multiopen_many_rotations(zk, oracle, rots_a, rots_b, n_sets, max_set, n_points):
     """Rotation sets of 12 and 13 points (> 8: the zkevm SHA-256 bit circuit queries its bit columns at many rotations,
     /root/reference/src/sha256_bit_circuit.rs:51-56; upstream's SHPLONK has no limit): zkhip_shplonk_open == the Python SHPLONK on the
-    oracle backend (commitments h1, h2), and the verifier's equation under the SRS trapdoor holds."""
+    oracle backend (commitments h1, h2), and the verifier's equation under the SRS trapdoor holds.  The library divides once per
+    DISTINCT point (partial fractions regrouped by root); the Python SHPLONK and the oracle divide per (set, point) as upstream does."""
     import halo2_zkcert_amd.prover as pv
     import halo2_zkcert_amd.shplonk as sp
     import pyref
@@ -146,8 +152,6 @@ def test_native_multiopen_many_rotations(zk, oracle):
     k, n, s = 9, 1 << 9, 0x5EED1234
     omega = pow(pv.ROOT_OF_UNITY, 1 << (28 - k), R)
     x = 0x1234567890ABCDEF1234567890ABCDEF % R
-    rots_a = list(range(-5, 7))                  # 12 points
-    rots_b = list(range(-6, 7))                  # 13 points, a different set
     polys_h = [zo.synth_raw253(7800 + j, n) for j in range(4)]
     pt = lambda r_: x * pow(omega, r_ % (1 << k), R) % R
     queries = []
@@ -178,5 +182,5 @@ def test_native_multiopen_many_rotations(zk, oracle):
                 break
         else:
             sets.append({"points": pts, "commitments": [(pid, [ev[p_] for p_ in pts])]})
-    assert len(sets) == 3 and max(len(rs["points"]) for rs in sets) == 13
+    assert len(sets) == n_sets and max(len(rs["points"]) for rs in sets) == max_set and len(supers) == n_points
     assert pyref.shplonk_verify(commits, sets, supers, ch["shplonk_y"], ch["shplonk_v"], ch["shplonk_u"], aff(pr["h1"]), aff(pr["h2"]), s)
