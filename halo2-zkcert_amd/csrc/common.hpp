@@ -54,7 +54,7 @@ struct Scratch {
 // Tuning knobs: environment variables (ZKHIP_*) read ONCE when the context is created, or set afterwards with
 // zkhip_set_option — never looked up on the hot path.  0 / -1 = "use the measured default".
 struct zkhip_options {
-    int msm_c = 0, msm_seg = 0, msm_tailparts = 0, msm_ch = 0, msm_widetail = -1, msm_adaptive_l = 1, msm_debug = 0;
+    int msm_c = 0, msm_seg = 0, msm_tailparts = 0, msm_ch = 0, msm_widetail = -1, msm_tail2 = -1, msm_adaptive_l = 1, msm_debug = 0;
     int sort_hb = 0, sort_tile = 0, sort_one_atomic = 1, sort_copies = 0, sort_wide = -1;   // sort_wide: low-pass block shape (-1: 1024 threads x 8 pairs for 8192-pair tiles)
     int ntt_lds_pad = 0;   // analysis only: KiB of unused dynamic LDS added to every register-tiled NTT workgroup (fewer tiles per CU: the occupancy-vs-time curve)
     int ntt_smax = 0, ntt_r8 = 4, ntt_group = 0;   // ntt_r8: 0 stage-per-barrier, 1 8 per thread, 2 / 3 4 per thread on 2048 / 1024 tiles, 4 auto

@@ -173,7 +173,7 @@ namespace {
 struct OptName { const char* env; const char* name; int zkhip_options::*field; };
 const OptName OPTIONS[] = {
     {"ZKHIP_MSM_C", "msm_c", &zkhip_options::msm_c}, {"ZKHIP_MSM_SEG", "msm_seg", &zkhip_options::msm_seg},
-    {"ZKHIP_MSM_TAILPARTS", "msm_tailparts", &zkhip_options::msm_tailparts}, {"ZKHIP_MSM_CH", "msm_ch", &zkhip_options::msm_ch},
+    {"ZKHIP_MSM_TAILPARTS", "msm_tailparts", &zkhip_options::msm_tailparts}, {"ZKHIP_MSM_CH", "msm_ch", &zkhip_options::msm_ch}, {"ZKHIP_MSM_TAIL2", "msm_tail2", &zkhip_options::msm_tail2},
     {"ZKHIP_MSM_WIDETAIL", "msm_widetail", &zkhip_options::msm_widetail}, {"ZKHIP_MSM_ADAPTIVE_L", "msm_adaptive_l", &zkhip_options::msm_adaptive_l},
     {"ZKHIP_MSM_DEBUG", "msm_debug", &zkhip_options::msm_debug}, {"ZKHIP_SORT_HB", "sort_hb", &zkhip_options::sort_hb},
     {"ZKHIP_SORT_TILE", "sort_tile", &zkhip_options::sort_tile}, {"ZKHIP_SORT_ONE_ATOMIC", "sort_one_atomic", &zkhip_options::sort_one_atomic}, {"ZKHIP_SORT_WIDE", "sort_wide", &zkhip_options::sort_wide}, {"ZKHIP_SORT_COPIES", "sort_copies", &zkhip_options::sort_copies},

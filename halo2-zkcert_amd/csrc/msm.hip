@@ -739,8 +739,13 @@ __global__ void __launch_bounds__(256) k_accum_affine(const ColPtrs tables, cons
     uint32_t* out = partial_all + (size_t)col * partial_stride * PART_WORDS;
     uint32_t b = find_bucket(off, B, start);
     uint32_t bend = off[b + 1];
-    g1x acc = g1x_identity();
-    for (uint32_t j = start; j < end; ++j) {
+    // The lane's first entry STARTS its sum (every lane, the same iteration): until round 4 it was added to the identity — the whole
+    // 8M + 2S formula with its result replaced by the fix-up — one addition in L wasted: 1.6 % of the kernel at L = 64, 6 % at 16 and
+    // half of it for the two-entry lanes of sparse columns.  (A run that crosses a bucket boundary mid-lane still restarts from the identity:
+    // its lane would only wait for the others' addition.)
+    const uint32_t e0 = entries[start];
+    g1x acc = g1x_from_affine(g1a_load_raw_cneg(table + (size_t)(e0 & 0x7fffffffu) * 16, (e0 >> 31) != 0));
+    for (uint32_t j = start + 1; j < end; ++j) {
         if (j >= bend) {   // the run crosses into the next non-empty bucket
             g1x_store_loose(out + (size_t)(segoff[b] + t - off[b] / L) * PART_WORDS, acc);
             do { ++b; bend = off[b + 1]; } while (bend <= j);
@@ -912,16 +917,19 @@ __device__ __forceinline__ void block_tree_sum_t(g1x* sh, uint32_t lt, uint32_t 
 }
 // sum_{b} (b+1) * S_b over CH consecutive buckets per logical thread (running-sum trick + base * run), then a
 // tree over the block: one partial sum per block.
+// tot_all != null (two-level tail): chunk t's total T_t = sum of its buckets is STORED (tot_all[col][t], raw XYZZ) instead of being
+// multiplied by the chunk's base; k_chunk_totals sums t * T_t over the chunks with the same running-sum trick.
 template <int LANES>
 __global__ void __launch_bounds__(256) k_bucket_chunks(const uint32_t* part_all, size_t part_stride, const uint32_t* cnt_all,
                                                        const uint32_t* off_all, uint32_t B, uint32_t CH, uint32_t* out_all,
-                                                       uint32_t nchunks) {
+                                                       uint32_t nchunks, uint32_t* tot_all) {
     constexpr uint32_t PER_BLOCK = 256 / LANES;
     __shared__ g1x sh[PER_BLOCK];
     const uint32_t col = blockIdx.y, q = threadIdx.x % LANES, lt = threadIdx.x / LANES;
     const uint32_t t = blockIdx.x * PER_BLOCK + lt;
     g1x acc = g1x_identity();
     if (t < nchunks) {
+        g1x total = g1x_identity();
         const uint32_t* cnt = cnt_all + (size_t)col * B;
         const uint32_t* off = off_all + (size_t)col * (B + 4);
         const uint32_t* part = part_all + (size_t)col * part_stride * PART_WORDS;
@@ -940,25 +948,73 @@ __global__ void __launch_bounds__(256) k_bucket_chunks(const uint32_t* part_all,
                 }
                 if (have) acc = tail_add<LANES>(acc, run, q);
             }
-            // + base * run
-            g1x d = run;
-            uint32_t m = base;
-            while (m) {
-                if (m & 1) acc = tail_add<LANES>(acc, d, q);
-                m >>= 1;
-                if (m) d = tail_double<LANES>(d, q);
+            if (tot_all) {
+                total = run;
+            } else {   // + base * run
+                g1x d = run;
+                uint32_t m = base;
+                while (m) {
+                    if (m & 1) acc = tail_add<LANES>(acc, d, q);
+                    m >>= 1;
+                    if (m) d = tail_double<LANES>(d, q);
+                }
             }
+        }
+        if (tot_all && q == 0) g1x_store_raw(tot_all + ((size_t)col * nchunks + t) * 32, total);
+    }
+    block_tree_sum_t<LANES>(sh, lt, q, acc);
+    if (threadIdx.x == 0) g1x_store_raw(out_all + ((size_t)col * gridDim.x + blockIdx.x) * 32, sh[0]);
+}
+// Second level of the tail: sum_t t * T_t over the chunk totals, CH2 consecutive chunks per logical thread — the running sums give
+// sum_j j * T_(base + j), the super-chunk's base is applied by double-and-add to ITS total: nchunks / CH2 of those products instead of one
+// per chunk (a quarter of the one-level tail's additions at CH = 32, half of them at CH = 4-8).  One partial sum per block.
+template <int LANES>
+__global__ void __launch_bounds__(256) k_chunk_totals(const uint32_t* tot_all, uint32_t nchunks, uint32_t CH2, uint32_t* out_all, uint32_t nsuper) {
+    constexpr uint32_t PER_BLOCK = 256 / LANES;
+    __shared__ g1x sh[PER_BLOCK];
+    const uint32_t col = blockIdx.y, q = threadIdx.x % LANES, lt = threadIdx.x / LANES;
+    const uint32_t s = blockIdx.x * PER_BLOCK + lt;
+    g1x acc = g1x_identity();
+    if (s < nsuper) {
+        const uint32_t* tot = tot_all + (size_t)col * nchunks * 32;
+        const uint32_t base = s * CH2;
+        g1x run = g1x_identity();
+        for (int j = (int)CH2 - 1; j >= 0; --j) {
+            const uint32_t t = base + (uint32_t)j;
+            if (t < nchunks) run = tail_add<LANES>(run, g1x_load_raw(tot + (size_t)t * 32), q);
+            if (j >= 1) acc = tail_add<LANES>(acc, run, q);
+        }
+        g1x d = run;
+        uint32_t m = base;
+        while (m) {
+            if (m & 1) acc = tail_add<LANES>(acc, d, q);
+            m >>= 1;
+            if (m) d = tail_double<LANES>(d, q);
         }
     }
     block_tree_sum_t<LANES>(sh, lt, q, acc);
     if (threadIdx.x == 0) g1x_store_raw(out_all + ((size_t)col * gridDim.x + blockIdx.x) * 32, sh[0]);
 }
 
-__global__ void __launch_bounds__(256) k_final_sum(const uint32_t* in_all, uint32_t count, uint32_t* out_all) {
+// in2_all != null (two-level tail): out = sum(in) + 2^shift * sum(in2) — the chunk totals' weighted sum, times the chunk length
+__global__ void __launch_bounds__(256) k_final_sum(const uint32_t* in_all, uint32_t count, uint32_t* out_all, const uint32_t* in2_all, uint32_t count2,
+                                                   uint32_t shift) {
     __shared__ g1x sh[64];
     const uint32_t col = blockIdx.x, q = threadIdx.x & 3, lt = threadIdx.x >> 2;
+    g1x second = g1x_identity();
+    if (in2_all) {
+        const uint32_t* in2 = in2_all + (size_t)col * count2 * 32;
+        g1x acc2 = g1x_identity();
+        for (uint32_t i = lt; i < count2; i += 64) acc2 = g1x_add_q4(acc2, g1x_load_raw(in2 + (size_t)i * 32), q);
+        block_tree_sum_t<4>(sh, lt, q, acc2);
+        if (lt == 0) {
+            second = sh[0];
+            for (uint32_t j = 0; j < shift; ++j) second = g1x_double_q4(second, q);
+        }
+        __syncthreads();   // sh[0] is read above and rewritten by the tree below
+    }
     const uint32_t* in = in_all + (size_t)col * count * 32;
-    g1x acc = g1x_identity();
+    g1x acc = lt == 0 ? second : g1x_identity();
     for (uint32_t i = lt; i < count; i += 64) acc = g1x_add_q4(acc, g1x_load_raw(in + (size_t)i * 32), q);
     block_tree_sum_t<4>(sh, lt, q, acc);
     if (threadIdx.x == 0) g1j_store_abi(out_all + (size_t)col * 24, g1x_to_jacobian(sh[0]));   // the ABI result: halo2curves G1 (R = 2^256)
@@ -992,6 +1048,7 @@ __global__ void k_set_identity(uint32_t* out_all, uint32_t ncols) {
 }
 
 // ------------------------------------------------------------------ host driver
+static uint32_t ilog2_u32(uint32_t v) { uint32_t l = 0; while ((1u << (l + 1)) <= v) ++l; return l; }
 // columns hold at least first + n scalars; scalar first + i pairs with base first + i (indices LOCAL to the handles' tables).
 static int msm_local(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const void* const* d_cols_host, size_t ncols, size_t first, size_t n,
                      void* d_out) {
@@ -1081,6 +1138,21 @@ static int msm_local(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const 
     if (ctx->opt.msm_widetail >= 0) wide_tail = ctx->opt.msm_widetail != 0;
     uint32_t nchunk_blocks = div_up(nchunks, wide_tail ? 256 : 64);
     ZK_TRY(ctx->get_scratch("msm_chunks", ncols * (size_t)nchunk_blocks * 128, &d_chunks));
+    // Two-level tail (round 4): the chunks' bases are applied to the chunk TOTALS by a second running-sum pass instead of one double-and-add
+    // per chunk (~21 of a chunk's 2 CH + 21 point operations).  It removes work, not depth — it adds a launch — so it is for the wide
+    // batches, whose tail runs beside the other stream's transforms; the one- and two-column MSMs of the multi-open run alone and keep
+    // the shorter one-level chain.
+    const uint32_t CH2 = 8;
+    bool two_level = wide_tail && nchunks >= 4096 && (CH & (CH - 1)) == 0;
+    if (ctx->opt.msm_tail2 >= 0) two_level = ctx->opt.msm_tail2 != 0 && nchunks >= 2 * CH2 && (CH & (CH - 1)) == 0;
+    const uint32_t nsuper = div_up(nchunks, CH2);
+    const bool wide2 = (size_t)nsuper * ncols >= (size_t)48 * 1024;
+    const uint32_t nblk2 = div_up(nsuper, wide2 ? 256 : 64);
+    void *d_tot = nullptr, *d_chunks2 = nullptr;
+    if (two_level) {
+        ZK_TRY(ctx->get_scratch("msm_tot", ncols * (size_t)nchunks * 128, &d_tot));
+        ZK_TRY(ctx->get_scratch("msm_chunks2", ncols * (size_t)nblk2 * 128, &d_chunks2));
+    }
 
     std::vector<const void*> h_ptrs(2 * ncols);
     for (size_t j = 0; j < ncols; ++j) { h_ptrs[j] = d_cols_host[j]; h_ptrs[ncols + j] = srs_per_col[j]->d_table; }
@@ -1244,11 +1316,18 @@ static int msm_local(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const 
     { ProfScope ps(ctx, "msm_tail");
     if (wide_tail)
         hipLaunchKernelGGL(k_bucket_chunks<1>, dim3(nchunk_blocks, (unsigned)ncols), dim3(256), 0, st, (const uint32_t*)cur_p, pstride0,
-                           cur_cnt, cur_off, B, CH, (uint32_t*)d_chunks, nchunks);
+                           cur_cnt, cur_off, B, CH, (uint32_t*)d_chunks, nchunks, (uint32_t*)d_tot);
     else
         hipLaunchKernelGGL(k_bucket_chunks<4>, dim3(nchunk_blocks, (unsigned)ncols), dim3(256), 0, st, (const uint32_t*)cur_p, pstride0,
-                           cur_cnt, cur_off, B, CH, (uint32_t*)d_chunks, nchunks);
-    hipLaunchKernelGGL(k_final_sum, dim3((unsigned)ncols), dim3(256), 0, st, (const uint32_t*)d_chunks, nchunk_blocks, (uint32_t*)d_out); }
+                           cur_cnt, cur_off, B, CH, (uint32_t*)d_chunks, nchunks, (uint32_t*)d_tot);
+    if (two_level) {
+        if (wide2)
+            hipLaunchKernelGGL(k_chunk_totals<1>, dim3(nblk2, (unsigned)ncols), dim3(256), 0, st, (const uint32_t*)d_tot, nchunks, CH2, (uint32_t*)d_chunks2, nsuper);
+        else
+            hipLaunchKernelGGL(k_chunk_totals<4>, dim3(nblk2, (unsigned)ncols), dim3(256), 0, st, (const uint32_t*)d_tot, nchunks, CH2, (uint32_t*)d_chunks2, nsuper);
+    }
+    hipLaunchKernelGGL(k_final_sum, dim3((unsigned)ncols), dim3(256), 0, st, (const uint32_t*)d_chunks, nchunk_blocks, (uint32_t*)d_out,
+                       (const uint32_t*)d_chunks2, nblk2, ilog2_u32(CH)); }
     ZK_LAUNCH_CHECK();
     return ZKHIP_OK;
 }

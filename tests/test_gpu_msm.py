@@ -142,6 +142,29 @@ def test_commit_batch_device(zk, oracle, params12):
         assert (ffi.g1_to_affine(out[j]) == exp).all()
 
 
+@pytest.mark.parametrize("tail2", [0, 1])
+def test_commit_batch_both_tail_forms(zk, oracle, params12, tail2):
+    """The tail's two forms — the chunk's base applied per chunk, or to the chunk totals by a second running-sum pass (k_chunk_totals;
+    the default only for wide batches at >= 4096 chunks) — forced in turn on a batch with a zero column, a skewed one and ragged lengths."""
+    ffi, ctx = zk
+    zo = oracle
+    p, _ = params12
+    ctx.set_option("msm_tail2", tail2)
+    try:
+        for n in (4096, 1000):
+            cols_h = [zo.synth_raw253(900 + j + n, n) for j in range(2)]
+            cols_h.append(np.zeros((n, 4), dtype=np.uint64))
+            ones = np.zeros((n, 4), dtype=np.uint64)
+            ones[:, 0] = 1                                    # every scalar the same small Montgomery-form value: one bucket takes a whole window
+            cols_h.append(ones)
+            out = ctx.to_host(p.commit_batch_device([ctx.to_device(c) for c in cols_h], lagrange=True))
+            bases = p.read_bases(p.g_lagrange, 0, n)
+            for j, c in enumerate(cols_h):
+                assert (ffi.g1_to_affine(out[j]) == zo.g1_to_affine(zo.best_multiexp(c, bases, 8))).all(), (tail2, n, j)
+    finally:
+        ctx.set_option("msm_tail2", -1)
+
+
 def test_commit_lagrange_equals_commit_coeff_equals_trapdoor(zk, oracle, params12):
     """commit_lagrange(evals) == commit(iNTT(evals)) == [p(s)] G — ties MSM, NTT and the SRS together."""
     ffi, ctx = zk
