@@ -658,7 +658,7 @@ def worker(args):
                                                      "peak_source": "SELF-MEASURED, not a vendor figure: tools/microbench (dense v_mad_u64_u32 loop, ILP 8, 8 waves per SIMD) = "
                                                                     "29.87 Tmad/s in profiles/r02_microbench_gfx950.txt:20 (5.27 cycles per wave-instruction per SIMD; "
                                                                     "4.6 by profiles/r04_clock_probe_gfx950.txt at the sustained 2.37 GHz)"},
-                                    "note": "VALU-issue (integer multiply) bound: valu_busy 0.89-0.99 in profiles/r04_v6_valu_*.csv; the window tables trade HBM bytes for doublings (counted traffic 6-18x the algorithmic bytes): see DESIGN.md 5"}
+                                    "note": "VALU-issue (integer multiply) bound: valu_busy 0.89-0.99 in profiles/r04_v7_valu_*.csv; the window tables trade HBM bytes for doublings (counted traffic 6-18x the algorithmic bytes): see DESIGN.md 5"}
         # NTT: 64 B per element per transform (one read + one write), whatever the number of passes.  Isolated batch of 8 coset NTTs
         # (coeff_to_extended: n -> extended_n) — the shape the proof issues
         ntt_ms = kernels["ntt_strided"]["ms_per_step"] + kernels["ntt_final"]["ms_per_step"]
@@ -676,7 +676,7 @@ def worker(args):
                            "in_proof_ms_per_step": round(ntt_ms, 3),
                            "transforms_per_step": counts["intt_n"] + counts["ntt_ext"] * (coset_q or 1) + counts["intt_ext"] * (coset_q or 1),
                            "note": "algorithmic = 64 B per element per transform; a transform of 2^m elements is ceil(m / 9) launches; VALU-issue bound "
-                                   "(4 elements per thread, four waves per SIMD; valu_busy in profiles/r04_v6_valu_*.csv; the memory side alone is 0.6 of the time and the two overlap imperfectly: profiles/r03_ntt_experiments.md), not HBM bound; in-proof spans overlap the MSM phases"}
+                                   "(4 elements per thread, four waves per SIMD; valu_busy in profiles/r04_v7_valu_*.csv; the memory side alone is 0.6 of the time and the two overlap imperfectly: profiles/r03_ntt_experiments.md), not HBM bound; in-proof spans overlap the MSM phases"}
         # sweep: 32 B x (distinct (column, rotation) reads + 1 write) per extended row
         sw = kernels["sweep"]
         if sw["ms_per_step"] > 0 and not shard:
