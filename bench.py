@@ -131,21 +131,47 @@ def pmc_traffic(config, bh):
     return out, os.path.relpath(best[0], ROOT)
 
 
-def cpu_pass_seconds(pv, shape, transcript, threads, repeats=3, warm=True):
-    """median of `repeats` full passes of the same schedule on the CPU oracle (oracle/zkoracle.c, OpenMP), after one warm-up pass"""
+CPU_PROOFS = []     # every proof the CPU leg made in this process: dict(shape, k, transcript, witness, proof_sha256, proof_bytes)
+
+
+def cpu_pass_seconds(pv, shape, transcript, threads, repeats=3, warm=True, witness_seed=0):
+    """median of `repeats` full passes of the same schedule on the CPU oracle (oracle/zkoracle.c, OpenMP), after one warm-up pass.
+    The oracle proves the SAME instance as the GPU leg (same shape -> same key, witness(witness_seed), same blinding seeds, same transcript):
+    the sha256 of its proof bytes is recorded in CPU_PROOFS so the line can say whether the GPU's bytes equal them (parity_check())."""
     sys.path[:0] = [p for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")) if p not in sys.path]
     from oracle_backend import OracleBackend
 
     p = pv.Prover(OracleBackend(threads), shape, satisfiable=True)
-    w = p.witness(0)
+    w = p.witness(witness_seed)
     if warm:
         p.prove(w, transcript=transcript)
-    ts = []
+    ts, digests = [], set()
     for _ in range(repeats):
         t0 = time.perf_counter()
-        p.prove(w, transcript=transcript)
+        pf = bytes(p.prove(w, transcript=transcript)["proof"])
         ts.append(time.perf_counter() - t0)
+        digests.add(hashlib.sha256(pf).hexdigest())
+    if len(digests) != 1:
+        raise RuntimeError(f"the CPU oracle's proof of {shape.name} is not deterministic: {sorted(digests)}")
+    CPU_PROOFS.append(dict(shape=shape.name, k=shape.k, transcript=transcript, witness=witness_seed, proof_sha256=digests.pop(), proof_bytes=len(pf)))
     return statistics.median(ts), ts
+
+
+def parity_check(gpu_proofs, cpu_proofs=None):
+    """north_star: "proof bytes bit-identical to the reference CPU prover on the same SRS and witness".  gpu_proofs: [dict(shape, k, transcript,
+    witness, proof_sha256, ...)] made by the HIP path in this run; every one whose (shape, transcript, witness) the CPU oracle also proved is
+    compared by digest.  -> dict(compared=[...], bytes_equal=True / False / None (nothing comparable))"""
+    cpu = {(c["shape"], c["transcript"], c["witness"]): c for c in (CPU_PROOFS if cpu_proofs is None else cpu_proofs)}
+    rows = []
+    for g in gpu_proofs:
+        c = cpu.get((g["shape"], g["transcript"], g["witness"]))
+        if c is None:
+            continue
+        rows.append(dict(shape=g["shape"], k=g["k"], transcript=g["transcript"], witness=g["witness"], where=g.get("where"), proof_bytes=c["proof_bytes"],
+                         gpu_sha256=g["proof_sha256"], cpu_sha256=c["proof_sha256"], equal=g["proof_sha256"] == c["proof_sha256"]))
+    return dict(compared=rows, bytes_equal=(all(r["equal"] for r in rows) if rows else None),
+                note="sha256 of the HIP path's proof bytes against the CPU oracle's (oracle/zkoracle.c through tests/oracle_backend.py) on the same "
+                     "key, witness, blinding draws and transcript; a mismatch makes bench.py exit non-zero")
 
 
 def recorded_cpu_k22():
@@ -209,10 +235,11 @@ def cpu_baseline(pv, args, config, head_k, transcript):
         out = dict(value=round(med, 4), unit="s", cores=threads, kind="port", measured_s=round(med, 4), scale=1.0,
                    sample=f"{sh.name}: median of 3 full passes after a warm-up ({', '.join(f'{t:.3f}' for t in ts)}); "
                           "oracle/zkoracle.c with OpenMP, SRS / keygen excluded")
+    out["proof_k"], out["proof_sha256"] = CPU_PROOFS[-1]["k"], CPU_PROOFS[-1]["proof_sha256"]     # the pass that was timed last = the measured size
     rsa = None
     if config != "rsa17" and not args.no_other_configs and args.gpus == 1 and not args.chain:
         med17, ts17 = cpu_pass_seconds(pv, pv.CircuitShape.rsa(17), "poseidon", threads)
-        rsa = dict(value=round(med17, 4), unit="s", cores=threads, kind="port",
+        rsa = dict(value=round(med17, 4), unit="s", cores=threads, kind="port", proof_k=17, proof_sha256=CPU_PROOFS[-1]["proof_sha256"],
                    sample=f"rsa_k17: median of 3 full passes after a warm-up ({', '.join(f'{t:.3f}' for t in ts17)})")
     return out, rsa
 
@@ -222,11 +249,26 @@ def chain_cpu_baseline(pv, args):
     pass of the SHA-shaped k = 19 proof, and the aggregation proof as cpu_baseline() samples it; value = 2 x rsa + 2 x sha + agg."""
     threads = host_threads()
     agg, _ = cpu_baseline(pv, args, "agg22", args.agg_k, "evm")
-    med17, _ = cpu_pass_seconds(pv, pv.CircuitShape.rsa(17), "poseidon", threads)
-    t19, _ = cpu_pass_seconds(pv, make_shape(pv, "sha19", args), "poseidon", threads, repeats=1, warm=False)
+    med17, _ = cpu_pass_seconds(pv, pv.CircuitShape.rsa(17), "poseidon", threads)                                           # leaf 0's instance (witness 0)
+    t19, _ = cpu_pass_seconds(pv, make_shape(pv, "sha19", args), "poseidon", threads, repeats=1, warm=False, witness_seed=1)   # leaf 1's instance (witness 1)
     return dict(value=round(2 * med17 + 2 * t19 + agg["value"], 4), unit="s", cores=threads, kind="port",
                 sample=f"2 x rsa_k17 ({med17:.3f} s, median of 3) + 2 x sha256_k19 ({t19:.3f} s, one pass) + the aggregation proof ({agg['value']:.3f} s: {agg['sample']})",
                 parts=dict(rsa17_s=round(med17, 4), sha19_s=round(t19, 4), agg=agg))
+
+
+def finish_parity(out):
+    """out["parity"] = every HIP-path proof of the line (out["gpu_proofs"]) against the CPU leg's digests; cpu_baseline.bytes_equal = the row of
+    the CPU pass that was timed (the headline size with --cpu-baseline-k 22, else the parity sample's size)"""
+    out["parity"] = parity_check(out.get("gpu_proofs") or [])
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict) and cb.get("proof_sha256"):
+        rows = [r for r in out["parity"]["compared"] if r["cpu_sha256"] == cb["proof_sha256"]]
+        cb["bytes_equal"] = all(r["equal"] for r in rows) if rows else None
+    for name, c in (out.get("configs") or {}).items():
+        cb_ = c.get("cpu_baseline") if isinstance(c, dict) else None
+        if isinstance(cb_, dict) and cb_.get("proof_sha256") and c.get("proof_sha256"):
+            cb_["bytes_equal"] = cb_["proof_sha256"] == c["proof_sha256"]
+    return out["parity"]["bytes_equal"]
 
 
 LADDER = {
@@ -389,9 +431,13 @@ def supervise(args):
                     try:
                         import halo2_zkcert_amd.prover as pv
                         out["cpu_baseline"] = chain_cpu_baseline(pv, args) if args.chain else cpu_baseline(pv, args, args.config, out["config"].get("k", args.agg_k), out["config"].get("transcript", TRANSCRIPT[args.config]))[0]
+                        finish_parity(out)
                     except Exception as e:   # noqa: BLE001 — the GPU measurement stands on its own
                         out["cpu_baseline"] = dict(error=str(e)[:300])
                 print(json.dumps(out), flush=True)
+                if isinstance(out.get("parity"), dict) and out["parity"].get("bytes_equal") is False:
+                    print("bench.py: PARITY FAILURE: a HIP-path proof differs from the CPU oracle's: " + json.dumps([r for r in out["parity"]["compared"] if not r["equal"]]), file=sys.stderr, flush=True)
+                    return 3
             return 0
         whys = []
         if rank == 0:
@@ -509,6 +555,11 @@ def worker(args):
         if info["nranks"] != world or info["transport_ranks"] not in (world, -1):
             raise SystemExit(f"bench.py: the library's communicator reports {info} for WORLD_SIZE {world}")
     bh = build_hash()
+    gpu_proofs = []     # every distinct proof the HIP path made: what parity_check() compares with the CPU oracle's digests
+
+    def note_proof(shape, kind, wseed, proof, where):
+        gpu_proofs.append(dict(shape=shape.name, k=shape.k, transcript=kind, witness=wseed, where=where, proof_bytes=len(proof),
+                               proof_sha256=hashlib.sha256(bytes(proof)).hexdigest()))
 
     def barrier():
         if world > 1:
@@ -543,7 +594,8 @@ def worker(args):
         t0 = time.perf_counter()
         backend = pv.GpuBackend(ctx, ffi)
         prover = pv.Prover(backend, shape, satisfiable=True)
-        wit = prover.witness(0 if (shard or world == 1) else rank, dist=witness)
+        wseed = 0 if (shard or world == 1) else rank
+        wit = prover.witness(wseed, dist=witness)
         torch.cuda.synchronize()
         setup_s = time.perf_counter() - t0
         n = 1 << shape.k
@@ -706,6 +758,7 @@ def worker(args):
                "traffic_source": traffic_file, "with_h2d": h2d, "msm_shard": shard_mode,
                "first_proof_s": round(setup_s + first_s, 3), "comm": comm_fields(gathered, shard_mode, coll_per_proof),
                "native_call_ms_per_step": round(native_s * 1000.0 / steps, 3) if native_s else None}   # zkhip_create_proof_ex alone; ms_per_step also holds the ctypes wrapper around it
+        note_proof(shape, kind, wseed if witness == "uniform" else f"{witness}:{wseed}", trace.get("proof", b""), f"configs.{name}" + ("" if witness == "uniform" else f" ({witness} witness)"))
         prover.release()          # the context's per-key caches (coset-layout key columns, sorted lookup table)
         backend.params.free()
         del prover, wit, trace, backend
@@ -716,6 +769,32 @@ def worker(args):
         gc.collect()
         torch.cuda.empty_cache()
         return res, shape
+
+    def parity_sample(name, k_):
+        """ONE proof of the headline shape at the size the CPU leg's bounded sample is timed at (default k = 20 for the k = 22 headline): the
+        default line then carries a byte comparison with the CPU oracle on the full circuit shape, through the same (sharded, when N > 1)
+        path, without the two-minute CPU pass at k = 22.  Collective: every rank calls it."""
+        shape = make_shape(pv, name, argparse.Namespace(**{**vars(args), "agg_k": k_}))
+        if shard:
+            ctx.comm_shard(args.shard if args.shard != "auto" else ("points" if shape.k >= 20 else "columns"))
+        backend = pv.GpuBackend(ctx, ffi)
+        prover = pv.Prover(backend, shape, satisfiable=True)
+        wit = prover.witness(0)
+        t0 = time.perf_counter()
+        pf = bytes(prover.prove_native(wit, transcript=TRANSCRIPT[name])["proof"])
+        torch.cuda.synchronize()
+        first_ms = (time.perf_counter() - t0) * 1000.0
+        if bytes(prover.prove_native(wit, transcript=TRANSCRIPT[name])["proof"]) != pf:
+            raise SystemExit(f"bench.py: the k = {k_} parity sample's proof is not deterministic")
+        note_proof(shape, TRANSCRIPT[name], 0, pf, f"parity sample (the headline shape at the CPU sample's size, k = {k_})")
+        prover.release()
+        backend.params.free()
+        del prover, wit, backend
+        import gc
+
+        gc.collect()
+        torch.cuda.empty_cache()
+        return dict(k=k_, shape=shape.name, transcript=TRANSCRIPT[name], proof_bytes=len(pf), proof_sha256=gpu_proofs[-1]["proof_sha256"], first_proof_ms=round(first_ms, 2))
 
     def run_chain(steps, warmup):
         """BASELINE configs[4] (/root/reference/src/tests/x509_aggregation.rs:20-110): four independent leaf proofs (rsa, sha, rsa, sha), a
@@ -732,7 +811,8 @@ def worker(args):
         for j, nm in enumerate(mine):
             sh_ = make_shape(pv, nm, args)
             pr_ = pv.Prover(pv.GpuBackend(leaf_ctx, ffi), sh_, satisfiable=True)
-            leaves.append((pr_, pr_.witness(j if world == 1 else rank), TRANSCRIPT[nm]))
+            ws_ = j if world == 1 else rank
+            leaves.append((pr_, dict(pr_.witness(ws_), seed=ws_), TRANSCRIPT[nm]))
             pairs += sh_.counts(pr_.dom.extended_k)["msm"] * float(1 << sh_.k)
         if shard:
             ctx.comm_shard("points" if args.shard == "auto" else args.shard)
@@ -742,19 +822,21 @@ def worker(args):
             agg = pv.Prover(pv.GpuBackend(ctx, ffi), agg_shape, satisfiable=True)
             agg_w = agg.witness(0)
             pairs += agg_shape.counts(agg.dom.extended_k)["msm"] * float(1 << agg_shape.k) / (world if shard else 1)
-        sizes, digests = [], []
+        sizes, digests, last = [], [], []
 
         def chain_step():
-            del sizes[:], digests[:]
+            del sizes[:], digests[:], last[:]
             for pr_, w_, kind_ in leaves:
                 pf_ = bytes(pr_.prove_native(w_, transcript=kind_)["proof"])
                 sizes.append(len(pf_))
                 digests.append(hashlib.sha256(pf_).hexdigest())
+                last.append((pr_.shape, kind_, w_["seed"], pf_, f"chain leaf (witness {w_['seed']})"))
             barrier()
             if agg_here:
                 pf_ = bytes(agg.prove_native(agg_w, transcript="evm")["proof"])
                 sizes.append(len(pf_))
                 digests.append(hashlib.sha256(pf_).hexdigest())
+                last.append((agg.shape, "evm", 0, pf_, "chain aggregation proof"))
 
         for _ in range(warmup):
             chain_step()
@@ -803,6 +885,8 @@ def worker(args):
                "parallelism": par, "proof_bytes": list(sizes), "proof_sha256": list(digests), "roofline": roof,
                "bytes_gathered_per_step": (ctx.comm_bytes_gathered() - g0) // steps if shard else 0,
                "collectives_per_step": (ctx.comm_describe()["collectives"] - c0) / steps if shard else 0}
+        for item in last:
+            note_proof(*item)
         for pr_, _, _ in leaves:
             pr_.release()
             pr_.b.params.free()
@@ -826,16 +910,23 @@ def worker(args):
 
     if args.chain:
         res = run_chain(args.steps, args.warmup)
+        # one GPU: the five proofs in sequence, nothing scales (null); N >= 4: total work fixed while the aggregation proof is sharded ("strong");
+        # --agg-unsharded (last rung of the ladder): the aggregation proof on rank 0 alone — more GPUs do not shorten it ("none")
+        chain_scaling = None if world == 1 else ("strong" if shard else "none")
         if rank == 0:
-            cb = None
+            cb = parity = None
             if world == 1 and not args.no_cpu_baseline:      # N > 1: rank 0's GPU-free supervisor times it once the workers are gone
                 cb = chain_cpu_baseline(pv, args)
+                parity = parity_check(gpu_proofs)
             print(json.dumps({"metric": "create_proof wall-time (s): RSA k=17 / SHA256 k=19 / agg k=22 at 1/2/4/8 GPU", "value": res["value"], "unit": "s",
                               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": False,
-                              "scaling": "strong", "vs_baseline": None, "dtype": "u256 (BN254 Fr/Fq, Montgomery)", "data": "synthetic", "proofs_per_step": 5,
+                              "scaling": chain_scaling, "vs_baseline": None, "dtype": "u256 (BN254 Fr/Fq, Montgomery)", "data": "synthetic", "proofs_per_step": 5,
                               "config": {"workload": res["workload"], "parallelism": res["parallelism"], "k": args.agg_k, "transcript": "evm"}, "proof_bytes": res["proof_bytes"], "proof_sha256": res["proof_sha256"],
                               "comm": comm_fields(res["bytes_gathered_per_step"], "points" if args.shard == "auto" else args.shard, res["collectives_per_step"]),
-                              "roofline": res["roofline"], "cpu_baseline": cb, "build": bh}), flush=True)
+                              "roofline": res["roofline"], "cpu_baseline": cb, "gpu_proofs": gpu_proofs, "parity": parity, "build": bh}), flush=True)
+            if parity and parity["bytes_equal"] is False:
+                print("bench.py: PARITY FAILURE: a HIP-path proof differs from the CPU oracle's: " + json.dumps([r for r in parity["compared"] if not r["equal"]]), file=sys.stderr, flush=True)
+                sys.exit(3)
         teardown()
         return
 
@@ -864,12 +955,24 @@ def worker(args):
         except Exception as e:   # noqa: BLE001
             out_configs["chain"] = dict(error=str(e)[:300])
 
+    # the headline shape at the size the CPU leg's bounded sample runs at: a byte-compared full-shape proof in the default line
+    sample = None
+    k_cpu = max(19, min(head["k"], args.cpu_baseline_k))
+    if args.config == "agg22" and head["k"] > 18 and k_cpu != head["k"] and not args.no_cpu_baseline and not args.replicas:
+        try:
+            sample = parity_sample("agg22", k_cpu)
+        except SystemExit:
+            raise
+        except Exception as e:   # noqa: BLE001
+            if world > 1:
+                raise
+            sample = dict(error=str(e)[:300])
     if rank == 0:
         dom = head["rooflines"]["msm_accum_affine"]
         out = {
             "metric": "create_proof wall-time (s): RSA k=17 / SHA256 k=19 / agg k=22 at 1/2/4/8 GPU",
             "value": head["value"], "unit": "s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
-            "higher_is_better": False, "scaling": "strong" if shard else "weak", "vs_baseline": None,
+            "higher_is_better": False, "scaling": None if world == 1 else ("strong" if shard else "weak"), "vs_baseline": None,
             "proofs_per_step": 1 if (shard or world == 1) else world,
             "dtype": "u256 (BN254 Fr/Fq, Montgomery, 9 x 29-bit limbs in registers / 8 x u32 in HBM)", "data": "synthetic",
             "config": {"workload": head["workload"], "headline": args.config, "k": head["k"], "advice": head["advice"], "fixed": head["fixed"],
@@ -883,13 +986,21 @@ def worker(args):
             "comm": head["comm"],
             "setup_s": head["setup_s"], "first_proof_s": head["first_proof_s"], "resident_bytes": head["resident_bytes"], "with_h2d": head["with_h2d"],
         }
+        out["parity_sample"] = sample
+        out["gpu_proofs"] = gpu_proofs
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"], rsa_cb = cpu_baseline(pv, args, args.config, head["k"], head["transcript"])
             if rsa_cb and "rsa17" in out_configs and "error" not in out_configs["rsa17"]:
                 out_configs["rsa17"]["cpu_baseline"] = rsa_cb
+            finish_parity(out)
         else:
             out["cpu_baseline"] = None     # N > 1: the GPU-free supervisor of rank 0 times it once the workers are gone (supervise())
+            out["parity"] = None           # ... and compares the digests in gpu_proofs with the CPU oracle's
         print(json.dumps(out), flush=True)
+        if out["parity"] and out["parity"]["bytes_equal"] is False:
+            print("bench.py: PARITY FAILURE: a HIP-path proof differs from the CPU oracle's: " + json.dumps([r for r in out["parity"]["compared"] if not r["equal"]]), file=sys.stderr, flush=True)
+            teardown()
+            sys.exit(3)
     teardown()
 
 

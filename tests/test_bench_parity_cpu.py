@@ -1,0 +1,79 @@
+"""bench.py's byte comparison of the HIP path's proofs with the CPU oracle's (north_star: "proof bytes bit-identical to the reference CPU prover
+on the same SRS and witness"; the reference's proving calls: /root/reference/src/helpers.rs:233,299, src/bin/cli.rs:320,369,519).  CPU only:
+the digest bookkeeping, and the supervisor's exit code when a digest differs (stand-in worker, tests/fake_bench_worker.py)."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [p for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")) if p not in sys.path]
+
+
+def test_parity_check_rows():
+    import bench
+
+    cpu = [dict(shape="a", k=5, transcript="evm", witness=0, proof_sha256="11", proof_bytes=10),
+           dict(shape="b", k=6, transcript="poseidon", witness=1, proof_sha256="22", proof_bytes=12)]
+    g = lambda shape, kind, w, d: dict(shape=shape, k=5, transcript=kind, witness=w, proof_sha256=d, where="t")
+    ok = bench.parity_check([g("a", "evm", 0, "11"), g("b", "poseidon", 1, "22"), g("c", "evm", 0, "99")], cpu)
+    assert ok["bytes_equal"] is True and len(ok["compared"]) == 2                       # "c" has no CPU counterpart: not a row
+    assert bench.parity_check([g("a", "evm", 0, "12")], cpu)["bytes_equal"] is False
+    assert bench.parity_check([g("a", "evm", 1, "11"), g("a", "poseidon", 0, "11"), g("a", "evm", "survey:0", "11")], cpu)["bytes_equal"] is None
+    out = dict(gpu_proofs=[g("a", "evm", 0, "11")], cpu_baseline=dict(proof_sha256="11"), configs=dict(x=dict(proof_sha256="5", cpu_baseline=dict(proof_sha256="6"))))
+    bench.CPU_PROOFS[:] = cpu
+    try:
+        assert bench.finish_parity(out) is True and out["cpu_baseline"]["bytes_equal"] is True and out["configs"]["x"]["cpu_baseline"]["bytes_equal"] is False
+    finally:
+        bench.CPU_PROOFS[:] = []
+
+
+def test_cpu_pass_records_the_oracle_proof_digest():
+    import bench
+    import halo2_zkcert_amd.prover as pv
+    from oracle_backend import OracleBackend
+
+    sh = pv.CircuitShape.agg(7, 3, 1)
+    bench.CPU_PROOFS[:] = []
+    try:
+        bench.cpu_pass_seconds(pv, sh, "evm", 2, repeats=2, warm=False, witness_seed=1)
+        p = pv.Prover(OracleBackend(2), sh, satisfiable=True)
+        want = hashlib.sha256(bytes(p.prove(p.witness(1), transcript="evm")["proof"])).hexdigest()
+        assert bench.CPU_PROOFS == [dict(shape=sh.name, k=7, transcript="evm", witness=1, proof_sha256=want, proof_bytes=bench.CPU_PROOFS[0]["proof_bytes"])]
+    finally:
+        bench.CPU_PROOFS[:] = []
+
+
+def _supervised(tmp_path, digest):
+    import halo2_zkcert_amd.prover as pv
+
+    sh = pv.CircuitShape.agg(7, 3, 1)
+    os.makedirs(tmp_path, exist_ok=True)
+    proofs = [dict(shape=sh.name, k=7, transcript="evm", witness=0, proof_sha256=digest, where="stand-in")]
+    env = dict(os.environ, ZKHIP_BENCH_WORKER_SCRIPT=os.path.join(ROOT, "tests", "fake_bench_worker.py"), FAKE_PLAN="{}", FAKE_COUNT_DIR=str(tmp_path),
+               FAKE_K="7", FAKE_GPU_PROOFS=json.dumps(proofs))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "ZKHIP_BENCH_ROLE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--agg-k", "7", "--no-ladder"], capture_output=True, text=True,
+                       timeout=300, cwd=ROOT, env=env)
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    return r, lines
+
+
+def test_supervisor_compares_the_workers_digests_with_the_cpu_leg(tmp_path):
+    """N > 1: rank 0's GPU-free supervisor times the CPU oracle once the workers are gone and compares its proof digest with the ones the
+    workers' line carries; equal -> exit 0 and bytes_equal true; different -> the line still comes out and the run fails"""
+    import halo2_zkcert_amd.prover as pv
+    from oracle_backend import OracleBackend
+
+    sh = pv.CircuitShape.agg(7, 3, 1)
+    p = pv.Prover(OracleBackend(2), sh, satisfiable=True)
+    good = hashlib.sha256(bytes(p.prove(p.witness(0), transcript="evm")["proof"])).hexdigest()
+    r, lines = _supervised(tmp_path / "a", good)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = lines[0]
+    assert d["parity"]["bytes_equal"] is True and d["cpu_baseline"]["bytes_equal"] is True and d["cpu_baseline"]["proof_sha256"] == good
+    r, lines = _supervised(tmp_path / "b", "00" * 32)
+    assert r.returncode != 0, r.stderr[-2000:]          # the supervisor exits 3; torch.distributed.run reports a failed child as 1
+    assert lines[0]["parity"]["bytes_equal"] is False and "PARITY FAILURE" in r.stderr

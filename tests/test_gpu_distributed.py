@@ -211,6 +211,21 @@ def test_agg_k22_proof_over_two_ranks_by_point_range(zk, tmp_path):
         assert o["modes"] == {"proofs_row_sharded": 1, "proofs_pieces_sharded": 1, "shplonk_row_sharded": 1}, o["modes"]
 
 
+def test_rsa_k17_proof_over_two_ranks_equals_the_cpu_oracle(zk, tmp_path):
+    """BASELINE configs[1] (RSA k = 17, Poseidon) over 2 ranks by column AND by point range: both equal the single-GPU proof, which equals the CPU
+    oracle backend's proof byte for byte (north_star: bit-identical to the CPU prover on the same SRS and witness)."""
+    sys.path[:0] = [p_ for p_ in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")) if p_ not in sys.path]
+    from oracle_backend import OracleBackend
+
+    spec = ["rsa", 17, "poseidon"]
+    ref, _ = _single_then_sharded(zk, tmp_path, spec, lambda: pv.CircuitShape.rsa(17), "columns", 900)
+    cp = pv.Prover(OracleBackend(os.cpu_count() or 8), pv.CircuitShape.rsa(17), satisfiable=True)
+    assert bytes(cp.prove(cp.witness(1), transcript="poseidon")["proof"]) == bytes(ref)
+    (tmp_path / "points").mkdir()
+    ref2, _ = _single_then_sharded(zk, tmp_path / "points", spec, lambda: pv.CircuitShape.rsa(17), "points", 900)
+    assert bytes(ref2) == bytes(ref)
+
+
 def test_sha_k19_proof_over_two_ranks_by_column(zk, tmp_path):
     """BASELINE configs[2] at its real size (32 advice / 12 fixed columns, degree 5, Poseidon) over 2 ranks, MSMs split by column with whole
     window tables on both ranks == the single-GPU proof bytes"""

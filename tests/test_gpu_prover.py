@@ -1,4 +1,6 @@
 """GPU parity: the whole create_proof-shaped pass (16 commitments + quotient pieces) vs the oracle backend."""
+import os
+
 import numpy as np
 import pytest
 
@@ -402,6 +404,24 @@ def test_rsa_k17_poseidon_proof_bytes_verify(zk, oracle):
     bad = bytearray(t["proof"])
     bad[-70] ^= 4
     assert not verify_proof(gp, w, bytes(bad), "poseidon", oracle_vk=True)
+
+
+def test_rsa_k17_proof_bytes_equal_the_cpu_oracle(zk, oracle):
+    """north_star's own sentence at a BASELINE size: "proof bytes bit-identical to the reference CPU prover on the same SRS and witness".
+    BASELINE configs[1] (RSA k = 17, the c = 16 window, the 2^17 NTT pass plan — kernels no k <= 12 case selects) under the transcript
+    prove-rsa uses (/root/reference/src/bin/cli.rs:320, helpers.rs:233): the one-call GPU proof == the CPU oracle backend's proof, byte for
+    byte, on the same key, witness and blinding draws; also with the advice columns handed over as host arrays."""
+    ffi, ctx = zk
+    sh = pv.CircuitShape.rsa(17)
+    gp = pv.Prover(pv.GpuBackend(ctx, ffi), sh, satisfiable=True)
+    cp = pv.Prover(OracleBackend(os.cpu_count() or 8), sh, satisfiable=True)
+    wg = gp.witness(0)
+    want = bytes(cp.prove(cp.witness(0), transcript="poseidon")["proof"])
+    got = bytes(gp.prove_native(wg, transcript="poseidon")["proof"])
+    assert len(want) > 1000 and got == want
+    assert bytes(gp.prove_native(wg, transcript="poseidon", host_inputs=True)["proof"]) == want
+    gp.release()
+    gp.b.params.free()
 
 
 def test_sha_satisfiable_matches_oracle_k11(zk, oracle):
