@@ -485,9 +485,20 @@ def main():
     ap.add_argument("--ladder-budget", type=float, default=1500.0, help="N > 1: wall-clock seconds for the whole ladder (the driver's own limit is 1800 s)")
     ap.add_argument("--no-ladder", action="store_true", help="N > 1: first rung only (a failure is the run's failure)")
     ap.add_argument("--comm-timeout-ms", type=int, default=60000, help="N > 1: the library's deadline for a host wait on a multi-rank context (zkhip_set_option comm_timeout_ms)")
+    ap.add_argument("--replay-rank", type=int, default=None, help="MEASUREMENT MODE on one GPU: run what rank R of an --of N proof runs, alone, with the peers' "
+                    "contributions fabricated on the device (tools/replay_rccl): rank R's kernels, launch structure and exchanges on an idle GPU. "
+                    "The proof bytes are wrong by construction; the line reports rank R's time and what does not divide by N, never an N-GPU result")
+    ap.add_argument("--of", type=int, default=0, help="with --replay-rank: the rank count N being replayed")
+    ap.add_argument("--replay-latency-us", type=float, default=0.0, help="with --replay-rank: modelled latency of one exchange (0: exchanges cost only the fabricating fill)")
+    ap.add_argument("--replay-link-gbs", type=float, default=0.0, help="with --replay-rank: modelled xGMI bandwidth per peer link and direction, GB/s (0: not modelled)")
     ap.add_argument("--agg-unsharded", action="store_true", help="--chain, N >= 4: the aggregation proof on rank 0 alone (last rung of the ladder: no collective)")
     args = ap.parse_args()
 
+    if args.replay_rank is not None:
+        if args.gpus != 1 or args.of < 2 or not 0 <= args.replay_rank < args.of or args.replicas:
+            raise SystemExit("bench.py: --replay-rank R needs --gpus 1 and --of N with 0 <= R < N, N >= 2")
+        args.no_cpu_baseline = True      # a replayed rank's proof is wrong by construction: nothing to compare, nothing to time beside it
+        args.no_other_configs = True
     if args.gpus > 1 and os.environ.get("ZKHIP_BENCH_ROLE") != "worker":
         # Neither of these two processes ever touches the GPU (no HIP call, no torch.cuda): children, never an exec.
         if "WORLD_SIZE" not in os.environ:
@@ -540,10 +551,33 @@ def worker(args):
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}")
 
     ctx = ffi.Context(local_rank)
-    shard = world > 1 and not args.replicas and not (args.chain and args.agg_unsharded)
+    replay = args.replay_rank is not None
+    shard = (world > 1 or replay) and not args.replicas and not (args.chain and args.agg_unsharded)
+    nshare = args.of if replay else world        # ranks the sharded proof is split over
+    replay_lib = None
     if world > 1:
         ctx.set_option("comm_timeout_ms", args.comm_timeout_ms)
-    if shard:
+    if replay:
+        import ctypes
+
+        os.environ["ZKREPLAY_LATENCY_US"], os.environ["ZKREPLAY_LINK_GBS"] = str(args.replay_latency_us), str(args.replay_link_gbs)
+        path = os.path.join(ROOT, "tools", "replay_rccl", "libreplay_rccl.so")
+        if not os.path.exists(path):
+            raise SystemExit(f"bench.py: {path} is missing (python -c 'import __graft_entry__ as g; g.build()')")
+        ctx.comm_init_replay(args.replay_rank, args.of, path)
+        replay_lib = ctypes.CDLL(path)      # the same loaded object (dlopen by path): its counters
+
+        class ReplayStats(ctypes.Structure):
+            _fields_ = [("collectives", ctypes.c_uint64), ("bytes_received", ctypes.c_uint64), ("bytes_sent", ctypes.c_uint64), ("wire_us", ctypes.c_double)]
+
+        def replay_stats(reset=False):
+            st = ReplayStats()
+            replay_lib.ncclReplayStats(ctypes.byref(st), ctypes.c_int(1 if reset else 0))
+            return dict(collectives=st.collectives, bytes_received=st.bytes_received, bytes_sent=st.bytes_sent, wire_us=st.wire_us)
+        info = ctx.comm_describe()
+        if info["nranks"] != args.of or info["transport_ranks"] != args.of or info["transport"] != "rccl":
+            raise SystemExit(f"bench.py: the replay communicator reports {info}")
+    elif shard:
         # RCCL communicator inside the library (unique id broadcast through torch.distributed).  If it cannot be created on some rank
         # (no librccl, an RCCL error) this worker FAILS — a line that says n_gpus N must come from N cooperating ranks — and the
         # supervisors move every rank to the next rung of the ladder in fresh processes (supervise()).
@@ -622,6 +656,8 @@ def worker(args):
         g0 = ctx.comm_bytes_gathered()
         c0 = ctx.comm_describe()["collectives"] if shard else 0
         barrier()
+        if replay:
+            replay_stats(reset=True)
         t0 = time.perf_counter()
         native_s = 0.0
         for _ in range(steps):
@@ -629,6 +665,7 @@ def worker(args):
             native_s += trace.get("native_call_s", 0.0)
         barrier()
         dt = time.perf_counter() - t0
+        rstats = {k_: v_ / steps for k_, v_ in replay_stats().items()} if replay else None
         gathered = (ctx.comm_bytes_gathered() - g0) // max(steps, 1)
         coll_per_proof = (ctx.comm_describe()["collectives"] - c0) / max(steps, 1) if shard else 0
         if world > 1:
@@ -668,7 +705,7 @@ def worker(args):
             del batch, outs
         ctx.profile_enable(False)
         h2d = None
-        if with_h2d and world == 1 and not args.python_schedule and not args.no_h2d:
+        if with_h2d and world == 1 and not replay and not args.python_schedule and not args.no_h2d:
             # the same step with the advice columns handed over as pinned HOST arrays (a Rust caller's Vec<Fr> columns) and the
             # instance columns built from the instance values: the uploads are inside the timed region
             prover.prove_native(wit, transcript=kind, host_inputs=True)
@@ -683,9 +720,9 @@ def worker(args):
         barrier()
 
         # ---- rooflines (algorithmic bytes: SURVEY.md §8(d)); one rank's share when the proof is sharded
-        share = world if shard else 1
+        share = nshare if shard else 1
         c_bits, windows = backend.params.window()
-        traffic, traffic_file = pmc_traffic(name, bh) if world == 1 else (None, None)
+        traffic, traffic_file = pmc_traffic(name, bh) if (world == 1 and not replay) else (None, None)
         def per_launch(kname):
             k_ = kernels[kname]
             return (k_["ms_per_step"] / k_["launches_per_step"]) if k_["launches_per_step"] else 0.0
@@ -758,7 +795,10 @@ def worker(args):
                "traffic_source": traffic_file, "with_h2d": h2d, "msm_shard": shard_mode,
                "first_proof_s": round(setup_s + first_s, 3), "comm": comm_fields(gathered, shard_mode, coll_per_proof),
                "native_call_ms_per_step": round(native_s * 1000.0 / steps, 3) if native_s else None}   # zkhip_create_proof_ex alone; ms_per_step also holds the ctypes wrapper around it
-        note_proof(shape, kind, wseed if witness == "uniform" else f"{witness}:{wseed}", trace.get("proof", b""), f"configs.{name}" + ("" if witness == "uniform" else f" ({witness} witness)"))
+        if replay:
+            res["replay_exchanges_per_step"] = rstats
+        if not replay:      # a replayed rank's bytes are wrong by construction: never offered for comparison
+            note_proof(shape, kind, wseed if witness == "uniform" else f"{witness}:{wseed}", trace.get("proof", b""), f"configs.{name}" + ("" if witness == "uniform" else f" ({witness} witness)"))
         prover.release()          # the context's per-key caches (coset-layout key columns, sorted lookup table)
         backend.params.free()
         del prover, wit, trace, backend
@@ -801,17 +841,18 @@ def worker(args):
         barrier, then the aggregation proof.  N >= 4: one leaf proof per rank 0..3 on an unsharded context, then the k = 22 proof
         sharded over all N ranks; N = 1: the five proofs one after the other.  (The aggregation circuit's witness generation — the
         in-circuit verification of the four snarks on the CPU, src/lib.rs:43-49 — is outside the path and not timed.)  Collective."""
-        if world > 1 and world < 4:
+        vworld, vrank = (nshare, args.replay_rank) if replay else (world, rank)      # (--replay-rank: the rank this process plays, alone)
+        if vworld > 1 and vworld < 4:
             raise SystemExit("--chain needs --gpus 1 or >= 4")
-        agg_here = shard or world == 1 or rank == 0        # --agg-unsharded (last rung of the ladder): the aggregation proof on rank 0 alone
+        agg_here = shard or vworld == 1 or vrank == 0        # --agg-unsharded (last rung of the ladder): the aggregation proof on rank 0 alone
         leaf_ctx = ffi.Context(local_rank) if shard else ctx
         leaf_names = ["rsa17", "sha19", "rsa17", "sha19"]
-        mine = leaf_names if world == 1 else ([leaf_names[rank]] if rank < 4 else [])
+        mine = leaf_names if vworld == 1 else ([leaf_names[vrank]] if vrank < 4 else [])
         leaves, pairs = [], 0.0
         for j, nm in enumerate(mine):
             sh_ = make_shape(pv, nm, args)
             pr_ = pv.Prover(pv.GpuBackend(leaf_ctx, ffi), sh_, satisfiable=True)
-            ws_ = j if world == 1 else rank
+            ws_ = j if vworld == 1 else vrank
             leaves.append((pr_, dict(pr_.witness(ws_), seed=ws_), TRANSCRIPT[nm]))
             pairs += sh_.counts(pr_.dom.extended_k)["msm"] * float(1 << sh_.k)
         if shard:
@@ -821,22 +862,27 @@ def worker(args):
             agg_shape = make_shape(pv, "agg22", args)
             agg = pv.Prover(pv.GpuBackend(ctx, ffi), agg_shape, satisfiable=True)
             agg_w = agg.witness(0)
-            pairs += agg_shape.counts(agg.dom.extended_k)["msm"] * float(1 << agg_shape.k) / (world if shard else 1)
+            pairs += agg_shape.counts(agg.dom.extended_k)["msm"] * float(1 << agg_shape.k) / (nshare if shard else 1)
         sizes, digests, last = [], [], []
+        phase_s = dict(leaf=0.0, agg=0.0)
 
         def chain_step():
             del sizes[:], digests[:], last[:]
+            t_l = time.perf_counter()
             for pr_, w_, kind_ in leaves:
                 pf_ = bytes(pr_.prove_native(w_, transcript=kind_)["proof"])
                 sizes.append(len(pf_))
                 digests.append(hashlib.sha256(pf_).hexdigest())
                 last.append((pr_.shape, kind_, w_["seed"], pf_, f"chain leaf (witness {w_['seed']})"))
             barrier()
+            t_a = time.perf_counter()
+            phase_s["leaf"] += t_a - t_l
             if agg_here:
                 pf_ = bytes(agg.prove_native(agg_w, transcript="evm")["proof"])
                 sizes.append(len(pf_))
                 digests.append(hashlib.sha256(pf_).hexdigest())
                 last.append((agg.shape, "evm", 0, pf_, "chain aggregation proof"))
+            phase_s["agg"] += time.perf_counter() - t_a
 
         for _ in range(warmup):
             chain_step()
@@ -848,11 +894,15 @@ def worker(args):
         g0 = ctx.comm_bytes_gathered()
         c0 = ctx.comm_describe()["collectives"] if shard else 0
         barrier()
+        phase_s["leaf"] = phase_s["agg"] = 0.0
+        if replay:
+            replay_stats(reset=True)
         t0 = time.perf_counter()
         for _ in range(steps):
             chain_step()
         barrier()
         dt = time.perf_counter() - t0
+        rstats = {k_: v_ / steps for k_, v_ in replay_stats().items()} if replay else None
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -873,19 +923,22 @@ def worker(args):
                     "launches_per_step": acc_l / steps, "timing": "HIP events inside the timed region, all proofs of the chain this rank ran",
                     "note": "rank 0's share: 96 B per (scalar, point) pair over every commitment of its leaf proof(s) and its 1/N of the aggregation proof's; "
                             "VALU-issue bound like the single proofs (DESIGN.md 5); traffic: see the per-configuration PMC passes of the N = 1 line"}
-        if world == 1:
+        if vworld == 1:
             par = "5 proofs in sequence on 1 GPU"
         elif shard:
-            par = f"leaf proofs on ranks 0-3 (one each), then one proof sharded x{world}"
+            par = f"leaf proofs on ranks 0-3 (one each), then one proof sharded x{vworld}"
         else:
             par = "leaf proofs on ranks 0-3 (one each), then the aggregation proof on rank 0 alone (no collective on the data path)"
         res = {"value": round(dt / steps, 6), "unit": "s", "steps": steps, "warmup": warmup, "ms_per_step": round(dt * 1000.0 / steps, 3), "proofs_per_step": 5,
                "workload": "chain (BASELINE configs[4]): 2 x RSA k=17 + 2 x SHA256-shaped k=19 leaf proofs (Poseidon), barrier, aggregation-shaped "
                            f"k={args.agg_k} proof (Keccak)",
                "parallelism": par, "proof_bytes": list(sizes), "proof_sha256": list(digests), "roofline": roof,
+               "phase_ms_per_step": {"leaf_proofs_until_the_barrier": round(phase_s["leaf"] * 1000.0 / steps, 3), "aggregation_proof": round(phase_s["agg"] * 1000.0 / steps, 3),
+                                     "note": "host wall clock on this rank; the barrier (and a device synchronize) separates the two phases"},
+               "replay_exchanges_per_step": rstats,
                "bytes_gathered_per_step": (ctx.comm_bytes_gathered() - g0) // steps if shard else 0,
                "collectives_per_step": (ctx.comm_describe()["collectives"] - c0) / steps if shard else 0}
-        for item in last:
+        for item in ([] if replay else last):
             note_proof(*item)
         for pr_, _, _ in leaves:
             pr_.release()
@@ -908,11 +961,23 @@ def worker(args):
                 "note": "nranks / transport_ranks / bytes: what the library's own communicator reports on rank 0 (zkhip_comm_info / zkhip_comm_describe; "
                         "transport_ranks = ncclCommCount); bytes = received by this rank through all-gathers in one step"}
 
+    def replay_block(exchanges):
+        """what the line says about a --replay-rank run"""
+        d = ctx.comm_describe()
+        return {"rank": args.replay_rank, "of": args.of, "exchanges_per_step": exchanges, "library_counters": {"collectives_total": d["collectives"], "bytes_gathered_total": d["bytes_gathered"]},
+                "modelled_wire": {"latency_us_per_exchange": args.replay_latency_us, "link_GBps_per_peer_and_direction": args.replay_link_gbs,
+                                  "note": "0 / 0: an exchange costs only the kernel that fabricates what would arrive (HBM write speed); otherwise the communicator's stream is "
+                                          "additionally held for latency + max-over-peers(bytes from that peer) / link bandwidth per exchange (xGMI: one link per peer)"},
+                "note": f"SINGLE-RANK REPLAY, not an {args.of}-GPU measurement: this process ran exactly what rank {args.replay_rank} of {args.of} runs (csrc/comm.hip's RCCL branch "
+                        "against tools/replay_rccl: the peers' partial sums, rows and evaluations are fabricated on the device), alone on one GPU.  `value` is that rank's "
+                        "time per step; the proof bytes are wrong by construction and are not compared with anything.  exchanges_per_step: what the stand-in "
+                        "saw on the RCCL branch (silent pairs skipped, no padding): collectives, bytes this rank would receive / send, modelled wire time"}
+
     if args.chain:
         res = run_chain(args.steps, args.warmup)
         # one GPU: the five proofs in sequence, nothing scales (null); N >= 4: total work fixed while the aggregation proof is sharded ("strong");
         # --agg-unsharded (last rung of the ladder): the aggregation proof on rank 0 alone — more GPUs do not shorten it ("none")
-        chain_scaling = None if world == 1 else ("strong" if shard else "none")
+        chain_scaling = None if world == 1 else ("strong" if shard else "none")      # (a --replay-rank run is one process: null)
         if rank == 0:
             cb = parity = None
             if world == 1 and not args.no_cpu_baseline:      # N > 1: rank 0's GPU-free supervisor times it once the workers are gone
@@ -923,7 +988,8 @@ def worker(args):
                               "scaling": chain_scaling, "vs_baseline": None, "dtype": "u256 (BN254 Fr/Fq, Montgomery)", "data": "synthetic", "proofs_per_step": 5,
                               "config": {"workload": res["workload"], "parallelism": res["parallelism"], "k": args.agg_k, "transcript": "evm"}, "proof_bytes": res["proof_bytes"], "proof_sha256": res["proof_sha256"],
                               "comm": comm_fields(res["bytes_gathered_per_step"], "points" if args.shard == "auto" else args.shard, res["collectives_per_step"]),
-                              "roofline": res["roofline"], "cpu_baseline": cb, "gpu_proofs": gpu_proofs, "parity": parity, "build": bh}), flush=True)
+                              "roofline": res["roofline"], "cpu_baseline": cb, "gpu_proofs": gpu_proofs, "parity": parity, "build": bh,
+                              "phase_ms_per_step": res["phase_ms_per_step"], **({"replay": replay_block(res["replay_exchanges_per_step"])} if replay else {})}), flush=True)
             if parity and parity["bytes_equal"] is False:
                 print("bench.py: PARITY FAILURE: a HIP-path proof differs from the CPU oracle's: " + json.dumps([r for r in parity["compared"] if not r["equal"]]), file=sys.stderr, flush=True)
                 sys.exit(3)
@@ -978,7 +1044,7 @@ def worker(args):
             "config": {"workload": head["workload"], "headline": args.config, "k": head["k"], "advice": head["advice"], "fixed": head["fixed"],
                        "lookups": head["lookups"], "perm_columns": head["perm_columns"], "degree": head["degree"], "transcript": head["transcript"],
                        "host": "prover.py (Python schedule over the C ABI)" if args.python_schedule else "zkhip_create_proof_ex (schedule and transcript in the library)",
-                       "parallelism": "1 GPU" if world == 1 else (f"one proof sharded x{world}: MSMs by {'point range (window tables 1/' + str(world) + ' per rank)' if head.get('msm_shard') == 'points' else 'column (whole tables on every rank)'}, coset NTTs by polynomial, then an all-to-all of row windows (own row range + halo of every coset block: 1/N of an all-gather of complete columns), sweep by row range per coset block, the quotient's pieces / h(X) / SHPLONK on row ranges (numerator blocks to their owners and back, Kate division with carries across ranks), evaluations by query, all-gather of the 96-byte partial sums — all inside the library (ncclSend/ncclRecv groups, ncclAllGather)" if shard
+                       "parallelism": (f"rank {args.replay_rank} of {args.of}, replayed alone on 1 GPU" if replay else "1 GPU") if world == 1 else (f"one proof sharded x{world}: MSMs by {'point range (window tables 1/' + str(world) + ' per rank)' if head.get('msm_shard') == 'points' else 'column (whole tables on every rank)'}, coset NTTs by polynomial, then an all-to-all of row windows (own row range + halo of every coset block: 1/N of an all-gather of complete columns), sweep by row range per coset block, the quotient's pieces / h(X) / SHPLONK on row ranges (numerator blocks to their owners and back, Kate division with carries across ranks), evaluations by query, all-gather of the 96-byte partial sums — all inside the library (ncclSend/ncclRecv groups, ncclAllGather)" if shard
                                                                    else f"{world} independent proofs, one per GPU, no collective")},
             "roofline": {k_: dom[k_] for k_ in ("kernel", "bound", "hbm_frac", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms", "note")},
             "int_roofline": dict(kernel="k_accum_affine", **dom["int_roofline"]),
@@ -987,6 +1053,8 @@ def worker(args):
             "setup_s": head["setup_s"], "first_proof_s": head["first_proof_s"], "resident_bytes": head["resident_bytes"], "with_h2d": head["with_h2d"],
         }
         out["parity_sample"] = sample
+        if replay:
+            out["replay"] = replay_block(head.get("replay_exchanges_per_step"))
         out["gpu_proofs"] = gpu_proofs
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"], rsa_cb = cpu_baseline(pv, args, args.config, head["k"], head["transcript"])

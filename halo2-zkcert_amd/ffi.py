@@ -255,6 +255,21 @@ class Context:
             raise ValueError(transport)
         self.rank, self.world, self.transport = rank, world, transport
 
+    def comm_init_replay(self, rank, world, library):
+        """MEASUREMENT ONLY (bench.py --replay-rank): this process becomes rank `rank` of a `world`-rank communicator whose collective
+        library is tools/replay_rccl (zkhip_comm_use_library): no peer exists, every peer contribution is fabricated on the device, so the
+        library's RCCL branch issues exactly rank `rank`'s kernels, fences and exchanges on an otherwise idle GPU.  Results computed on such
+        a context are wrong by construction."""
+        global _rccl_lib_named
+        if _rccl_lib_named:
+            raise ZkhipError("comm_init_replay: a collective library is already bound in this process")
+        _check(lib().zkhip_comm_use_library(os.fsencode(library)))
+        _rccl_lib_named = True
+        buf = (C.c_uint8 * 128)()
+        _check(lib().zkhip_comm_unique_id(buf))
+        _check(lib().zkhip_comm_init(self.h, buf, C.c_int(rank), C.c_int(world)))
+        self.rank, self.world, self.transport = rank, world, "rccl"
+
     shard_points = True      # ParamsKZG.setup / .read on a context with a communicator: point-range shards (True) or whole tables
 
     def comm_shard(self, mode):

@@ -57,6 +57,11 @@ def test_bench_prints_one_contract_line():
     assert m22["value"] > 3.0 * m22["k20_s"] > 9.0 * m22["k18_s"] and m22["cores"] == cb["cores"] and "profiles/r04_cpu_k22.json" in m22["source"]
     assert abs(cb["scale"] - m22["value"] / m22["k20_s"]) < 1e-3
     assert d["comm"] is None and d["first_proof_s"] > d["setup_s"]
+    # north_star's "proof bytes bit-identical to the CPU prover": the CPU leg's k = 20 pass proved the same instance as the GPU's parity sample
+    # (the headline shape at k = 20), digests compared in the line; a mismatch would have made bench.py exit non-zero
+    assert d["scaling"] is None
+    assert d["parity_sample"]["k"] == 20 and d["parity_sample"]["proof_sha256"] == cb["proof_sha256"] and cb["proof_k"] == 20 and cb["bytes_equal"] is True
+    assert d["parity"]["bytes_equal"] is True and [r["k"] for r in d["parity"]["compared"]] == [20]
 
 
 def test_bench_two_ranks_on_one_device():
@@ -199,3 +204,25 @@ def test_bench_two_ranks_through_the_rccl_transport_path():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and cm["transport"] == "rccl" and cm["nranks"] == 2 and cm["transport_ranks"] == 2
     assert cm["shard_mode"] == "points" and cm["bytes_gathered_per_step"] > 0
     assert cm["exchange_modes"]["proofs_row_sharded"] >= 3 and cm["exchange_modes"]["proofs_pieces_sharded"] >= 3
+
+
+def test_single_rank_replay_issues_the_exchanges_of_a_real_rank():
+    """bench.py --replay-rank 0 --of 2 (one process, tools/replay_rccl fabricating the peer) against a real 2-rank run of the same proof through
+    comm.hip's RCCL branch (tests/fake_rccl moving the bytes): rank 0 issues the same number of exchanges and receives the same number of
+    bytes per proof in both — the replay times rank 0's real launch structure.  The replay line says what it is and offers no proof for comparison."""
+    common = ["--steps", "2", "--warmup", "1", "--agg-k", "18", "--shard", "points", "--no-cpu-baseline"]
+    rp = _run([os.path.join(ROOT, "bench.py"), "--replay-rank", "0", "--of", "2"] + common)
+    assert rp["n_gpus"] == 1 and rp["scaling"] is None and rp["replay"]["rank"] == 0 and rp["replay"]["of"] == 2 and "SINGLE-RANK REPLAY" in rp["replay"]["note"]
+    assert rp["gpu_proofs"] == [] and rp["parity"] is None and rp["cpu_baseline"] is None
+    ex = rp["replay"]["exchanges_per_step"]
+    assert rp["comm"]["transport"] == "rccl" and rp["comm"]["nranks"] == 2 and rp["comm"]["transport_ranks"] == 2
+    env = dict(os.environ, ZKHIP_BENCH_ONE_DEVICE="1", ZKHIP_BENCH_DIST_BACKEND="gloo", ZKHIP_COMM_TRANSPORT="rccl", ZKHIP_RCCL_LIB=_fake_rccl(), ZKFAKE_RCCL_SLOT_MB="64")
+    env.pop("WORLD_SIZE", None)
+    real = _run([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-ladder"] + common, env=env)
+    assert real["comm"]["collectives_per_step"] == rp["comm"]["collectives_per_step"] == ex["collectives"]
+    assert real["comm"]["bytes_gathered_per_step"] == rp["comm"]["bytes_gathered_per_step"] == ex["bytes_received"]
+    assert real["comm"]["exchange_modes"]["proofs_row_sharded"] >= 3 and rp["comm"]["exchange_modes"]["proofs_row_sharded"] >= 3
+    # eight ranks, with a modelled wire: the stand-in holds the communicator's stream for latency + bytes / link bandwidth per exchange
+    r8 = _run([os.path.join(ROOT, "bench.py"), "--replay-rank", "3", "--of", "8", "--replay-latency-us", "20", "--replay-link-gbs", "50"] + common)
+    e8 = r8["replay"]["exchanges_per_step"]
+    assert r8["replay"]["of"] == 8 and e8["wire_us"] >= 20.0 * e8["collectives"] > 0 and e8["bytes_received"] > 0
