@@ -319,7 +319,9 @@ int zkhip_comm_init(zkhip_ctx* ctx, const uint8_t id[128], int rank, int nranks)
         }
         if (ok) {
             const hipError_t we = stream_wait(ctx, ctx->stream);
-            if (we == hipErrorLaunchTimeOut) {   // a peer never arrived: the communicator is unusable and the device is busy waiting on it — no destroy (it would block), just fail
+            if (we == hipErrorLaunchTimeOut) {   // a peer never arrived: the communicator is unusable and the device is busy waiting on it.  The context keeps the
+                // handle marked stuck (wait_poll set zkhip_comm::stuck): zkhip_comm_destroy / zkhip_destroy will not call into RCCL for it, and d_buf
+                // — still the target of the stuck exchange — is deliberately not freed (hipFree would wait for the device)
                 set_error("zkhip_comm_init: the all-to-all self-check did not complete");
                 return ZKHIP_EHIP;
             }
@@ -338,7 +340,7 @@ int zkhip_comm_init(zkhip_ctx* ctx, const uint8_t id[128], int rank, int nranks)
         } else {
             all_ok = 0;   // (if even the all-gather fails the proofs will report it; the exchange mode no longer matters)
         }
-        if (we == hipErrorLaunchTimeOut) {   // a peer failed its init (see above) or died: this rank follows, loudly
+        if (we == hipErrorLaunchTimeOut) {   // a peer failed its init (see above) or died: this rank follows, loudly (communicator marked stuck, d_buf abandoned: as above)
             set_error("zkhip_comm_init: the verdict all-gather of the self-check did not complete (a peer failed or left)");
             return ZKHIP_EHIP;
         }
@@ -374,8 +376,12 @@ int zkhip_comm_set_host_alltoall(zkhip_ctx* ctx, zkhip_host_alltoall_fn fn, void
 int zkhip_comm_destroy(zkhip_ctx* ctx) {
     if (!ctx) { set_error("null ctx"); return ZKHIP_EINVAL; }
     zkhip_comm& cm = ctx->comm;
-    (void)hipDeviceSynchronize();
-    if (cm.nccl && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)cm.nccl);
+    // a communicator a host wait has given up on (zkhip_comm::stuck): its stream holds a collective that will never complete, so neither the
+    // device-wide wait nor ncclCommDestroy (which joins that collective) may be called — both would block for ever.  The handle is abandoned;
+    // the streams / events are released by the runtime asynchronously, or by the process leaving (what a caller does after this error).
+    const bool dead = cm.stuck != 0;
+    if (!dead) (void)hipDeviceSynchronize();
+    if (cm.nccl && g_rccl.CommDestroy && !dead) (void)g_rccl.CommDestroy((ncclComm_t)cm.nccl);
     if (cm.stream) (void)hipStreamDestroy(cm.stream);
     if (cm.ev_in) (void)hipEventDestroy(cm.ev_in);
     if (cm.ev_out) (void)hipEventDestroy(cm.ev_out);

@@ -85,6 +85,8 @@ struct zkhip_comm {
     int shard_columns = 0;        // MSMs over whole-SRS handles: 1 = split the batch by column over the ranks, 0 = replicate
     int a2a_ok = 0;               // verdict of zkhip_comm_init's all-to-all self-check: 1 passed on every rank, -1 failed somewhere, 0 not run
     const char* phase = "";       // which part of the proof the host is issuing (what a timed-out wait reports)
+    mutable int stuck = 0;        // a host wait of this context ran into comm_timeout_ms: the communicator's stream (and whatever waits on it) is taken for
+                                  // dead from here on — later waits fail at once, error exits do not wait again, zkhip_comm_destroy does not touch RCCL
     // the exchange a multi-rank proof uses: row windows by grouped send / recv only where the user asked for it AND this communicator
     // has shown it can do it (the user's option itself is never overwritten)
     bool row_sharded(const zkhip_options& o) const { return o.row_sharded != 0 && a2a_ok >= 0; }
@@ -167,7 +169,10 @@ struct ProfScope {
 // A context with a communicator waits for its peers whenever it waits for its own stream — a collective whose partner never arrives (a
 // rank that died, an RCCL that cannot connect two GPUs) would leave the host polling for ever — so while the context has a communicator
 // (nranks > 1) the poll has a deadline (zkhip_options::comm_timeout_ms): on expiry the wait fails with hipErrorLaunchTimeOut and the error text names the rank,
-// the number of collectives issued so far and the phase of the proof.  Without a communicator: poll for 10 s, then the blocking wait.
+// the number of collectives issued so far and the phase of the proof.  The deadline is the TOTAL duration of one host wait (not "no progress for
+// N ms": the host cannot see progress inside a stream) and it applies to every wait of such a context — set it above the longest legitimate wait
+// (N ranks time-slicing one device, a large queued batch).  After an expiry the context is marked stuck (zkhip_comm::stuck): every later wait fails
+// at once.  Without a communicator: poll for 10 s, then the blocking wait.
 namespace zk {
 hipError_t wait_poll(const zkhip_ctx* c, hipStream_t st, hipEvent_t ev);   // ctx.hip: ev != null: wait for the event; else for the stream (null = the legacy default stream)
 }

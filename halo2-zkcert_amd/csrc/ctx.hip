@@ -34,6 +34,13 @@ hipError_t dev_malloc(void** p, size_t bytes) {
 hipError_t wait_poll(const zkhip_ctx* c, hipStream_t st, hipEvent_t ev) {
     const double limit_ms = c && c->comm.nranks > 1 && c->opt.comm_timeout_ms > 0 ? (double)c->opt.comm_timeout_ms : 0.0;
     const auto t0 = std::chrono::steady_clock::now();
+    if (c && c->comm.stuck) {   // an earlier wait already gave up on this communicator: nothing queued behind it will ever run
+        hipError_t e = ev ? hipEventQuery(ev) : hipStreamQuery(st);
+        if (e != hipErrorNotReady) return e;
+        (void)hipGetLastError();
+        snprintf(g_stuck, sizeof g_stuck, "rank %d of %d: an earlier host wait of this context exceeded comm_timeout_ms; the communicator is taken for dead", c->comm.rank, c->comm.nranks);
+        return hipErrorLaunchTimeOut;
+    }
     for (;;) {
         for (int i = 0; i < 64; ++i) {
             hipError_t e = ev ? hipEventQuery(ev) : hipStreamQuery(st);      // (st may be the null stream: a context bound to the caller's default stream)
@@ -43,8 +50,9 @@ hipError_t wait_poll(const zkhip_ctx* c, hipStream_t st, hipEvent_t ev) {
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         if (limit_ms > 0.0) {
             if (ms > limit_ms) {
-                snprintf(g_stuck, sizeof g_stuck, "rank %d of %d stuck after collective #%llu, phase '%s': no progress on the device for %d ms (comm_timeout_ms)",
+                snprintf(g_stuck, sizeof g_stuck, "rank %d of %d stuck after collective #%llu, phase '%s': a host wait exceeded %d ms (comm_timeout_ms)",
                          c->comm.rank, c->comm.nranks, (unsigned long long)c->comm.collectives, c->comm.phase ? c->comm.phase : "", c->opt.comm_timeout_ms);
+                c->comm.stuck = 1;
                 fprintf(stderr, "zkhip: %s\n", g_stuck);
                 return hipErrorLaunchTimeOut;
             }

@@ -58,14 +58,20 @@ struct Overlap {
 struct StreamGuard {   // whatever happens, the context leaves on its main stream
     zkhip_ctx* ctx;
     hipStream_t main;
-    bool host_uploads = false, done = false;
-    // an error exit after asynchronous copies FROM THE CALLER'S host buffers were enqueued: wait for them, or a caller that drops its
-    // Vec<Fr> / pinned buffers on the error races the DMA still in flight
+    bool host_uploads = false, aux_launched = false, done = false;
+    // Error exits.  (1) Asynchronous copies FROM THE CALLER'S host buffers may be in flight: wait for them, or a caller that drops its Vec<Fr> /
+    // pinned buffers on the error races the DMA.  (2) The random polynomial's MSM may still be running on the third stream (rand_late): it reads
+    // w_rand and writes the pinned commitment slot, which the NEXT proof reuses on the main stream — wait for it too.
+    // The waits are stream_wait's (polling, with the communicator's deadline), never a bare hipStreamSynchronize: when the error IS an expired
+    // deadline (zkhip_comm::stuck) the streams will never drain, so no wait is attempted at all and the call returns at once — the caller's
+    // host buffers must then stay alive until the process exits ("a rank that stops responding").
     ~StreamGuard() {
         ctx->stream = main;
-        if (host_uploads && !done) {
-            if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
-            (void)hipStreamSynchronize(main);
+        if (done || ctx->comm.stuck) return;
+        if (aux_launched && ctx->aux_stream) (void)stream_wait(ctx, ctx->aux_stream);
+        if (host_uploads && !ctx->comm.stuck) {
+            if (ctx->copy_stream) (void)stream_wait(ctx, ctx->copy_stream);
+            if (!ctx->comm.stuck) (void)stream_wait(ctx, main);
         }
     }
 };
@@ -127,10 +133,24 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
     if (NC && !pk->challenge_phase) { set_error("zkhip_create_proof: n_challenges = %u but challenge_phase is NULL", NC); return ZKHIP_EINVAL; }
     for (uint32_t c = 0; c < NC; ++c) max_phase = std::max<uint32_t>(max_phase, pk->challenge_phase[c]);
     {
+        // the phases of a circuit are the phases of its advice columns, without gaps (upstream's ConstraintSystem hands them out in order and a
+        // challenge is usable "after" a phase that exists); the callback is needed for every phase after the first
         uint32_t max_adv = 0;
         for (uint32_t j = 0; j < A; ++j) max_adv = std::max(max_adv, phase_of(j));
-        if (max_adv > 0 && !in->advice_phase) {
-            set_error("zkhip_create_proof: the key has advice columns of phase %u but zk_proof_inputs.advice_phase is NULL", max_adv);
+        if (max_adv >= 64) { set_error("zkhip_create_proof: advice phase %u (at most 63)", max_adv); return ZKHIP_EINVAL; }
+        uint64_t seen = 0;
+        for (uint32_t j = 0; j < A; ++j) seen |= 1ull << phase_of(j);
+        if (A && seen != ((max_adv == 63) ? ~0ull : ((1ull << (max_adv + 1)) - 1))) {
+            set_error("zkhip_create_proof: advice_column_phase has a phase without columns (phases 0..%u must all occur)", max_adv);
+            return ZKHIP_EINVAL;
+        }
+        for (uint32_t c = 0; c < NC; ++c)
+            if (pk->challenge_phase[c] > max_adv) {
+                set_error("zkhip_create_proof: challenge %u is of phase %u but the last advice phase is %u", c, (unsigned)pk->challenge_phase[c], max_adv);
+                return ZKHIP_EINVAL;
+            }
+        if (max_phase > 0 && !in->advice_phase) {
+            set_error("zkhip_create_proof: the key has phases up to %u but zk_proof_inputs.advice_phase is NULL", max_phase);
             return ZKHIP_EINVAL;
         }
     }
@@ -636,6 +656,7 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
             ctx->stream = ctx->aux_stream;
             const void* rc[1] = {w_rand};
             const zkhip_srs* rb[1] = {pk->g};
+            guard.aux_launched = true;
             const int rc_ = zkhip_msm_g1_multi_device(ctx, rb, rc, 1, 0, n, w_com_rand);
             ctx->stream = st;
             ZK_TRY(rc_);

@@ -43,6 +43,35 @@ if os.environ.get("ZK_STALL_TEST") == "1":
         json.dump(res, f)
     sys.stdout.flush()
     os._exit(0)
+if os.environ.get("ZK_STALL_TEST") == "proof":
+    # the same deadline met INSIDE a proof whose advice columns are the caller's host arrays (the error exit of zkhip_create_proof_ex
+    # used to wait for the stuck stream without a deadline).  Rank 0's collective stream is stalled at the proof's first exchange:
+    # its proof must come back with the deadline's error well before the stall ends.  Rank 1 then waits for a peer that has left (the stand-in's
+    # barrier): a watchdog thread writes its record and ends the process.
+    import threading
+    import time
+
+    def leave(res):
+        with open(os.path.join(os.environ["ZK_OUT"], f"rank{rank}.json"), "w") as f:
+            json.dump(res, f)
+        sys.stdout.flush()
+        os._exit(0)
+    if rank != 0:
+        threading.Timer(25.0, lambda: leave({"rank": rank, "error": "watchdog: the peer left", "elapsed_s": 25.0})).start()
+    ctx.comm_shard("points")
+    p = pv.Prover(pv.GpuBackend(ctx, ffi), pv.CircuitShape.small(8), satisfiable=True)
+    w = p.witness(1)
+    # the stand-in reads its fault plan at every call: stall rank 0's stream at the FIRST exchange of the proof (its call counter also counted
+    # the two exchanges of the init-time self-check, which the library's own counter leaves out)
+    os.environ["ZKFAKE_RCCL_STALL"] = f"device:0:{ctx.comm_describe()['collectives'] + 3}"
+    t0 = time.time()
+    res = {"rank": rank, "error": None}
+    try:
+        p.prove_native(w, transcript="poseidon", host_inputs=True)
+    except Exception as e:   # noqa: BLE001
+        res["error"] = str(e)
+    res["elapsed_s"] = time.time() - t0
+    leave(res)
 mode = os.environ.get("ZK_SHARD_MODE", "points")
 ctx.comm_shard(mode)
 out = {"transport": ctx.transport, "shard_mode": mode}

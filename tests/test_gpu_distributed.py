@@ -272,7 +272,19 @@ def test_a_stuck_collective_fails_the_host_wait_at_the_deadline(zk, tmp_path):
                                                          "ZKHIP_COMM_TIMEOUT_MS": "2000"}, timeout=300)
     assert outs[1]["error"] is None and outs[1]["recv"] == [1, 2]
     err = outs[0]["error"]
-    assert err and "rank 0 of 2 stuck after collective #1" in err and "no progress on the device for 2000 ms" in err, err
+    assert err and "rank 0 of 2 stuck after collective #1" in err and "a host wait exceeded 2000 ms" in err, err
+
+
+def test_a_stuck_collective_inside_a_proof_with_host_inputs_returns_at_the_deadline(zk, tmp_path):
+    """ADVICE r4 (prover.hip StreamGuard): rank 0's collective stream stalls (40 s) at the first exchange of a proof whose advice columns are
+    host arrays.  zkhip_create_proof_ex returns the deadline's error after ~2 s — its error exit does NOT wait for the streams the deadline
+    has just declared stuck — and later waits on that context fail at once."""
+    outs = _run_workers(tmp_path, 2, True, 0, extra_env={"ZKHIP_RCCL_LIB": _fake_rccl(), "ZKHIP_COMM_TRANSPORT": "rccl", "ZKFAKE_RCCL_SLOT_MB": "8",
+                                                         "ZK_STALL_TEST": "proof", "ZKFAKE_RCCL_STALL_S": "40",
+                                                         "ZKHIP_COMM_TIMEOUT_MS": "2000"}, timeout=300)
+    err = outs[0]["error"]
+    assert err and "a host wait exceeded 2000 ms" in err and "rank 0 of 2 stuck" in err, err
+    assert outs[0]["elapsed_s"] < 20.0, outs[0]
 
 
 def test_agg_k22_proof_over_two_ranks_through_the_rccl_branch(zk, tmp_path):
