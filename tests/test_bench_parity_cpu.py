@@ -77,3 +77,17 @@ def test_supervisor_compares_the_workers_digests_with_the_cpu_leg(tmp_path):
     r, lines = _supervised(tmp_path / "b", "00" * 32)
     assert r.returncode != 0, r.stderr[-2000:]          # the supervisor exits 3; torch.distributed.run reports a failed child as 1
     assert lines[0]["parity"]["bytes_equal"] is False and "PARITY FAILURE" in r.stderr
+
+
+def test_the_recorded_rsa_k17_digest_is_this_trees_oracle():
+    """tests/golden/cpu_oracle_proof_digests.json was written on the GPU box's host cores; the k = 17 row is cheap enough to regenerate here:
+    the oracle in THIS tree still produces it (the k = 19 / 20 / 22 rows came from the same process family: profiles/r05_cpu_parity.json)"""
+    import halo2_zkcert_amd.prover as pv
+    from oracle_backend import OracleBackend
+
+    with open(os.path.join(ROOT, "tests", "golden", "cpu_oracle_proof_digests.json")) as f:
+        want = json.load(f)["digests"]
+    assert set(want) == {"agg_k22_a3+1/evm/witness0", "sha256_k19/poseidon/witness0", "rsa_k17/poseidon/witness0", "agg_k20_a3+1/evm/witness0"}
+    p = pv.Prover(OracleBackend(os.cpu_count() or 8), pv.CircuitShape.rsa(17), satisfiable=True)
+    got = hashlib.sha256(bytes(p.prove(p.witness(0), transcript="poseidon")["proof"])).hexdigest()
+    assert got == want["rsa_k17/poseidon/witness0"]

@@ -1,4 +1,6 @@
 """GPU parity: the whole create_proof-shaped pass (16 commitments + quotient pieces) vs the oracle backend."""
+import hashlib
+import json
 import os
 
 import numpy as np
@@ -406,6 +408,11 @@ def test_rsa_k17_poseidon_proof_bytes_verify(zk, oracle):
     assert not verify_proof(gp, w, bytes(bad), "poseidon", oracle_vk=True)
 
 
+def _cpu_oracle_digest(key):
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cpu_oracle_proof_digests.json")) as f:
+        return json.load(f)["digests"][key]
+
+
 def test_rsa_k17_proof_bytes_equal_the_cpu_oracle(zk, oracle):
     """north_star's own sentence at a BASELINE size: "proof bytes bit-identical to the reference CPU prover on the same SRS and witness".
     BASELINE configs[1] (RSA k = 17, the c = 16 window, the 2^17 NTT pass plan — kernels no k <= 12 case selects) under the transcript
@@ -419,6 +426,7 @@ def test_rsa_k17_proof_bytes_equal_the_cpu_oracle(zk, oracle):
     want = bytes(cp.prove(cp.witness(0), transcript="poseidon")["proof"])
     got = bytes(gp.prove_native(wg, transcript="poseidon")["proof"])
     assert len(want) > 1000 and got == want
+    assert hashlib.sha256(want).hexdigest() == _cpu_oracle_digest("rsa_k17/poseidon/witness0")      # the recorded digest is this oracle's
     assert bytes(gp.prove_native(wg, transcript="poseidon", host_inputs=True)["proof"]) == want
     gp.release()
     gp.b.params.free()
@@ -464,6 +472,7 @@ def test_sha_k19_satisfiable_proof_verifies(zk, oracle):
     t1 = gp.prove_native(w, transcript="poseidon", fetch_h=True)
     assert t1["n_commitments"] == 40
     assert verify_proof(gp, w, t1["proof"], "poseidon")
+    assert hashlib.sha256(bytes(t1["proof"])).hexdigest() == _cpu_oracle_digest("sha256_k19/poseidon/witness0")      # == the CPU oracle's bytes (recorded digest)
     sm = zo.fr_from_int(s)
     qc = [c for tag, c in t1["commitments"] if tag == "quotient"]
     assert len(qc) == 4
@@ -588,6 +597,9 @@ def test_agg_k22_evm_proof_bytes_verify(zk, oracle):
     t = gp.prove_native(w, transcript="evm")
     assert t["n_commitments"] == 16 and len(t["proof"]) == 64 * 16 + 32 * (len(t["evals"]) - 1)
     assert verify_proof(gp, w, t["proof"], "evm")
+    # ... and they are the bytes the CPU oracle produced for this instance (north_star: bit-identical to the CPU prover on the same SRS and
+    # witness): the recorded digest of the oracle's two-minute pass on the GPU box's host cores (tests/golden/cpu_oracle_proof_digests.json)
+    assert hashlib.sha256(bytes(t["proof"])).hexdigest() == _cpu_oracle_digest("agg_k22_a3+1/evm/witness0")
     bf, n = sh.blinding_factors, 1 << sh.k
     host = dict(lookup_permuted=ctx.to_host(ctx.synth_fill(2 * (bf + 1), 11)), perm_z=ctx.to_host(ctx.synth_fill(sh.n_perm_sets * bf, 12)),
                 lookup_z=ctx.to_host(ctx.synth_fill(bf, 13)), random_poly=ctx.to_host(ctx.synth_fill(n, 14)))
