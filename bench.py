@@ -491,6 +491,8 @@ def main():
     ap.add_argument("--of", type=int, default=0, help="with --replay-rank: the rank count N being replayed")
     ap.add_argument("--replay-latency-us", type=float, default=0.0, help="with --replay-rank: modelled latency of one exchange (0: exchanges cost only the fabricating fill)")
     ap.add_argument("--replay-link-gbs", type=float, default=0.0, help="with --replay-rank: modelled xGMI bandwidth per peer link and direction, GB/s (0: not modelled)")
+    ap.add_argument("--row-sharded", type=int, default=None, choices=[0, 1], help="sharded proofs: 0 = all-gathers of complete columns instead of the all-to-all of row windows "
+                    "(the library's row_sharded option; default: the library's, 1)")
     ap.add_argument("--agg-unsharded", action="store_true", help="--chain, N >= 4: the aggregation proof on rank 0 alone (last rung of the ladder: no collective)")
     args = ap.parse_args()
 
@@ -555,6 +557,8 @@ def worker(args):
     shard = (world > 1 or replay) and not args.replicas and not (args.chain and args.agg_unsharded)
     nshare = args.of if replay else world        # ranks the sharded proof is split over
     replay_lib = None
+    if args.row_sharded is not None:
+        ctx.set_option("row_sharded", args.row_sharded)
     if world > 1:
         ctx.set_option("comm_timeout_ms", args.comm_timeout_ms)
     if replay:

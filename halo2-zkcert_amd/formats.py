@@ -44,6 +44,40 @@ def advice_columns_from_break_points(break_points):
     return [len(p) + 1 for p in break_points]
 
 
+# ----------------------------------------------------------------------------- SRS (ParamsKZG::write)
+class ParamsFile:
+    """halo2_proofs ParamsKZG<Bn256>::write (poly/kzg/commitment.rs, SerdeFormat::RawBytes) [UPSTREAM-RECALL] on the HOST — the file the
+    reference keeps under PARAMS_DIR as kzg_bn254_{k}.srs (/root/reference/src/bin/cli.rs:222): k as u32 LE | g (n points) | g_lagrange
+    (n points) | g2 | s_g2; a G1 point is x then y as 4 LE u64 Montgomery limbs each, a G2 point 128 bytes (x.c0, x.c1, y.c0, y.c1).
+    ffi.ParamsKZG.read / .write move the same layout to and from the device; this class is the host-only view (tests, tools)."""
+
+    def __init__(self, k, g, g_lagrange, g2_bytes):
+        self.k = int(k)
+        self.g = np.ascontiguousarray(g, dtype="<u8").reshape(-1, 8)
+        self.g_lagrange = np.ascontiguousarray(g_lagrange, dtype="<u8").reshape(-1, 8)
+        self.g2_bytes = bytes(g2_bytes)
+        n = 1 << self.k
+        if len(self.g) != n or len(self.g_lagrange) != n or len(self.g2_bytes) != 256:
+            raise ValueError(f"ParamsFile: k = {self.k} needs {n} + {n} G1 points and 256 G2 bytes (got {len(self.g)}, {len(self.g_lagrange)}, {len(self.g2_bytes)})")
+
+    @classmethod
+    def parse(cls, buf):
+        buf = bytes(buf)
+        if len(buf) < 4:
+            raise ValueError("params file truncated")
+        k = int.from_bytes(buf[:4], "little")
+        if not 1 <= k <= 28:
+            raise ValueError(f"k = {k} is not a KZG parameter file")
+        n = 1 << k
+        if len(buf) != 4 + 2 * n * 64 + 256:
+            raise ValueError(f"params file: {len(buf)} bytes for k = {k} (expected {4 + 2 * n * 64 + 256}: another layout, or truncated)")
+        pts = np.frombuffer(buf, dtype="<u8", count=2 * n * 8, offset=4).reshape(2, n, 8)
+        return cls(k, pts[0], pts[1], buf[4 + 2 * n * 64:])
+
+    def to_bytes(self):
+        return self.k.to_bytes(4, "little") + self.g.tobytes() + self.g_lagrange.tobytes() + self.g2_bytes
+
+
 # ----------------------------------------------------------------------------- proving key (SerdeFormat::RawBytesUnchecked)
 class _Reader:
     def __init__(self, buf):
@@ -250,6 +284,10 @@ class SnarkFile:
             return cls(buf[:protocol_len], got[0], got[1])
         # no length given: the (instances, proof) suffix is the unique offset from which both parse and end at the end of the file
         hits = [(o, t) for o in range(0, max(1, len(buf) - 15)) if (t := cls._parse_tail(buf, o)) is not None and len(t[1]) >= 64]
+        # a small last instance value ends in zero bytes: the 8 of them before the proof's length read as "zero instance columns" followed by
+        # that very length — an artefact of the true suffix, dropped when a candidate WITH instance columns exists
+        if len(hits) > 1 and any(t[0] for _, t in hits):
+            hits = [(o, t) for o, t in hits if t[0]]
         if len(hits) != 1:
             raise ValueError(f"{path}: {len(hits)} candidate offsets for the instances / proof suffix; pass protocol_len")
         o, (cols, proof) = hits[0]

@@ -687,6 +687,27 @@ class Prover:
         # vk.transcript_repr stand-in (upstream: a Blake2b hash of the verifying key's Debug form, absorbed first by vk.hash_into)
         self.vk_repr = fr_from_int_host(int.from_bytes(hashlib.blake2b(sh.name.encode(), digest_size=64).digest(), "little") % R)
 
+    @classmethod
+    def from_explicit(cls, backend, shape, fixed_columns, copy_cells, srs_trapdoor=0x1D5C0FFEE, vk_repr=None):
+        """A proving key from EXPLICIT data instead of the synthetic keygen: fixed_columns = one (n, 4) uint64 host array (ABI form) per
+        fixed column of the shape; copy_cells = [(permutation column, row, permutation column, row)] two-cycles over shape.perm_columns;
+        vk_repr = the verifying key's transcript representation (ABI limbs) or None for the stand-in.  What a circuit written against
+        upstream's API hands to keygen — the consumer of tests/golden/reference_vectors.json's `prover` section builds its key this way."""
+        p = cls(backend, shape, srs_trapdoor=srs_trapdoor, satisfiable=False)
+        b, n = backend, 1 << shape.k
+        if len(fixed_columns) != shape.n_fixed:
+            raise ValueError(f"{len(fixed_columns)} fixed columns for a shape with {shape.n_fixed}")
+        p.fixed_lagrange = [b.from_host(np.ascontiguousarray(c, dtype=np.uint64).reshape(n, 4)) for c in fixed_columns]
+        p._set_copy_constraints([(ca * n + ra, cb * n + rb) for ca, ra, cb, rb in copy_cells])
+        p.fixed_coeff = b.clone(p.fixed_lagrange)
+        b.lagrange_to_coeff(p.fixed_coeff)
+        p.sigma_coeff = b.clone(p.sigma_lagrange)
+        b.lagrange_to_coeff(p.sigma_coeff)
+        p.key_source = "explicit"
+        if vk_repr is not None:
+            p.vk_repr = np.ascontiguousarray(vk_repr, dtype=np.uint64).reshape(4)
+        return p
+
     def _extended_key(self):
         if self._ext is None and getattr(self, "_ext_file", None) is not None:
             kf, b = self._ext_file, self.b
@@ -942,6 +963,10 @@ class Prover:
         """Witness synthesis of a later phase (the circuit's job upstream: `synthesize` runs again with the challenges of the earlier
         phases): fills wit["advice"][c] for the columns of `phase`.  user_challenges: canonical ints, index = challenge index."""
         sh = self.shape
+        if wit.get("advice_for_phase") is not None:      # the caller's own synthesis (a witness that did not come from witness())
+            wit["advice_for_phase"](wit, phase, user_challenges)
+            wit.pop("advice_host", None)
+            return
         for c in range(sh.n_advice):
             if sh.advice_phase[c] == phase and phase > 0:
                 wit["advice"][c] = self.b.lincomb([wit["advice"][0]], [user_challenges[0]], None)
@@ -1246,12 +1271,25 @@ class Prover:
         trace["n_commitments"] = len(trace["commitments"])
         return trace
 
-    def prove(self, wit, transcript="blake2b-py"):
+    def prove(self, wit, transcript="blake2b-py", blinding=None):
         """One pass.  Returns the transcript trace: every commitment's bytes and the challenges.  transcript: "blake2b-py"
-        (Blake2bTranscript above), or the library's "blake2b" / "evm" / "poseidon" driven from here (make_transcript)."""
+        (Blake2bTranscript above), or the library's "blake2b" / "evm" / "poseidon" driven from here (make_transcript).
+        blinding: None = the seeded generator (wit["base"]); or the caller's rng draws as in prove_native: dict(lookup_permuted
+        (2 L (bf + 1), 4), perm_z (Zp bf, 4), lookup_z (L bf, 4), random_poly (n, 4)) of uint64 host arrays."""
         sh, b, n, dom = self.shape, self.b, self.n, self.dom
         base = wit["base"]
         L, Zp = len(sh.lookups), sh.n_perm_sets
+        bf_ = sh.blinding_factors
+        if blinding is not None:
+            hostb = {k_: np.ascontiguousarray(v_, dtype=np.uint64).reshape(-1, 4) for k_, v_ in blinding.items() if v_ is not None}
+            draw = dict(random_poly=lambda: b.from_host(hostb["random_poly"]),
+                        permuted=lambda j: b.from_host(hostb["lookup_permuted"][j * (bf_ + 1):(j + 1) * (bf_ + 1)]),
+                        perm_z=lambda: b.from_host(hostb["perm_z"]) if Zp * bf_ else b.synth(0, 0),
+                        lookup_z=lambda: b.from_host(hostb["lookup_z"]) if L * bf_ else b.synth(max(1, L) * bf_, 0))
+        else:
+            draw = dict(random_poly=lambda: b.synth(n, base + 380),
+                        permuted=lambda j: b.synth(bf_ + 1, base + (300 if j % 2 == 0 else 320) + j // 2),
+                        perm_z=lambda: b.synth(Zp * bf_, base + 340), lookup_z=lambda: b.synth(max(1, L) * bf_, base + 360))
         trace = {"commitments": [], "challenges": {}, "points": {}, "transcript": transcript}
         ts = make_transcript(transcript)
         # vk.hash_into(transcript), then every instance value (KZG: instances are hashed, not committed)
@@ -1274,7 +1312,7 @@ class Prover:
         #    stream as soon as their inputs exist, so they run beside the latency-bound MSM tails.
         #    Phases (CircuitShape.advice_phase): the columns of phase p are committed and absorbed, then the user challenges of phase p are
         #    squeezed, then the witness of phase p + 1 is synthesised with them (advice_for_phase) — upstream's loop over `phases`.
-        rand_poly = [b.synth(n, base + 380)]
+        rand_poly = [draw["random_poly"]()]
         user_ch, rand_commit = [], None
         for ph in sh.phases:
             if ph > 0:
@@ -1300,7 +1338,7 @@ class Prover:
         bf = sh.blinding_factors
         compressed = [(b.compress(gi, self.fixed_lagrange, wit["advice"], wit["instance"], theta, sh.k),
                        b.compress(gt, self.fixed_lagrange, wit["advice"], wit["instance"], theta, sh.k)) for gi, gt in self.compress_graphs]
-        permuted = [b.permute(sh.k, bf, compressed[i][0], compressed[i][1], b.synth(bf + 1, base + 300 + i), b.synth(bf + 1, base + 320 + i))
+        permuted = [b.permute(sh.k, bf, compressed[i][0], compressed[i][1], draw["permuted"](2 * i), draw["permuted"](2 * i + 1))
                     for i in range(L)]
         perm_in_l, perm_tab_l = [p_[0] for p_ in permuted], [p_[1] for p_ in permuted]
         perm_in, perm_tab = b.clone(perm_in_l), b.clone(perm_tab_l)
@@ -1314,9 +1352,9 @@ class Prover:
         # 3. grand products: permutation (chunks of degree-2 columns) and one per lookup; blinding rows are seeded stand-ins
         cols = {"advice": wit["advice"], "fixed": self.fixed_lagrange, "instance": wit["instance"]}
         perm_values = [cols[t][i] for t, i in sh.perm_columns]
-        perm_z, look_z = b.grand_products(sh.k, beta, gamma, bf, perm_values, self.sigma_lagrange, sh.degree - 2, b.synth(Zp * bf, base + 340),
+        perm_z, look_z = b.grand_products(sh.k, beta, gamma, bf, perm_values, self.sigma_lagrange, sh.degree - 2, draw["perm_z"](),
                                           [(compressed[i][0], compressed[i][1], perm_in_l[i], perm_tab_l[i]) for i in range(L)],
-                                          b.synth(max(1, L) * bf, base + 360))
+                                          draw["lookup_z"]())
         b.lagrange_to_coeff(perm_z + look_z)
         with b.overlap():
             ext_prod = b.coeff_to_extended(look_z + perm_z)

@@ -11,6 +11,8 @@ use halo2_proofs::transcript::{Blake2bWrite, Challenge255, Transcript, Transcrip
 use halo2curves::bn256::{Fr, G1Affine, G1};
 use serde_json::json;
 
+mod prover_vectors;
+
 fn splitmix64(x: u64) -> u64 {
     let mut z = x.wrapping_add(0x9E3779B97F4A7C15);
     z = (z ^ (z >> 30)).wrapping_mul(0xBF58476D1CE4E5B9);
@@ -117,6 +119,9 @@ fn main() {
     };
     let out = json!({ "source": "halo2curves e185711 / halo2_proofs 4b42325 / snark-verifier-sdk 7011e8c (the reference's pins)",
                       "constants": constants, "msm": msm, "fft": fft, "domain": domain,
+                      // whole create_proof runs (small(6), two_phase(6)) under the three transcripts with a replayable rng, the verifying key's
+                      // transcript representation, and the bytes of ParamsKZG::write / ProvingKey::write / bincode(Snark): prover_vectors.rs
+                      "prover": prover_vectors::emit(),
                       "transcripts": { "sequence": "common_scalar(7), write_point(5 G), write_scalar(0x1234567890abcdef), squeeze, squeeze",
                                        "blake2b": blake, "poseidon": poseidon, "evm": evm } });
     println!("{}", serde_json::to_string_pretty(&out).unwrap());

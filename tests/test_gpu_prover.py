@@ -702,3 +702,24 @@ def test_two_phase_circuit_native_schedule_and_oracle_agree(zk, oracle, k):
     assert rc == -1 and b"advice_phase is NULL" in ffi.lib().zkhip_last_error()
     gp.release()
     gp.b.params.free()
+
+
+def test_hip_consumer_of_the_prover_vectors_on_a_self_made_file(zk, oracle, tmp_path, monkeypatch):
+    """tests/test_reference_vectors.py::test_hip_create_proof_equals_upstreams_bytes — zkhip_create_proof_ex on an EXPLICIT circuit (key data,
+    witness and every rng draw from the file, Prover.from_explicit + zk_blinding), bytes and challenges compared — driven by a file of the same
+    schema written from the oracle (tests/refvec_util.py: self-made, pins nothing): the consumer that will meet upstream's file
+    (integration/rust/refvec, /root/reference/Cargo.lock:1320-1322) runs on the GPU today, for small(6) and two_phase(6) under all three transcripts."""
+    import importlib
+
+    import halo2_zkcert_amd.formats as fm
+    import refvec_util as ru
+    from verify_util import verify_proof, vk_commitments
+
+    ffi, ctx = zk
+    doc = {"prover": ru.emit_prover_section(pv, oracle, ffi, fm, verify_proof, vk_commitments, tmp_path)}
+    path = tmp_path / "reference_vectors.json"
+    path.write_text(json.dumps(doc))
+    mod = importlib.import_module("test_reference_vectors")
+    monkeypatch.setattr(mod, "PATH", str(path))
+    for which in ("small", "two_phase"):
+        mod.test_hip_create_proof_equals_upstreams_bytes(zk, oracle, which)

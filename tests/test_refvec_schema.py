@@ -10,19 +10,28 @@ import os
 import re
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MAIN_RS = os.path.join(ROOT, "integration", "rust", "refvec", "src", "main.rs")
+PROVER_RS = os.path.join(ROOT, "integration", "rust", "refvec", "src", "prover_vectors.rs")      # the `prover` section (round 5)
+UTIL = os.path.join(ROOT, "tests", "refvec_util.py")                                             # ... and its consumer-side helper
+
+
+def _emitted_keys():
+    return set(re.findall(r'"([a-z_0-9]+)"\s*:', open(MAIN_RS).read() + open(PROVER_RS).read()))
 CONSUMER = os.path.join(ROOT, "tests", "test_reference_vectors.py")
 
 
 def test_refvec_emits_every_key_the_tests_read():
-    rs = open(MAIN_RS).read()
-    emitted = set(re.findall(r'"([a-z_0-9]+)"\s*:', rs))
-    src = open(CONSUMER).read()
-    read = set(re.findall(r'\b(?:v|c|d|_load\(\))\["([a-z_0-9]+)"\]', src)) | set(re.findall(r'\]\["([a-z_0-9]+)"\]', src))
-    read |= {"blake2b", "poseidon", "evm"}          # for kind in (...): v[kind]
-    assert len(read) > 25, read
+    rs = open(MAIN_RS).read() + open(PROVER_RS).read()
+    emitted = _emitted_keys()
+    src = open(CONSUMER).read() + open(UTIL).read()
+    read = set(re.findall(r'\b(?:v|c|d|cs|doc|ref|files|circuit|_load\(\))\["([a-z_0-9]+)"\]', src)) | set(re.findall(r'\]\["([a-z_0-9]+)"\]', src))
+    read |= set(re.findall(r'\b(?:doc|files|v)\.get\("([a-z_0-9]+)"', src))
+    read |= {"blake2b", "poseidon", "evm", "small", "two_phase"}          # for kind in (...): v[kind]; parametrised sections
+    read -= {"advice_for_phase", "user"}                                    # keys of this repository's own witness / trace dicts, not of the file
+    assert len(read) > 50, read
     missing = sorted(read - emitted)
     assert not missing, f"tests/test_reference_vectors.py reads keys that refvec/src/main.rs never emits: {missing}"
     # the pins the program is to be built against are the reference's
@@ -66,6 +75,30 @@ def _self_made(zo, P, ffi, pv):
     return {"source": "SELF-MADE from oracle/ (schema check only; pins nothing)", "constants": constants, "msm": msm, "fft": fft, "domain": domain, "transcripts": tr}
 
 
+def test_the_explicit_circuit_is_satisfiable_and_matches_the_shape():
+    """refvec_util.build_circuit (the restatement of prover_vectors.rs ShapeCircuit::build): every gate, copy and lookup holds on the usable
+    rows — upstream's verifier must accept the proof the Rust side makes from the same values"""
+    import refvec_util as ru
+
+    for two_phase in (False, True):
+        c = ru.build_circuit(two_phase)
+        H = ru.H
+        fixed, adv, inst = [[H(x) for x in col] for col in c["fixed"]], [[H(x) for x in col] for col in c["advice"]], [H(x) for x in c["instance"][0]]
+        u = c["usable_rows"]
+        assert u == 57 and all(len(col) == u for col in fixed + adv)
+        for col in (0, 1):
+            for r in range(u - 3):
+                assert fixed[col][r] * (adv[col][r] + adv[col][r + 1] * adv[col][r + 2] - adv[col][r + 3]) % ru.R == 0
+            assert all(fixed[col][r] == 0 for r in range(u - 3, u))          # no gate reaches into the blinding rows
+        assert set(adv[2]) <= set(fixed[3])
+        n_adv = 4 if two_phase else 3
+        cell = lambda pc, r: adv[pc][r] if pc < 3 else (None if pc < n_adv else (fixed[2][r] if pc == n_adv else inst[r]))
+        cells = [(a, b) for a, ra, b, rb in c["copies"] for a, b in [((a, ra), (b, rb))]]
+        assert len(set(x for pair in cells for x in pair)) == 2 * len(cells)          # disjoint two-cycles
+        for (a, ra), (b, rb) in cells:
+            assert cell(a, ra) == cell(b, rb)
+
+
 def test_consumer_runs_on_a_file_of_that_schema(oracle, tmp_path, monkeypatch):
     import pyref as P
 
@@ -75,10 +108,15 @@ def test_consumer_runs_on_a_file_of_that_schema(oracle, tmp_path, monkeypatch):
     import halo2_zkcert_amd.ffi as ffi
     import halo2_zkcert_amd.prover as pv
 
+    import halo2_zkcert_amd.formats as fm
+    import refvec_util as ru
+    from verify_util import verify_proof, vk_commitments
+
     doc = _self_made(oracle, P, ffi, pv)
+    doc["prover"] = ru.emit_prover_section(pv, oracle, ffi, fm, verify_proof, vk_commitments, tmp_path)
+    assert all(doc["prover"][w]["proofs"][kind]["verified"] for w in ("small", "two_phase") for kind in ("blake2b", "poseidon", "evm"))
     # the self-made file has exactly the keys refvec emits (nested), no more, no fewer
-    rs = open(MAIN_RS).read()
-    emitted = set(re.findall(r'"([a-z_0-9]+)"\s*:', rs))
+    emitted = _emitted_keys()
 
     def keys(o):
         if isinstance(o, dict):
@@ -96,3 +134,12 @@ def test_consumer_runs_on_a_file_of_that_schema(oracle, tmp_path, monkeypatch):
     mod.test_constants_and_encodings(oracle)
     mod.test_transcripts(oracle)
     mod.test_oracle_msm_fft_domain(oracle)
+    for which in ("small", "two_phase"):
+        mod.test_oracle_create_proof_equals_upstreams_bytes(oracle, which)
+    mod.test_files_written_by_upstream_parse_and_round_trip(oracle, tmp_path)
+    # a stream with upstream's extra Blind draws is recognised by its count and mapped accordingly; any other count is reported, not guessed
+    sh = ru.shape_of(pv, doc["prover"]["small"]["circuit"])
+    assert ru.pick_model(sh, 8 * ru.expected_fr_draws(sh, "blinds")) == "blinds" and ru.pick_model(sh, 8 * ru.expected_fr_draws(sh, "kzg")) == "kzg"
+    assert ru.draw_roles(sh, "blinds")["u64_drawn"] == 8 * ru.expected_fr_draws(sh, "blinds") and ru.draw_roles(sh, "blinds")["random_poly"] != ru.draw_roles(sh, "kzg")["random_poly"]
+    with pytest.raises(AssertionError, match="upstream's order is another one"):
+        ru.pick_model(sh, 8 * ru.expected_fr_draws(sh, "kzg") + 8)
