@@ -279,10 +279,10 @@ LADDER = {
               ("independent proofs, one per GPU (no collective on the data path)", ["--replicas"], {"ZKHIP_BENCH_DIST_BACKEND": "gloo"})],
     "replicas": [("independent proofs, one per GPU", [], {}),
                  ("independent proofs, one per GPU, torch control plane on gloo", [], {"ZKHIP_BENCH_DIST_BACKEND": "gloo"})],
-    "chain": [("leaf proofs on ranks 0-3, aggregation proof row-sharded over all ranks", [], {}),
-              ("aggregation proof with the all-gather exchange, torch control plane on gloo", [], {"ZKHIP_ROW_SHARDED": "0", "ZKHIP_BENCH_DIST_BACKEND": "gloo"}),
-              ("aggregation proof with MSMs by column", ["--shard", "columns"], {"ZKHIP_ROW_SHARDED": "0", "ZKHIP_BENCH_DIST_BACKEND": "gloo"}),
-              ("aggregation proof on rank 0 alone (no collective on the data path)", ["--agg-unsharded"], {"ZKHIP_BENCH_DIST_BACKEND": "gloo"})],
+    "chain": [("leaf proofs on ranks 0-3 (N >= 6: the SHA leaves over rank groups), aggregation proof row-sharded over all ranks", [], {}),
+              ("one leaf per rank 0-3, aggregation proof with the all-gather exchange, torch control plane on gloo", ["--no-leaf-groups"], {"ZKHIP_ROW_SHARDED": "0", "ZKHIP_BENCH_DIST_BACKEND": "gloo"}),
+              ("one leaf per rank 0-3, aggregation proof with MSMs by column", ["--no-leaf-groups", "--shard", "columns"], {"ZKHIP_ROW_SHARDED": "0", "ZKHIP_BENCH_DIST_BACKEND": "gloo"}),
+              ("one leaf per rank 0-3, aggregation proof on rank 0 alone (no collective on the data path)", ["--no-leaf-groups", "--agg-unsharded"], {"ZKHIP_BENCH_DIST_BACKEND": "gloo"})],
 }
 
 
@@ -491,8 +491,11 @@ def main():
     ap.add_argument("--of", type=int, default=0, help="with --replay-rank: the rank count N being replayed")
     ap.add_argument("--replay-latency-us", type=float, default=0.0, help="with --replay-rank: modelled latency of one exchange (0: exchanges cost only the fabricating fill)")
     ap.add_argument("--replay-link-gbs", type=float, default=0.0, help="with --replay-rank: modelled xGMI bandwidth per peer link and direction, GB/s (0: not modelled)")
+    ap.add_argument("--msm-c", type=int, default=None, help="window width of the SRS tables built in this run (the library's msm_c option; default: by size)")
     ap.add_argument("--row-sharded", type=int, default=None, choices=[0, 1], help="sharded proofs: 0 = all-gathers of complete columns instead of the all-to-all of row windows "
                     "(the library's row_sharded option; default: the library's, 1)")
+    ap.add_argument("--no-leaf-groups", action="store_true", help="--chain, N >= 6: every leaf proof on one rank (ranks 4.. idle until the aggregation proof) instead of the "
+                    "SHA-shaped leaves over rank groups")
     ap.add_argument("--agg-unsharded", action="store_true", help="--chain, N >= 4: the aggregation proof on rank 0 alone (last rung of the ladder: no collective)")
     args = ap.parse_args()
 
@@ -559,6 +562,8 @@ def worker(args):
     replay_lib = None
     if args.row_sharded is not None:
         ctx.set_option("row_sharded", args.row_sharded)
+    if args.msm_c is not None:
+        ctx.set_option("msm_c", args.msm_c)
     if world > 1:
         ctx.set_option("comm_timeout_ms", args.comm_timeout_ms)
     if replay:
@@ -851,14 +856,38 @@ def worker(args):
         agg_here = shard or vworld == 1 or vrank == 0        # --agg-unsharded (last rung of the ladder): the aggregation proof on rank 0 alone
         leaf_ctx = ffi.Context(local_rank) if shard else ctx
         leaf_names = ["rsa17", "sha19", "rsa17", "sha19"]
-        mine = leaf_names if vworld == 1 else ([leaf_names[vrank]] if vrank < 4 else [])
+        # Who proves which leaf.  Leaf j's head is rank j; from N = 6 on the ranks 4.. — idle until the aggregation proof when every leaf sits on
+        # one rank, while the SHA-shaped leaves take 4.5x as long as the RSA ones — are dealt to the two SHA leaves in turn (N = 8: leaf 1 over
+        # ranks 1, 4, 6, leaf 3 over ranks 3, 5, 7): such a leaf is ONE proof over its group's own communicator, MSMs by column (k = 19: one MSM
+        # cannot fill several GPUs), the same bytes on every member.  The leaf contexts' communicators are used before the barrier, the
+        # aggregation proof's after it: never two collectives of different communicators in flight on one device.
+        groups = {j: [j] for j in range(4)}
+        if shard and vworld >= 6 and not args.no_leaf_groups:
+            for e_, r_ in enumerate(range(4, vworld)):
+                groups[1 if e_ % 2 == 0 else 3].append(r_)
+        my_leaf = next((j for j, rs in groups.items() if vrank in rs), None)
+        if any(len(rs) > 1 for rs in groups.values()):
+            pgs = {}
+            if not replay:
+                for j in sorted(groups):      # (new_group is collective over ALL ranks, in the same order everywhere)
+                    if len(groups[j]) > 1:
+                        pgs[j] = dist.new_group(groups[j])
+            if my_leaf is not None and len(groups[my_leaf]) > 1:
+                rs = groups[my_leaf]
+                if world > 1:
+                    leaf_ctx.set_option("comm_timeout_ms", args.comm_timeout_ms)
+                if replay:
+                    leaf_ctx.comm_init_replay(rs.index(vrank), len(rs), os.path.join(ROOT, "tools", "replay_rccl", "libreplay_rccl.so"))
+                else:
+                    leaf_ctx.comm_init(rs.index(vrank), len(rs), dist, group=pgs[my_leaf], src=rs[0])
+                leaf_ctx.comm_shard("columns")
+        mine = list(enumerate(leaf_names)) if vworld == 1 else ([(my_leaf, leaf_names[my_leaf])] if my_leaf is not None else [])
         leaves, pairs = [], 0.0
-        for j, nm in enumerate(mine):
+        for j, nm in mine:
             sh_ = make_shape(pv, nm, args)
             pr_ = pv.Prover(pv.GpuBackend(leaf_ctx, ffi), sh_, satisfiable=True)
-            ws_ = j if vworld == 1 else vrank
-            leaves.append((pr_, dict(pr_.witness(ws_), seed=ws_), TRANSCRIPT[nm]))
-            pairs += sh_.counts(pr_.dom.extended_k)["msm"] * float(1 << sh_.k)
+            leaves.append((pr_, dict(pr_.witness(j), seed=j), TRANSCRIPT[nm]))      # witness j: the same instance on every member of leaf j's group
+            pairs += sh_.counts(pr_.dom.extended_k)["msm"] * float(1 << sh_.k) / len(groups[j] if vworld > 1 else [0])
         if shard:
             ctx.comm_shard("points" if args.shard == "auto" else args.shard)
         agg = agg_w = None
@@ -930,7 +959,9 @@ def worker(args):
         if vworld == 1:
             par = "5 proofs in sequence on 1 GPU"
         elif shard:
-            par = f"leaf proofs on ranks 0-3 (one each), then one proof sharded x{vworld}"
+            par = ("leaf proofs " + ", ".join(f"{leaf_names[j]} on rank{'s' if len(rs) > 1 else ''} {'+'.join(map(str, rs))}" for j, rs in sorted(groups.items()))
+                   + (" (a leaf over several ranks: one proof on the group's own communicator, MSMs by column)" if any(len(rs) > 1 for rs in groups.values()) else "")
+                   + f", barrier, then one proof sharded x{vworld}")
         else:
             par = "leaf proofs on ranks 0-3 (one each), then the aggregation proof on rank 0 alone (no collective on the data path)"
         res = {"value": round(dt / steps, 6), "unit": "s", "steps": steps, "warmup": warmup, "ms_per_step": round(dt * 1000.0 / steps, 3), "proofs_per_step": 5,
@@ -939,11 +970,21 @@ def worker(args):
                "parallelism": par, "proof_bytes": list(sizes), "proof_sha256": list(digests), "roofline": roof,
                "phase_ms_per_step": {"leaf_proofs_until_the_barrier": round(phase_s["leaf"] * 1000.0 / steps, 3), "aggregation_proof": round(phase_s["agg"] * 1000.0 / steps, 3),
                                      "note": "host wall clock on this rank; the barrier (and a device synchronize) separates the two phases"},
-               "replay_exchanges_per_step": rstats,
+               "replay_exchanges_per_step": rstats, "leaf_proof_sha256": leaf_digests, "leaf_groups": {str(j): rs for j, rs in sorted(groups.items())},
                "bytes_gathered_per_step": (ctx.comm_bytes_gathered() - g0) // steps if shard else 0,
                "collectives_per_step": (ctx.comm_describe()["collectives"] - c0) / steps if shard else 0}
         for item in ([] if replay else last):
             note_proof(*item)
+        # every rank's leaf digest to rank 0: the members of a leaf's group must hold the same bytes, and the line carries all four leaves'
+        leaf_digests = {str(w_["seed"]): d_ for (pr_, w_, _), d_ in zip(leaves, digests)}
+        if world > 1:
+            got = [None] * world
+            dist.all_gather_object(got, leaf_digests)
+            leaf_digests = {}
+            for r_, g_ in enumerate(got):
+                for j_, d_ in (g_ or {}).items():
+                    if leaf_digests.setdefault(j_, d_) != d_:
+                        raise SystemExit(f"bench.py: rank {r_} holds another proof of leaf {j_} than a lower rank of its group")
         for pr_, _, _ in leaves:
             pr_.release()
             pr_.b.params.free()
@@ -951,6 +992,8 @@ def worker(args):
             agg.release()
             agg.b.params.free()
         if leaf_ctx is not ctx:
+            if leaf_ctx.world > 1 and not replay:
+                leaf_ctx.comm_destroy()
             leaf_ctx.close()
         return res
 
@@ -993,7 +1036,8 @@ def worker(args):
                               "config": {"workload": res["workload"], "parallelism": res["parallelism"], "k": args.agg_k, "transcript": "evm"}, "proof_bytes": res["proof_bytes"], "proof_sha256": res["proof_sha256"],
                               "comm": comm_fields(res["bytes_gathered_per_step"], "points" if args.shard == "auto" else args.shard, res["collectives_per_step"]),
                               "roofline": res["roofline"], "cpu_baseline": cb, "gpu_proofs": gpu_proofs, "parity": parity, "build": bh,
-                              "phase_ms_per_step": res["phase_ms_per_step"], **({"replay": replay_block(res["replay_exchanges_per_step"])} if replay else {})}), flush=True)
+                              "phase_ms_per_step": res["phase_ms_per_step"], "leaf_proof_sha256": res["leaf_proof_sha256"], "leaf_groups": res["leaf_groups"],
+                              **({"replay": replay_block(res["replay_exchanges_per_step"])} if replay else {})}), flush=True)
             if parity and parity["bytes_equal"] is False:
                 print("bench.py: PARITY FAILURE: a HIP-path proof differs from the CPU oracle's: " + json.dumps([r for r in parity["compared"] if not r["equal"]]), file=sys.stderr, flush=True)
                 sys.exit(3)

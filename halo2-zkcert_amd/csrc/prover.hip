@@ -311,17 +311,27 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
     if (row_mode) ctx->n_row_sharded += 1;
     if (pieces_sharded) ctx->n_pieces_sharded += 1;
     const size_t my_lo = pieces_sharded ? RK * m_rows : 0, my_n = pieces_sharded ? m_rows : n, my_lo_b = my_lo * 32;
+    // Owners (row-sharded exchange only).  Column j of a batch is transformed by ONE rank — the owner — and the batches of a proof are small
+    // (A + I, 2 L, Zp + L columns, q numerator blocks: 5, 2, 5, 3 for the aggregation shape): with owner = j mod N rank 0 owned a column of
+    // every batch and ranks 5-7 of 8 none (single-rank replay, round 5: 9.7 ms of transforms on rank 0, 5.2 on rank 3, none on rank 7).
+    // The batches are therefore dealt round robin ACROSS batches: owner(j) = (j + rot) mod N with rot = the columns dealt so far, so no
+    // rank owns more than ceil(total / N) columns of a proof (15 over 8 ranks: two each, one rank one).  The coset transforms of a batch
+    // float past the phase that issued them (the sweep is their first reader), so what a rank's GPU spends on them adds to ITS proof time
+    // wherever it falls — spreading them is what shortens the slowest rank.  first_of(rot, r) = the first column of rank r in a batch.
+    const size_t rot_adv = 0, rot_perm = dist ? (A + I) % NR : 0, rot_z = dist ? (A + I + 2 * L) % NR : 0, rot_h = dist ? (A + I + 2 * L + Zp + L) % NR : 0;
+    auto first_of = [&](size_t rot, size_t r) -> size_t { return (r + NR - rot % NR) % NR; };
+    auto owner_of = [&](size_t rot, size_t j) -> size_t { return (j + rot) % NR; };
     // coeff_to_extended of `count` polynomials whose outputs are consecutive EB-sized slices of one padded workspace block
-    auto to_extended = [&](const void* const* srcs, void* const* dsts, size_t count) -> int {
+    auto to_extended = [&](const void* const* srcs, void* const* dsts, size_t count, size_t rot) -> int {
         auto transform = [&](const void* const* s_, void* const* d_, size_t c_) -> int {
             return coset_mode ? zk::coeff_to_cosets(ctx, cplan, s_, d_, c_) : zkhip_coeff_to_extended_device(ctx, pk->domain, s_, n, d_, c_);
         };
         if (!dist) return transform(srcs, dsts, count);
         if (row_mode) {
-            // my columns (j = t NR + RK) in one batch, then the windows of every peer packed, exchanged and unpacked
+            // my columns (j = first_of(rot, RK) + t NR) in one batch, then the windows of every peer packed, exchanged and unpacked
             std::vector<const void*> ms;
             std::vector<void*> md;
-            for (size_t j = RK; j < count; j += NR) { ms.push_back(srcs[j]); md.push_back(dsts[j]); }
+            for (size_t j = first_of(rot, RK); j < count; j += NR) { ms.push_back(srcs[j]); md.push_back(dsts[j]); }
             if (!ms.empty()) ZK_TRY(transform(ms.data(), md.data(), ms.size()));
             const size_t maxcols = (count + NR - 1) / NR, W = m_rows + 2 * halo, blk = maxcols * qd * W * 32;
             char *w_send, *w_recv;
@@ -338,13 +348,13 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
             }
             ZK_TRY(zk::comm_row_copies(ctx, list));
             std::vector<uint8_t> has_cols(NR), to_all(NR, md.empty() ? 0 : 1);
-            for (size_t r = 0; r < NR; ++r) has_cols[r] = r < count;      // rank r transforms columns r, r + NR, ...: none if r >= count
+            for (size_t r = 0; r < NR; ++r) has_cols[r] = first_of(rot, r) < count;      // rank r transforms columns first_of(rot, r), + NR, ...: maybe none
             ZK_TRY(zk::comm_alltoall(ctx, w_send, w_recv, blk, to_all.data(), has_cols.data()));
             list.clear();
             for (size_t r = 0; r < NR; ++r) {
                 if (r == RK) continue;
                 size_t t = 0;
-                for (size_t j = r; j < count; j += NR, ++t)
+                for (size_t j = first_of(rot, r); j < count; j += NR, ++t)
                     for (uint32_t b_ = 0; b_ < qd; ++b_)
                         list.push_back(zk::RowCopy{(const uint32_t*)(w_recv + r * blk + (t * qd + b_) * W * 32), (uint32_t*)((char*)dsts[j] + (size_t)b_ * NB), 0u,
                                                    (uint32_t)((RK * m_rows + n - halo) & nmask), (uint32_t)W, 0xffffffffu, nmask});
@@ -372,21 +382,21 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
     // coefficient form, which is all a point-range commitment and SHPLONK on row ranges read.  exchange_ranges moves row ranges between
     // the ranks and the owners: dir 0 = every rank's rows of column j to owner(j) (who ends up with the whole column), dir 1 = the owner's
     // rows [r m, (r + 1) m) of column j to rank r.
-    auto exchange_ranges = [&](int dir, const void* const* src, void* const* dst, size_t count) -> int {
+    auto exchange_ranges = [&](int dir, const void* const* src, void* const* dst, size_t count, size_t rot) -> int {
         const size_t maxcols = (count + NR - 1) / NR, blk = maxcols * m_rows * 32;
         char *w_send, *w_recv;
         ZK_TRY(ws("cp_a2a_send", NR * blk, &w_send));
         ZK_TRY(ws("cp_a2a_recv", NR * blk, &w_recv));
         const uint32_t full = 0xffffffffu, M = (uint32_t)m_rows;
         std::vector<uint8_t> is_owner(NR), all1(NR, 1), all0(NR, 0);
-        for (size_t r = 0; r < NR; ++r) is_owner[r] = r < count;
-        const bool i_own = RK < count;
+        for (size_t r = 0; r < NR; ++r) is_owner[r] = first_of(rot, r) < count;
+        const bool i_own = first_of(rot, RK) < count;
         std::vector<zk::RowCopy> list;
         auto rows = [&](const void* base, size_t row) { return (const uint32_t*)((const char*)base + row * 32); };
         for (size_t r = 0; r < NR; ++r) {
             if (r == RK) continue;
-            if (dir == 0) { size_t t = 0; for (size_t j = r; j < count; j += NR, ++t) list.push_back(zk::RowCopy{rows(src[j], RK * m_rows), (uint32_t*)(w_send + r * blk + t * m_rows * 32), 0u, 0u, M, full, full}); }
-            else { size_t t = 0; for (size_t j = RK; j < count; j += NR, ++t) list.push_back(zk::RowCopy{rows(src[j], r * m_rows), (uint32_t*)(w_send + r * blk + t * m_rows * 32), 0u, 0u, M, full, full}); }
+            if (dir == 0) { size_t t = 0; for (size_t j = first_of(rot, r); j < count; j += NR, ++t) list.push_back(zk::RowCopy{rows(src[j], RK * m_rows), (uint32_t*)(w_send + r * blk + t * m_rows * 32), 0u, 0u, M, full, full}); }
+            else { size_t t = 0; for (size_t j = first_of(rot, RK); j < count; j += NR, ++t) list.push_back(zk::RowCopy{rows(src[j], r * m_rows), (uint32_t*)(w_send + r * blk + t * m_rows * 32), 0u, 0u, M, full, full}); }
         }
         ZK_TRY(zk::comm_row_copies(ctx, list));
         if (dir == 0) ZK_TRY(zk::comm_alltoall(ctx, w_send, w_recv, blk, is_owner.data(), i_own ? all1.data() : all0.data()));
@@ -394,22 +404,22 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
         list.clear();
         for (size_t r = 0; r < NR; ++r) {
             if (r == RK) continue;
-            if (dir == 0) { size_t t = 0; for (size_t j = RK; j < count; j += NR, ++t) list.push_back(zk::RowCopy{(const uint32_t*)(w_recv + r * blk + t * m_rows * 32), (uint32_t*)rows(dst[j], r * m_rows), 0u, 0u, M, full, full}); }
-            else { size_t t = 0; for (size_t j = r; j < count; j += NR, ++t) list.push_back(zk::RowCopy{(const uint32_t*)(w_recv + r * blk + t * m_rows * 32), (uint32_t*)rows(dst[j], RK * m_rows), 0u, 0u, M, full, full}); }
+            if (dir == 0) { size_t t = 0; for (size_t j = first_of(rot, RK); j < count; j += NR, ++t) list.push_back(zk::RowCopy{(const uint32_t*)(w_recv + r * blk + t * m_rows * 32), (uint32_t*)rows(dst[j], r * m_rows), 0u, 0u, M, full, full}); }
+            else { size_t t = 0; for (size_t j = first_of(rot, r); j < count; j += NR, ++t) list.push_back(zk::RowCopy{(const uint32_t*)(w_recv + r * blk + t * m_rows * 32), (uint32_t*)rows(dst[j], RK * m_rows), 0u, 0u, M, full, full}); }
         }
-        for (size_t j = RK; j < count; j += NR)      // the owner's own rows when the exchange is not in place
+        for (size_t j = first_of(rot, RK); j < count; j += NR)      // the owner's own rows when the exchange is not in place
             if (src[j] != dst[j]) list.push_back(zk::RowCopy{rows(src[j], RK * m_rows), (uint32_t*)rows(dst[j], RK * m_rows), 0u, 0u, M, full, full});
         return zk::comm_row_copies(ctx, list);
     };
     // lagrange_to_coeff of a batch by owner: lag[j] complete on every rank (lag_sharded = false) or present as row ranges only (true);
     // afterwards coeff[j] is complete on owner(j) and every rank holds its row range of it
-    auto owner_intt = [&](const void* const* lag, void* const* coeff, size_t count, bool lag_sharded) -> int {
-        if (lag_sharded) ZK_TRY(exchange_ranges(0, lag, coeff, count));
+    auto owner_intt = [&](const void* const* lag, void* const* coeff, size_t count, bool lag_sharded, size_t rot) -> int {
+        if (lag_sharded) ZK_TRY(exchange_ranges(0, lag, coeff, count, rot));
         std::vector<const void*> ms;
         std::vector<void*> md;
-        for (size_t j = RK; j < count; j += NR) { ms.push_back(lag_sharded ? (const void*)coeff[j] : lag[j]); md.push_back(coeff[j]); }
+        for (size_t j = first_of(rot, RK); j < count; j += NR) { ms.push_back(lag_sharded ? (const void*)coeff[j] : lag[j]); md.push_back(coeff[j]); }
         if (!ms.empty()) ZK_TRY(zk::lagrange_to_coeff_oop(ctx, pk->domain, ms.data(), md.data(), ms.size()));
-        return exchange_ranges(1, (const void* const*)coeff, coeff, count);
+        return exchange_ranges(1, (const void* const*)coeff, coeff, count, rot);
     };
 
     uint64_t ch[4];
@@ -496,9 +506,9 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
         if (A + I) {
             std::vector<const void*> lag(A + I);
             for (uint32_t j = 0; j < A + I; ++j) lag[j] = j < A ? d_advice[j] : d_instance[j - A];
-            if (pieces_sharded) ZK_TRY(owner_intt(lag.data(), coeff_ptrs.data(), A + I, false));
+            if (pieces_sharded) ZK_TRY(owner_intt(lag.data(), coeff_ptrs.data(), A + I, false, rot_adv));
             else ZK_TRY(zk::lagrange_to_coeff_oop(ctx, pk->domain, lag.data(), coeff_ptrs.data(), A + I));
-            ZK_TRY(to_extended((const void* const*)coeff_ptrs.data(), ext_ptrs.data(), A + I));
+            ZK_TRY(to_extended((const void* const*)coeff_ptrs.data(), ext_ptrs.data(), A + I, rot_adv));
         }
         ov.end();
     } else {
@@ -528,9 +538,9 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
         if (A + I) {
             std::vector<const void*> lag(A + I);   // out of place: the witness columns stay in Lagrange form, no copy
             for (uint32_t j = 0; j < A + I; ++j) lag[j] = j < A ? d_advice[j] : d_instance[j - A];
-            if (pieces_sharded) ZK_TRY(owner_intt(lag.data(), coeff_ptrs.data(), A + I, false));
+            if (pieces_sharded) ZK_TRY(owner_intt(lag.data(), coeff_ptrs.data(), A + I, false, rot_adv));
             else ZK_TRY(zk::lagrange_to_coeff_oop(ctx, pk->domain, lag.data(), coeff_ptrs.data(), A + I));
-            ZK_TRY(to_extended((const void* const*)coeff_ptrs.data(), ext_ptrs.data(), A + I));
+            ZK_TRY(to_extended((const void* const*)coeff_ptrs.data(), ext_ptrs.data(), A + I, rot_adv));
         }
         ov.end();
         absorb_vk_and_instances();
@@ -584,7 +594,7 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
         {
             std::vector<const void*> lag(2 * L);
             for (uint32_t j = 0; j < 2 * L; ++j) lag[j] = w_perm_l + j * NB;
-            if (pieces_sharded) ZK_TRY(owner_intt(lag.data(), perm_c.data(), 2 * L, false));
+            if (pieces_sharded) ZK_TRY(owner_intt(lag.data(), perm_c.data(), 2 * L, false, rot_perm));
             else ZK_TRY(zk::lagrange_to_coeff_oop(ctx, pk->domain, lag.data(), perm_c.data(), 2 * L));
         }
         // transcript order (lookup::Argument::commit_permuted per lookup): permuted input, then permuted table, lookup by lookup
@@ -597,7 +607,7 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
         ZK_TRY(zkhip_msm_g1_multi_device(ctx, bases.data(), cols.data(), cols.size(), 0, n, w_com));
         ZK_HIP(hipMemcpyAsync(h_err, w_perr, 4, hipMemcpyDeviceToHost, st));
         ZK_TRY(ov.begin_marked());
-        ZK_TRY(to_extended((const void* const*)perm_c.data(), ext_perm.data(), 2 * L));
+        ZK_TRY(to_extended((const void* const*)perm_c.data(), ext_perm.data(), 2 * L, rot_perm));
         ov.end();
         xy.resize(8 * cols.size());
         by.resize(32 * cols.size());
@@ -644,7 +654,7 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
         if (pieces_sharded) {   // row ranges -> the owners (batch order = the order of the coset transforms), inverse transform there, ranges back
             std::vector<void*> zb(Zp + L);
             for (uint32_t i = 0; i < Zp + L; ++i) zb[i] = const_cast<void*>(src[i]);
-            ZK_TRY(owner_intt(src.data(), zb.data(), Zp + L, true));
+            ZK_TRY(owner_intt(src.data(), zb.data(), Zp + L, true, rot_z));
         } else {
             ZK_TRY(zkhip_lagrange_to_coeff_device(ctx, pk->domain, z_ptrs.data(), Zp + L));
         }
@@ -667,7 +677,7 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
         ov.arm();
         ZK_TRY(commit_launch(cols, bases));
         ZK_TRY(ov.begin_marked());
-        ZK_TRY(to_extended(src.data(), ext_z.data(), Zp + L));
+        ZK_TRY(to_extended(src.data(), ext_z.data(), Zp + L, rot_z));
         ov.end();
         ZK_TRY(commit_read(cols.size(), 0, nullptr, nullptr));
     }
@@ -735,7 +745,7 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
         }
     }
     if (pieces_sharded) {
-        // Block b's inverse transform belongs to rank b mod N: (1) every rank sends its rows of block b to that owner (an all-to-all in
+        // Block b's inverse transform belongs to rank (b + rot_h) mod N (the round robin of the column batches goes on): (1) every rank sends its rows of block b to that owner (an all-to-all in
         // which only the owners receive), (2) the owner transforms its complete blocks, (3) sends every rank ITS row range of them, and
         // (4) each rank forms its rows of the q pieces (the q x q combination is pointwise).  2 q n / N rows cross instead of the all-gather's
         // q n, and no rank ever holds a complete piece: the commitments below read only this rank's rows.
@@ -744,15 +754,15 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
         ZK_TRY(ws("cp_a2a_send", NR * blk, &w_send));
         ZK_TRY(ws("cp_a2a_recv", NR * blk, &w_recv));
         std::vector<uint32_t> mine_blocks;
-        for (uint32_t b_ = (uint32_t)RK; b_ < qd; b_ += (uint32_t)NR) mine_blocks.push_back(b_);
+        for (uint32_t b_ = (uint32_t)first_of(rot_h, RK); b_ < qd; b_ += (uint32_t)NR) mine_blocks.push_back(b_);
         std::vector<uint8_t> owner(NR), everyone(NR, 1), nobody(NR, 0);
-        for (size_t r = 0; r < NR; ++r) owner[r] = r < qd;
+        for (size_t r = 0; r < NR; ++r) owner[r] = first_of(rot_h, r) < qd;
         std::vector<zk::RowCopy> list;
         const uint32_t full = 0xffffffffu;
         for (size_t r = 0; r < NR; ++r) {
             if (r == RK) continue;
             size_t t = 0;
-            for (uint32_t b_ = (uint32_t)r; b_ < qd; b_ += (uint32_t)NR, ++t)
+            for (uint32_t b_ = (uint32_t)first_of(rot_h, r); b_ < qd; b_ += (uint32_t)NR, ++t)
                 list.push_back(zk::RowCopy{(const uint32_t*)(w_hvals + ((size_t)b_ * n + RK * m_rows) * 32), (uint32_t*)(w_send + r * blk + t * m_rows * 32), 0u, 0u,
                                            (uint32_t)m_rows, full, full});
         }
@@ -780,7 +790,7 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
         for (size_t r = 0; r < NR; ++r) {
             if (r == RK) continue;
             size_t t = 0;
-            for (uint32_t b_ = (uint32_t)r; b_ < qd; b_ += (uint32_t)NR, ++t)
+            for (uint32_t b_ = (uint32_t)first_of(rot_h, r); b_ < qd; b_ += (uint32_t)NR, ++t)
                 list.push_back(zk::RowCopy{(const uint32_t*)(w_recv + r * blk + t * m_rows * 32), (uint32_t*)(w_hvals + ((size_t)b_ * n + RK * m_rows) * 32), 0u, 0u,
                                            (uint32_t)m_rows, full, full});
         }
@@ -893,9 +903,12 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
                 int o = -1;
                 const uint32_t pi_ = q_poly[i];
                 if (pieces_sharded) {
-                    if (pi_ < A) o = (int)(pi_ % NR);
-                    else if (pi_ >= o_pz && pi_ < o_lk) o = (int)((L + (pi_ - o_pz)) % NR);
-                    else if (pi_ >= o_lk && pi_ < o_rand) { const uint32_t li = (pi_ - o_lk) / 3, wh = (pi_ - o_lk) % 3; o = (int)((wh == 2 ? L + li : li) % NR); }
+                    if (pi_ < A) o = (int)owner_of(rot_adv, pi_);
+                    else if (pi_ >= o_pz && pi_ < o_lk) o = (int)owner_of(rot_z, L + (pi_ - o_pz));      // the products batch: lookup z's first, then the sets'
+                    else if (pi_ >= o_lk && pi_ < o_rand) {      // per lookup: z (products batch), a' and s' (permuted batch: inputs first, then tables)
+                        const uint32_t li = (pi_ - o_lk) / 3, wh = (pi_ - o_lk) % 3;
+                        o = (int)(wh == 0 ? owner_of(rot_z, li) : owner_of(rot_perm, wh == 2 ? L + li : li));
+                    }
                 }
                 q_rank[i] = (pieces_sharded && i == ih) ? -1 : (o >= 0 ? o : (int)(i % NR));
                 if (q_rank[i] >= 0) n_of[q_rank[i]] += 1;

@@ -189,11 +189,14 @@ class Context:
     # ---- one proof over several GPUs (zkhip_comm_*): one process per GPU
     world, rank = 1, 0
 
-    def comm_init(self, rank, world, dist=None, transport=None):
+    def comm_init(self, rank, world, dist=None, transport=None, group=None, src=0):
         """Gives the context its communicator.  transport "rccl" (default): rank 0's ncclUniqueId is broadcast through torch.distributed
         and every rank joins (ncclCommInitRank inside the library; the all-gathers of a proof then run over xGMI).  transport "host"
         (ZKHIP_COMM_TRANSPORT=host, or a torch.distributed backend without device support such as gloo): the same all-gathers staged
-        through host memory and torch.distributed — bring-up and tests on a one-GPU box, where RCCL refuses two ranks per device."""
+        through host memory and torch.distributed — bring-up and tests on a one-GPU box, where RCCL refuses two ranks per device.
+        group / src: a communicator over a SUBSET of the job's ranks (bench.py --chain: one leaf proof over a few ranks): `group` is the
+        torch.distributed process group of the subset, `rank` / `world` the position in and the size of the subset, `src` the GLOBAL rank of
+        its first member (who creates the unique id)."""
         import torch
 
         if transport is None:
@@ -211,7 +214,7 @@ class Context:
                 _check(lib().zkhip_comm_unique_id(buf))
                 ids = [bytes(buf)]
             if world > 1:
-                dist.broadcast_object_list(ids, src=0)
+                dist.broadcast_object_list(ids, src=src, group=group)
             _check(lib().zkhip_comm_init(self.h, (C.c_uint8 * 128)(*ids[0]), C.c_int(rank), C.c_int(world)))
         elif transport == "host":
             def _ag(user, send, recv, nbytes):
@@ -220,10 +223,10 @@ class Context:
                     outs = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
                     if dist.get_backend() == "nccl":
                         dev = [o.to(self.device) for o in outs]
-                        dist.all_gather(dev, mine.to(self.device))
+                        dist.all_gather(dev, mine.to(self.device), group=group)
                         outs = [d.cpu() for d in dev]
                     else:
-                        dist.all_gather(outs, mine.clone())
+                        dist.all_gather(outs, mine.clone(), group=group)
                     for r, o in enumerate(outs):
                         C.memmove(recv + r * nbytes, o.numpy().ctypes.data, nbytes)
                     return 0
@@ -239,10 +242,10 @@ class Context:
                     out = torch.empty(nbytes * world, dtype=torch.uint8)
                     if dist.get_backend() == "nccl":
                         o = out.to(self.device)
-                        dist.all_to_all_single(o, mine.to(self.device))
+                        dist.all_to_all_single(o, mine.to(self.device), group=group)
                         out = o.cpu()
                     else:
-                        dist.all_to_all_single(out, mine)
+                        dist.all_to_all_single(out, mine, group=group)
                     C.memmove(recv, out.numpy().ctypes.data, nbytes * world)
                     return 0
                 except Exception as e:   # noqa: BLE001
@@ -261,10 +264,11 @@ class Context:
         library's RCCL branch issues exactly rank `rank`'s kernels, fences and exchanges on an otherwise idle GPU.  Results computed on such
         a context are wrong by construction."""
         global _rccl_lib_named
-        if _rccl_lib_named:
-            raise ZkhipError("comm_init_replay: a collective library is already bound in this process")
-        _check(lib().zkhip_comm_use_library(os.fsencode(library)))
-        _rccl_lib_named = True
+        if _rccl_lib_named and _rccl_lib_named != os.path.abspath(library):
+            raise ZkhipError("comm_init_replay: another collective library is already bound in this process")
+        if not _rccl_lib_named:
+            _check(lib().zkhip_comm_use_library(os.fsencode(library)))
+            _rccl_lib_named = os.path.abspath(library)
         buf = (C.c_uint8 * 128)()
         _check(lib().zkhip_comm_unique_id(buf))
         _check(lib().zkhip_comm_init(self.h, buf, C.c_int(rank), C.c_int(world)))

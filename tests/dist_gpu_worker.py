@@ -45,9 +45,11 @@ if os.environ.get("ZK_STALL_TEST") == "1":
     os._exit(0)
 if os.environ.get("ZK_STALL_TEST") == "proof":
     # the same deadline met INSIDE a proof whose advice columns are the caller's host arrays (the error exit of zkhip_create_proof_ex
-    # used to wait for the stuck stream without a deadline).  Rank 0's collective stream is stalled at the proof's first exchange:
-    # its proof must come back with the deadline's error well before the stall ends.  Rank 1 then waits for a peer that has left (the stand-in's
-    # barrier): a watchdog thread writes its record and ends the process.
+    # used to wait for the stuck stream without a deadline).  Rank 0's collective stream is stalled after the proof's LAST exchange (the partial
+    # sums of SHPLONK's second commitment: the next thing the library does is a host wait for that commitment — the stand-in's own collectives
+    # are synchronous, so a stall before an earlier exchange would be absorbed by the next exchange's hipStreamSynchronize inside the stand-in
+    # instead of meeting the library's deadline).  Rank 0's proof must come back with the deadline's error well before the stall ends; rank 1's
+    # proof completes (the exchange itself was served).  A watchdog thread ends a rank that waits for a peer that has left.
     import threading
     import time
 
@@ -56,14 +58,16 @@ if os.environ.get("ZK_STALL_TEST") == "proof":
             json.dump(res, f)
         sys.stdout.flush()
         os._exit(0)
-    if rank != 0:
-        threading.Timer(25.0, lambda: leave({"rank": rank, "error": "watchdog: the peer left", "elapsed_s": 25.0})).start()
+    threading.Timer(120.0, lambda: leave({"rank": rank, "error": "watchdog: still waiting after 120 s", "elapsed_s": 120.0})).start()
     ctx.comm_shard("points")
     p = pv.Prover(pv.GpuBackend(ctx, ffi), pv.CircuitShape.small(8), satisfiable=True)
     w = p.witness(1)
-    # the stand-in reads its fault plan at every call: stall rank 0's stream at the FIRST exchange of the proof (its call counter also counted
-    # the two exchanges of the init-time self-check, which the library's own counter leaves out)
-    os.environ["ZKFAKE_RCCL_STALL"] = f"device:0:{ctx.comm_describe()['collectives'] + 3}"
+    c1 = ctx.comm_describe()["collectives"]
+    p.prove_native(w, transcript="poseidon", host_inputs=True)      # one proof without a fault: how many exchanges a proof issues
+    c2 = ctx.comm_describe()["collectives"]
+    # the stand-in reads its fault plan at every call: stall rank 0's stream after the LAST exchange of the next proof (its call counter also
+    # counted the two exchanges of the init-time self-check, which the library's own counter leaves out)
+    os.environ["ZKFAKE_RCCL_STALL"] = f"device:0:{2 + c2 + (c2 - c1)}"
     t0 = time.time()
     res = {"rank": rank, "error": None}
     try:

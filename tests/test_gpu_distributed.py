@@ -276,15 +276,16 @@ def test_a_stuck_collective_fails_the_host_wait_at_the_deadline(zk, tmp_path):
 
 
 def test_a_stuck_collective_inside_a_proof_with_host_inputs_returns_at_the_deadline(zk, tmp_path):
-    """ADVICE r4 (prover.hip StreamGuard): rank 0's collective stream stalls (40 s) at the first exchange of a proof whose advice columns are
+    """ADVICE r4 (prover.hip StreamGuard): rank 0's collective stream stalls (40 s) after the last exchange of a proof whose advice columns are
     host arrays.  zkhip_create_proof_ex returns the deadline's error after ~2 s — its error exit does NOT wait for the streams the deadline
-    has just declared stuck — and later waits on that context fail at once."""
+    has just declared stuck; rank 1, whose exchange was served, completes its proof."""
     outs = _run_workers(tmp_path, 2, True, 0, extra_env={"ZKHIP_RCCL_LIB": _fake_rccl(), "ZKHIP_COMM_TRANSPORT": "rccl", "ZKFAKE_RCCL_SLOT_MB": "8",
                                                          "ZK_STALL_TEST": "proof", "ZKFAKE_RCCL_STALL_S": "40",
                                                          "ZKHIP_COMM_TIMEOUT_MS": "2000"}, timeout=300)
     err = outs[0]["error"]
     assert err and "a host wait exceeded 2000 ms" in err and "rank 0 of 2 stuck" in err, err
     assert outs[0]["elapsed_s"] < 20.0, outs[0]
+    assert outs[1]["error"] is None, outs[1]
 
 
 def test_agg_k22_proof_over_two_ranks_through_the_rccl_branch(zk, tmp_path):

@@ -30,6 +30,12 @@ for n in 4 8; do
   run chain_rank1_of$n $C --replay-rank 1 --of $n
 done
 run chain_rank5_of8 $C --replay-rank 5 --of 8
+run chain_rank1_of8_no_groups $C --replay-rank 1 --of 8 --no-leaf-groups
+run chain_rank4_of8 $C --replay-rank 4 --of 8
+# the shard tables' window width at N = 8 (2^19 points per rank: c = 17 by default)
+for c in 15 16; do run k22_rank0_of8_c$c $S --replay-rank 0 --of 8 --msm-c $c; done
+run sha19_rank0_of2 --config sha19 $S --replay-rank 0 --of 2
+run sha19_rank0_of3 --config sha19 $S --replay-rank 0 --of 3
 # k = 19 / 17 sharded by column (whole tables on every rank)
 run sha19_single --config sha19 $S
 run sha19_rank0_of8 --config sha19 $S --replay-rank 0 --of 8
