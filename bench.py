@@ -858,13 +858,20 @@ def worker(args):
         leaf_names = ["rsa17", "sha19", "rsa17", "sha19"]
         # Who proves which leaf.  Leaf j's head is rank j; from N = 6 on the ranks 4.. — idle until the aggregation proof when every leaf sits on
         # one rank, while the SHA-shaped leaves take 4.5x as long as the RSA ones — are dealt to the two SHA leaves in turn (N = 8: leaf 1 over
-        # ranks 1, 4, 6, leaf 3 over ranks 3, 5, 7): such a leaf is ONE proof over its group's own communicator, MSMs by column (k = 19: one MSM
+        # ranks 1 + 4, leaf 3 over ranks 3 + 5): such a leaf is ONE proof over its group's own communicator, MSMs by column (k = 19: one MSM
         # cannot fill several GPUs), the same bytes on every member.  The leaf contexts' communicators are used before the barrier, the
         # aggregation proof's after it: never two collectives of different communicators in flight on one device.
         groups = {j: [j] for j in range(4)}
         if shard and vworld >= 6 and not args.no_leaf_groups:
-            for e_, r_ in enumerate(range(4, vworld)):
-                groups[1 if e_ % 2 == 0 else 3].append(r_)
+            # group sizes are powers of two (the sweep and the exchanges divide the rows by the group size; single-rank replay, k = 19: 31.0 ms on
+            # one rank, 18.6 over two, 19.4 over three): each SHA leaf takes (N - 4) / 2 extra ranks rounded down to 2^e - 1 — one each at N = 6 … 9
+            extra = 1
+            while 2 * (2 * extra + 1) <= vworld - 4:
+                extra = 2 * extra + 1
+            pool = list(range(4, vworld))
+            for j in (1, 3):
+                groups[j] += pool[:extra]
+                pool = pool[extra:]
         my_leaf = next((j for j, rs in groups.items() if vrank in rs), None)
         if any(len(rs) > 1 for rs in groups.values()):
             pgs = {}
@@ -956,6 +963,16 @@ def worker(args):
                     "launches_per_step": acc_l / steps, "timing": "HIP events inside the timed region, all proofs of the chain this rank ran",
                     "note": "rank 0's share: 96 B per (scalar, point) pair over every commitment of its leaf proof(s) and its 1/N of the aggregation proof's; "
                             "VALU-issue bound like the single proofs (DESIGN.md 5); traffic: see the per-configuration PMC passes of the N = 1 line"}
+        # every rank's leaf digest to rank 0: the members of a leaf's group must hold the same bytes, and the line carries all four leaves'
+        leaf_digests = {str(w_["seed"]): d_ for (pr_, w_, _), d_ in zip(leaves, digests)}
+        if world > 1:
+            got = [None] * world
+            dist.all_gather_object(got, leaf_digests)
+            leaf_digests = {}
+            for r_, g_ in enumerate(got):
+                for j_, d_ in (g_ or {}).items():
+                    if leaf_digests.setdefault(j_, d_) != d_:
+                        raise SystemExit(f"bench.py: rank {r_} holds another proof of leaf {j_} than a lower rank of its group")
         if vworld == 1:
             par = "5 proofs in sequence on 1 GPU"
         elif shard:
@@ -975,16 +992,6 @@ def worker(args):
                "collectives_per_step": (ctx.comm_describe()["collectives"] - c0) / steps if shard else 0}
         for item in ([] if replay else last):
             note_proof(*item)
-        # every rank's leaf digest to rank 0: the members of a leaf's group must hold the same bytes, and the line carries all four leaves'
-        leaf_digests = {str(w_["seed"]): d_ for (pr_, w_, _), d_ in zip(leaves, digests)}
-        if world > 1:
-            got = [None] * world
-            dist.all_gather_object(got, leaf_digests)
-            leaf_digests = {}
-            for r_, g_ in enumerate(got):
-                for j_, d_ in (g_ or {}).items():
-                    if leaf_digests.setdefault(j_, d_) != d_:
-                        raise SystemExit(f"bench.py: rank {r_} holds another proof of leaf {j_} than a lower rank of its group")
         for pr_, _, _ in leaves:
             pr_.release()
             pr_.b.params.free()
