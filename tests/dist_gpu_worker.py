@@ -62,12 +62,14 @@ if os.environ.get("ZK_STALL_TEST") == "proof":
     ctx.comm_shard("points")
     p = pv.Prover(pv.GpuBackend(ctx, ffi), pv.CircuitShape.small(8), satisfiable=True)
     w = p.witness(1)
+    p.prove_native(w, transcript="poseidon", host_inputs=True)      # the first proof of a key may issue one-time exchanges (the key's coset forms)
     c1 = ctx.comm_describe()["collectives"]
-    p.prove_native(w, transcript="poseidon", host_inputs=True)      # one proof without a fault: how many exchanges a proof issues
+    p.prove_native(w, transcript="poseidon", host_inputs=True)      # a steady-state proof without a fault: how many exchanges a proof issues
     c2 = ctx.comm_describe()["collectives"]
     # the stand-in reads its fault plan at every call: stall rank 0's stream after the LAST exchange of the next proof (its call counter also
     # counted the two exchanges of the init-time self-check, which the library's own counter leaves out)
     os.environ["ZKFAKE_RCCL_STALL"] = f"device:0:{2 + c2 + (c2 - c1)}"
+    res_plan = {"exchanges_per_proof": c2 - c1, "stall_at_call": 2 + c2 + (c2 - c1)}
     t0 = time.time()
     res = {"rank": rank, "error": None}
     try:
@@ -75,6 +77,7 @@ if os.environ.get("ZK_STALL_TEST") == "proof":
     except Exception as e:   # noqa: BLE001
         res["error"] = str(e)
     res["elapsed_s"] = time.time() - t0
+    res.update(res_plan, exchanges_issued=ctx.comm_describe()["collectives"] - c2)
     leave(res)
 mode = os.environ.get("ZK_SHARD_MODE", "points")
 ctx.comm_shard(mode)
