@@ -66,10 +66,10 @@ if os.environ.get("ZK_STALL_TEST") == "proof":
     c1 = ctx.comm_describe()["collectives"]
     p.prove_native(w, transcript="poseidon", host_inputs=True)      # a steady-state proof without a fault: how many exchanges a proof issues
     c2 = ctx.comm_describe()["collectives"]
-    # the stand-in reads its fault plan at every call: stall rank 0's stream after the LAST exchange of the next proof (its call counter also
-    # counted the two exchanges of the init-time self-check, which the library's own counter leaves out)
-    os.environ["ZKFAKE_RCCL_STALL"] = f"device:0:{2 + c2 + (c2 - c1)}"
-    res_plan = {"exchanges_per_proof": c2 - c1, "stall_at_call": 2 + c2 + (c2 - c1)}
+    # the stand-in reads its fault plan at every call and counts calls only while a plan is set: from here on.  Stall rank 0's stream after
+    # the LAST exchange of the next proof
+    os.environ["ZKFAKE_RCCL_STALL"] = f"device:0:{c2 - c1}"
+    res_plan = {"exchanges_per_proof": c2 - c1, "stall_at_call": c2 - c1}
     t0 = time.time()
     res = {"rank": rank, "error": None}
     try:

@@ -283,7 +283,7 @@ def test_a_stuck_collective_inside_a_proof_with_host_inputs_returns_at_the_deadl
                                                          "ZK_STALL_TEST": "proof", "ZKFAKE_RCCL_STALL_S": "40",
                                                          "ZKHIP_COMM_TIMEOUT_MS": "2000"}, timeout=300)
     err = outs[0]["error"]
-    assert err and "a host wait exceeded 2000 ms" in err and "rank 0 of 2 stuck" in err, err
+    assert err and "a host wait exceeded 2000 ms" in err and "rank 0 of 2 stuck" in err, outs[0]
     assert outs[0]["elapsed_s"] < 20.0, outs[0]
     assert outs[1]["error"] is None, outs[1]
 
