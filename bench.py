@@ -223,7 +223,10 @@ def cpu_baseline(pv, args, config, head_k, transcript):
         out = dict(value=round(t_m * scale, 4), unit="s", cores=threads, kind="port", measured_s=round(t_m, 4), scale=round(scale, 4),
                    sample=f"{shape_at(k_m).name}: ONE full pass at k = {k_m} = {t_m:.3f} s; {k18_txt}; growth per 4x rows k = 18 -> {k_m} = {per4:.3f}; {how}"
                           "; oracle/zkoracle.c with OpenMP, SRS / keygen excluded",
-                   measured_k=k_m, k18_s=round(med18, 4), growth_per_4x_rows=round(per4, 4))
+                   measured_k=k_m, k18_s=round(med18, 4), growth_per_4x_rows=round(per4, 4),
+                   # `value` is a MEASUREMENT only when the timed pass ran at the headline size; otherwise it is the measured pass carried to the
+                   # headline size: say so in a field, not only in the sample text
+                   extrapolated=(k_m != head_k), extrapolation=(None if k_m == head_k else ("recorded k = 22 / k = 20 ratio (profiles/r04_cpu_k22.json)" if use_rec else f"measured k = 18 -> {k_m} growth")))
         if t20 is not None:
             out["k20_s"] = round(t20, 4)
         if rec and k_m != head_k:
@@ -232,7 +235,7 @@ def cpu_baseline(pv, args, config, head_k, transcript):
     else:
         sh = shape_at(head_k) if config == "agg22" else make_shape(pv, config, args)
         med, ts = cpu_pass_seconds(pv, sh, transcript, threads)
-        out = dict(value=round(med, 4), unit="s", cores=threads, kind="port", measured_s=round(med, 4), scale=1.0,
+        out = dict(value=round(med, 4), unit="s", cores=threads, kind="port", measured_s=round(med, 4), scale=1.0, extrapolated=False, extrapolation=None,
                    sample=f"{sh.name}: median of 3 full passes after a warm-up ({', '.join(f'{t:.3f}' for t in ts)}); "
                           "oracle/zkoracle.c with OpenMP, SRS / keygen excluded")
     out["proof_k"], out["proof_sha256"] = CPU_PROOFS[-1]["k"], CPU_PROOFS[-1]["proof_sha256"]     # the pass that was timed last = the measured size

@@ -306,7 +306,7 @@ impl Circuit<Fr> for ShapeCircuit {
             || "shape",
             |mut region| {
                 // [UPSTREAM-RECALL] the axiom fork's Region: assign_advice(column, offset, Value<F>) -> AssignedCell, assign_fixed(column,
-                // offset, F) -> Cell, constrain_equal(&Cell, &Cell) — no annotation closures, no Result
+                // offset, F) -> Cell, constrain_equal(Cell, Cell) — no annotation closures, no Result (upstream PSE: closures and Results)
                 let fixed_cols = [cfg.q[0], cfg.q[1], cfg.constants, cfg.table];
                 let mut fixed_cells = vec![Vec::new(); 4];
                 for (j, col) in fixed_cols.iter().enumerate() {
@@ -331,7 +331,7 @@ impl Circuit<Fr> for ShapeCircuit {
                 for &(ca, ra, cb, rb) in &self.copies {
                     let cell_of = |c: usize, r: usize| if c < n_adv { Some(adv_cells[c][r]) } else if c == n_adv { Some(fixed_cells[2][r]) } else { None };
                     match (cell_of(ca, ra), cell_of(cb, rb)) {
-                        (Some(x), Some(y)) => region.constrain_equal(&x, &y),
+                        (Some(x), Some(y)) => region.constrain_equal(x, y), // [UPSTREAM-RECALL] Cell by value, unit result (halo2-lib's halo2-axiom branch calls it so)
                         (Some(x), None) => to_instance.push((x, rb)),
                         _ => unreachable!("an instance cell on the left of a copy"),
                     }
@@ -379,7 +379,7 @@ where
 {
     let mut rng = CountingRng::new(RNG_SEED);
     let mut rec = Rec { inner: writer, challenges: Vec::new() };
-    let inst = [circuit.instance.as_slice()];
+    let inst: Vec<&[Fr]> = vec![circuit.instance.as_slice()]; // (&[&inst] below: the shape snark-verifier-sdk's gen_proof passes)
     create_proof::<KZGCommitmentScheme<Bn256>, ProverSHPLONK<'_, Bn256>, E, _, _, _>(params, pk, &[circuit.clone()], &[&inst], &mut rng, &mut rec).expect("create_proof");
     let challenges = rec.challenges.clone();
     let proof = finalize(rec.inner);
