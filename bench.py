@@ -1015,6 +1015,7 @@ def worker(args):
                 "collectives_per_step": collectives_per_step,     # exchanges (all-gathers + all-to-alls) the library issued per timed step on this rank
                 "bytes_gathered_per_step": int(per_step_bytes), "shard_mode": shard_mode,
                 "exchange_modes": {k_: ctx.profile_counter(k_) for k_ in ("proofs_row_sharded", "proofs_pieces_sharded", "shplonk_row_sharded")},
+                "bulk_communicator": bool(ctx.profile_counter("comm_bulk")), "collectives_bulk_total": ctx.profile_counter("collectives_bulk"),   # the row windows' own communicator (comm.hip)
                 "note": "nranks / transport_ranks / bytes: what the library's own communicator reports on rank 0 (zkhip_comm_info / zkhip_comm_describe; "
                         "transport_ranks = ncclCommCount); bytes = received by this rank through all-gathers in one step"}
 

@@ -41,6 +41,7 @@ struct Rccl {
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;       // optional: what RCCL itself says the communicator spans
     ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommSplit)(ncclComm_t, int, int, ncclComm_t*, void*) = nullptr;   // optional: the bulk communicator (config = NULL)
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 Rccl g_rccl;
@@ -68,6 +69,7 @@ int load_rccl() {
     g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))dlsym(h, "ncclGroupEnd");
     g_rccl.CommCount = (decltype(g_rccl.CommCount))dlsym(h, "ncclCommCount");
     g_rccl.CommUserRank = (decltype(g_rccl.CommUserRank))dlsym(h, "ncclCommUserRank");
+    g_rccl.CommSplit = (decltype(g_rccl.CommSplit))dlsym(h, "ncclCommSplit");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy) {
         set_error("zkhip_comm: librccl lacks a required symbol");
         return ZKHIP_EINVAL;
@@ -184,9 +186,14 @@ int comm_row_copies(zkhip_ctx* ctx, const std::vector<RowCopy>& list) {
 // send_to[r] = 0: this rank has nothing for rank r; recv_from[r] = 0: rank r has nothing for this rank (null = all ones).  The two patterns
 // must be consistent across the ranks (they follow from column / block ownership, which every rank knows).  RCCL skips the silent pairs;
 // the host transport moves the padded buffers (a test transport: its counter says so).
-int comm_alltoall(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t bytes, const uint8_t* send_to, const uint8_t* recv_from) {
+int comm_alltoall(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t bytes, const uint8_t* send_to, const uint8_t* recv_from, bool bulk) {
     zkhip_comm& cm = ctx->comm;
     if (cm.nranks <= 1 || bytes == 0) return ZKHIP_OK;
+    // which communicator: the bulk one for the exchanges that asked for it, if the context has one — its own stream and events, so the
+    // transfer neither waits behind nor delays the latency-sized exchanges on the first communicator
+    const bool on_bulk = bulk && cm.nccl_bulk;
+    hipStream_t cstream = on_bulk ? cm.stream_bulk : cm.stream;
+    hipEvent_t e_in = on_bulk ? cm.ev_in_bulk : cm.ev_in, e_out = on_bulk ? cm.ev_out_bulk : cm.ev_out;
     const size_t N = (size_t)cm.nranks, total = bytes * N;
     if (cm.host_allgather) {
         const size_t need = cm.host_alltoall ? 2 * total : total * N + total;
@@ -217,9 +224,9 @@ int comm_alltoall(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t bytes
         return ZKHIP_OK;
     }
     if (!g_rccl.Send || !g_rccl.Recv || !g_rccl.GroupStart || !g_rccl.GroupEnd) { set_error("zkhip_comm: librccl lacks ncclSend / ncclRecv / ncclGroup*"); return ZKHIP_EINVAL; }
-    ncclComm_t c = (ncclComm_t)cm.nccl;
-    ZK_HIP(hipEventRecord(cm.ev_in, ctx->stream));
-    ZK_HIP(hipStreamWaitEvent(cm.stream, cm.ev_in, 0));
+    ncclComm_t c = (ncclComm_t)(on_bulk ? cm.nccl_bulk : cm.nccl);
+    ZK_HIP(hipEventRecord(e_in, ctx->stream));
+    ZK_HIP(hipStreamWaitEvent(cstream, e_in, 0));
     size_t received = 0;
     ZK_NCCL(g_rccl.GroupStart());
     // an error inside the group must not leave it open (every later call on this thread would be deferred into it and never launched):
@@ -228,8 +235,8 @@ int comm_alltoall(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t bytes
     const char* what = "";
     for (size_t r = 0; r < N && !first; ++r) {
         if ((int)r == cm.rank) continue;
-        if (!send_to || send_to[r]) { first = g_rccl.Send((const char*)d_send + r * bytes, bytes, ncclInt8, (int)r, c, cm.stream); what = "ncclSend"; }
-        if (!first && (!recv_from || recv_from[r])) { first = g_rccl.Recv((char*)d_recv + r * bytes, bytes, ncclInt8, (int)r, c, cm.stream); what = "ncclRecv"; received += bytes; }
+        if (!send_to || send_to[r]) { first = g_rccl.Send((const char*)d_send + r * bytes, bytes, ncclInt8, (int)r, c, cstream); what = "ncclSend"; }
+        if (!first && (!recv_from || recv_from[r])) { first = g_rccl.Recv((char*)d_recv + r * bytes, bytes, ncclInt8, (int)r, c, cstream); what = "ncclRecv"; received += bytes; }
     }
     const ncclResult_t closed = g_rccl.GroupEnd();
     if (first || closed) {
@@ -240,7 +247,10 @@ int comm_alltoall(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t bytes
     }
     cm.bytes_gathered += received;
     cm.collectives += 1;
-    return comm_allgather_end(ctx);
+    if (on_bulk) cm.collectives_bulk += 1;
+    ZK_HIP(hipEventRecord(e_out, cstream));                   // the calling stream consumes the blocks
+    ZK_HIP(hipStreamWaitEvent(ctx->stream, e_out, 0));
+    return ZKHIP_OK;
 }
 
 // the partial sums of a point-range-sharded batch of MSMs -> the sums, on every rank (d_out may be pinned host memory)
@@ -351,6 +361,61 @@ int zkhip_comm_init(zkhip_ctx* ctx, const uint8_t id[128], int rank, int nranks)
             fprintf(stderr, "zkhip_comm_init: the all-to-all self-check failed on some rank (this rank: %s): this communicator uses the all-gather exchange\n",
                     ok ? "ok" : "FAILED");
         ctx->comm.a2a_ok = all_ok ? 1 : -1;   // lives and dies with the communicator; the user's row_sharded option is left alone
+        // The bulk communicator: a split of this one over the same ranks (no second unique id to distribute), own stream and events.  It
+        // carries the all-to-alls of row windows only.  Proved like the first one before anything depends on it — a tagged all-to-all
+        // on it, the verdicts all-gathered on the FIRST communicator so that every rank takes the same decision; any failure (or a library
+        // without ncclCommSplit, or comm_bulk = 0) leaves nccl_bulk null on EVERY rank and those exchanges on the first communicator.
+        if (all_ok && ctx->opt.comm_bulk != 0 && g_rccl.CommSplit) {
+            zkhip_comm& c_ = ctx->comm;
+            ncclComm_t bulk = nullptr;
+            int okb = g_rccl.CommSplit((ncclComm_t)c_.nccl, 0, rank, &bulk, nullptr) == 0 && bulk;
+            if (okb) {
+                c_.nccl_bulk = bulk;
+                okb = hipStreamCreateWithFlags(&c_.stream_bulk, hipStreamNonBlocking) == hipSuccess &&
+                      hipEventCreateWithFlags(&c_.ev_in_bulk, hipEventDisableTiming) == hipSuccess &&
+                      hipEventCreateWithFlags(&c_.ev_out_bulk, hipEventDisableTiming) == hipSuccess;
+            }
+            const size_t blk = 64, N = (size_t)nranks;
+            void* d_b = nullptr;
+            std::vector<uint32_t> hb(3 * N * blk / 4, 0);
+            if (zk::dev_malloc((void**)&d_b, 3 * N * blk) != hipSuccess) { (void)hipGetLastError(); okb = 0; d_b = nullptr; }
+            if (okb) {
+                for (size_t r = 0; r < N; ++r) for (size_t w = 0; w < blk / 4; ++w) hb[r * blk / 4 + w] = 0xB0000000u | ((uint32_t)rank << 12) | (uint32_t)r;
+                okb = hipMemcpy(d_b, hb.data(), 3 * N * blk, hipMemcpyHostToDevice) == hipSuccess;
+            }
+            if (okb && comm_alltoall(ctx, d_b, (char*)d_b + N * blk, blk, nullptr, nullptr, true) != ZKHIP_OK) okb = 0;
+            if (okb) {
+                const hipError_t we = stream_wait(ctx, ctx->stream);
+                if (we == hipErrorLaunchTimeOut) { set_error("zkhip_comm_init: the bulk communicator's self-check did not complete"); return ZKHIP_EHIP; }
+                okb = we == hipSuccess && hipMemcpy(hb.data(), d_b, 3 * N * blk, hipMemcpyDeviceToHost) == hipSuccess;
+            }
+            for (size_t r = 0; okb && r < N; ++r)
+                if ((int)r != rank && hb[(N + r) * blk / 4] != (0xB0000000u | ((uint32_t)r << 12) | (uint32_t)rank)) okb = 0;
+            uint32_t mine_b = (uint32_t)okb;
+            int all_b = okb;
+            hipError_t we2 = hipSuccess;
+            if (d_b && hipMemcpy((char*)d_b + (2 * N + (size_t)rank) * blk, &mine_b, 4, hipMemcpyHostToDevice) == hipSuccess &&
+                comm_allgather(ctx, (char*)d_b + (2 * N + (size_t)rank) * blk, (char*)d_b + 2 * N * blk, blk) == ZKHIP_OK &&
+                (we2 = stream_wait(ctx, ctx->stream)) == hipSuccess && hipMemcpy(hb.data(), (char*)d_b + 2 * N * blk, N * blk, hipMemcpyDeviceToHost) == hipSuccess) {
+                for (size_t r = 0; r < N; ++r) all_b = all_b && hb[r * blk / 4] == 1u;
+            } else {
+                all_b = 0;
+            }
+            if (we2 == hipErrorLaunchTimeOut) { set_error("zkhip_comm_init: the verdict all-gather of the bulk self-check did not complete (a peer failed or left)"); return ZKHIP_EHIP; }
+            if (d_b) (void)hipFree(d_b);
+            if (!all_b) {
+                fprintf(stderr, "zkhip_comm_init: no bulk communicator (this rank: %s): the row windows ride on the first communicator\n", okb ? "ok" : "FAILED");
+                (void)hipDeviceSynchronize();
+                if (c_.nccl_bulk && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)c_.nccl_bulk);
+                if (c_.stream_bulk) (void)hipStreamDestroy(c_.stream_bulk);
+                if (c_.ev_in_bulk) (void)hipEventDestroy(c_.ev_in_bulk);
+                if (c_.ev_out_bulk) (void)hipEventDestroy(c_.ev_out_bulk);
+                c_.nccl_bulk = nullptr; c_.stream_bulk = nullptr; c_.ev_in_bulk = nullptr; c_.ev_out_bulk = nullptr;
+            }
+            ctx->comm.bytes_gathered = 0;
+            ctx->comm.collectives = 0;
+            ctx->comm.collectives_bulk = 0;
+        }
     }
     return ZKHIP_OK;
 }
@@ -381,6 +446,10 @@ int zkhip_comm_destroy(zkhip_ctx* ctx) {
     // the streams / events are released by the runtime asynchronously, or by the process leaving (what a caller does after this error).
     const bool dead = cm.stuck != 0;
     if (!dead) (void)hipDeviceSynchronize();
+    if (cm.nccl_bulk && g_rccl.CommDestroy && !dead) (void)g_rccl.CommDestroy((ncclComm_t)cm.nccl_bulk);   // the split before its parent
+    if (cm.stream_bulk) (void)hipStreamDestroy(cm.stream_bulk);
+    if (cm.ev_in_bulk) (void)hipEventDestroy(cm.ev_in_bulk);
+    if (cm.ev_out_bulk) (void)hipEventDestroy(cm.ev_out_bulk);
     if (cm.nccl && g_rccl.CommDestroy && !dead) (void)g_rccl.CommDestroy((ncclComm_t)cm.nccl);
     if (cm.stream) (void)hipStreamDestroy(cm.stream);
     if (cm.ev_in) (void)hipEventDestroy(cm.ev_in);

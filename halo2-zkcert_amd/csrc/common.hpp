@@ -61,6 +61,8 @@ struct zkhip_options {
     int permute_rank_sort = 1, eval_byval = 1, late_overlap = -1;
     int host_timing = 0;   // zkhip_create_proof prints its host-side phase times to stderr
     int row_sharded = 1;      // multi-rank proofs on the coset path: all-to-all of row windows (1) / all-gather of complete columns (0)
+    int comm_bulk = 1;        // multi-rank proofs: the all-to-alls of row windows (needed by the sweep only) ride on a SECOND communicator (ncclCommSplit) with its own stream, so the
+                              // latency-sized exchanges a commitment waits for never queue behind a 50 MB transfer (0: everything on the one communicator)
     int comm_timeout_ms = 120000;   // host waits of a multi-rank context give up after this long (0: wait for ever): see zk::CommWatch
     int eval_chunks = -1;     // evaluations at x in this many launches, absorbed chunk by chunk while the next is computed (1: one launch; -1: by size)
     int rand_overlap = -1;    // the vanishing argument's random polynomial is committed on a third stream beside the grand products (0: with the advice batch; -1: by size)
@@ -74,6 +76,13 @@ struct zkhip_comm {
     void* nccl = nullptr;
     hipStream_t stream = nullptr;             // every collective is enqueued here, fenced against the producing / consuming stream
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    // the BULK communicator (round 5): a split of `nccl` over the same ranks with its own stream and events; carries the all-to-alls of row
+    // windows (prover.hip to_extended) and nothing else.  null: those ride on `nccl` like everything else (no ncclCommSplit in the library, the
+    // option comm_bulk = 0, or its self-check failed on some rank)
+    void* nccl_bulk = nullptr;
+    hipStream_t stream_bulk = nullptr;
+    hipEvent_t ev_in_bulk = nullptr, ev_out_bulk = nullptr;
+    uint64_t collectives_bulk = 0;            // of `collectives`: issued on the bulk communicator
     zkhip_host_allgather_fn host_allgather = nullptr;
     void* host_user = nullptr;
     zkhip_host_alltoall_fn host_alltoall = nullptr;   // optional companion of the host transport (else emulated through the all-gather)
@@ -186,7 +195,8 @@ namespace zk {
 int comm_allgather(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t bytes);
 int comm_allgather_begin(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t bytes);
 int comm_allgather_end(zkhip_ctx* ctx);
-int comm_alltoall(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_pair, const uint8_t* send_to = nullptr, const uint8_t* recv_from = nullptr);
+int comm_alltoall(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_pair, const uint8_t* send_to = nullptr, const uint8_t* recv_from = nullptr,
+                  bool bulk = false);   // bulk: on the bulk communicator when the context has one (same result either way)
 struct RowCopy { const uint32_t* src; uint32_t* dst; uint32_t src_row0, dst_row0, count, src_mask, dst_mask; };
 #define ZK_ROWCOPY_MAX 48
 int comm_row_copies(zkhip_ctx* ctx, const std::vector<RowCopy>& list);

@@ -152,6 +152,8 @@ int zkhip_profile_counter(zkhip_ctx* c, const char* name, uint64_t* value) {
     else if (strcmp(name, "proofs_row_sharded") == 0) *value = c->n_row_sharded;         // always counted (not only while profiling)
     else if (strcmp(name, "proofs_pieces_sharded") == 0) *value = c->n_pieces_sharded;
     else if (strcmp(name, "shplonk_row_sharded") == 0) *value = c->n_shplonk_sharded;
+    else if (strcmp(name, "comm_bulk") == 0) *value = c->comm.nccl_bulk ? 1 : 0;          // the context has a bulk communicator (comm.hip)
+    else if (strcmp(name, "collectives_bulk") == 0) *value = c->comm.collectives_bulk;    // exchanges issued on it so far
     else { set_error("zkhip_profile_counter: unknown counter '%s'", name); return ZKHIP_EINVAL; }
     return ZKHIP_OK;
 }
@@ -190,7 +192,7 @@ const OptName OPTIONS[] = {
     {"ZKHIP_EVAL_BYVAL", "eval_byval", &zkhip_options::eval_byval}, {"ZKHIP_LATE_OVERLAP", "late_overlap", &zkhip_options::late_overlap},
     {"ZKHIP_HOST_TIMING", "host_timing", &zkhip_options::host_timing},
     {"ZKHIP_COSET_QUOTIENT", "coset_quotient", &zkhip_options::coset_quotient}, {"ZKHIP_ROW_SHARDED", "row_sharded", &zkhip_options::row_sharded},
-    {"ZKHIP_COMM_TIMEOUT_MS", "comm_timeout_ms", &zkhip_options::comm_timeout_ms}, {"ZKHIP_RAND_OVERLAP", "rand_overlap", &zkhip_options::rand_overlap},
+    {"ZKHIP_COMM_BULK", "comm_bulk", &zkhip_options::comm_bulk}, {"ZKHIP_COMM_TIMEOUT_MS", "comm_timeout_ms", &zkhip_options::comm_timeout_ms}, {"ZKHIP_RAND_OVERLAP", "rand_overlap", &zkhip_options::rand_overlap},
     {"ZKHIP_EVAL_CHUNKS", "eval_chunks", &zkhip_options::eval_chunks},
 };
 }  // namespace

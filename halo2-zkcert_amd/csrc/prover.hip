@@ -349,7 +349,8 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
             ZK_TRY(zk::comm_row_copies(ctx, list));
             std::vector<uint8_t> has_cols(NR), to_all(NR, md.empty() ? 0 : 1);
             for (size_t r = 0; r < NR; ++r) has_cols[r] = first_of(rot, r) < count;      // rank r transforms columns first_of(rot, r), + NR, ...: maybe none
-            ZK_TRY(zk::comm_alltoall(ctx, w_send, w_recv, blk, to_all.data(), has_cols.data()));
+            // (on the bulk communicator when the context has one: the sweep is these windows' first reader, nothing here is latency-critical)
+            ZK_TRY(zk::comm_alltoall(ctx, w_send, w_recv, blk, to_all.data(), has_cols.data(), true));
             list.clear();
             for (size_t r = 0; r < NR; ++r) {
                 if (r == RK) continue;

@@ -81,7 +81,8 @@ int  zkhip_profile_read(zkhip_ctx* ctx, const char* kernel, double* total_ms, ui
 /* Work counters accumulated while profiling ALL kernels (no selection): "msm_pairs" = (non-zero digit, point) pairs the MSM
  * accumulations really processed (zero digits are skipped), "msm_dense_pairs" = n * windows per column.  Counted always, on a context with
  * a communicator: "proofs_row_sharded" (zkhip_create_proof_ex calls that exchanged row windows instead of complete columns),
- * "proofs_pieces_sharded" (... whose quotient pieces stayed row ranges), "shplonk_row_sharded" (zkhip_shplonk_open calls on row ranges). */
+ * "proofs_pieces_sharded" (... whose quotient pieces stayed row ranges), "shplonk_row_sharded" (zkhip_shplonk_open calls on row ranges),
+ * "comm_bulk" (1: the communicator has its bulk companion, see below) and "collectives_bulk" (exchanges issued on it). */
 int  zkhip_profile_counter(zkhip_ctx* ctx, const char* name, uint64_t* value);
 
 /* ---- one proof over several GPUs: one process per GPU, RCCL over xGMI ----
@@ -97,6 +98,10 @@ int  zkhip_profile_counter(zkhip_ctx* ctx, const char* name, uint64_t* value);
  *     is this rank's point range: linear combinations on the range, divisions by X - r with the carries exchanged as 32-byte range
  *     totals).  Every rank must call it with identical inputs and obtains the identical proof; zk_proof_out.d_h then holds this
  *     rank's rows of the pieces only.  Option "row_sharded" = 0 restores the all-gather form.
+ *   - the all-to-alls of row windows — tens of megabytes per peer that only the sweep reads — ride on a BULK communicator: a split of the
+ *     first one over the same ranks (ncclCommSplit: no second id to distribute) with its own stream, created and self-checked by
+ *     zkhip_comm_init, so the latency-sized exchanges a commitment waits for never queue behind them.  A library without ncclCommSplit,
+ *     a failed self-check on any rank, or option "comm_bulk" = 0 leave them on the first communicator (same results).
  * zkhip_comm_init_host is the same with the all-gathers staged through host memory and a caller-supplied function (bring-up on a
  * one-GPU box, launchers without RCCL): fn(user, send, recv, bytes) must fill recv[r * bytes ..] with rank r's send block. */
 typedef int (*zkhip_host_allgather_fn)(void* user, const void* send, void* recv, size_t bytes_per_rank);

@@ -124,6 +124,15 @@ ncclResult_t ncclCommInitRank(ncclComm_t* out, int nranks, ncclUniqueId id, int 
     *out = c;
     return 0;
 }
+// a split over the SAME ranks (color / key as the library passes them: one colour, key = rank): another segment, named after the parent's
+ncclResult_t ncclCommSplit(ncclComm_t parent, int /*color*/, int key, ncclComm_t* out, void* /*config*/) {
+    static int n_splits = 0;
+    if (!parent || key != parent->rank) { g_err = "fake rccl: ncclCommSplit supports one colour with key = rank"; return 5; }
+    ncclUniqueId id;
+    memset(id.internal, 0, sizeof id.internal);
+    snprintf(id.internal, sizeof id.internal, "%.40s_s%d", parent->name, ++n_splits);      // every rank splits in the same order: the same name
+    return ncclCommInitRank(out, parent->nranks, id, parent->rank);
+}
 ncclResult_t ncclCommDestroy(ncclComm_t c) {
     if (!c) return 0;
     munmap((void*)c->h, c->map_bytes);

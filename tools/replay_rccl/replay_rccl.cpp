@@ -12,8 +12,9 @@
 //   ncclGroupEnd    (outermost) and ncclAllGather: optionally a MODELLED wire time — a kernel that holds the communicator's stream for
 //                   latency + max-over-peers(bytes received from that peer) / per-link bandwidth (xGMI is point-to-point: one link per peer,
 //                   all of them busy at once) — ZKREPLAY_LATENCY_US / ZKREPLAY_LINK_GBS; both 0 (default): exchanges cost only their fill.
-// Fill contents: blocks of <= 64 bytes take what csrc/comm.hip's init-time self-check expects from a healthy peer (the word peer << 16 | me
-// from a receive, the verdict word 1 from an all-gather); larger blocks are pseudo-random 32-byte rows with the top limb masked below both
+// Fill contents: blocks of <= 64 bytes take what csrc/comm.hip's init-time self-checks expect from a healthy peer (the word peer << 16 | me
+// from a receive — 0xB0000000 | peer << 12 | me on a communicator made by ncclCommSplit, the library's bulk communicator —, the verdict word 1
+// from an all-gather); larger blocks are pseudo-random 32-byte rows with the top limb masked below both
 // BN254 moduli, so that scalars taken from a peer's rows spread over the MSM's buckets like real coefficients do (a constant fill would put
 // every point of a window into one bucket and time a pathological accumulation).
 // Counters (ncclReplayStats, read by bench.py through ctypes): collectives, bytes received, bytes sent, modelled wire microseconds.
@@ -53,6 +54,7 @@ struct ncclComm {
     int rank, nranks;
     double latency_us, link_gbs;
     int wall_khz;
+    int split;      // made by ncclCommSplit (the library's bulk communicator): its init-time self-check expects other tag words
 };
 typedef ncclComm* ncclComm_t;
 struct ReplayStats { uint64_t collectives, bytes_received, bytes_sent; double wire_us; };
@@ -75,8 +77,14 @@ ncclResult_t ncclCommInitRank(ncclComm_t* out, int nranks, ncclUniqueId, int ran
     c->latency_us = l ? atof(l) : 0.0;
     c->link_gbs = b ? atof(b) : 0.0;
     c->wall_khz = 100000;
+    c->split = 0;
     (void)hipDeviceGetAttribute(&c->wall_khz, hipDeviceAttributeWallClockRate, 0);
     *out = c;
+    return 0;
+}
+ncclResult_t ncclCommSplit(ncclComm_t parent, int, int, ncclComm_t* out, void*) {      // the library's bulk communicator: same rank / size / wire model, own handle
+    *out = new ncclComm(*parent);
+    (*out)->split = 1;
     return 0;
 }
 ncclResult_t ncclCommDestroy(ncclComm_t c) { delete c; return 0; }
@@ -140,7 +148,8 @@ ncclResult_t ncclSend(const void*, size_t count, int, int peer, ncclComm_t c, hi
 }
 ncclResult_t ncclRecv(void* buf, size_t count, int, int peer, ncclComm_t c, hipStream_t st) {
     if (peer < 0 || peer >= c->nranks || peer == c->rank) { g_err = "replay rccl: bad peer"; return 5; }
-    if (ncclResult_t rc = fill(buf, count, ((uint32_t)peer << 16) | (uint32_t)c->rank, 0x5E0000u + (uint32_t)g_stats.collectives * 64u + (uint32_t)peer, st)) return rc;
+    const uint32_t tag = c->split ? (0xB0000000u | ((uint32_t)peer << 12) | (uint32_t)c->rank) : (((uint32_t)peer << 16) | (uint32_t)c->rank);      // what csrc/comm.hip's self-checks expect from peer
+    if (ncclResult_t rc = fill(buf, count, tag, 0x5E0000u + (uint32_t)g_stats.collectives * 64u + (uint32_t)peer, st)) return rc;
     g_stats.bytes_received += count;
     g_comm = c; g_stream = st; g_worst = std::max(g_worst, count);
     return g_depth ? 0 : end_group();
