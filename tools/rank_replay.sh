@@ -1,6 +1,6 @@
 #!/bin/bash
-# One rank's share of the sharded proofs, timed alone on one GPU (bench.py --replay-rank; tools/replay_rccl): the k = 22 headline and the
-# chain at N = 2 / 4 / 8, without and with a modelled wire, beside the single-GPU line of the same box.  Writes gpurun_out/<tag>/rank_replay.jsonl
+# One rank's share of the sharded proofs, timed alone on one GPU (bench.py --replay-rank; tools/replay_rccl): the k = 22 headline at N = 2 / 4 / 8
+# (the chain: tools/rank_replay_chain.sh), without and with a modelled wire, beside the single-GPU line of the same box.  Writes gpurun_out/<tag>/rank_replay.jsonl
 # (one bench line per run, prefixed by its label); tools/install_rank_replay.py reduces it to profiles/<tag>_rank_replay.json.
 #   gpurun --timeout 2400 -- bash tools/rank_replay.sh r05
 tag=${1:-r05}
@@ -19,19 +19,14 @@ for n in 2 4 8; do
   run k22_rank0_of$n $S --replay-rank 0 --of $n
   run k22_rank0_of${n}_wire20us_50GBs $S --replay-rank 0 --of $n --replay-latency-us 20 --replay-link-gbs 50
 done
+ZKHIP_COMM_BULK=0 run k22_rank0_of8_wire20us_50GBs_one_communicator $S --replay-rank 0 --of 8 --replay-latency-us 20 --replay-link-gbs 50
+ZKHIP_COMM_BULK=0 run k22_rank0_of4_wire20us_50GBs_one_communicator $S --replay-rank 0 --of 4 --replay-latency-us 20 --replay-link-gbs 50
 run k22_rank7_of8 $S --replay-rank 7 --of 8
 run k22_rank3_of8 $S --replay-rank 3 --of 8
+run k22_rank0_of2_columns $S --replay-rank 0 --of 2 --shard columns
+run k22_rank0_of2_columns_wire20us_50GBs $S --replay-rank 0 --of 2 --shard columns --replay-latency-us 20 --replay-link-gbs 50
 run k22_rank0_of8_allgather $S --replay-rank 0 --of 8 --row-sharded 0
 run k22_rank0_of8_columns $S --replay-rank 0 --of 8 --shard columns
-C="--chain --steps 5 --warmup 1"
-run chain_single $C
-for n in 4 8; do
-  run chain_rank0_of$n $C --replay-rank 0 --of $n
-  run chain_rank1_of$n $C --replay-rank 1 --of $n
-done
-run chain_rank5_of8 $C --replay-rank 5 --of 8
-run chain_rank1_of8_no_groups $C --replay-rank 1 --of 8 --no-leaf-groups
-run chain_rank4_of8 $C --replay-rank 4 --of 8
 # the shard tables' window width at N = 8 (2^19 points per rank: c = 17 by default)
 for c in 15 16; do run k22_rank0_of8_c$c $S --replay-rank 0 --of 8 --msm-c $c; done
 run sha19_rank0_of2 --config sha19 $S --replay-rank 0 --of 2
