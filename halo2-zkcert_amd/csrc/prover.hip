@@ -383,7 +383,7 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
     // coefficient form, which is all a point-range commitment and SHPLONK on row ranges read.  exchange_ranges moves row ranges between
     // the ranks and the owners: dir 0 = every rank's rows of column j to owner(j) (who ends up with the whole column), dir 1 = the owner's
     // rows [r m, (r + 1) m) of column j to rank r.
-    auto exchange_ranges = [&](int dir, const void* const* src, void* const* dst, size_t count, size_t rot) -> int {
+    auto exchange_ranges = [&](int dir, const void* const* src, void* const* dst, size_t count, size_t rot, bool bulk = false) -> int {
         const size_t maxcols = (count + NR - 1) / NR, blk = maxcols * m_rows * 32;
         char *w_send, *w_recv;
         ZK_TRY(ws("cp_a2a_send", NR * blk, &w_send));
@@ -400,8 +400,8 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
             else { size_t t = 0; for (size_t j = first_of(rot, RK); j < count; j += NR, ++t) list.push_back(zk::RowCopy{rows(src[j], r * m_rows), (uint32_t*)(w_send + r * blk + t * m_rows * 32), 0u, 0u, M, full, full}); }
         }
         ZK_TRY(zk::comm_row_copies(ctx, list));
-        if (dir == 0) ZK_TRY(zk::comm_alltoall(ctx, w_send, w_recv, blk, is_owner.data(), i_own ? all1.data() : all0.data()));
-        else ZK_TRY(zk::comm_alltoall(ctx, w_send, w_recv, blk, i_own ? all1.data() : all0.data(), is_owner.data()));
+        if (dir == 0) ZK_TRY(zk::comm_alltoall(ctx, w_send, w_recv, blk, is_owner.data(), i_own ? all1.data() : all0.data(), bulk));
+        else ZK_TRY(zk::comm_alltoall(ctx, w_send, w_recv, blk, i_own ? all1.data() : all0.data(), is_owner.data(), bulk));
         list.clear();
         for (size_t r = 0; r < NR; ++r) {
             if (r == RK) continue;
@@ -414,13 +414,15 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
     };
     // lagrange_to_coeff of a batch by owner: lag[j] complete on every rank (lag_sharded = false) or present as row ranges only (true);
     // afterwards coeff[j] is complete on owner(j) and every rank holds its row range of it
-    auto owner_intt = [&](const void* const* lag, void* const* coeff, size_t count, bool lag_sharded, size_t rot) -> int {
-        if (lag_sharded) ZK_TRY(exchange_ranges(0, lag, coeff, count, rot));
+    // bulk: nothing latency-critical reads the result (the advice batch: its commitments are over the Lagrange basis; the coefficient ranges
+    // are for the evaluations and SHPLONK, much later) — the ranges travel on the bulk communicator beside the row windows
+    auto owner_intt = [&](const void* const* lag, void* const* coeff, size_t count, bool lag_sharded, size_t rot, bool bulk = false) -> int {
+        if (lag_sharded) ZK_TRY(exchange_ranges(0, lag, coeff, count, rot, bulk));
         std::vector<const void*> ms;
         std::vector<void*> md;
         for (size_t j = first_of(rot, RK); j < count; j += NR) { ms.push_back(lag_sharded ? (const void*)coeff[j] : lag[j]); md.push_back(coeff[j]); }
         if (!ms.empty()) ZK_TRY(zk::lagrange_to_coeff_oop(ctx, pk->domain, ms.data(), md.data(), ms.size()));
-        return exchange_ranges(1, (const void* const*)coeff, coeff, count, rot);
+        return exchange_ranges(1, (const void* const*)coeff, coeff, count, rot, bulk);
     };
 
     uint64_t ch[4];
@@ -507,7 +509,7 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
         if (A + I) {
             std::vector<const void*> lag(A + I);
             for (uint32_t j = 0; j < A + I; ++j) lag[j] = j < A ? d_advice[j] : d_instance[j - A];
-            if (pieces_sharded) ZK_TRY(owner_intt(lag.data(), coeff_ptrs.data(), A + I, false, rot_adv));
+            if (pieces_sharded) ZK_TRY(owner_intt(lag.data(), coeff_ptrs.data(), A + I, false, rot_adv, true));
             else ZK_TRY(zk::lagrange_to_coeff_oop(ctx, pk->domain, lag.data(), coeff_ptrs.data(), A + I));
             ZK_TRY(to_extended((const void* const*)coeff_ptrs.data(), ext_ptrs.data(), A + I, rot_adv));
         }
@@ -539,7 +541,7 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
         if (A + I) {
             std::vector<const void*> lag(A + I);   // out of place: the witness columns stay in Lagrange form, no copy
             for (uint32_t j = 0; j < A + I; ++j) lag[j] = j < A ? d_advice[j] : d_instance[j - A];
-            if (pieces_sharded) ZK_TRY(owner_intt(lag.data(), coeff_ptrs.data(), A + I, false, rot_adv));
+            if (pieces_sharded) ZK_TRY(owner_intt(lag.data(), coeff_ptrs.data(), A + I, false, rot_adv, true));
             else ZK_TRY(zk::lagrange_to_coeff_oop(ctx, pk->domain, lag.data(), coeff_ptrs.data(), A + I));
             ZK_TRY(to_extended((const void* const*)coeff_ptrs.data(), ext_ptrs.data(), A + I, rot_adv));
         }
