@@ -275,16 +275,18 @@ def finish_parity(out):
 
 
 LADDER = {
-    # one sharded proof: each rung is a FRESH set of worker processes (a rank that touched the GPU is never reused or exec'ed over)
+    # one sharded proof: each rung is a FRESH set of worker processes (a rank that touched the GPU is never reused or exec'ed over).
+    # From the second rung on the library's bulk communicator is off too (ZKHIP_COMM_BULK=0: no ncclCommSplit, one communicator as in round 4):
+    # whatever made the first rung fail, the fall-backs do not repeat its newest moving part
     "shard": [("row-sharded (all-to-all of row windows, torch control plane on RCCL)", [], {}),
-              ("all-gather exchange (row_sharded = 0), torch control plane on gloo", [], {"ZKHIP_ROW_SHARDED": "0", "ZKHIP_BENCH_DIST_BACKEND": "gloo"}),
-              ("MSMs by column, whole tables on every rank", ["--shard", "columns"], {"ZKHIP_ROW_SHARDED": "0", "ZKHIP_BENCH_DIST_BACKEND": "gloo"}),
+              ("all-gather exchange (row_sharded = 0), torch control plane on gloo", [], {"ZKHIP_ROW_SHARDED": "0", "ZKHIP_COMM_BULK": "0", "ZKHIP_BENCH_DIST_BACKEND": "gloo"}),
+              ("MSMs by column, whole tables on every rank", ["--shard", "columns"], {"ZKHIP_ROW_SHARDED": "0", "ZKHIP_COMM_BULK": "0", "ZKHIP_BENCH_DIST_BACKEND": "gloo"}),
               ("independent proofs, one per GPU (no collective on the data path)", ["--replicas"], {"ZKHIP_BENCH_DIST_BACKEND": "gloo"})],
     "replicas": [("independent proofs, one per GPU", [], {}),
                  ("independent proofs, one per GPU, torch control plane on gloo", [], {"ZKHIP_BENCH_DIST_BACKEND": "gloo"})],
     "chain": [("leaf proofs on ranks 0-3 (N >= 6: the SHA leaves over rank groups), aggregation proof row-sharded over all ranks", [], {}),
-              ("one leaf per rank 0-3, aggregation proof with the all-gather exchange, torch control plane on gloo", ["--no-leaf-groups"], {"ZKHIP_ROW_SHARDED": "0", "ZKHIP_BENCH_DIST_BACKEND": "gloo"}),
-              ("one leaf per rank 0-3, aggregation proof with MSMs by column", ["--no-leaf-groups", "--shard", "columns"], {"ZKHIP_ROW_SHARDED": "0", "ZKHIP_BENCH_DIST_BACKEND": "gloo"}),
+              ("one leaf per rank 0-3, aggregation proof with the all-gather exchange, torch control plane on gloo", ["--no-leaf-groups"], {"ZKHIP_ROW_SHARDED": "0", "ZKHIP_COMM_BULK": "0", "ZKHIP_BENCH_DIST_BACKEND": "gloo"}),
+              ("one leaf per rank 0-3, aggregation proof with MSMs by column", ["--no-leaf-groups", "--shard", "columns"], {"ZKHIP_ROW_SHARDED": "0", "ZKHIP_COMM_BULK": "0", "ZKHIP_BENCH_DIST_BACKEND": "gloo"}),
               ("one leaf per rank 0-3, aggregation proof on rank 0 alone (no collective on the data path)", ["--no-leaf-groups", "--agg-unsharded"], {"ZKHIP_BENCH_DIST_BACKEND": "gloo"})],
 }
 
