@@ -393,7 +393,9 @@ typedef struct zk_proving_key {
      * in phase 0, no user challenge — the reference's three circuits. */
     const uint8_t* advice_column_phase;       /* HOST, n_advice, or NULL */
     uint32_t n_challenges;
-    const uint8_t* challenge_phase;           /* HOST, n_challenges (non-decreasing use is not required: challenge j is squeezed after phase challenge_phase[j]) */
+    const uint8_t* challenge_phase;           /* HOST, n_challenges (non-decreasing use is not required: challenge j is squeezed after phase challenge_phase[j]).
+                                                 Checked (ZKHIP_EINVAL): the advice phases are 0 .. max without a gap, no challenge's phase exceeds the last
+                                                 advice phase, and zk_proof_inputs.advice_phase is set whenever a phase > 0 exists */
 } zk_proving_key;
 typedef struct zk_proof_out {
     const void* d_h;          /* the quotient in coefficient form (quotient_poly_degree * n elements, library-owned, valid until the next proof) */

@@ -723,3 +723,26 @@ def test_hip_consumer_of_the_prover_vectors_on_a_self_made_file(zk, oracle, tmp_
     monkeypatch.setattr(mod, "PATH", str(path))
     for which in ("small", "two_phase"):
         mod.test_hip_create_proof_equals_upstreams_bytes(zk, oracle, which)
+
+
+def test_malformed_phases_are_rejected_before_any_work(zk, oracle):
+    """zk_proving_key.advice_column_phase / challenge_phase (upstream: cs.advice_column_phase() / cs.challenge_phase(), handed out in order by
+    ConstraintSystem): a phase without columns, a challenge after the last advice phase, or later phases without the advice_phase callback are
+    ZKHIP_EINVAL with a message — not a NULL call or a silent single-phase proof."""
+    ffi, ctx = zk
+    sh = pv.CircuitShape.two_phase(6)
+    p = pv.Prover(pv.GpuBackend(ctx, ffi), sh, satisfiable=True)
+    w = p.witness(0)
+    good = p.prove_native(w, transcript="poseidon")["proof"]
+    sh.advice_phase[-1] = 2                     # phases 0 and 2, none of phase 1
+    p._npk = None
+    with pytest.raises(ffi.ZkhipError, match="a phase without columns"):
+        p.prove_native(p.witness(0), transcript="poseidon")
+    sh.advice_phase[-1] = 1
+    sh.challenge_phase[0] = 2                   # a challenge of a phase after the last advice phase
+    p._npk = None
+    with pytest.raises(ffi.ZkhipError, match="the last advice phase is 1"):
+        p.prove_native(p.witness(0), transcript="poseidon")
+    sh.challenge_phase[0] = 0
+    p._npk = None
+    assert p.prove_native(p.witness(0), transcript="poseidon")["proof"] == good
