@@ -27,8 +27,10 @@ ctx = ffi.Context(dev)
 ctx.comm_init(rank, world, dist)
 if os.environ.get("ZK_STALL_TEST") == "1":
     # the library's wait deadline (common.hpp wait_poll): one all-gather through the communicator, then a host wait on the context's stream.
-    # The stand-in library stalls ONE rank's collective stream (ZKFAKE_RCCL_STALL=device:<rank>:3): that rank's wait must fail with the
-    # deadline's message, the other rank's must succeed.  No teardown: a communicator with a stuck stream is not destroyed, the process leaves.
+    # The stand-in library stalls ONE rank's collective stream (ZKFAKE_RCCL_STALL=device:<rank>:<nth call>, set HERE: the stand-in counts calls
+    # only while a plan is set, so the count does not depend on how many exchanges zkhip_comm_init's self-checks issued): that rank's wait must
+    # fail with the deadline's message, the other rank's must succeed.  No teardown: a communicator with a stuck stream is not destroyed.
+    os.environ["ZKFAKE_RCCL_STALL"] = "device:0:1"
     send = torch.full((64,), rank + 1, dtype=torch.uint8, device="cuda")
     recv = torch.zeros((64 * world,), dtype=torch.uint8, device="cuda")
     res = {"rank": rank, "error": None}

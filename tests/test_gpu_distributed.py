@@ -264,15 +264,15 @@ def test_rccl_transport_path_with_emulated_rccl(zk, tmp_path, world, mode):
 
 def test_a_stuck_collective_fails_the_host_wait_at_the_deadline(zk, tmp_path):
     """comm_timeout_ms (common.hpp wait_poll): the stand-in library leaves rank 0's collective stream spinning after the first all-gather that
-    follows the init-time self-check (ZKFAKE_RCCL_STALL=device:0:3) — a collective whose peer never arrives, as the host sees it.  Rank 0's next
+    follows zkhip_comm_init (the worker arms ZKFAKE_RCCL_STALL=device:0:1 after the init) — a collective whose peer never arrives, as the host sees it.  Rank 0's next
     wait on its context fails after 2 s with the rank, the collective count and the phase in the message instead of polling for ever;
     rank 1, whose all-gather completed, is not affected."""
     outs = _run_workers(tmp_path, 2, True, 0, extra_env={"ZKHIP_RCCL_LIB": _fake_rccl(), "ZKHIP_COMM_TRANSPORT": "rccl", "ZKFAKE_RCCL_SLOT_MB": "8",
-                                                         "ZK_STALL_TEST": "1", "ZKFAKE_RCCL_STALL": "device:0:3", "ZKFAKE_RCCL_STALL_S": "40",
+                                                         "ZK_STALL_TEST": "1", "ZKFAKE_RCCL_STALL_S": "40",
                                                          "ZKHIP_COMM_TIMEOUT_MS": "2000"}, timeout=300)
     assert outs[1]["error"] is None and outs[1]["recv"] == [1, 2]
     err = outs[0]["error"]
-    assert err and "rank 0 of 2 stuck after collective #1" in err and "a host wait exceeded 2000 ms" in err, err
+    assert err and "rank 0 of 2 stuck after collective #1" in err and "a host wait exceeded 2000 ms" in err, outs[0]
 
 
 def test_a_stuck_collective_inside_a_proof_with_host_inputs_returns_at_the_deadline(zk, tmp_path):
