@@ -354,3 +354,26 @@ def test_point_range_shard_handles(zk, oracle):
     with pytest.raises(ffi.ZkhipError):
         shard.read_bases(shard.g, 0, 4)
     whole.free(); shard.free(); loaded.free()
+
+
+def test_published_eip196_add_and_mul_vectors_hip(zk, oracle):
+    """the HIP MSM (window tables built from the caller's bases, signed digits, bucket accumulation, tail) on go-ethereum's published
+    bn256Add / bn256ScalarMul vectors "chfast1" — points of unknown discrete logarithm, results fixed by a third party
+    (tests/golden/eip196_published.json): a + b and [s] P come out as published"""
+    ffi, ctx = zk
+    zo = oracle
+    v = load("eip196_published.json")
+    pt = lambda xy: (H(xy[0]), H(xy[1]))
+    a, b, c = pt(v["add"]["a"]), pt(v["add"]["b"]), pt(v["add"]["sum"])
+    res = aff(zk, ffi.best_multiexp(ctx, zo.fr_arr_from_ints([1, 1]), zo.affine_from_ints([a, b])))
+    assert zo.affine_to_ints(res)[0] == c
+    m, s, r = pt(v["mul"]["point"]), H(v["mul"]["scalar"]), pt(v["mul"]["product"])
+    res = aff(zk, ffi.best_multiexp(ctx, zo.fr_arr_from_ints([s, 0, 5, 0]), zo.affine_from_ints([m, a, (0, 0), b])))      # zero scalars and an identity base contribute nothing
+    assert zo.affine_to_ints(res)[0] == r
+    R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+    for case in v["mul_more"]:
+        pnt, sc, want = pt(case["point"]), H(case["scalar"]) % R, pt(case["product"])
+        res = aff(zk, ffi.best_multiexp(ctx, zo.fr_arr_from_ints([sc, 1, R - 1]), zo.affine_from_ints([pnt, a, a])))
+        assert zo.affine_to_ints(res)[0] == want
+    res = aff(zk, ffi.best_multiexp(ctx, zo.fr_arr_from_ints([1, 1]), zo.affine_from_ints([pt(v["add2"]["a"]), pt(v["add2"]["b"])])))
+    assert zo.affine_to_ints(res)[0] == pt(v["add2"]["sum"])

@@ -223,3 +223,35 @@ def test_shplonk_prover_host_logic(oracle):
     assert written == ["shplonk_h1", "shplonk_h2"]
     for got, exp in ((pr["h1"], g["h1"]), (pr["h2"], g["h2"])):
         assert zo.affine_to_ints(got[0].reshape(1, 8))[0] == (H(exp[0]), H(exp[1]))
+
+
+def test_published_eip196_add_and_mul_vectors(oracle):
+    """External anchors for G1 arithmetic on points of UNKNOWN discrete logarithm (everything else here multiplies the generator): go-ethereum's
+    published bn256Add / bn256ScalarMul vectors "chfast1" (EIP-196 precompiles; tests/golden/eip196_published.json).  The big-int model
+    (oracle/pyref.py) and the C oracle's best_multiexp (oracle/zkoracle.c, the restatement of halo2curves' multiexp the reference pins:
+    /root/reference/Cargo.lock:1359-1361) both reproduce them."""
+    import json
+    import os
+
+    import pyref as P
+
+    zo = oracle
+    v = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "eip196_published.json")))
+    H = lambda s: int(s, 16)
+    pt = lambda xy: (H(xy[0]), H(xy[1]))
+    a, b, c = pt(v["add"]["a"]), pt(v["add"]["b"]), pt(v["add"]["sum"])
+    assert P.to_affine(P.jac_add(P.from_affine(a), P.from_affine(b))) == c
+    m, s, r = pt(v["mul"]["point"]), H(v["mul"]["scalar"]), pt(v["mul"]["product"])
+    assert P.to_affine(P.scalar_mul(s, P.from_affine(m))) == r
+    one = [1, 1]
+    got = zo.affine_to_ints(zo.g1_to_affine(zo.best_multiexp(zo.fr_arr_from_ints(one), zo.affine_from_ints([a, b]), 2)).reshape(1, 8))[0]
+    assert got == c
+    got = zo.affine_to_ints(zo.g1_to_affine(zo.best_multiexp(zo.fr_arr_from_ints([s, 0]), zo.affine_from_ints([m, a]), 2)).reshape(1, 8))[0]
+    assert got == r
+    a2, b2, c2 = pt(v["add2"]["a"]), pt(v["add2"]["b"]), pt(v["add2"]["sum"])
+    assert P.to_affine(P.jac_add(P.from_affine(a2), P.from_affine(b2))) == c2 == m
+    for case in v["mul_more"]:
+        pnt, sc, want = pt(case["point"]), H(case["scalar"]) % P.R, pt(case["product"])
+        assert P.to_affine(P.scalar_mul(sc, P.from_affine(pnt))) == want
+        got = zo.affine_to_ints(zo.g1_to_affine(zo.best_multiexp(zo.fr_arr_from_ints([sc, 1, P.R - 1]), zo.affine_from_ints([pnt, a, a]), 2)).reshape(1, 8))[0]
+        assert got == want          # (+ a - a: a three-term sum whose other terms cancel)
