@@ -24,6 +24,14 @@ coset NTTs by polynomial, the quotient sweep by row range; partial sums / column
 (zkhip_comm_*), everything else replicated -> "scaling": "strong".  --replicas runs N independent proofs instead ("weak");
 --chain runs BASELINE configs[4] (2 x RSA + 2 x SHA leaf proofs on 4 ranks, barrier, then the sharded aggregation proof).
 Prints ONE JSON line (rank 0).
+
+Parity (round 5): every proof the CPU leg makes and every distinct proof of the HIP path is kept by sha256; the line's `parity` block lists the
+pairs both legs proved (RSA k = 17 at its own size and the headline SHAPE at the CPU sample's size in a default run; the headline itself with
+--cpu-baseline-k 22) and bench.py EXITS NON-ZERO when a pair differs — north_star's "proof bytes bit-identical to the CPU prover on the same SRS and
+witness" is checked in every run, not only in tests.
+--replay-rank R --of N: a MEASUREMENT MODE on one GPU — this process runs exactly what rank R of an N-rank proof runs (the library's RCCL branch bound
+to tools/replay_rccl, which fabricates what the peers would send and can hold the communicator's stream for a modelled wire time), alone.  The line
+is an N = 1 line with a `replay` block that says so; its proof bytes are wrong by construction and are offered for no comparison.
 """
 import argparse
 import glob
