@@ -1126,10 +1126,17 @@ def worker(args):
             out["replay"] = replay_block(head.get("replay_exchanges_per_step"))
         out["gpu_proofs"] = gpu_proofs
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"], rsa_cb = cpu_baseline(pv, args, args.config, head["k"], head["transcript"])
-            if rsa_cb and "rsa17" in out_configs and "error" not in out_configs["rsa17"]:
-                out_configs["rsa17"]["cpu_baseline"] = rsa_cb
-            finish_parity(out)
+            try:
+                out["cpu_baseline"], rsa_cb = cpu_baseline(pv, args, args.config, head["k"], head["transcript"])
+                if rsa_cb and "rsa17" in out_configs and "error" not in out_configs["rsa17"]:
+                    out_configs["rsa17"]["cpu_baseline"] = rsa_cb
+                finish_parity(out)
+            except Exception as e:   # noqa: BLE001 — the GPU measurement stands on its own: the line still comes out, the CPU leg says why it is missing
+                import traceback
+
+                traceback.print_exc()
+                out["cpu_baseline"] = dict(error=f"{type(e).__name__}: {e}"[:300])
+                out["parity"] = None
         else:
             out["cpu_baseline"] = None     # N > 1: the GPU-free supervisor of rank 0 times it once the workers are gone (supervise())
             out["parity"] = None           # ... and compares the digests in gpu_proofs with the CPU oracle's
