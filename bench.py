@@ -282,6 +282,24 @@ def finish_parity(out):
     return out["parity"]["bytes_equal"]
 
 
+def chain_leaf_groups(n_ranks, grouped=True):
+    """--chain: {leaf index: [ranks]} — who proves which of the four leaves (0, 2: RSA-shaped k = 17; 1, 3: SHA-shaped k = 19).  Leaf j's head is
+    rank j.  From 6 ranks on (grouped) the ranks 4.. — idle until the aggregation proof otherwise — are dealt to the two SHA leaves, whose proofs take
+    4.5x as long as the RSA ones.  Group sizes are powers of two (the sweep and the exchanges divide the rows by the group size; single-rank replay,
+    k = 19: 31.0 ms on one rank, 18.6 over two, 19.4 over three): each SHA leaf takes 2^e - 1 of the extra ranks, the largest e that both can have —
+    one each at 6-9 ranks, three each from 10."""
+    groups = {j: [j] for j in range(4)}
+    if grouped and n_ranks >= 6:
+        extra = 1
+        while 2 * (2 * extra + 1) <= n_ranks - 4:
+            extra = 2 * extra + 1
+        pool = list(range(4, n_ranks))
+        for j in (1, 3):
+            groups[j] += pool[:extra]
+            pool = pool[extra:]
+    return groups
+
+
 LADDER = {
     # one sharded proof: each rung is a FRESH set of worker processes (a rank that touched the GPU is never reused or exec'ed over).
     # From the second rung on the library's bulk communicator is off too (ZKHIP_COMM_BULK=0: no ncclCommSplit, one communicator as in round 4):
@@ -874,17 +892,7 @@ def worker(args):
         # ranks 1 + 4, leaf 3 over ranks 3 + 5): such a leaf is ONE proof over its group's own communicator, MSMs by column (k = 19: one MSM
         # cannot fill several GPUs), the same bytes on every member.  The leaf contexts' communicators are used before the barrier, the
         # aggregation proof's after it: never two collectives of different communicators in flight on one device.
-        groups = {j: [j] for j in range(4)}
-        if shard and vworld >= 6 and not args.no_leaf_groups:
-            # group sizes are powers of two (the sweep and the exchanges divide the rows by the group size; single-rank replay, k = 19: 31.0 ms on
-            # one rank, 18.6 over two, 19.4 over three): each SHA leaf takes (N - 4) / 2 extra ranks rounded down to 2^e - 1 — one each at N = 6 … 9
-            extra = 1
-            while 2 * (2 * extra + 1) <= vworld - 4:
-                extra = 2 * extra + 1
-            pool = list(range(4, vworld))
-            for j in (1, 3):
-                groups[j] += pool[:extra]
-                pool = pool[extra:]
+        groups = chain_leaf_groups(vworld, shard and not args.no_leaf_groups)
         my_leaf = next((j for j, rs in groups.items() if vrank in rs), None)
         if any(len(rs) > 1 for rs in groups.values()):
             pgs = {}

@@ -91,3 +91,20 @@ def test_the_recorded_rsa_k17_digest_is_this_trees_oracle():
     p = pv.Prover(OracleBackend(os.cpu_count() or 8), pv.CircuitShape.rsa(17), satisfiable=True)
     got = hashlib.sha256(bytes(p.prove(p.witness(0), transcript="poseidon")["proof"])).hexdigest()
     assert got == want["rsa_k17/poseidon/witness0"]
+
+
+def test_chain_leaf_groups():
+    """bench.py --chain: who proves which leaf (BASELINE configs[4], /root/reference/src/tests/x509_aggregation.rs:20-110): one leaf per rank below 6
+    ranks; from 6 on the extra ranks join the two SHA-shaped leaves in groups whose sizes are powers of two; every rank is in at most one group"""
+    import bench
+
+    flat = {j: [j] for j in range(4)}
+    assert bench.chain_leaf_groups(4) == flat and bench.chain_leaf_groups(5) == flat and bench.chain_leaf_groups(8, grouped=False) == flat
+    assert bench.chain_leaf_groups(6) == {0: [0], 1: [1, 4], 2: [2], 3: [3, 5]}
+    assert bench.chain_leaf_groups(8) == {0: [0], 1: [1, 4], 2: [2], 3: [3, 5]}          # ranks 6, 7: no leaf (a third member would stop the rows dividing)
+    assert bench.chain_leaf_groups(10) == {0: [0], 1: [1, 4, 5, 6], 2: [2], 3: [3, 7, 8, 9]}
+    for n in range(4, 20):
+        g = bench.chain_leaf_groups(n)
+        ranks = [r for rs in g.values() for r in rs]
+        assert len(ranks) == len(set(ranks)) and all(0 <= r < n for r in ranks) and all(len(rs) & (len(rs) - 1) == 0 for rs in g.values())
+        assert all(rs[0] == j for j, rs in g.items()) and len(g[1]) == len(g[3]) and len(g[0]) == len(g[2]) == 1
