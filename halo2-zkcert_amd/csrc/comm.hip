@@ -11,6 +11,10 @@
 // in the other order is the classic RCCL deadlock.  Every all-gather is therefore enqueued on the communicator's own stream, fenced
 // with events against the stream that produces / consumes the data; the enqueue order is the host's program order, identical on
 // every rank.
+// Round 5: a second, BULK communicator (ncclCommSplit of the first over the same ranks) with its own stream carries the all-to-alls of row
+// windows — tens of megabytes per peer that only the sweep reads — and nothing else, so the latency-sized exchanges a commitment waits for never
+// sit behind them in a FIFO.  The discipline is unchanged: one stream per communicator, nothing else on it, the host's program order on every rank,
+// and never a collective of one communicator queued behind a collective of the other.
 // RCCL is resolved at run time (dlopen of the already-loaded librccl — torch ships its own copy with the same SONAME, and two
 // RCCL / HIP runtimes in one process do not share devices), so the library still loads where RCCL is absent.
 // A second transport stages the same all-gathers through host buffers and a caller-supplied function: bring-up and tests on a
