@@ -231,6 +231,7 @@ def cpu_baseline(pv, args, config, head_k, transcript):
         out = dict(value=round(t_m * scale, 4), unit="s", cores=threads, kind="port", measured_s=round(t_m, 4), scale=round(scale, 4),
                    sample=f"{shape_at(k_m).name}: ONE full pass at k = {k_m} = {t_m:.3f} s; {k18_txt}; growth per 4x rows k = 18 -> {k_m} = {per4:.3f}; {how}"
                           "; oracle/zkoracle.c with OpenMP, SRS / keygen excluded",
+                   sample_short=f"{shape_at(k_m).name}: one pass at k={k_m} = {t_m:.2f} s" + ("" if k_m == head_k else f" x{scale:.3f} ({'recorded k22/k20 ratio' if use_rec else 'measured growth'})") + f"; zkoracle.c, {threads} OpenMP threads",
                    measured_k=k_m, k18_s=round(med18, 4), growth_per_4x_rows=round(per4, 4),
                    # `value` is a MEASUREMENT only when the timed pass ran at the headline size; otherwise it is the measured pass carried to the
                    # headline size: say so in a field, not only in the sample text
@@ -243,7 +244,8 @@ def cpu_baseline(pv, args, config, head_k, transcript):
     else:
         sh = shape_at(head_k) if config == "agg22" else make_shape(pv, config, args)
         med, ts = cpu_pass_seconds(pv, sh, transcript, threads)
-        out = dict(value=round(med, 4), unit="s", cores=threads, kind="port", measured_s=round(med, 4), scale=1.0, extrapolated=False, extrapolation=None,
+        out = dict(value=round(med, 4), unit="s", cores=threads, kind="port", measured_s=round(med, 4), scale=1.0, extrapolated=False, extrapolation=None, measured_k=sh.k,
+                   sample_short=f"{sh.name}: median of 3 full passes = {med:.3f} s; zkoracle.c, {threads} OpenMP threads",
                    sample=f"{sh.name}: median of 3 full passes after a warm-up ({', '.join(f'{t:.3f}' for t in ts)}); "
                           "oracle/zkoracle.c with OpenMP, SRS / keygen excluded")
     out["proof_k"], out["proof_sha256"] = CPU_PROOFS[-1]["k"], CPU_PROOFS[-1]["proof_sha256"]     # the pass that was timed last = the measured size
@@ -262,7 +264,8 @@ def chain_cpu_baseline(pv, args):
     agg, _ = cpu_baseline(pv, args, "agg22", args.agg_k, "evm")
     med17, _ = cpu_pass_seconds(pv, pv.CircuitShape.rsa(17), "poseidon", threads)                                           # leaf 0's instance (witness 0)
     t19, _ = cpu_pass_seconds(pv, make_shape(pv, "sha19", args), "poseidon", threads, repeats=1, warm=False, witness_seed=1)   # leaf 1's instance (witness 1)
-    return dict(value=round(2 * med17 + 2 * t19 + agg["value"], 4), unit="s", cores=threads, kind="port",
+    return dict(value=round(2 * med17 + 2 * t19 + agg["value"], 4), unit="s", cores=threads, kind="port", extrapolated=agg.get("extrapolated"), measured_k=agg.get("measured_k"),
+                sample_short=f"2 x rsa_k17 ({med17:.2f} s) + 2 x sha_k19 ({t19:.2f} s) + agg ({agg['value']:.1f} s{', extrapolated' if agg.get('extrapolated') else ''}); {threads} threads",
                 sample=f"2 x rsa_k17 ({med17:.3f} s, median of 3) + 2 x sha256_k19 ({t19:.3f} s, one pass) + the aggregation proof ({agg['value']:.3f} s: {agg['sample']})",
                 parts=dict(rsa17_s=round(med17, 4), sha19_s=round(t19, 4), agg=agg))
 
@@ -280,6 +283,96 @@ def finish_parity(out):
         if isinstance(cb_, dict) and cb_.get("proof_sha256") and c.get("proof_sha256"):
             cb_["bytes_equal"] = cb_["proof_sha256"] == c["proof_sha256"]
     return out["parity"]["bytes_equal"]
+
+
+LINE_LIMIT = 4096      # the driver reads the last stdout line; round 5's 24 KB line came back unparsed (BENCH_r05.parsed == null)
+
+
+def _cut(s, n):
+    return s if not isinstance(s, str) or len(s) <= n else s[: n - 3] + "..."
+
+
+def compact_line(out, detail_path):
+    """The ONE stdout line the driver parses: the contract's fields, `roofline` (incl. traffic), `int_roofline` (numbers), `cpu_baseline` (numbers,
+    `extrapolated`, `bytes_equal`), `parity` {bytes_equal, n_compared} and the name of the detail file; every string short.  Everything else of `out`
+    (configs, gpu_proofs, chain, comm, replay, the long notes) lives in the detail file only."""
+    cfg = out.get("config") or {}
+    line = {k_: out.get(k_) for k_ in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline")}
+    line["dtype"] = "u256"
+    line["data"] = out.get("data", "synthetic")
+    line["proofs_per_step"] = out.get("proofs_per_step")
+    line["config"] = {"workload": _cut(cfg.get("workload_short") or cfg.get("workload"), 126)}
+    for k_ in ("headline", "k", "advice", "fixed", "lookups", "perm_columns", "degree", "transcript"):
+        if k_ in cfg:
+            line["config"][k_] = cfg[k_]
+    line["config"]["parallelism"] = _cut(cfg.get("parallelism_short") or cfg.get("parallelism"), 126)
+    rf = out.get("roofline")
+    if isinstance(rf, dict):
+        line["roofline"] = {k_: rf.get(k_) for k_ in ("kernel", "bound", "achieved", "peak", "unit", "frac", "hbm_frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms") if k_ in rf}
+    else:
+        line["roofline"] = None
+    ir = out.get("int_roofline")
+    if isinstance(ir, dict):
+        line["int_roofline"] = {k_: ir.get(k_) for k_ in ("kernel", "achieved", "peak", "unit", "frac")}
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        c = {k_: cb[k_] for k_ in ("value", "unit", "cores", "kind", "measured_s", "measured_k", "scale", "extrapolated", "bytes_equal", "error") if k_ in cb}
+        if "sample" in cb:
+            c["sample"] = _cut(cb.get("sample_short") or cb["sample"], 126)
+        if isinstance(cb.get("measured_at_k22"), dict):
+            c["measured_at_k22_s"] = cb["measured_at_k22"].get("value")
+        line["cpu_baseline"] = c
+    else:
+        line["cpu_baseline"] = None
+    par = out.get("parity")
+    line["parity"] = {"bytes_equal": par.get("bytes_equal"), "n_compared": len(par.get("compared") or [])} if isinstance(par, dict) else None
+    for k_ in ("build", "setup_s", "first_proof_s"):
+        if out.get(k_) is not None:
+            line[k_] = out[k_]
+    if isinstance(out.get("with_h2d"), dict):
+        line["with_h2d_s"] = out["with_h2d"].get("value")
+    if isinstance(out.get("ffi_levels"), dict):
+        line["ffi_levels_s"] = {k_: v_.get("value") for k_, v_ in out["ffi_levels"].items() if isinstance(v_, dict) and "value" in v_}
+    if isinstance(out.get("configs"), dict):
+        line["configs_s"] = {k_: v_.get("value") for k_, v_ in out["configs"].items() if isinstance(v_, dict) and "value" in v_}
+    if isinstance(out.get("ladder"), dict):
+        line["ladder"] = {"rung": out["ladder"].get("rung"), "of": out["ladder"].get("of"), "label": _cut(out["ladder"].get("label"), 100)}
+    if isinstance(out.get("comm"), dict):
+        line["comm"] = {k_: out["comm"].get(k_) for k_ in ("transport", "nranks", "transport_ranks", "shard_mode", "collectives_per_step", "bytes_gathered_per_step")}
+    if isinstance(out.get("replay"), dict):
+        line["replay"] = {"rank": out["replay"].get("rank"), "of": out["replay"].get("of"), "note": "single-rank replay on 1 GPU, not an N-GPU measurement"}
+    line["detail"] = detail_path
+    text = json.dumps(line)
+    for victim in ("configs_s", "ffi_levels_s", "comm", "ladder", "replay"):     # never needed with the strings bounded as above; a guarantee, not a plan
+        if len(text) < LINE_LIMIT:
+            break
+        line.pop(victim, None)
+        text = json.dumps(line)
+    if len(text) >= LINE_LIMIT:
+        raise RuntimeError(f"bench.py: the stdout line is {len(text)} bytes (limit {LINE_LIMIT})")
+    return text
+
+
+def emit(out, args):
+    """Rank 0's last word: the whole result object goes to the detail file (--detail-out, default bench_detail.json next to this script), the compact
+    line (compact_line) to stdout.  A worker rank of an N > 1 run prints the WHOLE object instead: its stdout is a temp file its supervisor reads."""
+    if os.environ.get("ZKHIP_BENCH_ROLE") == "worker":
+        print(json.dumps(out), flush=True)
+        return
+    path = getattr(args, "detail_out", None) or os.path.join(ROOT, "bench_detail.json")
+    try:
+        with open(path, "w") as fh:
+            json.dump(out, fh, indent=1)
+            fh.write("\n")
+    except OSError:
+        import tempfile
+
+        with tempfile.NamedTemporaryFile("w", prefix="bench_detail_", suffix=".json", delete=False) as fh:
+            json.dump(out, fh, indent=1)
+            path = fh.name
+    shown = os.path.relpath(path, ROOT) if os.path.abspath(path).startswith(ROOT + os.sep) else path
+    print(f"bench.py: detail ({os.path.getsize(path)} bytes) in {shown}", file=sys.stderr, flush=True)
+    print(compact_line(out, shown), flush=True)
 
 
 def chain_leaf_groups(n_ranks, grouped=True):
@@ -465,7 +558,7 @@ def supervise(args):
                         finish_parity(out)
                     except Exception as e:   # noqa: BLE001 — the GPU measurement stands on its own
                         out["cpu_baseline"] = dict(error=str(e)[:300])
-                print(json.dumps(out), flush=True)
+                emit(out, args)
                 if isinstance(out.get("parity"), dict) and out["parity"].get("bytes_equal") is False:
                     print("bench.py: PARITY FAILURE: a HIP-path proof differs from the CPU oracle's: " + json.dumps([r for r in out["parity"]["compared"] if not r["equal"]]), file=sys.stderr, flush=True)
                     return 3
@@ -527,6 +620,8 @@ def main():
                     "(the library's row_sharded option; default: the library's, 1)")
     ap.add_argument("--no-leaf-groups", action="store_true", help="--chain, N >= 6: every leaf proof on one rank (ranks 4.. idle until the aggregation proof) instead of the "
                     "SHA-shaped leaves over rank groups")
+    ap.add_argument("--detail-out", default=None, help="where rank 0 writes the whole result object (default: bench_detail.json next to this script); "
+                    "stdout carries one compact line (< 4 KB) that names it")
     ap.add_argument("--agg-unsharded", action="store_true", help="--chain, N >= 4: the aggregation proof on rank 0 alone (last rung of the ladder: no collective)")
     args = ap.parse_args()
 
@@ -827,6 +922,8 @@ def worker(args):
                            + ("uniform field elements (the worst case for the commitments)" if witness == "uniform" or shape.layout == "sha" else
                               "drawn from SURVEY.md 8(d)'s value mix (limbs / bits / uniform)")
                            + (" [bit / word columns by construction]" if shape.layout == "sha" else "") + f"; {kind} transcript as {REFERENCE_CMD[name]}",
+               "workload_short": f"{shape.name}: {counts['msm']} MSM + {counts['intt_n']} iNTT + " + (f"{counts['ntt_ext']}x{coset_q} coset NTT + {coset_q} iNTT" if coset_q else
+                                 f"{counts['ntt_ext']} NTT_2^{prover.dom.extended_k} + 1 iNTT_2^{prover.dom.extended_k}") + f" of 2^{shape.k}, sweep {q_rows >> shape.k}x2^{shape.k} rows, SHPLONK; {kind}",
                "witness": "bits / words (SHA-256 bit circuit layout)" if shape.layout == "sha" else witness,
                "k": shape.k, "advice": shape.n_advice, "fixed": shape.n_fixed, "instance_values": prover.n_instance_values, "lookups": len(shape.lookups),
                "perm_columns": len(shape.perm_columns), "degree": shape.degree, "transcript": kind, "proof_bytes": len(trace.get("proof", b"")),
@@ -1053,7 +1150,7 @@ def worker(args):
         res = run_chain(args.steps, args.warmup)
         # one GPU: the five proofs in sequence, nothing scales (null); N >= 4: total work fixed while the aggregation proof is sharded ("strong");
         # --agg-unsharded (last rung of the ladder): the aggregation proof on rank 0 alone — more GPUs do not shorten it ("none")
-        chain_scaling = None if world == 1 else ("strong" if shard else "none")      # (a --replay-rank run is one process: null)
+        chain_scaling = (None if replay else "strong") if world == 1 else ("strong" if shard else "none")      # (a --replay-rank run is one process: null)
         if rank == 0:
             cb = parity = None
             if world == 1 and not args.no_cpu_baseline:      # N > 1: rank 0's GPU-free supervisor times it once the workers are gone
@@ -1062,14 +1159,15 @@ def worker(args):
                     parity = parity_check(gpu_proofs)
                 except Exception as e:   # noqa: BLE001 — the GPU measurement stands on its own
                     cb = dict(error=f"{type(e).__name__}: {e}"[:300])
-            print(json.dumps({"metric": "create_proof wall-time (s): RSA k=17 / SHA256 k=19 / agg k=22 at 1/2/4/8 GPU", "value": res["value"], "unit": "s",
-                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": False,
-                              "scaling": chain_scaling, "vs_baseline": None, "dtype": "u256 (BN254 Fr/Fq, Montgomery)", "data": "synthetic", "proofs_per_step": 5,
-                              "config": {"workload": res["workload"], "parallelism": res["parallelism"], "k": args.agg_k, "transcript": "evm"}, "proof_bytes": res["proof_bytes"], "proof_sha256": res["proof_sha256"],
-                              "comm": comm_fields(res["bytes_gathered_per_step"], "points" if args.shard == "auto" else args.shard, res["collectives_per_step"]),
-                              "roofline": res["roofline"], "cpu_baseline": cb, "gpu_proofs": gpu_proofs, "parity": parity, "build": bh,
-                              "phase_ms_per_step": res["phase_ms_per_step"], "leaf_proof_sha256": res["leaf_proof_sha256"], "leaf_groups": res["leaf_groups"],
-                              **({"replay": replay_block(res["replay_exchanges_per_step"])} if replay else {})}), flush=True)
+            emit({"metric": "create_proof wall-time (s): RSA k=17 / SHA256 k=19 / agg k=22 at 1/2/4/8 GPU", "value": res["value"], "unit": "s",
+                  "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": False,
+                  "scaling": chain_scaling, "vs_baseline": None, "dtype": "u256 (BN254 Fr/Fq, Montgomery)", "data": "synthetic", "proofs_per_step": 5,
+                  "config": {"workload": res["workload"], "workload_short": f"chain: 2 x RSA k=17 + 2 x SHA256-shaped k=19 leaf proofs (Poseidon), barrier, agg k={args.agg_k} proof (Keccak)",
+                             "parallelism": res["parallelism"], "k": args.agg_k, "transcript": "evm"}, "proof_bytes": res["proof_bytes"], "proof_sha256": res["proof_sha256"],
+                  "comm": comm_fields(res["bytes_gathered_per_step"], "points" if args.shard == "auto" else args.shard, res["collectives_per_step"]),
+                  "roofline": res["roofline"], "cpu_baseline": cb, "gpu_proofs": gpu_proofs, "parity": parity, "build": bh,
+                  "phase_ms_per_step": res["phase_ms_per_step"], "leaf_proof_sha256": res["leaf_proof_sha256"], "leaf_groups": res["leaf_groups"],
+                  **({"replay": replay_block(res["replay_exchanges_per_step"])} if replay else {})}, args)
             if parity and parity["bytes_equal"] is False:
                 print("bench.py: PARITY FAILURE: a HIP-path proof differs from the CPU oracle's: " + json.dumps([r for r in parity["compared"] if not r["equal"]]), file=sys.stderr, flush=True)
                 sys.exit(3)
@@ -1118,12 +1216,14 @@ def worker(args):
         out = {
             "metric": "create_proof wall-time (s): RSA k=17 / SHA256 k=19 / agg k=22 at 1/2/4/8 GPU",
             "value": head["value"], "unit": "s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
-            "higher_is_better": False, "scaling": None if world == 1 else ("strong" if shard else "weak"), "vs_baseline": None,
+            "higher_is_better": False, "scaling": ("weak" if args.replicas else "strong") if world == 1 and not replay else (None if replay else ("strong" if shard else "weak")), "vs_baseline": None,
             "proofs_per_step": 1 if (shard or world == 1) else world,
             "dtype": "u256 (BN254 Fr/Fq, Montgomery, 9 x 29-bit limbs in registers / 8 x u32 in HBM)", "data": "synthetic",
-            "config": {"workload": head["workload"], "headline": args.config, "k": head["k"], "advice": head["advice"], "fixed": head["fixed"],
+            "config": {"workload": head["workload"], "workload_short": head["workload_short"], "headline": args.config, "k": head["k"], "advice": head["advice"], "fixed": head["fixed"],
                        "lookups": head["lookups"], "perm_columns": head["perm_columns"], "degree": head["degree"], "transcript": head["transcript"],
                        "host": "prover.py (Python schedule over the C ABI)" if args.python_schedule else "zkhip_create_proof_ex (schedule and transcript in the library)",
+                       "parallelism_short": (f"rank {args.replay_rank} of {args.of}, replayed alone on 1 GPU" if replay else "1 GPU") if world == 1 else (
+                           f"one proof sharded x{world}: MSMs by {'point range' if head.get('msm_shard') == 'points' else 'column'}, NTTs by polynomial, sweep by rows" if shard else f"{world} independent proofs, one per GPU, no collective"),
                        "parallelism": (f"rank {args.replay_rank} of {args.of}, replayed alone on 1 GPU" if replay else "1 GPU") if world == 1 else (f"one proof sharded x{world}: MSMs by {'point range (window tables 1/' + str(world) + ' per rank)' if head.get('msm_shard') == 'points' else 'column (whole tables on every rank)'}, coset NTTs by polynomial, then an all-to-all of row windows (own row range + halo of every coset block: 1/N of an all-gather of complete columns), sweep by row range per coset block, the quotient's pieces / h(X) / SHPLONK on row ranges (numerator blocks to their owners and back, Kate division with carries across ranks), evaluations by query, all-gather of the 96-byte partial sums — all inside the library (ncclSend/ncclRecv groups, ncclAllGather)" if shard
                                                                    else f"{world} independent proofs, one per GPU, no collective")},
             "roofline": {k_: dom[k_] for k_ in ("kernel", "bound", "hbm_frac", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms", "note")},
@@ -1151,7 +1251,7 @@ def worker(args):
         else:
             out["cpu_baseline"] = None     # N > 1: the GPU-free supervisor of rank 0 times it once the workers are gone (supervise())
             out["parity"] = None           # ... and compares the digests in gpu_proofs with the CPU oracle's
-        print(json.dumps(out), flush=True)
+        emit(out, args)
         if out["parity"] and out["parity"]["bytes_equal"] is False:
             print("bench.py: PARITY FAILURE: a HIP-path proof differs from the CPU oracle's: " + json.dumps([r for r in out["parity"]["compared"] if not r["equal"]]), file=sys.stderr, flush=True)
             teardown()

@@ -11,16 +11,30 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _details(r, detail):
+    """the detail object of every JSON line on stdout (each line is held to the driver's bound: under 4 KB, naming a detail file that parses)"""
+    out = []
+    for ln in r.stdout.splitlines():
+        if ln.strip().startswith("{"):
+            assert len(ln) < 4096, len(ln)
+            line = json.loads(ln)
+            assert line["detail"] == detail and line["ladder"]["rung"] >= 1 and "cpu_baseline" in line and "roofline" in line and "parity" in line
+            d = json.load(open(detail))
+            assert d["ladder"]["rung"] == line["ladder"]["rung"] and d["value"] == line["value"] and d["n_gpus"] == line["n_gpus"]
+            out.append(d)
+    return out
+
+
 def _run(tmp_path, plan, extra=(), world=2, timeout=300):
     env = dict(os.environ, ZKHIP_BENCH_WORKER_SCRIPT=os.path.join(ROOT, "tests", "fake_bench_worker.py"), FAKE_PLAN=json.dumps(plan),
                FAKE_COUNT_DIR=str(tmp_path))
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "ZKHIP_BENCH_ROLE"):
         env.pop(k, None)
     t0 = time.time()
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--no-cpu-baseline"] + list(extra), capture_output=True,
+    detail = os.path.join(str(tmp_path), "detail.json")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--no-cpu-baseline", "--detail-out", detail] + list(extra), capture_output=True,
                        text=True, timeout=timeout, cwd=ROOT, env=env)
-    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
-    return r, lines, time.time() - t0
+    return r, _details(r, detail), time.time() - t0
 
 
 def test_first_rung_succeeds(tmp_path):
@@ -86,8 +100,8 @@ def test_supervisors_under_the_drivers_own_launch_line(tmp_path):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "ZKHIP_BENCH_ROLE"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True,
-                       timeout=300, cwd=ROOT, env=env)
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--detail-out", os.path.join(str(tmp_path), "detail.json")],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    lines = _details(r, os.path.join(str(tmp_path), "detail.json"))
     assert len(lines) == 1 and lines[0]["ladder"]["rung"] == 2

@@ -55,9 +55,19 @@ def _supervised(tmp_path, digest):
                FAKE_K="7", FAKE_GPU_PROOFS=json.dumps(proofs))
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "ZKHIP_BENCH_ROLE"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--agg-k", "7", "--no-ladder"], capture_output=True, text=True,
+    detail = os.path.join(str(tmp_path), "detail.json")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--agg-k", "7", "--no-ladder", "--detail-out", detail], capture_output=True, text=True,
                        timeout=300, cwd=ROOT, env=env)
-    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    lines = []
+    for ln in r.stdout.splitlines():
+        if ln.strip().startswith("{"):
+            # the N > 1 supervisor's line: under the driver's 4 KB, a parity summary and the CPU leg's numbers in it, everything else in the file it names
+            short = json.loads(ln)
+            assert len(ln) < 4096 and short["detail"] == detail and set(short["parity"]) == {"bytes_equal", "n_compared"} and "gpu_proofs" not in short
+            d = json.load(open(detail))
+            assert short["parity"]["bytes_equal"] == d["parity"]["bytes_equal"] and short["cpu_baseline"]["bytes_equal"] == d["cpu_baseline"]["bytes_equal"]
+            assert short["cpu_baseline"]["value"] == d["cpu_baseline"]["value"] and short["cpu_baseline"]["cores"] >= 1
+            lines.append(d)
     return r, lines
 
 

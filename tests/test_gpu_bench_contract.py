@@ -19,17 +19,40 @@ def _free_port():
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+             "roofline", "cpu_baseline", "parity", "detail")
+
+
 def _run(args, env=None, timeout=900):
-    r = subprocess.run([sys.executable] + args, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
-    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
-    assert len(lines) == 1
-    return json.loads(lines[0])
+    """-> the DETAIL object of one bench.py run (the file the stdout line names), with the parsed stdout line under "_line".  Every run is held to the
+    driver's contract: exactly one JSON line on stdout, shorter than 4 KB (round 5's 24 KB line came back from the driver unparsed), with every
+    required key, naming a detail file that parses."""
+    import tempfile
+
+    with tempfile.TemporaryDirectory(prefix="zkbench_detail_") as td:
+        path = os.path.join(td, "detail.json")
+        r = subprocess.run([sys.executable] + args + ["--detail-out", path], capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+        assert len(lines) == 1 and r.stdout.rstrip().splitlines()[-1] == lines[0]
+        assert len(lines[0]) < 4096, len(lines[0])
+        line = json.loads(lines[0])
+        for key in LINE_KEYS:
+            assert key in line, key
+        assert line["detail"] == path and all(len(v) <= 128 for v in line["config"].values() if isinstance(v, str))
+        d = json.load(open(path))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline"):
+        assert line[key] == d[key], key
+    d["_line"], d["_stderr"] = line, r.stderr
+    return d
 
 
-def test_bench_prints_one_contract_line():
-    """the default headline (aggregation-shaped k = 22 under Keccak), one step, no other configurations"""
-    d = _run([os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-other-configs"])
+def test_the_drivers_exact_command_prints_one_short_line():
+    """`python bench.py --gpus 1 --steps 2 --warmup 1` — the driver's command (it uses more steps), other configurations, chain and CPU leg included:
+    ONE stdout line under 4 KB with the contract's fields, `roofline` (incl. traffic), `int_roofline`, `cpu_baseline` and the parity summary; the whole
+    result object (configs, gpu_proofs, chain, notes) in the detail file the line names.  Headline: aggregation-shaped k = 22 under Keccak."""
+    d = _run([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1"], timeout=1200)
+    ln = d["_line"]
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline", "cpu_baseline", "configs", "setup_s", "resident_bytes", "with_h2d", "build"):
         assert key in d, key
@@ -41,27 +64,38 @@ def test_bench_prints_one_contract_line():
     assert rf["bound"] in ("hbm", "mfma", "valu") and abs(rf["hbm_frac"] - rf["frac"]) < 1e-9 and rf["unit"] in ("GB/s", "TFLOP/s") and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and rf["avg_launch_ms"] > 0
     assert rf["traffic"] is None or rf["traffic"] > 0          # quoted only when profiles/ holds a PMC pass of exactly this build
+    # the line itself: numbers only, the same as the detail's
+    assert ln["config"]["headline"] == "agg22" and ln["config"]["k"] == 22 and ln["config"]["transcript"] == "evm" and ln["config"]["workload"].startswith("agg_k22")
+    for k_ in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms"):
+        assert ln["roofline"][k_] == rf[k_], k_
+    assert ln["int_roofline"]["frac"] == d["int_roofline"]["frac"] and 0 < ln["int_roofline"]["frac"] < 1 and ln["int_roofline"]["unit"] == "Tmad/s"
+    assert ln["parity"] == {"bytes_equal": True, "n_compared": len(d["parity"]["compared"])}
+    for k_ in ("value", "unit", "cores", "kind", "measured_s", "measured_k", "scale", "extrapolated", "bytes_equal"):
+        assert ln["cpu_baseline"][k_] == d["cpu_baseline"][k_], k_
+    assert ln["cpu_baseline"]["sample"] and len(ln["cpu_baseline"]["sample"]) <= 128 and ln["cpu_baseline"]["extrapolated"] is True
+    assert set(ln["configs_s"]) >= {"agg22", "rsa17", "sha19", "chain"} and ln["configs_s"]["agg22"] == d["value"]
     cfg = d["configs"]["agg22"]
     assert set(cfg["rooflines"]) == {"msm_accum_affine", "ntt", "sweep"}
     for r in cfg["rooflines"].values():
         assert 0 < r["frac"] < 1 and r["avg_launch_ms"] > 0 and r["unit"] == "GB/s"
     assert cfg["with_h2d"]["value"] > d["value"] * 0.9 and cfg["with_h2d"]["h2d_bytes"] == cfg["advice"] * (1 << 22) * 32
     assert cfg["setup_s"] > 0 and cfg["resident_bytes"] > (6 << 30) and cfg["proof_bytes"] > 1000
+    for name in ("rsa17", "sha19", "chain"):
+        assert "error" not in d["configs"][name] and d["configs"][name]["value"] > 0, d["configs"][name]
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > d["value"] and cb["unit"] == "s" and cb["sample"]
-    # measured at k = 20 (one full pass) and carried to k = 22 by the k = 22 / k = 20 ratio of the RECORDED real passes (profiles/r04_cpu_k22.json),
-    # which the line quotes beside it (measured_at_k22: scale 1 on record)
-    assert cb["measured_k"] == 20 and 3.0 < cb["scale"] <= 5.0 and 3.0 < cb["growth_per_4x_rows"] < 8.0
+    # measured at k = 20 (one full pass) and carried to k = 22 by the k = 22 / k = 20 ratio of the RECORDED real passes (profiles/r04_cpu_k22.json)
+    # when this box has the record's core count (the line quotes it beside: measured_at_k22), else by the measured k = 18 -> 20 growth
+    assert cb["measured_k"] == 20 and 3.0 < cb["scale"] <= 8.0 and 3.0 < cb["growth_per_4x_rows"] < 8.0
     assert abs(cb["value"] - cb["measured_s"] * cb["scale"]) < 0.05 and cb["k18_s"] < cb["measured_s"]
     m22 = cb["measured_at_k22"]
-    assert m22["value"] > 3.0 * m22["k20_s"] > 9.0 * m22["k18_s"] and m22["cores"] == cb["cores"] and "profiles/r04_cpu_k22.json" in m22["source"]
-    assert abs(cb["scale"] - m22["value"] / m22["k20_s"]) < 1e-3
+    assert m22["value"] > 3.0 * m22["k20_s"] > 9.0 * m22["k18_s"] and "profiles/r04_cpu_k22.json" in m22["source"]
     assert d["comm"] is None and d["first_proof_s"] > d["setup_s"]
     # north_star's "proof bytes bit-identical to the CPU prover": the CPU leg's k = 20 pass proved the same instance as the GPU's parity sample
-    # (the headline shape at k = 20), digests compared in the line; a mismatch would have made bench.py exit non-zero
-    assert d["scaling"] is None
+    # (the headline shape at k = 20), and RSA k = 17 at its own size; digests compared in the line; a mismatch would have made bench.py exit non-zero
+    assert d["scaling"] == "strong"
     assert d["parity_sample"]["k"] == 20 and d["parity_sample"]["proof_sha256"] == cb["proof_sha256"] and cb["proof_k"] == 20 and cb["bytes_equal"] is True
-    assert d["parity"]["bytes_equal"] is True and [r["k"] for r in d["parity"]["compared"]] == [20]
+    assert d["parity"]["bytes_equal"] is True and {r["k"] for r in d["parity"]["compared"]} == {17, 20}
 
 
 def test_bench_two_ranks_on_one_device():
@@ -118,14 +152,12 @@ def test_a_stuck_collective_moves_the_run_to_the_next_rung():
     env = dict(os.environ, ZKHIP_BENCH_ONE_DEVICE="1", ZKHIP_BENCH_DIST_BACKEND="gloo", ZKHIP_COMM_TRANSPORT="rccl", ZKHIP_RCCL_LIB=_fake_rccl(),
                ZKFAKE_RCCL_SLOT_MB="64", ZKFAKE_RCCL_STALL="device-row:1:6", ZKFAKE_RCCL_STALL_S="600")
     env.pop("WORLD_SIZE", None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--agg-k", "16", "--shard", "points",
-                        "--no-cpu-baseline", "--comm-timeout-ms", "4000", "--rung-budget", "60"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
-    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
-    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][-1])
-    assert d["ladder"]["rung"] == 2 and d["scaling"] == "strong" and d["comm"]["transport"] == "rccl", r.stderr[-3000:]
+    d = _run([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--agg-k", "16", "--shard", "points",
+              "--no-cpu-baseline", "--comm-timeout-ms", "4000", "--rung-budget", "60"], env=env)
+    assert d["ladder"]["rung"] == 2 and d["scaling"] == "strong" and d["comm"]["transport"] == "rccl", d["_stderr"][-3000:]
     why = d["ladder"]["failed_rungs"][0]["why"]
     assert "exited with code" in why or "overran" in why, why
-    assert "stalls its stream" in r.stderr
+    assert "stalls its stream" in d["_stderr"]
 
 
 def test_a_blocked_collective_call_is_ended_by_the_rung_budget():
@@ -212,7 +244,7 @@ def test_single_rank_replay_issues_the_exchanges_of_a_real_rank():
     bytes per proof in both — the replay times rank 0's real launch structure.  The replay line says what it is and offers no proof for comparison."""
     common = ["--steps", "2", "--warmup", "1", "--agg-k", "18", "--shard", "points", "--no-cpu-baseline"]
     rp = _run([os.path.join(ROOT, "bench.py"), "--replay-rank", "0", "--of", "2"] + common)
-    assert rp["n_gpus"] == 1 and rp["scaling"] is None and rp["replay"]["rank"] == 0 and rp["replay"]["of"] == 2 and "SINGLE-RANK REPLAY" in rp["replay"]["note"]
+    assert rp["n_gpus"] == 1 and rp["scaling"] is None and rp["_line"]["replay"]["of"] == 2 and rp["replay"]["rank"] == 0 and rp["replay"]["of"] == 2 and "SINGLE-RANK REPLAY" in rp["replay"]["note"]
     assert rp["gpu_proofs"] == [] and rp["parity"] is None and rp["cpu_baseline"] is None
     ex = rp["replay"]["exchanges_per_step"]
     assert rp["comm"]["transport"] == "rccl" and rp["comm"]["nranks"] == 2 and rp["comm"]["transport_ranks"] == 2
