@@ -681,6 +681,9 @@ def worker(args):
     if args.gpus != world:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}")
 
+    # the bulk communicator (csrc/comm.hip): off by default in the library since round 6 (a caller without a fallback ladder must not meet two
+    # co-resident communicators first); bench.py opts in — its ladder's later rungs switch it off again (ZKHIP_COMM_BULK=0 in their environment)
+    os.environ.setdefault("ZKHIP_COMM_BULK", "1")
     ctx = ffi.Context(local_rank)
     replay = args.replay_rank is not None
     shard = (world > 1 or replay) and not args.replicas and not (args.chain and args.agg_unsharded)

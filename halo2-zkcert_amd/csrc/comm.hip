@@ -190,9 +190,11 @@ int comm_row_copies(zkhip_ctx* ctx, const std::vector<RowCopy>& list) {
 // send_to[r] = 0: this rank has nothing for rank r; recv_from[r] = 0: rank r has nothing for this rank (null = all ones).  The two patterns
 // must be consistent across the ranks (they follow from column / block ownership, which every rank knows).  RCCL skips the silent pairs;
 // the host transport moves the padded buffers (a test transport: its counter says so).
-int comm_alltoall(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t bytes, const uint8_t* send_to, const uint8_t* recv_from, bool bulk) {
+// with_self (the init-time self-checks of a ONE-rank communicator only, RCCL transport): the pair (rank, rank) is part of the group — a grouped
+// ncclSend / ncclRecv to self is legal (NCCL 2.7+) and is the only way one process can drive those entry points of the real library.
+int comm_alltoall(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t bytes, const uint8_t* send_to, const uint8_t* recv_from, bool bulk, bool with_self) {
     zkhip_comm& cm = ctx->comm;
-    if (cm.nranks <= 1 || bytes == 0) return ZKHIP_OK;
+    if ((cm.nranks <= 1 && !with_self) || bytes == 0) return ZKHIP_OK;
     // which communicator: the bulk one for the exchanges that asked for it, if the context has one — its own stream and events, so the
     // transfer neither waits behind nor delays the latency-sized exchanges on the first communicator
     const bool on_bulk = bulk && cm.nccl_bulk;
@@ -238,7 +240,7 @@ int comm_alltoall(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t bytes
     ncclResult_t first = 0;
     const char* what = "";
     for (size_t r = 0; r < N && !first; ++r) {
-        if ((int)r == cm.rank) continue;
+        if ((int)r == cm.rank && !with_self) continue;
         if (!send_to || send_to[r]) { first = g_rccl.Send((const char*)d_send + r * bytes, bytes, ncclInt8, (int)r, c, cstream); what = "ncclSend"; }
         if (!first && (!recv_from || recv_from[r])) { first = g_rccl.Recv((char*)d_recv + r * bytes, bytes, ncclInt8, (int)r, c, cstream); what = "ncclRecv"; received += bytes; }
     }
@@ -269,6 +271,163 @@ int comm_fold_partials(zkhip_ctx* ctx, const void* d_part, size_t ncols, void* d
     return ZKHIP_OK;
 }
 }  // namespace zk
+
+
+namespace {
+enum : uint32_t {          // zkhip_comm::selfcheck (zkhip_profile_counter "comm_selfcheck")
+    SC_A2A = 1,            // the tagged grouped send / recv exchange on the first communicator arrived intact on every rank
+    SC_SPLIT = 2,          // ncclCommSplit gave a bulk communicator (and its stream / events exist) on every rank
+    SC_A2A_BULK = 4,       // the tagged exchange on the bulk communicator arrived intact on every rank
+    SC_COUNTS = 8,         // ncclCommCount / ncclCommUserRank of every communicator of this context agree with (nranks, rank)
+    SC_SELF_PAIR = 16,     // the groups contained the pair (rank, rank): a forced self-check of a one-rank communicator
+};
+struct SelfCheckBuf {      // 3 N blocks of 64 bytes: [0, N) what this rank sends, [N, 2N) what arrives, [2N, 3N) the verdict words
+    void* d = nullptr;
+    std::vector<uint32_t> h;
+    size_t N = 0;
+    static constexpr size_t blk = 64;
+    bool alloc(size_t nranks) {
+        N = nranks;
+        h.assign(3 * N * blk / 4, 0);
+        if (zk::dev_malloc(&d, 3 * N * blk) != hipSuccess) { (void)hipGetLastError(); d = nullptr; return false; }
+        return true;
+    }
+    void release() { if (d) (void)hipFree(d); d = nullptr; }
+};
+// tag word rank a sends rank b: first communicator (a << 16 | b), bulk communicator 0xB0000000 | a << 12 | b (tools/replay_rccl fabricates exactly these)
+inline uint32_t tag_word(bool bulk, uint32_t from, uint32_t to) { return bulk ? (0xB0000000u | (from << 12) | to) : ((from << 16) | to); }
+
+// One tagged all-to-all on the first / the bulk communicator.  -> ZKHIP_OK with *ok = the blocks arrived intact on THIS rank (0 also when local
+// resources were missing: nothing was issued); ZKHIP_EHIP when a call into RCCL failed (*issued_error) or the wait ran into the deadline (*timed_out).
+int selfcheck_exchange(zkhip_ctx* ctx, SelfCheckBuf& b, bool bulk, bool with_self, int* ok, bool* timed_out) {
+    const int rank = ctx->comm.rank;
+    const size_t N = b.N, blk = SelfCheckBuf::blk;
+    *timed_out = false;
+    *ok = b.d != nullptr;
+    if (*ok) {
+        std::fill(b.h.begin(), b.h.end(), 0u);
+        for (size_t r = 0; r < N; ++r) for (size_t w = 0; w < blk / 4; ++w) b.h[r * blk / 4 + w] = tag_word(bulk, (uint32_t)rank, (uint32_t)r);
+        *ok = hipMemcpy(b.d, b.h.data(), 3 * N * blk, hipMemcpyHostToDevice) == hipSuccess;
+    }
+    if (*ok && (!g_rccl.Send || !g_rccl.Recv || !g_rccl.GroupStart || !g_rccl.GroupEnd)) *ok = 0;
+    if (!*ok) return ZKHIP_OK;
+    if (comm_alltoall(ctx, b.d, (char*)b.d + N * blk, blk, nullptr, nullptr, bulk, with_self) != ZKHIP_OK) return ZKHIP_EHIP;
+    const hipError_t we = stream_wait(ctx, ctx->stream);
+    if (we == hipErrorLaunchTimeOut) { *timed_out = true; return ZKHIP_EHIP; }
+    *ok = we == hipSuccess && hipMemcpy(b.h.data(), b.d, 3 * N * blk, hipMemcpyDeviceToHost) == hipSuccess;
+    for (size_t r = 0; *ok && r < N; ++r)
+        if (((int)r != rank || with_self) && b.h[(N + r) * blk / 4] != tag_word(bulk, (uint32_t)r, (uint32_t)rank)) *ok = 0;
+    return ZKHIP_OK;
+}
+// The ranks agree on a verdict: every rank's word all-gathered on the FIRST communicator (the primitive every multi-GPU round has used) -> *all = every
+// rank said 1.  A failure of the all-gather itself counts as "no" (the proofs will report it).  ZKHIP_EHIP only when the wait ran into the deadline.
+int selfcheck_agree(zkhip_ctx* ctx, SelfCheckBuf& b, int mine, int* all, bool* timed_out) {
+    const size_t N = b.N, blk = SelfCheckBuf::blk, at = (2 * N + (size_t)ctx->comm.rank) * blk;
+    const uint32_t word = (uint32_t)mine;
+    hipError_t we = hipSuccess;
+    *timed_out = false;
+    *all = mine;
+    if (b.d && hipMemcpy((char*)b.d + at, &word, 4, hipMemcpyHostToDevice) == hipSuccess &&
+        comm_allgather(ctx, (char*)b.d + at, (char*)b.d + 2 * N * blk, blk) == ZKHIP_OK && (we = stream_wait(ctx, ctx->stream)) == hipSuccess &&
+        hipMemcpy(b.h.data(), (char*)b.d + 2 * N * blk, N * blk, hipMemcpyDeviceToHost) == hipSuccess) {
+        for (size_t r = 0; r < N; ++r) *all = *all && b.h[r * blk / 4] == 1u;
+    } else {
+        *all = 0;
+    }
+    if (we == hipErrorLaunchTimeOut) { *timed_out = true; return ZKHIP_EHIP; }
+    return ZKHIP_OK;
+}
+bool counts_agree(void* comm, int rank, int nranks) {
+    if (!comm || !g_rccl.CommCount || !g_rccl.CommUserRank) return false;
+    int cnt = -1, ur = -1;
+    return g_rccl.CommCount((ncclComm_t)comm, &cnt) == 0 && g_rccl.CommUserRank((ncclComm_t)comm, &ur) == 0 && cnt == nranks && ur == rank;
+}
+void drop_bulk(zkhip_comm& c_) {
+    (void)hipDeviceSynchronize();
+    if (c_.nccl_bulk && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)c_.nccl_bulk);
+    if (c_.stream_bulk) (void)hipStreamDestroy(c_.stream_bulk);
+    if (c_.ev_in_bulk) (void)hipEventDestroy(c_.ev_in_bulk);
+    if (c_.ev_out_bulk) (void)hipEventDestroy(c_.ev_out_bulk);
+    c_.nccl_bulk = nullptr; c_.stream_bulk = nullptr; c_.ev_in_bulk = nullptr; c_.ev_out_bulk = nullptr;
+}
+
+// zkhip_comm_init's self-checks (see there).  On a deadline expiry the communicator is marked stuck by the wait (zkhip_comm::stuck): the handle is
+// abandoned, and the check buffer — still the target of the stuck exchange — is deliberately not freed (hipFree would wait for the device).
+int comm_selfchecks(zkhip_ctx* ctx, bool with_self) {
+    zkhip_comm& c_ = ctx->comm;
+    const int rank = c_.rank, nranks = c_.nranks;
+    SelfCheckBuf b;
+    int ok = 0, all_ok = 0;
+    bool late = false;
+    (void)b.alloc((size_t)nranks);
+    uint32_t report = with_self ? SC_SELF_PAIR : 0;
+    if (selfcheck_exchange(ctx, b, false, with_self, &ok, &late) != ZKHIP_OK) {
+        if (late) { set_error("zkhip_comm_init: the all-to-all self-check did not complete"); return ZKHIP_EHIP; }
+        // a send / recv / group call FAILED on this communicator (not: wrong bytes arrived).  Its state is unknown, so no verdict
+        // all-gather is issued on it: init fails here, with the RCCL error, and the peers run into their wait deadline.
+        std::string why = zkhip_last_error();
+        b.release();
+        (void)zkhip_comm_destroy(ctx);
+        set_error("zkhip_comm_init: the all-to-all self-check could not be issued: %s", why.c_str());
+        return ZKHIP_EHIP;
+    }
+    if (selfcheck_agree(ctx, b, ok, &all_ok, &late) != ZKHIP_OK) {   // a peer failed its init (see above) or died: this rank follows, loudly
+        set_error("zkhip_comm_init: the verdict all-gather of the self-check did not complete (a peer failed or left)");
+        return ZKHIP_EHIP;
+    }
+    if (!all_ok)
+        fprintf(stderr, "zkhip_comm_init: the all-to-all self-check failed on some rank (this rank: %s): this communicator uses the all-gather exchange\n",
+                ok ? "ok" : "FAILED");
+    c_.a2a_ok = all_ok ? 1 : -1;   // lives and dies with the communicator; the user's row_sharded option is left alone
+    if (all_ok) report |= SC_A2A;
+    bool counts = counts_agree(c_.nccl, rank, nranks);
+    // The bulk communicator.  Three agreements, each all-gathered on the FIRST communicator so that every rank takes the same decision:
+    //   (1) "my split, stream, events and check buffer exist" — BEFORE anyone issues an exchange on the new communicator: a rank with a local
+    //       failure would otherwise sit out an all-to-all its peers have already entered (they would wait out comm_timeout_ms);
+    //   (2) the tagged exchange on it arrived intact.
+    // Any "no" (or a library without ncclCommSplit, or comm_bulk = 0) leaves nccl_bulk null on EVERY rank: those exchanges stay on the first communicator.
+    if (all_ok && (ctx->opt.comm_bulk != 0 || with_self) && g_rccl.CommSplit) {
+        ncclComm_t bulk = nullptr;
+        int okb = g_rccl.CommSplit((ncclComm_t)c_.nccl, 0, rank, &bulk, nullptr) == 0 && bulk;
+        if (okb) {
+            c_.nccl_bulk = bulk;
+            okb = hipStreamCreateWithFlags(&c_.stream_bulk, hipStreamNonBlocking) == hipSuccess &&
+                  hipEventCreateWithFlags(&c_.ev_in_bulk, hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&c_.ev_out_bulk, hipEventDisableTiming) == hipSuccess;
+        }
+        if (!b.d) okb = 0;
+        int ready = 0, all_b = 0;
+        if (selfcheck_agree(ctx, b, okb, &ready, &late) != ZKHIP_OK) {
+            set_error("zkhip_comm_init: the readiness all-gather of the bulk communicator did not complete (a peer failed or left)");
+            return ZKHIP_EHIP;
+        }
+        if (ready) {
+            report |= SC_SPLIT;
+            if (selfcheck_exchange(ctx, b, true, with_self, &okb, &late) != ZKHIP_OK) {
+                if (late) { set_error("zkhip_comm_init: the bulk communicator's self-check did not complete"); return ZKHIP_EHIP; }
+                okb = 0;     // the call into RCCL failed on the split: the first communicator is intact, say "no" on it
+            }
+            if (selfcheck_agree(ctx, b, okb, &all_b, &late) != ZKHIP_OK) {
+                set_error("zkhip_comm_init: the verdict all-gather of the bulk self-check did not complete (a peer failed or left)");
+                return ZKHIP_EHIP;
+            }
+            if (all_b) report |= SC_A2A_BULK;
+            counts = counts && counts_agree(c_.nccl_bulk, rank, nranks);
+        }
+        if (!all_b) {
+            fprintf(stderr, "zkhip_comm_init: no bulk communicator (this rank: %s): the row windows ride on the first communicator\n", okb ? "ok" : "FAILED");
+            drop_bulk(c_);
+        }
+    }
+    if (counts) report |= SC_COUNTS;
+    b.release();
+    c_.selfcheck = report;
+    c_.bytes_gathered = 0;
+    c_.collectives = 0;
+    c_.collectives_bulk = 0;
+    return ZKHIP_OK;
+}
+}  // namespace
 
 extern "C" {
 
@@ -311,115 +470,16 @@ int zkhip_comm_init(zkhip_ctx* ctx, const uint8_t id[128], int rank, int nranks)
     // build: prove it on THIS communicator before any proof depends on it.  Every rank sends peer r the word (rank << 16 | r) in a
     // 64-byte block and checks what arrives; the verdicts are all-gathered (the primitive the round-2 path has always used) so that
     // all ranks take the same decision: any failure switches this context to the all-gather exchange (row_sharded = 0), loudly.
-    if (nranks > 1) {
-        int ok = 1;
-        void* d_buf = nullptr;
-        const size_t blk = 64, N = (size_t)nranks;
-        if (zk::dev_malloc((void**)&d_buf, (2 * N + N) * blk) != hipSuccess) { (void)hipGetLastError(); ok = 0; }
-        std::vector<uint32_t> h((2 * N + N) * blk / 4, 0);
-        if (ok) {
-            for (size_t r = 0; r < N; ++r) for (size_t w = 0; w < blk / 4; ++w) h[r * blk / 4 + w] = ((uint32_t)rank << 16) | (uint32_t)r;
-            ok = hipMemcpy(d_buf, h.data(), (2 * N + N) * blk, hipMemcpyHostToDevice) == hipSuccess;
-        }
-        if (ok && (!g_rccl.Send || !g_rccl.Recv || !g_rccl.GroupStart || !g_rccl.GroupEnd)) ok = 0;
-        if (ok && comm_alltoall(ctx, d_buf, (char*)d_buf + N * blk, blk) != ZKHIP_OK) {
-            // a send / recv / group call FAILED on this communicator (not: wrong bytes arrived).  Its state is unknown, so no verdict
-            // all-gather is issued on it: init fails here, with the RCCL error, and the peers run into their wait deadline.
-            std::string why = zkhip_last_error();
-            (void)hipFree(d_buf);
-            (void)zkhip_comm_destroy(ctx);
-            set_error("zkhip_comm_init: the all-to-all self-check could not be issued: %s", why.c_str());
-            return ZKHIP_EHIP;
-        }
-        if (ok) {
-            const hipError_t we = stream_wait(ctx, ctx->stream);
-            if (we == hipErrorLaunchTimeOut) {   // a peer never arrived: the communicator is unusable and the device is busy waiting on it.  The context keeps the
-                // handle marked stuck (wait_poll set zkhip_comm::stuck): zkhip_comm_destroy / zkhip_destroy will not call into RCCL for it, and d_buf
-                // — still the target of the stuck exchange — is deliberately not freed (hipFree would wait for the device)
-                set_error("zkhip_comm_init: the all-to-all self-check did not complete");
-                return ZKHIP_EHIP;
-            }
-            ok = we == hipSuccess && hipMemcpy(h.data(), d_buf, (2 * N + N) * blk, hipMemcpyDeviceToHost) == hipSuccess;
-        }
-        for (size_t r = 0; ok && r < N; ++r)
-            if ((int)r != rank && h[(N + r) * blk / 4] != (((uint32_t)r << 16) | (uint32_t)rank)) ok = 0;
-        // agree: verdict of rank r at word r of the third region
-        uint32_t mine = (uint32_t)ok;
-        int all_ok = ok;
-        hipError_t we = hipSuccess;
-        if (d_buf && hipMemcpy((char*)d_buf + (2 * N + (size_t)rank) * blk, &mine, 4, hipMemcpyHostToDevice) == hipSuccess &&
-            comm_allgather(ctx, (char*)d_buf + (2 * N + (size_t)rank) * blk, (char*)d_buf + 2 * N * blk, blk) == ZKHIP_OK &&
-            (we = stream_wait(ctx, ctx->stream)) == hipSuccess && hipMemcpy(h.data(), (char*)d_buf + 2 * N * blk, N * blk, hipMemcpyDeviceToHost) == hipSuccess) {
-            for (size_t r = 0; r < N; ++r) all_ok = all_ok && h[r * blk / 4] == 1u;
-        } else {
-            all_ok = 0;   // (if even the all-gather fails the proofs will report it; the exchange mode no longer matters)
-        }
-        if (we == hipErrorLaunchTimeOut) {   // a peer failed its init (see above) or died: this rank follows, loudly (communicator marked stuck, d_buf abandoned: as above)
-            set_error("zkhip_comm_init: the verdict all-gather of the self-check did not complete (a peer failed or left)");
-            return ZKHIP_EHIP;
-        }
-        if (d_buf) (void)hipFree(d_buf);
-        ctx->comm.bytes_gathered = 0;
-        ctx->comm.collectives = 0;
-        if (!all_ok)
-            fprintf(stderr, "zkhip_comm_init: the all-to-all self-check failed on some rank (this rank: %s): this communicator uses the all-gather exchange\n",
-                    ok ? "ok" : "FAILED");
-        ctx->comm.a2a_ok = all_ok ? 1 : -1;   // lives and dies with the communicator; the user's row_sharded option is left alone
-        // The bulk communicator: a split of this one over the same ranks (no second unique id to distribute), own stream and events.  It
-        // carries the all-to-alls of row windows only.  Proved like the first one before anything depends on it — a tagged all-to-all
-        // on it, the verdicts all-gathered on the FIRST communicator so that every rank takes the same decision; any failure (or a library
-        // without ncclCommSplit, or comm_bulk = 0) leaves nccl_bulk null on EVERY rank and those exchanges on the first communicator.
-        if (all_ok && ctx->opt.comm_bulk != 0 && g_rccl.CommSplit) {
-            zkhip_comm& c_ = ctx->comm;
-            ncclComm_t bulk = nullptr;
-            int okb = g_rccl.CommSplit((ncclComm_t)c_.nccl, 0, rank, &bulk, nullptr) == 0 && bulk;
-            if (okb) {
-                c_.nccl_bulk = bulk;
-                okb = hipStreamCreateWithFlags(&c_.stream_bulk, hipStreamNonBlocking) == hipSuccess &&
-                      hipEventCreateWithFlags(&c_.ev_in_bulk, hipEventDisableTiming) == hipSuccess &&
-                      hipEventCreateWithFlags(&c_.ev_out_bulk, hipEventDisableTiming) == hipSuccess;
-            }
-            const size_t blk = 64, N = (size_t)nranks;
-            void* d_b = nullptr;
-            std::vector<uint32_t> hb(3 * N * blk / 4, 0);
-            if (zk::dev_malloc((void**)&d_b, 3 * N * blk) != hipSuccess) { (void)hipGetLastError(); okb = 0; d_b = nullptr; }
-            if (okb) {
-                for (size_t r = 0; r < N; ++r) for (size_t w = 0; w < blk / 4; ++w) hb[r * blk / 4 + w] = 0xB0000000u | ((uint32_t)rank << 12) | (uint32_t)r;
-                okb = hipMemcpy(d_b, hb.data(), 3 * N * blk, hipMemcpyHostToDevice) == hipSuccess;
-            }
-            if (okb && comm_alltoall(ctx, d_b, (char*)d_b + N * blk, blk, nullptr, nullptr, true) != ZKHIP_OK) okb = 0;
-            if (okb) {
-                const hipError_t we = stream_wait(ctx, ctx->stream);
-                if (we == hipErrorLaunchTimeOut) { set_error("zkhip_comm_init: the bulk communicator's self-check did not complete"); return ZKHIP_EHIP; }
-                okb = we == hipSuccess && hipMemcpy(hb.data(), d_b, 3 * N * blk, hipMemcpyDeviceToHost) == hipSuccess;
-            }
-            for (size_t r = 0; okb && r < N; ++r)
-                if ((int)r != rank && hb[(N + r) * blk / 4] != (0xB0000000u | ((uint32_t)r << 12) | (uint32_t)rank)) okb = 0;
-            uint32_t mine_b = (uint32_t)okb;
-            int all_b = okb;
-            hipError_t we2 = hipSuccess;
-            if (d_b && hipMemcpy((char*)d_b + (2 * N + (size_t)rank) * blk, &mine_b, 4, hipMemcpyHostToDevice) == hipSuccess &&
-                comm_allgather(ctx, (char*)d_b + (2 * N + (size_t)rank) * blk, (char*)d_b + 2 * N * blk, blk) == ZKHIP_OK &&
-                (we2 = stream_wait(ctx, ctx->stream)) == hipSuccess && hipMemcpy(hb.data(), (char*)d_b + 2 * N * blk, N * blk, hipMemcpyDeviceToHost) == hipSuccess) {
-                for (size_t r = 0; r < N; ++r) all_b = all_b && hb[r * blk / 4] == 1u;
-            } else {
-                all_b = 0;
-            }
-            if (we2 == hipErrorLaunchTimeOut) { set_error("zkhip_comm_init: the verdict all-gather of the bulk self-check did not complete (a peer failed or left)"); return ZKHIP_EHIP; }
-            if (d_b) (void)hipFree(d_b);
-            if (!all_b) {
-                fprintf(stderr, "zkhip_comm_init: no bulk communicator (this rank: %s): the row windows ride on the first communicator\n", okb ? "ok" : "FAILED");
-                (void)hipDeviceSynchronize();
-                if (c_.nccl_bulk && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)c_.nccl_bulk);
-                if (c_.stream_bulk) (void)hipStreamDestroy(c_.stream_bulk);
-                if (c_.ev_in_bulk) (void)hipEventDestroy(c_.ev_in_bulk);
-                if (c_.ev_out_bulk) (void)hipEventDestroy(c_.ev_out_bulk);
-                c_.nccl_bulk = nullptr; c_.stream_bulk = nullptr; c_.ev_in_bulk = nullptr; c_.ev_out_bulk = nullptr;
-            }
-            ctx->comm.bytes_gathered = 0;
-            ctx->comm.collectives = 0;
-            ctx->comm.collectives_bulk = 0;
-        }
+    // Then the bulk communicator (option comm_bulk): a split of this one over the same ranks (no second unique id to distribute), own stream
+    // and events, carrying the all-to-alls of row windows only; proved the same way with other tag words before anything depends on it.
+    // A ONE-rank communicator has no peers and no use for either — unless comm_selfcheck_force is set (round 6): then the same sequence runs
+    // with the pair (rank, rank) in every group, so that ONE process on ONE GPU drives ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd /
+    // ncclCommSplit / ncclCommCount / ncclCommUserRank and the destroy order of the REAL librccl (all a one-GPU pool can show of it; the
+    // N > 1 transport itself stays unexercised).  zkhip_profile_counter "comm_selfcheck" reports what ran (bits below).
+    const bool forced = nranks == 1 && ctx->opt.comm_selfcheck_force != 0;
+    if (nranks > 1 || forced) {
+        const int rc = comm_selfchecks(ctx, forced);
+        if (rc != ZKHIP_OK) return rc;
     }
     return ZKHIP_OK;
 }
@@ -448,13 +508,20 @@ int zkhip_comm_destroy(zkhip_ctx* ctx) {
     // a communicator a host wait has given up on (zkhip_comm::stuck): its stream holds a collective that will never complete, so neither the
     // device-wide wait nor ncclCommDestroy (which joins that collective) may be called — both would block for ever.  The handle is abandoned;
     // the streams / events are released by the runtime asynchronously, or by the process leaving (what a caller does after this error).
-    const bool dead = cm.stuck != 0;
-    if (!dead) (void)hipDeviceSynchronize();
-    if (cm.nccl_bulk && g_rccl.CommDestroy && !dead) (void)g_rccl.CommDestroy((ncclComm_t)cm.nccl_bulk);   // the split before its parent
+    const bool dead = cm.stuck != 0 || ctx->dead != 0;
+    if (dead) {
+        // neither RCCL nor the device may be touched: hipStreamDestroy / hipEventDestroy / hipHostFree of resources a stuck stream still uses can
+        // wait for that stream.  Everything is abandoned; ctx->dead outlives the reset below, so every later wait of the context still fails at once.
+        ctx->dead = 1;
+        cm = zkhip_comm();
+        return ZKHIP_OK;
+    }
+    (void)hipDeviceSynchronize();
+    if (cm.nccl_bulk && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)cm.nccl_bulk);   // the split before its parent
     if (cm.stream_bulk) (void)hipStreamDestroy(cm.stream_bulk);
     if (cm.ev_in_bulk) (void)hipEventDestroy(cm.ev_in_bulk);
     if (cm.ev_out_bulk) (void)hipEventDestroy(cm.ev_out_bulk);
-    if (cm.nccl && g_rccl.CommDestroy && !dead) (void)g_rccl.CommDestroy((ncclComm_t)cm.nccl);
+    if (cm.nccl && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)cm.nccl);
     if (cm.stream) (void)hipStreamDestroy(cm.stream);
     if (cm.ev_in) (void)hipEventDestroy(cm.ev_in);
     if (cm.ev_out) (void)hipEventDestroy(cm.ev_out);

@@ -61,8 +61,11 @@ struct zkhip_options {
     int permute_rank_sort = 1, eval_byval = 1, late_overlap = -1;
     int host_timing = 0;   // zkhip_create_proof prints its host-side phase times to stderr
     int row_sharded = 1;      // multi-rank proofs on the coset path: all-to-all of row windows (1) / all-gather of complete columns (0)
-    int comm_bulk = 1;        // multi-rank proofs: the all-to-alls of row windows (needed by the sweep only) ride on a SECOND communicator (ncclCommSplit) with its own stream, so the
-                              // latency-sized exchanges a commitment waits for never queue behind a 50 MB transfer (0: everything on the one communicator)
+    int comm_bulk = 0;        // multi-rank proofs: 1 = the all-to-alls of row windows (needed by the sweep only) ride on a SECOND communicator (ncclCommSplit) with its own stream, so the
+                              // latency-sized exchanges a commitment waits for never queue behind a 50 MB transfer; 0 (the library's default since round 6): everything on the one
+                              // communicator.  Two communicators' kernels must co-reside on every rank to make progress and that has only met stand-ins, so callers opt in
+                              // (bench.py's first rung does, with a fallback ladder behind it; a Rust caller has no ladder)
+    int comm_selfcheck_force = 0;   // zkhip_comm_init on a ONE-rank communicator still runs the self-checks, with the pair (rank, rank) in every group, and creates the bulk communicator (comm.hip)
     int comm_timeout_ms = 120000;   // host waits of a multi-rank context give up after this long (0: wait for ever): see zk::CommWatch
     int eval_chunks = -1;     // evaluations at x in this many launches, absorbed chunk by chunk while the next is computed (1: one launch; -1: by size)
     int rand_overlap = -1;    // the vanishing argument's random polynomial is committed on a third stream beside the grand products (0: with the advice batch; -1: by size)
@@ -93,6 +96,7 @@ struct zkhip_comm {
     uint64_t collectives = 0;     // exchanges issued so far
     int shard_columns = 0;        // MSMs over whole-SRS handles: 1 = split the batch by column over the ranks, 0 = replicate
     int a2a_ok = 0;               // verdict of zkhip_comm_init's all-to-all self-check: 1 passed on every rank, -1 failed somewhere, 0 not run
+    uint32_t selfcheck = 0;       // what zkhip_comm_init's self-checks ran and passed (bits: comm.hip SC_*; zkhip_profile_counter "comm_selfcheck")
     const char* phase = "";       // which part of the proof the host is issuing (what a timed-out wait reports)
     mutable int stuck = 0;        // a host wait of this context ran into comm_timeout_ms: the communicator's stream (and whatever waits on it) is taken for
                                   // dead from here on — later waits fail at once, error exits do not wait again, zkhip_comm_destroy does not touch RCCL
@@ -105,6 +109,10 @@ struct zkhip_ctx {
     int device = 0;
     zkhip_options opt;
     zkhip_comm comm;
+    // A host wait of this context ran into comm_timeout_ms (set together with zkhip_comm::stuck, but it SURVIVES zkhip_comm_destroy, which resets `comm`):
+    // some stream of the context is fenced behind a collective that will never complete.  Every later wait fails at once; zkhip_destroy neither
+    // synchronises nor frees device memory nor destroys streams (each of those would block for ever): it abandons them and returns.
+    mutable int dead = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -196,7 +204,7 @@ int comm_allgather(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t byte
 int comm_allgather_begin(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t bytes);
 int comm_allgather_end(zkhip_ctx* ctx);
 int comm_alltoall(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_pair, const uint8_t* send_to = nullptr, const uint8_t* recv_from = nullptr,
-                  bool bulk = false);   // bulk: on the bulk communicator when the context has one (same result either way)
+                  bool bulk = false, bool with_self = false);   // bulk: on the bulk communicator when the context has one (same result either way)
 struct RowCopy { const uint32_t* src; uint32_t* dst; uint32_t src_row0, dst_row0, count, src_mask, dst_mask; };
 #define ZK_ROWCOPY_MAX 48
 int comm_row_copies(zkhip_ctx* ctx, const std::vector<RowCopy>& list);

@@ -34,7 +34,7 @@ hipError_t dev_malloc(void** p, size_t bytes) {
 hipError_t wait_poll(const zkhip_ctx* c, hipStream_t st, hipEvent_t ev) {
     const double limit_ms = c && c->comm.nranks > 1 && c->opt.comm_timeout_ms > 0 ? (double)c->opt.comm_timeout_ms : 0.0;
     const auto t0 = std::chrono::steady_clock::now();
-    if (c && c->comm.stuck) {   // an earlier wait already gave up on this communicator: nothing queued behind it will ever run
+    if (c && (c->comm.stuck || c->dead)) {   // an earlier wait already gave up on this communicator: nothing queued behind it will ever run (dead: the flag that survives zkhip_comm_destroy)
         hipError_t e = ev ? hipEventQuery(ev) : hipStreamQuery(st);
         if (e != hipErrorNotReady) return e;
         (void)hipGetLastError();
@@ -53,6 +53,7 @@ hipError_t wait_poll(const zkhip_ctx* c, hipStream_t st, hipEvent_t ev) {
                 snprintf(g_stuck, sizeof g_stuck, "rank %d of %d stuck after collective #%llu, phase '%s': a host wait exceeded %d ms (comm_timeout_ms)",
                          c->comm.rank, c->comm.nranks, (unsigned long long)c->comm.collectives, c->comm.phase ? c->comm.phase : "", c->opt.comm_timeout_ms);
                 c->comm.stuck = 1;
+                c->dead = 1;
                 fprintf(stderr, "zkhip: %s\n", g_stuck);
                 return hipErrorLaunchTimeOut;
             }
@@ -154,6 +155,8 @@ int zkhip_profile_counter(zkhip_ctx* c, const char* name, uint64_t* value) {
     else if (strcmp(name, "shplonk_row_sharded") == 0) *value = c->n_shplonk_sharded;
     else if (strcmp(name, "comm_bulk") == 0) *value = c->comm.nccl_bulk ? 1 : 0;          // the context has a bulk communicator (comm.hip)
     else if (strcmp(name, "collectives_bulk") == 0) *value = c->comm.collectives_bulk;    // exchanges issued on it so far
+    else if (strcmp(name, "comm_selfcheck") == 0) *value = c->comm.selfcheck;             // what zkhip_comm_init's self-checks ran and passed (bits: zkhip.h)
+    else if (strcmp(name, "ctx_dead") == 0) *value = c->dead ? 1 : 0;                     // a host wait gave up on this context (comm_timeout_ms): only zkhip_destroy is left to call
     else { set_error("zkhip_profile_counter: unknown counter '%s'", name); return ZKHIP_EINVAL; }
     return ZKHIP_OK;
 }
@@ -192,7 +195,7 @@ const OptName OPTIONS[] = {
     {"ZKHIP_EVAL_BYVAL", "eval_byval", &zkhip_options::eval_byval}, {"ZKHIP_LATE_OVERLAP", "late_overlap", &zkhip_options::late_overlap},
     {"ZKHIP_HOST_TIMING", "host_timing", &zkhip_options::host_timing},
     {"ZKHIP_COSET_QUOTIENT", "coset_quotient", &zkhip_options::coset_quotient}, {"ZKHIP_ROW_SHARDED", "row_sharded", &zkhip_options::row_sharded},
-    {"ZKHIP_COMM_BULK", "comm_bulk", &zkhip_options::comm_bulk}, {"ZKHIP_COMM_TIMEOUT_MS", "comm_timeout_ms", &zkhip_options::comm_timeout_ms}, {"ZKHIP_RAND_OVERLAP", "rand_overlap", &zkhip_options::rand_overlap},
+    {"ZKHIP_COMM_BULK", "comm_bulk", &zkhip_options::comm_bulk}, {"ZKHIP_COMM_SELFCHECK_FORCE", "comm_selfcheck_force", &zkhip_options::comm_selfcheck_force}, {"ZKHIP_COMM_TIMEOUT_MS", "comm_timeout_ms", &zkhip_options::comm_timeout_ms}, {"ZKHIP_RAND_OVERLAP", "rand_overlap", &zkhip_options::rand_overlap},
     {"ZKHIP_EVAL_CHUNKS", "eval_chunks", &zkhip_options::eval_chunks},
 };
 }  // namespace
@@ -240,6 +243,17 @@ int zkhip_init(zkhip_ctx** out, int device_id) {
 void zkhip_destroy(zkhip_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->dead || c->comm.stuck) {
+        // A host wait of this context gave up on a collective (comm_timeout_ms): the main stream — and whatever else is fenced behind the
+        // communicator — will never drain, so hipStreamSynchronize, hipFree (which waits for the device) and hipStreamDestroy would all block for
+        // ever.  Abandon every device-side resource (the runtime reclaims them when the process leaves — what a caller does after this error)
+        // and return: a Rust Drop / Python close() after the deadline error must come back.
+        c->comm.stuck = 1;
+        (void)zkhip_comm_destroy(c);     // (stuck: touches neither RCCL nor the device)
+        fprintf(stderr, "zkhip_destroy: the context was given up on by a host wait (comm_timeout_ms): its device memory and streams are abandoned, not freed\n");
+        delete c;
+        return;
+    }
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)zkhip_comm_destroy(c);
     for (auto& kv : c->scratch)

@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
+#include <thread>
 #include <vector>
 
 #include "common.hpp"
@@ -62,16 +63,34 @@ struct StreamGuard {   // whatever happens, the context leaves on its main strea
     // Error exits.  (1) Asynchronous copies FROM THE CALLER'S host buffers may be in flight: wait for them, or a caller that drops its Vec<Fr> /
     // pinned buffers on the error races the DMA.  (2) The random polynomial's MSM may still be running on the third stream (rand_late): it reads
     // w_rand and writes the pinned commitment slot, which the NEXT proof reuses on the main stream — wait for it too.
-    // The waits are stream_wait's (polling, with the communicator's deadline), never a bare hipStreamSynchronize: when the error IS an expired
-    // deadline (zkhip_comm::stuck) the streams will never drain, so no wait is attempted at all and the call returns at once — the caller's
-    // host buffers must then stay alive until the process exits ("a rank that stops responding").
+    // The waits are stream_wait's (polling, with the communicator's deadline), never a bare hipStreamSynchronize.  When the error IS an expired
+    // deadline (zkhip_comm::stuck / zkhip_ctx::dead) the streams fenced behind the communicator will never drain and are not waited for — but the
+    // COPY stream never depends on the communicator (it waits only for an event recorded on the main stream before this proof's first collective), so
+    // the caller's large host columns are still waited for, with a bounded poll of its own (bounded_drain: the sticky stuck flag would make stream_wait
+    // return at once).  Small uploads ride on the main stream ahead of every collective of this proof: they completed before the collective that hung
+    // could start.  What is left after a stuck exit: the main / side / aux streams; the caller's buffers are not read by them.
+    static void bounded_drain(hipStream_t s, double limit_ms) {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (hipStreamQuery(s) == hipErrorNotReady) {
+            (void)hipGetLastError();
+            if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > limit_ms) {
+                fprintf(stderr, "zkhip_create_proof: the upload stream did not drain within %.0f ms of a stuck exit: keep the host columns alive until the process leaves\n", limit_ms);
+                return;
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+    }
     ~StreamGuard() {
         ctx->stream = main;
-        if (done || ctx->comm.stuck) return;
+        if (done) return;
+        if (ctx->comm.stuck || ctx->dead) {
+            if (host_uploads && ctx->copy_stream) bounded_drain(ctx->copy_stream, 5000.0);
+            return;
+        }
         if (aux_launched && ctx->aux_stream) (void)stream_wait(ctx, ctx->aux_stream);
-        if (host_uploads && !ctx->comm.stuck) {
+        if (host_uploads && !(ctx->comm.stuck || ctx->dead)) {
             if (ctx->copy_stream) (void)stream_wait(ctx, ctx->copy_stream);
-            if (!ctx->comm.stuck) (void)stream_wait(ctx, main);
+            if (!(ctx->comm.stuck || ctx->dead)) (void)stream_wait(ctx, main);
         }
     }
 };

@@ -82,7 +82,11 @@ int  zkhip_profile_read(zkhip_ctx* ctx, const char* kernel, double* total_ms, ui
  * accumulations really processed (zero digits are skipped), "msm_dense_pairs" = n * windows per column.  Counted always, on a context with
  * a communicator: "proofs_row_sharded" (zkhip_create_proof_ex calls that exchanged row windows instead of complete columns),
  * "proofs_pieces_sharded" (... whose quotient pieces stayed row ranges), "shplonk_row_sharded" (zkhip_shplonk_open calls on row ranges),
- * "comm_bulk" (1: the communicator has its bulk companion, see below) and "collectives_bulk" (exchanges issued on it). */
+ * "comm_bulk" (1: the communicator has its bulk companion, see below), "collectives_bulk" (exchanges issued on it), "comm_selfcheck" (what
+ * zkhip_comm_init's self-checks ran and passed, bits: 1 tagged grouped send / recv exchange on the first communicator, 2 ncclCommSplit gave the
+ * bulk communicator on every rank, 4 tagged exchange on it, 8 ncclCommCount / ncclCommUserRank of both agree with (nranks, rank), 16 the groups
+ * held the pair (rank, rank): a forced self-check of a one-rank communicator) and "ctx_dead" (1: a host wait of this context gave up at
+ * comm_timeout_ms; every later wait fails at once, and zkhip_destroy abandons the device-side resources instead of waiting for them). */
 int  zkhip_profile_counter(zkhip_ctx* ctx, const char* name, uint64_t* value);
 
 /* ---- one proof over several GPUs: one process per GPU, RCCL over xGMI ----
@@ -100,8 +104,15 @@ int  zkhip_profile_counter(zkhip_ctx* ctx, const char* name, uint64_t* value);
  *     rank's rows of the pieces only.  Option "row_sharded" = 0 restores the all-gather form.
  *   - the all-to-alls of row windows — tens of megabytes per peer that only the sweep reads — ride on a BULK communicator: a split of the
  *     first one over the same ranks (ncclCommSplit: no second id to distribute) with its own stream, created and self-checked by
- *     zkhip_comm_init, so the latency-sized exchanges a commitment waits for never queue behind them.  A library without ncclCommSplit,
- *     a failed self-check on any rank, or option "comm_bulk" = 0 leave them on the first communicator (same results).
+ *     zkhip_comm_init when option "comm_bulk" = 1 (ZKHIP_COMM_BULK=1), so the latency-sized exchanges a commitment waits for never queue
+ *     behind them.  OFF by default since round 6: two communicators' kernels must co-reside on every rank to make progress, which has only
+ *     met stand-ins of librccl so far, and a caller without a fallback ladder should not be the first to try (bench.py opts in on its first
+ *     rung).  A library without ncclCommSplit, a rank whose split / stream / buffer could not be made (agreed BEFORE anyone uses the split), or a
+ *     failed self-check on any rank leave them on the first communicator (same results).
+ *   - option "comm_selfcheck_force" = 1 (ZKHIP_COMM_SELFCHECK_FORCE): zkhip_comm_init on a ONE-rank communicator still runs every self-check
+ *     with the pair (rank, rank) in each group and creates the bulk communicator — one process on one GPU drives ncclSend / ncclRecv /
+ *     ncclGroupStart / ncclGroupEnd / ncclCommSplit / ncclCommCount / ncclCommUserRank and the destroy order (split before parent) of the
+ *     real librccl; counter "comm_selfcheck" says what passed.  A bring-up check, not a data path.
  * zkhip_comm_init_host is the same with the all-gathers staged through host memory and a caller-supplied function (bring-up on a
  * one-GPU box, launchers without RCCL): fn(user, send, recv, bytes) must fill recv[r * bytes ..] with rank r's send block. */
 typedef int (*zkhip_host_allgather_fn)(void* user, const void* send, void* recv, size_t bytes_per_rank);

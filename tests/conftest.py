@@ -11,6 +11,20 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: opt-in (minutes of CPU, or pure stress on the GPU); skipped unless -m names it or ZK_RUN_SLOW=1")
+
+
+def pytest_collection_modifyitems(config, items):
+    """`slow` tests run only when asked for: `-m slow`, `-m "gpu and slow"`, or ZK_RUN_SLOW=1.  The driver's two commands (-m "not gpu", -m gpu) skip them:
+    the CPU suite stays within a few minutes and the GPU suite within its budget (tests/README.md)."""
+    import os
+
+    if "slow" in (config.getoption("-m") or "") or os.environ.get("ZK_RUN_SLOW") == "1":
+        return
+    skip = pytest.mark.skip(reason="slow: opt in with -m slow (or -m 'gpu and slow') or ZK_RUN_SLOW=1")
+    for item in items:
+        if "slow" in item.keywords:
+            item.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

@@ -41,6 +41,23 @@ if os.environ.get("ZK_STALL_TEST") == "1":
         res["recv"] = recv.cpu().tolist()[::64]
     except Exception as e:   # noqa: BLE001
         res["error"] = str(e)
+    if res["error"]:
+        # what a Rust Drop / Python close() does after the deadline error must RETURN (zkhip_destroy used to hipStreamSynchronize the
+        # stuck stream without a deadline).  The context stays dead across zkhip_comm_destroy (which resets the communicator's own stuck flag):
+        # a later wait still fails at once; then close() abandons the device-side resources and comes back.
+        import time
+
+        t0 = time.time()
+        res["ctx_dead"] = ctx.profile_counter("ctx_dead")
+        ctx.comm_destroy()
+        res["ctx_dead_after_comm_destroy"] = ctx.profile_counter("ctx_dead")
+        try:
+            ctx.synchronize()
+            res["wait_after_destroy"] = "returned"
+        except Exception as e:   # noqa: BLE001
+            res["wait_after_destroy"] = str(e)
+        ctx.close()
+        res["close_s"] = time.time() - t0
     with open(os.path.join(os.environ["ZK_OUT"], f"rank{rank}.json"), "w") as f:
         json.dump(res, f)
     sys.stdout.flush()
@@ -80,6 +97,10 @@ if os.environ.get("ZK_STALL_TEST") == "proof":
         res["error"] = str(e)
     res["elapsed_s"] = time.time() - t0
     res.update(res_plan, exchanges_issued=ctx.comm_describe()["collectives"] - c2)
+    if res["error"]:      # the same exit a caller takes: drop the context.  Must return
+        t1 = time.time()
+        ctx.close()
+        res["close_s"] = time.time() - t1
     leave(res)
 mode = os.environ.get("ZK_SHARD_MODE", "points")
 ctx.comm_shard(mode)

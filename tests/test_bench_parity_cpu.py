@@ -7,6 +7,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [p for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")) if p not in sys.path]
 
@@ -101,6 +103,23 @@ def test_the_recorded_rsa_k17_digest_is_this_trees_oracle():
     p = pv.Prover(OracleBackend(os.cpu_count() or 8), pv.CircuitShape.rsa(17), satisfiable=True)
     got = hashlib.sha256(bytes(p.prove(p.witness(0), transcript="poseidon")["proof"])).hexdigest()
     assert got == want["rsa_k17/poseidon/witness0"]
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("k", [19, 20])
+def test_the_recorded_full_size_digests_regenerate_from_the_oracle_alone(k):
+    """opt-in (-m slow; k = 19: ~3 min, k = 20: ~1 min on 8 cores): tools/regen_cpu_digests.py's rows at k = 19 (SHA-shaped, Poseidon) and k = 20 (the
+    headline shape, Keccak) come out of the CPU oracle in THIS tree as committed — the digests the full-size -m gpu tests hold the HIP path's proof
+    bytes to (tests/test_gpu_prover.py) need no GPU box to be reproduced.  k = 22: `python tools/regen_cpu_digests.py --k 22` (12 min on 8 cores)."""
+    import halo2_zkcert_amd.prover as pv
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import regen_cpu_digests as rg
+
+    with open(rg.FIXTURE) as f:
+        want = json.load(f)["digests"]
+    (key, sh, kind), = rg.rows_for(pv, [k])
+    assert rg.oracle_digest(pv, sh, kind, os.cpu_count() or 8) == want[key]
 
 
 def test_chain_leaf_groups():

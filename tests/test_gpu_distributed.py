@@ -101,6 +101,53 @@ def test_rccl_communicator_single_rank(zk):
         ctx.close()
 
 
+def test_every_rccl_entry_point_meets_the_real_librccl_with_one_rank(zk):
+    """VERDICT r5 item 2.  Everything the multi-GPU path calls in RCCL, against the REAL library, with the one rank this pool allows: option
+    comm_selfcheck_force makes zkhip_comm_init run its self-checks on a one-rank communicator with the pair (rank, rank) in every group —
+    a grouped ncclSend / ncclRecv to self on the communicator's stream, ncclCommSplit(comm, 0, rank, &bulk, NULL), the tagged exchange on the
+    split on ITS stream, the verdict / readiness all-gathers, ncclCommCount / ncclCommUserRank on both — and zkhip_comm_destroy the split before
+    its parent.  A k = 10 proof on that context is unchanged.  Left unexercised: the N > 1 transport itself."""
+    import ctypes
+
+    ffi, ctx0 = zk
+    sh = pv.CircuitShape.small(10)
+    p0 = pv.Prover(pv.GpuBackend(ctx0, ffi), sh, satisfiable=True)
+    want = bytes(p0.prove_native(p0.witness(0), transcript="poseidon")["proof"])
+    p0.release()
+    p0.b.params.free()
+    ctx = ffi.Context(0)
+    try:
+        ctx.set_option("comm_selfcheck_force", 1)
+        for cycle in range(2):        # init -> use -> destroy twice on one context: the destroy order leaves nothing behind
+            ctx.comm_init(0, 1, None, transport="rccl")
+            assert ctx.profile_counter("comm_bulk") == 1
+            assert ctx.profile_counter("comm_selfcheck") == 1 | 2 | 4 | 8 | 16      # a2a, split, a2a on the split, counts agree, self pairs (comm.hip SC_*)
+            d = ctx.comm_describe()
+            assert d["transport"] == "rccl" and d["transport_ranks"] == 1 and d["nranks"] == 1 and d["collectives"] == 0
+            if cycle == 0:
+                # the library that served those calls is the real one: the mapped librccl (torch's copy), no stand-in in this process
+                maps = open("/proc/self/maps").read()
+                assert "fake_rccl" not in maps and "replay_rccl" not in maps
+                paths = sorted({ln.split()[-1] for ln in maps.splitlines() if "librccl" in ln})
+                assert paths, "no librccl mapped"
+                ver = ctypes.c_int(0)
+                assert ctypes.CDLL(paths[0]).ncclGetVersion(ctypes.byref(ver)) == 0 and ver.value >= 20700, ver.value   # send / recv to self: 2.7+
+                print(f"real librccl: {paths[0]} version code {ver.value}")
+            p = pv.Prover(pv.GpuBackend(ctx, ffi), sh, satisfiable=True)
+            assert bytes(p.prove_native(p.witness(0), transcript="poseidon")["proof"]) == want
+            p.release()
+            p.b.params.free()
+            ctx.comm_destroy()
+            assert ctx.profile_counter("comm_bulk") == 0 and ctx.profile_counter("comm_selfcheck") == 0
+        # without the option a one-rank communicator runs no self-check and has no bulk companion (the default)
+        ctx.set_option("comm_selfcheck_force", 0)
+        ctx.comm_init(0, 1, None, transport="rccl")
+        assert ctx.profile_counter("comm_bulk") == 0 and ctx.profile_counter("comm_selfcheck") == 0
+        ctx.comm_destroy()
+    finally:
+        ctx.close()
+
+
 def test_multi_device_rccl_if_available(zk, tmp_path):
     """with >= 2 GPUs: the same worker, one rank per device, RCCL transport"""
     import torch
@@ -273,6 +320,9 @@ def test_a_stuck_collective_fails_the_host_wait_at_the_deadline(zk, tmp_path):
     assert outs[1]["error"] is None and outs[1]["recv"] == [1, 2]
     err = outs[0]["error"]
     assert err and "rank 0 of 2 stuck after collective #1" in err and "a host wait exceeded 2000 ms" in err, outs[0]
+    # ... and the context can still be dropped: dead across zkhip_comm_destroy, later waits fail at once, close() returns (the stall lasts 40 s)
+    assert outs[0]["ctx_dead"] == 1 and outs[0]["ctx_dead_after_comm_destroy"] == 1 and "taken for dead" in outs[0]["wait_after_destroy"], outs[0]
+    assert outs[0]["close_s"] < 5.0, outs[0]
 
 
 def test_a_stuck_collective_inside_a_proof_with_host_inputs_returns_at_the_deadline(zk, tmp_path):
@@ -284,7 +334,7 @@ def test_a_stuck_collective_inside_a_proof_with_host_inputs_returns_at_the_deadl
                                                          "ZKHIP_COMM_TIMEOUT_MS": "2000"}, timeout=300)
     err = outs[0]["error"]
     assert err and "a host wait exceeded 2000 ms" in err and "rank 0 of 2 stuck" in err, outs[0]
-    assert outs[0]["elapsed_s"] < 20.0, outs[0]
+    assert outs[0]["elapsed_s"] < 20.0 and outs[0]["close_s"] < 5.0, outs[0]
     assert outs[1]["error"] is None, outs[1]
 
 
