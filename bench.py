@@ -620,6 +620,10 @@ def main():
                     "(the library's row_sharded option; default: the library's, 1)")
     ap.add_argument("--no-leaf-groups", action="store_true", help="--chain, N >= 6: every leaf proof on one rank (ranks 4.. idle until the aggregation proof) instead of the "
                     "SHA-shaped leaves over rank groups")
+    ap.add_argument("--ffi-level", default="all", choices=["all", "curves", "domain", "one-call", "none"],
+                    help="N = 1: the boundary timed at each patch level of INTEGRATION.md (`ffi_levels` in the detail file): `curves` = one proof's worth of best_multiexp / "
+                         "best_fft calls through the HOST-pointer zkhip_msm_g1 / zkhip_fft with pageable arrays (what patching only halo2curves buys), `domain` = the same with "
+                         "EvaluationDomain's host forms (zkhip_lagrange_to_coeff / coeff_to_extended / extended_to_coeff), `one-call` = the headline (zkhip_create_proof_ex)")
     ap.add_argument("--detail-out", default=None, help="where rank 0 writes the whole result object (default: bench_detail.json next to this script); "
                     "stdout carries one compact line (< 4 KB) that names it")
     ap.add_argument("--agg-unsharded", action="store_true", help="--chain, N >= 4: the aggregation proof on rank 0 alone (last rung of the ladder: no collective)")
@@ -823,6 +827,20 @@ def worker(args):
             kernels[kname] = dict(ms_per_step=round(ms / breakdown_passes, 4), launches_per_step=launches / breakdown_passes)
         real_pairs = ctx.profile_counter("msm_pairs") / breakdown_passes          # non-zero digits only (this rank's share)
         dense_pairs = ctx.profile_counter("msm_dense_pairs") / breakdown_passes    # n x windows per column
+        trace_passes = None
+        if replay:
+            # the rank's exchange timeline (zkhip_comm_trace): when each of the proof's exchanges completed on the communicator's stream, relative to the
+            # proof's start, in 3 extra untimed passes — what tools/install_rank_replay.py composes into a synchronised step (sum over exchanges of the
+            # max over ranks of the span between consecutive exchanges) beside the max over ranks of whole proofs
+            ctx.profile_enable(False)
+            trace_passes = []
+            for _ in range(3):
+                ctx.comm_trace(True)
+                prove()
+                ent, end_us = ctx.comm_trace_read()
+                trace_passes.append(dict(end_us=round(end_us, 1), done_us=[e["stream_done_us"] for e in ent], host_issue_us=[e["host_issue_us"] for e in ent],
+                                         exchanges=[[e["phase"], e["kind"], int(e["bulk"]), e["bytes_received"]] for e in ent]))
+            ctx.comm_trace(False)
         # the NTT and sweep kernels overlap the MSM phases inside a proof (two streams), so their in-proof event spans are stretched
         # by the kernels they share the chip with: their rooflines are taken from isolated launches of the same shapes instead
         iso = {}
@@ -937,6 +955,7 @@ def worker(args):
                "native_call_ms_per_step": round(native_s * 1000.0 / steps, 3) if native_s else None}   # zkhip_create_proof_ex alone; ms_per_step also holds the ctypes wrapper around it
         if replay:
             res["replay_exchanges_per_step"] = rstats
+            res["replay_trace"] = trace_passes
         if not replay:      # a replayed rank's bytes are wrong by construction: never offered for comparison
             note_proof(shape, kind, wseed if witness == "uniform" else f"{witness}:{wseed}", trace.get("proof", b""), f"configs.{name}" + ("" if witness == "uniform" else f" ({witness} witness)"))
         prover.release()          # the context's per-key caches (coset-layout key columns, sorted lookup table)
@@ -975,6 +994,83 @@ def worker(args):
         gc.collect()
         torch.cuda.empty_cache()
         return dict(k=k_, shape=shape.name, transcript=TRANSCRIPT[name], proof_bytes=len(pf), proof_sha256=gpu_proofs[-1]["proof_sha256"], first_proof_ms=round(first_ms, 2))
+
+    def ffi_levels(name, one_call_s, reps=3):
+        """The drop-in boundary at each patch level: how long ONE PROOF'S WORTH of the calls a patch level
+        replaces takes through the entry points that level binds, with the caller's data in pageable host memory (a Rust Vec<Fr>) — one call per
+        commitment / transform, in sequence, exactly as upstream's create_proof issues them (/root/reference/src/helpers.rs:233,299, src/bin/cli.rs:320,369,519).
+          curves   halo2curves patched only: counts.msm x zkhip_msm_g1 + (counts.intt_n x best_fft(2^k) + (counts.ntt_ext + counts.intt_ext) x best_fft(2^extended_k))
+                   through zkhip_fft.  Everything else of create_proof (sweep, permute, grand products, evaluations ...) stays upstream's CPU code: NOT in the figure.
+          domain   + EvaluationDomain patched: the transforms through zkhip_lagrange_to_coeff / zkhip_coeff_to_extended / zkhip_extended_to_coeff (host forms).
+          one-call zkhip_create_proof_ex: the whole proof (the headline)."""
+        import numpy as np
+
+        which = ("curves", "domain", "one-call") if args.ffi_level == "all" else (args.ffi_level,)
+        shape = make_shape(pv, name, args)
+        backend = pv.GpuBackend(ctx, ffi)
+        prover = pv.Prover(backend, shape, satisfiable=True)
+        dom, params = prover.dom, backend.params
+        n, en = 1 << shape.k, 1 << dom.extended_k
+        counts = shape.counts(dom.extended_k)
+        cols = [ctx.to_host(ctx.synth_fill(n, 7000 + j)).copy() for j in range(4)]      # numpy-owned: pageable
+        ext = np.empty((en, 4), dtype=np.uint64)
+        ext[:] = np.tile(cols[0], (en // n, 1))
+        out = {}
+
+        def timed(f):
+            f()
+            ts = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                f()
+                ts.append(time.perf_counter() - t0)
+            return statistics.median(ts)
+
+        def call(fn, *a):
+            ffi._check(getattr(ffi.lib(), fn)(ctx.h, *a))
+        import ctypes as C_
+
+        t_msm = timed(lambda: [params.commit(cols[j % 4]) if j % 2 else params.commit_lagrange(cols[j % 4]) for j in range(counts["msm"])])
+        per = {"zkhip_msm_g1_ms": round(t_msm * 1000.0 / counts["msm"], 3)}
+        if "curves" in which:
+            w_n, w_e = ffi._u64(dom.omega), ffi._u64(dom.extended_omega)
+            t_fn = timed(lambda: [call("zkhip_fft", ffi._p(cols[j % 4]), ffi._p(w_n), C_.c_uint32(shape.k)) for j in range(counts["intt_n"])])
+            ne = counts["ntt_ext"] + counts["intt_ext"]
+            t_fe = timed(lambda: [call("zkhip_fft", ffi._p(ext), ffi._p(w_e), C_.c_uint32(dom.extended_k)) for _ in range(ne)])
+            per.update(zkhip_fft_n_ms=round(t_fn * 1000.0 / counts["intt_n"], 3), zkhip_fft_extended_ms=round(t_fe * 1000.0 / ne, 3))
+            out["curves"] = dict(value=round(t_msm + t_fn + t_fe, 6), unit="s", calls={"zkhip_msm_g1 (2^%d)" % shape.k: counts["msm"], "zkhip_fft (2^%d)" % shape.k: counts["intt_n"],
+                                 "zkhip_fft (2^%d)" % dom.extended_k: ne}, parts_s=dict(msm=round(t_msm, 6), fft_n=round(t_fn, 6), fft_extended=round(t_fe, 6)),
+                                 note="GPU-side calls only: the rest of create_proof is upstream's CPU code at this patch level and is not in the figure")
+        if "domain" in which:
+            t_l = timed(lambda: [call("zkhip_lagrange_to_coeff", dom.h, ffi._p(cols[j % 4])) for j in range(counts["intt_n"])])
+            t_c = timed(lambda: [call("zkhip_coeff_to_extended", dom.h, ffi._p(cols[j % 4]), C_.c_size_t(n), ffi._p(ext)) for j in range(counts["ntt_ext"])])
+            t_x = timed(lambda: [call("zkhip_extended_to_coeff", dom.h, ffi._p(ext)) for _ in range(counts["intt_ext"])])
+            per.update(zkhip_lagrange_to_coeff_ms=round(t_l * 1000.0 / counts["intt_n"], 3), zkhip_coeff_to_extended_ms=round(t_c * 1000.0 / counts["ntt_ext"], 3),
+                       zkhip_extended_to_coeff_ms=round(t_x * 1000.0 / counts["intt_ext"], 3))
+            out["domain"] = dict(value=round(t_msm + t_l + t_c + t_x, 6), unit="s", calls={"zkhip_msm_g1 (2^%d)" % shape.k: counts["msm"], "zkhip_lagrange_to_coeff": counts["intt_n"],
+                                 "zkhip_coeff_to_extended (2^%d -> 2^%d)" % (shape.k, dom.extended_k): counts["ntt_ext"], "zkhip_extended_to_coeff": counts["intt_ext"]},
+                                 parts_s=dict(msm=round(t_msm, 6), lagrange_to_coeff=round(t_l, 6), coeff_to_extended=round(t_c, 6), extended_to_coeff=round(t_x, 6)),
+                                 note="GPU-side calls only: sweep, permute, grand products, evaluations, SHPLONK stay upstream's CPU code at this patch level")
+        if "one-call" in which:
+            out["one-call"] = dict(value=one_call_s, unit="s", calls={"zkhip_create_proof_ex": 1}, note="the whole proof, transcript included (the headline)")
+        # the device-resident one-column forms of the same two kernels, for the ratio the host-pointer level is judged by
+        d_col = ctx.synth_fill(n, 7100)
+
+        def dev_msm():
+            params.commit_batch_device([d_col])
+            ctx.synchronize()
+        per["msm_device_resident_one_column_ms"] = round(timed(dev_msm) * 1000.0, 3)
+        per["zkhip_msm_g1_over_device_resident"] = round(per["zkhip_msm_g1_ms"] / per["msm_device_resident_one_column_ms"], 3)
+        out["per_call"] = per
+        out["host_memory"] = "pageable (numpy-owned arrays), one blocking call per commitment / transform"
+        prover.release()
+        backend.params.free()
+        del prover, backend, cols, ext, d_col
+        import gc
+
+        gc.collect()
+        torch.cuda.empty_cache()
+        return out
 
     def run_chain(steps, warmup):
         """BASELINE configs[4] (/root/reference/src/tests/x509_aggregation.rs:20-110): four independent leaf proofs (rsa, sha, rsa, sha), a
@@ -1027,7 +1123,8 @@ def worker(args):
         sizes, digests, last = [], [], []
         phase_s = dict(leaf=0.0, agg=0.0)
 
-        def chain_step():
+        def chain_step(trace=None):
+            """trace: a list that receives the aggregation proof's exchange timeline (--replay-rank: zkhip_comm_trace)"""
             del sizes[:], digests[:], last[:]
             t_l = time.perf_counter()
             for pr_, w_, kind_ in leaves:
@@ -1039,7 +1136,13 @@ def worker(args):
             t_a = time.perf_counter()
             phase_s["leaf"] += t_a - t_l
             if agg_here:
+                if trace is not None:
+                    ctx.comm_trace(True)
                 pf_ = bytes(agg.prove_native(agg_w, transcript="evm")["proof"])
+                if trace is not None:
+                    ent, end_us = ctx.comm_trace_read()
+                    trace.append(dict(end_us=round(end_us, 1), done_us=[e["stream_done_us"] for e in ent], host_issue_us=[e["host_issue_us"] for e in ent],
+                                      exchanges=[[e["phase"], e["kind"], int(e["bulk"]), e["bytes_received"]] for e in ent]))
                 sizes.append(len(pf_))
                 digests.append(hashlib.sha256(pf_).hexdigest())
                 last.append((agg.shape, "evm", 0, pf_, "chain aggregation proof"))
@@ -1068,6 +1171,12 @@ def worker(args):
             t = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
+        agg_trace = None
+        if replay and shard and agg_here:      # the aggregation proof's exchange timeline on this rank, 3 extra untimed steps
+            agg_trace = []
+            for _ in range(3):
+                chain_step(trace=agg_trace)
+            ctx.comm_trace(False)
         acc_ms, acc_l = 0.0, 0
         for c_ in ctxs:
             ms_, l_ = c_.profile_read(DOMINANT)
@@ -1108,7 +1217,7 @@ def worker(args):
                "parallelism": par, "proof_bytes": list(sizes), "proof_sha256": list(digests), "roofline": roof,
                "phase_ms_per_step": {"leaf_proofs_until_the_barrier": round(phase_s["leaf"] * 1000.0 / steps, 3), "aggregation_proof": round(phase_s["agg"] * 1000.0 / steps, 3),
                                      "note": "host wall clock on this rank; the barrier (and a device synchronize) separates the two phases"},
-               "replay_exchanges_per_step": rstats, "leaf_proof_sha256": leaf_digests, "leaf_groups": {str(j): rs for j, rs in sorted(groups.items())},
+               "replay_exchanges_per_step": rstats, "replay_trace": agg_trace, "leaf_proof_sha256": leaf_digests, "leaf_groups": {str(j): rs for j, rs in sorted(groups.items())},
                "bytes_gathered_per_step": (ctx.comm_bytes_gathered() - g0) // steps if shard else 0,
                "collectives_per_step": (ctx.comm_describe()["collectives"] - c0) / steps if shard else 0}
         for item in ([] if replay else last):
@@ -1137,10 +1246,10 @@ def worker(args):
                 "note": "nranks / transport_ranks / bytes: what the library's own communicator reports on rank 0 (zkhip_comm_info / zkhip_comm_describe; "
                         "transport_ranks = ncclCommCount); bytes = received by this rank through all-gathers in one step"}
 
-    def replay_block(exchanges):
+    def replay_block(exchanges, trace=None):
         """what the line says about a --replay-rank run"""
         d = ctx.comm_describe()
-        return {"rank": args.replay_rank, "of": args.of, "exchanges_per_step": exchanges, "library_counters": {"collectives_total": d["collectives"], "bytes_gathered_total": d["bytes_gathered"]},
+        return {"rank": args.replay_rank, "of": args.of, "exchanges_per_step": exchanges, "trace": trace, "library_counters": {"collectives_total": d["collectives"], "bytes_gathered_total": d["bytes_gathered"]},
                 "modelled_wire": {"latency_us_per_exchange": args.replay_latency_us, "link_GBps_per_peer_and_direction": args.replay_link_gbs,
                                   "note": "0 / 0: an exchange costs only the kernel that fabricates what would arrive (HBM write speed); otherwise the communicator's stream is "
                                           "additionally held for latency + max-over-peers(bytes from that peer) / link bandwidth per exchange (xGMI: one link per peer)"},
@@ -1170,7 +1279,7 @@ def worker(args):
                   "comm": comm_fields(res["bytes_gathered_per_step"], "points" if args.shard == "auto" else args.shard, res["collectives_per_step"]),
                   "roofline": res["roofline"], "cpu_baseline": cb, "gpu_proofs": gpu_proofs, "parity": parity, "build": bh,
                   "phase_ms_per_step": res["phase_ms_per_step"], "leaf_proof_sha256": res["leaf_proof_sha256"], "leaf_groups": res["leaf_groups"],
-                  **({"replay": replay_block(res["replay_exchanges_per_step"])} if replay else {})}, args)
+                  **({"replay": replay_block(res["replay_exchanges_per_step"], res.get("replay_trace"))} if replay else {})}, args)
             if parity and parity["bytes_equal"] is False:
                 print("bench.py: PARITY FAILURE: a HIP-path proof differs from the CPU oracle's: " + json.dumps([r for r in parity["compared"] if not r["equal"]]), file=sys.stderr, flush=True)
                 sys.exit(3)
@@ -1201,6 +1310,19 @@ def worker(args):
             out_configs["chain"] = run_chain(max(2, args.other_steps // 3), 1)
         except Exception as e:   # noqa: BLE001
             out_configs["chain"] = dict(error=str(e)[:300])
+
+    # the boundary at each patch level (host-pointer entry points with pageable arrays): the headline configuration and RSA k = 17
+    ffi_lv = None
+    if world == 1 and not replay and args.ffi_level != "none" and not args.python_schedule:
+        try:
+            ffi_lv = ffi_levels(args.config, head["value"])
+            if not args.no_other_configs and "rsa17" in out_configs and args.config != "rsa17" and "error" not in out_configs["rsa17"]:
+                out_configs["rsa17"]["ffi_levels"] = ffi_levels("rsa17", out_configs["rsa17"]["value"], reps=5)
+        except Exception as e:   # noqa: BLE001 — never allowed to break the headline measurement
+            import traceback
+
+            traceback.print_exc()
+            ffi_lv = dict(error=f"{type(e).__name__}: {e}"[:300])
 
     # the headline shape at the size the CPU leg's bounded sample runs at: a byte-compared full-shape proof in the default line
     sample = None
@@ -1236,8 +1358,9 @@ def worker(args):
             "setup_s": head["setup_s"], "first_proof_s": head["first_proof_s"], "resident_bytes": head["resident_bytes"], "with_h2d": head["with_h2d"],
         }
         out["parity_sample"] = sample
+        out["ffi_levels"] = ffi_lv
         if replay:
-            out["replay"] = replay_block(head.get("replay_exchanges_per_step"))
+            out["replay"] = replay_block(head.get("replay_exchanges_per_step"), head.get("replay_trace"))
         out["gpu_proofs"] = gpu_proofs
         if not args.no_cpu_baseline and world == 1:
             try:

@@ -115,6 +115,16 @@ __global__ void k_fold_partials(const uint32_t* parts, uint32_t nranks, uint32_t
 }  // namespace
 
 namespace zk {
+// zkhip_comm_trace: one entry per exchange issued on the RCCL branch — a timing event on the communicator's stream right behind the exchange
+static void trace_mark(zkhip_comm& cm, hipStream_t cstream, uint64_t bytes_received, uint8_t flags) {
+    if (!cm.trace_on) return;
+    hipEvent_t e = nullptr;
+    if (!cm.trace_pool.empty()) { e = cm.trace_pool.back(); cm.trace_pool.pop_back(); }
+    else if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); return; }
+    (void)hipEventRecord(e, cstream);
+    cm.trace.push_back({cm.phase ? cm.phase : "", bytes_received,
+                        std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - cm.trace_t0).count(), e, flags});
+}
 // recv holds nranks blocks of `bytes`; rank r's block is at r * bytes; d_send may be that block itself (in place).
 // comm_allgather_begin enqueues the exchange behind everything already issued on the calling stream and returns; the calling stream
 // does NOT wait for it (it may go on producing the next block: the coset NTT of round t + 1 overlaps the all-gather of round t);
@@ -152,6 +162,7 @@ int comm_allgather_begin(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_
     ZK_NCCL(g_rccl.AllGather(d_send, d_recv, bytes, ncclInt8, c, cm.stream));
     cm.bytes_gathered += bytes * (size_t)(cm.nranks - 1);
     cm.collectives += 1;
+    trace_mark(cm, cm.stream, bytes * (size_t)(cm.nranks - 1), 0);
     return ZKHIP_OK;
 }
 int comm_allgather_end(zkhip_ctx* ctx) {
@@ -254,6 +265,7 @@ int comm_alltoall(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t bytes
     cm.bytes_gathered += received;
     cm.collectives += 1;
     if (on_bulk) cm.collectives_bulk += 1;
+    trace_mark(cm, cstream, received, (uint8_t)(2 | (on_bulk ? 1 : 0)));
     ZK_HIP(hipEventRecord(e_out, cstream));                   // the calling stream consumes the blocks
     ZK_HIP(hipStreamWaitEvent(ctx->stream, e_out, 0));
     return ZKHIP_OK;
@@ -526,7 +538,58 @@ int zkhip_comm_destroy(zkhip_ctx* ctx) {
     if (cm.ev_in) (void)hipEventDestroy(cm.ev_in);
     if (cm.ev_out) (void)hipEventDestroy(cm.ev_out);
     if (cm.stage) (void)hipHostFree(cm.stage);
+    for (auto& t : cm.trace) if (t.done) (void)hipEventDestroy(t.done);
+    for (auto e : cm.trace_pool) (void)hipEventDestroy(e);
+    if (cm.trace_base) (void)hipEventDestroy(cm.trace_base);
     cm = zkhip_comm();
+    return ZKHIP_OK;
+}
+
+// ---- per-exchange trace (measurement aid; bench.py --replay-rank records one rank's exchange timeline with it)
+static const char* const PHASES[] = {"", "advice", "lookup permute", "grand products", "quotient", "evaluations", "shplonk"};
+const char* zkhip_comm_phase_name(uint8_t id) { return id < sizeof PHASES / sizeof PHASES[0] ? PHASES[id] : "?"; }
+
+int zkhip_comm_trace(zkhip_ctx* ctx, int on) {
+    if (!ctx) { set_error("null ctx"); return ZKHIP_EINVAL; }
+    zkhip_comm& cm = ctx->comm;
+    for (auto& t : cm.trace) if (t.done) cm.trace_pool.push_back(t.done);
+    cm.trace.clear();
+    cm.trace_on = on != 0;
+    if (on) {
+        if (!cm.trace_base) ZK_HIP(hipEventCreate(&cm.trace_base));
+        ZK_HIP(hipEventRecord(cm.trace_base, ctx->stream));     // time zero: everything issued on the context's stream so far is before it
+        cm.trace_t0 = std::chrono::steady_clock::now();
+    }
+    return ZKHIP_OK;
+}
+
+int zkhip_comm_trace_read(zkhip_ctx* ctx, size_t cap, size_t* n, uint8_t* phase, uint64_t* bytes, double* host_us, double* done_us, uint8_t* flags,
+                          double* end_us) {
+    if (!ctx || !n) { set_error("zkhip_comm_trace_read: null argument"); return ZKHIP_EINVAL; }
+    zkhip_comm& cm = ctx->comm;
+    if (!cm.trace_base) { set_error("zkhip_comm_trace_read: no trace was started (zkhip_comm_trace(ctx, 1))"); return ZKHIP_EINVAL; }
+    hipEvent_t end = nullptr;
+    ZK_HIP(hipEventCreate(&end));
+    ZK_HIP(hipEventRecord(end, ctx->stream));
+    ZK_HIP(stream_wait(ctx, ctx->stream));
+    float ms = 0;
+    ZK_HIP(hipEventSynchronize(end));
+    ZK_HIP(hipEventElapsedTime(&ms, cm.trace_base, end));
+    (void)hipEventDestroy(end);
+    if (end_us) *end_us = (double)ms * 1000.0;
+    *n = cm.trace.size();
+    for (size_t i = 0; i < cm.trace.size() && i < cap; ++i) {
+        const auto& t = cm.trace[i];
+        ZK_HIP(hipEventSynchronize(t.done));
+        ZK_HIP(hipEventElapsedTime(&ms, cm.trace_base, t.done));
+        uint8_t id = 255;
+        for (uint8_t j = 0; j < sizeof PHASES / sizeof PHASES[0]; ++j) if (strcmp(PHASES[j], t.phase) == 0) id = j;
+        if (phase) phase[i] = id;
+        if (bytes) bytes[i] = t.bytes;
+        if (host_us) host_us[i] = t.host_us;
+        if (done_us) done_us[i] = (double)ms * 1000.0;
+        if (flags) flags[i] = t.flags;
+    }
     return ZKHIP_OK;
 }
 

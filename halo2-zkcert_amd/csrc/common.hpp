@@ -7,6 +7,7 @@
 
 #include <atomic>
 #include <deque>
+#include <chrono>
 #include <map>
 #include <memory>
 #include <string>
@@ -54,6 +55,7 @@ struct Scratch {
 // Tuning knobs: environment variables (ZKHIP_*) read ONCE when the context is created, or set afterwards with
 // zkhip_set_option — never looked up on the hot path.  0 / -1 = "use the measured default".
 struct zkhip_options {
+    int msm_host_chunks = 0;   // zkhip_msm_g1 (host slice): pieces the upload + MSM pipeline is cut into (0: by size — 4 from 2^21 scalars, 2 from 2^20, else 1)
     int msm_c = 0, msm_seg = 0, msm_tailparts = 0, msm_ch = 0, msm_widetail = -1, msm_tail2 = -1, msm_adaptive_l = 1, msm_debug = 0;
     int sort_hb = 0, sort_tile = 0, sort_one_atomic = 1, sort_copies = 0, sort_wide = -1;   // sort_wide: low-pass block shape (-1: 1024 threads x 8 pairs for 8192-pair tiles)
     int ntt_lds_pad = 0;   // analysis only: KiB of unused dynamic LDS added to every register-tiled NTT workgroup (fewer tiles per CU: the occupancy-vs-time curve)
@@ -96,6 +98,15 @@ struct zkhip_comm {
     uint64_t collectives = 0;     // exchanges issued so far
     int shard_columns = 0;        // MSMs over whole-SRS handles: 1 = split the batch by column over the ranks, 0 = replicate
     int a2a_ok = 0;               // verdict of zkhip_comm_init's all-to-all self-check: 1 passed on every rank, -1 failed somewhere, 0 not run
+    // Per-exchange trace (zkhip_comm_trace: a measurement aid, off by default; RCCL branch only): for every exchange the phase of the proof, the bytes this
+    // rank receives, the host clock at the issue and a timing event recorded on the communicator's stream right behind the exchange.  Read back by
+    // zkhip_comm_trace_read as (host_us, done_us) relative to the mark zkhip_comm_trace(ctx, 1) set on the context's stream.
+    struct TraceEntry { const char* phase; uint64_t bytes; double host_us; hipEvent_t done; uint8_t flags; };
+    bool trace_on = false;
+    std::vector<TraceEntry> trace;
+    std::vector<hipEvent_t> trace_pool;
+    hipEvent_t trace_base = nullptr;
+    std::chrono::steady_clock::time_point trace_t0;
     uint32_t selfcheck = 0;       // what zkhip_comm_init's self-checks ran and passed (bits: comm.hip SC_*; zkhip_profile_counter "comm_selfcheck")
     const char* phase = "";       // which part of the proof the host is issuing (what a timed-out wait reports)
     mutable int stuck = 0;        // a host wait of this context ran into comm_timeout_ms: the communicator's stream (and whatever waits on it) is taken for
@@ -126,6 +137,7 @@ struct zkhip_ctx {
     hipEvent_t eval_event[4] = {nullptr, nullptr, nullptr, nullptr};   // one per chunk of the pipelined evaluations (zkhip_create_proof_ex)
     hipStream_t copy_stream = nullptr;   // uploads of large host advice columns (zkhip_create_proof_ex, advice_on_host), created on first use
     hipEvent_t copy_event[4] = {nullptr, nullptr, nullptr, nullptr};   // one per upload group
+    std::vector<hipEvent_t> host_chunk_event;   // zkhip_msm_g1's pipelined upload: one per chunk + one fence (created on first use)
     // Small host->device uploads of host temporaries (pointer tables, lowered programs): the bytes are copied into a pinned ring
     // and the asynchronous copy reads from there, so the call neither blocks on the stream nor keeps the caller's buffer alive.
     // The ring is 8 MiB against ~100 KiB staged per proof; wrapping around synchronises the device.

@@ -1448,20 +1448,82 @@ int zkhip_msm_g1_batch_range_device(zkhip_ctx* ctx, const zkhip_srs* srs, const 
     return msm_run(ctx, v.data(), d_scalar_cols, ncols, first, count, d_out_xyz);
 }
 
+// best_multiexp on a caller's host slice (the `curves` patch level: halo2curves::msm::best_multiexp -> this, reached from
+// /root/reference/src/helpers.rs:233,299 and src/bin/cli.rs:320,369,519 through ParamsKZG::commit / commit_lagrange).
+// Small inputs: one upload, one MSM.  From 2^20 scalars (32 MiB: the upload is no longer noise against the sum) the call is PIPELINED: the slice
+// is uploaded in K chunks on the copy stream — pageable memory goes over the link at the pinned rate on this platform (profiles/r06_h2d_probe.txt:
+// 56.5 against 57.4 GB/s, hipHostRegister is free), so no staging copy — and chunk j's whole MSM (digits, sort, accumulation, its own tail, over
+// points [off_j, off_j + len_j)) starts as soon as ITS bytes have landed, on the main and the side stream alternately, so that the throughput-bound
+// accumulation of chunk j + 1 runs beside the latency-bound tail of chunk j; the K partial sums are added on the host.  Measured at 2^22 (one MI355X):
+// 8.38 ms before (2.4 upload + 5.6 MSM + read-back, nothing overlapped) against 5.59 for the device-resident column; after: see INTEGRATION.md §1.
 int zkhip_msm_g1(zkhip_ctx* ctx, const zkhip_srs* srs, const uint64_t* scalars, size_t n, uint64_t out_xyz[12]) {
     if (!ctx || !srs || !out_xyz || (!scalars && n)) { set_error("zkhip_msm_g1: null argument"); return ZKHIP_EINVAL; }
     void *d_s, *d_o;
     ZK_TRY(ctx->get_scratch("msm_host_scalars", (n ? n : 1) * 32, &d_s));
-    ZK_TRY(ctx->get_scratch("msm_host_out", 96, &d_o));
-    if (n) ZK_HIP(hipMemcpyAsync(d_s, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    const void* cols[1] = {d_s};
     const zkhip_srs* one_srs[1] = {srs};
-    ZK_TRY(msm_run(ctx, one_srs, cols, 1, 0, n, d_o));
-    uint64_t jac[12];
-    ZK_HIP(hipMemcpyAsync(jac, d_o, 96, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    size_t K = 1;
+    if (srs->n_total == srs->n && ctx->comm.nranks <= 1) {      // (a point-range shard / a communicator: the collective form, one piece)
+        K = n >= ((size_t)1 << 21) ? 4 : n >= ((size_t)1 << 20) ? 2 : 1;
+        const int v = ctx->opt.msm_host_chunks;
+        if (v >= 1 && v <= 16) K = (size_t)v;
+        while (K > 1 && n / K < 65536) K /= 2;
+    }
+    ZK_TRY(ctx->get_scratch("msm_host_out", K * 96, &d_o));
+    std::vector<uint64_t> jac(12 * K);
+    if (K == 1) {
+        if (n) ZK_HIP(hipMemcpyAsync(d_s, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+        const void* cols[1] = {d_s};
+        ZK_TRY(msm_run(ctx, one_srs, cols, 1, 0, n, d_o));
+        ZK_HIP(hipMemcpyAsync(jac.data(), d_o, 96, hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP(hipStreamSynchronize(ctx->stream));
+    } else {
+        hipStream_t main = ctx->stream;
+        if (!ctx->copy_stream) {
+            ZK_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+            for (auto& e : ctx->copy_event) ZK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        if (!ctx->side_stream) {
+            ZK_HIP(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+            ZK_HIP(hipEventCreateWithFlags(&ctx->side_event, hipEventDisableTiming));
+        }
+        if (ctx->host_chunk_event.size() < K + 1) {
+            const size_t have = ctx->host_chunk_event.size();
+            ctx->host_chunk_event.resize(K + 1, nullptr);
+            for (size_t j = have; j <= K; ++j) ZK_HIP(hipEventCreateWithFlags(&ctx->host_chunk_event[j], hipEventDisableTiming));
+        }
+        // the staging column's last readers (an earlier call's kernels) were issued on the main and the side stream: the copies start behind both
+        ZK_HIP(hipEventRecord(ctx->host_chunk_event[K], main));
+        ZK_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->host_chunk_event[K], 0));
+        ZK_HIP(hipEventRecord(ctx->side_event, ctx->side_stream));
+        ZK_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->side_event, 0));
+        const size_t per = ((n + K - 1) / K + 255) & ~(size_t)255;
+        for (size_t j = 0; j < K; ++j) {
+            const size_t off = std::min(n, j * per), len = std::min(per, n - off);
+            if (len) ZK_HIP(hipMemcpyAsync((char*)d_s + off * 32, (const char*)scalars + off * 32, len * 32, hipMemcpyHostToDevice, ctx->copy_stream));
+            ZK_HIP(hipEventRecord(ctx->host_chunk_event[j], ctx->copy_stream));
+        }
+        // whatever happens, the context leaves on its main stream, and the caller's slice is no longer being read when the call returns (an error exit
+        // must not race the DMA against a Vec<Fr> the caller drops; the copy stream depends on nothing but the fence above)
+        struct Restore { zkhip_ctx* c; hipStream_t s; bool ok = false; ~Restore() { c->stream = s; if (!ok && !c->dead) (void)hipStreamSynchronize(c->copy_stream); } } restore{ctx, main};
+        const void* cols[1] = {d_s};
+        for (size_t j = 0; j < K; ++j) {
+            const size_t off = std::min(n, j * per), len = std::min(per, n - off);
+            hipStream_t sj = (j & 1) ? ctx->side_stream : main;
+            ZK_HIP(hipStreamWaitEvent(sj, ctx->host_chunk_event[j], 0));
+            ctx->stream = sj;      // (scratch is keyed by the stream: the two streams' MSMs do not share a buffer; d_o was handed out above)
+            ZK_TRY(msm_run(ctx, one_srs, cols, 1, off, len, (char*)d_o + j * 96));
+        }
+        ctx->stream = main;
+        ZK_HIP(hipEventRecord(ctx->side_event, ctx->side_stream));
+        ZK_HIP(hipStreamWaitEvent(main, ctx->side_event, 0));
+        ZK_HIP(hipMemcpyAsync(jac.data(), d_o, K * 96, hipMemcpyDeviceToHost, main));
+        ZK_HIP(stream_wait(ctx, main));
+        restore.ok = true;
+    }
+    g1j acc = g1j_load_abi(jac.data());
+    for (size_t j = 1; j < K; ++j) acc = g1j_add(acc, g1j_load_abi(jac.data() + 12 * j));
     // normalise: (x, y, 1) or the identity (0, 1, 0), like G1::from(G1Affine)
-    g1j_store_abi(out_xyz, g1j_from_affine(g1j_to_affine(g1j_load_abi(jac))));
+    g1j_store_abi(out_xyz, g1j_from_affine(g1j_to_affine(acc)));
     return ZKHIP_OK;
 }
 

@@ -56,6 +56,7 @@ class ZkEvalhArgs(C.Structure):
 SYMBOLS = [
     "zkhip_init", "zkhip_destroy", "zkhip_last_error", "zkhip_set_stream", "zkhip_synchronize", "zkhip_set_option", "zkhip_trim", "zkhip_key_release",
     "zkhip_comm_use_library", "zkhip_comm_unique_id", "zkhip_comm_init", "zkhip_comm_init_host", "zkhip_comm_set_host_alltoall", "zkhip_comm_destroy", "zkhip_comm_info", "zkhip_comm_describe", "zkhip_comm_allgather_device", "zkhip_comm_shard_columns",
+    "zkhip_comm_trace", "zkhip_comm_trace_read", "zkhip_comm_phase_name",
     "zkhip_kzg_setup_range", "zkhip_srs_load_range", "zkhip_srs_range", "zkhip_malloc", "zkhip_free",
     "zkhip_memcpy_h2d", "zkhip_memcpy_d2h", "zkhip_timer_start", "zkhip_timer_stop_ms",
     "zkhip_profile_enable", "zkhip_profile_select", "zkhip_profile_read", "zkhip_profile_counter",
@@ -95,6 +96,7 @@ def lib():
 
         L = C.CDLL(LIB_PATH)
         L.zkhip_last_error.restype = C.c_char_p
+        L.zkhip_comm_phase_name.restype = C.c_char_p
         L.zkhip_srs_len.restype = C.c_size_t
         L.zkhip_evm_transcript_new.restype = C.c_void_p
         L.zkhip_evm_transcript_callbacks.restype = C.c_void_p
@@ -302,6 +304,21 @@ class Context:
         _check(lib().zkhip_comm_info(self.h, C.byref(rk), C.byref(nr), C.byref(by)))
         return dict(transport=buf.value.decode(), rank=rk.value, nranks=nr.value, transport_ranks=tr.value, bytes_gathered=by.value,
                     collectives=co.value)
+
+    def comm_trace(self, on=True):
+        """start (clearing the record, marking time zero on the context's stream) / stop the per-exchange trace of the RCCL branch"""
+        _check(lib().zkhip_comm_trace(self.h, C.c_int(1 if on else 0)))
+
+    def comm_trace_read(self, cap=4096):
+        """-> (entries, end_us): per exchange since the mark dict(phase, bytes_received, host_issue_us, stream_done_us, bulk, kind); end_us = when the
+        context's stream drained (zkhip.h)"""
+        n, end = C.c_size_t(), C.c_double()
+        ph, fl = (C.c_uint8 * cap)(), (C.c_uint8 * cap)()
+        by, hu, du = (C.c_uint64 * cap)(), (C.c_double * cap)(), (C.c_double * cap)()
+        _check(lib().zkhip_comm_trace_read(self.h, C.c_size_t(cap), C.byref(n), ph, by, hu, du, fl, C.byref(end)))
+        m = min(n.value, cap)
+        return [dict(phase=lib().zkhip_comm_phase_name(C.c_uint8(ph[i])).decode(), bytes_received=by[i], host_issue_us=round(hu[i], 1), stream_done_us=round(du[i], 1),
+                     bulk=bool(fl[i] & 1), kind="sendrecv" if fl[i] & 2 else "allgather") for i in range(m)], end.value
 
     def comm_allgather(self, send, recv):
         """all-gather of device tensors through the context's communicator (recv: world x send)"""

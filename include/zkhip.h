@@ -139,6 +139,17 @@ int  zkhip_comm_info(const zkhip_ctx* ctx, int* rank, int* nranks, uint64_t* byt
  * symbol is missing); collectives <- exchanges issued so far.  What a launcher prints to show that RCCL really spans N processes. */
 int  zkhip_comm_describe(const zkhip_ctx* ctx, char* transport, size_t cap, int* transport_ranks, uint64_t* collectives);
 int  zkhip_comm_allgather_device(zkhip_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_rank);
+/* Per-exchange trace of a context with an RCCL communicator (a measurement aid, off by default; bench.py --replay-rank records one rank's
+ * exchange timeline with it).  zkhip_comm_trace(ctx, 1) clears the record and marks time zero on the context's stream (an event) and on the host
+ * clock; from then on every all-gather / grouped send-recv exchange leaves an entry: the phase of the proof it belongs to (zkhip_comm_phase_name
+ * of phase[i]: "advice", "lookup permute", "grand products", "quotient", "evaluations", "shplonk", "" outside a proof), the bytes this rank
+ * receives, the host time of the issue and the time the exchange COMPLETED on the communicator's stream (a timing event right behind it), both
+ * in microseconds since the mark; flags bit 0 = on the bulk communicator, bit 1 = send / recv group (else all-gather).  zkhip_comm_trace_read waits
+ * for the context's stream, writes min(n, cap) entries (any array may be NULL) and end_us = when the context's stream drained. */
+int  zkhip_comm_trace(zkhip_ctx* ctx, int on);
+int  zkhip_comm_trace_read(zkhip_ctx* ctx, size_t cap, size_t* n, uint8_t* phase, uint64_t* bytes_received, double* host_issue_us, double* stream_done_us,
+                           uint8_t* flags, double* end_us);
+const char* zkhip_comm_phase_name(uint8_t id);
 
 /* ---- SRS: ParamsKZG::{g, g_lagrange} (halo2_proofs src/poly/kzg/commitment.rs) ----
  * Uploaded once; the device keeps, per base, its W window multiples 2^(c*w) * P_i in affine form

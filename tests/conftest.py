@@ -45,3 +45,14 @@ def zk():
     ctx = ffi.Context(0)
     yield ffi, ctx
     ctx.close()
+
+
+@pytest.fixture(scope="session")
+def cpu_rsa17_proof():
+    """The CPU oracle backend's proof of BASELINE configs[1] (RSA k = 17, Poseidon, witness 0): ~25 s of host time, computed ONCE per session and shared by
+    the single-GPU and the two-rank byte-equality tests (tests/README.md: the GPU suite's time budget)."""
+    import halo2_zkcert_amd.prover as pv
+    from oracle_backend import OracleBackend
+
+    cp = pv.Prover(OracleBackend(os.cpu_count() or 8), pv.CircuitShape.rsa(17), satisfiable=True)
+    return bytes(cp.prove(cp.witness(0), transcript="poseidon")["proof"])

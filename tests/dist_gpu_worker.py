@@ -124,7 +124,7 @@ for spec in json.loads(os.environ["ZK_SHAPES"]):
     p = pv.Prover(pv.GpuBackend(ctx, ffi), sh, satisfiable=True)
     first, count, total = p.b.params.range()
     assert total == 1 << sh.k and (first, count) == (ctx.shard_range(total) if mode == "points" else (0, total)), (first, count, total)
-    w = p.witness(1)
+    w = p.witness(int(os.environ.get("ZK_WITNESS", "1")))
     g0 = ctx.comm_bytes_gathered()
     tr = p.prove_native(w, transcript=spec[2])
     gathered = ctx.comm_bytes_gathered() - g0

@@ -217,19 +217,19 @@ def test_column_round_robin_sharding(zk, tmp_path):
 # ---- the BASELINE configurations at FULL size over two ranks ("configs not exercised on the hardware they name" — the
 # sharded path had only ever run at k <= 9).  One device, host-staged transport: c = 17 shard tables of 2^21 points, 384 MiB gathers,
 # padded rounds at real size.  The single-GPU reference proof is made first and its memory given back before the ranks start.
-def _single_then_sharded(zk, tmp_path, spec, make_shape, mode, timeout, extra_env=None, world=2):
+def _single_then_sharded(zk, tmp_path, spec, make_shape, mode, timeout, extra_env=None, world=2, witness=1):
     import torch
 
     ffi, ctx = zk
     p = pv.Prover(pv.GpuBackend(ctx, ffi), make_shape(), satisfiable=True)
-    w = p.witness(1)
+    w = p.witness(witness)
     ref = p.prove_native(w, transcript=spec[2])["proof"]
     p.release()
     p.b.params.free()
     del p, w
     ctx.trim()
     torch.cuda.empty_cache()
-    outs = _run_workers(tmp_path, world, True, 0, shapes=[spec], extra_env={"ZK_SHARD_MODE": mode, "ZK_NATIVE_ONLY": "1", **(extra_env or {})}, timeout=timeout)
+    outs = _run_workers(tmp_path, world, True, 0, shapes=[spec], extra_env={"ZK_SHARD_MODE": mode, "ZK_NATIVE_ONLY": "1", "ZK_WITNESS": str(witness), **(extra_env or {})}, timeout=timeout)
     key = f"{spec[0]}{spec[1]}{spec[2]}"
     for o in outs:
         assert o["shard_mode"] == mode and o["comm"]["nranks"] == world and o["comm"]["transport"] == (extra_env or {}).get("ZKHIP_COMM_TRANSPORT", "host")
@@ -258,18 +258,15 @@ def test_agg_k22_proof_over_two_ranks_by_point_range(zk, tmp_path):
         assert o["modes"] == {"proofs_row_sharded": 1, "proofs_pieces_sharded": 1, "shplonk_row_sharded": 1}, o["modes"]
 
 
-def test_rsa_k17_proof_over_two_ranks_equals_the_cpu_oracle(zk, tmp_path):
+def test_rsa_k17_proof_over_two_ranks_equals_the_cpu_oracle(zk, tmp_path, cpu_rsa17_proof):
     """BASELINE configs[1] (RSA k = 17, Poseidon) over 2 ranks by column AND by point range: both equal the single-GPU proof, which equals the CPU
-    oracle backend's proof byte for byte (north_star: bit-identical to the CPU prover on the same SRS and witness)."""
-    sys.path[:0] = [p_ for p_ in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")) if p_ not in sys.path]
-    from oracle_backend import OracleBackend
-
+    oracle backend's proof byte for byte (north_star: bit-identical to the CPU prover on the same SRS and witness; the oracle's proof of witness 0
+    is made once per session: conftest.py)."""
     spec = ["rsa", 17, "poseidon"]
-    ref, _ = _single_then_sharded(zk, tmp_path, spec, lambda: pv.CircuitShape.rsa(17), "columns", 900)
-    cp = pv.Prover(OracleBackend(os.cpu_count() or 8), pv.CircuitShape.rsa(17), satisfiable=True)
-    assert bytes(cp.prove(cp.witness(1), transcript="poseidon")["proof"]) == bytes(ref)
+    ref, _ = _single_then_sharded(zk, tmp_path, spec, lambda: pv.CircuitShape.rsa(17), "columns", 900, witness=0)
+    assert cpu_rsa17_proof == bytes(ref)
     (tmp_path / "points").mkdir()
-    ref2, _ = _single_then_sharded(zk, tmp_path / "points", spec, lambda: pv.CircuitShape.rsa(17), "points", 900)
+    ref2, _ = _single_then_sharded(zk, tmp_path / "points", spec, lambda: pv.CircuitShape.rsa(17), "points", 900, witness=0)
     assert bytes(ref2) == bytes(ref)
 
 
@@ -286,7 +283,7 @@ def test_sha_k19_proof_over_two_ranks_by_column(zk, tmp_path):
 def _fake_rccl():
     src = os.path.join(ROOT, "tests", "fake_rccl", "fake_rccl.cpp")
     lib = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
-    if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
+    if not os.path.exists(lib):      # __graft_entry__.build() compiles it from the current source every time (file times do not survive the trip to the GPU box)
         subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-shared", "-fPIC", "-O1", src, "-o", lib])
     return lib
 

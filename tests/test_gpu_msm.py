@@ -220,6 +220,51 @@ def test_large_msm_trapdoor_property(zk, oracle, k):
     p.free()
 
 
+def test_pipelined_host_slice_msm_equals_the_device_resident_sum(zk, oracle):
+    """zkhip_msm_g1 on a caller's HOST slice (best_multiexp at the `curves` patch level: /root/reference/src/helpers.rs:233,299, src/bin/cli.rs:320,369,519
+    through ParamsKZG::commit): from 2^20 scalars the call is pipelined — the slice uploaded in K chunks, chunk j's whole MSM over points
+    [off_j, off_j + len_j) started when its bytes have landed, on two streams alternately, the K partial sums added on the host.  Same point as
+    the device-resident one-column MSM and as the trapdoor value, for every K (option msm_host_chunks), for ragged lengths, from pageable and from
+    pinned memory; an error inside restores the context's stream."""
+    import torch
+
+    ffi, ctx = zk
+    zo = oracle
+    k = 21
+    n = 1 << k
+    s = zo.fr_from_int(0xFEEDFACE7777)
+    p = ffi.ParamsKZG.setup(ctx, k, s)
+    d_col = ctx.synth_fill(n, 0xC0FFEE21)
+    host = ctx.to_host(d_col).copy()                                   # numpy-owned: pageable
+    pin = torch.empty((n, 4), dtype=torch.int64).pin_memory()
+    pin.numpy().view(np.uint64)[:] = host
+    want = ffi.g1_to_affine(ctx.to_host(p.commit_batch_device([d_col]))[0])
+    assert (want == zo.g1_mul_gen(zo.eval_polynomial(host, s))).all()
+    try:
+        for chunks in (0, 1, 2, 3, 4, 8):                              # 0: by size (4 at 2^21)
+            ctx.set_option("msm_host_chunks", chunks)
+            assert (ffi.g1_to_affine(p.commit(host)) == want).all(), chunks
+        assert (ffi.g1_to_affine(p.commit(pin.numpy().view(np.uint64))) == want).all()
+        # ragged: the last chunk is short; a length that is not a multiple of the sort's 256-scalar blocks; chunk boundaries move with n
+        for m in (n - 1, n - 255, (1 << 20) + 12345, (3 << 19) + 1):
+            ref = ffi.g1_to_affine(ctx.to_host(p.commit_batch_device([d_col], n=m))[0])
+            for chunks in (0, 3, 4):
+                ctx.set_option("msm_host_chunks", chunks)
+                assert (ffi.g1_to_affine(p.commit(host[:m])) == ref).all(), (m, chunks)
+        # all-zero and single-non-zero slices through the pipelined form
+        ctx.set_option("msm_host_chunks", 4)
+        z = np.zeros((n, 4), dtype=np.uint64)
+        assert (ffi.g1_to_affine(p.commit(z)) == 0).all()
+        z[n - 7] = zo.fr_from_int(5)
+        bases = p.read_bases(p.g, n - 7, 1)
+        assert (ffi.g1_to_affine(p.commit(z)) == zo.g1_to_affine(zo.best_multiexp(z[n - 7:n - 6], bases, 1))).all()
+    finally:
+        ctx.set_option("msm_host_chunks", 0)
+    # back to back with device-resident work on the same context: the pipelined call leaves the context on its main stream
+    assert (ffi.g1_to_affine(ctx.to_host(p.commit_batch_device([d_col]))[0]) == want).all()
+    p.free()
+
+
 @pytest.mark.parametrize("k", [18, 19])
 def test_c17_window_path(zk, oracle, k):
     """2^18 and 2^19 points: the only sizes that select the window c = 17 / W = 15 (15 x 17 = 255 bits, no short top window) —

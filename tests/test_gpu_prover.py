@@ -413,7 +413,7 @@ def _cpu_oracle_digest(key):
         return json.load(f)["digests"][key]
 
 
-def test_rsa_k17_proof_bytes_equal_the_cpu_oracle(zk, oracle):
+def test_rsa_k17_proof_bytes_equal_the_cpu_oracle(zk, oracle, cpu_rsa17_proof):
     """north_star's own sentence at a BASELINE size: "proof bytes bit-identical to the reference CPU prover on the same SRS and witness".
     BASELINE configs[1] (RSA k = 17, the c = 16 window, the 2^17 NTT pass plan — kernels no k <= 12 case selects) under the transcript
     prove-rsa uses (/root/reference/src/bin/cli.rs:320, helpers.rs:233): the one-call GPU proof == the CPU oracle backend's proof, byte for
@@ -421,9 +421,8 @@ def test_rsa_k17_proof_bytes_equal_the_cpu_oracle(zk, oracle):
     ffi, ctx = zk
     sh = pv.CircuitShape.rsa(17)
     gp = pv.Prover(pv.GpuBackend(ctx, ffi), sh, satisfiable=True)
-    cp = pv.Prover(OracleBackend(os.cpu_count() or 8), sh, satisfiable=True)
     wg = gp.witness(0)
-    want = bytes(cp.prove(cp.witness(0), transcript="poseidon")["proof"])
+    want = cpu_rsa17_proof      # Prover(OracleBackend, rsa(17)).prove(witness(0), "poseidon"): conftest.py, once per session
     got = bytes(gp.prove_native(wg, transcript="poseidon")["proof"])
     assert len(want) > 1000 and got == want
     assert hashlib.sha256(want).hexdigest() == _cpu_oracle_digest("rsa_k17/poseidon/witness0")      # the recorded digest is this oracle's

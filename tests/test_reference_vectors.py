@@ -9,7 +9,10 @@ import numpy as np
 import pytest
 
 PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.json")
-pytestmark = pytest.mark.skipif(not os.path.exists(PATH), reason="tests/golden/reference_vectors.json not generated yet (integration/rust/refvec)")
+# Reported as XFAIL (an expected, named gap in the summary line), not as a silent skip, while the file is absent: "parity unpinned against upstream" stays visible in
+# every test run.  With the file present the marker does nothing (run = the condition is false).
+pytestmark = pytest.mark.xfail(not os.path.exists(PATH), run=False, strict=False,
+                               reason="PARITY UNPINNED against upstream: tests/golden/reference_vectors.json has not been generated (integration/rust/refvec needs a machine with Rust)")
 H = lambda s: int(s, 16)
 
 

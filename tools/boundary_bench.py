@@ -3,7 +3,7 @@
 array in PAGEABLE host memory (a Rust Vec<Fr>: what integration/rust/halo2curves-zkhip/src/zkhip.rs hands over, reached from
 /root/reference/src/helpers.rs:233,299 and src/bin/cli.rs:320,369,519 through best_multiexp / best_fft), in pinned host memory, and the
 device-resident one-column forms of the same work beside them.  Median of --reps calls after a warm-up, wall clock around the blocking call.
-    python tools/boundary_bench.py [--k 17 22] [--reps 9] [--modes 0 1 2]     (modes: the library's host_xfer option, see csrc/hostxfer.hpp)
+    python tools/boundary_bench.py [--k 17 22] [--reps 9] [--chunks 1 2 4 8]     (chunks: the library's msm_host_chunks option — pieces of zkhip_msm_g1's upload + MSM pipeline; 1 = unpipelined)
 Prints one JSON object."""
 import argparse
 import json
@@ -30,7 +30,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--k", type=int, nargs="+", default=[17, 22])
     ap.add_argument("--reps", type=int, default=9)
-    ap.add_argument("--modes", type=int, nargs="+", default=None, help="values of the library's host_xfer option to time (default: whatever the library does)")
+    ap.add_argument("--chunks", type=int, nargs="+", default=None, help="values of the library's msm_host_chunks option to time (default: the library's own choice by size)")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -49,7 +49,6 @@ def main():
         pin_t = torch.empty((n, 4), dtype=torch.int64).pin_memory()
         pinned = pin_t.numpy().view(np.uint64)
         pinned[:] = pageable
-        omega = np.array(zo.Domain(4, k).omega if hasattr(zo.Domain(4, k), "omega") else dom.omega, dtype=np.uint64) if False else None
         res = {"bytes": n * 32}
         want = ffi.g1_to_affine(ctx.to_host(params.commit_batch_device([d_col]))[0])
 
@@ -63,10 +62,10 @@ def main():
             dom.lagrange_to_coeff_device([d_poly])
             ctx.synchronize()
         res["intt_device_resident_one_column"] = med(dev_fft, args.reps)
-        for mode in (args.modes if args.modes is not None else [None]):
-            tag = "" if mode is None else f"_mode{mode}"
+        for mode in (args.chunks if args.chunks is not None else [None]):
+            tag = "" if mode is None else f"_chunks{mode}"
             if mode is not None:
-                ctx.set_option("host_xfer", mode)
+                ctx.set_option("msm_host_chunks", mode)
             assert (ffi.g1_to_affine(params.commit(pageable)) == want).all(), "zkhip_msm_g1 (pageable) differs from the device-resident MSM"
             assert (ffi.g1_to_affine(params.commit(pinned)) == want).all(), "zkhip_msm_g1 (pinned) differs from the device-resident MSM"
             res["zkhip_msm_g1_pageable" + tag] = med(lambda: params.commit(pageable), args.reps)
@@ -82,8 +81,9 @@ def main():
                 ffi._check(ffi.lib().zkhip_lagrange_to_coeff(ctx.h, dom.h, ffi._p(buf)))
             res["zkhip_lagrange_to_coeff_pageable" + tag] = med(lambda: host_fft(work), args.reps)
             res["zkhip_lagrange_to_coeff_pinned" + tag] = med(lambda: host_fft(pinned), args.reps)
-        dev, hp = res["msm_device_resident_one_column"][0], res.get("zkhip_msm_g1_pageable" + ("" if args.modes is None else f"_mode{args.modes[-1]}"))[0]
-        res["msm_pageable_over_device_resident"] = round(hp / dev, 3)
+        ctx.set_option("msm_host_chunks", 0)
+        dev = res["msm_device_resident_one_column"][0]
+        res["msm_pageable_over_device_resident"] = {k_[len("zkhip_msm_g1_pageable"):] or "default": round(v_[0] / dev, 3) for k_, v_ in res.items() if k_.startswith("zkhip_msm_g1_pageable")}
         out["sizes"][f"k{k}"] = res
         params.free()
         dom.free()
