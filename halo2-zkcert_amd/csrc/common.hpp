@@ -148,6 +148,7 @@ struct zkhip_ctx {
     void* h_pinned = nullptr;   // 64 KiB of pinned host memory for the small device->host reads on the critical path
     static constexpr size_t PINNED_BYTES = 64 * 1024;
     std::map<std::string, zk::Scratch> scratch;
+    std::string scratch_tag;   // appended to every scratch name while set: zkhip_msm_g1's pipelined chunks keep their buffers apart (msm.hip)
     // name -> a buffer of ANOTHER phase that is dead while this name is in use (zkhip_create_proof_ex lends the advice cosets' block to
     // SHPLONK's quotient scratch): get_scratch hands it out instead of allocating, if it is large enough.  Set and cleared by the lender.
     std::map<std::string, zk::Scratch> lent;

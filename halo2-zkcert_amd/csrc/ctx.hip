@@ -69,7 +69,7 @@ using namespace zk;
 int zkhip_ctx::get_scratch(const char* name, size_t bytes, void** out) {
     // scratch is private to the stream it is used on: two streams may run the same kind of call concurrently
     char key[96];
-    snprintf(key, sizeof key, "%s@%p", name, (void*)stream);
+    snprintf(key, sizeof key, "%s%s@%p", name, scratch_tag.c_str(), (void*)stream);
     if (!lent.empty()) {
         auto it = lent.find(name);
         if (it != lent.end() && it->second.bytes >= bytes && scratch.find(key) == scratch.end()) { *out = it->second.ptr; return ZKHIP_OK; }

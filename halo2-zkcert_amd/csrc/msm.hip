@@ -1050,9 +1050,14 @@ __global__ void k_set_identity(uint32_t* out_all, uint32_t ncols) {
 // ------------------------------------------------------------------ host driver
 static uint32_t ilog2_u32(uint32_t v) { uint32_t l = 0; while ((1u << (l + 1)) <= v) ++l; return l; }
 // columns hold at least first + n scalars; scalar first + i pairs with base first + i (indices LOCAL to the handles' tables).
-static int msm_local(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const void* const* d_cols_host, size_t ncols, size_t first, size_t n,
-                     void* d_out) {
-    if (ncols == 0) return ZKHIP_OK;
+// What the accumulation (round 0 + the reduction rounds for heavy buckets) leaves behind: per column and bucket b, cnt[b] partial sums (loose XYZZ, PART_WORDS
+// words each) at p[off[b] ..]; the tail folds them, weights bucket b by b + 1 and sums (msm_tail).  empty: every digit of every column was zero.
+struct MsmPartials { const uint32_t* p; const uint32_t* cnt; const uint32_t* off; size_t stride; uint32_t B; bool empty; };
+static int msm_tail(zkhip_ctx* ctx, size_t ncols, const MsmPartials& P, void* d_out);
+
+// digits, sort by bucket, plan, bucket accumulation and the reduction rounds of ncols columns over points [first, first + n) -> the buckets' partial sums
+static int msm_partials(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const void* const* d_cols_host, size_t ncols, size_t first, size_t n,
+                        MsmPartials* P) {
     const zkhip_srs* srs = srs_per_col[0];
     for (size_t j = 0; j < ncols; ++j) {
         const zkhip_srs* q = srs_per_col[j];
@@ -1060,14 +1065,10 @@ static int msm_local(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const 
         if (q->n != srs->n || q->c != srs->c) { set_error("zkhip_msm: the SRS of column %zu has a different size", j); return ZKHIP_EINVAL; }
     }
     if (first + n > srs->n) { set_error("zkhip_msm: range [%zu, %zu) exceeds the %zu bases loaded", first, first + n, srs->n); return ZKHIP_EINVAL; }
-    if (ncols == 0) return ZKHIP_OK;
     hipStream_t st = ctx->stream;
-    if (n == 0) {
-        hipLaunchKernelGGL(k_set_identity, dim3(div_up(ncols, 64)), dim3(64), 0, st, (uint32_t*)d_out, (uint32_t)ncols);
-        ZK_LAUNCH_CHECK();
-        return ZKHIP_OK;
-    }
     const uint32_t c = srs->c, W = srs->W, B = srs->B;
+    *P = MsmPartials{nullptr, nullptr, nullptr, 0, B, true};
+    if (n == 0) return ZKHIP_OK;
     const size_t items = n * W;
     const uint32_t seg0_min = 8;
     // Round-0 segment length depends on the problem size only: aim for ~2 waves per SIMD over the chip.
@@ -1086,7 +1087,7 @@ static int msm_local(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const 
         { int v = ctx->opt.msm_seg; if (v >= (int)seg0_min && v <= 256) seg = (uint32_t)v; }
     }
     // scratch
-    void *d_colptrs, *d_zero, *d_off, *d_tmp_entry, *d_tmp_key, *d_entries, *d_max, *d_cntA, *d_cntB, *d_offA, *d_offB, *d_pA, *d_pB, *d_chunks;
+    void *d_colptrs, *d_zero, *d_off, *d_tmp_entry, *d_tmp_key, *d_entries, *d_max, *d_cntA, *d_cntB, *d_offA, *d_offB, *d_pA, *d_pB;
     // Partial sums per column: one per (round-0 lane, bucket it touches).  A lane covers l consecutive sorted entries, l = lane_len(total, items,
     // seg, ncols) >= total * seg / items (and >= 2), so there are at most total / l + B <= items / seg + B of them whatever the column's density;
     // the reduction rounds only shrink that.  (Until round 4 the two buffers were sized for seg = 8: 11.3 GiB for a five-column batch at k = 22,
@@ -1130,30 +1131,6 @@ static int msm_local(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const 
     ZK_TRY(ctx->get_scratch("msm_offB", ncols * (B + 4) * 4, &d_offB));
     ZK_TRY(ctx->get_scratch("msm_pA", ncols * pstride0 * PART_WORDS * 4, &d_pA));
     ZK_TRY(ctx->get_scratch("msm_pB", ncols * pstride0 * PART_WORDS * 4, &d_pB));
-    uint32_t CH = B > 8192 ? std::min<uint32_t>(B / 8192, 32) : 1;   // 2^19 buckets (c = 20): 32 beats 64 by 0.4 ms per k = 22 proof, 16 equals 32
-    { int v = ctx->opt.msm_ch; if (v >= 1 && v <= 256) CH = (uint32_t)v; }
-    uint32_t nchunks = (B + CH - 1) / CH;
-    // a wide batch has enough chunks to fill the chip with one lane each; otherwise four lanes share every point operation
-    bool wide_tail = (size_t)nchunks * ncols >= (size_t)48 * 1024;   // measured crossover: 6-8 columns at 8192 chunks
-    if (ctx->opt.msm_widetail >= 0) wide_tail = ctx->opt.msm_widetail != 0;
-    uint32_t nchunk_blocks = div_up(nchunks, wide_tail ? 256 : 64);
-    ZK_TRY(ctx->get_scratch("msm_chunks", ncols * (size_t)nchunk_blocks * 128, &d_chunks));
-    // Two-level tail (round 4): the chunks' bases are applied to the chunk TOTALS by a second running-sum pass instead of one double-and-add
-    // per chunk (~21 of a chunk's 2 CH + 21 point operations).  It removes work, not depth — it adds a launch — so it is for the wide
-    // batches, whose tail runs beside the other stream's transforms; the one- and two-column MSMs of the multi-open run alone and keep
-    // the shorter one-level chain.
-    const uint32_t CH2 = 8;
-    bool two_level = wide_tail && nchunks >= 4096 && (CH & (CH - 1)) == 0;
-    if (ctx->opt.msm_tail2 >= 0) two_level = ctx->opt.msm_tail2 != 0 && nchunks >= 2 * CH2 && (CH & (CH - 1)) == 0;
-    const uint32_t nsuper = div_up(nchunks, CH2);
-    const bool wide2 = (size_t)nsuper * ncols >= (size_t)48 * 1024;
-    const uint32_t nblk2 = div_up(nsuper, wide2 ? 256 : 64);
-    void *d_tot = nullptr, *d_chunks2 = nullptr;
-    if (two_level) {
-        ZK_TRY(ctx->get_scratch("msm_tot", ncols * (size_t)nchunks * 128, &d_tot));
-        ZK_TRY(ctx->get_scratch("msm_chunks2", ncols * (size_t)nblk2 * 128, &d_chunks2));
-    }
-
     std::vector<const void*> h_ptrs(2 * ncols);
     for (size_t j = 0; j < ncols; ++j) { h_ptrs[j] = d_cols_host[j]; h_ptrs[ncols + j] = srs_per_col[j]->d_table; }
     ColPtrs cp_scalars, cp_tables;
@@ -1263,11 +1240,7 @@ static int msm_local(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const 
         else ZK_HIP(stream_wait(ctx, st));                               // pageable destination: wait for everything
         for (size_t j = 0; j < ncols; ++j) maxcnt = std::max(maxcnt, h_max[j]);
     }
-    if (maxcnt == 0) {
-        hipLaunchKernelGGL(k_set_identity, dim3(div_up(ncols, 64)), dim3(64), 0, st, (uint32_t*)d_out, (uint32_t)ncols);
-        ZK_LAUNCH_CHECK();
-        return ZKHIP_OK;
-    }
+    if (maxcnt == 0) return ZKHIP_OK;      // (P->empty)
     if (ctx->opt.msm_debug) fprintf(stderr, "msm: n=%zu ncols=%zu c=%u W=%u L=%u max partials per bucket=%u\n", n, ncols, c, W, L, maxcnt);
     const uint32_t* cur_cnt = (const uint32_t*)d_cntA;
     const uint32_t* cur_off = (const uint32_t*)d_offA;
@@ -1313,6 +1286,43 @@ static int msm_local(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const 
         for (size_t j = 0; j < ncols; ++j) ctx->prof_msm_pairs += tot[j];
         ctx->prof_msm_dense_pairs += (uint64_t)ncols * items;
     }
+    *P = MsmPartials{cur_p, cur_cnt, cur_off, pstride0, B, false};
+    return ZKHIP_OK;
+}
+
+// The bucket reduction ("tail"): out[col] = sum_b (b + 1) * (sum of bucket b's partial sums), by chunks of CH buckets with running sums.
+static int msm_tail(zkhip_ctx* ctx, size_t ncols, const MsmPartials& P, void* d_out) {
+    hipStream_t st = ctx->stream;
+    const uint32_t B = P.B;
+    const uint32_t* cur_p = P.p;
+    const uint32_t* cur_cnt = P.cnt;
+    const uint32_t* cur_off = P.off;
+    const size_t pstride0 = P.stride;
+    void* d_chunks;
+    uint32_t CH = B > 8192 ? std::min<uint32_t>(B / 8192, 32) : 1;   // 2^19 buckets (c = 20): 32 beats 64 by 0.4 ms per k = 22 proof, 16 equals 32
+    { int v = ctx->opt.msm_ch; if (v >= 1 && v <= 256) CH = (uint32_t)v; }
+    uint32_t nchunks = (B + CH - 1) / CH;
+    // a wide batch has enough chunks to fill the chip with one lane each; otherwise four lanes share every point operation
+    bool wide_tail = (size_t)nchunks * ncols >= (size_t)48 * 1024;   // measured crossover: 6-8 columns at 8192 chunks
+    if (ctx->opt.msm_widetail >= 0) wide_tail = ctx->opt.msm_widetail != 0;
+    uint32_t nchunk_blocks = div_up(nchunks, wide_tail ? 256 : 64);
+    ZK_TRY(ctx->get_scratch("msm_chunks", ncols * (size_t)nchunk_blocks * 128, &d_chunks));
+    // Two-level tail (round 4): the chunks' bases are applied to the chunk TOTALS by a second running-sum pass instead of one double-and-add
+    // per chunk (~21 of a chunk's 2 CH + 21 point operations).  It removes work, not depth — it adds a launch — so it is for the wide
+    // batches, whose tail runs beside the other stream's transforms; the one- and two-column MSMs of the multi-open run alone and keep
+    // the shorter one-level chain.
+    const uint32_t CH2 = 8;
+    bool two_level = wide_tail && nchunks >= 4096 && (CH & (CH - 1)) == 0;
+    if (ctx->opt.msm_tail2 >= 0) two_level = ctx->opt.msm_tail2 != 0 && nchunks >= 2 * CH2 && (CH & (CH - 1)) == 0;
+    const uint32_t nsuper = div_up(nchunks, CH2);
+    const bool wide2 = (size_t)nsuper * ncols >= (size_t)48 * 1024;
+    const uint32_t nblk2 = div_up(nsuper, wide2 ? 256 : 64);
+    void *d_tot = nullptr, *d_chunks2 = nullptr;
+    if (two_level) {
+        ZK_TRY(ctx->get_scratch("msm_tot", ncols * (size_t)nchunks * 128, &d_tot));
+        ZK_TRY(ctx->get_scratch("msm_chunks2", ncols * (size_t)nblk2 * 128, &d_chunks2));
+    }
+
     { ProfScope ps(ctx, "msm_tail");
     if (wide_tail)
         hipLaunchKernelGGL(k_bucket_chunks<1>, dim3(nchunk_blocks, (unsigned)ncols), dim3(256), 0, st, (const uint32_t*)cur_p, pstride0,
@@ -1331,6 +1341,44 @@ static int msm_local(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const 
     ZK_LAUNCH_CHECK();
     return ZKHIP_OK;
 }
+
+static int msm_local(zkhip_ctx* ctx, const zkhip_srs* const* srs_per_col, const void* const* d_cols_host, size_t ncols, size_t first, size_t n,
+                     void* d_out) {
+    if (ncols == 0) return ZKHIP_OK;
+    MsmPartials P;
+    ZK_TRY(msm_partials(ctx, srs_per_col, d_cols_host, ncols, first, n, &P));
+    if (P.empty) {
+        hipLaunchKernelGGL(k_set_identity, dim3(div_up(ncols, 64)), dim3(64), 0, ctx->stream, (uint32_t*)d_out, (uint32_t)ncols);
+        ZK_LAUNCH_CHECK();
+        return ZKHIP_OK;
+    }
+    return msm_tail(ctx, ncols, P, d_out);
+}
+
+// zkhip_msm_g1's pipelined form: the K chunks' partial sums of ONE column, bucket by bucket, folded into one dense set (bucket b's single sum at slot b)
+// so that the chunks share ONE tail.  One thread per bucket; B + 1 threads (the last writes the closing offset).
+struct MergeSrc { const uint32_t* p; const uint32_t* cnt; const uint32_t* off; };
+struct MergeArgs { MergeSrc s[16]; uint32_t K; };
+__global__ void __launch_bounds__(256) k_merge_buckets(const MergeArgs A, uint32_t B, uint32_t* out_p, uint32_t* out_cnt, uint32_t* out_off) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b > B) return;
+    out_off[b] = b;
+    if (b == B) return;
+    g1x acc = g1x_identity();
+    bool have = false;
+    for (uint32_t j = 0; j < A.K; ++j) {
+        if (!A.s[j].p) continue;      // an all-zero chunk
+        const uint32_t c = A.s[j].cnt[b], o = A.s[j].off[b];
+        for (uint32_t i = 0; i < c; ++i) {
+            const g1x v = g1x_load_loose(A.s[j].p + (size_t)(o + i) * PART_WORDS);
+            acc = have ? g1x_add(acc, v) : v;
+            have = true;
+        }
+    }
+    out_cnt[b] = have ? 1u : 0u;
+    if (have) g1x_store_loose(out_p + (size_t)b * PART_WORDS, acc);
+}
+
 
 // GLOBAL point indices.  Over whole-SRS handles this is msm_local.  Over point-range shards (zkhip_kzg_setup_range /
 // zkhip_srs_load_range) every rank sums the part of [first, first + n) its tables hold — scalar pointers shifted so that local base 0
@@ -1450,32 +1498,32 @@ int zkhip_msm_g1_batch_range_device(zkhip_ctx* ctx, const zkhip_srs* srs, const 
 
 // best_multiexp on a caller's host slice (the `curves` patch level: halo2curves::msm::best_multiexp -> this, reached from
 // /root/reference/src/helpers.rs:233,299 and src/bin/cli.rs:320,369,519 through ParamsKZG::commit / commit_lagrange).
-// Small inputs: one upload, one MSM.  From 2^20 scalars (32 MiB: the upload is no longer noise against the sum) the call is PIPELINED: the slice
-// is uploaded in K chunks on the copy stream — pageable memory goes over the link at the pinned rate on this platform (profiles/r06_h2d_probe.txt:
-// 56.5 against 57.4 GB/s, hipHostRegister is free), so no staging copy — and chunk j's whole MSM (digits, sort, accumulation, its own tail, over
-// points [off_j, off_j + len_j)) starts as soon as ITS bytes have landed, on the main and the side stream alternately, so that the throughput-bound
-// accumulation of chunk j + 1 runs beside the latency-bound tail of chunk j; the K partial sums are added on the host.  Measured at 2^22 (one MI355X):
-// 8.38 ms before (2.4 upload + 5.6 MSM + read-back, nothing overlapped) against 5.59 for the device-resident column; after: see INTEGRATION.md §1.
+// Small inputs: one upload, one MSM.  From 2^20 scalars (32 MiB: the upload is no longer noise against the sum) the call is PIPELINED:
+//   * the slice is registered with the runtime (hipHostRegister: 2 us on this platform, profiles/r06_h2d_probe.txt) so that the K chunk uploads on the
+//     copy stream are truly asynchronous — an unregistered (pageable) source makes every hipMemcpyAsync block the host for its own duration, and the
+//     chunked form then only adds overhead (measured: 8.2 -> 9.6 ms at 2^22, K = 4); registered, pageable memory moves at the pinned rate (56.5 vs 57.4 GB/s);
+//   * chunk j's digits, sort and bucket accumulation over points [off_j, off_j + len_j) start as soon as ITS bytes have landed, on the main and the
+//     side stream alternately, each chunk in its own scratch (scratch_tag);
+//   * the K chunks' bucket sums are folded bucket by bucket (k_merge_buckets) and ONE tail finishes: a chunk costs its share of the throughput-bound
+//     work plus a plan, not a bucket reduction of its own (K separate MSMs added on the host: 7.2 ms at 2^22 from pinned memory; merged: see INTEGRATION.md 1).
 int zkhip_msm_g1(zkhip_ctx* ctx, const zkhip_srs* srs, const uint64_t* scalars, size_t n, uint64_t out_xyz[12]) {
     if (!ctx || !srs || !out_xyz || (!scalars && n)) { set_error("zkhip_msm_g1: null argument"); return ZKHIP_EINVAL; }
     void *d_s, *d_o;
     ZK_TRY(ctx->get_scratch("msm_host_scalars", (n ? n : 1) * 32, &d_s));
+    ZK_TRY(ctx->get_scratch("msm_host_out", 96, &d_o));
     const zkhip_srs* one_srs[1] = {srs};
+    const void* cols[1] = {d_s};
     size_t K = 1;
-    if (srs->n_total == srs->n && ctx->comm.nranks <= 1) {      // (a point-range shard / a communicator: the collective form, one piece)
+    if (srs->n_total == srs->n && ctx->comm.nranks <= 1 && n <= srs->n) {      // (a point-range shard / a communicator: the collective form, one piece)
         K = n >= ((size_t)1 << 21) ? 4 : n >= ((size_t)1 << 20) ? 2 : 1;
         const int v = ctx->opt.msm_host_chunks;
         if (v >= 1 && v <= 16) K = (size_t)v;
         while (K > 1 && n / K < 65536) K /= 2;
     }
-    ZK_TRY(ctx->get_scratch("msm_host_out", K * 96, &d_o));
-    std::vector<uint64_t> jac(12 * K);
+    uint64_t jac[12];
     if (K == 1) {
         if (n) ZK_HIP(hipMemcpyAsync(d_s, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
-        const void* cols[1] = {d_s};
         ZK_TRY(msm_run(ctx, one_srs, cols, 1, 0, n, d_o));
-        ZK_HIP(hipMemcpyAsync(jac.data(), d_o, 96, hipMemcpyDeviceToHost, ctx->stream));
-        ZK_HIP(hipStreamSynchronize(ctx->stream));
     } else {
         hipStream_t main = ctx->stream;
         if (!ctx->copy_stream) {
@@ -1491,6 +1539,20 @@ int zkhip_msm_g1(zkhip_ctx* ctx, const zkhip_srs* srs, const uint64_t* scalars, 
             ctx->host_chunk_event.resize(K + 1, nullptr);
             for (size_t j = have; j <= K; ++j) ZK_HIP(hipEventCreateWithFlags(&ctx->host_chunk_event[j], hipEventDisableTiming));
         }
+        // pin the caller's pages in place for the duration of the call (a slice that already is pinned — hipHostMalloc, a torch pinned tensor — says so: fine)
+        const bool registered = hipHostRegister((void*)scalars, n * 32, hipHostRegisterDefault) == hipSuccess;
+        if (!registered) (void)hipGetLastError();
+        // whatever happens: the context leaves on its main stream with no scratch tag, the caller's slice is no longer being read (an error exit must not
+        // race the DMA against a Vec<Fr> the caller drops; the copy stream depends on nothing but the fence below) and is unregistered again
+        struct Restore {
+            zkhip_ctx* c; hipStream_t s; const void* host; bool reg; bool ok = false;
+            ~Restore() {
+                c->stream = s;
+                c->scratch_tag.clear();
+                if (!ok && !c->dead) (void)hipStreamSynchronize(c->copy_stream);
+                if (reg) (void)hipHostUnregister((void*)host);
+            }
+        } restore{ctx, main, scalars, registered};
         // the staging column's last readers (an earlier call's kernels) were issued on the main and the side stream: the copies start behind both
         ZK_HIP(hipEventRecord(ctx->host_chunk_event[K], main));
         ZK_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->host_chunk_event[K], 0));
@@ -1502,28 +1564,51 @@ int zkhip_msm_g1(zkhip_ctx* ctx, const zkhip_srs* srs, const uint64_t* scalars, 
             if (len) ZK_HIP(hipMemcpyAsync((char*)d_s + off * 32, (const char*)scalars + off * 32, len * 32, hipMemcpyHostToDevice, ctx->copy_stream));
             ZK_HIP(hipEventRecord(ctx->host_chunk_event[j], ctx->copy_stream));
         }
-        // whatever happens, the context leaves on its main stream, and the caller's slice is no longer being read when the call returns (an error exit
-        // must not race the DMA against a Vec<Fr> the caller drops; the copy stream depends on nothing but the fence above)
-        struct Restore { zkhip_ctx* c; hipStream_t s; bool ok = false; ~Restore() { c->stream = s; if (!ok && !c->dead) (void)hipStreamSynchronize(c->copy_stream); } } restore{ctx, main};
-        const void* cols[1] = {d_s};
+        std::vector<MsmPartials> parts(K);
+        bool any = false;
         for (size_t j = 0; j < K; ++j) {
             const size_t off = std::min(n, j * per), len = std::min(per, n - off);
             hipStream_t sj = (j & 1) ? ctx->side_stream : main;
             ZK_HIP(hipStreamWaitEvent(sj, ctx->host_chunk_event[j], 0));
-            ctx->stream = sj;      // (scratch is keyed by the stream: the two streams' MSMs do not share a buffer; d_o was handed out above)
-            ZK_TRY(msm_run(ctx, one_srs, cols, 1, off, len, (char*)d_o + j * 96));
+            ctx->stream = sj;
+            char tag[16];
+            snprintf(tag, sizeof tag, "#c%zu", j);
+            ctx->scratch_tag = tag;      // chunk j's sort / accumulation buffers are its own: they stay alive until the merge below has read them
+            ZK_TRY(msm_partials(ctx, one_srs, cols, 1, off, len, &parts[j]));
+            any |= !parts[j].empty;
         }
+        ctx->scratch_tag.clear();
         ctx->stream = main;
         ZK_HIP(hipEventRecord(ctx->side_event, ctx->side_stream));
         ZK_HIP(hipStreamWaitEvent(main, ctx->side_event, 0));
-        ZK_HIP(hipMemcpyAsync(jac.data(), d_o, K * 96, hipMemcpyDeviceToHost, main));
+        if (!any) {
+            hipLaunchKernelGGL(k_set_identity, dim3(1), dim3(64), 0, main, (uint32_t*)d_o, 1u);
+        } else {
+            const uint32_t B = srs->B;
+            void *d_mp, *d_mcnt, *d_moff;
+            ZK_TRY(ctx->get_scratch("msm_merge_p", (size_t)B * PART_WORDS * 4, &d_mp));
+            ZK_TRY(ctx->get_scratch("msm_merge_cnt", (size_t)B * 4, &d_mcnt));
+            ZK_TRY(ctx->get_scratch("msm_merge_off", ((size_t)B + 4) * 4, &d_moff));
+            MergeArgs A;
+            memset(&A, 0, sizeof A);
+            A.K = (uint32_t)K;
+            for (size_t j = 0; j < K; ++j) if (!parts[j].empty) A.s[j] = MergeSrc{parts[j].p, parts[j].cnt, parts[j].off};
+            { ProfScope ps(ctx, "msm_accum_jac");
+            hipLaunchKernelGGL(k_merge_buckets, dim3(div_up((size_t)B + 1, 256)), dim3(256), 0, main, A, B, (uint32_t*)d_mp, (uint32_t*)d_mcnt, (uint32_t*)d_moff); }
+            ZK_TRY(msm_tail(ctx, 1, MsmPartials{(const uint32_t*)d_mp, (const uint32_t*)d_mcnt, (const uint32_t*)d_moff, B, B, false}, d_o));
+        }
+        ZK_LAUNCH_CHECK();
+        // every chunk's bytes have been consumed once the main stream drains: wait here, so that the slice can be unregistered / dropped
+        ZK_HIP(hipMemcpyAsync(jac, d_o, 96, hipMemcpyDeviceToHost, main));
         ZK_HIP(stream_wait(ctx, main));
         restore.ok = true;
+        g1j_store_abi(out_xyz, g1j_from_affine(g1j_to_affine(g1j_load_abi(jac))));
+        return ZKHIP_OK;
     }
-    g1j acc = g1j_load_abi(jac.data());
-    for (size_t j = 1; j < K; ++j) acc = g1j_add(acc, g1j_load_abi(jac.data() + 12 * j));
+    ZK_HIP(hipMemcpyAsync(jac, d_o, 96, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
     // normalise: (x, y, 1) or the identity (0, 1, 0), like G1::from(G1Affine)
-    g1j_store_abi(out_xyz, g1j_from_affine(g1j_to_affine(acc)));
+    g1j_store_abi(out_xyz, g1j_from_affine(g1j_to_affine(g1j_load_abi(jac))));
     return ZKHIP_OK;
 }
 

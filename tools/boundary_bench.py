@@ -66,12 +66,17 @@ def main():
             tag = "" if mode is None else f"_chunks{mode}"
             if mode is not None:
                 ctx.set_option("msm_host_chunks", mode)
-            assert (ffi.g1_to_affine(params.commit(pageable)) == want).all(), "zkhip_msm_g1 (pageable) differs from the device-resident MSM"
-            assert (ffi.g1_to_affine(params.commit(pinned)) == want).all(), "zkhip_msm_g1 (pinned) differs from the device-resident MSM"
+            for src_name, src in (("pageable", pageable), ("pinned", pinned)):      # parity first; a mismatch is recorded (and retried once) instead of ending the run
+                if not (ffi.g1_to_affine(params.commit(src)) == want).all():
+                    again = bool((ffi.g1_to_affine(params.commit(src)) == want).all())
+                    out.setdefault("MISMATCHES", []).append(dict(k=k, chunks=mode, source=src_name, repeat_ok=again, source_intact=bool((pinned == pageable).all())))
             res["zkhip_msm_g1_pageable" + tag] = med(lambda: params.commit(pageable), args.reps)
             res["zkhip_msm_g1_pinned" + tag] = med(lambda: params.commit(pinned), args.reps)
             # zkhip_lagrange_to_coeff: best_fft + the 1/n scaling on a host array, in place (the reference's EvaluationDomain::lagrange_to_coeff)
-            work = pageable.copy()
+            work = pageable.copy()                          # (the host forms transform IN PLACE: never on the arrays the MSM parity is checked with)
+            pin_work_t = torch.empty((n, 4), dtype=torch.int64).pin_memory()
+            pin_work = pin_work_t.numpy().view(np.uint64)
+            pin_work[:] = pageable
             ref = dom.lagrange_to_coeff(pageable)
             dref = [d_col.clone()]
             dom.lagrange_to_coeff_device(dref)
@@ -80,7 +85,7 @@ def main():
             def host_fft(buf):
                 ffi._check(ffi.lib().zkhip_lagrange_to_coeff(ctx.h, dom.h, ffi._p(buf)))
             res["zkhip_lagrange_to_coeff_pageable" + tag] = med(lambda: host_fft(work), args.reps)
-            res["zkhip_lagrange_to_coeff_pinned" + tag] = med(lambda: host_fft(pinned), args.reps)
+            res["zkhip_lagrange_to_coeff_pinned" + tag] = med(lambda: host_fft(pin_work), args.reps)
         ctx.set_option("msm_host_chunks", 0)
         dev = res["msm_device_resident_one_column"][0]
         res["msm_pageable_over_device_resident"] = {k_[len("zkhip_msm_g1_pageable"):] or "default": round(v_[0] / dev, 3) for k_, v_ in res.items() if k_.startswith("zkhip_msm_g1_pageable")}
