@@ -180,7 +180,7 @@ def test_a_blocked_collective_call_is_ended_by_the_rung_budget():
 
 def test_one_rank_under_the_launcher_matches_the_plain_run():
     """python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1 (the driver's launch shape at N = 1) = the plain run within 2 %"""
-    common = ["--gpus", "1", "--steps", "8", "--warmup", "2", "--no-other-configs", "--no-cpu-baseline", "--no-h2d"]
+    common = ["--gpus", "1", "--steps", "6", "--warmup", "2", "--no-other-configs", "--no-cpu-baseline", "--no-h2d", "--ffi-level", "none"]
     plain = _run([os.path.join(ROOT, "bench.py")] + common)
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None)
@@ -205,7 +205,14 @@ def test_full_size_chain_over_four_ranks_equals_the_single_gpu_bytes():
     """BASELINE configs[4] at FULL size with the k = 22 aggregation proof sharded over four ranks (`--chain --gpus 4 --agg-k 22`; one device,
     host-staged transport): the aggregation proof's bytes are the single-GPU proof's, the leaf proofs' are the single-GPU chain's
     (/root/reference/src/tests/x509_aggregation.rs:20-110, src/bin/cli.rs:464-527)."""
-    one = _run([os.path.join(ROOT, "bench.py"), "--chain", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"])
+    one = _run([os.path.join(ROOT, "bench.py"), "--chain", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    # (the single-GPU chain on its own: five proofs per step, each of the size its single-configuration run produces, in about the sum of their times)
+    assert one["roofline"]["kernel"] == "k_accum_affine" and one["roofline"]["launches_per_step"] >= 10 and 0 < one["roofline"]["frac"] < 1
+    assert one["n_gpus"] == 1 and one["proofs_per_step"] == 5 and "chain" in one["config"]["workload"] and one["comm"] is None
+    sizes = one["proof_bytes"]
+    assert len(sizes) == 5 and sizes[0] == sizes[2] and sizes[1] == sizes[3] and all(s_ > 1000 for s_ in sizes)
+    assert sizes[4] > sizes[0]                      # 64-byte points under the EVM transcript
+    assert 0.12 < one["value"] < 0.5                # 2 x 7 ms + 2 x 32 ms + 0.12 s
     env = dict(os.environ, ZKHIP_BENCH_ONE_DEVICE="1", ZKHIP_BENCH_DIST_BACKEND="gloo")
     env.pop("WORLD_SIZE", None)
     four = _run([os.path.join(ROOT, "bench.py"), "--gpus", "4", "--chain", "--steps", "1", "--warmup", "1", "--agg-k", "22", "--no-cpu-baseline",
@@ -215,19 +222,6 @@ def test_full_size_chain_over_four_ranks_equals_the_single_gpu_bytes():
     assert len(one["proof_sha256"]) == 5 and len(four["proof_sha256"]) == 2            # rank 0: its RSA leaf proof + the aggregation proof
     assert four["proof_sha256"][1] == one["proof_sha256"][4] and four["proof_bytes"][1] == one["proof_bytes"][4] > 2000
     assert four["proof_sha256"][0] == one["proof_sha256"][0]
-
-
-def test_full_size_chain_on_one_gpu():
-    """BASELINE configs[4] at FULL size on one GPU (`--chain`): 2 x RSA k = 17 + 2 x SHA-shaped k = 19 leaf proofs (Poseidon), then the k = 22
-    aggregation-shaped proof (Keccak) — five proofs per step, each of the size its single-configuration run produces, in about the sum
-    of their times."""
-    d = _run([os.path.join(ROOT, "bench.py"), "--chain", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
-    assert d["roofline"]["kernel"] == "k_accum_affine" and d["roofline"]["launches_per_step"] >= 10 and 0 < d["roofline"]["frac"] < 1
-    assert d["n_gpus"] == 1 and d["proofs_per_step"] == 5 and "chain" in d["config"]["workload"] and d["comm"] is None
-    sizes = d["proof_bytes"]
-    assert len(sizes) == 5 and sizes[0] == sizes[2] and sizes[1] == sizes[3] and all(s > 1000 for s in sizes)
-    assert sizes[4] > sizes[0]                      # 64-byte points under the EVM transcript
-    assert 0.12 < d["value"] < 0.5                  # 2 x 7 ms + 2 x 32 ms + 0.12 s
 
 
 def test_bench_two_ranks_through_the_rccl_transport_path():

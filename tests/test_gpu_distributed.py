@@ -186,15 +186,16 @@ def test_all_gather_path_and_emulated_all_to_all(zk, tmp_path):
     """the two fall-backs of the row-sharded exchange give the same bytes: complete columns all-gathered (option row_sharded = 0, what
     N = 3 / 5 and the extended-domain circuits use anyway), and the all-to-all emulated through the host transport's all-gather callback"""
     ref = _single_gpu_proofs(zk)
+    vol = {}
     for extra in ({"ZKHIP_ROW_SHARDED": "0"}, {"ZKHIP_HOST_A2A": "0"}):
         outs = _run_workers(tmp_path, 2, True, 0, extra_env=extra)
         for o in outs:
             for key, hexs in ref.items():
                 assert o[key]["native"] == hexs and o[key]["python"] == hexs, (extra, key)
-    # and the volumes differ as designed: the row-sharded exchange of the k = 10 circuit moves less than the all-gathers
-    a = _run_workers(tmp_path, 2, True, 0, extra_env={"ZKHIP_ROW_SHARDED": "0"})[0]["small10evm"]["bytes_gathered"]
-    b = _run_workers(tmp_path, 2, True, 0)[0]["small10evm"]["bytes_gathered"]
-    assert b < a, (a, b)
+        vol[next(iter(extra))] = outs[0]["small10evm"]["bytes_gathered"]
+    # and the volumes differ as designed: the row-sharded exchange of the k = 10 circuit (the second run: row windows, the all-to-all emulated — the counter
+    # reports what an all-to-all moves) receives less than the all-gathers of complete columns (the first run)
+    assert vol["ZKHIP_HOST_A2A"] < vol["ZKHIP_ROW_SHARDED"], vol
 
 
 def test_column_round_robin_sharding(zk, tmp_path):

@@ -2,8 +2,10 @@
 """gpurun_out/<tag>/detail/*.json (tools/rank_replay_r06.sh) -> profiles/<tag>_rank_replay.json: every rank of the sharded proofs replayed alone, composed
 two ways per (N, wire point):
     max_rank_sum_ms        max over ranks of the rank's whole step (round 5's figure: every rank runs ahead freely — an UPPER bound on the speed-up)
-    synchronised_step_ms   sum over the proof's exchanges of the max over ranks of the span between the completions of consecutive exchanges, + the max
-                           tail after the last one (every exchange a full barrier — a LOWER bound on the speed-up)
+    synchronised_step_ms   sum over the proof's exchanges (in issue order, the same on every rank) of the max over ranks of the span between "exchanges 0..i-1 have all
+                           completed" and "exchanges 0..i have all completed" (a running max: the bulk communicator's transfers overlap the first communicator's,
+                           so completions are not monotone in issue order), + the max tail after the last one: every prefix of the exchange sequence a full
+                           barrier across the ranks — a LOWER bound on the speed-up
 The real step lies between the two.  Spans come from zkhip_comm_trace (a timing event on the communicator's stream behind every exchange), median of
 3 untimed passes per rank.  NOT an N-GPU measurement: single-rank replays on one MI355X, peers fabricated, wire modelled.
     python tools/install_rank_replay_r06.py r06"""
@@ -55,8 +57,15 @@ def compose(prefix, n, w, single_ms, phase_key=None):
     if all(tls.values()):
         m = min(len(t[0]) for t in tls.values())
         labels = tls[0][2][:m]
-        spans = {r: [t[0][0]] + [t[0][i] - t[0][i - 1] for i in range(1, m)] for r, t in tls.items()}
-        tails = {r: t[1] - t[0][m - 1] for r, t in tls.items()}
+        def prefix_done(done):      # when exchanges 0..i have ALL completed on this rank
+            out_, cur = [], 0.0
+            for v in done[:m]:
+                cur = max(cur, v)
+                out_.append(cur)
+            return out_
+        pref = {r: prefix_done(t[0]) for r, t in tls.items()}
+        spans = {r: [p_[0]] + [p_[i] - p_[i - 1] for i in range(1, m)] for r, p_ in pref.items()}
+        tails = {r: t[1] - pref[r][m - 1] for r, t in tls.items()}
         sync_us = sum(max(spans[r][i] for r in spans) for i in range(m)) + max(tails.values())
         by_phase = {}
         for i in range(m):
