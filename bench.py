@@ -1313,7 +1313,7 @@ def worker(args):
 
     # the boundary at each patch level (host-pointer entry points with pageable arrays): the headline configuration and RSA k = 17
     ffi_lv = None
-    if world == 1 and not replay and args.ffi_level != "none" and not args.python_schedule:
+    if world == 1 and not replay and args.ffi_level != "none" and not args.python_schedule and not args.no_other_configs:      # (--no-other-configs: the headline's kernels only — what the profiling passes trace)
         try:
             ffi_lv = ffi_levels(args.config, head["value"])
             if not args.no_other_configs and "rsa17" in out_configs and args.config != "rsa17" and "error" not in out_configs["rsa17"]:

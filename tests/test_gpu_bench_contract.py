@@ -180,7 +180,7 @@ def test_a_blocked_collective_call_is_ended_by_the_rung_budget():
 
 def test_one_rank_under_the_launcher_matches_the_plain_run():
     """python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1 (the driver's launch shape at N = 1) = the plain run within 2 %"""
-    common = ["--gpus", "1", "--steps", "6", "--warmup", "2", "--no-other-configs", "--no-cpu-baseline", "--no-h2d", "--ffi-level", "none"]
+    common = ["--gpus", "1", "--steps", "6", "--warmup", "2", "--no-other-configs", "--no-cpu-baseline", "--no-h2d"]
     plain = _run([os.path.join(ROOT, "bench.py")] + common)
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None)

@@ -11,8 +11,9 @@ import sys
 tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", tag)
-for f in ("bench.json", "kernel_bench.txt"):
-    shutil.copy(os.path.join(src, f), os.path.join(root, "profiles", f"{tag}_{f}"))
+for f in ("bench.json", "kernel_bench.txt", "bench_detail.json"):      # bench.json: the stdout line (< 4 KB since round 6); bench_detail.json: the whole result object
+    if os.path.exists(os.path.join(src, f)):
+        shutil.copy(os.path.join(src, f), os.path.join(root, "profiles", f"{tag}_{f}"))
 for c in ("rsa17", "sha19", "agg22"):
     shutil.copy(os.path.join(src, f"pmc_{c}.csv"), os.path.join(root, "profiles", f"{tag}_pmc_{c}.csv"))
     shutil.copy(os.path.join(src, f"valu_{c}.csv"), os.path.join(root, "profiles", f"{tag}_valu_{c}.csv"))
@@ -22,7 +23,11 @@ if "--remove" in sys.argv:
     for f in glob.glob(os.path.join(root, "profiles", f"{old}_*")):
         os.remove(f)
 j = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
-print("build", j["build"], "value", j["value"])
+print("build", j["build"], "value", j["value"], "line bytes", len(json.dumps(j)))
+if os.path.exists(os.path.join(src, "bench_detail.json")):
+    j = json.load(open(os.path.join(src, "bench_detail.json")))
+if "configs" not in j:
+    raise SystemExit("no bench_detail.json beside the line: the per-configuration table needs the detail object (python bench.py --detail-out ...)")
 for k in ("rsa17", "sha19", "agg22"):
     c = j["configs"][k]
     r = c["rooflines"]

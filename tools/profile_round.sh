@@ -29,4 +29,4 @@ python3 tools/summarize_profiles.py "$out"
 # the bench line last, with this generation's PMC passes in place: bench.py reads roofline.traffic from profiles/*_pmc_<cfg>.csv of the
 # build it runs (matching `# build=` hash)
 for cfg in rsa17 sha19 agg22; do cp "$out/pmc_$cfg.csv" "profiles/${tag}_pmc_$cfg.csv"; done
-python3 bench.py > "$out/bench.json" 2>> "$out/bench.err"
+python3 bench.py --detail-out "$out/bench_detail.json" > "$out/bench.json" 2>> "$out/bench.err"
