@@ -403,7 +403,7 @@ LADDER = {
               ("independent proofs, one per GPU (no collective on the data path)", ["--replicas"], {"ZKHIP_BENCH_DIST_BACKEND": "gloo"})],
     "replicas": [("independent proofs, one per GPU", [], {}),
                  ("independent proofs, one per GPU, torch control plane on gloo", [], {"ZKHIP_BENCH_DIST_BACKEND": "gloo"})],
-    "chain": [("leaf proofs on ranks 0-3 (N >= 6: the SHA leaves over rank groups), aggregation proof row-sharded over all ranks", [], {}),
+    "chain": [("one leaf per rank 0-3 (--leaf-groups: the SHA leaves over rank groups), aggregation proof row-sharded over all ranks", [], {}),
               ("one leaf per rank 0-3, aggregation proof with the all-gather exchange, torch control plane on gloo", ["--no-leaf-groups"], {"ZKHIP_ROW_SHARDED": "0", "ZKHIP_COMM_BULK": "0", "ZKHIP_BENCH_DIST_BACKEND": "gloo"}),
               ("one leaf per rank 0-3, aggregation proof with MSMs by column", ["--no-leaf-groups", "--shard", "columns"], {"ZKHIP_ROW_SHARDED": "0", "ZKHIP_COMM_BULK": "0", "ZKHIP_BENCH_DIST_BACKEND": "gloo"}),
               ("one leaf per rank 0-3, aggregation proof on rank 0 alone (no collective on the data path)", ["--no-leaf-groups", "--agg-unsharded"], {"ZKHIP_BENCH_DIST_BACKEND": "gloo"})],
@@ -618,8 +618,10 @@ def main():
     ap.add_argument("--msm-c", type=int, default=None, help="window width of the SRS tables built in this run (the library's msm_c option; default: by size)")
     ap.add_argument("--row-sharded", type=int, default=None, choices=[0, 1], help="sharded proofs: 0 = all-gathers of complete columns instead of the all-to-all of row windows "
                     "(the library's row_sharded option; default: the library's, 1)")
-    ap.add_argument("--no-leaf-groups", action="store_true", help="--chain, N >= 6: every leaf proof on one rank (ranks 4.. idle until the aggregation proof) instead of the "
-                    "SHA-shaped leaves over rank groups")
+    ap.add_argument("--leaf-groups", action="store_true", help="--chain, N >= 6: the SHA-shaped leaves over rank GROUPS (ranks 4.. join them) instead of one rank per leaf.  Off by "
+                    "default since round 6: replayed with a modelled wire the two-rank SHA leaf is slower than the one-rank leaf unless a link sustains ~100 GB/s "
+                    "(profiles/r06_rank_replay.json: 20.7 ms with a free interconnect, 27.8 / 41.2 / 66.0 ms at 100 / 50 / 25 GB/s, against 32 ms alone)")
+    ap.add_argument("--no-leaf-groups", action="store_true", help="--chain: every leaf proof on one rank (the default; kept for the ladder's rungs and older command lines)")
     ap.add_argument("--ffi-level", default="all", choices=["all", "curves", "domain", "one-call", "none"],
                     help="N = 1: the boundary timed at each patch level of INTEGRATION.md (`ffi_levels` in the detail file): `curves` = one proof's worth of best_multiexp / "
                          "best_fft calls through the HOST-pointer zkhip_msm_g1 / zkhip_fft with pageable arrays (what patching only halo2curves buys), `domain` = the same with "
@@ -1088,7 +1090,7 @@ def worker(args):
         # ranks 1 + 4, leaf 3 over ranks 3 + 5): such a leaf is ONE proof over its group's own communicator, MSMs by column (k = 19: one MSM
         # cannot fill several GPUs), the same bytes on every member.  The leaf contexts' communicators are used before the barrier, the
         # aggregation proof's after it: never two collectives of different communicators in flight on one device.
-        groups = chain_leaf_groups(vworld, shard and not args.no_leaf_groups)
+        groups = chain_leaf_groups(vworld, shard and args.leaf_groups and not args.no_leaf_groups)
         my_leaf = next((j for j, rs in groups.items() if vrank in rs), None)
         if any(len(rs) > 1 for rs in groups.values()):
             pgs = {}
@@ -1171,6 +1173,7 @@ def worker(args):
             t = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
+        timed_phase_s = dict(phase_s)      # (the traced steps below keep adding to phase_s: the line reports the TIMED steps' phases)
         agg_trace = None
         if replay and shard and agg_here:      # the aggregation proof's exchange timeline on this rank, 3 extra untimed steps
             agg_trace = []
@@ -1215,7 +1218,7 @@ def worker(args):
                "workload": "chain (BASELINE configs[4]): 2 x RSA k=17 + 2 x SHA256-shaped k=19 leaf proofs (Poseidon), barrier, aggregation-shaped "
                            f"k={args.agg_k} proof (Keccak)",
                "parallelism": par, "proof_bytes": list(sizes), "proof_sha256": list(digests), "roofline": roof,
-               "phase_ms_per_step": {"leaf_proofs_until_the_barrier": round(phase_s["leaf"] * 1000.0 / steps, 3), "aggregation_proof": round(phase_s["agg"] * 1000.0 / steps, 3),
+               "phase_ms_per_step": {"leaf_proofs_until_the_barrier": round(timed_phase_s["leaf"] * 1000.0 / steps, 3), "aggregation_proof": round(timed_phase_s["agg"] * 1000.0 / steps, 3),
                                      "note": "host wall clock on this rank; the barrier (and a device synchronize) separates the two phases"},
                "replay_exchanges_per_step": rstats, "replay_trace": agg_trace, "leaf_proof_sha256": leaf_digests, "leaf_groups": {str(j): rs for j, rs in sorted(groups.items())},
                "bytes_gathered_per_step": (ctx.comm_bytes_gathered() - g0) // steps if shard else 0,

@@ -262,16 +262,16 @@ def test_single_rank_replay_issues_the_exchanges_of_a_real_rank():
 
 
 def test_chain_six_ranks_with_the_sha_leaves_over_rank_groups():
-    """`--chain --gpus 6`: ranks 4 and 5 — idle until the aggregation proof when every leaf sits on one rank — join the two SHA-shaped leaves (leaf 1
+    """`--chain --gpus 6 --leaf-groups`: ranks 4 and 5 — idle until the aggregation proof when every leaf sits on one rank — join the two SHA-shaped leaves (leaf 1
     over ranks 1 + 4, leaf 3 over ranks 3 + 5: one proof each on the group's own communicator, MSMs by column).  One device, host-staged
     transport: every leaf's bytes are the single-GPU chain's, the members of a group agree (bench.py checks), the aggregation proof (k = 18
     here) is sharded over all six.  BASELINE configs[4]: /root/reference/src/tests/x509_aggregation.rs:20-110."""
     one = _run([os.path.join(ROOT, "bench.py"), "--chain", "--steps", "1", "--warmup", "1", "--agg-k", "18", "--no-cpu-baseline"])
     env = dict(os.environ, ZKHIP_BENCH_ONE_DEVICE="1", ZKHIP_BENCH_DIST_BACKEND="gloo")
     env.pop("WORLD_SIZE", None)
-    six = _run([os.path.join(ROOT, "bench.py"), "--gpus", "6", "--chain", "--steps", "1", "--warmup", "1", "--agg-k", "18", "--no-cpu-baseline", "--no-ladder"], env=env, timeout=1500)
+    six = _run([os.path.join(ROOT, "bench.py"), "--gpus", "6", "--chain", "--steps", "1", "--warmup", "1", "--agg-k", "18", "--no-cpu-baseline", "--no-ladder", "--leaf-groups"], env=env, timeout=1500)
     assert six["n_gpus"] == 6 and six["leaf_groups"] == {"0": [0], "1": [1, 4], "2": [2], "3": [3, 5]} and "rsa17 on rank 0" in six["config"]["parallelism"]
     assert [six["leaf_proof_sha256"][str(j)] for j in range(4)] == one["proof_sha256"][:4]
     assert six["proof_sha256"][-1] == one["proof_sha256"][4]
-    flat = _run([os.path.join(ROOT, "bench.py"), "--gpus", "6", "--chain", "--steps", "1", "--warmup", "1", "--agg-k", "18", "--no-cpu-baseline", "--no-ladder", "--no-leaf-groups"], env=env, timeout=1500)
+    flat = _run([os.path.join(ROOT, "bench.py"), "--gpus", "6", "--chain", "--steps", "1", "--warmup", "1", "--agg-k", "18", "--no-cpu-baseline", "--no-ladder"], env=env, timeout=1500)      # the default: one rank per leaf
     assert flat["leaf_groups"] == {str(j): [j] for j in range(4)} and [flat["leaf_proof_sha256"][str(j)] for j in range(4)] == one["proof_sha256"][:4]

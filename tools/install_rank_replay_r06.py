@@ -120,9 +120,25 @@ for w in WIRES:
         row["speedup_upper"] = round(chain1["ms_per_step"] / row["step_ms_upper_speedup"], 2)
         if "step_ms_lower_speedup" in row:
             row["speedup_lower"] = round(chain1["ms_per_step"] / row["step_ms_lower_speedup"], 2)
+    # one rank per leaf (the default since round 6; ranks 0, 1, 6 replayed): the leaf phase is the slowest leaf ALONE (no exchange in it), the aggregation phase as above
+    ng = {r: runs.get(f"chain_nogroups_of8_rank{r}_{w}") for r in (0, 1, 6)}
+    if all(ng.values()):
+        leaf_ng = max(d_["phase_ms_per_step"]["leaf_proofs_until_the_barrier"] for d_ in ng.values())
+        e = {"leaf_phase_ms": {str(r): round(d_["phase_ms_per_step"]["leaf_proofs_until_the_barrier"], 3) for r, d_ in ng.items()}, "leaf_phase_slowest_ms": round(leaf_ng, 3),
+             "step_ms_upper_speedup": round(leaf_ng + agg["max_rank_sum_ms"], 3)}
+        if "synchronised_step_ms" in agg:
+            e["step_ms_lower_speedup"] = round(leaf_ng + agg["synchronised_step_ms"], 3)
+        if chain1:
+            e["speedup_upper"] = round(chain1["ms_per_step"] / e["step_ms_upper_speedup"], 2)
+            if "step_ms_lower_speedup" in e:
+                e["speedup_lower"] = round(chain1["ms_per_step"] / e["step_ms_lower_speedup"], 2)
+        row["one_rank_per_leaf"] = e
     out["chain"].append(row)
 json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_rank_replay.json"), "w"), indent=1)
 for row in out["k22"]:
     print(f"k22 N={row['N']} wire [{row['wire'][:12]}]: max-rank {row['max_rank_sum_ms']} ms, synchronised {row.get('synchronised_step_ms')} ms -> speed-up {row.get('speedup_lower')} - {row.get('speedup_upper')}")
 for row in out["chain"]:
-    print(f"chain N=8 wire [{row['wire'][:12]}]: {row.get('step_ms_lower_speedup')} - {row['step_ms_upper_speedup']} ms -> speed-up {row.get('speedup_lower')} - {row.get('speedup_upper')}")
+    if "one_rank_per_leaf" in row:
+        e = row["one_rank_per_leaf"]
+        print(f"chain N=8 one rank per leaf, wire [{row['wire'][:12]}]: {e.get('step_ms_lower_speedup')} - {e['step_ms_upper_speedup']} ms -> speed-up {e.get('speedup_lower')} - {e.get('speedup_upper')}")
+    print(f"chain N=8 (SHA leaves over rank pairs) wire [{row['wire'][:12]}]: {row.get('step_ms_lower_speedup')} - {row['step_ms_upper_speedup']} ms -> speed-up {row.get('speedup_lower')} - {row.get('speedup_upper')}")

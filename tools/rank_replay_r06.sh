@@ -27,5 +27,7 @@ done
 C="--chain --steps 4 --warmup 1"
 run chain_single $C
 for w in w0 w10 w20 w40; do
-  for r in 0 1 2 3 4 5 6 7; do run chain_of8_rank${r}_$w $C --replay-rank $r --of 8 $(wire $w); done
+  for r in 0 1 2 3 4 5 6 7; do run chain_of8_rank${r}_$w $C --leaf-groups --replay-rank $r --of 8 $(wire $w); done
+  # one rank per leaf (the default since round 6): rank 0 = an RSA leaf, rank 1 = a SHA leaf alone, rank 6 = no leaf; the aggregation phase is the grouped rows' own
+  for r in 0 1 6; do run chain_nogroups_of8_rank${r}_$w $C --replay-rank $r --of 8 $(wire $w); done
 done
