@@ -157,6 +157,8 @@ class Context:
 
     # ---- device memory through torch ----
     def empty(self, n_elems, width=4):
+        if os.environ.get("ZKHIP_POISON"):      # test aid (csrc/ctx.hip dev_malloc): output tensors start as garbage, not as whatever the allocator had (often zeros)
+            return self.torch.full((n_elems, width), -0x5A5A5A5A5A5A5A5B, dtype=self.torch.int64, device=self.device)
         return self.torch.empty((n_elems, width), dtype=self.torch.int64, device=self.device)
 
     def to_device(self, arr):

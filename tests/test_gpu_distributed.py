@@ -289,7 +289,7 @@ def _fake_rccl():
     return lib
 
 
-@pytest.mark.parametrize("world,mode", [(2, "points"), (4, "points"), (8, "points"), (4, "columns")])
+@pytest.mark.parametrize("world,mode", [(2, "points"), (4, "points"), (8, "points"), (2, "columns")])      # (4, "columns") took 29-44 s of the suite's budget: two ranks exercise the same branch
 def test_rccl_transport_path_with_emulated_rccl(zk, tmp_path, world, mode):
     """zkhip_comm_init (dlopen, ncclCommInitRank, the all-to-all self-check), the event-fenced ncclAllGather and the grouped ncclSend / ncclRecv
     exchanges with their silent pairs — comm.hip's RCCL branch — under 2, 4 and 8 ranks: same proof bytes as the single GPU, the
