@@ -29,3 +29,18 @@ def test_host_slice_msm_under_random_chunkings():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "host_msm_stress.py"), "--seconds", "40"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "MISMATCH" not in r.stdout, r.stdout[-2000:] + r.stderr[-1000:]
     assert ", 0 mismatches" in r.stdout.strip().splitlines()[-1]
+
+
+def test_no_kernel_depends_on_a_fresh_allocation_being_zero(tmp_path):
+    """ZKHIP_POISON=1 fills every fresh device allocation of the library (and every ffi.Context.empty tensor) with 0xA5 bytes — what a GPU shared with other
+    processes hands out, where a lone process mostly sees zeros: the single-GPU chain's five proof digests (2 x RSA k = 17, 2 x SHA-shaped k = 19, aggregation
+    k = 18) are the unpoisoned run's.  (The whole single-process parity suite under the same variable: `bash tools/poison_check.sh`; round 6: 197 + 8 tests green.)"""
+    digests = []
+    for poison in ("0", "1"):
+        path = str(tmp_path / f"chain_{poison}.json")
+        env = dict(os.environ, ZKHIP_POISON=poison) if poison == "1" else {k_: v_ for k_, v_ in os.environ.items() if k_ != "ZKHIP_POISON"}
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--chain", "--steps", "1", "--warmup", "1", "--agg-k", "18", "--no-cpu-baseline", "--detail-out", path],
+                           capture_output=True, text=True, env=env, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        digests.append(json.load(open(path))["proof_sha256"])
+    assert len(digests[0]) == 5 and digests[0] == digests[1]
