@@ -248,6 +248,14 @@ def test_single_rank_replay_issues_the_exchanges_of_a_real_rank():
     assert rp["n_gpus"] == 1 and rp["scaling"] is None and rp["_line"]["replay"]["of"] == 2 and rp["replay"]["rank"] == 0 and rp["replay"]["of"] == 2 and "SINGLE-RANK REPLAY" in rp["replay"]["note"]
     assert rp["gpu_proofs"] == [] and rp["parity"] is None and rp["cpu_baseline"] is None
     ex = rp["replay"]["exchanges_per_step"]
+    # the rank's exchange timeline (zkhip_comm_trace, 3 untimed passes): one entry per exchange, labelled with the proof's phases, completed inside the proof
+    tr = rp["replay"]["trace"]
+    assert len(tr) == 3
+    for p_ in tr:
+        assert len(p_["done_us"]) == len(p_["exchanges"]) == ex["collectives"] and 0 < max(p_["done_us"]) <= p_["end_us"] + 1.0
+        assert {e[0] for e in p_["exchanges"]} <= {"advice", "lookup permute", "grand products", "quotient", "evaluations", "shplonk"}
+        assert {e[1] for e in p_["exchanges"]} == {"allgather", "sendrecv"} and sum(e[3] for e in p_["exchanges"]) == ex["bytes_received"]
+        assert all(b_ >= a_ for a_, b_ in zip(p_["host_issue_us"], p_["host_issue_us"][1:]))      # issued in program order
     assert rp["comm"]["transport"] == "rccl" and rp["comm"]["nranks"] == 2 and rp["comm"]["transport_ranks"] == 2
     env = dict(os.environ, ZKHIP_BENCH_ONE_DEVICE="1", ZKHIP_BENCH_DIST_BACKEND="gloo", ZKHIP_COMM_TRANSPORT="rccl", ZKHIP_RCCL_LIB=_fake_rccl(), ZKFAKE_RCCL_SLOT_MB="64")
     env.pop("WORLD_SIZE", None)
