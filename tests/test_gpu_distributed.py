@@ -88,9 +88,19 @@ def test_rccl_communicator_single_rank(zk):
         ctx.comm_init(0, 1, None, transport="rccl")
         a = ctx.synth_fill(1000, 77)
         b = torch.zeros_like(a)
+        ctx.comm_trace(True)          # the per-exchange trace (zkhip_comm_trace): one entry per exchange since the mark, outside a proof the phase is ""
         ctx.comm_allgather(a, b)
         ctx.synchronize()
         assert (ctx.to_host(a) == ctx.to_host(b)).all()
+        ent, end_us = ctx.comm_trace_read()
+        assert len(ent) == 1 and ent[0]["kind"] == "allgather" and ent[0]["phase"] == "" and ent[0]["bytes_received"] == 0 and not ent[0]["bulk"]
+        assert 0 <= ent[0]["host_issue_us"] and 0 < ent[0]["stream_done_us"] <= end_us + 1.0
+        assert ctx.comm_trace_read(cap=0)[0] == []      # a too-small caller buffer truncates, it does not overflow
+        ctx.comm_trace(False)
+        ctx.comm_allgather(a, b)
+        ctx.comm_trace(True)          # restarting clears the record; nothing is recorded while it was off
+        assert ctx.comm_trace_read()[0] == []
+        ctx.comm_trace(False)
         sh = pv.CircuitShape.small(7)
         p = pv.Prover(pv.GpuBackend(ctx, ffi), sh, satisfiable=True)
         w = p.witness(0)
