@@ -1496,6 +1496,109 @@ int zkhip_msm_g1_batch_range_device(zkhip_ctx* ctx, const zkhip_srs* srs, const 
     return msm_run(ctx, v.data(), d_scalar_cols, ncols, first, count, d_out_xyz);
 }
 
+// How many pieces the upload + MSM pipeline of a host slice of n scalars is cut into (1: one upload, one MSM)
+static size_t host_msm_chunks(const zkhip_ctx* ctx, const zkhip_srs* srs, size_t n) {
+    if (srs->n_total != srs->n || ctx->comm.nranks > 1 || n > srs->n) return 1;      // (a point-range shard / a communicator: the collective form, one piece)
+    size_t K = n >= ((size_t)1 << 21) ? 4 : n >= ((size_t)1 << 20) ? 2 : 1;
+    const int v = ctx->opt.msm_host_chunks;
+    if (v >= 1 && v <= 16) K = (size_t)v;
+    while (K > 1 && n / K < 65536) K /= 2;
+    return K;
+}
+// the streams and events of the pipelined host forms (created on first use)
+static int host_msm_streams(zkhip_ctx* ctx, size_t nevents) {
+    if (!ctx->copy_stream) {
+        ZK_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        for (auto& e : ctx->copy_event) ZK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    if (!ctx->side_stream) {
+        ZK_HIP(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+        ZK_HIP(hipEventCreateWithFlags(&ctx->side_event, hipEventDisableTiming));
+    }
+    if (ctx->host_chunk_event.size() < nevents) {
+        const size_t have = ctx->host_chunk_event.size();
+        ctx->host_chunk_event.resize(nevents, nullptr);
+        for (size_t j = have; j < nevents; ++j) ZK_HIP(hipEventCreateWithFlags(&ctx->host_chunk_event[j], hipEventDisableTiming));
+    }
+    return ZKHIP_OK;
+}
+// the copy stream starts behind everything already issued on the main and the side stream (the staging columns' last readers)
+static int host_msm_fence(zkhip_ctx* ctx, hipStream_t main, hipEvent_t fence) {
+    ZK_HIP(hipEventRecord(fence, main));
+    ZK_HIP(hipStreamWaitEvent(ctx->copy_stream, fence, 0));
+    ZK_HIP(hipEventRecord(ctx->side_event, ctx->side_stream));
+    ZK_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->side_event, 0));
+    return ZKHIP_OK;
+}
+// Restores what the pipelined host forms change on the context, whatever happens: the main stream, no scratch tag; on an error exit the caller's slices are no
+// longer being read (the copy stream depends on nothing but the fence) — a Vec<Fr> the caller drops must not race the DMA; registered slices are unregistered.
+struct HostMsmRestore {
+    zkhip_ctx* c; hipStream_t s; std::vector<const void*> registered; bool ok = false;
+    ~HostMsmRestore() {
+        c->stream = s;
+        c->scratch_tag.clear();
+        if (!ok && !c->dead && c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+        for (const void* h : registered) if (hipHostUnregister((void*)h) != hipSuccess) (void)hipGetLastError();      // (never leave a sticky error behind: the next launch check would report it)
+    }
+    // pins the caller's pages in place for the duration of the call: an unregistered (pageable) source makes every chunked hipMemcpyAsync block the HOST for its own
+    // duration (a slice that already is pinned — hipHostMalloc, a torch pinned tensor — says so: fine, its copies are asynchronous anyway)
+    void pin(const void* h, size_t bytes) {
+        if (std::find(registered.begin(), registered.end(), h) != registered.end()) return;      // the same slice twice in one batch
+        if (hipHostRegister((void*)h, bytes, hipHostRegisterDefault) == hipSuccess) registered.push_back(h); else (void)hipGetLastError();
+    }
+};
+// ONE host column through the K-chunk pipeline: uploads on the copy stream (issued here), chunk j's digits, sort and bucket accumulation over points [off_j, off_j + len_j)
+// on the main and the side stream alternately as soon as ITS bytes have landed, each chunk in its own scratch (scratch_tag), the chunks' bucket sums folded bucket by bucket
+// (k_merge_buckets) and ONE tail.  Everything is enqueued; the result lands in d_out (96 bytes, device); the main stream has joined the side stream when this returns.
+static int host_msm_pipelined(zkhip_ctx* ctx, hipStream_t main, const zkhip_srs* srs, const uint64_t* scalars, size_t n, size_t K, void* d_s, void* d_out) {
+    const zkhip_srs* one_srs[1] = {srs};
+    const void* cols[1] = {d_s};
+    const size_t per = ((n + K - 1) / K + 255) & ~(size_t)255;
+    for (size_t j = 0; j < K; ++j) {
+        const size_t off = std::min(n, j * per), len = std::min(per, n - off);
+        if (len) ZK_HIP(hipMemcpyAsync((char*)d_s + off * 32, (const char*)scalars + off * 32, len * 32, hipMemcpyHostToDevice, ctx->copy_stream));
+        ZK_HIP(hipEventRecord(ctx->host_chunk_event[j], ctx->copy_stream));
+    }
+    std::vector<MsmPartials> parts(K);
+    bool any = false;
+    for (size_t j = 0; j < K; ++j) {
+        const size_t off = std::min(n, j * per), len = std::min(per, n - off);
+        hipStream_t sj = (j & 1) ? ctx->side_stream : main;
+        ZK_HIP(hipStreamWaitEvent(sj, ctx->host_chunk_event[j], 0));
+        ctx->stream = sj;
+        char tag[16];
+        snprintf(tag, sizeof tag, "#c%zu", j);
+        ctx->scratch_tag = tag;      // chunk j's sort / accumulation buffers are its own: they stay alive until the merge below has read them
+        ZK_TRY(msm_partials(ctx, one_srs, cols, 1, off, len, &parts[j]));
+        any |= !parts[j].empty;
+    }
+    ctx->scratch_tag.clear();
+    ctx->stream = main;
+    ZK_HIP(hipEventRecord(ctx->side_event, ctx->side_stream));
+    ZK_HIP(hipStreamWaitEvent(main, ctx->side_event, 0));
+    if (!any) {
+        hipLaunchKernelGGL(k_set_identity, dim3(1), dim3(64), 0, main, (uint32_t*)d_out, 1u);
+    } else {
+        const uint32_t B = srs->B;
+        void *d_mp, *d_mcnt, *d_moff;
+        ZK_TRY(ctx->get_scratch("msm_merge_p", (size_t)B * PART_WORDS * 4, &d_mp));
+        ZK_TRY(ctx->get_scratch("msm_merge_cnt", (size_t)B * 4, &d_mcnt));
+        ZK_TRY(ctx->get_scratch("msm_merge_off", ((size_t)B + 4) * 4, &d_moff));
+        MergeArgs A;
+        memset(&A, 0, sizeof A);
+        A.K = (uint32_t)K;
+        for (size_t j = 0; j < K; ++j) if (!parts[j].empty) A.s[j] = MergeSrc{parts[j].p, parts[j].cnt, parts[j].off};
+        { ProfScope ps(ctx, "msm_accum_jac");
+        hipLaunchKernelGGL(k_merge_buckets, dim3(div_up((size_t)B + 1, 256)), dim3(256), 0, main, A, B, (uint32_t*)d_mp, (uint32_t*)d_mcnt, (uint32_t*)d_moff); }
+        ZK_TRY(msm_tail(ctx, 1, MsmPartials{(const uint32_t*)d_mp, (const uint32_t*)d_mcnt, (const uint32_t*)d_moff, B, B, false}, d_out));
+    }
+    ZK_LAUNCH_CHECK();
+    // the side stream's next chunk (of a following column) must not overwrite scratch the merge on the main stream is still reading
+    ZK_HIP(hipEventRecord(ctx->side_event, main));
+    ZK_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->side_event, 0));
+    return ZKHIP_OK;
+}
+
 // best_multiexp on a caller's host slice (the `curves` patch level: halo2curves::msm::best_multiexp -> this, reached from
 // /root/reference/src/helpers.rs:233,299 and src/bin/cli.rs:320,369,519 through ParamsKZG::commit / commit_lagrange).
 // Small inputs: one upload, one MSM.  From 2^20 scalars (32 MiB: the upload is no longer noise against the sum) the call is PIPELINED:
@@ -1505,110 +1608,67 @@ int zkhip_msm_g1_batch_range_device(zkhip_ctx* ctx, const zkhip_srs* srs, const 
 //   * chunk j's digits, sort and bucket accumulation over points [off_j, off_j + len_j) start as soon as ITS bytes have landed, on the main and the
 //     side stream alternately, each chunk in its own scratch (scratch_tag);
 //   * the K chunks' bucket sums are folded bucket by bucket (k_merge_buckets) and ONE tail finishes: a chunk costs its share of the throughput-bound
-//     work plus a plan, not a bucket reduction of its own (K separate MSMs added on the host: 7.2 ms at 2^22 from pinned memory; merged: see INTEGRATION.md 1).
+//     work plus a plan, not a bucket reduction of its own (K separate MSMs added on the host: 7.2 ms at 2^22 from pinned memory; merged: 6.7 from pageable).
 int zkhip_msm_g1(zkhip_ctx* ctx, const zkhip_srs* srs, const uint64_t* scalars, size_t n, uint64_t out_xyz[12]) {
     if (!ctx || !srs || !out_xyz || (!scalars && n)) { set_error("zkhip_msm_g1: null argument"); return ZKHIP_EINVAL; }
     void *d_s, *d_o;
     ZK_TRY(ctx->get_scratch("msm_host_scalars", (n ? n : 1) * 32, &d_s));
     ZK_TRY(ctx->get_scratch("msm_host_out", 96, &d_o));
-    const zkhip_srs* one_srs[1] = {srs};
-    const void* cols[1] = {d_s};
-    size_t K = 1;
-    if (srs->n_total == srs->n && ctx->comm.nranks <= 1 && n <= srs->n) {      // (a point-range shard / a communicator: the collective form, one piece)
-        K = n >= ((size_t)1 << 21) ? 4 : n >= ((size_t)1 << 20) ? 2 : 1;
-        const int v = ctx->opt.msm_host_chunks;
-        if (v >= 1 && v <= 16) K = (size_t)v;
-        while (K > 1 && n / K < 65536) K /= 2;
-    }
+    const size_t K = host_msm_chunks(ctx, srs, n);
     uint64_t jac[12];
     if (K == 1) {
+        const zkhip_srs* one_srs[1] = {srs};
+        const void* cols[1] = {d_s};
         if (n) ZK_HIP(hipMemcpyAsync(d_s, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
         ZK_TRY(msm_run(ctx, one_srs, cols, 1, 0, n, d_o));
+        ZK_HIP(hipMemcpyAsync(jac, d_o, 96, hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP(hipStreamSynchronize(ctx->stream));
     } else {
         hipStream_t main = ctx->stream;
-        if (!ctx->copy_stream) {
-            ZK_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-            for (auto& e : ctx->copy_event) ZK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        }
-        if (!ctx->side_stream) {
-            ZK_HIP(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
-            ZK_HIP(hipEventCreateWithFlags(&ctx->side_event, hipEventDisableTiming));
-        }
-        if (ctx->host_chunk_event.size() < K + 1) {
-            const size_t have = ctx->host_chunk_event.size();
-            ctx->host_chunk_event.resize(K + 1, nullptr);
-            for (size_t j = have; j <= K; ++j) ZK_HIP(hipEventCreateWithFlags(&ctx->host_chunk_event[j], hipEventDisableTiming));
-        }
-        // pin the caller's pages in place for the duration of the call (a slice that already is pinned — hipHostMalloc, a torch pinned tensor — says so: fine)
-        const bool registered = hipHostRegister((void*)scalars, n * 32, hipHostRegisterDefault) == hipSuccess;
-        if (!registered) (void)hipGetLastError();
-        // whatever happens: the context leaves on its main stream with no scratch tag, the caller's slice is no longer being read (an error exit must not
-        // race the DMA against a Vec<Fr> the caller drops; the copy stream depends on nothing but the fence below) and is unregistered again
-        struct Restore {
-            zkhip_ctx* c; hipStream_t s; const void* host; bool reg; bool ok = false;
-            ~Restore() {
-                c->stream = s;
-                c->scratch_tag.clear();
-                if (!ok && !c->dead) (void)hipStreamSynchronize(c->copy_stream);
-                if (reg) (void)hipHostUnregister((void*)host);
-            }
-        } restore{ctx, main, scalars, registered};
-        // the staging column's last readers (an earlier call's kernels) were issued on the main and the side stream: the copies start behind both
-        ZK_HIP(hipEventRecord(ctx->host_chunk_event[K], main));
-        ZK_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->host_chunk_event[K], 0));
-        ZK_HIP(hipEventRecord(ctx->side_event, ctx->side_stream));
-        ZK_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->side_event, 0));
-        const size_t per = ((n + K - 1) / K + 255) & ~(size_t)255;
-        for (size_t j = 0; j < K; ++j) {
-            const size_t off = std::min(n, j * per), len = std::min(per, n - off);
-            if (len) ZK_HIP(hipMemcpyAsync((char*)d_s + off * 32, (const char*)scalars + off * 32, len * 32, hipMemcpyHostToDevice, ctx->copy_stream));
-            ZK_HIP(hipEventRecord(ctx->host_chunk_event[j], ctx->copy_stream));
-        }
-        std::vector<MsmPartials> parts(K);
-        bool any = false;
-        for (size_t j = 0; j < K; ++j) {
-            const size_t off = std::min(n, j * per), len = std::min(per, n - off);
-            hipStream_t sj = (j & 1) ? ctx->side_stream : main;
-            ZK_HIP(hipStreamWaitEvent(sj, ctx->host_chunk_event[j], 0));
-            ctx->stream = sj;
-            char tag[16];
-            snprintf(tag, sizeof tag, "#c%zu", j);
-            ctx->scratch_tag = tag;      // chunk j's sort / accumulation buffers are its own: they stay alive until the merge below has read them
-            ZK_TRY(msm_partials(ctx, one_srs, cols, 1, off, len, &parts[j]));
-            any |= !parts[j].empty;
-        }
-        ctx->scratch_tag.clear();
-        ctx->stream = main;
-        ZK_HIP(hipEventRecord(ctx->side_event, ctx->side_stream));
-        ZK_HIP(hipStreamWaitEvent(main, ctx->side_event, 0));
-        if (!any) {
-            hipLaunchKernelGGL(k_set_identity, dim3(1), dim3(64), 0, main, (uint32_t*)d_o, 1u);
-        } else {
-            const uint32_t B = srs->B;
-            void *d_mp, *d_mcnt, *d_moff;
-            ZK_TRY(ctx->get_scratch("msm_merge_p", (size_t)B * PART_WORDS * 4, &d_mp));
-            ZK_TRY(ctx->get_scratch("msm_merge_cnt", (size_t)B * 4, &d_mcnt));
-            ZK_TRY(ctx->get_scratch("msm_merge_off", ((size_t)B + 4) * 4, &d_moff));
-            MergeArgs A;
-            memset(&A, 0, sizeof A);
-            A.K = (uint32_t)K;
-            for (size_t j = 0; j < K; ++j) if (!parts[j].empty) A.s[j] = MergeSrc{parts[j].p, parts[j].cnt, parts[j].off};
-            { ProfScope ps(ctx, "msm_accum_jac");
-            hipLaunchKernelGGL(k_merge_buckets, dim3(div_up((size_t)B + 1, 256)), dim3(256), 0, main, A, B, (uint32_t*)d_mp, (uint32_t*)d_mcnt, (uint32_t*)d_moff); }
-            ZK_TRY(msm_tail(ctx, 1, MsmPartials{(const uint32_t*)d_mp, (const uint32_t*)d_mcnt, (const uint32_t*)d_moff, B, B, false}, d_o));
-        }
-        ZK_LAUNCH_CHECK();
+        ZK_TRY(host_msm_streams(ctx, K + 1));
+        HostMsmRestore restore{ctx, main};
+        restore.pin(scalars, n * 32);
+        ZK_TRY(host_msm_fence(ctx, main, ctx->host_chunk_event[K]));
+        ZK_TRY(host_msm_pipelined(ctx, main, srs, scalars, n, K, d_s, d_o));
         // every chunk's bytes have been consumed once the main stream drains: wait here, so that the slice can be unregistered / dropped
         ZK_HIP(hipMemcpyAsync(jac, d_o, 96, hipMemcpyDeviceToHost, main));
         ZK_HIP(stream_wait(ctx, main));
         restore.ok = true;
-        g1j_store_abi(out_xyz, g1j_from_affine(g1j_to_affine(g1j_load_abi(jac))));
-        return ZKHIP_OK;
     }
-    ZK_HIP(hipMemcpyAsync(jac, d_o, 96, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
     // normalise: (x, y, 1) or the identity (0, 1, 0), like G1::from(G1Affine)
     g1j_store_abi(out_xyz, g1j_from_affine(g1j_to_affine(g1j_load_abi(jac))));
+    return ZKHIP_OK;
+}
+
+// ncols host columns in one call (SURVEY.md 8(b)'s zkhip_msm_g1_batch: what a patched ParamsKZG would call for a batch of commitments): out_xyz receives
+// ncols x 12 u64, each normalised like zkhip_msm_g1's.  Every column goes through the chunk pipeline above, one after the other WITHOUT a host synchronisation in
+// between: column j + 1's first chunk is on the wire while column j's last accumulation, merge and tail run, so only the very first chunk's upload is exposed
+// (a loop over zkhip_msm_g1 pays it, a read-back and a drained GPU per column).  One wait and one read-back at the end.
+int zkhip_msm_g1_batch(zkhip_ctx* ctx, const zkhip_srs* srs, const uint64_t* const* scalar_cols, size_t ncols, size_t n, uint64_t* out_xyz) {
+    if (!ctx || !srs || (ncols && (!scalar_cols || !out_xyz))) { set_error("zkhip_msm_g1_batch: null argument"); return ZKHIP_EINVAL; }
+    if (ncols == 0) return ZKHIP_OK;
+    for (size_t j = 0; j < ncols; ++j) if (!scalar_cols[j] && n) { set_error("zkhip_msm_g1_batch: column %zu is null", j); return ZKHIP_EINVAL; }
+    if (n > srs->n_total) { set_error("zkhip_msm_g1_batch: %zu scalars for an SRS of %zu bases", n, srs->n_total); return ZKHIP_EINVAL; }
+    if (n < 65536 || srs->n_total != srs->n || ctx->comm.nranks > 1 || n > srs->n) {      // small or collective: column by column through the plain form
+        for (size_t j = 0; j < ncols; ++j) ZK_TRY(zkhip_msm_g1(ctx, srs, scalar_cols[j], n, out_xyz + 12 * j));
+        return ZKHIP_OK;
+    }
+    const size_t K = host_msm_chunks(ctx, srs, n);
+    void *d_s, *d_o;
+    ZK_TRY(ctx->get_scratch("msm_host_batch_scalars", ncols * n * 32, &d_s));
+    ZK_TRY(ctx->get_scratch("msm_host_batch_out", ncols * 96, &d_o));
+    hipStream_t main = ctx->stream;
+    ZK_TRY(host_msm_streams(ctx, K + 1));
+    HostMsmRestore restore{ctx, main};
+    for (size_t j = 0; j < ncols; ++j) restore.pin(scalar_cols[j], n * 32);
+    ZK_TRY(host_msm_fence(ctx, main, ctx->host_chunk_event[K]));
+    for (size_t j = 0; j < ncols; ++j)
+        ZK_TRY(host_msm_pipelined(ctx, main, srs, scalar_cols[j], n, K, (char*)d_s + j * n * 32, (char*)d_o + j * 96));
+    std::vector<uint64_t> jac(12 * ncols);
+    ZK_HIP(hipMemcpyAsync(jac.data(), d_o, ncols * 96, hipMemcpyDeviceToHost, main));
+    ZK_HIP(stream_wait(ctx, main));
+    restore.ok = true;
+    for (size_t j = 0; j < ncols; ++j) g1j_store_abi(out_xyz + 12 * j, g1j_from_affine(g1j_to_affine(g1j_load_abi(jac.data() + 12 * j))));
     return ZKHIP_OK;
 }
 

@@ -61,7 +61,7 @@ SYMBOLS = [
     "zkhip_memcpy_h2d", "zkhip_memcpy_d2h", "zkhip_timer_start", "zkhip_timer_stop_ms",
     "zkhip_profile_enable", "zkhip_profile_select", "zkhip_profile_read", "zkhip_profile_counter",
     "zkhip_srs_load", "zkhip_srs_load_device", "zkhip_srs_free", "zkhip_srs_len", "zkhip_srs_window", "zkhip_kzg_setup", "zkhip_srs_read",
-    "zkhip_msm_g1", "zkhip_msm_g1_batch_device", "zkhip_msm_g1_batch_range_device", "zkhip_msm_g1_multi_device", "zkhip_g1_add", "zkhip_g1_to_affine", "zkhip_g1_batch_to_affine",
+    "zkhip_msm_g1", "zkhip_msm_g1_batch", "zkhip_msm_g1_batch_device", "zkhip_msm_g1_batch_range_device", "zkhip_msm_g1_multi_device", "zkhip_g1_add", "zkhip_g1_to_affine", "zkhip_g1_batch_to_affine",
     "zkhip_g1_to_bytes", "zkhip_commitments_read",
     "zkhip_fft", "zkhip_fft_batch_device",
     "zkhip_domain_new", "zkhip_domain_free", "zkhip_domain_k", "zkhip_domain_extended_k", "zkhip_domain_quotient_poly_degree",
@@ -832,6 +832,16 @@ class ParamsKZG:
         scalars = _u64(scalars).reshape(-1, 4)
         out = np.zeros(12, dtype=np.uint64)
         _check(lib().zkhip_msm_g1(self.ctx.h, srs, _p(scalars), C.c_size_t(scalars.shape[0]), _p(out)))
+        return out
+
+    def commit_batch_host(self, polys, lagrange=False):
+        """several HOST columns of one length in one call (zkhip_msm_g1_batch) -> (ncols, 12) uint64 array of normalised Jacobian sums"""
+        cols = [_u64(p_).reshape(-1, 4) for p_ in polys]
+        n = cols[0].shape[0] if cols else 0
+        assert all(c.shape[0] == n for c in cols)
+        out = np.zeros((len(cols), 12), dtype=np.uint64)
+        ptrs = (C.c_void_p * len(cols))(*[c.ctypes.data for c in cols])
+        _check(lib().zkhip_msm_g1_batch(self.ctx.h, self.g_lagrange if lagrange else self.g, ptrs, C.c_size_t(len(cols)), C.c_size_t(n), _p(out)))
         return out
 
     def commit(self, poly):

@@ -178,6 +178,11 @@ int  zkhip_srs_read(zkhip_ctx* ctx, const zkhip_srs* srs, size_t first, size_t c
  * ParamsKZG::commit / commit_lagrange with bases = srs[..n] ----
  * zkhip_msm_g1: out_xyz is the sum in Jacobian form with z = 1 (or the identity (0,1,0)). */
 int  zkhip_msm_g1(zkhip_ctx* ctx, const zkhip_srs* srs, const uint64_t* scalars, size_t n, uint64_t out_xyz[12]);
+/* ncols HOST columns of n scalars in one call: out_xyz receives ncols x 12 u64, each sum normalised like zkhip_msm_g1's.  Both host forms
+ * are pipelined from 2^20 scalars (round 6): the slices are registered with the runtime for the duration of the call (they must stay alive and unmoved until it
+ * returns), uploaded on a copy stream chunk by chunk (option "msm_host_chunks") and summed as their bytes land; the batch form does not synchronise between its columns
+ * (column j + 1 is on the wire while column j is summed).  Same results as the device-resident forms for every chunking. */
+int  zkhip_msm_g1_batch(zkhip_ctx* ctx, const zkhip_srs* srs, const uint64_t* const* scalar_cols, size_t ncols, size_t n, uint64_t* out_xyz);
 /* ncols independent columns in one pass; d_scalar_cols is a HOST array of device pointers,
  * d_out_xyz receives ncols x 12 u64 (device): Jacobian sums, any representative (normalise with
  * zkhip_g1_to_affine after fetching).  Asynchronous apart from one 4-byte-per-column read-back. */

@@ -265,6 +265,39 @@ def test_pipelined_host_slice_msm_equals_the_device_resident_sum(zk, oracle):
     p.free()
 
 
+@pytest.mark.parametrize("k", [16, 20])
+def test_host_column_batch_equals_the_device_batch(zk, oracle, k):
+    """zkhip_msm_g1_batch (several HOST columns in one call — what a patched ParamsKZG would hand over for a batch of commitments, the callers being
+    /root/reference/src/helpers.rs:233,299 through create_proof's commitment loops): the first column through the chunk pipeline, the others in device batches of up to
+    four as their uploads land.  Every sum equals the device-resident batch's, for 1 / 2 / 5 / 6 columns, ragged lengths, a repeated column, an all-zero column, over the
+    Lagrange basis too; below 2^16 scalars the call is a loop over zkhip_msm_g1."""
+    ffi, ctx = zk
+    zo = oracle
+    n = 1 << k
+    p = ffi.ParamsKZG.setup(ctx, k, zo.fr_from_int(0xBA7C4000 + k))
+    d_cols = [ctx.synth_fill(n, 0xBA7C0 + j) for j in range(6)]
+    host = [ctx.to_host(c).copy() for c in d_cols]
+    host[3][:] = 0                                       # an all-zero column in the middle of a batch
+    d_cols[3] = ctx.to_device(host[3])
+    want = ffi.g1_batch_to_affine(ctx.to_host(p.commit_batch_device(d_cols)))
+    for ncols in (1, 2, 5, 6):
+        got = p.commit_batch_host(host[:ncols])
+        assert (ffi.g1_batch_to_affine(got) == want[:ncols]).all(), ncols
+    assert (ffi.g1_batch_to_affine(p.commit_batch_host([host[2], host[2], host[0]])) == want[[2, 2, 0]]).all()      # the same host array twice
+    for m in (n - 1, n - 300, n // 2 + 77):
+        ref = ffi.g1_batch_to_affine(ctx.to_host(p.commit_batch_device(d_cols[:3], n=m)))
+        assert (ffi.g1_batch_to_affine(p.commit_batch_host([h[:m] for h in host[:3]])) == ref).all(), m
+    lag = ffi.g1_batch_to_affine(ctx.to_host(p.commit_batch_device(d_cols[:2], lagrange=True)))
+    assert (ffi.g1_batch_to_affine(p.commit_batch_host(host[:2], lagrange=True)) == lag).all()
+    assert p.commit_batch_host([]).shape == (0, 12)
+    small = [h[:1000] for h in host[:3]]                 # below the pipeline's floor: a loop over the plain form
+    ref = ffi.g1_batch_to_affine(ctx.to_host(p.commit_batch_device(d_cols[:3], n=1000)))
+    assert (ffi.g1_batch_to_affine(p.commit_batch_host(small)) == ref).all()
+    # and the context is back on its main stream: device work right behind it
+    assert (ffi.g1_batch_to_affine(ctx.to_host(p.commit_batch_device(d_cols))) == want).all()
+    p.free()
+
+
 @pytest.mark.parametrize("k", [18, 19])
 def test_c17_window_path(zk, oracle, k):
     """2^18 and 2^19 points: the only sizes that select the window c = 17 / W = 15 (15 x 17 = 255 bits, no short top window) —
