@@ -873,7 +873,23 @@ def worker(args):
             for _ in range(hs):
                 prover.prove_native(wit, transcript=kind, host_inputs=True)
             torch.cuda.synchronize()
-            h2d = dict(value=round((time.perf_counter() - t0) / hs, 6), unit="s", steps=hs, h2d_bytes=shape.n_advice * n * 32,
+            def timed_host(mode):
+                prover.prove_native(wit, transcript=kind, host_inputs=mode)
+                torch.cuda.synchronize()
+                t_ = time.perf_counter()
+                for _ in range(hs):
+                    prover.prove_native(wit, transcript=kind, host_inputs=mode)
+                torch.cuda.synchronize()
+                return round((time.perf_counter() - t_) / hs, 6)
+            pinned_s = round((time.perf_counter() - t0) / hs, 6)
+            # the same from PAGEABLE host arrays — what a Rust caller's Vec<Fr> columns are: the library registers them for the call (option host_register, round 6) so that the
+            # uploads stay asynchronous; with the registration switched off every copy blocks the host for its own duration
+            pageable_s = timed_host("pageable")
+            ctx.set_option("host_register", 0)
+            unregistered_s = timed_host("pageable")
+            ctx.set_option("host_register", 1)
+            wit.pop("advice_host_pageable", None)
+            h2d = dict(value=pinned_s, pageable_value=pageable_s, pageable_unregistered_value=unregistered_s, unit="s", steps=hs, h2d_bytes=shape.n_advice * n * 32,
                        note="advice columns uploaded from pinned host memory inside the step (copy stream; the random polynomial's commitment and, for many-column circuits, the earlier column groups' commitments overlap the uploads); never part of `value`")
         barrier()
 

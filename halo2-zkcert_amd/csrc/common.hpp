@@ -55,6 +55,7 @@ struct Scratch {
 // Tuning knobs: environment variables (ZKHIP_*) read ONCE when the context is created, or set afterwards with
 // zkhip_set_option — never looked up on the hot path.  0 / -1 = "use the measured default".
 struct zkhip_options {
+    int host_register = 1;     // zkhip_create_proof_ex registers large host advice columns (advice_on_host) with the runtime for the call: pageable sources then upload asynchronously (0: as handed over)
     int msm_host_chunks = 0;   // zkhip_msm_g1 (host slice): pieces the upload + MSM pipeline is cut into (0: by size — 4 from 2^21 scalars, 2 from 2^20, else 1)
     int msm_c = 0, msm_seg = 0, msm_tailparts = 0, msm_ch = 0, msm_widetail = -1, msm_tail2 = -1, msm_adaptive_l = 1, msm_debug = 0;
     int sort_hb = 0, sort_tile = 0, sort_one_atomic = 1, sort_copies = 0, sort_wide = -1;   // sort_wide: low-pass block shape (-1: 1024 threads x 8 pairs for 8192-pair tiles)

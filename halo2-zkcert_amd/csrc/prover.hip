@@ -60,6 +60,19 @@ struct StreamGuard {   // whatever happens, the context leaves on its main strea
     zkhip_ctx* ctx;
     hipStream_t main;
     bool host_uploads = false, aux_launched = false, done = false;
+    // The caller's large host advice columns are registered with the runtime for the duration of the call (round 6): a Rust Vec<Fr> is PAGEABLE memory, and an
+    // unregistered source makes every hipMemcpyAsync block the HOST for the copy's duration — the split upload below, which is designed to run beside the random
+    // polynomial's commitment, would then hold the host (and every launch behind it) for 2.4 ms per 2^22 column.  hipHostRegister costs 2 us here
+    // (profiles/r06_h2d_probe.txt) and fails harmlessly on memory that already is pinned.  Unregistered once the copies are known to be over.
+    std::vector<const void*> registered;
+    void pin(const void* h, size_t bytes) {
+        if (std::find(registered.begin(), registered.end(), h) != registered.end()) return;
+        if (hipHostRegister((void*)h, bytes, hipHostRegisterDefault) == hipSuccess) registered.push_back(h); else (void)hipGetLastError();
+    }
+    void unpin() {
+        for (const void* h : registered) if (hipHostUnregister((void*)h) != hipSuccess) (void)hipGetLastError();
+        registered.clear();
+    }
     // Error exits.  (1) Asynchronous copies FROM THE CALLER'S host buffers may be in flight: wait for them, or a caller that drops its Vec<Fr> /
     // pinned buffers on the error races the DMA.  (2) The random polynomial's MSM may still be running on the third stream (rand_late): it reads
     // w_rand and writes the pinned commitment slot, which the NEXT proof reuses on the main stream — wait for it too.
@@ -82,9 +95,10 @@ struct StreamGuard {   // whatever happens, the context leaves on its main strea
     }
     ~StreamGuard() {
         ctx->stream = main;
-        if (done) return;
+        if (done) { unpin(); return; }      // (a finished proof has read every column: its commitments and evaluations are in the transcript)
         if (ctx->comm.stuck || ctx->dead) {
             if (host_uploads && ctx->copy_stream) bounded_drain(ctx->copy_stream, 5000.0);
+            if (!ctx->copy_stream || hipStreamQuery(ctx->copy_stream) == hipSuccess) unpin(); else (void)hipGetLastError();      // still in flight: the registration is abandoned with the stream
             return;
         }
         if (aux_launched && ctx->aux_stream) (void)stream_wait(ctx, ctx->aux_stream);
@@ -92,6 +106,7 @@ struct StreamGuard {   // whatever happens, the context leaves on its main strea
             if (ctx->copy_stream) (void)stream_wait(ctx, ctx->copy_stream);
             if (!(ctx->comm.stuck || ctx->dead)) (void)stream_wait(ctx, main);
         }
+        if (!(ctx->comm.stuck || ctx->dead)) unpin();
     }
 };
 inline void abi_of(const HF& a, uint64_t out[4]) { fe32 m = hf_abi(a); memcpy(out, m.w, 32); }
@@ -255,6 +270,8 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
             ZK_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
             for (auto& e : ctx->copy_event) ZK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         }
+        if (ctx->opt.host_register != 0)
+            for (uint32_t j = 0; j < A; ++j) if (phase_of(j) == 0) guard.pin(in->advice[j], NB);
         ZK_HIP(hipEventRecord(ctx->copy_event[0], st));   // the upload buffer's last readers (the previous proof) were issued on the main stream
         ZK_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->copy_event[0], 0));
     }

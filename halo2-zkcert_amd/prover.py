@@ -1166,9 +1166,11 @@ class Prover:
         out.evals, out.evals_cap, out.eval_write_order = evals.ctypes.data, len(qlist), worder.ctypes.data
         inp = ffi.ZkProofInputs()
         if host_inputs:
-            host_adv = wit.get("advice_host")
+            # True: pinned host arrays; "pageable": plain host arrays — what a Rust caller's Vec<Fr> columns really are (the library registers large ones for the call)
+            key_ = "advice_host_pageable" if host_inputs == "pageable" else "advice_host"
+            host_adv = wit.get(key_)
             if host_adv is None:
-                host_adv = wit["advice_host"] = [c_.cpu().pin_memory() for c_ in wit["advice"]]
+                host_adv = wit[key_] = [c_.cpu() if host_inputs == "pageable" else c_.cpu().pin_memory() for c_ in wit["advice"]]
             adv = (C.c_void_p * max(1, A))(*[c_.data_ptr() for c_ in host_adv])
             inp.advice_on_host = 1
             inp.d_instance = None
