@@ -882,14 +882,14 @@ def worker(args):
                 torch.cuda.synchronize()
                 return round((time.perf_counter() - t_) / hs, 6)
             pinned_s = round((time.perf_counter() - t0) / hs, 6)
-            # the same from PAGEABLE host arrays — what a Rust caller's Vec<Fr> columns are: the library registers them for the call (option host_register, round 6) so that the
-            # uploads stay asynchronous; with the registration switched off every copy blocks the host for its own duration
+            # the same from PAGEABLE host arrays — what a Rust caller's Vec<Fr> columns are: the library issues those copies from a worker thread (option host_copy_thread,
+            # round 6), so that they block that thread and not the one launching the proof; with the worker switched off every copy blocks the proof's thread for its own duration
             pageable_s = timed_host("pageable")
-            ctx.set_option("host_register", 0)
-            unregistered_s = timed_host("pageable")
-            ctx.set_option("host_register", 1)
+            ctx.set_option("host_copy_thread", 0)
+            unthreaded_s = timed_host("pageable")
+            ctx.set_option("host_copy_thread", 1)
             wit.pop("advice_host_pageable", None)
-            h2d = dict(value=pinned_s, pageable_value=pageable_s, pageable_unregistered_value=unregistered_s, unit="s", steps=hs, h2d_bytes=shape.n_advice * n * 32,
+            h2d = dict(value=pinned_s, pageable_value=pageable_s, pageable_without_copy_thread_value=unthreaded_s, unit="s", steps=hs, h2d_bytes=shape.n_advice * n * 32,
                        note="advice columns uploaded from pinned host memory inside the step (copy stream; the random polynomial's commitment and, for many-column circuits, the earlier column groups' commitments overlap the uploads); never part of `value`")
         barrier()
 

@@ -11,6 +11,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/zkhip.h"
@@ -55,7 +56,8 @@ struct Scratch {
 // Tuning knobs: environment variables (ZKHIP_*) read ONCE when the context is created, or set afterwards with
 // zkhip_set_option — never looked up on the hot path.  0 / -1 = "use the measured default".
 struct zkhip_options {
-    int host_register = 1;     // zkhip_create_proof_ex registers large host advice columns (advice_on_host) with the runtime for the call: pageable sources then upload asynchronously (0: as handed over)
+    int host_copy_thread = 1;  // zkhip_create_proof_ex issues its large host uploads (advice_on_host, a host random polynomial) from a worker thread: pageable sources do not hold the proof's thread (0: from the proof's thread)
+    int host_register = 0;     // ... and / or registers those buffers with the runtime for the call (pays ~0.7 ms per buffer for pages not pinned recently: off by default)
     int msm_host_chunks = 0;   // zkhip_msm_g1 (host slice): pieces the upload + MSM pipeline is cut into (0: by size — 4 from 2^21 scalars, 2 from 2^20, else 1)
     int msm_c = 0, msm_seg = 0, msm_tailparts = 0, msm_ch = 0, msm_widetail = -1, msm_tail2 = -1, msm_adaptive_l = 1, msm_debug = 0;
     int sort_hb = 0, sort_tile = 0, sort_one_atomic = 1, sort_copies = 0, sort_wide = -1;   // sort_wide: low-pass block shape (-1: 1024 threads x 8 pairs for 8192-pair tiles)
@@ -117,6 +119,36 @@ struct zkhip_comm {
     bool row_sharded(const zkhip_options& o) const { return o.row_sharded != 0 && a2a_ok >= 0; }
 };
 
+// Host -> device copies of the caller's PAGEABLE buffers, issued from a thread of their own.  hipMemcpyAsync from pageable memory blocks the calling host thread for the
+// copy's duration (only registered / pinned sources are asynchronous), and registering is no general answer: pinning pages that were not pinned recently costs ~0.7 ms per
+// hipHostRegister CALL (a fresh Vec<Fr> per proof is always cold; 32 columns: +22 ms — profiles/r06_host_inputs.txt).  So zkhip_create_proof_ex hands its large uploads to this
+// worker: the copies block THAT thread, the proof's own thread goes on launching, and before it makes a stream wait for a job's event it waits (host side) until the worker
+// has recorded it.  Jobs run in order on one stream; done = jobs finished so far; joined before the call returns, on every path.
+struct zk_copy_job { void* dst; const void* src; size_t bytes; hipEvent_t ev; };
+struct zk_copy_worker {
+    std::vector<zk_copy_job> jobs;
+    std::thread th;
+    std::atomic<size_t> done{0};
+    std::atomic<int> err{0};
+    void start(int device, hipStream_t stream) {
+        th = std::thread([this, device, stream] {
+            hipError_t e = hipSetDevice(device);
+            for (auto& j : jobs) {
+                if (e == hipSuccess && j.bytes) e = hipMemcpyAsync(j.dst, j.src, j.bytes, hipMemcpyHostToDevice, stream);
+                if (e == hipSuccess && j.ev) e = hipEventRecord(j.ev, stream);
+                if (e != hipSuccess) err.store((int)e, std::memory_order_relaxed);
+                done.fetch_add(1, std::memory_order_release);
+            }
+        });
+    }
+    hipError_t wait(size_t job) {      // until job `job` (0-based) has been issued and its event recorded
+        while (done.load(std::memory_order_acquire) <= job) std::this_thread::yield();
+        return (hipError_t)err.load(std::memory_order_relaxed);
+    }
+    void join() { if (th.joinable()) th.join(); }
+    ~zk_copy_worker() { join(); }
+};
+
 struct zkhip_ctx {
     int device = 0;
     zkhip_options opt;
@@ -138,6 +170,7 @@ struct zkhip_ctx {
     hipEvent_t eval_event[4] = {nullptr, nullptr, nullptr, nullptr};   // one per chunk of the pipelined evaluations (zkhip_create_proof_ex)
     hipStream_t copy_stream = nullptr;   // uploads of large host advice columns (zkhip_create_proof_ex, advice_on_host), created on first use
     hipEvent_t copy_event[4] = {nullptr, nullptr, nullptr, nullptr};   // one per upload group
+    hipEvent_t copy_event_rand = nullptr;        // the caller's random polynomial has landed (zkhip_create_proof_ex, host blinding + split upload)
     std::vector<hipEvent_t> host_chunk_event;   // zkhip_msm_g1's pipelined upload: one per chunk + one fence (created on first use)
     // Small host->device uploads of host temporaries (pointer tables, lowered programs): the bytes are copied into a pinned ring
     // and the asynchronous copy reads from there, so the call neither blocks on the stream nor keeps the caller's buffer alive.
@@ -223,6 +256,10 @@ struct RowCopy { const uint32_t* src; uint32_t* dst; uint32_t src_row0, dst_row0
 #define ZK_ROWCOPY_MAX 48
 int comm_row_copies(zkhip_ctx* ctx, const std::vector<RowCopy>& list);
 int comm_fold_partials(zkhip_ctx* ctx, const void* d_part, size_t ncols, void* d_out);
+// msm.hip: one HOST column through the chunk pipeline of zkhip_msm_g1, split in two for zkhip_create_proof_ex (uploads issued early, the commitment later)
+size_t host_column_chunks(const zkhip_ctx* ctx, const zkhip_srs* srs, size_t n);
+int host_column_jobs(zkhip_ctx* ctx, const void* host, size_t n, size_t K, void* d_col, std::vector<zk_copy_job>* jobs);   // the K chunk copies (each with its event) appended to a worker's list
+int host_column_commit(zkhip_ctx* ctx, const zkhip_srs* srs, size_t n, size_t K, const void* d_col, void* d_out, zk_copy_worker* worker, size_t first_job);
 int lagrange_to_coeff_oop(zkhip_ctx* ctx, const zkhip_domain* d, const void* const* srcs, void* const* dsts, size_t npolys);
 int permute_expression_pair_async(zkhip_ctx* ctx, uint32_t k, uint32_t blinding_factors, const void* d_input, const void* d_table,
                                   const void* d_blind_in, const void* d_blind_tab, void* d_perm_in, void* d_perm_tab, uint32_t* d_err_flag,

@@ -1550,20 +1550,26 @@ struct HostMsmRestore {
 // ONE host column through the K-chunk pipeline: uploads on the copy stream (issued here), chunk j's digits, sort and bucket accumulation over points [off_j, off_j + len_j)
 // on the main and the side stream alternately as soon as ITS bytes have landed, each chunk in its own scratch (scratch_tag), the chunks' bucket sums folded bucket by bucket
 // (k_merge_buckets) and ONE tail.  Everything is enqueued; the result lands in d_out (96 bytes, device); the main stream has joined the side stream when this returns.
-static int host_msm_pipelined(zkhip_ctx* ctx, hipStream_t main, const zkhip_srs* srs, const uint64_t* scalars, size_t n, size_t K, void* d_s, void* d_out) {
-    const zkhip_srs* one_srs[1] = {srs};
-    const void* cols[1] = {d_s};
+static int host_msm_upload(zkhip_ctx* ctx, const uint64_t* scalars, size_t n, size_t K, void* d_s) {
     const size_t per = ((n + K - 1) / K + 255) & ~(size_t)255;
     for (size_t j = 0; j < K; ++j) {
         const size_t off = std::min(n, j * per), len = std::min(per, n - off);
         if (len) ZK_HIP(hipMemcpyAsync((char*)d_s + off * 32, (const char*)scalars + off * 32, len * 32, hipMemcpyHostToDevice, ctx->copy_stream));
         ZK_HIP(hipEventRecord(ctx->host_chunk_event[j], ctx->copy_stream));
     }
+    return ZKHIP_OK;
+}
+static int host_msm_commit(zkhip_ctx* ctx, hipStream_t main, const zkhip_srs* srs, size_t n, size_t K, const void* d_s, void* d_out, zk_copy_worker* worker = nullptr,
+                           size_t first_job = 0) {
+    const zkhip_srs* one_srs[1] = {srs};
+    const void* cols[1] = {d_s};
+    const size_t per = ((n + K - 1) / K + 255) & ~(size_t)255;
     std::vector<MsmPartials> parts(K);
     bool any = false;
     for (size_t j = 0; j < K; ++j) {
         const size_t off = std::min(n, j * per), len = std::min(per, n - off);
         hipStream_t sj = (j & 1) ? ctx->side_stream : main;
+        if (worker) ZK_HIP(worker->wait(first_job + j));      // the chunk's event exists only once the copy thread has recorded it
         ZK_HIP(hipStreamWaitEvent(sj, ctx->host_chunk_event[j], 0));
         ctx->stream = sj;
         char tag[16];
@@ -1598,6 +1604,32 @@ static int host_msm_pipelined(zkhip_ctx* ctx, hipStream_t main, const zkhip_srs*
     ZK_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->side_event, 0));
     return ZKHIP_OK;
 }
+static int host_msm_pipelined(zkhip_ctx* ctx, hipStream_t main, const zkhip_srs* srs, const uint64_t* scalars, size_t n, size_t K, void* d_s, void* d_out) {
+    ZK_TRY(host_msm_upload(ctx, scalars, n, K, d_s));
+    return host_msm_commit(ctx, main, srs, n, K, d_s, d_out);
+}
+}  // extern "C"
+namespace zk {
+// zkhip_create_proof_ex's use of the pipeline for ONE host column that the proof's first commitment needs (the caller's random polynomial): the chunk uploads are issued
+// early, ahead of every other upload on the copy stream (host_column_upload; the caller registers the slice and fences the copy stream), the commitment later
+// (host_column_commit, on the context's current stream and its side stream; d_out: 96 bytes, device or pinned host).  -> K = 1: not worth it, the caller's plain path.
+size_t host_column_chunks(const zkhip_ctx* ctx, const zkhip_srs* srs, size_t n) { return host_msm_chunks(ctx, srs, n); }
+int host_column_jobs(zkhip_ctx* ctx, const void* host, size_t n, size_t K, void* d_col, std::vector<zk_copy_job>* jobs) {
+    ZK_TRY(host_msm_streams(ctx, K + 1));
+    const size_t per = ((n + K - 1) / K + 255) & ~(size_t)255;
+    for (size_t j = 0; j < K; ++j) {
+        const size_t off = std::min(n, j * per), len = std::min(per, n - off);
+        jobs->push_back(zk_copy_job{(char*)d_col + off * 32, (const char*)host + off * 32, len * 32, ctx->host_chunk_event[j]});
+    }
+    return ZKHIP_OK;
+}
+int host_column_commit(zkhip_ctx* ctx, const zkhip_srs* srs, size_t n, size_t K, const void* d_col, void* d_out, zk_copy_worker* worker, size_t first_job) {
+    hipStream_t main = ctx->stream;
+    struct Back { zkhip_ctx* c; hipStream_t s; ~Back() { c->stream = s; c->scratch_tag.clear(); } } back{ctx, main};
+    return host_msm_commit(ctx, main, srs, n, K, d_col, d_out, worker, first_job);
+}
+}  // namespace zk
+extern "C" {
 
 // best_multiexp on a caller's host slice (the `curves` patch level: halo2curves::msm::best_multiexp -> this, reached from
 // /root/reference/src/helpers.rs:233,299 and src/bin/cli.rs:320,369,519 through ParamsKZG::commit / commit_lagrange).
@@ -1627,12 +1659,23 @@ int zkhip_msm_g1(zkhip_ctx* ctx, const zkhip_srs* srs, const uint64_t* scalars, 
         hipStream_t main = ctx->stream;
         ZK_TRY(host_msm_streams(ctx, K + 1));
         HostMsmRestore restore{ctx, main};
-        restore.pin(scalars, n * 32);
         ZK_TRY(host_msm_fence(ctx, main, ctx->host_chunk_event[K]));
-        ZK_TRY(host_msm_pipelined(ctx, main, srs, scalars, n, K, d_s, d_o));
-        // every chunk's bytes have been consumed once the main stream drains: wait here, so that the slice can be unregistered / dropped
-        ZK_HIP(hipMemcpyAsync(jac, d_o, 96, hipMemcpyDeviceToHost, main));
-        ZK_HIP(stream_wait(ctx, main));
+        if (ctx->opt.host_copy_thread != 0) {
+            // the chunk copies from a worker thread (common.hpp zk_copy_worker): a pageable slice blocks THAT thread copy by copy, this one launches the chunks' MSMs behind the
+            // events as the worker records them.  No registration: pinning pages that were not pinned recently costs ~0.4 ms per call for one slice (0.7 ms each for many)
+            zk_copy_worker worker;      // (declared after `restore`: joined — its destructor — before the restore's error path drains the copy stream)
+            ZK_TRY(zk::host_column_jobs(ctx, scalars, n, K, d_s, &worker.jobs));
+            worker.start(ctx->device, ctx->copy_stream);
+            ZK_TRY(host_msm_commit(ctx, main, srs, n, K, d_s, d_o, &worker, 0));
+            ZK_HIP(hipMemcpyAsync(jac, d_o, 96, hipMemcpyDeviceToHost, main));
+            ZK_HIP(stream_wait(ctx, main));
+        } else {
+            restore.pin(scalars, n * 32);
+            ZK_TRY(host_msm_pipelined(ctx, main, srs, scalars, n, K, d_s, d_o));
+            // every chunk's bytes have been consumed once the main stream drains: wait here, so that the slice can be unregistered / dropped
+            ZK_HIP(hipMemcpyAsync(jac, d_o, 96, hipMemcpyDeviceToHost, main));
+            ZK_HIP(stream_wait(ctx, main));
+        }
         restore.ok = true;
     }
     // normalise: (x, y, 1) or the identity (0, 1, 0), like G1::from(G1Affine)

@@ -265,28 +265,77 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
     // groups — every extra batch costs a host round trip and a latency-bound tail, so no finer
     const uint32_t n_groups = !split_upload ? 1 : NB >= ((size_t)64 << 20) ? std::min<uint32_t>(4, (A + 1) / 2) : std::max<uint32_t>(1, std::min<uint32_t>(4, A / 8));
     auto group_begin = [&](uint32_t g_) { return (uint32_t)((uint64_t)A * g_ / n_groups); };
+    bool rand_on_copy_stream = false;
+    size_t rand_chunks = 1, rand_first_job = 0;
+    // The large uploads of the caller's host buffers: a list of copy jobs on the copy stream — the random polynomial first (it is what the main stream needs first), then the
+    // advice columns group by group, each group's last copy followed by the group's event.  With option host_copy_thread (default) the list is executed by a worker thread
+    // (zk_copy_worker, common.hpp): pageable sources — a Rust caller's Vec<Fr> — block THAT thread for their copies' duration while this one goes on launching; measured with
+    // FRESH pageable columns per proof: SHA-shaped k = 19 45.2 ms from this thread, 58-60 ms with the buffers registered first (cold hipHostRegister: ~0.7 ms per call), and the
+    // pinned figure with the worker (profiles/r06_host_inputs.txt).  Before the main stream is made to wait for a job's event, this thread waits for the worker to have recorded it.
+    zk_copy_worker upload_worker;
+    std::vector<size_t> group_job(n_groups, 0);
+    const bool threaded = split_upload && ctx->opt.host_copy_thread != 0;
     if (split_upload) {
         if (!ctx->copy_stream) {
             ZK_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
             for (auto& e : ctx->copy_event) ZK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         }
-        if (ctx->opt.host_register != 0)
-            for (uint32_t j = 0; j < A; ++j) if (phase_of(j) == 0) guard.pin(in->advice[j], NB);
         ZK_HIP(hipEventRecord(ctx->copy_event[0], st));   // the upload buffer's last readers (the previous proof) were issued on the main stream
         ZK_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->copy_event[0], 0));
+        // The caller's random polynomial (zk_blinding on the host: n scalars drawn from ITS rng — 128 MiB at k = 22) is the FIRST thing the main stream needs: it goes over the
+        // link first, on the copy stream — as a pageable hipMemcpyAsync on the main stream (until round 6) it blocked the host for 2.4 ms at the top of the proof while
+        // competing with the advice uploads for the link (k = 22 with host advice + host blinding: +5.8 ms) — in K chunks when it is large: its commitment, the proof's first
+        // MSM, then runs chunk by chunk behind the bytes (msm.hip host_column_*: the pipeline of zkhip_msm_g1)
+        if (bl && bl->on_host && bl->random_poly && NB >= ((size_t)16 << 20)) {
+            if (ctx->opt.host_register != 0) guard.pin(bl->random_poly, NB);
+            rand_chunks = zk::host_column_chunks(ctx, pk->g, n);
+            rand_first_job = upload_worker.jobs.size();
+            if (rand_chunks > 1) {
+                ZK_TRY(zk::host_column_jobs(ctx, bl->random_poly, n, rand_chunks, w_rand, &upload_worker.jobs));
+            } else {
+                if (!ctx->copy_event_rand) ZK_HIP(hipEventCreateWithFlags(&ctx->copy_event_rand, hipEventDisableTiming));
+                upload_worker.jobs.push_back(zk_copy_job{w_rand, bl->random_poly, NB, ctx->copy_event_rand});
+            }
+            rand_on_copy_stream = true;
+        }
+    } else if (bl && bl->on_host && bl->random_poly && NB >= ((size_t)16 << 20) && ctx->opt.host_register != 0) {
+        guard.pin(bl->random_poly, NB);      // (uploaded on the main stream below: registered, the copy does not hold the host)
     }
     for (uint32_t g_ = 0; g_ < n_groups; ++g_) {
         for (uint32_t j = group_begin(g_); j < group_begin(g_ + 1); ++j) {
             if (phase_of(j) != 0) continue;     // bound after its phase's witness exists (bind_phase below)
             if (in->advice_on_host) {
-                ZK_HIP(hipMemcpyAsync(w_adv_in + j * NB, in->advice[j], NB, hipMemcpyHostToDevice, split_upload ? ctx->copy_stream : st));
+                if (split_upload) {
+                    if (ctx->opt.host_register != 0) guard.pin(in->advice[j], NB);
+                    upload_worker.jobs.push_back(zk_copy_job{w_adv_in + j * NB, in->advice[j], NB, nullptr});
+                } else {
+                    ZK_HIP(hipMemcpyAsync(w_adv_in + j * NB, in->advice[j], NB, hipMemcpyHostToDevice, st));
+                }
                 adv_cols[j] = w_adv_in + j * NB;
             } else {
                 adv_cols[j] = in->advice[j];
             }
         }
-        if (split_upload) ZK_HIP(hipEventRecord(ctx->copy_event[g_], ctx->copy_stream));
+        if (split_upload) {      // the group's event behind its last copy (an empty job if the group had none)
+            upload_worker.jobs.push_back(zk_copy_job{nullptr, nullptr, 0, ctx->copy_event[g_]});
+            group_job[g_] = upload_worker.jobs.size() - 1;
+        }
     }
+    if (split_upload) {
+        if (threaded) {
+            // (declared after `guard`: on every exit the worker is joined — its destructor — BEFORE the guard drains the copy stream and gives the buffers back)
+            upload_worker.start(ctx->device, ctx->copy_stream);
+        } else {      // from this thread, in order (pageable sources block it copy by copy)
+            for (auto& j : upload_worker.jobs) {
+                if (j.bytes) ZK_HIP(hipMemcpyAsync(j.dst, j.src, j.bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+                if (j.ev) ZK_HIP(hipEventRecord(j.ev, ctx->copy_stream));
+            }
+        }
+    }
+    auto upload_issued = [&](size_t job) -> int {      // host side: the worker has issued job `job` (and recorded its event)
+        if (threaded) ZK_HIP(upload_worker.wait(job));
+        return ZKHIP_OK;
+    };
     for (uint32_t j = 0; j < I; ++j) {
         if (in->d_instance) { ins_cols[j] = in->d_instance[j]; continue; }
         const size_t len = in->instance_len[j];
@@ -485,7 +534,12 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
     };
 
     // ---- 1. advice (+ the vanishing argument's random polynomial, which depends on no challenge) ; coset NTTs of advice/instance overlap
-    if (bl && bl->random_poly) {
+    if (rand_on_copy_stream) {
+        if (rand_chunks <= 1) {      // (in chunks: the commitment below waits chunk by chunk)
+            ZK_TRY(upload_issued(rand_first_job));
+            ZK_HIP(hipStreamWaitEvent(st, ctx->copy_event_rand, 0));
+        }
+    } else if (bl && bl->random_poly) {
         if (bl->on_host) ZK_HIP(hipMemcpyAsync(w_rand, bl->random_poly, NB, hipMemcpyHostToDevice, st));
         else ZK_HIP(hipMemcpyAsync(w_rand, bl->random_poly, NB, hipMemcpyDeviceToDevice, st));
     } else {
@@ -562,9 +616,11 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
             // the advice columns'
             const void* rc[1] = {w_rand};
             const zkhip_srs* rb[1] = {pk->g};
-            ZK_TRY(zkhip_msm_g1_multi_device(ctx, rb, rc, 1, 0, n, w_com + (size_t)A * 96));
+            if (rand_chunks > 1) ZK_TRY(zk::host_column_commit(ctx, pk->g, n, rand_chunks, w_rand, w_com + (size_t)A * 96, threaded ? &upload_worker : nullptr, rand_first_job));
+            else ZK_TRY(zkhip_msm_g1_multi_device(ctx, rb, rc, 1, 0, n, w_com + (size_t)A * 96));
             for (uint32_t g_ = 0; g_ < n_groups; ++g_) {
                 const uint32_t j0 = group_begin(g_), j1 = group_begin(g_ + 1);
+                ZK_TRY(upload_issued(group_job[g_]));
                 ZK_HIP(hipStreamWaitEvent(st, ctx->copy_event[g_], 0));
                 if (g_ + 1 == n_groups) ov.arm();   // the overlapped NTTs follow the last group's accumulation
                 ZK_TRY(zkhip_msm_g1_multi_device(ctx, bases.data() + j0, cols.data() + j0, j1 - j0, 0, n, w_com + (size_t)j0 * 96));

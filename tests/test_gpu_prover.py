@@ -481,12 +481,15 @@ def test_sha_k19_satisfiable_proof_verifies(zk, oracle):
     # the 32 advice columns as pinned HOST arrays: uploaded in 4 groups on a copy stream, each group committed while the next is on the wire
     assert gp.prove_native(w, transcript="poseidon", host_inputs=True)["proof"] == t1["proof"]
     # ... and as PAGEABLE host arrays — what a Rust caller's Vec<Fr> columns are (/root/reference/src/helpers.rs:233: gen_snark_shplonk hands create_proof the witness as
-    # vectors): the library registers them with the runtime for the call (option host_register) so that the uploads stay asynchronous; same bytes with and without it,
-    # twice in a row (the registration of one call is gone before the next)
-    for reg in (1, 1, 0):
+    # vectors): their copies are issued from a worker thread (option host_copy_thread; a pageable hipMemcpyAsync blocks its caller), optionally from registered memory
+    # (host_register); the same bytes every way, twice in a row, and with FRESH host arrays per proof
+    for thr, reg in ((1, 0), (1, 0), (0, 0), (0, 1), (1, 1)):
+        ctx.set_option("host_copy_thread", thr)
         ctx.set_option("host_register", reg)
-        assert gp.prove_native(w, transcript="poseidon", host_inputs="pageable")["proof"] == t1["proof"], reg
-    ctx.set_option("host_register", 1)
+        w.pop("advice_host_pageable", None)
+        assert gp.prove_native(w, transcript="poseidon", host_inputs="pageable")["proof"] == t1["proof"], (thr, reg)
+    ctx.set_option("host_copy_thread", 1)
+    ctx.set_option("host_register", 0)
     gp.b.params.free()
     del gp, w
 
