@@ -130,7 +130,9 @@ struct zk_copy_worker {
     std::thread th;
     std::atomic<size_t> done{0};
     std::atomic<int> err{0};
-    void start(int device, hipStream_t stream) {
+    // -> false: no thread could be created (the jobs are then run by the caller, in order: run_inline) — no exception crosses the C ABI
+    bool start(int device, hipStream_t stream) {
+        try {
         th = std::thread([this, device, stream] {
             hipError_t e = hipSetDevice(device);
             for (auto& j : jobs) {
@@ -140,6 +142,18 @@ struct zk_copy_worker {
                 done.fetch_add(1, std::memory_order_release);
             }
         });
+        } catch (...) { return false; }
+        return true;
+    }
+    hipError_t run_inline(hipStream_t stream) {
+        for (auto& j : jobs) {
+            hipError_t e = hipSuccess;
+            if (j.bytes) e = hipMemcpyAsync(j.dst, j.src, j.bytes, hipMemcpyHostToDevice, stream);
+            if (e == hipSuccess && j.ev) e = hipEventRecord(j.ev, stream);
+            if (e != hipSuccess) return e;
+            done.fetch_add(1, std::memory_order_release);
+        }
+        return hipSuccess;
     }
     hipError_t wait(size_t job) {      // until job `job` (0-based) has been issued and its event recorded
         while (done.load(std::memory_order_acquire) <= job) std::this_thread::yield();

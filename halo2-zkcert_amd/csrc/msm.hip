@@ -1559,8 +1559,16 @@ static int host_msm_upload(zkhip_ctx* ctx, const uint64_t* scalars, size_t n, si
     }
     return ZKHIP_OK;
 }
+// the K chunk copies of one host column as jobs of a copy worker; chunk j's event is host_chunk_event[event_base + j]
+static void host_msm_jobs(zkhip_ctx* ctx, const void* host, size_t n, size_t K, void* d_col, size_t event_base, std::vector<zk_copy_job>* jobs) {
+    const size_t per = ((n + K - 1) / K + 255) & ~(size_t)255;
+    for (size_t j = 0; j < K; ++j) {
+        const size_t off = std::min(n, j * per), len = std::min(per, n - off);
+        jobs->push_back(zk_copy_job{(char*)d_col + off * 32, (const char*)host + off * 32, len * 32, ctx->host_chunk_event[event_base + j]});
+    }
+}
 static int host_msm_commit(zkhip_ctx* ctx, hipStream_t main, const zkhip_srs* srs, size_t n, size_t K, const void* d_s, void* d_out, zk_copy_worker* worker = nullptr,
-                           size_t first_job = 0) {
+                           size_t first_job = 0, size_t event_base = 0) {
     const zkhip_srs* one_srs[1] = {srs};
     const void* cols[1] = {d_s};
     const size_t per = ((n + K - 1) / K + 255) & ~(size_t)255;
@@ -1570,7 +1578,7 @@ static int host_msm_commit(zkhip_ctx* ctx, hipStream_t main, const zkhip_srs* sr
         const size_t off = std::min(n, j * per), len = std::min(per, n - off);
         hipStream_t sj = (j & 1) ? ctx->side_stream : main;
         if (worker) ZK_HIP(worker->wait(first_job + j));      // the chunk's event exists only once the copy thread has recorded it
-        ZK_HIP(hipStreamWaitEvent(sj, ctx->host_chunk_event[j], 0));
+        ZK_HIP(hipStreamWaitEvent(sj, ctx->host_chunk_event[event_base + j], 0));
         ctx->stream = sj;
         char tag[16];
         snprintf(tag, sizeof tag, "#c%zu", j);
@@ -1616,11 +1624,7 @@ namespace zk {
 size_t host_column_chunks(const zkhip_ctx* ctx, const zkhip_srs* srs, size_t n) { return host_msm_chunks(ctx, srs, n); }
 int host_column_jobs(zkhip_ctx* ctx, const void* host, size_t n, size_t K, void* d_col, std::vector<zk_copy_job>* jobs) {
     ZK_TRY(host_msm_streams(ctx, K + 1));
-    const size_t per = ((n + K - 1) / K + 255) & ~(size_t)255;
-    for (size_t j = 0; j < K; ++j) {
-        const size_t off = std::min(n, j * per), len = std::min(per, n - off);
-        jobs->push_back(zk_copy_job{(char*)d_col + off * 32, (const char*)host + off * 32, len * 32, ctx->host_chunk_event[j]});
-    }
+    host_msm_jobs(ctx, host, n, K, d_col, 0, jobs);
     return ZKHIP_OK;
 }
 int host_column_commit(zkhip_ctx* ctx, const zkhip_srs* srs, size_t n, size_t K, const void* d_col, void* d_out, zk_copy_worker* worker, size_t first_job) {
@@ -1665,7 +1669,7 @@ int zkhip_msm_g1(zkhip_ctx* ctx, const zkhip_srs* srs, const uint64_t* scalars, 
             // events as the worker records them.  No registration: pinning pages that were not pinned recently costs ~0.4 ms per call for one slice (0.7 ms each for many)
             zk_copy_worker worker;      // (declared after `restore`: joined — its destructor — before the restore's error path drains the copy stream)
             ZK_TRY(zk::host_column_jobs(ctx, scalars, n, K, d_s, &worker.jobs));
-            worker.start(ctx->device, ctx->copy_stream);
+            if (!worker.start(ctx->device, ctx->copy_stream)) ZK_HIP(worker.run_inline(ctx->copy_stream));
             ZK_TRY(host_msm_commit(ctx, main, srs, n, K, d_s, d_o, &worker, 0));
             ZK_HIP(hipMemcpyAsync(jac, d_o, 96, hipMemcpyDeviceToHost, main));
             ZK_HIP(stream_wait(ctx, main));
@@ -1701,12 +1705,20 @@ int zkhip_msm_g1_batch(zkhip_ctx* ctx, const zkhip_srs* srs, const uint64_t* con
     ZK_TRY(ctx->get_scratch("msm_host_batch_scalars", ncols * n * 32, &d_s));
     ZK_TRY(ctx->get_scratch("msm_host_batch_out", ncols * 96, &d_o));
     hipStream_t main = ctx->stream;
-    ZK_TRY(host_msm_streams(ctx, K + 1));
+    ZK_TRY(host_msm_streams(ctx, ncols * K + 1));      // an event per (column, chunk): the worker runs ahead of the commits
     HostMsmRestore restore{ctx, main};
-    for (size_t j = 0; j < ncols; ++j) restore.pin(scalar_cols[j], n * 32);
-    ZK_TRY(host_msm_fence(ctx, main, ctx->host_chunk_event[K]));
-    for (size_t j = 0; j < ncols; ++j)
-        ZK_TRY(host_msm_pipelined(ctx, main, srs, scalar_cols[j], n, K, (char*)d_s + j * n * 32, (char*)d_o + j * 96));
+    ZK_TRY(host_msm_fence(ctx, main, ctx->host_chunk_event[ncols * K]));
+    zk_copy_worker worker;      // (after `restore`: joined before its error path drains the copy stream)
+    if (ctx->opt.host_copy_thread != 0) {
+        for (size_t j = 0; j < ncols; ++j) host_msm_jobs(ctx, scalar_cols[j], n, K, (char*)d_s + j * n * 32, j * K, &worker.jobs);
+        if (!worker.start(ctx->device, ctx->copy_stream)) ZK_HIP(worker.run_inline(ctx->copy_stream));
+        for (size_t j = 0; j < ncols; ++j)
+            ZK_TRY(host_msm_commit(ctx, main, srs, n, K, (char*)d_s + j * n * 32, (char*)d_o + j * 96, &worker, j * K, j * K));
+    } else {
+        for (size_t j = 0; j < ncols; ++j) restore.pin(scalar_cols[j], n * 32);
+        for (size_t j = 0; j < ncols; ++j)
+            ZK_TRY(host_msm_pipelined(ctx, main, srs, scalar_cols[j], n, K, (char*)d_s + j * n * 32, (char*)d_o + j * 96));
+    }
     std::vector<uint64_t> jac(12 * ncols);
     ZK_HIP(hipMemcpyAsync(jac.data(), d_o, ncols * 96, hipMemcpyDeviceToHost, main));
     ZK_HIP(stream_wait(ctx, main));

@@ -322,18 +322,12 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
         }
     }
     if (split_upload) {
-        if (threaded) {
-            // (declared after `guard`: on every exit the worker is joined — its destructor — BEFORE the guard drains the copy stream and gives the buffers back)
-            upload_worker.start(ctx->device, ctx->copy_stream);
-        } else {      // from this thread, in order (pageable sources block it copy by copy)
-            for (auto& j : upload_worker.jobs) {
-                if (j.bytes) ZK_HIP(hipMemcpyAsync(j.dst, j.src, j.bytes, hipMemcpyHostToDevice, ctx->copy_stream));
-                if (j.ev) ZK_HIP(hipEventRecord(j.ev, ctx->copy_stream));
-            }
-        }
+        // (the worker is declared after `guard`: on every exit it is joined — its destructor — BEFORE the guard drains the copy stream and gives the buffers back)
+        if (!threaded || !upload_worker.start(ctx->device, ctx->copy_stream))
+            ZK_HIP(upload_worker.run_inline(ctx->copy_stream));      // from this thread, in order (pageable sources block it copy by copy); wait() then returns at once
     }
     auto upload_issued = [&](size_t job) -> int {      // host side: the worker has issued job `job` (and recorded its event)
-        if (threaded) ZK_HIP(upload_worker.wait(job));
+        if (split_upload) ZK_HIP(upload_worker.wait(job));
         return ZKHIP_OK;
     };
     for (uint32_t j = 0; j < I; ++j) {
@@ -616,7 +610,7 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
             // the advice columns'
             const void* rc[1] = {w_rand};
             const zkhip_srs* rb[1] = {pk->g};
-            if (rand_chunks > 1) ZK_TRY(zk::host_column_commit(ctx, pk->g, n, rand_chunks, w_rand, w_com + (size_t)A * 96, threaded ? &upload_worker : nullptr, rand_first_job));
+            if (rand_chunks > 1) ZK_TRY(zk::host_column_commit(ctx, pk->g, n, rand_chunks, w_rand, w_com + (size_t)A * 96, &upload_worker, rand_first_job));
             else ZK_TRY(zkhip_msm_g1_multi_device(ctx, rb, rc, 1, 0, n, w_com + (size_t)A * 96));
             for (uint32_t g_ = 0; g_ < n_groups; ++g_) {
                 const uint32_t j0 = group_begin(g_), j1 = group_begin(g_ + 1);
