@@ -56,6 +56,11 @@ int  zkhip_synchronize(zkhip_ctx* ctx);
  * by its environment name ("ZKHIP_MSM_C") or short name ("msm_c").  Options that shape SRS tables (msm_c) apply to tables
  * built afterwards. */
 int  zkhip_set_option(zkhip_ctx* ctx, const char* name, int value);
+/* Host buffers handed to the library (zkhip_msm_g1 / _batch slices; zkhip_create_proof_ex's advice_on_host columns and host zk_blinding) may be plain pageable memory — a
+ * Rust Vec<Fr>: they must stay alive and unmodified until the call returns, nothing more.  For large ones (>= 2^20 scalars; >= 64 MiB of advice in all) the library spawns a
+ * short-lived WORKER THREAD per call that issues the host-to-device copies (a copy from pageable memory blocks its calling thread; this way it is not the thread that launches
+ * the kernels) and joins it before returning, on every path; option "host_copy_thread" = 0 keeps everything on the calling thread, "host_register" = 1 additionally pins the
+ * buffers with hipHostRegister for the call (slow for pages that were not pinned recently: off by default).  profiles/r06_host_inputs.txt has the numbers. */
 /* Frees the scratch buffers of streams the context no longer uses (scratch is per stream).  Synchronises the device. */
 int  zkhip_trim(zkhip_ctx* ctx);
 /* Drops what the context keeps per proving key (zk_proving_key.key_id): the sorted lookup tables and the key's columns in the coset
