@@ -16,6 +16,9 @@
 //    partial sums are folded in further rounds.  Skewed buckets (boolean columns) therefore cost
 //    depth O(log), not O(count).
 //  * Integer-multiply bound: 8 * 171 + 2 * 126 = 1620 v_mad_u64_u32 per (pair, window).
+//  * Host slices (zkhip_msm_g1 / zkhip_msm_g1_batch, round 6): msm_local = msm_partials (everything up to the buckets' partial sums) + msm_tail (the bucket reduction),
+//    so that a large host slice can be uploaded in chunks by a worker thread and accumulated chunk by chunk as the bytes land, the chunks' buckets merged
+//    (k_merge_buckets) before ONE tail — see host_msm_* near the end of the file.
 #include <algorithm>
 #include <mutex>
 
