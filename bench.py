@@ -149,19 +149,51 @@ def cpu_pass_seconds(pv, shape, transcript, threads, repeats=3, warm=True, witne
     sys.path[:0] = [p for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")) if p not in sys.path]
     from oracle_backend import OracleBackend
 
-    p = pv.Prover(OracleBackend(threads), shape, satisfiable=True)
+    class Timed(OracleBackend):
+        """the same backend with a clock around the two things the `curves` / `domain` patch levels move to the GPU: best_multiexp (every commitment) and the transforms"""
+        def __init__(self, threads_):
+            super().__init__(threads_)
+            self.clock_s = dict(msm=0.0, fft=0.0)
+
+        def _clocked(self, key, f, *a):
+            t_ = time.perf_counter()
+            r = f(*a)
+            self.clock_s[key] += time.perf_counter() - t_
+            return r
+
+        def partial_commit(self, *a):
+            return self._clocked("msm", super().partial_commit, *a)
+
+        def lagrange_to_coeff(self, *a):
+            return self._clocked("fft", super().lagrange_to_coeff, *a)
+
+        def coeff_to_lagrange(self, *a):
+            return self._clocked("fft", super().coeff_to_lagrange, *a)
+
+        def coeff_to_extended(self, *a):
+            return self._clocked("fft", super().coeff_to_extended, *a)
+
+        def divide_and_to_coeff(self, *a):
+            return self._clocked("fft", super().divide_and_to_coeff, *a)
+
+    backend = Timed(threads)
+    p = pv.Prover(backend, shape, satisfiable=True)
     w = p.witness(witness_seed)
     if warm:
         p.prove(w, transcript=transcript)
-    ts, digests = [], set()
+    ts, digests, splits = [], set(), []
     for _ in range(repeats):
+        backend.clock_s = dict(msm=0.0, fft=0.0)
         t0 = time.perf_counter()
         pf = bytes(p.prove(w, transcript=transcript)["proof"])
         ts.append(time.perf_counter() - t0)
+        splits.append(dict(backend.clock_s, total=ts[-1]))
         digests.add(hashlib.sha256(pf).hexdigest())
     if len(digests) != 1:
         raise RuntimeError(f"the CPU oracle's proof of {shape.name} is not deterministic: {sorted(digests)}")
-    CPU_PROOFS.append(dict(shape=shape.name, k=shape.k, transcript=transcript, witness=witness_seed, proof_sha256=digests.pop(), proof_bytes=len(pf)))
+    med_split = sorted(splits, key=lambda d_: d_["total"])[len(splits) // 2]
+    CPU_PROOFS.append(dict(shape=shape.name, k=shape.k, transcript=transcript, witness=witness_seed, proof_sha256=digests.pop(), proof_bytes=len(pf),
+                           split_s={k_: round(v_, 4) for k_, v_ in med_split.items()}))
     return statistics.median(ts), ts
 
 
@@ -249,6 +281,12 @@ def cpu_baseline(pv, args, config, head_k, transcript):
                    sample=f"{sh.name}: median of 3 full passes after a warm-up ({', '.join(f'{t:.3f}' for t in ts)}); "
                           "oracle/zkoracle.c with OpenMP, SRS / keygen excluded")
     out["proof_k"], out["proof_sha256"] = CPU_PROOFS[-1]["k"], CPU_PROOFS[-1]["proof_sha256"]     # the pass that was timed last = the measured size
+    sp = CPU_PROOFS[-1].get("split_s")
+    if sp and sp.get("total"):
+        # where the CPU pass went: commitments (best_multiexp), transforms, and everything else — the part that stays on the CPU at the `curves` / `domain` patch levels
+        rest = max(0.0, sp["total"] - sp["msm"] - sp["fft"])
+        out["split_s"] = dict(msm=sp["msm"], fft=sp["fft"], rest=round(rest, 4), total=sp["total"], k=CPU_PROOFS[-1]["k"],
+                              rest_fraction=round(rest / sp["total"], 4))
     rsa = None
     if config != "rsa17" and not args.no_other_configs and args.gpus == 1 and not args.chain:
         med17, ts17 = cpu_pass_seconds(pv, pv.CircuitShape.rsa(17), "poseidon", threads)
@@ -1387,6 +1425,18 @@ def worker(args):
                 if rsa_cb and "rsa17" in out_configs and "error" not in out_configs["rsa17"]:
                     out_configs["rsa17"]["cpu_baseline"] = rsa_cb
                 finish_parity(out)
+                cb_, fl_ = out["cpu_baseline"], out.get("ffi_levels")
+                if isinstance(fl_, dict) and isinstance(cb_.get("split_s"), dict) and "error" not in fl_:
+                    # What a proof would still take at the host-pointer patch levels: the level's GPU-side calls + the CPU remainder (everything that is neither a commitment nor
+                    # a transform), taken from THIS run's CPU oracle pass and carried to the headline size like `value`.  An ESTIMATE: the remainder is the oracle's C code on
+                    # these host cores, not upstream's rayon code.
+                    rest_s = cb_["split_s"]["rest_fraction"] * cb_["value"]
+                    for lv in ("curves", "domain"):
+                        if isinstance(fl_.get(lv), dict) and "value" in fl_[lv]:
+                            fl_[lv]["with_cpu_remainder_estimate_s"] = round(fl_[lv]["value"] + rest_s, 3)
+                    fl_["cpu_remainder_estimate"] = dict(value=round(rest_s, 3), unit="s", from_k=cb_["split_s"]["k"], rest_fraction=cb_["split_s"]["rest_fraction"],
+                                                         note="the CPU oracle's time outside best_multiexp and the transforms (sweep, permute, grand products, evaluations, SHPLONK arithmetic, "
+                                                              "transcript), as a fraction of its pass at the measured size, times cpu_baseline.value")
             except Exception as e:   # noqa: BLE001 — the GPU measurement stands on its own: the line still comes out, the CPU leg says why it is missing
                 import traceback
 
