@@ -81,6 +81,10 @@ def test_the_drivers_exact_command_prints_one_short_line():
     assert fl["curves"]["calls"]["zkhip_msm_g1 (2^22)"] == 16 and fl["per_call"]["zkhip_msm_g1_ms"] > 0
     assert fl["per_call"]["zkhip_msm_g1_over_device_resident"] < 1.35, fl["per_call"]      # pipelined upload (round 5: 1.50)
     assert "error" not in d["configs"]["rsa17"]["ffi_levels"] and d["configs"]["rsa17"]["ffi_levels"]["curves"]["value"] > 0
+    # the CPU leg says where its pass went, and the host-pointer levels carry what would stay on the CPU there (an estimate from this run's pass)
+    sp = d["cpu_baseline"]["split_s"]
+    assert sp["k"] == 20 and abs(sp["msm"] + sp["fft"] + sp["rest"] - sp["total"]) < 0.01 and 0.05 < sp["rest_fraction"] < 0.6
+    assert fl["curves"]["with_cpu_remainder_estimate_s"] > fl["curves"]["value"] + 1.0 and abs(fl["cpu_remainder_estimate"]["value"] - sp["rest_fraction"] * d["cpu_baseline"]["value"]) < 0.01
     cfg = d["configs"]["agg22"]
     assert set(cfg["rooflines"]) == {"msm_accum_affine", "ntt", "sweep"}
     for r in cfg["rooflines"].values():
