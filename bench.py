@@ -370,7 +370,7 @@ def compact_line(out, detail_path):
     if isinstance(out.get("with_h2d"), dict):
         line["with_h2d_s"] = out["with_h2d"].get("value")
     if isinstance(out.get("ffi_levels"), dict):
-        line["ffi_levels_s"] = {k_: v_.get("value") for k_, v_ in out["ffi_levels"].items() if isinstance(v_, dict) and "value" in v_}
+        line["ffi_levels_s"] = {k_: out["ffi_levels"][k_].get("value") for k_ in ("curves", "domain", "one-call") if isinstance(out["ffi_levels"].get(k_), dict)}
     if isinstance(out.get("configs"), dict):
         line["configs_s"] = {k_: v_.get("value") for k_, v_ in out["configs"].items() if isinstance(v_, dict) and "value" in v_}
     if isinstance(out.get("ladder"), dict):
