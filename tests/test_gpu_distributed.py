@@ -306,8 +306,10 @@ def test_rccl_transport_path_with_emulated_rccl(zk, tmp_path, world, mode):
     communicator reports transport "rccl" with ncclCommCount = N, the self-check passed (the row-sharded modes were taken), and no send
     was left without its receive (the stand-in turns that into an error)."""
     ref = _single_gpu_proofs(zk)
+    # (four ranks: the library's own schedule only — the Python schedule's many small collectives through the stand-in's spin-waits made this case take 13 to 58 s
+    # from run to run; it goes through the RCCL branch with 2 and 8 ranks)
     outs = _run_workers(tmp_path, world, True, 0, extra_env={"ZKHIP_RCCL_LIB": _fake_rccl(), "ZKHIP_COMM_TRANSPORT": "rccl", "ZK_SHARD_MODE": mode,
-                                                            "ZKFAKE_RCCL_SLOT_MB": "8"})
+                                                            "ZKFAKE_RCCL_SLOT_MB": "8", **({"ZK_NATIVE_ONLY": "1"} if world == 4 else {})})
     for o in outs:
         assert o["transport"] == "rccl" and o["comm"]["transport"] == "rccl" and o["comm"]["transport_ranks"] == world and o["comm"]["nranks"] == world
         assert o["bytes_gathered"] > 0 and o["modes"]["proofs_row_sharded"] >= 1, o["modes"]
