@@ -56,6 +56,8 @@ struct Scratch {
 // Tuning knobs: environment variables (ZKHIP_*) read ONCE when the context is created, or set afterwards with
 // zkhip_set_option — never looked up on the hot path.  0 / -1 = "use the measured default".
 struct zkhip_options {
+    int debug_delay_main_us = 0;   // test aid, the reverse: the MAIN stream is held this long right after it has issued a side-stream section
+    int debug_delay_us = 0;    // test aid: every side-stream / third-stream section of a proof starts with a kernel that holds that stream this long (prover.hip k_debug_delay)
     int host_copy_thread = 1;  // zkhip_create_proof_ex issues its large host uploads (advice_on_host, a host random polynomial) from a worker thread: pageable sources do not hold the proof's thread (0: from the proof's thread)
     int host_register = 0;     // ... and / or registers those buffers with the runtime for the call (pays ~0.7 ms per buffer for pages not pinned recently: off by default)
     int msm_host_chunks = 0;   // zkhip_msm_g1 (host slice): pieces the upload + MSM pipeline is cut into (0: by size — 4 from 2^21 scalars, 2 from 2^20, else 1)

@@ -191,7 +191,7 @@ int zkhip_profile_read(zkhip_ctx* c, const char* kernel, double* total_ms, uint6
 namespace {
 struct OptName { const char* env; const char* name; int zkhip_options::*field; };
 const OptName OPTIONS[] = {
-    {"ZKHIP_MSM_HOST_CHUNKS", "msm_host_chunks", &zkhip_options::msm_host_chunks}, {"ZKHIP_HOST_REGISTER", "host_register", &zkhip_options::host_register}, {"ZKHIP_HOST_COPY_THREAD", "host_copy_thread", &zkhip_options::host_copy_thread}, {"ZKHIP_MSM_C", "msm_c", &zkhip_options::msm_c}, {"ZKHIP_MSM_SEG", "msm_seg", &zkhip_options::msm_seg},
+    {"ZKHIP_MSM_HOST_CHUNKS", "msm_host_chunks", &zkhip_options::msm_host_chunks}, {"ZKHIP_HOST_REGISTER", "host_register", &zkhip_options::host_register}, {"ZKHIP_HOST_COPY_THREAD", "host_copy_thread", &zkhip_options::host_copy_thread}, {"ZKHIP_DEBUG_DELAY_US", "debug_delay_us", &zkhip_options::debug_delay_us}, {"ZKHIP_DEBUG_DELAY_MAIN_US", "debug_delay_main_us", &zkhip_options::debug_delay_main_us}, {"ZKHIP_MSM_C", "msm_c", &zkhip_options::msm_c}, {"ZKHIP_MSM_SEG", "msm_seg", &zkhip_options::msm_seg},
     {"ZKHIP_MSM_TAILPARTS", "msm_tailparts", &zkhip_options::msm_tailparts}, {"ZKHIP_MSM_CH", "msm_ch", &zkhip_options::msm_ch}, {"ZKHIP_MSM_TAIL2", "msm_tail2", &zkhip_options::msm_tail2},
     {"ZKHIP_MSM_WIDETAIL", "msm_widetail", &zkhip_options::msm_widetail}, {"ZKHIP_MSM_ADAPTIVE_L", "msm_adaptive_l", &zkhip_options::msm_adaptive_l},
     {"ZKHIP_MSM_DEBUG", "msm_debug", &zkhip_options::msm_debug}, {"ZKHIP_SORT_HB", "sort_hb", &zkhip_options::sort_hb},

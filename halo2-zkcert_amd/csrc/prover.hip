@@ -26,6 +26,21 @@ using namespace zk;
 namespace {
 // Work issued between begin() and end() runs on a second stream, ordered after everything already issued on the main one
 // (the coset NTTs of finished columns beside the latency-bound MSM phases); join() makes the main stream wait for it.
+// Debug aid (option debug_delay_us / ZKHIP_DEBUG_DELAY_US, off by default): every section of work that the proof puts on a stream OTHER than its main one — the side stream's
+// overlapped transforms, the third stream's random-polynomial commitment, the sharded proof's communicator streams are not touched — starts with a kernel that holds that stream for
+// this many microseconds.  The proof's bytes must not notice: a consumer on the main stream that lacks its event dependency on such a section (or a later writer of a buffer the
+// section still reads) is invisible at normal timing, shows up once in a while when other processes take turns on the device, and shows up ALWAYS with the section held back.
+__global__ void k_debug_delay(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+static void debug_delay(zkhip_ctx* ctx, hipStream_t s, int us = -1) {
+    if (us < 0) us = ctx->opt.debug_delay_us;
+    if (us <= 0) return;
+    static int khz = [] { int v = 100000; (void)hipDeviceGetAttribute(&v, hipDeviceAttributeWallClockRate, 0); return v; }();
+    hipLaunchKernelGGL(k_debug_delay, dim3(1), dim3(1), 0, s, (unsigned long long)((double)us * 1e-3 * khz));
+    (void)hipGetLastError();
+}
 struct Overlap {
     zkhip_ctx* ctx;
     hipStream_t main, side;
@@ -33,6 +48,7 @@ struct Overlap {
     int begin() {
         ZK_HIP(hipEventRecord(ev, main));
         ZK_HIP(hipStreamWaitEvent(side, ev, 0));
+        if (side != main) debug_delay(ctx, side);
         ctx->stream = side;
         return ZKHIP_OK;
     }
@@ -46,10 +62,11 @@ struct Overlap {
     int begin_marked() {
         if (late && ctx->accum_mark) { ctx->accum_mark = nullptr; ZK_HIP(hipEventRecord(ev, main)); }   // no MSM consumed it: mark now
         ZK_HIP(hipStreamWaitEvent(side, ev, 0));
+        if (side != main) debug_delay(ctx, side);
         ctx->stream = side;
         return ZKHIP_OK;
     }
-    void end() { ctx->stream = main; }
+    void end() { ctx->stream = main; if (side != main && ctx->opt.debug_delay_main_us > 0) debug_delay(ctx, main, ctx->opt.debug_delay_main_us); }      // (the reverse experiment: the MAIN stream held back behind every section it has just issued)
     int join() {
         ZK_HIP(hipEventRecord(ev, side));
         ZK_HIP(hipStreamWaitEvent(main, ev, 0));
@@ -752,6 +769,7 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
             // (the grand products and the inverse transforms above are queued on the main stream; the host blocks ~1 ms inside this MSM
             // for its plan read-back and is back long before they finish)
             ZK_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->aux_event[0], 0));
+            debug_delay(ctx, ctx->aux_stream);
             ctx->stream = ctx->aux_stream;
             const void* rc[1] = {w_rand};
             const zkhip_srs* rb[1] = {pk->g};

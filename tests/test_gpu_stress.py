@@ -44,3 +44,17 @@ def test_no_kernel_depends_on_a_fresh_allocation_being_zero(tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
         digests.append(json.load(open(path))["proof_sha256"])
     assert len(digests[0]) == 5 and digests[0] == digests[1]
+
+
+def test_proof_bytes_do_not_depend_on_the_relative_timing_of_a_proofs_streams(tmp_path):
+    """options debug_delay_us / debug_delay_main_us: every side-stream / third-stream section of a proof held back 5 ms, then the main stream held back 5 ms behind every section it
+    has issued — what contention for the device does to a proof's streams, made deterministic.  The single-GPU chain's five proof digests are the undisturbed run's: no consumer
+    lacks its event dependency on an overlapped section, no writer overtakes a section that still reads (`bash tools/delay_check.sh` runs the parity files under it too)."""
+    digests = []
+    for env_extra in ({}, {"ZKHIP_DEBUG_DELAY_US": "5000"}, {"ZKHIP_DEBUG_DELAY_MAIN_US": "5000"}):
+        path = str(tmp_path / f"chain_{len(digests)}.json")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--chain", "--steps", "1", "--warmup", "1", "--agg-k", "18", "--no-cpu-baseline", "--detail-out", path],
+                           capture_output=True, text=True, env=dict(os.environ, **env_extra), timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        digests.append(json.load(open(path))["proof_sha256"])
+    assert len(digests[0]) == 5 and digests[0] == digests[1] == digests[2]
