@@ -1661,7 +1661,7 @@ int zkhip_msm_g1(zkhip_ctx* ctx, const zkhip_srs* srs, const uint64_t* scalars, 
         if (n) ZK_HIP(hipMemcpyAsync(d_s, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
         ZK_TRY(msm_run(ctx, one_srs, cols, 1, 0, n, d_o));
         ZK_HIP(hipMemcpyAsync(jac, d_o, 96, hipMemcpyDeviceToHost, ctx->stream));
-        ZK_HIP(hipStreamSynchronize(ctx->stream));
+        ZK_HIP(stream_wait(ctx, ctx->stream));      // (polling: a 2^17 MSM is 0.5 ms, an interrupt-driven wait wakes tens of microseconds late)
     } else {
         hipStream_t main = ctx->stream;
         ZK_TRY(host_msm_streams(ctx, K + 1));

@@ -738,7 +738,7 @@ int zkhip_fft(zkhip_ctx* ctx, uint64_t* a, const uint64_t omega[4], uint32_t log
     void* polys[1] = {d};
     ZK_TRY(zkhip_fft_batch_device(ctx, polys, 1, omega, log_n));
     ZK_HIP(hipMemcpyAsync(a, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    ZK_HIP(stream_wait(ctx, ctx->stream));
     return ZKHIP_OK;
 }
 
@@ -879,7 +879,7 @@ int zkhip_lagrange_to_coeff(zkhip_ctx* ctx, const zkhip_domain* d, uint64_t* a) 
     void* polys[1] = {dev};
     ZK_TRY(zkhip_lagrange_to_coeff_device(ctx, d, polys, 1));
     ZK_HIP(hipMemcpyAsync(a, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    ZK_HIP(stream_wait(ctx, ctx->stream));
     return ZKHIP_OK;
 }
 int zkhip_coeff_to_extended(zkhip_ctx* ctx, const zkhip_domain* d, const uint64_t* coeffs, size_t n_in, uint64_t* out) {
@@ -894,7 +894,7 @@ int zkhip_coeff_to_extended(zkhip_ctx* ctx, const zkhip_domain* d, const uint64_
     void* outs[1] = {dout};
     ZK_TRY(zkhip_coeff_to_extended_device(ctx, d, ins, n_in, outs, 1));
     ZK_HIP(hipMemcpyAsync(out, dout, en * 32, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    ZK_HIP(stream_wait(ctx, ctx->stream));
     return ZKHIP_OK;
 }
 int zkhip_extended_to_coeff(zkhip_ctx* ctx, const zkhip_domain* d, uint64_t* a) {
@@ -906,7 +906,7 @@ int zkhip_extended_to_coeff(zkhip_ctx* ctx, const zkhip_domain* d, uint64_t* a) 
     void* polys[1] = {dev};
     ZK_TRY(zkhip_extended_to_coeff_device(ctx, d, polys, 1));
     ZK_HIP(hipMemcpyAsync(a, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    ZK_HIP(stream_wait(ctx, ctx->stream));
     return ZKHIP_OK;
 }
 
