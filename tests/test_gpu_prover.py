@@ -755,3 +755,30 @@ def test_malformed_phases_are_rejected_before_any_work(zk, oracle):
     sh.challenge_phase[0] = 0
     p._npk = None
     assert p.prove_native(p.witness(0), transcript="poseidon")["proof"] == good
+
+
+def test_a_proof_four_times_the_baseline_size_verifies():
+    """Maximum sizes: the aggregation-shaped circuit at k = 24 (2^24 rows, the quotient on 3 cosets of 2^24, transforms of 2^24, 138 GiB resident on the 288 GB device — four
+    times BASELINE configs[3], /root/reference/src/bin/cli.rs:464-527; 0.49 s per proof) proved by one zkhip_create_proof_ex call under Keccak on a context of its own: the proof
+    BYTES pass the byte-driven verifier, and the pageable-host-input path (worker-thread uploads of 4 x 512 MiB columns) gives the same bytes."""
+    k = 24
+    import torch
+
+    import halo2_zkcert_amd.ffi as ffi
+    from verify_util import verify_proof
+
+    torch.cuda.empty_cache()      # (the session's other tests leave cached blocks behind: this one wants 140 GiB of the device's 288)
+    ctx = ffi.Context(0)
+    try:
+        sh = pv.CircuitShape.agg(k, 3, 1)
+        gp = pv.Prover(pv.GpuBackend(ctx, ffi), sh, satisfiable=True)
+        w = gp.witness(0)
+        t = gp.prove_native(w, transcript="evm")
+        assert t["n_commitments"] == 16 and verify_proof(gp, w, t["proof"], "evm")
+        assert gp.prove_native(w, transcript="evm", host_inputs="pageable")["proof"] == t["proof"]
+        gp.release()
+        gp.b.params.free()
+        del gp, w
+    finally:
+        torch.cuda.empty_cache()
+        ctx.close()
