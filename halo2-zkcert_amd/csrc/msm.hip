@@ -1650,6 +1650,7 @@ extern "C" {
 //     work plus a plan, not a bucket reduction of its own (K separate MSMs added on the host: 7.2 ms at 2^22 from pinned memory; merged: 6.7 from pageable).
 int zkhip_msm_g1(zkhip_ctx* ctx, const zkhip_srs* srs, const uint64_t* scalars, size_t n, uint64_t out_xyz[12]) {
     if (!ctx || !srs || !out_xyz || (!scalars && n)) { set_error("zkhip_msm_g1: null argument"); return ZKHIP_EINVAL; }
+    if (ctx->dead || ctx->comm.stuck) { set_error("zkhip_msm_g1: the context was given up on by an earlier host wait (comm_timeout_ms)"); return ZKHIP_EHIP; }
     void *d_s, *d_o;
     ZK_TRY(ctx->get_scratch("msm_host_scalars", (n ? n : 1) * 32, &d_s));
     ZK_TRY(ctx->get_scratch("msm_host_out", 96, &d_o));
@@ -1699,6 +1700,7 @@ int zkhip_msm_g1_batch(zkhip_ctx* ctx, const zkhip_srs* srs, const uint64_t* con
     if (ncols == 0) return ZKHIP_OK;
     for (size_t j = 0; j < ncols; ++j) if (!scalar_cols[j] && n) { set_error("zkhip_msm_g1_batch: column %zu is null", j); return ZKHIP_EINVAL; }
     if (n > srs->n_total) { set_error("zkhip_msm_g1_batch: %zu scalars for an SRS of %zu bases", n, srs->n_total); return ZKHIP_EINVAL; }
+    if (ctx->dead || ctx->comm.stuck) { set_error("zkhip_msm_g1_batch: the context was given up on by an earlier host wait (comm_timeout_ms)"); return ZKHIP_EHIP; }
     if (n < 65536 || srs->n_total != srs->n || ctx->comm.nranks > 1 || n > srs->n) {      // small or collective: column by column through the plain form
         for (size_t j = 0; j < ncols; ++j) ZK_TRY(zkhip_msm_g1(ctx, srs, scalar_cols[j], n, out_xyz + 12 * j));
         return ZKHIP_OK;

@@ -147,6 +147,10 @@ extern "C" int zkhip_create_proof_ex(zkhip_ctx* ctx, const zk_proving_key* pk, c
         set_error("zkhip_create_proof: null argument");
         return ZKHIP_EINVAL;
     }
+    if (ctx->dead || ctx->comm.stuck) {      // a host wait of this context gave up on a collective earlier: its streams will never drain, nothing may be queued behind them (and no upload thread started)
+        set_error("zkhip_create_proof: the context was given up on by an earlier host wait (comm_timeout_ms): only zkhip_destroy is left to call");
+        return ZKHIP_EHIP;
+    }
     const uint64_t blinding_seed = in->blinding_seed;
     const zk_blinding* bl = in->blinding;
     // host-side phase clock (ZKHIP_HOST_TIMING=1): where the host spends the time between the launches of a proof

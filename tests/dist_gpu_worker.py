@@ -98,6 +98,13 @@ if os.environ.get("ZK_STALL_TEST") == "proof":
     res["elapsed_s"] = time.time() - t0
     res.update(res_plan, exchanges_issued=ctx.comm_describe()["collectives"] - c2)
     if res["error"]:      # the same exit a caller takes: drop the context.  Must return
+        t2 = time.time()
+        try:                  # ... and a caller that tries once more is refused at once: nothing is queued behind the stuck streams, no upload thread is started
+            p.prove_native(w, transcript="poseidon", host_inputs=True)
+            res["second_call"] = "returned a proof"
+        except Exception as e:   # noqa: BLE001
+            res["second_call"] = str(e)
+        res["second_call_s"] = time.time() - t2
         t1 = time.time()
         ctx.close()
         res["close_s"] = time.time() - t1

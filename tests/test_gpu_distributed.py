@@ -345,6 +345,7 @@ def test_a_stuck_collective_inside_a_proof_with_host_inputs_returns_at_the_deadl
     err = outs[0]["error"]
     assert err and "a host wait exceeded 2000 ms" in err and "rank 0 of 2 stuck" in err, outs[0]
     assert outs[0]["elapsed_s"] < 20.0 and outs[0]["close_s"] < 5.0, outs[0]
+    assert "given up on by an earlier host wait" in outs[0]["second_call"] and outs[0]["second_call_s"] < 2.0, outs[0]
     assert outs[1]["error"] is None, outs[1]
 
 
