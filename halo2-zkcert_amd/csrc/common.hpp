@@ -126,6 +126,9 @@ struct zkhip_comm {
 // hipHostRegister CALL (a fresh Vec<Fr> per proof is always cold; 32 columns: +22 ms — profiles/r06_host_inputs.txt).  So zkhip_create_proof_ex hands its large uploads to this
 // worker: the copies block THAT thread, the proof's own thread goes on launching, and before it makes a stream wait for a job's event it waits (host side) until the worker
 // has recorded it.  Jobs run in order on one stream; done = jobs finished so far; joined before the call returns, on every path.
+// The copy stream the jobs go to depends on nothing but an event recorded on the main stream when the call began, so the worker cannot end up behind a collective of THIS call; a
+// context whose earlier call was given up on (zkhip_ctx::dead) is refused before a worker is started.  What is not covered: a main stream already stuck behind a collective of an
+// EARLIER call that no host wait has noticed yet — the worker's first pageable copy then blocks as the same copy issued from the caller's thread always did, without a deadline.
 struct zk_copy_job { void* dst; const void* src; size_t bytes; hipEvent_t ev; };
 struct zk_copy_worker {
     std::vector<zk_copy_job> jobs;

@@ -1641,9 +1641,10 @@ extern "C" {
 // best_multiexp on a caller's host slice (the `curves` patch level: halo2curves::msm::best_multiexp -> this, reached from
 // /root/reference/src/helpers.rs:233,299 and src/bin/cli.rs:320,369,519 through ParamsKZG::commit / commit_lagrange).
 // Small inputs: one upload, one MSM.  From 2^20 scalars (32 MiB: the upload is no longer noise against the sum) the call is PIPELINED:
-//   * the slice is registered with the runtime (hipHostRegister: 2 us on this platform, profiles/r06_h2d_probe.txt) so that the K chunk uploads on the
-//     copy stream are truly asynchronous — an unregistered (pageable) source makes every hipMemcpyAsync block the host for its own duration, and the
-//     chunked form then only adds overhead (measured: 8.2 -> 9.6 ms at 2^22, K = 4); registered, pageable memory moves at the pinned rate (56.5 vs 57.4 GB/s);
+//   * the K chunk uploads are issued on the copy stream by a worker thread (zk_copy_worker, option host_copy_thread, default): a pageable source makes every
+//     hipMemcpyAsync block the thread that issues it for the copy's own duration, and issued from THIS thread the chunked form only adds overhead (measured: 8.2 -> 9.6 ms
+//     at 2^22, K = 4).  Pageable memory moves at the pinned rate here (56.5 vs 57.4 GB/s).  host_copy_thread = 0: the slice is registered (hipHostRegister) for the call
+//     instead and the copies come from this thread, asynchronous — cheap for pages that were pinned recently (2 us), ~0.4 ms per call for cold ones;
 //   * chunk j's digits, sort and bucket accumulation over points [off_j, off_j + len_j) start as soon as ITS bytes have landed, on the main and the
 //     side stream alternately, each chunk in its own scratch (scratch_tag);
 //   * the K chunks' bucket sums are folded bucket by bucket (k_merge_buckets) and ONE tail finishes: a chunk costs its share of the throughput-bound

@@ -77,10 +77,11 @@ struct StreamGuard {   // whatever happens, the context leaves on its main strea
     zkhip_ctx* ctx;
     hipStream_t main;
     bool host_uploads = false, aux_launched = false, done = false;
-    // The caller's large host advice columns are registered with the runtime for the duration of the call (round 6): a Rust Vec<Fr> is PAGEABLE memory, and an
-    // unregistered source makes every hipMemcpyAsync block the HOST for the copy's duration — the split upload below, which is designed to run beside the random
-    // polynomial's commitment, would then hold the host (and every launch behind it) for 2.4 ms per 2^22 column.  hipHostRegister costs 2 us here
-    // (profiles/r06_h2d_probe.txt) and fails harmlessly on memory that already is pinned.  Unregistered once the copies are known to be over.
+    // Option host_register (off by default): the caller's large host columns are registered with the runtime for the duration of the call.  A Rust Vec<Fr> is PAGEABLE
+    // memory, and an unregistered source makes every hipMemcpyAsync block the CALLING THREAD for the copy's duration; registered, the copies are asynchronous — but pinning
+    // pages that were not pinned recently costs ~0.7 ms per hipHostRegister call (a fresh Vec<Fr> per proof always is cold: 32 columns, +22 ms; the 2 us of
+    // profiles/r06_h2d_probe.txt is the re-registration of warm pages), so the default is the upload thread instead (zk_copy_worker) and this stays for callers that keep
+    // their columns in one long-lived allocation.  Fails harmlessly on memory that already is pinned.  Unregistered once the copies are known to be over.
     std::vector<const void*> registered;
     void pin(const void* h, size_t bytes) {
         if (std::find(registered.begin(), registered.end(), h) != registered.end()) return;
