@@ -91,7 +91,8 @@ int  zkhip_profile_read(zkhip_ctx* ctx, const char* kernel, double* total_ms, ui
  * zkhip_comm_init's self-checks ran and passed, bits: 1 tagged grouped send / recv exchange on the first communicator, 2 ncclCommSplit gave the
  * bulk communicator on every rank, 4 tagged exchange on it, 8 ncclCommCount / ncclCommUserRank of both agree with (nranks, rank), 16 the groups
  * held the pair (rank, rank): a forced self-check of a one-rank communicator) and "ctx_dead" (1: a host wait of this context gave up at
- * comm_timeout_ms; every later wait fails at once, and zkhip_destroy abandons the device-side resources instead of waiting for them). */
+ * comm_timeout_ms; every later wait fails at once, zkhip_create_proof_ex / zkhip_msm_g1 / zkhip_msm_g1_batch are refused on entry with ZKHIP_EHIP, and
+ * zkhip_destroy abandons the device-side resources instead of waiting for them). */
 int  zkhip_profile_counter(zkhip_ctx* ctx, const char* name, uint64_t* value);
 
 /* ---- one proof over several GPUs: one process per GPU, RCCL over xGMI ----
