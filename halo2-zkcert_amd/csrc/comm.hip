@@ -568,14 +568,15 @@ int zkhip_comm_trace_read(zkhip_ctx* ctx, size_t cap, size_t* n, uint8_t* phase,
     if (!ctx || !n) { set_error("zkhip_comm_trace_read: null argument"); return ZKHIP_EINVAL; }
     zkhip_comm& cm = ctx->comm;
     if (!cm.trace_base) { set_error("zkhip_comm_trace_read: no trace was started (zkhip_comm_trace(ctx, 1))"); return ZKHIP_EINVAL; }
-    hipEvent_t end = nullptr;
-    ZK_HIP(hipEventCreate(&end));
+    if (ctx->dead || cm.stuck) { set_error("zkhip_comm_trace_read: the context was given up on by an earlier host wait: its events will never complete"); return ZKHIP_EHIP; }
+    struct End { hipEvent_t e = nullptr; ~End() { if (e) (void)hipEventDestroy(e); } } end_;      // (released on the error returns too)
+    ZK_HIP(hipEventCreate(&end_.e));
+    hipEvent_t end = end_.e;
     ZK_HIP(hipEventRecord(end, ctx->stream));
-    ZK_HIP(stream_wait(ctx, ctx->stream));
+    ZK_HIP(stream_wait(ctx, ctx->stream));      // (the deadline of a multi-rank context applies; every exchange's event below lies before this point of the stream)
     float ms = 0;
     ZK_HIP(hipEventSynchronize(end));
     ZK_HIP(hipEventElapsedTime(&ms, cm.trace_base, end));
-    (void)hipEventDestroy(end);
     if (end_us) *end_us = (double)ms * 1000.0;
     *n = cm.trace.size();
     for (size_t i = 0; i < cm.trace.size() && i < cap; ++i) {
