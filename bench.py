@@ -16,7 +16,7 @@ transcript (what gen_snark_shplonk uses, cli.rs:320,369), aggregation k = 22 und
 
 N > 1: the N processes torch.distributed.run starts (the driver's launch line, or `python bench.py --gpus N` on its own) are GPU-free
 SUPERVISORS: each runs the real rank as a child process with a wall-clock budget, and together they walk a ladder of fresh worker sets
-(row-sharded -> all-gather exchange -> MSMs by column -> independent proofs) until one rung completes on every rank; the line says which
+(row-sharded -> row-sharded on one communicator -> all-gather exchange -> MSMs by column -> independent proofs) until one rung completes on every rank; the line says which
 rung it is (`ladder`, `comm_note`) and the run fails only if every rung does.  Inside the library every host wait of a multi-rank context
 has a deadline (comm_timeout_ms), so a rank stuck in a collective dies loudly instead of spinning.
 The workers (one process per GPU, RCCL): ONE k = 22 proof sharded over the ranks — every MSM by point range (window tables sharded 1/N),
@@ -434,14 +434,18 @@ def chain_leaf_groups(n_ranks, grouped=True):
 LADDER = {
     # one sharded proof: each rung is a FRESH set of worker processes (a rank that touched the GPU is never reused or exec'ed over).
     # From the second rung on the library's bulk communicator is off too (ZKHIP_COMM_BULK=0: no ncclCommSplit, one communicator as in round 4):
-    # whatever made the first rung fail, the fall-backs do not repeat its newest moving part
+    # whatever made the first rung fail, the fall-backs do not repeat its newest moving part.  The second rung keeps the row-sharded exchange (the
+    # faster one by replay) and drops only what has never met more than one real GPU together with it: the second communicator on
+    # every rank and torch's own RCCL communicator beside the library's
     "shard": [("row-sharded (all-to-all of row windows, torch control plane on RCCL)", [], {}),
+              ("row-sharded on ONE communicator (no bulk communicator), torch control plane on gloo", [], {"ZKHIP_COMM_BULK": "0", "ZKHIP_BENCH_DIST_BACKEND": "gloo"}),
               ("all-gather exchange (row_sharded = 0), torch control plane on gloo", [], {"ZKHIP_ROW_SHARDED": "0", "ZKHIP_COMM_BULK": "0", "ZKHIP_BENCH_DIST_BACKEND": "gloo"}),
               ("MSMs by column, whole tables on every rank", ["--shard", "columns"], {"ZKHIP_ROW_SHARDED": "0", "ZKHIP_COMM_BULK": "0", "ZKHIP_BENCH_DIST_BACKEND": "gloo"}),
               ("independent proofs, one per GPU (no collective on the data path)", ["--replicas"], {"ZKHIP_BENCH_DIST_BACKEND": "gloo"})],
     "replicas": [("independent proofs, one per GPU", [], {}),
                  ("independent proofs, one per GPU, torch control plane on gloo", [], {"ZKHIP_BENCH_DIST_BACKEND": "gloo"})],
     "chain": [("one leaf per rank 0-3 (--leaf-groups: the SHA leaves over rank groups), aggregation proof row-sharded over all ranks", [], {}),
+              ("one leaf per rank 0-3, aggregation proof row-sharded on ONE communicator, torch control plane on gloo", ["--no-leaf-groups"], {"ZKHIP_COMM_BULK": "0", "ZKHIP_BENCH_DIST_BACKEND": "gloo"}),
               ("one leaf per rank 0-3, aggregation proof with the all-gather exchange, torch control plane on gloo", ["--no-leaf-groups"], {"ZKHIP_ROW_SHARDED": "0", "ZKHIP_COMM_BULK": "0", "ZKHIP_BENCH_DIST_BACKEND": "gloo"}),
               ("one leaf per rank 0-3, aggregation proof with MSMs by column", ["--no-leaf-groups", "--shard", "columns"], {"ZKHIP_ROW_SHARDED": "0", "ZKHIP_COMM_BULK": "0", "ZKHIP_BENCH_DIST_BACKEND": "gloo"}),
               ("one leaf per rank 0-3, aggregation proof on rank 0 alone (no collective on the data path)", ["--no-leaf-groups", "--agg-unsharded"], {"ZKHIP_BENCH_DIST_BACKEND": "gloo"})],
@@ -502,7 +506,7 @@ def supervise(args):
     """One of the N processes torch.distributed.run started (by the driver, or by self_launch).  It NEVER touches the GPU: it runs the actual
     bench rank as a child process (ZKHIP_BENCH_ROLE=worker, own process group), with a wall-clock budget, and coordinates with the
     other supervisors through a TCP store.  A rung fails when any rank's worker exits non-zero or overruns its budget; every supervisor
-    then kills its worker's process group and all of them start a FRESH worker on the next rung of LADDER (row-sharded -> all-gather
+    then kills its worker's process group and all of them start a FRESH worker on the next rung of LADDER (row-sharded -> row-sharded on one communicator -> all-gather
     exchange -> MSMs by column -> independent proofs).  Rank 0 relays the JSON line of the first rung that completes on every rank, adds
     the ladder's history and — workers gone, GPU idle — times the CPU baseline.  -> exit code (non-zero only if every rung failed)."""
     import datetime

@@ -22,5 +22,5 @@ if what == "hang":
 time.sleep(0.5)
 if rank == 0:
     print(json.dumps({"metric": "fake", "value": 1.0, "n_gpus": int(os.environ["WORLD_SIZE"]), "rung_label": label, "argv": sys.argv[1:], "cpu_baseline": None,
-                      "row_sharded_env": os.environ.get("ZKHIP_ROW_SHARDED", "1"), "config": {"k": int(os.environ.get("FAKE_K", "16")), "transcript": "evm"},
+                      "row_sharded_env": os.environ.get("ZKHIP_ROW_SHARDED", "1"), "comm_bulk_env": os.environ.get("ZKHIP_COMM_BULK", "1"), "config": {"k": int(os.environ.get("FAKE_K", "16")), "transcript": "evm"},
                       "gpu_proofs": json.loads(os.environ.get("FAKE_GPU_PROOFS", "[]"))}))

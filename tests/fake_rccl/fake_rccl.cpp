@@ -24,7 +24,8 @@
 
 // Fault injection (tests of bench.py's fallback ladder and of the library's wait deadline), ZKFAKE_RCCL_STALL="<mode>:<rank>:<nth>": on rank
 // <rank>, at the <nth> collective call after ncclCommInitRank (all-gathers and send / recv groups both count; the library's init-time
-// self-check is calls 1 and 2; mode suffix "-row": only while ZKHIP_ROW_SHARDED is not 0, i.e. on the first rung of bench.py's ladder),
+// self-check is calls 1 and 2, 1 to 5 with the bulk communicator; mode suffix "-row": only while ZKHIP_ROW_SHARDED is not 0 and ZKHIP_COMM_BULK is not 0, i.e. on the
+// first rung of bench.py's ladder — row-sharded exchange with the bulk communicator asked for; the second rung is row-sharded on one communicator),
 //   device — the exchange completes, then a kernel that spins for ZKFAKE_RCCL_STALL_S seconds (default 30) is enqueued on the collective's
 //            stream: what a collective whose peer never arrives looks like to the host (a stream that makes no progress);
 //   host   — the call never returns: what a blocked RCCL host call looks like (only an outer watchdog can end it).
@@ -39,9 +40,11 @@ static void maybe_stall(int rank, hipStream_t st, bool before) {
     char mode[16] = "";
     int r = -1, nth = -1;
     if (sscanf(e, "%15[^:]:%d:%d", mode, &r, &nth) != 3 || r != rank) return;
-    if (char* suffix = strstr(mode, "-row")) {      // "device-row" / "host-row": only while the library is on its row-sharded exchange
+    if (char* suffix = strstr(mode, "-row")) {      // "device-row" / "host-row": only on the first rung (row-sharded exchange + bulk communicator)
         const char* rs = getenv("ZKHIP_ROW_SHARDED");
         if (rs && strcmp(rs, "0") == 0) return;
+        const char* bk = getenv("ZKHIP_COMM_BULK");
+        if (bk && strcmp(bk, "0") == 0) return;
         *suffix = 0;
     }
     if (before) { ++g_calls; if (g_calls == nth && strcmp(mode, "host") == 0) for (;;) sleep(1000); return; }

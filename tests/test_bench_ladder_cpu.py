@@ -49,7 +49,7 @@ def test_a_failing_rank_moves_every_rank_to_the_next_rung(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     assert len(lines) == 1
     d = lines[0]
-    assert d["ladder"]["rung"] == 2 and d["row_sharded_env"] == "0" and "all-gather" in d["rung_label"]
+    assert d["ladder"]["rung"] == 2 and d["row_sharded_env"] == "1" and d["comm_bulk_env"] == "0" and "ONE communicator" in d["rung_label"]      # still row-sharded: only the bulk communicator and torch's RCCL control plane are dropped
     assert len(d["ladder"]["failed_rungs"]) == 1 and "rank 1" in d["ladder"]["failed_rungs"][0]["why"] and "code 3" in d["ladder"]["failed_rungs"][0]["why"]
     assert "rung 1" in d["comm_note"] and "rung 2" in d["comm_note"]
     # every rank started exactly two workers: fresh processes per rung
@@ -60,19 +60,20 @@ def test_a_hanging_rank_is_killed_at_the_rung_budget(tmp_path):
     r, lines, dt = _run(tmp_path, {"1": {"0": "hang"}, "2": {"1": "hang"}}, extra=["--rung-budget", "6"])
     assert r.returncode == 0, r.stderr[-2000:]
     d = lines[0]
-    assert d["ladder"]["rung"] == 3 and "--shard" in d["argv"] and "columns" in d["argv"]
+    assert d["ladder"]["rung"] == 3 and d["row_sharded_env"] == "0" and "all-gather" in d["rung_label"]
     assert "overran" in d["ladder"]["failed_rungs"][0]["why"] and "overran" in d["ladder"]["failed_rungs"][1]["why"]
     assert dt < 120
 
 
 def test_last_rung_is_independent_proofs(tmp_path):
-    r, lines, _ = _run(tmp_path, {str(i): {"0": "fail"} for i in (1, 2, 3)})
+    r, lines, _ = _run(tmp_path, {str(i): {"0": "fail"} for i in (1, 2, 3, 4)})
     assert r.returncode == 0, r.stderr[-2000:]
-    assert lines[0]["ladder"]["rung"] == 4 and "--replicas" in lines[0]["argv"] and len(lines[0]["ladder"]["failed_rungs"]) == 3
+    assert lines[0]["ladder"]["rung"] == 5 and "--replicas" in lines[0]["argv"] and len(lines[0]["ladder"]["failed_rungs"]) == 4
+    assert "--shard" in lines[0]["ladder"]["failed_rungs"][3]["label"] or "by column" in lines[0]["ladder"]["failed_rungs"][3]["label"]
 
 
 def test_every_rung_failing_fails_the_run(tmp_path):
-    r, lines, _ = _run(tmp_path, {str(i): {"1": "fail"} for i in (1, 2, 3, 4)})
+    r, lines, _ = _run(tmp_path, {str(i): {"1": "fail"} for i in (1, 2, 3, 4, 5)})
     assert r.returncode != 0 and lines == []
     assert "every rung of the ladder failed" in r.stderr
 
@@ -83,9 +84,9 @@ def test_no_ladder_means_first_rung_only(tmp_path):
 
 
 def test_chain_ladder_ends_with_the_unsharded_aggregation(tmp_path):
-    r, lines, _ = _run(tmp_path, {str(i): {"3": "fail"} for i in (1, 2, 3)}, extra=["--chain"], world=4)
+    r, lines, _ = _run(tmp_path, {str(i): {"3": "fail"} for i in (1, 2, 3, 4)}, extra=["--chain"], world=4)
     assert r.returncode == 0, r.stderr[-2000:]
-    assert lines[0]["ladder"]["rung"] == 4 and "--agg-unsharded" in lines[0]["argv"]
+    assert lines[0]["ladder"]["rung"] == 5 and "--agg-unsharded" in lines[0]["argv"]
 
 
 def test_supervisors_under_the_drivers_own_launch_line(tmp_path):

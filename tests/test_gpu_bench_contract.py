@@ -137,12 +137,12 @@ def test_ladder_falls_back_when_the_communicator_fails():
     assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
     d = _run(args[1:], env=env)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["proofs_per_step"] == 2 and d["comm"] is None
-    assert d["ladder"]["rung"] == 4 and len(d["ladder"]["failed_rungs"]) == 3
-    assert "rung 1" in d["comm_note"] and "rung 4" in d["comm_note"] and "exited with code" in d["comm_note"]
-    # only the row-sharded exchange fails: the second rung (all-gather exchange) carries the run, still one sharded proof
+    assert d["ladder"]["rung"] == 5 and len(d["ladder"]["failed_rungs"]) == 4
+    assert "rung 1" in d["comm_note"] and "rung 5" in d["comm_note"] and "exited with code" in d["comm_note"]
+    # only the row-sharded exchange fails (both of its rungs: with the bulk communicator and on one communicator): the third rung (all-gather exchange) carries the run, still one sharded proof
     env["ZKHIP_BENCH_FAIL_COMM"] = "row"
     d = _run(args[1:], env=env)
-    assert d["scaling"] == "strong" and d["ladder"]["rung"] == 2 and d["comm"]["exchange_modes"]["proofs_row_sharded"] == 0 and d["comm"]["nranks"] == 2
+    assert d["scaling"] == "strong" and d["ladder"]["rung"] == 3 and d["comm"]["exchange_modes"]["proofs_row_sharded"] == 0 and d["comm"]["nranks"] == 2
 
 
 def _fake_rccl():
@@ -159,7 +159,7 @@ def test_a_stuck_collective_moves_the_run_to_the_next_rung():
     """A collective whose stream never makes progress on rank 1 (tests/fake_rccl, ZKFAKE_RCCL_STALL=device-row:1:6 — sixth collective call, row-sharded
     rung only, a 10-minute stall): rung 1 ends either at the library's wait deadline ("stuck after collective #n, phase ...": rank 1's worker
     exits, the supervisors stop rank 0's) or — if the next thing rank 1's host did was to enter another collective — at the rung budget; either
-    way fresh processes complete the run on the all-gather exchange.  (The deadline itself: test_gpu_distributed.py::test_a_stuck_collective_fails...)"""
+    way fresh processes complete the run on the next rung (row-sharded on one communicator: the injected stall is tied to the first rung).  (The deadline itself: test_gpu_distributed.py::test_a_stuck_collective_fails...)"""
     env = dict(os.environ, ZKHIP_BENCH_ONE_DEVICE="1", ZKHIP_BENCH_DIST_BACKEND="gloo", ZKHIP_COMM_TRANSPORT="rccl", ZKHIP_RCCL_LIB=_fake_rccl(),
                ZKFAKE_RCCL_SLOT_MB="64", ZKFAKE_RCCL_STALL="device-row:1:6", ZKFAKE_RCCL_STALL_S="600")
     env.pop("WORLD_SIZE", None)
