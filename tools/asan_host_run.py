@@ -35,6 +35,13 @@ ffi.keccak256(b"abc" * 100)
 h = C.c_void_p()
 assert L.zkhip_init(C.byref(h), 0) != 0
 assert L.zkhip_comm_destroy(None) != 0 and L.zkhip_set_option(None, b"x", 1) != 0
+# round 6's entry points: argument validation with no context behind them
+out12 = (C.c_uint64 * 12)()
+n_ = C.c_size_t()
+assert L.zkhip_msm_g1(None, None, None, 0, out12) != 0 and L.zkhip_msm_g1_batch(None, None, None, 0, 0, out12) != 0
+assert L.zkhip_comm_trace(None, 1) != 0 and L.zkhip_comm_trace_read(None, 0, C.byref(n_), None, None, None, None, None, None) != 0
+assert L.zkhip_comm_phase_name(0) is not None and L.zkhip_comm_phase_name(200) is not None
+assert b"null" in L.zkhip_last_error()
 buf = (C.c_uint8 * 128)()
 L.zkhip_comm_unique_id(buf)   # may fail (no librccl / no device): must not crash
 print("asan host run ok")
