@@ -413,6 +413,14 @@ def emit(out, args):
     print(compact_line(out, shown), flush=True)
 
 
+def lib_transport():
+    """What carries the library's own exchanges in an N > 1 worker: RCCL — whatever backend torch's control plane uses (the ladder's later rungs put torch on gloo so
+    that the library's communicator is the only RCCL communicator of the process; ffi.Context.comm_init on its own would take a gloo backend to mean the host-staged
+    test transport).  The host-staged transport only where RCCL cannot run: every rank on ONE device (ZKHIP_BENCH_ONE_DEVICE=1, the one-GPU tests), or when the
+    environment names it (ZKHIP_COMM_TRANSPORT)."""
+    return os.environ.get("ZKHIP_COMM_TRANSPORT") or ("host" if os.environ.get("ZKHIP_BENCH_ONE_DEVICE") == "1" else "rccl")
+
+
 def chain_leaf_groups(n_ranks, grouped=True):
     """--chain: {leaf index: [ranks]} — who proves which of the four leaves (0, 2: RSA-shaped k = 17; 1, 3: SHA-shaped k = 19).  Leaf j's head is
     rank j.  From 6 ranks on (grouped) the ranks 4.. — idle until the aggregation proof otherwise — are dealt to the two SHA leaves, whose proofs take
@@ -770,7 +778,7 @@ def worker(args):
         hook = os.environ.get("ZKHIP_BENCH_FAIL_COMM", "")     # test hook: what a missing librccl / an RCCL error looks like ("1": always, "row": on the row-sharded rung only)
         if hook == "1" or (hook == "row" and os.environ.get("ZKHIP_ROW_SHARDED", "1") != "0"):
             raise SystemExit(f"bench.py rank {rank}: ZKHIP_BENCH_FAIL_COMM={hook} (injected communicator failure)")
-        ctx.comm_init(rank, world, dist)
+        ctx.comm_init(rank, world, dist, transport=lib_transport())
         info = ctx.comm_describe()
         if info["nranks"] != world or info["transport_ranks"] not in (world, -1):
             raise SystemExit(f"bench.py: the library's communicator reports {info} for WORLD_SIZE {world}")
@@ -1163,7 +1171,7 @@ def worker(args):
                 if replay:
                     leaf_ctx.comm_init_replay(rs.index(vrank), len(rs), os.path.join(ROOT, "tools", "replay_rccl", "libreplay_rccl.so"))
                 else:
-                    leaf_ctx.comm_init(rs.index(vrank), len(rs), dist, group=pgs[my_leaf], src=rs[0])
+                    leaf_ctx.comm_init(rs.index(vrank), len(rs), dist, transport=lib_transport(), group=pgs[my_leaf], src=rs[0])
                 leaf_ctx.comm_shard("columns")
         mine = list(enumerate(leaf_names)) if vworld == 1 else ([(my_leaf, leaf_names[my_leaf])] if my_leaf is not None else [])
         leaves, pairs = [], 0.0

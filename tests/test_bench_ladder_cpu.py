@@ -106,3 +106,22 @@ def test_supervisors_under_the_drivers_own_launch_line(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     lines = _details(r, os.path.join(str(tmp_path), "detail.json"))
     assert len(lines) == 1 and lines[0]["ladder"]["rung"] == 2
+
+
+def test_the_librarys_transport_does_not_follow_torchs_backend(monkeypatch):
+    """The ladder's later rungs put TORCH on gloo (ZKHIP_BENCH_DIST_BACKEND) so that the library's communicator is the only RCCL communicator of the process: the library's
+    own exchanges stay on RCCL there.  Host staging only where RCCL cannot run (every rank on one device: the one-GPU tests) or where the environment asks for it."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    for k in ("ZKHIP_COMM_TRANSPORT", "ZKHIP_BENCH_ONE_DEVICE", "ZKHIP_BENCH_DIST_BACKEND"):
+        monkeypatch.delenv(k, raising=False)
+    assert bench.lib_transport() == "rccl"
+    monkeypatch.setenv("ZKHIP_BENCH_DIST_BACKEND", "gloo")
+    assert bench.lib_transport() == "rccl"
+    monkeypatch.setenv("ZKHIP_BENCH_ONE_DEVICE", "1")
+    assert bench.lib_transport() == "host"
+    monkeypatch.setenv("ZKHIP_COMM_TRANSPORT", "rccl")
+    assert bench.lib_transport() == "rccl"
+    for label, extra_args, extra_env in bench.LADDER["shard"][1:] + bench.LADDER["chain"][1:]:
+        assert extra_env.get("ZKHIP_BENCH_DIST_BACKEND") == "gloo" and "ZKHIP_COMM_TRANSPORT" not in extra_env, label
